@@ -9,10 +9,11 @@ PARITY UNPINNED: the arithmetic the reference uses lives in the external crate
 values.  This file restates the *published* algorithms of that
 crate's lineage (zcash `bn`: BN254 with the tower Fq2=Fq[u]/(u^2+1),
 Fq6=Fq2[v]/(v^3-(9+u)), Fq12=Fq6[w]/(w^2-v); G1: y^2=x^3+3, generator (1,2);
-G2 on the D-type sextic twist y^2=x^3+3/(9+u); optimal-ate pairing with the exact final
-exponent (p^12-1)/r) in the most literal way available: affine chord-and-tangent
-formulas, a Miller loop written over full Fq12 elements through the untwist map, and a
-final exponentiation that is one generic square-and-multiply by (p^12-1)//r.  It is
+G2 on the D-type sextic twist y^2=x^3+3/(9+u); optimal-ate pairing whose final exponent is
+the libff/zcash-bn one -- see FINAL_EXP below) in the most literal way available: affine
+chord-and-tangent formulas, a Miller loop written over full Fq12 elements through the
+untwist map, and a final exponentiation that is one generic square-and-multiply by the
+integer exponent.  It is
 pinned against the public alt_bn128 vectors (EIP-196 point doubling, generator orders)
 and against bilinearity / non-degeneracy, see tests/test_oracle_bn254.py.
 
@@ -385,7 +386,25 @@ def _frob_point12(q):
     return (fp12_frobenius(q[0]), fp12_frobenius(q[1]))
 
 
-FINAL_EXP = (P**12 - 1) // R
+# Final exponent.  The zcash `bn` lineage (which `rabe-bn` forks, /root/reference/README.md:8)
+# takes its `final_exponentiation_last_chunk` from libff's alt_bn128: after the easy part
+# (p^6-1)(p^2+1) it raises to
+#   lambda = p^3(12z^3+6z^2+4z-1) + p^2(12z^3+6z^2+6z) + p(12z^3+6z^2+4z) + (12z^3+12z^2+6z+1)
+# (Fuentes-Castaneda et al.), which is 2z(6z^2+3z+1) TIMES the exact hard exponent
+# (p^4-p^2+1)/r -- asserted below.  Both give a bilinear non-degenerate pairing; they differ by
+# the fixed power FE_MULTIPLE.  `pairing` follows the lineage (ASSUMPTION (iii) of SURVEY.md 8c,
+# corrected: the survey calls the exponent "exact"); `pairing_exact` is the textbook
+# (p^12-1)/r variant.  This is the single place the choice is made in the oracle.
+_Z = U
+FE_EASY = (P**6 - 1) * (P**2 + 1)
+FE_HARD_EXACT = (P**4 - P**2 + 1) // R
+FE_HARD_LIBFF = (P**3 * (12 * _Z**3 + 6 * _Z**2 + 4 * _Z - 1) + P**2 * (12 * _Z**3 + 6 * _Z**2 + 6 * _Z)
+                 + P * (12 * _Z**3 + 6 * _Z**2 + 4 * _Z) + (12 * _Z**3 + 12 * _Z**2 + 6 * _Z + 1))
+FE_MULTIPLE = 2 * _Z * (6 * _Z**2 + 3 * _Z + 1)
+assert (P**4 - P**2 + 1) % R == 0 and FE_EASY * FE_HARD_EXACT == (P**12 - 1) // R
+assert FE_HARD_LIBFF == FE_MULTIPLE * FE_HARD_EXACT
+FINAL_EXP_EXACT = FE_EASY * FE_HARD_EXACT
+FINAL_EXP = FE_EASY * FE_HARD_LIBFF
 
 
 def miller_loop(p1, q2):
@@ -417,6 +436,11 @@ def final_exponentiation(f):
 def pairing(p1, q2):
     """`rabe_bn::pairing(G1, G2) -> Gt` (call sites: ac17/mod.rs:148,415-416; bsw/mod.rs:108,292-293,308)."""
     return final_exponentiation(miller_loop(p1, q2))
+
+
+def pairing_exact(p1, q2):
+    """Optimal ate pairing with the exact exponent (p^12-1)/r; pairing == pairing_exact ** FE_MULTIPLE."""
+    return fp12_pow(miller_loop(p1, q2), FINAL_EXP_EXACT)
 
 
 def gt_mul(a, b): return fp12_mul(a, b)

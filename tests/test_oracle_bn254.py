@@ -48,3 +48,11 @@ def test_pairing_bilinear_nondegenerate():
     assert bn.pairing(bn.g1_mul(bn.G1_GEN, a), bn.g2_mul(bn.G2_GEN, b)) == bn.fp12_pow(e, a * b % bn.R)
     assert bn.pairing(None, bn.G2_GEN) == bn.FP12_ONE
     assert bn.pairing(bn.g1_neg(bn.G1_GEN), bn.G2_GEN) == bn.fp12_inv(e)
+
+
+def test_final_exponent_lineage():
+    # pairing (libff/zcash-bn hard-part chain) is the exact optimal-ate pairing raised to 2z(6z^2+3z+1)
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    ex = bn.pairing_exact(bn.G1_GEN, bn.G2_GEN)
+    assert e == bn.fp12_pow(ex, bn.FE_MULTIPLE % bn.R)
+    assert e != ex and e != bn.FP12_ONE
