@@ -1,0 +1,184 @@
+// BN254 group arithmetic: G1 over Fp (y^2 = x^3 + 3), G2 over Fp2 (y^2 = x^3 + 3/(9+u)).
+// Replaces `rabe_bn::{G1, G2}` `+`, `-`, `* Fr` (call sites: src/schemes/ac17/mod.rs:219-260,300-348,
+// 406-415; bsw/mod.rs:138-148,233-242; lsw/mod.rs:141-160,203-206; aw11/mod.rs:146,218,275-276).
+// Jacobian coordinates internally (infinity: Z = 0); affine (x, y) at the boundary, infinity = (0, 0).
+// One template serves both groups through the f* overload set below.
+#pragma once
+#include "tower.h"
+
+namespace rabe { namespace bn254 {
+
+// ---- field overload set
+RB_HD Fp fadd(const Fp& a, const Fp& b) { return add(a, b); }
+RB_HD Fp fsub(const Fp& a, const Fp& b) { return sub(a, b); }
+RB_HD Fp fmul(const Fp& a, const Fp& b) { return mul(a, b); }
+RB_HD Fp fsqr(const Fp& a) { return sqr(a); }
+RB_HD Fp fdbl(const Fp& a) { return dbl(a); }
+RB_HD Fp fneg(const Fp& a) { return neg(a); }
+RB_HD Fp finv(const Fp& a) { return inv(a); }
+RB_HD bool fis_zero(const Fp& a) { return is_zero(a); }
+RB_HD bool feq(const Fp& a, const Fp& b) { return eq(a, b); }
+RB_HD Fp2 fadd(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
+RB_HD Fp2 fsub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
+RB_HD Fp2 fmul(const Fp2& a, const Fp2& b) { return fp2_mul(a, b); }
+RB_HD Fp2 fsqr(const Fp2& a) { return fp2_sqr(a); }
+RB_HD Fp2 fdbl(const Fp2& a) { return fp2_dbl(a); }
+RB_HD Fp2 fneg(const Fp2& a) { return fp2_neg(a); }
+RB_HD Fp2 finv(const Fp2& a) { return fp2_inv(a); }
+RB_HD bool fis_zero(const Fp2& a) { return fp2_is_zero(a); }
+RB_HD bool feq(const Fp2& a, const Fp2& b) { return fp2_eq(a, b); }
+template <class F> RB_HD F fzero();
+template <class F> RB_HD F fone();
+template <> RB_HD Fp fzero<Fp>() { return zero<FpParams>(); }
+template <> RB_HD Fp fone<Fp>() { return one<FpParams>(); }
+template <> RB_HD Fp2 fzero<Fp2>() { return fp2_zero(); }
+template <> RB_HD Fp2 fone<Fp2>() { return fp2_one(); }
+
+template <class F>
+struct Aff {
+  F x, y;   // infinity: x = y = 0
+};
+template <class F>
+struct Jac {
+  F x, y, z;   // infinity: z = 0
+};
+typedef Aff<Fp> G1Aff;
+typedef Jac<Fp> G1Jac;
+typedef Aff<Fp2> G2Aff;
+typedef Jac<Fp2> G2Jac;
+
+template <class F> RB_HD bool aff_is_inf(const Aff<F>& p) { return fis_zero(p.x) & fis_zero(p.y); }
+template <class F> RB_HD bool jac_is_inf(const Jac<F>& p) { return fis_zero(p.z); }
+template <class F> RB_HD Jac<F> jac_inf() { return Jac<F>{fone<F>(), fone<F>(), fzero<F>()}; }
+template <class F> RB_HD Aff<F> aff_inf() { return Aff<F>{fzero<F>(), fzero<F>()}; }
+template <class F> RB_HD Aff<F> aff_neg(const Aff<F>& p) { return Aff<F>{p.x, fneg(p.y)}; }
+template <class F> RB_HD Jac<F> jac_neg(const Jac<F>& p) { return Jac<F>{p.x, fneg(p.y), p.z}; }
+template <class F>
+RB_HD Jac<F> aff_to_jac(const Aff<F>& p) {
+  if (aff_is_inf(p)) return jac_inf<F>();
+  return Jac<F>{p.x, p.y, fone<F>()};
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+template <class F>
+RB_FN Jac<F> jac_dbl(const Jac<F>& p) {
+  F A = fsqr(p.x);
+  F B = fsqr(p.y);
+  F C = fsqr(B);
+  F D = fsub(fsub(fsqr(fadd(p.x, B)), A), C);
+  D = fdbl(D);
+  F E = fadd(fdbl(A), A);
+  F Fq = fsqr(E);
+  Jac<F> r;
+  r.x = fsub(Fq, fdbl(D));
+  F C8 = fdbl(fdbl(fdbl(C)));
+  r.z = fdbl(fmul(p.y, p.z));   // Y = 0 cannot happen on an odd-order group; Z = 0 stays 0
+  r.y = fsub(fmul(E, fsub(D, r.x)), C8);
+  return r;
+}
+
+// madd-2007-bl: Jacobian + affine, 7M + 4S, all special cases handled.
+template <class F>
+RB_FN Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
+  if (aff_is_inf(q)) return p;
+  if (jac_is_inf(p)) return Jac<F>{q.x, q.y, fone<F>()};
+  F Z1Z1 = fsqr(p.z);
+  F U2 = fmul(q.x, Z1Z1);
+  F S2 = fmul(fmul(q.y, p.z), Z1Z1);
+  F H = fsub(U2, p.x);
+  F rr = fsub(S2, p.y);
+  if (fis_zero(H)) {
+    if (fis_zero(rr)) return jac_dbl(p);
+    return jac_inf<F>();
+  }
+  rr = fdbl(rr);
+  F HH = fsqr(H);
+  F I = fdbl(fdbl(HH));
+  F J = fmul(H, I);
+  F V = fmul(p.x, I);
+  Jac<F> r;
+  r.x = fsub(fsub(fsqr(rr), J), fdbl(V));
+  r.y = fsub(fmul(rr, fsub(V, r.x)), fdbl(fmul(p.y, J)));
+  r.z = fsub(fsub(fsqr(fadd(p.z, H)), Z1Z1), HH);
+  return r;
+}
+
+// add-2007-bl: Jacobian + Jacobian, 11M + 5S.
+template <class F>
+RB_FN Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+  if (jac_is_inf(q)) return p;
+  if (jac_is_inf(p)) return q;
+  F Z1Z1 = fsqr(p.z);
+  F Z2Z2 = fsqr(q.z);
+  F U1 = fmul(p.x, Z2Z2);
+  F U2 = fmul(q.x, Z1Z1);
+  F S1 = fmul(fmul(p.y, q.z), Z2Z2);
+  F S2 = fmul(fmul(q.y, p.z), Z1Z1);
+  F H = fsub(U2, U1);
+  F rr = fsub(S2, S1);
+  if (fis_zero(H)) {
+    if (fis_zero(rr)) return jac_dbl(p);
+    return jac_inf<F>();
+  }
+  rr = fdbl(rr);
+  F I = fsqr(fdbl(H));
+  F J = fmul(H, I);
+  F V = fmul(U1, I);
+  Jac<F> r;
+  r.x = fsub(fsub(fsqr(rr), J), fdbl(V));
+  r.y = fsub(fmul(rr, fsub(V, r.x)), fdbl(fmul(S1, J)));
+  r.z = fmul(fsub(fsub(fsqr(fadd(p.z, q.z)), Z1Z1), Z2Z2), H);
+  return r;
+}
+
+// to affine with a caller-supplied inverse of z (batch inversion happens outside)
+template <class F>
+RB_HD Aff<F> jac_to_aff_with_zinv(const Jac<F>& p, const F& zinv) {
+  if (jac_is_inf(p)) return aff_inf<F>();
+  F zi2 = fsqr(zinv);
+  return Aff<F>{fmul(p.x, zi2), fmul(p.y, fmul(zi2, zinv))};
+}
+template <class F>
+RB_FN Aff<F> jac_to_aff(const Jac<F>& p) {
+  if (jac_is_inf(p)) return aff_inf<F>();
+  return jac_to_aff_with_zinv(p, finv(p.z));
+}
+
+// on-curve test for affine inputs
+template <class F> RB_HD F curve_b();
+template <> RB_HD Fp curve_b<Fp>() { return fp_three(); }
+template <> RB_HD Fp2 curve_b<Fp2>() { return twist_b(); }
+template <class F>
+RB_HD bool aff_on_curve(const Aff<F>& p) {
+  if (aff_is_inf(p)) return true;
+  return feq(fsqr(p.y), fadd(fmul(fsqr(p.x), p.x), curve_b<F>()));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variable-base scalar multiplication, left-to-right binary double-and-add over a canonical
+// (non-Montgomery) little-endian scalar k < 2^256.  No table, nothing runtime-indexed; lanes with
+// different scalars diverge only on the (masked) add.  The value equals the reference's `G * Fr`.
+template <class F>
+RB_FN Jac<F> jac_mul_binary(const Aff<F>& base, const uint32_t k[8]) {
+  Jac<F> acc = jac_inf<F>();
+  for (int w = 7; w >= 0; w--) {
+    uint32_t word = 0;
+    switch (w) {   // keep k[] indices compile-time constant
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    for (int b = 31; b >= 0; b--) {
+      acc = jac_dbl(acc);   // doubling infinity (Z = 0) stays infinity
+      if ((word >> b) & 1u) acc = jac_add_aff(acc, base);
+    }
+  }
+  return acc;
+}
+
+}}  // namespace rabe::bn254

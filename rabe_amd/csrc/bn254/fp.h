@@ -1,0 +1,269 @@
+// BN254 prime-field arithmetic for gfx950: 8 x 32-bit limbs, Montgomery form (R = 2^256).
+//
+// This is the bottom of the engine that replaces the `rabe_bn` Fr / Fq arithmetic the
+// reference reaches through `use rabe_bn::{Fr, G1, G2, Gt, pairing}` (src/schemes/ac17/mod.rs:42).
+// The limb width is 32 bits because CDNA4 has no 64-bit integer multiplier: a limb product is one
+// `v_mad_u64_u32` (32x32+64 -> 64).  All loops are fully unrolled with compile-time indices so the
+// limbs live in VGPRs (cdna_hip_programming.md rule 20: runtime-indexed arrays go to scratch).
+//
+// The same template serves Fp (base field) and Fr (scalar field); only the constants differ.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "constants.h"
+
+// Inlining policy (code size / compile time vs call overhead on gfx950):
+//   RB_HD     small helpers (add/sub/neg/select, constants): always inlined.
+//   RB_FN     real functions.  Field multiplications are functions at Fp and Fp2 granularity whose
+//             operands are single-member structs of an 8-lane vector type, which the AMDGPU calling
+//             convention passes in VGPRs (no scratch traffic); everything from Fp6 upwards (tower,
+//             curve, pairing steps) is a function taking references -- its operands are 48..96 dwords
+//             and the memory traffic is <5% of the multiplications inside.
+#define RB_HD __host__ __device__ __forceinline__
+#define RB_FN __host__ __device__ __attribute__((noinline))
+#define RB_HD_NOINLINE RB_FN
+
+namespace rabe { namespace bn254 {
+
+struct FpParams {
+  static RB_HD constexpr uint32_t mod(int i) { constexpr uint32_t m[8] = RB_FP_MOD; return m[i]; }
+  static RB_HD constexpr uint32_t one(int i) { constexpr uint32_t m[8] = RB_FP_ONE; return m[i]; }
+  static RB_HD constexpr uint32_t r2(int i) { constexpr uint32_t m[8] = RB_FP_R2; return m[i]; }
+  static RB_HD constexpr uint32_t exp_inv(int i) { constexpr uint32_t m[8] = RB_FP_PM2; return m[i]; }
+  static constexpr uint32_t INV = RB_FP_INV32;
+};
+struct FrParams {
+  static RB_HD constexpr uint32_t mod(int i) { constexpr uint32_t m[8] = RB_FR_MOD; return m[i]; }
+  static RB_HD constexpr uint32_t one(int i) { constexpr uint32_t m[8] = RB_FR_ONE; return m[i]; }
+  static RB_HD constexpr uint32_t r2(int i) { constexpr uint32_t m[8] = RB_FR_R2; return m[i]; }
+  static RB_HD constexpr uint32_t exp_inv(int i) { constexpr uint32_t m[8] = RB_FR_RM2; return m[i]; }
+  static constexpr uint32_t INV = RB_FR_INV32;
+};
+
+// A field element in Montgomery form, fully reduced (< modulus).
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+template <class M>
+struct Mont {
+  u32x8 v;   // single-member struct of a vector: passed and returned in 8 VGPRs
+};
+typedef Mont<FpParams> Fp;
+typedef Mont<FrParams> Fr;
+
+// ---------------------------------------------------------------------------------------------
+// raw 256-bit helpers
+RB_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+  uint64_t s = (uint64_t)a + b + carry;
+  carry = (uint32_t)(s >> 32);
+  return (uint32_t)s;
+}
+RB_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+  uint64_t d = (uint64_t)a - b - borrow;
+  borrow = (uint32_t)(d >> 63);
+  return (uint32_t)d;
+}
+
+template <class M>
+RB_HD bool is_zero(const Mont<M>& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+template <class M>
+RB_HD bool eq(const Mont<M>& a, const Mont<M>& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+template <class M>
+RB_HD Mont<M> zero() {
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r;
+}
+template <class M>
+RB_HD Mont<M> one() {
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = M::one(i);
+  return r;
+}
+
+// r = a - mod if a >= mod (a < 2*mod, optional extra carry bit `hi`)
+template <class M>
+RB_HD void cond_sub_mod(uint32_t* t, uint32_t hi) {
+  uint32_t d[8];
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = subb32(t[i], M::mod(i), borrow);
+  // keep the difference when no borrow out of (hi:t) - mod
+  bool ge = (hi != 0) | (borrow == 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = ge ? d[i] : t[i];
+}
+
+template <class M>
+RB_HD Mont<M> add(const Mont<M>& a, const Mont<M>& b) {
+  uint32_t t[8];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = addc32(a.v[i], b.v[i], c);
+  cond_sub_mod<M>(t, c);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+template <class M>
+RB_HD Mont<M> sub(const Mont<M>& a, const Mont<M>& b) {
+  Mont<M> r;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = subb32(a.v[i], b.v[i], borrow);
+  // add the modulus back when the subtraction wrapped
+  uint32_t mask = 0u - borrow;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = addc32(r.v[i], M::mod(i) & mask, c);
+  return r;
+}
+template <class M>
+RB_HD Mont<M> neg(const Mont<M>& a) {
+  Mont<M> r;
+  uint32_t borrow = 0;
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) nz |= a.v[i];
+  uint32_t mask = nz ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = subb32(M::mod(i) & mask, a.v[i], borrow);
+  return r;
+}
+template <class M>
+RB_HD Mont<M> dbl(const Mont<M>& a) {
+  return add(a, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Montgomery multiplication, CIOS over 32-bit limbs.  136 limb products (64 a*b, 64 m*p, 8 m).
+// Inputs < mod, output < mod.  Because mod < 2^254 the running value never exceeds 2*mod, so the
+// ninth accumulator word stays zero and only one conditional subtraction is needed at the end.
+template <class M, class A, class B>
+RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    const uint32_t bi = b[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint64_t x = (uint64_t)a[j] * bi + t[j] + c;
+      t[j] = (uint32_t)x;
+      c = x >> 32;
+    }
+    t[8] = (uint32_t)c;  // previous t[8] is always 0 here (value < 2*mod < 2^255 after each reduction step)
+    const uint32_t m = t[0] * M::INV;
+    uint64_t x = (uint64_t)m * M::mod(0) + t[0];
+    c = x >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      x = (uint64_t)m * M::mod(j) + t[j] + c;
+      t[j - 1] = (uint32_t)x;
+      c = x >> 32;
+    }
+    x = (uint64_t)t[8] + c;
+    t[7] = (uint32_t)x;
+    // (x >> 32) is 0: see above
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = t[i];
+  cond_sub_mod<M>(r, 0);
+}
+
+// inlined form (used inside the Fp2-level functions, which are themselves real functions)
+template <class M>
+RB_HD Mont<M> mul_inl(const Mont<M>& a, const Mont<M>& b) {
+  uint32_t t[8];
+  mont_mul_raw<M>(t, a.v, b.v);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+// out-of-line form: operands and result travel in VGPRs
+template <class M>
+RB_FN Mont<M> mul(Mont<M> a, Mont<M> b) { return mul_inl(a, b); }
+template <class M>
+RB_FN Mont<M> sqr(Mont<M> a) { return mul_inl(a, a); }
+
+// canonical integer (little-endian limbs, < mod) <-> Montgomery
+template <class M>
+RB_HD Mont<M> to_mont(const uint32_t x[8]) {
+  uint32_t r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r2[i] = M::r2(i);
+  Mont<M> xm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { xm.v[i] = x[i]; }
+  Mont<M> rm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { rm.v[i] = r2[i]; }
+  return mul(xm, rm);
+}
+template <class M>
+RB_HD void from_mont(uint32_t out[8], const Mont<M>& a) {
+  Mont<M> o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.v[i] = (i == 0) ? 1u : 0u;
+  Mont<M> r = mul(a, o);
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = r.v[i];
+}
+// Reduce an arbitrary 256-bit integer into Montgomery form: mont_mul(x, R^2) = x*R mod m for any
+// x < 2^256 (the CIOS bound only needs one operand < mod).  This is `Fr::from_slice` on a SHA3
+// digest (src/utils/hash/mod.rs:16) -- SURVEY.md 8c assumption (i).
+template <class M>
+RB_HD Mont<M> to_mont_reduce256(const uint32_t x[8]) {
+  uint32_t r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r2[i] = M::r2(i);
+  Mont<M> xm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { xm.v[i] = x[i]; }
+  Mont<M> rm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { rm.v[i] = r2[i]; }
+  return mul(rm, xm);   // x plays `b`: rows use b[i] freely, the a-operand (R2) is < mod
+}
+
+// a^(mod-2): Fermat inversion, left-to-right binary over the constant exponent (the instruction
+// stream is identical for every lane: no divergence, no table, nothing runtime-indexed).  inv(0) = 0.
+template <class M>
+RB_HD uint32_t inv_exp_word(int k) {
+  switch (k) {
+    case 0: return M::exp_inv(0);
+    case 1: return M::exp_inv(1);
+    case 2: return M::exp_inv(2);
+    case 3: return M::exp_inv(3);
+    case 4: return M::exp_inv(4);
+    case 5: return M::exp_inv(5);
+    case 6: return M::exp_inv(6);
+    default: return M::exp_inv(7);
+  }
+}
+template <class M>
+RB_HD_NOINLINE Mont<M> inv(Mont<M> a) {
+  Mont<M> acc = a;   // top bit (bit 253) of mod-2 is set
+  for (int i = 252; i >= 0; i--) {
+    acc = sqr(acc);
+    const uint32_t bit = (inv_exp_word<M>(i >> 5) >> (i & 31)) & 1u;
+    if (bit) acc = mul(acc, a);
+  }
+  return acc;
+}
+
+}}  // namespace rabe::bn254

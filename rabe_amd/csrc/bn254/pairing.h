@@ -1,0 +1,192 @@
+// Optimal-ate pairing on BN254: `rabe_bn::pairing(G1, G2) -> Gt`
+// (call sites: src/schemes/ac17/mod.rs:148,415-416; bsw/mod.rs:108,292-293,308; lsw/mod.rs:106,275-276;
+//  aw11/mod.rs:144,263,274,340-341).
+//
+// Split the way the batched engine needs it:
+//   miller_loop(P, Q)          one lane per (P, Q) pair, G2 in homogeneous projective coordinates
+//                              (Costello-Lange-Naehrig doubling/addition with line coefficients),
+//                              sparse line multiplication; P may be given in Jacobian form (no inversion).
+//   final_exponentiation(f)    ONE per product of pairings: easy part, then the libff / zcash-bn hard-part
+//                              chain (three exponentiations by u with Granger-Scott squarings).
+// A product of pairings  prod e(P_i, Q_i)  is  final_exponentiation(prod miller_loop(P_i, Q_i)).
+#pragma once
+#include "curve.h"
+
+namespace rabe { namespace bn254 {
+
+// G2 point in homogeneous projective coordinates (x = X/Z, y = Y/Z) for the Miller loop.
+struct G2Hom {
+  Fp2 x, y, z;
+};
+
+// Line through the untwisted points evaluated at P, as (l0, l1, l3) with value l0*yP' + l1*xP' w + l3 w^3.
+// The coefficients returned here are (c_y, c_x, c_0): the caller scales c_y by y_P and c_x by x_P.
+struct LineCoeffs {
+  Fp2 cy, cx, c0;
+};
+
+// Doubling step: T <- 2T, returns the tangent line coefficients.  (Costello et al., as used for
+// D-type twists: cy = -2YZ, cx = 3X^2, c0 = 3b'Z^2 - Y^2.)
+RB_FN LineCoeffs g2hom_double(G2Hom& r) {
+  const Fp two_inv = fp_two_inv();
+  Fp2 a = fp2_mul_fp(fp2_mul(r.x, r.y), two_inv);
+  Fp2 b = fp2_sqr(r.y);
+  Fp2 c = fp2_sqr(r.z);
+  Fp2 e = fp2_mul(twist_b(), fp2_add(fp2_dbl(c), c));   // 3 b' Z^2
+  Fp2 f = fp2_add(fp2_dbl(e), e);                       // 9 b' Z^2
+  Fp2 g = fp2_mul_fp(fp2_add(b, f), two_inv);
+  Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));   // 2YZ
+  Fp2 i = fp2_sub(e, b);
+  Fp2 j = fp2_sqr(r.x);
+  Fp2 e2 = fp2_sqr(e);
+  r.x = fp2_mul(a, fp2_sub(b, f));
+  r.y = fp2_sub(fp2_sqr(g), fp2_add(fp2_dbl(e2), e2));
+  r.z = fp2_mul(b, h);
+  LineCoeffs l;
+  l.cy = fp2_neg(h);
+  l.cx = fp2_add(fp2_dbl(j), j);
+  l.c0 = i;
+  return l;
+}
+
+// Addition step: T <- T + Q (Q affine), returns the chord line coefficients.
+RB_FN LineCoeffs g2hom_add(G2Hom& r, const G2Aff& q) {
+  Fp2 theta = fp2_sub(r.y, fp2_mul(q.y, r.z));
+  Fp2 lambda = fp2_sub(r.x, fp2_mul(q.x, r.z));
+  Fp2 c = fp2_sqr(theta);
+  Fp2 d = fp2_sqr(lambda);
+  Fp2 e = fp2_mul(lambda, d);
+  Fp2 f = fp2_mul(r.z, c);
+  Fp2 g = fp2_mul(r.x, d);
+  Fp2 h = fp2_sub(fp2_add(e, f), fp2_dbl(g));
+  Fp2 ry = r.y;
+  r.x = fp2_mul(lambda, h);
+  r.y = fp2_sub(fp2_mul(theta, fp2_sub(g, h)), fp2_mul(e, ry));
+  r.z = fp2_mul(r.z, e);
+  LineCoeffs l;
+  l.cy = lambda;
+  l.cx = fp2_neg(theta);
+  l.c0 = fp2_sub(fp2_mul(theta, q.x), fp2_mul(lambda, q.y));
+  return l;
+}
+
+// pi(Q) and pi^2(Q) in twist coordinates: pi(x', y') = (conj(x') gamma1_2, conj(y') gamma1_3),
+// pi^2(x', y') = (x' gamma2_2, y' gamma2_3).
+RB_HD G2Aff g2_frob1(const G2Aff& q) {
+  return G2Aff{fp2_mul(fp2_conj(q.x), gamma1_2()), fp2_mul(fp2_conj(q.y), gamma1_3())};
+}
+RB_HD G2Aff g2_frob2(const G2Aff& q) {
+  return G2Aff{fp2_mul_fp(q.x, gamma2_2()), fp2_mul_fp(q.y, gamma2_3())};
+}
+
+// P for the Miller loop: (px, py, and the scale s applied to the constant coefficient).
+// For affine P: px = x, py = y, pz3 = 1.  For Jacobian P = (X, Y, Z): multiply the whole line by Z^3
+// (an Fp factor, killed by the final exponentiation): py = Y, px = X*Z, pz3 = Z^3.
+struct MillerP {
+  Fp px, py, pz3;
+  bool scaled;   // false: pz3 == 1 (skip the multiplication)
+};
+RB_HD MillerP miller_p_from_aff(const G1Aff& p) { return MillerP{p.x, p.y, one<FpParams>(), false}; }
+RB_HD MillerP miller_p_from_jac(const G1Jac& p) {
+  Fp z2 = sqr(p.z);
+  return MillerP{mul(p.x, p.z), p.y, mul(z2, p.z), true};
+}
+
+RB_FN Fp12 ell(const Fp12& f, const LineCoeffs& l, const MillerP& p) {
+  Fp2 l0 = fp2_mul_fp(l.cy, p.py);
+  Fp2 l1 = fp2_mul_fp(l.cx, p.px);
+  Fp2 l3 = p.scaled ? fp2_mul_fp(l.c0, p.pz3) : l.c0;
+  return fp12_mul_by_line(f, l0, l1, l3);
+}
+
+// Miller loop.  Either argument at infinity gives 1 (as `pairing` does for zero inputs).
+RB_FN Fp12 miller_loop(const MillerP& p, bool p_is_inf, const G2Aff& q) {
+  Fp12 f = fp12_one();
+  if (p_is_inf || aff_is_inf(q)) return f;
+  G2Hom t{q.x, q.y, fp2_one()};
+  // 6u+2 has 65 bits; the top bit (bit 64) is consumed by initialising T = Q.
+  for (int i = RB_ATE_LOOP_BITS - 2; i >= 0; i--) {
+    f = fp12_sqr(f);
+    LineCoeffs l = g2hom_double(t);
+    f = ell(f, l, p);
+    const uint32_t bit = (uint32_t)((RB_ATE_LOOP_LO >> i) & 1ull);
+    if (bit) {
+      LineCoeffs la = g2hom_add(t, q);
+      f = ell(f, la, p);
+    }
+  }
+  G2Aff q1 = g2_frob1(q);
+  G2Aff q2 = aff_neg(g2_frob2(q));
+  LineCoeffs l1 = g2hom_add(t, q1);
+  f = ell(f, l1, p);
+  LineCoeffs l2 = g2hom_add(t, q2);
+  f = ell(f, l2, p);
+  return f;
+}
+
+// f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).
+RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {
+  Fp12 acc = f;   // top bit (bit 62)
+  for (int i = 61; i >= 0; i--) {
+    acc = fp12_cyclotomic_sqr(acc);
+    if ((RB_BN_U >> i) & 1ull) acc = fp12_mul(acc, f);
+  }
+  return acc;
+}
+
+// Final exponentiation: f^((p^6-1)(p^2+1)) then the libff / zcash-bn `final_exponentiation_last_chunk`
+// chain, whose exponent is 2u(6u^2+3u+1) * (p^4-p^2+1)/r (oracle/bn254.py FINAL_EXP documents the choice).
+RB_FN Fp12 final_exponentiation(const Fp12& f_in) {
+  // easy part
+  Fp12 f = fp12_mul(fp12_conj(f_in), fp12_inv(f_in));   // f^(p^6-1)
+  f = fp12_mul(fp12_frob2(f), f);                       // ^(p^2+1)
+  // hard part; in the cyclotomic subgroup inversion is conjugation, exp_by_neg_z(x) = conj(x^u)
+  Fp12 a = fp12_conj(fp12_cyclotomic_exp_u(f));
+  Fp12 b = fp12_cyclotomic_sqr(a);
+  Fp12 c = fp12_cyclotomic_sqr(b);
+  Fp12 d = fp12_mul(c, b);
+  Fp12 e = fp12_conj(fp12_cyclotomic_exp_u(d));
+  Fp12 ff = fp12_cyclotomic_sqr(e);
+  Fp12 g = fp12_conj(fp12_cyclotomic_exp_u(ff));
+  Fp12 h = fp12_conj(d);
+  Fp12 i = fp12_conj(g);
+  Fp12 j = fp12_mul(i, e);
+  Fp12 k = fp12_mul(j, h);
+  Fp12 l = fp12_mul(k, b);
+  Fp12 m = fp12_mul(k, e);
+  Fp12 n = fp12_mul(m, f);
+  Fp12 o = fp12_frob1(l);
+  Fp12 pp = fp12_mul(o, n);
+  Fp12 q = fp12_frob2(k);
+  Fp12 r = fp12_mul(q, pp);
+  Fp12 s = fp12_conj(f);
+  Fp12 t = fp12_mul(s, l);
+  Fp12 uu = fp12_frob3(t);
+  return fp12_mul(uu, r);
+}
+
+// Gt exponentiation by a canonical little-endian scalar (`Gt::pow(Fr)`), binary, cyclotomic squarings.
+// Valid for elements of Gt (unitary); the reference only ever raises pairing outputs.
+RB_FN Fp12 gt_pow_binary(const Fp12& base, const uint32_t k[8]) {
+  Fp12 acc = fp12_one();
+  for (int w = 7; w >= 0; w--) {
+    uint32_t word = 0;
+    switch (w) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    for (int b = 31; b >= 0; b--) {
+      acc = fp12_cyclotomic_sqr(acc);
+      if ((word >> b) & 1u) acc = fp12_mul(acc, base);
+    }
+  }
+  return acc;
+}
+
+}}  // namespace rabe::bn254

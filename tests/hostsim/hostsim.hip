@@ -1,0 +1,77 @@
+// TEST INFRASTRUCTURE: runs the engine's __host__ __device__ math (rabe_amd/csrc/bn254/*.h) on the CPU
+// so the arithmetic can be checked against the Python oracle in a container without a GPU.
+// Built with `hipcc --cuda-host-only`; never loaded by the product (rabe_amd/), which only ever
+// launches the same functions as HIP kernels.
+#include "../../rabe_amd/csrc/bn254/io.h"
+#include <string.h>
+
+using namespace rabe::bn254;
+
+extern "C" {
+
+void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp(out, mul(load_fp(a), load_fp(b))); }
+void hs_fp_add(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp(out, add(load_fp(a), load_fp(b))); }
+void hs_fp_sub(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp(out, sub(load_fp(a), load_fp(b))); }
+void hs_fp_neg(const uint32_t* a, uint32_t* out) { store_fp(out, neg(load_fp(a))); }
+void hs_fp_inv(const uint32_t* a, uint32_t* out) { store_fp(out, inv(load_fp(a))); }
+void hs_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fr(out, mul(load_fr(a), load_fr(b))); }
+void hs_fr_inv(const uint32_t* a, uint32_t* out) { store_fr(out, inv(load_fr(a))); }
+void hs_fr_reduce256(const uint32_t* a, uint32_t* out) { store_fr(out, to_mont_reduce256<FrParams>(a)); }
+
+void hs_fp2_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp2(out, fp2_mul(load_fp2(a), load_fp2(b))); }
+void hs_fp2_sqr(const uint32_t* a, uint32_t* out) { store_fp2(out, fp2_sqr(load_fp2(a))); }
+void hs_fp2_inv(const uint32_t* a, uint32_t* out) { store_fp2(out, fp2_inv(load_fp2(a))); }
+void hs_fp2_mul_xi(const uint32_t* a, uint32_t* out) { store_fp2(out, fp2_mul_xi(load_fp2(a))); }
+
+void hs_fp12_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_gt(out, fp12_mul(load_gt(a), load_gt(b))); }
+void hs_fp12_sqr(const uint32_t* a, uint32_t* out) { store_gt(out, fp12_sqr(load_gt(a))); }
+void hs_fp12_inv(const uint32_t* a, uint32_t* out) { store_gt(out, fp12_inv(load_gt(a))); }
+void hs_fp12_frob(const uint32_t* a, int k, uint32_t* out) {
+  Fp12 x = load_gt(a);
+  store_gt(out, k == 1 ? fp12_frob1(x) : (k == 2 ? fp12_frob2(x) : fp12_frob3(x)));
+}
+void hs_fp12_cyclotomic_sqr(const uint32_t* a, uint32_t* out) { store_gt(out, fp12_cyclotomic_sqr(load_gt(a))); }
+void hs_fp12_mul_by_line(const uint32_t* f, const uint32_t* l0, const uint32_t* l1, const uint32_t* l3, uint32_t* out) {
+  store_gt(out, fp12_mul_by_line(load_gt(f), load_fp2(l0), load_fp2(l1), load_fp2(l3)));
+}
+
+void hs_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  store_g1(out, jac_to_aff(jac_add_aff(aff_to_jac(load_g1(a)), load_g1(b))));
+}
+void hs_g1_add_jac(const uint32_t* a, const uint32_t* b, const uint32_t* zscale, uint32_t* out) {
+  // exercise the Jacobian+Jacobian path with non-trivial Z on both sides: scale (x,y,1) -> (x z^2, y z^3, z)
+  Fp z = load_fp(zscale);
+  G1Aff pa = load_g1(a), pb = load_g1(b);
+  G1Jac ja = aff_to_jac(pa), jb = aff_to_jac(pb);
+  if (!aff_is_inf(pa)) { Fp z2 = sqr(z); ja = G1Jac{mul(pa.x, z2), mul(pa.y, mul(z2, z)), z}; }
+  if (!aff_is_inf(pb)) { Fp zz = add(z, one<FpParams>()); Fp z2 = sqr(zz); jb = G1Jac{mul(pb.x, z2), mul(pb.y, mul(z2, zz)), zz}; }
+  store_g1(out, jac_to_aff(jac_add(ja, jb)));
+}
+void hs_g1_mul(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_binary(load_g1(p), k))); }
+void hs_g2_add(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  store_g2(out, jac_to_aff(jac_add_aff(aff_to_jac(load_g2(a)), load_g2(b))));
+}
+void hs_g2_mul(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g2(out, jac_to_aff(jac_mul_binary(load_g2(p), k))); }
+int hs_g1_on_curve(const uint32_t* p) { return aff_on_curve(load_g1(p)); }
+int hs_g2_on_curve(const uint32_t* p) { return aff_on_curve(load_g2(p)); }
+
+void hs_miller(const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff P = load_g1(p);
+  store_gt(out, miller_loop(miller_p_from_aff(P), aff_is_inf(P), load_g2(q)));
+}
+void hs_final_exp(const uint32_t* f, uint32_t* out) { store_gt(out, final_exponentiation(load_gt(f))); }
+void hs_pairing(const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff P = load_g1(p);
+  store_gt(out, final_exponentiation(miller_loop(miller_p_from_aff(P), aff_is_inf(P), load_g2(q))));
+}
+// pairing with P handed over in Jacobian form scaled by z (checks the no-inversion path)
+void hs_pairing_jac(const uint32_t* p, const uint32_t* zscale, const uint32_t* q, uint32_t* out) {
+  G1Aff P = load_g1(p);
+  Fp z = load_fp(zscale);
+  Fp z2 = sqr(z);
+  G1Jac J{mul(P.x, z2), mul(P.y, mul(z2, z)), z};
+  store_gt(out, final_exponentiation(miller_loop(miller_p_from_jac(J), aff_is_inf(P), load_g2(q))));
+}
+void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+"""The engine's BN254 math (rabe_amd/csrc/bn254/*.h -- the exact functions the HIP kernels call)
+executed on the CPU and compared bit-for-bit with the Python big-int oracle.  No GPU needed; the
+same comparisons run on the device in tests/test_gpu_elements.py."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import bn254 as bn
+from tests.hostsim import build as hs_build
+
+try:
+    HS = hs_build.load()
+except Exception as e:  # pragma: no cover
+    HS = None
+    _ERR = e
+
+pytestmark = pytest.mark.skipif(HS is None, reason="hostsim library could not be built")
+
+RND = random.Random(20260928)
+
+
+def buf(n):
+    return (ctypes.c_uint32 * (n // 4))()
+
+
+def b2c(b):
+    return (ctypes.c_uint32 * (len(b) // 4)).from_buffer_copy(b)
+
+
+def call(name, *ins, out=32):
+    o = buf(out)
+    args = [b2c(x) if isinstance(x, (bytes, bytearray)) else x for x in ins]
+    getattr(HS, name)(*args, o)
+    return bytes(o)
+
+
+def le(x, mod=None):
+    return int(x).to_bytes(32, "little")
+
+
+def fp2_le(a):
+    return le(a[0]) + le(a[1])
+
+
+def rand_fp():
+    return RND.randrange(bn.P)
+
+
+def rand_fp12():
+    return bn.fp12_from_coeffs([rand_fp() for _ in range(12)])
+
+
+EDGE = [0, 1, 2, bn.P - 1, bn.P - 2, (1 << 253), (1 << 32) - 1, 1 << 32]
+
+
+def test_fp_ops():
+    vals = EDGE + [rand_fp() for _ in range(40)]
+    for a in vals:
+        for b in (vals[0], vals[3], rand_fp(), rand_fp()):
+            assert call("hs_fp_mul", le(a), le(b)) == le(a * b % bn.P)
+            assert call("hs_fp_add", le(a), le(b)) == le((a + b) % bn.P)
+            assert call("hs_fp_sub", le(a), le(b)) == le((a - b) % bn.P)
+        assert call("hs_fp_neg", le(a)) == le((-a) % bn.P)
+    for a in [1, 2, bn.P - 1] + [rand_fp() for _ in range(5)]:
+        assert call("hs_fp_inv", le(a)) == le(pow(a, bn.P - 2, bn.P))
+    assert call("hs_fp_inv", le(0)) == le(0)
+
+
+def test_fr_ops():
+    for _ in range(20):
+        a, b = RND.randrange(bn.R), RND.randrange(bn.R)
+        assert call("hs_fr_mul", le(a), le(b)) == le(a * b % bn.R)
+    a = RND.randrange(1, bn.R)
+    assert call("hs_fr_inv", le(a)) == le(pow(a, bn.R - 2, bn.R))
+    # Fr::from_slice on an arbitrary 256-bit digest (reduction mod r)
+    for x in [(1 << 256) - 1, bn.R, bn.R + 5, RND.getrandbits(256), 0]:
+        assert call("hs_fr_reduce256", le(x)) == le(x % bn.R)
+
+
+def test_fp2_ops():
+    for _ in range(20):
+        a = (rand_fp(), rand_fp())
+        b = (rand_fp(), rand_fp())
+        assert call("hs_fp2_mul", fp2_le(a), fp2_le(b), out=64) == fp2_le(bn.fp2_mul(a, b))
+        assert call("hs_fp2_sqr", fp2_le(a), out=64) == fp2_le(bn.fp2_sqr(a))
+        assert call("hs_fp2_mul_xi", fp2_le(a), out=64) == fp2_le(bn.fp2_mul_xi(a))
+    a = (rand_fp(), rand_fp())
+    assert call("hs_fp2_inv", fp2_le(a), out=64) == fp2_le(bn.fp2_inv(a))
+
+
+def test_fp12_ops():
+    for _ in range(6):
+        a, b = rand_fp12(), rand_fp12()
+        assert call("hs_fp12_mul", bn.gt_to_le(a), bn.gt_to_le(b), out=384) == bn.gt_to_le(bn.fp12_mul(a, b))
+        assert call("hs_fp12_sqr", bn.gt_to_le(a), out=384) == bn.gt_to_le(bn.fp12_sqr(a))
+        for k in (1, 2, 3):
+            assert call("hs_fp12_frob", bn.gt_to_le(a), k, out=384) == bn.gt_to_le(bn.fp12_pow(a, bn.P ** k))
+        l0, l1, l3 = [(rand_fp(), rand_fp()) for _ in range(3)]
+        line = ((l0, bn.FP2_ZERO, bn.FP2_ZERO), (l1, l3, bn.FP2_ZERO))
+        assert call("hs_fp12_mul_by_line", bn.gt_to_le(a), fp2_le(l0), fp2_le(l1), fp2_le(l3), out=384) == \
+            bn.gt_to_le(bn.fp12_mul(a, line))
+    a = rand_fp12()
+    assert call("hs_fp12_inv", bn.gt_to_le(a), out=384) == bn.gt_to_le(bn.fp12_inv(a))
+
+
+def test_cyclotomic_sqr():
+    # an element of the cyclotomic subgroup: x^((p^6-1)(p^2+1))
+    x = bn.fp12_pow(rand_fp12(), bn.FE_EASY)
+    assert call("hs_fp12_cyclotomic_sqr", bn.gt_to_le(x), out=384) == bn.gt_to_le(bn.fp12_sqr(x))
+
+
+def test_g1_g2_ops():
+    for _ in range(4):
+        k1, k2 = RND.randrange(1, bn.R), RND.randrange(1, bn.R)
+        p1, p2 = bn.g1_mul(bn.G1_GEN, k1), bn.g1_mul(bn.G1_GEN, k2)
+        assert call("hs_g1_add", bn.g1_to_le(p1), bn.g1_to_le(p2), out=64) == bn.g1_to_le(bn.g1_add(p1, p2))
+        assert call("hs_g1_add_jac", bn.g1_to_le(p1), bn.g1_to_le(p2), le(rand_fp()), out=64) == bn.g1_to_le(bn.g1_add(p1, p2))
+        assert call("hs_g1_mul", bn.g1_to_le(p1), le(k2), out=64) == bn.g1_to_le(bn.g1_mul(p1, k2))
+        q1, q2 = bn.g2_mul(bn.G2_GEN, k1), bn.g2_mul(bn.G2_GEN, k2)
+        assert call("hs_g2_add", bn.g2_to_le(q1), bn.g2_to_le(q2), out=128) == bn.g2_to_le(bn.g2_add(q1, q2))
+        assert call("hs_g2_mul", bn.g2_to_le(q1), le(k2), out=128) == bn.g2_to_le(bn.g2_mul(q1, k2))
+    p1 = bn.g1_mul(bn.G1_GEN, 5)
+    # special cases: P + P, P + (-P), P + 0, 0 + P, k = 0, k = r
+    assert call("hs_g1_add", bn.g1_to_le(p1), bn.g1_to_le(p1), out=64) == bn.g1_to_le(bn.g1_mul(bn.G1_GEN, 10))
+    assert call("hs_g1_add", bn.g1_to_le(p1), bn.g1_to_le(bn.g1_neg(p1)), out=64) == bytes(64)
+    assert call("hs_g1_add", bn.g1_to_le(p1), bytes(64), out=64) == bn.g1_to_le(p1)
+    assert call("hs_g1_add", bytes(64), bn.g1_to_le(p1), out=64) == bn.g1_to_le(p1)
+    assert call("hs_g1_add_jac", bn.g1_to_le(p1), bn.g1_to_le(p1), le(7), out=64) == bn.g1_to_le(bn.g1_mul(bn.G1_GEN, 10))
+    assert call("hs_g1_mul", bn.g1_to_le(p1), le(0), out=64) == bytes(64)
+    assert call("hs_g1_mul", bn.g1_to_le(p1), le(bn.R), out=64) == bytes(64)
+    assert HS.hs_g1_on_curve(b2c(bn.g1_to_le(p1))) == 1
+    assert HS.hs_g1_on_curve(b2c(le(1) + le(3))) == 0
+    assert HS.hs_g2_on_curve(b2c(bn.g2_to_le(bn.G2_GEN))) == 1
+
+
+def test_pairing_matches_oracle():
+    k1, k2 = RND.randrange(1, bn.R), RND.randrange(1, bn.R)
+    p = bn.g1_mul(bn.G1_GEN, k1)
+    q = bn.g2_mul(bn.G2_GEN, k2)
+    want = bn.pairing(p, q)
+    got = call("hs_pairing", bn.g1_to_le(p), bn.g2_to_le(q), out=384)
+    assert got == bn.gt_to_le(want)
+    # Miller values differ by subfield factors but agree after the final exponentiation
+    m = call("hs_miller", bn.g1_to_le(p), bn.g2_to_le(q), out=384)
+    assert bn.final_exponentiation(bn.gt_from_le(m)) == want
+    assert call("hs_final_exp", m, out=384) == bn.gt_to_le(want)
+    # Jacobian P (no inversion) path
+    assert call("hs_pairing_jac", bn.g1_to_le(p), le(rand_fp()), bn.g2_to_le(q), out=384) == bn.gt_to_le(want)
+    # infinity inputs -> 1
+    assert call("hs_pairing", bytes(64), bn.g2_to_le(q), out=384) == bn.gt_to_le(bn.GT_ONE)
+    assert call("hs_pairing", bn.g1_to_le(p), bytes(128), out=384) == bn.gt_to_le(bn.GT_ONE)
+    # Gt pow
+    k = RND.randrange(bn.R)
+    assert call("hs_gt_pow", bn.gt_to_le(want), le(k), out=384) == bn.gt_to_le(bn.gt_pow(want, k))
