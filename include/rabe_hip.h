@@ -1,0 +1,176 @@
+/*
+ * rabe_hip.h -- C ABI of the MI355X (gfx950) batched ABE pairing / scalar-multiplication engine.
+ *
+ * This is the drop-in boundary for the hot path of Fraunhofer-AISEC/rabe: the per-attribute loops of
+ * rabe::schemes::{ac17,bsw,lsw,aw11}::{keygen,encrypt,decrypt}.  In the reference all of that math
+ * enters through `use rabe_bn::{Group, Gt, G1, G2, Fr, pairing}` (src/schemes/ac17/mod.rs:42,
+ * bsw/mod.rs:23, lsw/mod.rs:23, aw11/mod.rs:27); a Rust host keeps policy parsing, MSP, pruning, KDF
+ * and AES and binds these symbols over FFI (INTEGRATION.md shows the `extern "C"` block).
+ * The convention follows the reference's own (stale) C FFI, src/ffi/bsw.rs:22-163: opaque context
+ * pointers created/destroyed by paired functions, int32 status (0 ok, <0 error).
+ *
+ * Two levels:
+ *   Level E  element batches -- `rabe_bn` operator semantics on arrays (n independent operations),
+ *            used for parity against the oracle and for a `rabe-bn`-shaped shim.
+ *   Level B  scheme batches -- whole encrypt / keygen / decrypt group-arithmetic of n independent calls.
+ *
+ * Wire format (all little-endian, canonical = fully reduced, NOT Montgomery):
+ *   rhip_fr  32 B   integer < r
+ *   rhip_g1  64 B   affine x || y, each an integer < p; the point at infinity is all-zero
+ *   rhip_g2 128 B   affine x.c0 || x.c1 || y.c0 || y.c1  (Fq2 = c0 + c1*u); infinity all-zero
+ *   rhip_gt 384 B   12 integers < p in tower order c0.a0.c0, c0.a0.c1, c0.a1.c0, ... c1.a2.c1
+ *                   (Fq12 = c0 + c1*w, Fq6 = a0 + a1*v + a2*v^2, Fq2 = c0 + c1*u)
+ * Every `dev` pointer below is DEVICE memory (hipMalloc / rhip_malloc / a torch CUDA tensor);
+ * the call is asynchronous on the context's stream; rhip_sync() waits.
+ */
+#ifndef RABE_HIP_H
+#define RABE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint32_t l[8]; } rhip_fr;
+typedef struct { uint32_t l[16]; } rhip_g1;
+typedef struct { uint32_t l[32]; } rhip_g2;
+typedef struct { uint32_t l[96]; } rhip_gt;
+
+typedef struct rhip_ctx rhip_ctx;
+
+#define RHIP_OK 0
+#define RHIP_ERR_NO_DEVICE (-1)   /* no HIP device / kernels not loadable: the engine never falls back to the CPU */
+#define RHIP_ERR_HIP (-2)         /* a HIP runtime call failed; see rhip_last_error */
+#define RHIP_ERR_ARG (-3)
+#define RHIP_ERR_NOT_MEMBER (-4)  /* an input point is not on the curve (rabe_bn::FieldError::NotMember, src/error.rs:60-69) */
+
+/* ---- context (one per host thread / per GPU; single owner) ------------------------------------ */
+int32_t rhip_ctx_create(int32_t device, rhip_ctx** out);
+void rhip_ctx_destroy(rhip_ctx* ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* hip_stream);
+int32_t rhip_sync(rhip_ctx* ctx);
+const char* rhip_last_error(rhip_ctx* ctx);
+/* number of compute units / device name of the context's GPU */
+int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len);
+
+/* device memory helpers for hosts without their own allocator */
+int32_t rhip_malloc(rhip_ctx* ctx, size_t bytes, void** dev);
+int32_t rhip_free(rhip_ctx* ctx, void* dev);
+int32_t rhip_upload(rhip_ctx* ctx, void* dev, const void* host, size_t bytes);
+int32_t rhip_download(rhip_ctx* ctx, void* host, const void* dev, size_t bytes);
+
+/* ---- Level E: element batches (n independent operations) --------------------------------------
+ * rabe_bn surface replaced ("rabe_bn API surface actually used"):
+ *   Fr: + - * neg inverse            src/utils/secretsharing/mod.rs:25-28,66,218; ac17/mod.rs:213,229,240
+ *   Fr::from_slice(SHA3 digest)      src/utils/hash/mod.rs:16,27
+ *   G1/G2: + - neg, * Fr             ac17/mod.rs:219,235-240,300-302,343-348,406-415
+ *   Gt: * inverse pow                ac17/mod.rs:357-360,418; bsw/mod.rs:234,291-294,308
+ *   pairing(G1,G2)                   ac17/mod.rs:148,415-416; bsw/mod.rs:108,292-293,308
+ */
+enum { RHIP_FR_ADD = 0, RHIP_FR_SUB = 1, RHIP_FR_MUL = 2, RHIP_FR_NEG = 3, RHIP_FR_INV = 4 };
+int32_t rhip_fr_op(rhip_ctx* ctx, int32_t op, size_t n, const rhip_fr* dev_a, const rhip_fr* dev_b, rhip_fr* dev_out);
+/* `Fr::from_slice` of n 32-byte BIG-endian digests: integer mod r */
+int32_t rhip_fr_from_be32_reduce(rhip_ctx* ctx, size_t n, const uint8_t* dev_digests, rhip_fr* dev_out);
+
+int32_t rhip_g1_add(rhip_ctx* ctx, size_t n, const rhip_g1* dev_a, const rhip_g1* dev_b, rhip_g1* dev_out);
+int32_t rhip_g1_neg(rhip_ctx* ctx, size_t n, const rhip_g1* dev_a, rhip_g1* dev_out);
+int32_t rhip_g1_mul(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, const rhip_fr* dev_k, rhip_g1* dev_out);
+int32_t rhip_g2_add(rhip_ctx* ctx, size_t n, const rhip_g2* dev_a, const rhip_g2* dev_b, rhip_g2* dev_out);
+int32_t rhip_g2_neg(rhip_ctx* ctx, size_t n, const rhip_g2* dev_a, rhip_g2* dev_out);
+int32_t rhip_g2_mul(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, const rhip_fr* dev_k, rhip_g2* dev_out);
+/* per-element curve membership: dev_ok[i] = 1 if on the curve (or infinity) */
+int32_t rhip_g1_on_curve(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, uint32_t* dev_ok);
+int32_t rhip_g2_on_curve(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
+
+int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_gt* dev_b, rhip_gt* dev_out);
+int32_t rhip_gt_inv(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, rhip_gt* dev_out);
+int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_fr* dev_k, rhip_gt* dev_out);
+
+/* n independent pairings e(p_i, q_i) */
+int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, const rhip_g2* dev_q, rhip_gt* dev_out);
+/* n_items products of pairings: out[i] = prod_{j in [off[i], off[i+1])} e(p_j, q_j), with ONE final
+ * exponentiation per item (the restructuring of SURVEY.md Appendix B).  dev_off has n_items+1 entries. */
+int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* dev_off, size_t n_pairs,
+                             const rhip_g1* dev_p, const rhip_g2* dev_q, rhip_gt* dev_out);
+
+/* ---- fixed-base tables (per public key; resident in HBM) --------------------------------------
+ * Every G1/G2 element the schemes create is a known-scalar multiple of a generator from the public
+ * key (hash-to-group is g * Fr(SHA3(label)), src/utils/hash/mod.rs:10-20), and every Gt power is of a
+ * public-key constant, so the engine keeps 8-bit window tables of those bases. */
+typedef struct rhip_g1_table rhip_g1_table;
+typedef struct rhip_g2_table rhip_g2_table;
+typedef struct rhip_gt_table rhip_gt_table;
+int32_t rhip_g1_table_create(rhip_ctx* ctx, const rhip_g1* host_base, rhip_g1_table** out);
+int32_t rhip_g2_table_create(rhip_ctx* ctx, const rhip_g2* host_base, rhip_g2_table** out);
+int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* host_base, rhip_gt_table** out);
+void rhip_g1_table_destroy(rhip_g1_table* t);
+void rhip_g2_table_destroy(rhip_g2_table* t);
+void rhip_gt_table_destroy(rhip_gt_table* t);
+/* out[i] = base * k[i]  /  base ^ k[i] */
+int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size_t n, const rhip_fr* dev_k, rhip_g1* dev_out);
+int32_t rhip_g2_table_mul(rhip_ctx* ctx, const rhip_g2_table* t, size_t n, const rhip_fr* dev_k, rhip_g2* dev_out);
+int32_t rhip_gt_table_pow(rhip_ctx* ctx, const rhip_gt_table* t, size_t n, const rhip_fr* dev_k, rhip_gt* dev_out);
+
+/* ---- Level B: AC17 (FAME) CP-ABE -------------------------------------------------------------- */
+/* Public key side of ac17::cp_encrypt (Ac17PublicKey, src/schemes/ac17/mod.rs:62-66). */
+typedef struct rhip_ac17_pk rhip_ac17_pk;
+int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* host_g, const rhip_g2* host_h_a /*[3]*/,
+                            const rhip_gt* host_e_gh_ka /*[2]*/, rhip_ac17_pk** out);
+void rhip_ac17_pk_destroy(rhip_ac17_pk* pk);
+
+/* Group arithmetic of n_items calls of ac17::cp_encrypt (src/schemes/ac17/mod.rs:274-376).
+ * The host has parsed each policy and built its MSP; per distinct policy it supplies the Fr table
+ *   A[row][l][t] = h(pi_row || l || t) + sum_j M[row][j] * h("0" || (j+1) || l || t)   (mod r)
+ * (h = Fr::from_slice(SHA3-256), src/utils/hash/mod.rs:16) for row < n_rows, l < 3, t < 2.
+ * All items of one call share that policy.  Per item i the explicit randomness is s[i][0..2)
+ * (drawn at :292) and the Gt `msg` (drawn at :362).  Outputs, per item:
+ *   c_0[i][0..3)  = (h_a0*s0, h_a1*s1, h_a2*(s0+s1))                       (:297-302)
+ *   c[i][row][l]  = g * (s0*A[row][l][0] + s1*A[row][l][1])                (:330-356)
+ *   c_p[i]        = e_gh_ka0^s0 * e_gh_ka1^s1 * msg                        (:357-368)
+ */
+int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, size_t n_rows,
+                                   const rhip_fr* dev_A /*[n_rows][3][2]*/, const rhip_fr* dev_s /*[n_items][2]*/,
+                                   const rhip_gt* dev_msg /*[n_items]*/, rhip_g2* dev_c0 /*[n_items][3]*/,
+                                   rhip_g1* dev_c /*[n_items][n_rows][3]*/, rhip_gt* dev_cp /*[n_items]*/);
+
+/* Group arithmetic of n_items calls of ac17::cp_keygen (src/schemes/ac17/mod.rs:191-264).
+ * Host supplies per attribute y the hashes H[y][l][t] = h(y||l||t) and, once, H01[l][t] = h("01"||l||t);
+ * per item the randomness r0, r1, sigma_y (one per attribute), sigma'.  a_inv[t] = a_t^-1, b[t] from the msk.
+ * Outputs per item: k_0[3] (G2), k[y][3] (G1), k_p[3] (G1).  g_k[3] are the msk's G1 elements. */
+int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table* g_table, const rhip_g2_table* h_table,
+                                  const rhip_g1* dev_g_k /*[3]*/, const rhip_fr* dev_a_inv /*[2]*/, const rhip_fr* dev_b /*[2]*/,
+                                  size_t n_items, size_t n_attrs, const rhip_fr* dev_H /*[n_attrs][3][2]*/,
+                                  const rhip_fr* dev_H01 /*[3][2]*/, const rhip_fr* dev_r /*[n_items][2]*/,
+                                  const rhip_fr* dev_sigma /*[n_items][n_attrs]*/, const rhip_fr* dev_sigma_p /*[n_items]*/,
+                                  rhip_g2* dev_k0 /*[n_items][3]*/, rhip_g1* dev_k /*[n_items][n_attrs][3]*/,
+                                  rhip_g1* dev_kp /*[n_items][3]*/);
+
+/* Group arithmetic of n_items calls of ac17::cp_decrypt (src/schemes/ac17/mod.rs:385-430).
+ * Ciphertext i occupies rows [ct_row_off[i], ct_row_off[i+1]) of dev_ct_c; it is decrypted with secret
+ * key sk_idx[i], whose attribute rows are [sk_row_off[k], sk_row_off[k+1]) of dev_sk_k.  The host has run
+ * traverse_policy / calc_pruned (string work) and hands over, per item, the matched row indices:
+ * ct_sel / sk_sel hold row numbers relative to the item's ciphertext / key, delimited by sel_off
+ * (one (ct,sk) index list pair per item; entries are summed once per occurrence exactly as the
+ * reference's name-matching loops do, :403-414).  Output: the Gt handed to decrypt_symmetric (:418). */
+int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items,
+                                   const rhip_g2* dev_ct_c0 /*[n_items][3]*/, const rhip_g1* dev_ct_c /*[rows][3]*/,
+                                   const uint32_t* dev_ct_row_off /*[n_items+1]*/, const rhip_gt* dev_ct_cp /*[n_items]*/,
+                                   const rhip_g2* dev_sk_k0 /*[n_sk][3]*/, const rhip_g1* dev_sk_k /*[sk rows][3]*/,
+                                   const uint32_t* dev_sk_row_off /*[n_sk+1]*/, const rhip_g1* dev_sk_kp /*[n_sk][3]*/,
+                                   const uint32_t* dev_sk_idx /*[n_items]*/,
+                                   const uint32_t* dev_ct_sel, const uint32_t* dev_ct_sel_off /*[n_items+1]*/,
+                                   const uint32_t* dev_sk_sel, const uint32_t* dev_sk_sel_off /*[n_items+1]*/,
+                                   rhip_gt* dev_out /*[n_items]*/);
+
+/* ---- measurement helper: integer-multiply issue-rate microbenchmark (the roofline denominator) --
+ * Runs `iters` dependent-free v_mad_u64_u32 per lane on every CU and returns elapsed milliseconds
+ * and the number of multiply-adds executed. */
+int32_t rhip_calibrate_mad(rhip_ctx* ctx, int32_t variant, uint32_t iters, double* ms, double* n_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RABE_HIP_H */

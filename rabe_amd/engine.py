@@ -1,0 +1,233 @@
+"""ctypes binding of include/rabe_hip.h (plumbing only).
+
+`Engine()` fails loudly -- EngineError -- when librabe_hip.so is missing or there is no HIP device;
+there is no CPU fallback.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FR, G1, G2, GT = 32, 64, 128, 384
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "librabe_hip.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen the engine (works without a GPU; only rhip_ctx_create needs one)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise EngineError("HIP engine not built: %s missing (run `python -m rabe_amd.build`)" % path)
+        lib = ctypes.CDLL(path)
+        lib.rhip_last_error.restype = ctypes.c_char_p
+        _LIB = lib
+    return _LIB
+
+
+def fr_bytes(x):
+    return int(x % R_ORDER).to_bytes(32, "little")
+
+
+class DevBuf:
+    """A device allocation owned by an Engine."""
+
+    def __init__(self, eng, nbytes):
+        self.eng = eng
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_malloc(eng.ctx, ctypes.c_size_t(nbytes), ctypes.byref(p)))
+        self.ptr = p
+
+    def free(self):
+        if self.ptr:
+            self.eng.lib.rhip_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.rhip_ctx_create(ctypes.c_int32(device), ctypes.byref(ctx))
+        if rc != 0:
+            raise EngineError("rhip_ctx_create(device=%d) failed with %d: no usable HIP device "
+                              "(the engine has no CPU fallback)" % (device, rc))
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            self.lib.rhip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError("rabe_hip call failed (%d): %s" % (rc, self.lib.rhip_last_error(self.ctx).decode()))
+
+    # ------------------------------------------------------------------ memory
+    def alloc(self, nbytes):
+        return DevBuf(self, max(int(nbytes), 4))
+
+    def upload(self, data):
+        data = bytes(data)
+        b = self.alloc(len(data))
+        if data:
+            self._check(self.lib.rhip_upload(self.ctx, b.ptr, data, ctypes.c_size_t(len(data))))
+        return b
+
+    def upload_u32(self, values):
+        import array
+        return self.upload(array.array("I", values).tobytes())
+
+    def download(self, buf, nbytes=None):
+        n = buf.nbytes if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(n)
+        if n:
+            self._check(self.lib.rhip_download(self.ctx, out, buf.ptr, ctypes.c_size_t(n)))
+        return out.raw
+
+    def sync(self):
+        self._check(self.lib.rhip_sync(self.ctx))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self.lib.rhip_ctx_set_stream(self.ctx, ctypes.c_void_p(hip_stream_ptr)))
+
+    def device_info(self):
+        n = ctypes.c_int32()
+        name = ctypes.create_string_buffer(128)
+        self._check(self.lib.rhip_device_info(self.ctx, ctypes.byref(n), name, ctypes.c_size_t(128)))
+        return n.value, name.value.decode()
+
+    # ------------------------------------------------------------------ Level E helpers (host bytes in, host bytes out)
+    def _elem(self, fn, n, ins, out_elem_bytes, extra_first=()):
+        bufs = [self.upload(b"".join(x)) if not isinstance(x, (bytes, bytearray)) else self.upload(x) for x in ins]
+        out = self.alloc(n * out_elem_bytes)
+        args = list(extra_first) + [ctypes.c_size_t(n)] + [b.ptr for b in bufs] + [out.ptr]
+        self._check(getattr(self.lib, fn)(self.ctx, *args))
+        raw = self.download(out, n * out_elem_bytes)
+        return [raw[i * out_elem_bytes:(i + 1) * out_elem_bytes] for i in range(n)]
+
+    def fr_op(self, op, a, b=None):
+        n = len(a)
+        bb = b if b is not None else a
+        return self._elem("rhip_fr_op", n, [a, bb], FR, extra_first=(ctypes.c_int32(op),))
+
+    def fr_from_be32_reduce(self, digests):
+        return self._elem("rhip_fr_from_be32_reduce", len(digests), [digests], FR)
+
+    def g1_add(self, a, b): return self._elem("rhip_g1_add", len(a), [a, b], G1)
+    def g1_neg(self, a): return self._elem("rhip_g1_neg", len(a), [a], G1)
+    def g1_mul(self, p, k): return self._elem("rhip_g1_mul", len(p), [p, k], G1)
+    def g2_add(self, a, b): return self._elem("rhip_g2_add", len(a), [a, b], G2)
+    def g2_neg(self, a): return self._elem("rhip_g2_neg", len(a), [a], G2)
+    def g2_mul(self, p, k): return self._elem("rhip_g2_mul", len(p), [p, k], G2)
+    def gt_mul(self, a, b): return self._elem("rhip_gt_mul", len(a), [a, b], GT)
+    def gt_inv(self, a): return self._elem("rhip_gt_inv", len(a), [a], GT)
+    def gt_pow(self, a, k): return self._elem("rhip_gt_pow", len(a), [a, k], GT)
+    def pairing(self, p, q): return self._elem("rhip_pairing", len(p), [p, q], GT)
+
+    def g1_on_curve(self, p):
+        return [int.from_bytes(x, "little") for x in self._elem("rhip_g1_on_curve", len(p), [p], 4)]
+
+    def g2_on_curve(self, p):
+        return [int.from_bytes(x, "little") for x in self._elem("rhip_g2_on_curve", len(p), [p], 4)]
+
+    def pairing_product(self, offsets, p, q):
+        n_items = len(offsets) - 1
+        off = self.upload_u32(offsets)
+        bp, bq = self.upload(b"".join(p)), self.upload(b"".join(q))
+        out = self.alloc(n_items * GT)
+        self._check(self.lib.rhip_pairing_product(self.ctx, ctypes.c_size_t(n_items), off.ptr, ctypes.c_size_t(len(p)),
+                                                  bp.ptr, bq.ptr, out.ptr))
+        raw = self.download(out, n_items * GT)
+        return [raw[i * GT:(i + 1) * GT] for i in range(n_items)]
+
+    # ------------------------------------------------------------------ tables
+    def g1_table(self, base): return _Table(self, "g1", base)
+    def g2_table(self, base): return _Table(self, "g2", base)
+    def gt_table(self, base): return _Table(self, "gt", base)
+
+    def calibrate(self, variant, iters):
+        ms, ops = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.rhip_calibrate_mad(self.ctx, ctypes.c_int32(variant), ctypes.c_uint32(iters),
+                                                ctypes.byref(ms), ctypes.byref(ops)))
+        return ms.value, ops.value
+
+
+class _Table:
+    _OUT = {"g1": G1, "g2": G2, "gt": GT}
+
+    def __init__(self, eng, kind, base):
+        self.eng, self.kind = eng, kind
+        self.h = ctypes.c_void_p()
+        eng._check(getattr(eng.lib, "rhip_%s_table_create" % kind)(eng.ctx, bytes(base), ctypes.byref(self.h)))
+
+    def mul(self, scalars):
+        fn = "rhip_%s_table_%s" % (self.kind, "pow" if self.kind == "gt" else "mul")
+        eng = self.eng
+        n = len(scalars)
+        k = eng.upload(b"".join(scalars))
+        sz = self._OUT[self.kind]
+        out = eng.alloc(n * sz)
+        eng._check(getattr(eng.lib, fn)(eng.ctx, self.h, ctypes.c_size_t(n), k.ptr, out.ptr))
+        raw = eng.download(out, n * sz)
+        return [raw[i * sz:(i + 1) * sz] for i in range(n)]
+
+    def destroy(self):
+        if self.h:
+            getattr(self.eng.lib, "rhip_%s_table_destroy" % self.kind)(self.h)
+            self.h = None
+
+
+# ---------------------------------------------------------------------- Level B: AC17 (device-buffer level)
+class Ac17Pk:
+    """Device tables of an Ac17PublicKey (g, h_a[3], e_gh_ka[2])."""
+
+    def __init__(self, eng, g, h_a, e_gh_ka):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_ac17_pk_create(eng.ctx, bytes(g), b"".join(h_a), b"".join(e_gh_ka), ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_ac17_pk_destroy(self.h)
+            self.h = None
+
+
+def _sz(n):
+    return ctypes.c_size_t(int(n))
+
+
+def ac17_encrypt_dev(eng, pk, n_items, n_rows, dA, ds, dmsg, dc0, dc, dcp):
+    eng._check(eng.lib.rhip_ac17_cp_encrypt_batch(eng.ctx, pk.h, _sz(n_items), _sz(n_rows), dA.ptr, ds.ptr, dmsg.ptr,
+                                                  dc0.ptr, dc.ptr, dcp.ptr))
+
+
+def ac17_keygen_dev(eng, g_table, h_table, dgk, dainv, db, n_items, n_attrs, dH, dH01, dr, dsigma, dsigmap, dk0, dk, dkp):
+    eng._check(eng.lib.rhip_ac17_cp_keygen_batch(eng.ctx, g_table.h, h_table.h, dgk.ptr, dainv.ptr, db.ptr, _sz(n_items),
+                                                 _sz(n_attrs), dH.ptr, dH01.ptr, dr.ptr, dsigma.ptr, dsigmap.ptr,
+                                                 dk0.ptr, dk.ptr, dkp.ptr))
+
+
+def ac17_decrypt_dev(eng, n_items, dct_c0, dct_c, dct_row_off, dct_cp, dsk_k0, dsk_k, dsk_row_off, dsk_kp, dsk_idx,
+                     dct_sel, dct_sel_off, dsk_sel, dsk_sel_off, dout):
+    eng._check(eng.lib.rhip_ac17_cp_decrypt_batch(eng.ctx, _sz(n_items), dct_c0.ptr, dct_c.ptr, dct_row_off.ptr, dct_cp.ptr,
+                                                  dsk_k0.ptr, dsk_k.ptr, dsk_row_off.ptr, dsk_kp.ptr, dsk_idx.ptr,
+                                                  dct_sel.ptr, dct_sel_off.ptr, dsk_sel.ptr, dsk_sel_off.ptr, dout.ptr))
