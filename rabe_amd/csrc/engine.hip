@@ -65,28 +65,41 @@ static int32_t ensure_scratch(rhip_ctx* ctx, size_t bytes) {
   return RHIP_OK;
 }
 
+static std::string g_create_err;   // diagnostics for a failed rhip_ctx_create (no ctx exists yet)
+static int32_t create_fail(const char* what, hipError_t e) {
+  g_create_err = std::string(what) + ": " + hipGetErrorString(e);
+  return RHIP_ERR_NO_DEVICE;
+}
 extern "C" int32_t rhip_ctx_create(int32_t device, rhip_ctx** out) {
   if (!out) return RHIP_ERR_ARG;
   *out = nullptr;
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RHIP_ERR_NO_DEVICE;
-  if (hipSetDevice(device) != hipSuccess) return RHIP_ERR_NO_DEVICE;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return create_fail("hipGetDeviceCount", e);
+  if (n <= 0 || device < 0 || device >= n) {
+    g_create_err = "no such HIP device (count=" + std::to_string(n) + ", asked " + std::to_string(device) + ")";
+    return RHIP_ERR_NO_DEVICE;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return create_fail("hipSetDevice", e);
   rhip_ctx* c = new rhip_ctx();
   c->device = device;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return RHIP_ERR_NO_DEVICE; }
-  c->n_cu = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RHIP_ERR_NO_DEVICE; }
+  int cus = 0;
+  e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (e != hipSuccess) { delete c; return create_fail("hipDeviceGetAttribute", e); }
+  c->n_cu = cus;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return create_fail("hipStreamCreateWithFlags", e); }
   c->stream = c->own_stream;
   *out = c;
   return RHIP_OK;
 }
 extern "C" void rhip_ctx_destroy(rhip_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->scratch) hipFree(ctx->scratch);
-  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 extern "C" int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* s) {
@@ -99,13 +112,13 @@ extern "C" int32_t rhip_sync(rhip_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return RHIP_OK;
 }
-extern "C" const char* rhip_last_error(rhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" const char* rhip_last_error(rhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len) {
   if (!ctx) return RHIP_ERR_ARG;
-  hipDeviceProp_t prop;
-  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (n_cu) *n_cu = ctx->n_cu;
   if (name && name_len) {
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     strncpy(name, prop.gcnArchName, name_len - 1);
     name[name_len - 1] = 0;
   }
@@ -633,7 +646,7 @@ extern "C" int32_t rhip_calibrate_mad(rhip_ctx* ctx, int32_t variant, uint32_t i
       case 4: hipLaunchKernelGGL(k_calibrate<4>, dim3(blocks), dim3(bs), 0, ctx->stream, iters, 12345u, sink); break;
       case 5: hipLaunchKernelGGL(k_calibrate<5>, dim3(blocks), dim3(bs), 0, ctx->stream, iters, 12345u, sink); break;
       case 6: hipLaunchKernelGGL(k_calibrate<6>, dim3(blocks), dim3(bs), 0, ctx->stream, iters, 12345u, sink); break;
-      default: hipFree(sink); return RHIP_ERR_ARG;
+      default: (void)hipFree(sink); return RHIP_ERR_ARG;
     }
     LAUNCH_CHECK(ctx, "k_calibrate");
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
@@ -644,9 +657,9 @@ extern "C" int32_t rhip_calibrate_mad(rhip_ctx* ctx, int32_t variant, uint32_t i
   *ms = t;
   const double per_iter = (variant == 5) ? 2.0 : 32.0;   // variant 5 counts Fp multiplications
   *n_ops = (double)blocks * bs * (double)iters * per_iter;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
   return RHIP_OK;
 }
 
@@ -796,9 +809,9 @@ extern "C" int32_t rhip_g2_table_create(rhip_ctx* ctx, const rhip_g2* b, rhip_g2
 extern "C" int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* b, rhip_gt_table** out) {
   return table_create<rhip_gt_table, GtM>(ctx, b, out, k_table_build_gt, 64);
 }
-extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) { if (t) { hipFree(t->dev); delete t; } }
-extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { hipFree(t->dev); delete t; } }
-extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { hipFree(t->dev); delete t; } }
+extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
+extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
+extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
 extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size_t n, const rhip_fr* k, rhip_g1* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;

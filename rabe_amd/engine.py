@@ -23,6 +23,24 @@ def lib_path():
 _LIB = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (same SONAME as /opt/rocm's); whichever is loaded first wins, and if ours came first torch would
+    later find "No HIP GPUs".  So when torch is installed, map its runtime before librabe_hip.so is
+    resolved -- import order then no longer matters (bench.py and smoke() need torch for streams and
+    torch.distributed in the same process)."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen the engine (works without a GPU; only rhip_ctx_create needs one)."""
     global _LIB
@@ -30,6 +48,7 @@ def load_library():
         path = lib_path()
         if not os.path.exists(path):
             raise EngineError("HIP engine not built: %s missing (run `python -m rabe_amd.build`)" % path)
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(path)
         lib.rhip_last_error.restype = ctypes.c_char_p
         _LIB = lib
@@ -68,8 +87,9 @@ class Engine:
         ctx = ctypes.c_void_p()
         rc = self.lib.rhip_ctx_create(ctypes.c_int32(device), ctypes.byref(ctx))
         if rc != 0:
-            raise EngineError("rhip_ctx_create(device=%d) failed with %d: no usable HIP device "
-                              "(the engine has no CPU fallback)" % (device, rc))
+            why = self.lib.rhip_last_error(None)
+            raise EngineError("rhip_ctx_create(device=%d) failed with %d [%s]: no usable HIP device "
+                              "(the engine has no CPU fallback)" % (device, rc, why.decode() if why else "?"))
         self.ctx = ctx
 
     def close(self):
