@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- AC17 CP-ABE encrypt+decrypt throughput on MI355X (BASELINE.json metric, config 2).
+
+One step = one pass of the hot path over one batch: `--batch` (4096) independent
+ac17::cp_encrypt + ac17::cp_decrypt group-arithmetic calls at `--attrs` (50) attributes, 16 distinct
+random binary AND/OR policies x 256 items, one public key, one secret key holding all attributes
+(SURVEY.md 8d config 2).  Inputs (randomness s0,s1 and the Gt message per item, policy tables, key
+material, selection lists) are resident in HBM before the timed region; ciphertexts go
+encrypt -> HBM -> decrypt without touching the host.  N>1: the batch definition is per rank
+(weak scaling), ranks are independent (no data-path collective); the only collective is the
+max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (integer-VALU bound: the
+path is modular big-integer arithmetic, neither HBM- nor MFMA-bound -- DESIGN.md section 5);
+`cpu_baseline` times the oracle's reference-order restatement on the host CPU (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
+    10857046999023057135944570762232829481370756359578518086990519993285655852781,
+    11559732032986387107991004021392285783925812861821192530917403151452391805634,
+    8495653923123431417604973247489272438418190587263600148770280649306958101930,
+    4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+# Algorithmic work, in Fp multiplications (1 Fp mul = 136 32x32 multiply-adds: 8-limb CIOS), per lane:
+#   SURVEY.md 8d constants (the "algorithmic minimum" the roofline is priced against) and the
+#   instrumented counts of this engine's own code (tools/count_muls.py).
+MAC_PER_FPMUL = 136
+SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
+SURVEY_MIXED_ADD_FPMUL = 11
+IMPL_MILLER_FPMUL = 9950            # tools/count_muls.py: miller_loop with Jacobian P
+IMPL_FINAL_EXP_FPMUL = 8940
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="items per step per GPU")
+    ap.add_argument("--attrs", type=int, default=50)
+    ap.add_argument("--policies", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="items for the CPU baseline (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+
+    from rabe_amd import Engine
+    from rabe_amd import engine as E
+    from rabe_amd import hostprep as hp
+
+    eng = Engine(local_rank)
+    n_cu, dev_name = eng.device_info()
+    stream = torch.cuda.Stream(device=local_rank)
+    eng.set_stream(stream.cuda_stream)
+
+    rnd = random.Random(args.seed * 1000003 + rank)
+    R = hp.R_ORDER
+    le = hp.fr_le
+
+    def rfr():
+        return rnd.randrange(1, R)
+
+    # ---------------------------------------------------------------- key material (ac17::setup, :141-182) via Level E ops
+    a = [rfr(), rfr()]
+    b = [rfr(), rfr()]
+    k = [rfr(), rfr(), rfr()]
+    g = eng.g1_mul([G1_GEN], [le(rfr())])[0]
+    h = eng.g2_mul([G2_GEN], [le(rfr())])[0]
+    h_a = eng.g2_mul([h, h], [le(a[0]), le(a[1])]) + [h]
+    g_k = eng.g1_mul([g] * 3, [le(x) for x in k])
+    e_gh = eng.pairing([g], [h])[0]
+    e_gh_ka = eng.gt_pow([e_gh] * 2, [le(k[i] * a[i] + k[2]) for i in range(2)])
+    pk = E.Ac17Pk(eng, g, h_a, e_gh_ka)
+
+    # ---------------------------------------------------------------- secret key with all attributes (ac17::cp_keygen, :191-264)
+    attrs = ["a%d" % (i + 1) for i in range(args.attrs)]
+    g_tab, h_tab = eng.g1_table(g), eng.g2_table(h)
+    H, H01 = hp.ac17_keygen_tables(attrs)
+    dk0, dk, dkp = eng.alloc(3 * 128), eng.alloc(len(attrs) * 3 * 64), eng.alloc(3 * 64)
+    E.ac17_keygen_dev(eng, g_tab, h_tab, eng.upload(b"".join(g_k)), eng.upload(b"".join(le(pow(x, R - 2, R)) for x in a)),
+                      eng.upload(b"".join(le(x) for x in b)), 1, len(attrs), eng.upload(H), eng.upload(H01),
+                      eng.upload(le(rfr()) + le(rfr())), eng.upload(b"".join(le(rfr()) for _ in attrs)), eng.upload(le(rfr())),
+                      dk0, dk, dkp)
+
+    # ---------------------------------------------------------------- policies (host: parse/MSP/prune are string work)
+    prnd = random.Random(args.seed)          # the same policies on every rank
+    trees = [hp.random_binary_tree(attrs, prnd) for _ in range(args.policies)]
+    tables, sels, pol_rows, nnz = [], [], [], []
+    for t in trees:
+        pi, A, z = hp.ac17_policy_table(t)
+        ok, ct_sel, sk_sel = hp.ac17_decrypt_selection(attrs, pi, t)
+        assert ok
+        tables.append(A)
+        sels.append((ct_sel, sk_sel))
+        pol_rows.append(len(pi))
+        nnz.append(z)
+    A_off = [0]
+    for r_ in pol_rows:
+        A_off.append(A_off[-1] + r_)
+    dA = eng.upload(b"".join(tables))
+
+    B = args.batch
+    item_pol = [i % args.policies for i in range(B)]
+    ct_row_off = [0]
+    ct_sel_all, sk_sel_all, ct_sel_off, sk_sel_off = [], [], [0], [0]
+    for i in range(B):
+        p_ = item_pol[i]
+        ct_row_off.append(ct_row_off[-1] + pol_rows[p_])
+        ct_sel_all += sels[p_][0]
+        sk_sel_all += sels[p_][1]
+        ct_sel_off.append(len(ct_sel_all))
+        sk_sel_off.append(len(sk_sel_all))
+    total_rows = ct_row_off[-1]
+    d_item_A_off = eng.upload_u32([A_off[p_] for p_ in item_pol])
+    d_ct_row_off = eng.upload_u32(ct_row_off)
+    d_ct_sel, d_ct_sel_off = eng.upload_u32(ct_sel_all), eng.upload_u32(ct_sel_off)
+    d_sk_sel, d_sk_sel_off = eng.upload_u32(sk_sel_all), eng.upload_u32(sk_sel_off)
+    d_sk_idx = eng.upload_u32([0] * B)
+    d_sk_row_off = eng.upload_u32([0, len(attrs)])
+
+    # per-item randomness: s0, s1 and the Gt message msg = e_gh^rho (computed on the GPU, untimed)
+    ds = eng.upload(b"".join(le(rfr()) for _ in range(2 * B)))
+    e_tab = eng.gt_table(e_gh)
+    dmsg = eng.alloc(B * 384)
+    drho = eng.upload(b"".join(le(rfr()) for _ in range(B)))
+    eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, e_tab.h, E._sz(B), drho.ptr, dmsg.ptr))
+
+    dc0, dc, dcp, dout = eng.alloc(B * 3 * 128), eng.alloc(total_rows * 3 * 64), eng.alloc(B * 384), eng.alloc(B * 384)
+
+    def step():
+        E.ac17_encrypt_dev(eng, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds, dmsg, dc0, dc, dcp)
+        E.ac17_decrypt_dev(eng, B, dc0, dc, d_ct_row_off, dcp, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
+                           d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, dout)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---------------------------------------------------------------- timed region
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------------------------------------------------------- size-independent correctness property on the FULL batch:
+    # decrypt(encrypt(msg)) == msg, bit for bit, for every item (oracle parity at small sizes is in tests/)
+    ok = eng.download(dout) == eng.download(dmsg)
+    if world > 1:
+        f = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        ok = bool(f.item())
+
+    value = world * B * args.steps / elapsed
+    result = {
+        "metric": "ABE ops/sec (AC17 CP-ABE encrypt+decrypt)", "value": round(value, 2), "unit": "ops/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fp/Fr Montgomery, 8x32)",
+        "data": "synthetic", "roundtrip_bit_exact": ok,
+        "config": {"workload": "AC17 CP-ABE, %d-attribute random binary AND/OR MSP policies (%d distinct), batch %d encrypt+decrypt per GPU"
+                               % (args.attrs, args.policies, B),
+                   "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": total_rows // B,
+                   "pruned_leaves_avg": round(len(ct_sel_all) / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
+                   "parallelism": "batch-sharded x%d (no data-path collective)" % world, "device": dev_name},
+    }
+
+    if rank == 0:
+        # ------------------------------------------------------------ roofline of the dominant kernel (HIP events on the launch stream)
+        eng.timing(True)
+        eng.timing_read()
+        reps = 3
+        for _ in range(reps):
+            step()
+        tim = eng.timing_read()
+        eng.timing(False)
+        per_kernel = {kname: ms / cnt for kname, (ms, cnt) in tim.items()}
+        dom = max(per_kernel, key=lambda kk: per_kernel[kk])
+        dom_ms = per_kernel[dom]
+        # peak: dependent-free v_mad_u64_u32 issue rate measured live on this chip
+        ms_c, ops_c = eng.calibrate(0, 20000)
+        peak_tmac = ops_c / (ms_c * 1e-3) / 1e12
+        m_avg = len(ct_sel_all) / B
+        lanes = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_enc_rows": total_rows,
+                 "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
+        alg = {"k_ac17_dec_miller": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL,
+               "k_final_exp": 9000 + 6 * 54, "k_ac17_enc_rows": 3 * 352, "k_ac17_enc_c0": 1056, "k_ac17_enc_cp": 2 * 1700 + 54}
+        impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54}
+        macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
+        achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # HBM side (reported, not binding): algorithmic bytes of the whole step
+        alg_bytes = B * (2 * 32 + 384) + total_rows * 192 * 2 + B * (384 + 384) * 2 + len(ct_sel_all) * 4 * 2 + B * 384
+        result["roofline"] = {
+            "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
+            "kernel_ms": round(dom_ms, 4), "achieved": round(achieved, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
+            "frac": round(achieved / peak_tmac, 4) if peak_tmac else None,
+            "work": "algorithmic Fp-muls/lane (SURVEY 8d) x 136 MAC32 x lanes = %.3e MAC32 per launch" % macs,
+            "achieved_impl_count": round(lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL / (dom_ms * 1e-3) / 1e12, 4)
+            if dom_ms > 0 else None,
+            "traffic": None,
+            "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
+                    "peak_GBps": 8000},
+            "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
+        }
+        # ------------------------------------------------------------ CPU baseline (oracle = reference-order restatement; checker only)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, trees[0])
+            except Exception as ex:  # the GPU number must still be reported
+                result["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(result), flush=True)
+
+    pk.destroy()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, tree):
+    """Times the oracle (reference operation order) on the host CPU on a bounded sample of the same workload."""
+    from rabe_amd import hostprep as hp
+    policy = hp.to_json(tree)
+    try:
+        from oracle import cport
+        have_c = cport.available()
+    except Exception:
+        have_c = False
+    if have_c:
+        n = args.cpu_sample or 4
+        t0 = time.perf_counter()
+        cport.ac17_encdec(policy, args.attrs, n, seed=args.seed)
+        dt = time.perf_counter() - t0
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+                "sample": "%d AC17 encrypt+decrypt at %d attributes, C restatement in reference operation order "
+                          "(oracle/c), single thread" % (n, args.attrs)}
+    # pure-Python big-int oracle: one item at a reduced attribute count scaled linearly in the encrypt part
+    from oracle import bn254 as bn
+    from oracle import policy as pol
+    from oracle import schemes as sch
+    from oracle.tape import SeededRng
+    n_attr = min(args.attrs, 6)
+    names = ["a%d" % (i + 1) for i in range(n_attr)]
+    rnd = random.Random(args.seed)
+    sub = hp.random_binary_tree(names, rnd)
+    rng = SeededRng(args.seed)
+    pk, msk = sch.ac17_setup(rng)
+    sk = sch.ac17_cp_keygen(msk, names, rng)
+    msg = bn.gt_pow(pk["e_gh_ka"][0], 12345)
+    t0 = time.perf_counter()
+    ct = sch.ac17_cp_encrypt(pk, hp.to_json(sub), pol.JSON, rng, msg)
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = sch.ac17_cp_decrypt(sk, ct)
+    t_dec = time.perf_counter() - t0
+    assert out == msg
+    est = t_enc * args.attrs / n_attr + t_dec
+    return {"value": round(1.0 / est, 6), "unit": "ops/s", "cores": 1, "kind": "port",
+            "sample": "pure-Python big-int oracle (reference operation order): 1 encrypt+decrypt at %d attributes measured "
+                      "(%.1f s + %.1f s), encrypt scaled linearly to %d attributes" % (n_attr, t_enc, t_dec, args.attrs)}
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,10 @@ void rhip_ctx_destroy(rhip_ctx* ctx);
 int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* hip_stream);
 int32_t rhip_sync(rhip_ctx* ctx);
 const char* rhip_last_error(rhip_ctx* ctx);
+/* per-kernel timing with HIP events on the launch stream (measurement only; off by default).
+ * rhip_ctx_timing_read drains the record as "kernel_name total_ms launches\n" lines. */
+int32_t rhip_ctx_timing(rhip_ctx* ctx, int32_t enable);
+int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len);
 /* number of compute units / device name of the context's GPU */
 int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len);
 
@@ -124,17 +128,20 @@ void rhip_ac17_pk_destroy(rhip_ac17_pk* pk);
 /* Group arithmetic of n_items calls of ac17::cp_encrypt (src/schemes/ac17/mod.rs:274-376).
  * The host has parsed each policy and built its MSP; per distinct policy it supplies the Fr table
  *   A[row][l][t] = h(pi_row || l || t) + sum_j M[row][j] * h("0" || (j+1) || l || t)   (mod r)
- * (h = Fr::from_slice(SHA3-256), src/utils/hash/mod.rs:16) for row < n_rows, l < 3, t < 2.
- * All items of one call share that policy.  Per item i the explicit randomness is s[i][0..2)
- * (drawn at :292) and the Gt `msg` (drawn at :362).  Outputs, per item:
+ * (h = Fr::from_slice(SHA3-256), src/utils/hash/mod.rs:16) for row < n_rows(policy), l < 3, t < 2; the
+ * tables of all policies used by the batch are concatenated in dev_A and item i points at the first row
+ * of its policy with item_A_off[i].  Ciphertext i owns output rows [ct_row_off[i], ct_row_off[i+1])
+ * (n_rows of its policy).  Per item the explicit randomness is s[i][0..2) (drawn at :292) and the Gt
+ * `msg` (drawn at :362).  Outputs:
  *   c_0[i][0..3)  = (h_a0*s0, h_a1*s1, h_a2*(s0+s1))                       (:297-302)
- *   c[i][row][l]  = g * (s0*A[row][l][0] + s1*A[row][l][1])                (:330-356)
+ *   c[row][l]     = g * (s0*A[a][l][0] + s1*A[a][l][1])                    (:330-356)
  *   c_p[i]        = e_gh_ka0^s0 * e_gh_ka1^s1 * msg                        (:357-368)
  */
-int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, size_t n_rows,
-                                   const rhip_fr* dev_A /*[n_rows][3][2]*/, const rhip_fr* dev_s /*[n_items][2]*/,
-                                   const rhip_gt* dev_msg /*[n_items]*/, rhip_g2* dev_c0 /*[n_items][3]*/,
-                                   rhip_g1* dev_c /*[n_items][n_rows][3]*/, rhip_gt* dev_cp /*[n_items]*/);
+int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items,
+                                   const rhip_fr* dev_A /*[policy rows][3][2]*/, const uint32_t* dev_item_A_off /*[n_items]*/,
+                                   const uint32_t* dev_ct_row_off /*[n_items+1]*/, size_t total_rows,
+                                   const rhip_fr* dev_s /*[n_items][2]*/, const rhip_gt* dev_msg /*[n_items]*/,
+                                   rhip_g2* dev_c0 /*[n_items][3]*/, rhip_g1* dev_c /*[total_rows][3]*/, rhip_gt* dev_cp /*[n_items]*/);
 
 /* Group arithmetic of n_items calls of ac17::cp_keygen (src/schemes/ac17/mod.rs:191-264).
  * Host supplies per attribute y the hashes H[y][l][t] = h(y||l||t) and, once, H01[l][t] = h("01"||l||t);

@@ -23,6 +23,10 @@
 #define RB_FN __host__ __device__ __attribute__((noinline))
 #define RB_HD_NOINLINE RB_FN
 
+#if defined(RB_COUNT_MULS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" unsigned long long rb_mul_counter;
+#endif
+
 namespace rabe { namespace bn254 {
 
 struct FpParams {
@@ -184,9 +188,18 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
   cond_sub_mod<M>(r, 0);
 }
 
+// Host-only instrumentation for the roofline's algorithmic work count (tests/hostsim builds with
+// -DRB_COUNT_MULS; never defined for device code): every Montgomery multiplication bumps a counter.
+#if defined(RB_COUNT_MULS) && !defined(__HIP_DEVICE_COMPILE__)
+#define RB_COUNT_ONE_MUL() (++::rb_mul_counter)
+#else
+#define RB_COUNT_ONE_MUL() ((void)0)
+#endif
+
 // inlined form (used inside the Fp2-level functions, which are themselves real functions)
 template <class M>
 RB_HD Mont<M> mul_inl(const Mont<M>& a, const Mont<M>& b) {
+  RB_COUNT_ONE_MUL();
   uint32_t t[8];
   mont_mul_raw<M>(t, a.v, b.v);
   Mont<M> r;

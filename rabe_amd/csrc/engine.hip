@@ -33,7 +33,30 @@ struct rhip_ctx {
   // grow-only device scratch (Miller values between k_miller and k_final_exp)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
+  bool timing = false;
+  struct Pending { std::string name; hipEvent_t e0, e1; };
+  std::vector<Pending> pending;
 };
+static void ktime_begin(rhip_ctx* ctx, const char* name) {
+  if (!ctx->timing) return;
+  rhip_ctx::Pending p;
+  p.name = name;
+  if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+  (void)hipEventRecord(p.e0, ctx->stream);
+  ctx->pending.push_back(p);
+}
+static void ktime_end(rhip_ctx* ctx) {
+  if (!ctx->timing || ctx->pending.empty()) return;
+  (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
+}
+#define KLAUNCH(ctx, NAME, ...)            \
+  do {                                     \
+    ktime_begin(ctx, NAME);                \
+    hipLaunchKernelGGL(__VA_ARGS__);       \
+    ktime_end(ctx);                        \
+    LAUNCH_CHECK(ctx, NAME);               \
+  } while (0)
 
 static int32_t fail(rhip_ctx* ctx, hipError_t e, const char* what) {
   if (ctx) {
@@ -110,6 +133,41 @@ extern "C" int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* s) {
 extern "C" int32_t rhip_sync(rhip_ctx* ctx) {
   if (!ctx) return RHIP_ERR_ARG;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_ctx_timing(rhip_ctx* ctx, int32_t enable) {
+  if (!ctx) return RHIP_ERR_ARG;
+  ctx->timing = enable != 0;
+  return RHIP_OK;
+}
+// Drains the recorded launches: writes "kernel_name total_ms launches\n" lines into buf.
+extern "C" int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len) {
+  if (!ctx || !buf || !len) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<std::string> names;
+  std::vector<double> total;
+  std::vector<long> count;
+  for (auto& p : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      size_t k = 0;
+      for (; k < names.size(); k++) if (names[k] == p.name) break;
+      if (k == names.size()) { names.push_back(p.name); total.push_back(0); count.push_back(0); }
+      total[k] += ms;
+      count[k] += 1;
+    }
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  ctx->pending.clear();
+  std::string out;
+  for (size_t k = 0; k < names.size(); k++) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %.6f %ld\n", names[k].c_str(), total[k], count[k]);
+    out += line;
+  }
+  strncpy(buf, out.c_str(), len - 1);
+  buf[len - 1] = 0;
   return RHIP_OK;
 }
 extern "C" const char* rhip_last_error(rhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -444,17 +502,26 @@ __device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac
   store_g1(out[2].l, ic ? aff_inf<Fp>() : jac_to_aff_with_zinv(c, zc_inv));
 }
 
-// one lane per (item, row): c[item][row][l] = g * (s0*A[row][l][0] + s1*A[row][l][1]), l = 0..2
-__global__ void __launch_bounds__(256) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t n_rows, const rhip_fr* A,
-                                                       const rhip_fr* s, rhip_g1* c) {
+// one lane per ciphertext row (items may carry different policies):
+//   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
+//   row_off[i] <= row < row_off[i+1] and a = item_A_off[item] + (row - row_off[item]).
+__global__ void __launch_bounds__(256) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
+                                                       const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_items * n_rows) return;
-  size_t item = t / n_rows, row = t % n_rows;
+  if (t >= total_rows) return;
+  // binary search for the item owning row t (row_off is non-decreasing, row_off[n_items] = total_rows)
+  size_t lo = 0, hi = n_items;
+  while (hi - lo > 1) {
+    size_t mid = (lo + hi) >> 1;
+    if (row_off[mid] <= t) lo = mid; else hi = mid;
+  }
+  const size_t item = lo;
+  const size_t arow = (size_t)item_A_off[item] + (t - row_off[item]);
   Fr s0 = load_fr(s[2 * item].l), s1 = load_fr(s[2 * item + 1].l);
   G1Jac pt[3];
 #pragma unroll 1
   for (int l = 0; l < 3; l++) {
-    Fr a0 = load_fr(A[(row * 3 + l) * 2].l), a1 = load_fr(A[(row * 3 + l) * 2 + 1].l);
+    Fr a0 = load_fr(A[(arow * 3 + l) * 2].l), a1 = load_fr(A[(arow * 3 + l) * 2 + 1].l);
     Fr k = add(mul(s0, a0), mul(s1, a1));
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
@@ -671,92 +738,79 @@ extern "C" int32_t rhip_fr_op(rhip_ctx* ctx, int32_t op, size_t n, const rhip_fr
   NEED(ctx);
   if (op < 0 || op > RHIP_FR_INV) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_fr_op, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, n, a, b, out);
-  LAUNCH_CHECK(ctx, "k_fr_op");
+  KLAUNCH(ctx, "k_fr_op", k_fr_op, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, n, a, b, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_fr_from_be32_reduce(rhip_ctx* ctx, size_t n, const uint8_t* dig, rhip_fr* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_fr_from_be32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, dig, out);
-  LAUNCH_CHECK(ctx, "k_fr_from_be32");
+  KLAUNCH(ctx, "k_fr_from_be32", k_fr_from_be32, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, dig, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g1_add(rhip_ctx* ctx, size_t n, const rhip_g1* a, const rhip_g1* b, rhip_g1* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g1_add, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, a, b, out, 0);
-  LAUNCH_CHECK(ctx, "k_g1_add");
+  KLAUNCH(ctx, "k_g1_add", k_g1_add, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, a, b, out, 0);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g1_neg(rhip_ctx* ctx, size_t n, const rhip_g1* a, rhip_g1* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g1_neg, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, a, out);
-  LAUNCH_CHECK(ctx, "k_g1_neg");
+  KLAUNCH(ctx, "k_g1_neg", k_g1_neg, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, a, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g1_mul(rhip_ctx* ctx, size_t n, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g1_mul, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, p, k, out);
-  LAUNCH_CHECK(ctx, "k_g1_mul");
+  KLAUNCH(ctx, "k_g1_mul", k_g1_mul, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, p, k, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g1_on_curve(rhip_ctx* ctx, size_t n, const rhip_g1* p, uint32_t* ok) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g1_on_curve, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, p, ok);
-  LAUNCH_CHECK(ctx, "k_g1_on_curve");
+  KLAUNCH(ctx, "k_g1_on_curve", k_g1_on_curve, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, p, ok);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_add(rhip_ctx* ctx, size_t n, const rhip_g2* a, const rhip_g2* b, rhip_g2* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g2_add, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, a, b, out);
-  LAUNCH_CHECK(ctx, "k_g2_add");
+  KLAUNCH(ctx, "k_g2_add", k_g2_add, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, a, b, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_neg(rhip_ctx* ctx, size_t n, const rhip_g2* a, rhip_g2* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g2_neg, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, a, out);
-  LAUNCH_CHECK(ctx, "k_g2_neg");
+  KLAUNCH(ctx, "k_g2_neg", k_g2_neg, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, a, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_mul(rhip_ctx* ctx, size_t n, const rhip_g2* p, const rhip_fr* k, rhip_g2* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g2_mul, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, k, out);
-  LAUNCH_CHECK(ctx, "k_g2_mul");
+  KLAUNCH(ctx, "k_g2_mul", k_g2_mul, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, k, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_on_curve(rhip_ctx* ctx, size_t n, const rhip_g2* p, uint32_t* ok) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_g2_on_curve, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok);
-  LAUNCH_CHECK(ctx, "k_g2_on_curve");
+  KLAUNCH(ctx, "k_g2_on_curve", k_g2_on_curve, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* a, const rhip_gt* b, rhip_gt* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_gt_mul, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, b, out);
-  LAUNCH_CHECK(ctx, "k_gt_mul");
+  KLAUNCH(ctx, "k_gt_mul", k_gt_mul, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, b, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_inv(rhip_ctx* ctx, size_t n, const rhip_gt* a, rhip_gt* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_gt_inv, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, out);
-  LAUNCH_CHECK(ctx, "k_gt_inv");
+  KLAUNCH(ctx, "k_gt_inv", k_gt_inv, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* a, const rhip_fr* k, rhip_gt* out) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_gt_pow, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, k, out);
-  LAUNCH_CHECK(ctx, "k_gt_pow");
+  KLAUNCH(ctx, "k_gt_pow", k_gt_pow, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, k, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* off, size_t n_pairs, const rhip_g1* p,
@@ -767,12 +821,10 @@ extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uin
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
   if (n_pairs) {
-    hipLaunchKernelGGL(k_miller, dim3(blocks_for(n_pairs, 64)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
-    LAUNCH_CHECK(ctx, "k_miller");
+    KLAUNCH(ctx, "k_miller", k_miller, dim3(blocks_for(n_pairs, 64)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
   }
-  hipLaunchKernelGGL(k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, 1u, (const GtM*)mill,
+  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, 1u, (const GtM*)mill,
                      (const rhip_gt*)nullptr, out);
-  LAUNCH_CHECK(ctx, "k_final_exp");
   return RHIP_OK;
 }
 extern "C" int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* p, const rhip_g2* q, rhip_gt* out) {
@@ -790,8 +842,7 @@ static int32_t table_create(rhip_ctx* ctx, const BASE* host_base, TBL** out, KER
   HIP_TRY(ctx, hipMalloc((void**)&dbase, sizeof(BASE)));
   HIP_TRY(ctx, hipMalloc((void**)&dev, sizeof(ENTRY) * TBL_WINDOWS * TBL_DIGITS));
   HIP_TRY(ctx, hipMemcpyAsync(dbase, host_base, sizeof(BASE), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3(blocks_for(TBL_WINDOWS * TBL_DIGITS, bs)), dim3(bs), 0, ctx->stream, (const BASE*)dbase, dev);
-  LAUNCH_CHECK(ctx, "k_table_build");
+  KLAUNCH(ctx, "k_table_build", kern, dim3(blocks_for(TBL_WINDOWS * TBL_DIGITS, bs)), dim3(bs), 0, ctx->stream, (const BASE*)dbase, dev);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipFree(dbase));
   TBL* t = new TBL();
@@ -816,24 +867,21 @@ extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_table_mul_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const G1M*)t->dev, n, k, out);
-  LAUNCH_CHECK(ctx, "k_table_mul_g1");
+  KLAUNCH(ctx, "k_table_mul_g1", k_table_mul_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const G1M*)t->dev, n, k, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_table_mul(rhip_ctx* ctx, const rhip_g2_table* t, size_t n, const rhip_fr* k, rhip_g2* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_table_mul_g2, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, (const G2M*)t->dev, n, k, out);
-  LAUNCH_CHECK(ctx, "k_table_mul_g2");
+  KLAUNCH(ctx, "k_table_mul_g2", k_table_mul_g2, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, (const G2M*)t->dev, n, k, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_table_pow(rhip_ctx* ctx, const rhip_gt_table* t, size_t n, const rhip_fr* k, rhip_gt* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  hipLaunchKernelGGL(k_table_pow_gt, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, (const GtM*)t->dev, n, k, out);
-  LAUNCH_CHECK(ctx, "k_table_pow_gt");
+  KLAUNCH(ctx, "k_table_pow_gt", k_table_pow_gt, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, (const GtM*)t->dev, n, k, out);
   return RHIP_OK;
 }
 
@@ -861,22 +909,20 @@ extern "C" int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* g, const rh
   *out = pk;
   return RHIP_OK;
 }
-extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, size_t n_rows, const rhip_fr* A,
+extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* A,
+                                              const uint32_t* item_A_off, const uint32_t* ct_row_off, size_t total_rows,
                                               const rhip_fr* s, const rhip_gt* msg, rhip_g2* c0, rhip_g1* c, rhip_gt* cp) {
   NEED(ctx);
   if (!pk) return RHIP_ERR_ARG;
   if (!n_items) return RHIP_OK;
-  if (n_rows) {
-    hipLaunchKernelGGL(k_ac17_enc_rows, dim3(blocks_for(n_items * n_rows, 256)), dim3(256), 0, ctx->stream, (const G1M*)pk->g->dev,
-                       n_items, n_rows, A, s, c);
-    LAUNCH_CHECK(ctx, "k_ac17_enc_rows");
+  if (total_rows) {
+    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, (const G1M*)pk->g->dev,
+                       n_items, total_rows, A, item_A_off, ct_row_off, s, c);
   }
-  hipLaunchKernelGGL(k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
+  KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
                      (const G2M*)pk->h_a[1]->dev, (const G2M*)pk->h_a[2]->dev, n_items, s, c0);
-  LAUNCH_CHECK(ctx, "k_ac17_enc_c0");
-  hipLaunchKernelGGL(k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, (const GtM*)pk->e[0]->dev,
+  KLAUNCH(ctx, "k_ac17_enc_cp", k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, (const GtM*)pk->e[0]->dev,
                      (const GtM*)pk->e[1]->dev, n_items, s, msg, cp);
-  LAUNCH_CHECK(ctx, "k_ac17_enc_cp");
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table* g_table, const rhip_g2_table* h_table, const rhip_g1* g_k,
@@ -886,12 +932,10 @@ extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table*
   NEED(ctx);
   if (!g_table || !h_table) return RHIP_ERR_ARG;
   if (!n_items) return RHIP_OK;
-  hipLaunchKernelGGL(k_ac17_keygen_rows, dim3(blocks_for(n_items * (n_attrs + 1), 256)), dim3(256), 0, ctx->stream,
+  KLAUNCH(ctx, "k_ac17_keygen_rows", k_ac17_keygen_rows, dim3(blocks_for(n_items * (n_attrs + 1), 256)), dim3(256), 0, ctx->stream,
                      (const G1M*)g_table->dev, g_k, a_inv, b, n_items, n_attrs, H, H01, r, sigma, sigma_p, k, kp);
-  LAUNCH_CHECK(ctx, "k_ac17_keygen_rows");
-  hipLaunchKernelGGL(k_ac17_keygen_k0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)h_table->dev, b,
+  KLAUNCH(ctx, "k_ac17_keygen_k0", k_ac17_keygen_k0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)h_table->dev, b,
                      n_items, r, k0);
-  LAUNCH_CHECK(ctx, "k_ac17_keygen_k0");
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
@@ -904,11 +948,9 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
   int32_t rc = ensure_scratch(ctx, n_items * 6 * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
-  hipLaunchKernelGGL(k_ac17_dec_miller, dim3(blocks_for(n_items * 6, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
+  KLAUNCH(ctx, "k_ac17_dec_miller", k_ac17_dec_miller, dim3(blocks_for(n_items * 6, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
                      sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
-  LAUNCH_CHECK(ctx, "k_ac17_dec_miller");
-  hipLaunchKernelGGL(k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 6u,
+  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 6u,
                      (const GtM*)mill, ct_cp, out);
-  LAUNCH_CHECK(ctx, "k_final_exp");
   return RHIP_OK;
 }

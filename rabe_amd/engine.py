@@ -129,6 +129,19 @@ class Engine:
     def set_stream(self, hip_stream_ptr):
         self._check(self.lib.rhip_ctx_set_stream(self.ctx, ctypes.c_void_p(hip_stream_ptr)))
 
+    def timing(self, enable):
+        self._check(self.lib.rhip_ctx_timing(self.ctx, ctypes.c_int32(1 if enable else 0)))
+
+    def timing_read(self):
+        """{kernel_name: (total_ms, launches)} since the last read."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.rhip_ctx_timing_read(self.ctx, buf, ctypes.c_size_t(len(buf))))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt = line.split()
+            out[name] = (float(ms), int(cnt))
+        return out
+
     def device_info(self):
         n = ctypes.c_int32()
         name = ctypes.create_string_buffer(128)
@@ -235,9 +248,9 @@ def _sz(n):
     return ctypes.c_size_t(int(n))
 
 
-def ac17_encrypt_dev(eng, pk, n_items, n_rows, dA, ds, dmsg, dc0, dc, dcp):
-    eng._check(eng.lib.rhip_ac17_cp_encrypt_batch(eng.ctx, pk.h, _sz(n_items), _sz(n_rows), dA.ptr, ds.ptr, dmsg.ptr,
-                                                  dc0.ptr, dc.ptr, dcp.ptr))
+def ac17_encrypt_dev(eng, pk, n_items, dA, ditem_A_off, dct_row_off, total_rows, ds, dmsg, dc0, dc, dcp):
+    eng._check(eng.lib.rhip_ac17_cp_encrypt_batch(eng.ctx, pk.h, _sz(n_items), dA.ptr, ditem_A_off.ptr, dct_row_off.ptr,
+                                                  _sz(total_rows), ds.ptr, dmsg.ptr, dc0.ptr, dc.ptr, dcp.ptr))
 
 
 def ac17_keygen_dev(eng, g_table, h_table, dgk, dainv, db, n_items, n_attrs, dH, dH01, dr, dsigma, dsigmap, dk0, dk, dkp):

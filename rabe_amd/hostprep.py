@@ -1,0 +1,151 @@
+"""Host-side preparation of engine inputs (strings / integers only -- no group arithmetic).
+
+What the reference does on the host before and after its group loops, restated for the batch ABI:
+  policy tree -> LSSS matrix          src/utils/policy/msp.rs:78-147 (Lewko-Waters, binary AND)
+  label -> Fr                         src/utils/hash/mod.rs:23-31 (SHA3-256, big-endian, mod r)
+  satisfiable? / pruned leaf list     src/utils/tools/mod.rs:31-61, src/utils/secretsharing/mod.rs:143-199
+  AC17 per-policy Fr table            SURVEY.md Appendix B.3 (pre-combination of ac17/mod.rs:305-348)
+Policies here are already-parsed trees: ("leaf", name) | ("and", [l, r]) | ("or", [children...]);
+`to_json` renders the reference's JSON policy language (src/json.policy.pest) for the same tree.
+The full text parsers live in the C++ host layer (rabe_amd/csrc/host/) -- this module is the
+benchmark's / tests' plumbing and does not import oracle/.
+"""
+import hashlib
+
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def h_fr(label):
+    return int.from_bytes(hashlib.sha3_256(label.encode("utf-8")).digest(), "big") % R_ORDER
+
+
+def fr_le(x):
+    return int(x % R_ORDER).to_bytes(32, "little")
+
+
+def to_json(tree):
+    if tree[0] == "leaf":
+        return '{"name": "%s"}' % tree[1]
+    return '{"name": "%s", "children": [%s]}' % (tree[0], ", ".join(to_json(c) for c in tree[1]))
+
+
+def leaves(tree):
+    if tree[0] == "leaf":
+        return [tree[1]]
+    out = []
+    for c in tree[1]:
+        out += leaves(c)
+    return out
+
+
+def lw_msp(tree):
+    """(m, pi, c): rows sorted by attribute name (stable), padded to c columns (msp.rs:78-147)."""
+    m, pi = [], []
+    c = [1]
+
+    def lw(node, v):
+        if node[0] == "leaf":
+            m.insert(0, list(v))
+            pi.insert(0, node[1])
+            return
+        ch = node[1]
+        if len(ch) < 2:
+            raise ValueError("lw: policy with just a single attribute is not allowed")
+        if node[0] == "or":
+            for x in ch:
+                lw(x, v)
+            return
+        if len(ch) != 2:
+            raise ValueError("lw: Invalid policy. Number of arguments under AND != 2")
+        right = list(v) + [0] * (c[0] - len(v)) + [1]
+        left = [0] * c[0] + [-1]
+        c[0] += 1
+        lw(ch[0], right)
+        lw(ch[1], left)
+
+    lw(tree, [1])
+    m = [r + [0] * (c[0] - len(r)) for r in m]
+    order = sorted(range(len(pi)), key=lambda i: pi[i])
+    return [m[i] for i in order], [pi[i] for i in order], c[0]
+
+
+def ac17_policy_table(tree):
+    """(pi, A_bytes, nnz): A[row][l][t] = h(pi_row||l||t) + sum_j M[row][j] h("0"||(j+1)||l||t) mod r."""
+    m, pi, c = lw_msp(tree)
+    cols = [[[h_fr("0" + str(j + 1) + str(l) + str(t)) for t in range(2)] for l in range(3)] for j in range(c)]
+    out = []
+    nnz = 0
+    for i, row in enumerate(m):
+        nnz += sum(1 for x in row if x)
+        for l in range(3):
+            for t in range(2):
+                v = h_fr(pi[i] + str(l) + str(t))
+                for j, mij in enumerate(row):
+                    if mij:
+                        v += mij * cols[j][l][t]
+                out.append(fr_le(v))
+    return pi, b"".join(out), nnz
+
+
+def ac17_keygen_tables(attributes):
+    H = b"".join(fr_le(h_fr(a + str(l) + str(t))) for a in attributes for l in range(3) for t in range(2))
+    H01 = b"".join(fr_le(h_fr("01" + str(l) + str(t))) for l in range(3) for t in range(2))
+    return H, H01
+
+
+def satisfies(attrs, tree):
+    if not attrs:
+        return False
+    if tree[0] == "leaf":
+        return tree[1] in attrs
+    if tree[0] == "and":
+        ok = True
+        for c in tree[1]:
+            ok &= satisfies(attrs, c)
+        return ok
+    ok = False
+    for c in tree[1]:
+        ok |= satisfies(attrs, c)
+    return ok
+
+
+def pruned(attrs, tree):
+    """(match, [leaf names]) -- all children of AND, the first satisfying child of OR."""
+    if tree[0] == "leaf":
+        return (True, [tree[1]]) if tree[1] in attrs else (False, [])
+    if tree[0] == "and":
+        ok, acc = True, []
+        for c in tree[1]:
+            f, l = pruned(attrs, c)
+            ok = ok and f
+            if ok:
+                acc += l
+        return (ok, acc if ok else [])
+    for c in tree[1]:
+        f, l = pruned(attrs, c)
+        if f:
+            return True, l
+    return False, []
+
+
+def ac17_decrypt_selection(sk_attrs, ct_row_names, tree):
+    """Index lists walked by the name-matching loops of ac17/mod.rs:403-414."""
+    if not satisfies(sk_attrs, tree):
+        return False, [], []
+    ok, lst = pruned(sk_attrs, tree)
+    if not ok:
+        return False, [], []
+    ct_sel, sk_sel = [], []
+    for name in lst:
+        ct_sel += [i for i, n in enumerate(ct_row_names) if n == name]
+        sk_sel += [i for i, n in enumerate(sk_attrs) if n == name]
+    return True, ct_sel, sk_sel
+
+
+def random_binary_tree(names, rnd, p_and=0.5):
+    """Random binary AND/OR tree over the given leaves in order."""
+    if len(names) == 1:
+        return ("leaf", names[0])
+    k = rnd.randrange(1, len(names))
+    op = "and" if rnd.random() < p_and else "or"
+    return (op, [random_binary_tree(names[:k], rnd, p_and), random_binary_tree(names[k:], rnd, p_and)])

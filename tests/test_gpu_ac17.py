@@ -39,7 +39,8 @@ def gpu_encrypt(eng, E, dpk, policy, lang, s_list, msgs):
     ds = eng.upload(b"".join(host.le(s0) + host.le(s1) for s0, s1 in s_list))
     dmsg = eng.upload(b"".join(bn.gt_to_le(m) for m in msgs))
     dc0, dc, dcp = eng.alloc(n_items * 3 * 128), eng.alloc(n_items * n_rows * 3 * 64), eng.alloc(n_items * 384)
-    E.ac17_encrypt_dev(eng, dpk, n_items, n_rows, dA, ds, dmsg, dc0, dc, dcp)
+    E.ac17_encrypt_dev(eng, dpk, n_items, dA, eng.upload_u32([0] * n_items), eng.upload_u32([i * n_rows for i in range(n_items + 1)]),
+                       n_items * n_rows, ds, dmsg, dc0, dc, dcp)
     return pi, eng.download(dc0), eng.download(dc), eng.download(dcp), (dc0, dc, dcp)
 
 
