@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the oracle (oracle/*.py).
+
+The reference cannot run here (Rust, and its arithmetic crate rabe-bn is not vendored), and it holds no
+known-answer vectors for group values, so these vectors pin the ORACLE: inputs (keys,
+policy strings, explicit-randomness tapes) and every output element in the canonical wire format of
+include/rabe_hip.h, hex-encoded.  The policy strings and attribute sets are the ones the reference's own
+tests use (ac17/mod.rs:756-809, bsw/mod.rs:344-602, lsw/mod.rs:300-374, aw11/mod.rs:400-561).
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import bn254 as bn  # noqa: E402
+from oracle import policy as pol  # noqa: E402
+from oracle import schemes as sch  # noqa: E402
+from oracle.tape import ListRng, SeededRng  # noqa: E402
+
+
+def hx(b):
+    return b.hex()
+
+
+def g1(p): return hx(bn.g1_to_le(p))
+def g2(p): return hx(bn.g2_to_le(p))
+def gt(x): return hx(bn.gt_to_le(x))
+def fr(x): return hx(bn.fr_to_le(x))
+
+
+class RecRng(SeededRng):
+    """SeededRng whose tape is recorded so the vectors carry the explicit randomness."""
+
+
+def primitives():
+    rng = SeededRng(100)
+    out = {"fp_mul": [], "fr_inv": [], "g1_mul": [], "g2_mul": [], "g1_add": [], "pairing": [], "gt_pow": [], "fr_from_digest": []}
+    import random
+    rnd = random.Random(1)
+    for _ in range(4):
+        a, b = rnd.randrange(bn.P), rnd.randrange(bn.P)
+        out["fp_mul"].append({"a": hx(bn.fp_to_le(a)), "b": hx(bn.fp_to_le(b)), "out": hx(bn.fp_to_le(a * b % bn.P))})
+    for _ in range(3):
+        a = rng.fr_nonzero()
+        out["fr_inv"].append({"a": fr(a), "out": fr(bn.fr_inv(a))})
+    for _ in range(3):
+        k, s = rng.fr_nonzero(), rng.fr()
+        p = bn.g1_mul(bn.G1_GEN, k)
+        q = bn.g2_mul(bn.G2_GEN, k)
+        out["g1_mul"].append({"p": g1(p), "k": fr(s), "out": g1(bn.g1_mul(p, s))})
+        out["g2_mul"].append({"p": g2(q), "k": fr(s), "out": g2(bn.g2_mul(q, s))})
+        p2 = bn.g1_mul(bn.G1_GEN, s)
+        out["g1_add"].append({"a": g1(p), "b": g1(p2), "out": g1(bn.g1_add(p, p2))})
+    # EIP-196 public vector: 2*(1,2)
+    out["g1_mul"].append({"p": g1(bn.G1_GEN), "k": fr(2), "out": g1(bn.g1_mul(bn.G1_GEN, 2)), "note": "EIP-196 doubling vector"})
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    out["pairing"].append({"p": g1(bn.G1_GEN), "q": g2(bn.G2_GEN), "out": gt(e), "note": "generators; libff/zcash-bn final exponent"})
+    k1, k2 = rng.fr_nonzero(), rng.fr_nonzero()
+    out["pairing"].append({"p": g1(bn.g1_mul(bn.G1_GEN, k1)), "q": g2(bn.g2_mul(bn.G2_GEN, k2)), "out": gt(bn.gt_pow(e, k1 * k2 % bn.R))})
+    k = rng.fr()
+    out["gt_pow"].append({"a": gt(e), "k": fr(k), "out": gt(bn.gt_pow(e, k))})
+    import hashlib
+    for label in ["A00", "01 20", "attribute", ""]:
+        d = hashlib.sha3_256(label.encode()).digest()
+        out["fr_from_digest"].append({"label": label, "digest_be": d.hex(), "out": fr(bn.fr_from_be32_reduce(d))})
+    return out
+
+
+E_GEN = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+
+
+def ac17_cases():
+    rng = SeededRng(17)
+    pk, msk = sch.ac17_setup(rng)
+    doc = {"pk": {"g": g1(pk["g"]), "h_a": [g2(x) for x in pk["h_a"]], "e_gh_ka": [gt(x) for x in pk["e_gh_ka"]]},
+           "msk": {"g": g1(msk["g"]), "h": g2(msk["h"]), "g_k": [g1(x) for x in msk["g_k"]], "a": [fr(x) for x in msk["a"]],
+                   "b": [fr(x) for x in msk["b"]]}, "cases": []}
+    cases = [('"A" and "B"', pol.HUMAN, ["A", "B"]),
+             (r'''{"name": "or", "children": [{"name": "X"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}''', pol.JSON, ["A", "B"]),
+             (r'''{"name": "and", "children": [{"name": "A"}, {"name": "or", "children": [{"name": "D"}, {"name": "and", "children": [{"name": "B"},{"name": "C"}]}]}]}''', pol.JSON, ["A", "B", "C"])]
+    for policy, lang, attrs in cases:
+        kt = [rng.fr() for _ in range(2 + len(attrs) + 1)]
+        sk = sch.ac17_cp_keygen(msk, attrs, ListRng(kt))
+        et = [rng.fr(), rng.fr()]
+        rho = rng.fr_nonzero()
+        msg = bn.gt_pow(E_GEN, rho)
+        ct = sch.ac17_cp_encrypt(pk, policy, lang, ListRng(et), msg)
+        dec = sch.ac17_cp_decrypt(sk, ct)
+        assert dec == msg
+        doc["cases"].append({
+            "policy": policy, "language": lang, "attrs": attrs,
+            "keygen_tape": [fr(x) for x in kt], "encrypt_tape": [fr(x) for x in et], "msg": gt(msg),
+            "sk": {"k_0": [g2(x) for x in sk["sk"]["k_0"]], "k": [[n, [g1(p) for p in v]] for n, v in sk["sk"]["k"]],
+                   "k_p": [g1(x) for x in sk["sk"]["k_p"]]},
+            "ct": {"c_0": [g2(x) for x in ct["ct"]["c_0"]], "c": [[n, [g1(p) for p in v]] for n, v in ct["ct"]["c"]],
+                   "c_p": gt(ct["ct"]["c_p"])},
+            "decrypted": gt(dec)})
+    return doc
+
+
+def bsw_cases():
+    rng = SeededRng(18)
+    pk, msk = sch.bsw_setup(rng)
+    doc = {"pk": {"g1": g1(pk["g1"]), "g2": g2(pk["g2"]), "h": g1(pk["h"]), "f": g2(pk["f"]), "e_gg_alpha": gt(pk["e_gg_alpha"])},
+           "msk": {"beta": fr(msk["beta"]), "g2_alpha": g2(msk["g2_alpha"])}, "cases": []}
+    cases = [(r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}, {"name": "C"}]}''', pol.JSON, ["A", "B", "C"]),
+             (r'''{"name": "or", "children": [{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children":  [{"name": "C"}, {"name": "D"}]}]}''', pol.JSON, ["C", "D"]),
+             ('"A" or ("B" and "C")', pol.HUMAN, ["B", "C"])]
+    for policy, lang, attrs in cases:
+        kt = [rng.fr() for _ in range(1 + len(attrs))]
+        sk = sch.bsw_keygen(pk, msk, attrs, ListRng(kt))
+        rec = RecRng(rng.fr() % (1 << 62))
+        msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+        ct = sch.bsw_encrypt(pk, policy, lang, rec, msg)
+        dec = sch.bsw_decrypt(sk, ct)
+        assert dec == msg
+        doc["cases"].append({
+            "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in kt],
+            "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+            "sk": {"d": g2(sk["d"]), "d_j": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in sk["d_j"]]},
+            "ct": {"c": g1(ct["c"]), "c_p": gt(ct["c_p"]), "c_y": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in ct["c_y"]]},
+            "decrypted": gt(dec)})
+    return doc
+
+
+def lsw_cases():
+    rng = SeededRng(19)
+    pk, msk = sch.lsw_setup(rng)
+    doc = {"pk": {k: (gt(v) if k == "e_gg_alpha" else g2(v) if k == "g2" else g1(v)) for k, v in pk.items()},
+           "msk": {"alpha1": fr(msk["alpha1"]), "alpha2": fr(msk["alpha2"]), "b": fr(msk["b"]), "h_g1": g1(msk["h_g1"]), "h_g2": g2(msk["h_g2"])},
+           "cases": []}
+    cases = [(r'''{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}''', pol.JSON, ["A", "B", "C"]),
+             (r'''{"name": "or", "children": [{"name": "X"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}, {"name": "A"}]}]}''', pol.JSON, ["A", "B", "C"])]
+    for policy, lang, attrs in cases:
+        rk = RecRng(rng.fr() % (1 << 62))
+        sk = sch.lsw_keygen(pk, msk, policy, lang, rk)
+        re_ = RecRng(rng.fr() % (1 << 62))
+        msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+        ct = sch.lsw_encrypt(pk, attrs, re_, msg)
+        dec = sch.lsw_decrypt(sk, ct)
+        assert dec == msg
+
+        def pt(x, f):
+            return f(x)
+        doc["cases"].append({
+            "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in rk.log],
+            "encrypt_tape": [fr(x) for x in re_.log], "msg": gt(msg),
+            "sk": {"dj": [[d[0], g1(d[1]), g2(d[2]), g1(d[3]), g1(d[4]), g1(d[5])] for d in sk["dj"]]},
+            "ct": {"e1": gt(ct["e1"]), "e2": g2(ct["e2"]), "ej": [[e[0], g1(e[1]), g1(e[2]), g1(e[3])] for e in ct["ej"]]},
+            "decrypted": gt(dec)})
+    return doc
+
+
+def aw11_cases():
+    rng = SeededRng(20)
+    gk = sch.aw11_setup(rng)
+    ta1 = [rng.fr() for _ in range(4)]
+    ta2 = [rng.fr() for _ in range(2)]
+    pk1, msk1 = sch.aw11_authgen(gk, ["a", "b"], ListRng(ta1))
+    pk2, msk2 = sch.aw11_authgen(gk, ["C"], ListRng(ta2))
+    doc = {"gk": {"g1": g1(gk["g1"]), "g2": g2(gk["g2"])},
+           "authorities": [{"attrs": ["a", "b"], "tape": [fr(x) for x in ta1], "pk": [[n, gt(e), g2(y)] for n, e, y in pk1["attr"]],
+                            "msk": [[n, fr(a), fr(y)] for n, a, y in msk1["attr"]]},
+                           {"attrs": ["C"], "tape": [fr(x) for x in ta2], "pk": [[n, gt(e), g2(y)] for n, e, y in pk2["attr"]],
+                            "msk": [[n, fr(a), fr(y)] for n, a, y in msk2["attr"]]}],
+           "cases": []}
+    sk = sch.aw11_keygen(gk, msk1, "alice", ["A", "B"])
+    policy = r'''{"name": "or", "children": [{"name": "C"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}'''
+    rec = RecRng(rng.fr() % (1 << 62))
+    msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+    ct = sch.aw11_encrypt(gk, [pk1, pk2], policy, pol.JSON, rec, msg)
+    dec = sch.aw11_decrypt(gk, sk, ct)
+    assert dec == msg
+    doc["cases"].append({
+        "policy": policy, "language": pol.JSON, "gid": "alice", "key_authority": 0, "key_attrs": ["A", "B"],
+        "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+        "sk": [[n, g1(p)] for n, p in sk["attr"]],
+        "ct": {"c_0": gt(ct["c_0"]), "c": [[n, gt(c1), g2(c2), g2(c3)] for n, c1, c2, c3 in ct["c"]]},
+        "decrypted": gt(dec)})
+    return doc
+
+
+def main():
+    for name, fn in (("bn254_primitives", primitives), ("ac17", ac17_cases), ("bsw", bsw_cases), ("lsw", lsw_cases), ("aw11", aw11_cases)):
+        doc = fn()
+        path = os.path.join(HERE, name + ".json")
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
