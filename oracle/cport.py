@@ -95,11 +95,16 @@ def ac17_encdec(policy, n_attrs, n_items, seed=0):
     assert ok
     msg = bn.gt_to_le(e)
     outs = []
+    import time
+    seconds = 0.0
     for _ in range(n_items):
-        pi, c0, c, cp = ac17_cp_encrypt_raw(pk, policy, pol.JSON, rfr(), rfr(), msg)
+        s0, s1 = rfr(), rfr()
+        t0 = time.perf_counter()
+        pi, c0, c, cp = ac17_cp_encrypt_raw(pk, policy, pol.JSON, s0, s1, msg)
         ct_sel, sk_sel = [], []
         for name, _nc in lst:
             ct_sel += [i for i, n in enumerate(pi) if n == name]
             sk_sel += [i for i, n in enumerate(attrs) if n == name]
         outs.append(ac17_cp_decrypt_raw(c0, c, cp, sk_k0, sk_k, sk_kp, ct_sel, sk_sel))
-    return outs
+        seconds += time.perf_counter() - t0
+    return outs, seconds

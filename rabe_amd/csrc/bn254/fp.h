@@ -54,17 +54,10 @@ typedef Mont<FpParams> Fp;
 typedef Mont<FrParams> Fr;
 
 // ---------------------------------------------------------------------------------------------
-// raw 256-bit helpers
-RB_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
-  uint64_t s = (uint64_t)a + b + carry;
-  carry = (uint32_t)(s >> 32);
-  return (uint32_t)s;
-}
-RB_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
-  uint64_t d = (uint64_t)a - b - borrow;
-  borrow = (uint32_t)(d >> 63);
-  return (uint32_t)d;
-}
+// raw 256-bit helpers: explicit carry chains (clang lowers __builtin_addc/__builtin_subc to
+// v_add_co_u32 / v_addc_co_u32 / v_subb_co_u32 on gfx950 -- one instruction per limb).
+RB_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) { return __builtin_addc(a, b, carry, &carry); }
+RB_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) { return __builtin_subc(a, b, borrow, &borrow); }
 
 template <class M>
 RB_HD bool is_zero(const Mont<M>& a) {
@@ -95,26 +88,26 @@ RB_HD Mont<M> one() {
   return r;
 }
 
-// r = a - mod if a >= mod (a < 2*mod, optional extra carry bit `hi`)
+// t <- t - mod if t >= mod, for t < 2*mod < 2^255 (so t itself never carries out of 256 bits)
 template <class M>
 RB_HD void cond_sub_mod(uint32_t* t, uint32_t hi) {
   uint32_t d[8];
   uint32_t borrow = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) d[i] = subb32(t[i], M::mod(i), borrow);
-  // keep the difference when no borrow out of (hi:t) - mod
-  bool ge = (hi != 0) | (borrow == 0);
+  const bool keep = (borrow != 0) & (hi == 0);   // borrow: t < mod
 #pragma unroll
-  for (int i = 0; i < 8; i++) t[i] = ge ? d[i] : t[i];
+  for (int i = 0; i < 8; i++) t[i] = keep ? t[i] : d[i];
 }
 
+// a + b mod m: both < m < 2^254, so the sum needs no ninth limb
 template <class M>
 RB_HD Mont<M> add(const Mont<M>& a, const Mont<M>& b) {
   uint32_t t[8];
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) t[i] = addc32(a.v[i], b.v[i], c);
-  cond_sub_mod<M>(t, c);
+  cond_sub_mod<M>(t, 0);
   Mont<M> r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
@@ -122,32 +115,42 @@ RB_HD Mont<M> add(const Mont<M>& a, const Mont<M>& b) {
 }
 template <class M>
 RB_HD Mont<M> sub(const Mont<M>& a, const Mont<M>& b) {
-  Mont<M> r;
+  uint32_t t[8];
   uint32_t borrow = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = subb32(a.v[i], b.v[i], borrow);
+  for (int i = 0; i < 8; i++) t[i] = subb32(a.v[i], b.v[i], borrow);
   // add the modulus back when the subtraction wrapped
-  uint32_t mask = 0u - borrow;
+  const uint32_t mask = 0u - borrow;
   uint32_t c = 0;
+  Mont<M> r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = addc32(r.v[i], M::mod(i) & mask, c);
+  for (int i = 0; i < 8; i++) r.v[i] = addc32(t[i], M::mod(i) & mask, c);
   return r;
 }
 template <class M>
 RB_HD Mont<M> neg(const Mont<M>& a) {
-  Mont<M> r;
-  uint32_t borrow = 0;
   uint32_t nz = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) nz |= a.v[i];
-  uint32_t mask = nz ? 0xFFFFFFFFu : 0u;
+  const uint32_t mask = nz ? 0xFFFFFFFFu : 0u;
+  uint32_t borrow = 0;
+  Mont<M> r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = subb32(M::mod(i) & mask, a.v[i], borrow);
   return r;
 }
+// 2a mod m: shift left by one, then one conditional subtraction
 template <class M>
 RB_HD Mont<M> dbl(const Mont<M>& a) {
-  return add(a, a);
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 7; i > 0; i--) t[i] = (a.v[i] << 1) | (a.v[i - 1] >> 31);
+  t[0] = a.v[0] << 1;
+  cond_sub_mod<M>(t, 0);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
