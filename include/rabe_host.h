@@ -1,0 +1,101 @@
+/*
+ * rabe_host.h -- C interface of the C++ host layer (rabe::schemes::* mirror, rabe_amd/csrc/host/).
+ *
+ * Same convention as the reference's own C FFI (src/ffi/bsw.rs:22-163): opaque object pointers created by
+ * one call and destroyed by a paired free, int32 status, out-buffers returned through out-pointers.
+ * Status: 0 ok; 1 = `None` (the reference returns Option::None: bsw::keygen :132-134, aw11::authgen :127-129);
+ * -1 = RabeError (text via rabe_host_last_error); -2 = a condition on which the reference panics
+ * (malformed policy shapes, unwrap on None).  Group arithmetic always runs on the HIP engine.
+ */
+#ifndef RABE_HOST_H
+#define RABE_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rabe_host rabe_host;
+
+enum {   /* object kinds for rabe_obj_free / rabe_obj_serialize / rabe_obj_deserialize */
+  RABE_AC17_PK = 1, RABE_AC17_MSK = 2, RABE_AC17_CP_SK = 3, RABE_AC17_CP_CT = 4,
+  RABE_BSW_PK = 10, RABE_BSW_MSK = 11, RABE_BSW_SK = 12, RABE_BSW_CT = 13,
+  RABE_LSW_PK = 20, RABE_LSW_MSK = 21, RABE_LSW_SK = 22, RABE_LSW_CT = 23,
+  RABE_AW11_GK = 30, RABE_AW11_PK = 31, RABE_AW11_MSK = 32, RABE_AW11_SK = 33, RABE_AW11_CT = 34
+};
+enum { RABE_JSON_POLICY = 0, RABE_HUMAN_POLICY = 1 };   /* PolicyLanguage, src/utils/policy/pest/mod.rs:18-23 */
+
+int32_t rabe_host_create(int32_t device, rabe_host** out);
+void rabe_host_destroy(rabe_host* h);
+const char* rabe_host_last_error(rabe_host* h);          /* h may be NULL: error of the last host-free call on this thread */
+/* Explicit randomness: the next calls draw their Fr values from this tape, in the reference's
+ * draw order, instead of the OS generator.  n = 0 switches back to OS randomness. */
+int32_t rabe_host_set_tape(rabe_host* h, const uint8_t* fr_le32, size_t n);
+
+void rabe_obj_free(int32_t kind, void* obj);
+/* canonical byte form of a key / ciphertext (layout: rabe_amd/csrc/host/host_abi.cpp); free with rabe_bytes_free */
+int32_t rabe_obj_serialize(int32_t kind, const void* obj, uint8_t** out, size_t* len);
+int32_t rabe_obj_deserialize(int32_t kind, const uint8_t* data, size_t len, void** obj);
+void rabe_bytes_free(void* p);
+
+/* ---- ac17 (src/schemes/ac17/mod.rs:141-430) */
+int32_t rabe_ac17_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_ac17_cp_keygen(rabe_host* h, const void* msk, const char* const* attributes, size_t n, void** sk);
+int32_t rabe_ac17_cp_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_ac17_cp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_ac17_cp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* n independent cp_encrypt calls in one launch set; cts receives n object pointers */
+int32_t rabe_ac17_cp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* policies, int32_t language,
+                                   const uint8_t* const* plaintexts, const size_t* lens, void** cts);
+/* n independent cp_decrypt calls; status[i] = 0 ok / -1 error; plaintexts[i] malloc'd (rabe_bytes_free) */
+int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                                   uint8_t** plaintexts, size_t* lens);
+
+/* ---- bsw (src/schemes/bsw/mod.rs:92-318) */
+int32_t rabe_bsw_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_bsw_keygen(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, size_t n, void** sk);
+int32_t rabe_bsw_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_bsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_bsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+
+/* ---- lsw (src/schemes/lsw/mod.rs:86-290) */
+int32_t rabe_lsw_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_lsw_keygen(rabe_host* h, const void* pk, const void* msk, const char* policy, int32_t language, void** sk);
+int32_t rabe_lsw_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_lsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_lsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+
+/* ---- aw11 (src/schemes/aw11/mod.rs:100-390) */
+int32_t rabe_aw11_setup(rabe_host* h, void** gk);
+int32_t rabe_aw11_authgen(rabe_host* h, const void* gk, const char* const* attributes, size_t n, void** pk, void** msk);
+int32_t rabe_aw11_keygen(rabe_host* h, const void* gk, const void* msk, const char* name, const char* const* attributes, size_t n, void** sk);
+int32_t rabe_aw11_add_to_attribute(rabe_host* h, const void* gk, const void* msk, const char* attribute, void* sk);
+int32_t rabe_aw11_encrypt(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
+                          const uint8_t* data, size_t len, void** ct);
+int32_t rabe_aw11_decrypt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_aw11_decrypt_gt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t out_gt[384]);
+
+/* ---- host-only policy utilities (no GPU needed): results as small JSON texts, free with rabe_bytes_free.
+ *   rabe_policy_parse      -> serialize_policy(parse(policy, language), out_language)       pest/mod.rs:40-114
+ *   rabe_policy_msp        -> {"m": [[..]], "pi": [..], "c": n}                             msp.rs:78-147
+ *   rabe_policy_pruned     -> {"match": bool, "list": [[name, name_col], ..]}               secretsharing/mod.rs:143-199
+ *   rabe_policy_traverse   -> 1 / 0                                                         tools/mod.rs:31-61
+ *   rabe_policy_shares     -> [[name_col, hex(fr_le)], ..] for secret + coefficient tape    secretsharing/mod.rs:82-141
+ *   rabe_policy_coeffs     -> [[name_col, hex(fr_le)], ..]                                  secretsharing/mod.rs:9-72
+ */
+int32_t rabe_policy_parse(const char* policy, int32_t language, int32_t out_language, char** out);
+int32_t rabe_policy_msp(const char* policy, int32_t language, char** out);
+int32_t rabe_policy_pruned(const char* policy, int32_t language, const char* const* attributes, size_t n, char** out);
+int32_t rabe_policy_traverse(const char* policy, int32_t language, const char* const* attributes, size_t n, int32_t* result);
+int32_t rabe_policy_shares(const char* policy, int32_t language, const uint8_t secret_le32[32], const uint8_t* tape_le32, size_t n_tape, char** out);
+int32_t rabe_policy_coeffs(const char* policy, int32_t language, char** out);
+/* KDF + AES-256-GCM of src/utils/aes/mod.rs with an explicit nonce; out = nonce || ct || tag */
+int32_t rabe_encrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, const uint8_t nonce[12], uint8_t** out, size_t* out_len);
+int32_t rabe_decrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

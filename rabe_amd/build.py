@@ -9,11 +9,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
-SOURCES = [os.path.join(CSRC, "engine.hip")]
+SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "host", "schemes.cpp"), os.path.join(CSRC, "host", "host_abi.cpp")]
 
 
 def _deps():
-    deps = list(SOURCES) + [os.path.join(os.path.dirname(HERE), "include", "rabe_hip.h")]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = list(SOURCES) + [os.path.join(inc, "rabe_hip.h"), os.path.join(inc, "rabe_host.h")]
     for root, _dirs, files in os.walk(CSRC):
         deps += [os.path.join(root, f) for f in files]
     return deps

@@ -1,0 +1,143 @@
+// Host layer common pieces: group-element value types (canonical wire format of include/rabe_hip.h),
+// RabeError, randomness sources, and a thin RAII wrapper of the engine's C ABI.
+//
+// This layer mirrors the reference's scheme API (rabe::schemes::{ac17,bsw,lsw,aw11}) in C++ because the
+// container has no Rust toolchain; a Rust host would call the same rhip_* entry points.
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rabe_hip.h"
+#include "aes_gcm.h"
+#include "policy.h"
+
+namespace rabe {
+
+// src/error.rs:19-28
+struct RabeError : std::runtime_error {
+  explicit RabeError(const std::string& details) : std::runtime_error(details) {}
+};
+
+typedef std::vector<uint8_t> Bytes;
+typedef std::array<uint8_t, 64> G1;
+typedef std::array<uint8_t, 128> G2;
+typedef std::array<uint8_t, 384> Gt;
+using host::Fr;
+using host::PolicyLanguage;
+
+inline G1 g1_generator() {
+  G1 g{};
+  g[0] = 1;
+  g[32] = 2;
+  return g;
+}
+inline G2 g2_generator() {
+  static const uint64_t L[16] = {
+      0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull,     // x.c0
+      0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull,     // x.c1
+      0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull,     // y.c0
+      0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull};     // y.c1
+  G2 g{};
+  memcpy(g.data(), L, 128);
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------- randomness
+// Stands where the reference uses rand::thread_rng() (ac17/mod.rs:143,201,281; bsw/mod.rs:227;
+// lsw/mod.rs:129,188; aw11/mod.rs:131,249; aes/mod.rs:11).
+struct Rng : host::FrSource {
+  virtual void fill(uint8_t* out, size_t n) = 0;
+};
+struct OsRng : Rng {
+  void fill(uint8_t* out, size_t n) override;
+  Fr next_fr() override {
+    uint8_t b[64];
+    fill(b, 64);
+    return host::fr_from_le64_reduce(b);     // `Fr::random`: 512 random bits mod r
+  }
+};
+// Explicit-randomness tape: replays a list of Fr values in draw order; byte draws (the AES
+// nonce) take the low bytes of the next tape entry.
+struct TapeRng : Rng {
+  std::vector<Fr> tape;
+  size_t pos = 0;
+  explicit TapeRng(std::vector<Fr> t) : tape(std::move(t)) {}
+  Fr next_fr() override {
+    if (pos >= tape.size()) throw RabeError("randomness tape exhausted");
+    return tape[pos++];
+  }
+  void fill(uint8_t* out, size_t n) override {
+    size_t off = 0;
+    while (off < n) {
+      Fr f = next_fr();
+      size_t k = n - off < 32 ? n - off : 32;
+      memcpy(out + off, f.l, k);
+      off += k;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- engine wrapper
+class Engine;
+class DBuf {
+ public:
+  DBuf() {}
+  DBuf(Engine* e, size_t bytes);
+  DBuf(Engine* e, const void* host_data, size_t bytes);
+  ~DBuf();
+  DBuf(DBuf&& o) noexcept : eng_(o.eng_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+  DBuf& operator=(DBuf&& o) noexcept;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  void* ptr() const { return p_; }
+  template <class T> T* as() const { return (T*)p_; }
+  size_t size() const { return n_; }
+  void download(void* host, size_t bytes) const;
+ private:
+  Engine* eng_ = nullptr;
+  void* p_ = nullptr;
+  size_t n_ = 0;
+};
+
+class Engine {
+ public:
+  explicit Engine(int device = 0);
+  ~Engine();
+  rhip_ctx* ctx() const { return ctx_; }
+  void check(int32_t rc, const char* what) const;
+
+  // Level E conveniences on host values (each a small batched launch)
+  std::vector<G1> g1_mul(const std::vector<G1>& p, const std::vector<Fr>& k);
+  std::vector<G2> g2_mul(const std::vector<G2>& p, const std::vector<Fr>& k);
+  std::vector<Gt> gt_pow(const std::vector<Gt>& a, const std::vector<Fr>& k);
+  std::vector<Gt> gt_mul(const std::vector<Gt>& a, const std::vector<Gt>& b);
+  std::vector<Gt> pairing(const std::vector<G1>& p, const std::vector<G2>& q);
+  // `rng.gen::<G1>()` = generator * Fr::random
+  G1 random_g1(Rng& rng) { return g1_mul({g1_generator()}, {rng.next_fr()})[0]; }
+  G2 random_g2(Rng& rng) { return g2_mul({g2_generator()}, {rng.next_fr()})[0]; }
+  // `rng.gen::<Gt>()`: e(G1::one(), G2::one()) ^ Fr::random
+  Gt random_gt(Rng& rng);
+
+ private:
+  rhip_ctx* ctx_ = nullptr;
+  bool have_e_ = false;
+  Gt e_gen_;
+};
+
+template <class T, size_t N>
+inline std::vector<uint8_t> flatten(const std::vector<std::array<T, N>>& v) {
+  std::vector<uint8_t> o(v.size() * N);
+  for (size_t i = 0; i < v.size(); i++) memcpy(o.data() + i * N, v[i].data(), N);
+  return o;
+}
+inline std::vector<uint8_t> flatten_fr(const std::vector<Fr>& v) {
+  std::vector<uint8_t> o(v.size() * 32);
+  for (size_t i = 0; i < v.size(); i++) memcpy(o.data() + i * 32, v[i].l, 32);
+  return o;
+}
+
+}  // namespace rabe

@@ -1,0 +1,484 @@
+// C interface of the host layer (include/rabe_host.h): opaque handles, status codes, canonical serialisation.
+//
+// Serialised layout ("canonical byte form"; the reference's serde/borsh layouts of rabe-bn types are not
+// visible in /root/reference -- SURVEY.md 8f item 2 -- so this is the engine's own, borsh-shaped one):
+//   u32 little-endian lengths; String = u32 len + UTF-8; Vec<T> = u32 count + items; PolicyLanguage = u8;
+//   Fr 32 B, G1 64 B, G2 128 B, Gt 384 B in the wire format of include/rabe_hip.h; struct fields in the
+//   reference's declaration order (ac17/mod.rs:58-135, bsw/mod.rs:39-89, lsw/mod.rs:40-83, aw11/mod.rs:46-97).
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/rabe_host.h"
+#include "schemes.h"
+
+using namespace rabe;
+using namespace rabe::host;
+using namespace rabe::schemes;
+
+struct rabe_host {
+  Engine eng;
+  OsRng os;
+  std::unique_ptr<TapeRng> tape;
+  std::string err;
+  explicit rabe_host(int device) : eng(device) {}
+  Rng& rng() { return tape ? (Rng&)*tape : (Rng&)os; }
+};
+static thread_local std::string g_err;
+
+#define GUARD_BEGIN try {
+#define GUARD_END(h)                                                         \
+  }                                                                          \
+  catch (const RabeError& e) { set_err(h, e.what()); return -1; }            \
+  catch (const PolicyError& e) { set_err(h, e.what()); return -1; }          \
+  catch (const std::exception& e) { set_err(h, std::string("panic: ") + e.what()); return -2; }
+static void set_err(rabe_host* h, const std::string& s) { g_err = s; if (h) h->err = s; }
+
+// ------------------------------------------------------------------------------------------------ serialisation
+struct W {
+  Bytes b;
+  void u8(uint8_t v) { b.push_back(v); }
+  void u32(uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+  void raw(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
+  void str(const std::string& s) { u32((uint32_t)s.size()); raw((const uint8_t*)s.data(), s.size()); }
+  void bytes(const Bytes& v) { u32((uint32_t)v.size()); raw(v.data(), v.size()); }
+  void fr(const Fr& f) { raw((const uint8_t*)f.l, 32); }
+  template <size_t N> void el(const std::array<uint8_t, N>& e) { raw(e.data(), N); }
+  template <size_t N> void vec(const std::vector<std::array<uint8_t, N>>& v) { u32((uint32_t)v.size()); for (auto& e : v) el(e); }
+  void vfr(const std::vector<Fr>& v) { u32((uint32_t)v.size()); for (auto& e : v) fr(e); }
+  void pol(const PolicyRef& p) { str(p.first); u8((uint8_t)p.second); }
+};
+struct R {
+  const uint8_t* p;
+  size_t n, o = 0;
+  R(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+  void need(size_t k) { if (o + k > n) throw RabeError("deserialize: truncated input"); }
+  uint8_t u8() { need(1); return p[o++]; }
+  uint32_t u32() { need(4); uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)p[o + i] << (8 * i); o += 4; return v; }
+  std::string str() { uint32_t l = u32(); need(l); std::string s((const char*)p + o, l); o += l; return s; }
+  Bytes bytes() { uint32_t l = u32(); need(l); Bytes b(p + o, p + o + l); o += l; return b; }
+  Fr fr() { need(32); Fr f; memcpy(f.l, p + o, 32); o += 32; return f; }
+  template <size_t N> std::array<uint8_t, N> el() { need(N); std::array<uint8_t, N> e; memcpy(e.data(), p + o, N); o += N; return e; }
+  template <size_t N> std::vector<std::array<uint8_t, N>> vec() { uint32_t c = u32(); std::vector<std::array<uint8_t, N>> v; for (uint32_t i = 0; i < c; i++) v.push_back(el<N>()); return v; }
+  std::vector<Fr> vfr() { uint32_t c = u32(); std::vector<Fr> v; for (uint32_t i = 0; i < c; i++) v.push_back(fr()); return v; }
+  PolicyRef pol() { std::string s = str(); uint8_t l = u8(); return {s, l ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy}; }
+};
+typedef std::vector<std::pair<std::string, std::vector<G1>>> NamedG1Vec;
+static void w_named(W& w, const NamedG1Vec& v) { w.u32((uint32_t)v.size()); for (auto& e : v) { w.str(e.first); w.vec(e.second); } }
+static NamedG1Vec r_named(R& r) { uint32_t c = r.u32(); NamedG1Vec v; for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); v.push_back({s, r.vec<64>()}); } return v; }
+
+static void ser(W& w, int32_t kind, const void* o) {
+  switch (kind) {
+    case RABE_AC17_PK: { auto& x = *(const ac17::Ac17PublicKey*)o; w.el(x.g); w.vec(x.h_a); w.vec(x.e_gh_ka); break; }
+    case RABE_AC17_MSK: { auto& x = *(const ac17::Ac17MasterKey*)o; w.el(x.g); w.el(x.h); w.vec(x.g_k); w.vfr(x.a); w.vfr(x.b); break; }
+    case RABE_AC17_CP_SK: { auto& x = *(const ac17::Ac17CpSecretKey*)o; w.u32((uint32_t)x.attr.size()); for (auto& a : x.attr) w.str(a);
+                            w.vec(x.sk.k_0); w_named(w, x.sk.k); w.vec(x.sk.k_p); break; }
+    case RABE_AC17_CP_CT: { auto& x = *(const ac17::Ac17CpCiphertext*)o; w.pol(x.policy); w.vec(x.ct.c_0); w_named(w, x.ct.c); w.el(x.ct.c_p);
+                            w.bytes(x.ct.ct); break; }
+    case RABE_BSW_PK: { auto& x = *(const bsw::CpAbePublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.h); w.el(x.f); w.el(x.e_gg_alpha); break; }
+    case RABE_BSW_MSK: { auto& x = *(const bsw::CpAbeMasterKey*)o; w.fr(x.beta); w.el(x.g2_alpha); break; }
+    case RABE_BSW_SK: { auto& x = *(const bsw::CpAbeSecretKey*)o; w.el(x.d); w.u32((uint32_t)x.d_j.size());
+                        for (auto& a : x.d_j) { w.str(a.string); w.el(a.g1); w.el(a.g2); } break; }
+    case RABE_BSW_CT: { auto& x = *(const bsw::CpAbeCiphertext*)o; w.pol(x.policy); w.el(x.c); w.el(x.c_p); w.u32((uint32_t)x.c_y.size());
+                        for (auto& a : x.c_y) { w.str(a.string); w.el(a.g1); w.el(a.g2); } w.bytes(x.data); break; }
+    case RABE_LSW_PK: { auto& x = *(const lsw::KpAbePublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.g1_b); w.el(x.g1_b2); w.el(x.h_b); w.el(x.e_gg_alpha); break; }
+    case RABE_LSW_MSK: { auto& x = *(const lsw::KpAbeMasterKey*)o; w.fr(x.alpha1); w.fr(x.alpha2); w.fr(x.b); w.el(x.h_g1); w.el(x.h_g2); break; }
+    case RABE_LSW_SK: { auto& x = *(const lsw::KpAbeSecretKey*)o; w.pol(x.policy); w.u32((uint32_t)x.dj.size());
+                        for (auto& d : x.dj) { w.str(d.name); w.el(d.d1); w.el(d.d2); w.el(d.d3); w.el(d.d4); w.el(d.d5); } break; }
+    case RABE_LSW_CT: { auto& x = *(const lsw::KpAbeCiphertext*)o; w.el(x.e1); w.el(x.e2); w.u32((uint32_t)x.ej.size());
+                        for (auto& e : x.ej) { w.str(e.name); w.el(e.e1); w.el(e.e2); w.el(e.e3); } w.bytes(x.ct); break; }
+    case RABE_AW11_GK: { auto& x = *(const aw11::Aw11GlobalKey*)o; w.el(x.g1); w.el(x.g2); break; }
+    case RABE_AW11_PK: { auto& x = *(const aw11::Aw11PublicKey*)o; w.u32((uint32_t)x.attr.size());
+                         for (auto& a : x.attr) { w.str(a.name); w.el(a.egg_alpha); w.el(a.g2_y); } break; }
+    case RABE_AW11_MSK: { auto& x = *(const aw11::Aw11MasterKey*)o; w.u32((uint32_t)x.attr.size());
+                          for (auto& a : x.attr) { w.str(a.name); w.fr(a.alpha); w.fr(a.y); } break; }
+    case RABE_AW11_SK: { auto& x = *(const aw11::Aw11SecretKey*)o; w.str(x.gid); w.u32((uint32_t)x.attr.size());
+                         for (auto& a : x.attr) { w.str(a.first); w.el(a.second); } break; }
+    case RABE_AW11_CT: { auto& x = *(const aw11::Aw11Ciphertext*)o; w.pol(x.policy); w.el(x.c_0); w.u32((uint32_t)x.c.size());
+                         for (auto& c : x.c) { w.str(c.name); w.el(c.c1); w.el(c.c2); w.el(c.c3); } w.bytes(x.ct); break; }
+    default: throw RabeError("serialize: unknown object kind");
+  }
+}
+static void* deser(R& r, int32_t kind) {
+  switch (kind) {
+    case RABE_AC17_PK: { auto* x = new ac17::Ac17PublicKey(); x->g = r.el<64>(); x->h_a = r.vec<128>(); x->e_gh_ka = r.vec<384>(); return x; }
+    case RABE_AC17_MSK: { auto* x = new ac17::Ac17MasterKey(); x->g = r.el<64>(); x->h = r.el<128>(); x->g_k = r.vec<64>(); x->a = r.vfr(); x->b = r.vfr(); return x; }
+    case RABE_AC17_CP_SK: { auto* x = new ac17::Ac17CpSecretKey(); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
+                            x->sk.k_0 = r.vec<128>(); x->sk.k = r_named(r); x->sk.k_p = r.vec<64>(); return x; }
+    case RABE_AC17_CP_CT: { auto* x = new ac17::Ac17CpCiphertext(); x->policy = r.pol(); x->ct.c_0 = r.vec<128>(); x->ct.c = r_named(r);
+                            x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return x; }
+    case RABE_BSW_PK: { auto* x = new bsw::CpAbePublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->h = r.el<64>(); x->f = r.el<128>(); x->e_gg_alpha = r.el<384>(); return x; }
+    case RABE_BSW_MSK: { auto* x = new bsw::CpAbeMasterKey(); x->beta = r.fr(); x->g2_alpha = r.el<128>(); return x; }
+    case RABE_BSW_SK: { auto* x = new bsw::CpAbeSecretKey(); x->d = r.el<128>(); uint32_t c = r.u32();
+                        for (uint32_t i = 0; i < c; i++) { bsw::CpAbeAttribute a; a.string = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->d_j.push_back(a); } return x; }
+    case RABE_BSW_CT: { auto* x = new bsw::CpAbeCiphertext(); x->policy = r.pol(); x->c = r.el<64>(); x->c_p = r.el<384>(); uint32_t c = r.u32();
+                        for (uint32_t i = 0; i < c; i++) { bsw::CpAbeAttribute a; a.string = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->c_y.push_back(a); }
+                        x->data = r.bytes(); return x; }
+    case RABE_LSW_PK: { auto* x = new lsw::KpAbePublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_b = r.el<64>(); x->g1_b2 = r.el<64>(); x->h_b = r.el<64>();
+                        x->e_gg_alpha = r.el<384>(); return x; }
+    case RABE_LSW_MSK: { auto* x = new lsw::KpAbeMasterKey(); x->alpha1 = r.fr(); x->alpha2 = r.fr(); x->b = r.fr(); x->h_g1 = r.el<64>(); x->h_g2 = r.el<128>(); return x; }
+    case RABE_LSW_SK: { auto* x = new lsw::KpAbeSecretKey(); x->policy = r.pol(); uint32_t c = r.u32();
+                        for (uint32_t i = 0; i < c; i++) { lsw::KpAbeKeyRow d; d.name = r.str(); d.d1 = r.el<64>(); d.d2 = r.el<128>(); d.d3 = r.el<64>(); d.d4 = r.el<64>(); d.d5 = r.el<64>(); x->dj.push_back(d); }
+                        return x; }
+    case RABE_LSW_CT: { auto* x = new lsw::KpAbeCiphertext(); x->e1 = r.el<384>(); x->e2 = r.el<128>(); uint32_t c = r.u32();
+                        for (uint32_t i = 0; i < c; i++) { lsw::KpAbeCtRow e; e.name = r.str(); e.e1 = r.el<64>(); e.e2 = r.el<64>(); e.e3 = r.el<64>(); x->ej.push_back(e); }
+                        x->ct = r.bytes(); return x; }
+    case RABE_AW11_GK: { auto* x = new aw11::Aw11GlobalKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); return x; }
+    case RABE_AW11_PK: { auto* x = new aw11::Aw11PublicKey(); uint32_t c = r.u32();
+                         for (uint32_t i = 0; i < c; i++) { aw11::Aw11PkAttr a; a.name = r.str(); a.egg_alpha = r.el<384>(); a.g2_y = r.el<128>(); x->attr.push_back(a); } return x; }
+    case RABE_AW11_MSK: { auto* x = new aw11::Aw11MasterKey(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { aw11::Aw11MkAttr a; a.name = r.str(); a.alpha = r.fr(); a.y = r.fr(); x->attr.push_back(a); } return x; }
+    case RABE_AW11_SK: { auto* x = new aw11::Aw11SecretKey(); x->gid = r.str(); uint32_t c = r.u32();
+                         for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); x->attr.push_back({s, r.el<64>()}); } return x; }
+    case RABE_AW11_CT: { auto* x = new aw11::Aw11Ciphertext(); x->policy = r.pol(); x->c_0 = r.el<384>(); uint32_t c = r.u32();
+                         for (uint32_t i = 0; i < c; i++) { aw11::Aw11CtRow t; t.name = r.str(); t.c1 = r.el<384>(); t.c2 = r.el<128>(); t.c3 = r.el<128>(); x->c.push_back(t); }
+                         x->ct = r.bytes(); return x; }
+    default: throw RabeError("deserialize: unknown object kind");
+  }
+}
+
+static int32_t give_bytes(const Bytes& b, uint8_t** out, size_t* len) {
+  *out = (uint8_t*)malloc(b.size() ? b.size() : 1);
+  if (!*out) return -1;
+  memcpy(*out, b.data(), b.size());
+  *len = b.size();
+  return 0;
+}
+static int32_t give_text(const std::string& s, char** out) {
+  *out = (char*)malloc(s.size() + 1);
+  if (!*out) return -1;
+  memcpy(*out, s.c_str(), s.size() + 1);
+  return 0;
+}
+static std::vector<std::string> strs(const char* const* a, size_t n) {
+  std::vector<std::string> v;
+  for (size_t i = 0; i < n; i++) v.push_back(a[i]);
+  return v;
+}
+static PolicyLanguage lang_of(int32_t l) { return l == RABE_HUMAN_POLICY ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy; }
+
+extern "C" {
+
+int32_t rabe_host_create(int32_t device, rabe_host** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  GUARD_BEGIN
+  *out = new rabe_host(device);
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+void rabe_host_destroy(rabe_host* h) { delete h; }
+const char* rabe_host_last_error(rabe_host* h) { return h ? h->err.c_str() : g_err.c_str(); }
+int32_t rabe_host_set_tape(rabe_host* h, const uint8_t* fr_le32, size_t n) {
+  if (!h) return -1;
+  if (!n) { h->tape.reset(); return 0; }
+  std::vector<Fr> t(n);
+  for (size_t i = 0; i < n; i++) memcpy(t[i].l, fr_le32 + 32 * i, 32);
+  h->tape.reset(new TapeRng(t));
+  return 0;
+}
+void rabe_bytes_free(void* p) { free(p); }
+
+void rabe_obj_free(int32_t kind, void* o) {
+  switch (kind) {
+    case RABE_AC17_PK: delete (ac17::Ac17PublicKey*)o; break;
+    case RABE_AC17_MSK: delete (ac17::Ac17MasterKey*)o; break;
+    case RABE_AC17_CP_SK: delete (ac17::Ac17CpSecretKey*)o; break;
+    case RABE_AC17_CP_CT: delete (ac17::Ac17CpCiphertext*)o; break;
+    case RABE_BSW_PK: delete (bsw::CpAbePublicKey*)o; break;
+    case RABE_BSW_MSK: delete (bsw::CpAbeMasterKey*)o; break;
+    case RABE_BSW_SK: delete (bsw::CpAbeSecretKey*)o; break;
+    case RABE_BSW_CT: delete (bsw::CpAbeCiphertext*)o; break;
+    case RABE_LSW_PK: delete (lsw::KpAbePublicKey*)o; break;
+    case RABE_LSW_MSK: delete (lsw::KpAbeMasterKey*)o; break;
+    case RABE_LSW_SK: delete (lsw::KpAbeSecretKey*)o; break;
+    case RABE_LSW_CT: delete (lsw::KpAbeCiphertext*)o; break;
+    case RABE_AW11_GK: delete (aw11::Aw11GlobalKey*)o; break;
+    case RABE_AW11_PK: delete (aw11::Aw11PublicKey*)o; break;
+    case RABE_AW11_MSK: delete (aw11::Aw11MasterKey*)o; break;
+    case RABE_AW11_SK: delete (aw11::Aw11SecretKey*)o; break;
+    case RABE_AW11_CT: delete (aw11::Aw11Ciphertext*)o; break;
+    default: break;
+  }
+}
+int32_t rabe_obj_serialize(int32_t kind, const void* obj, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  W w;
+  ser(w, kind, obj);
+  return give_bytes(w.b, out, len);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_obj_deserialize(int32_t kind, const uint8_t* data, size_t len, void** obj) {
+  GUARD_BEGIN
+  R r(data, len);
+  *obj = deser(r, kind);
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+
+// ---------------------------------------------------------------- ac17
+int32_t rabe_ac17_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = ac17::setup(h->eng, h->rng());
+  *pk = new ac17::Ac17PublicKey(r.first);
+  *msk = new ac17::Ac17MasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_keygen(rabe_host* h, const void* msk, const char* const* attributes, size_t n, void** sk) {
+  GUARD_BEGIN
+  *sk = new ac17::Ac17CpSecretKey(ac17::cp_keygen(h->eng, h->rng(), *(const ac17::Ac17MasterKey*)msk, strs(attributes, n)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, void** ct) {
+  GUARD_BEGIN
+  *ct = new ac17::Ac17CpCiphertext(ac17::cp_encrypt(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, policy, Bytes(pt, pt + len), lang_of(language)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(ac17::cp_decrypt(h->eng, *(const ac17::Ac17CpSecretKey*)sk, *(const ac17::Ac17CpCiphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = ac17::cp_decrypt_gt(h->eng, *(const ac17::Ac17CpSecretKey*)sk, *(const ac17::Ac17CpCiphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* policies, int32_t language,
+                                   const uint8_t* const* plaintexts, const size_t* lens, void** cts) {
+  GUARD_BEGIN
+  std::vector<Bytes> pts;
+  for (size_t i = 0; i < n; i++) pts.push_back(Bytes(plaintexts[i], plaintexts[i] + lens[i]));
+  auto r = ac17::cp_encrypt_batch(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, strs(policies, n), pts, lang_of(language));
+  for (size_t i = 0; i < n; i++) cts[i] = new ac17::Ac17CpCiphertext(r[i]);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                                   uint8_t** plaintexts, size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const ac17::Ac17CpSecretKey*> s;
+  std::vector<const ac17::Ac17CpCiphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const ac17::Ac17CpSecretKey*)sks[i]); c.push_back((const ac17::Ac17CpCiphertext*)cts[i]); }
+  auto r = ac17::cp_decrypt_batch(h->eng, s, c);
+  for (size_t i = 0; i < n; i++) {
+    status[i] = r[i].ok ? 0 : -1;
+    plaintexts[i] = nullptr;
+    lens[i] = 0;
+    if (r[i].ok) give_bytes(r[i].plaintext, &plaintexts[i], &lens[i]);
+    else set_err(h, r[i].error);
+  }
+  return 0;
+  GUARD_END(h)
+}
+
+// ---------------------------------------------------------------- bsw
+int32_t rabe_bsw_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = bsw::setup(h->eng, h->rng());
+  *pk = new bsw::CpAbePublicKey(r.first);
+  *msk = new bsw::CpAbeMasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_keygen(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, size_t n, void** sk) {
+  GUARD_BEGIN
+  bsw::CpAbeSecretKey out;
+  if (!bsw::keygen(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, *(const bsw::CpAbeMasterKey*)msk, strs(attributes, n), &out)) return 1;
+  *sk = new bsw::CpAbeSecretKey(out);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, void** ct) {
+  GUARD_BEGIN
+  *ct = new bsw::CpAbeCiphertext(bsw::encrypt(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, policy, lang_of(language), Bytes(pt, pt + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(bsw::decrypt(h->eng, *(const bsw::CpAbeSecretKey*)sk, *(const bsw::CpAbeCiphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_bsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = bsw::decrypt_gt(h->eng, *(const bsw::CpAbeSecretKey*)sk, *(const bsw::CpAbeCiphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
+// ---------------------------------------------------------------- lsw
+int32_t rabe_lsw_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = lsw::setup(h->eng, h->rng());
+  *pk = new lsw::KpAbePublicKey(r.first);
+  *msk = new lsw::KpAbeMasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_keygen(rabe_host* h, const void* pk, const void* msk, const char* policy, int32_t language, void** sk) {
+  GUARD_BEGIN
+  *sk = new lsw::KpAbeSecretKey(lsw::keygen(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, *(const lsw::KpAbeMasterKey*)msk, policy, lang_of(language)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* pt, size_t len, void** ct) {
+  GUARD_BEGIN
+  *ct = new lsw::KpAbeCiphertext(lsw::encrypt(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, strs(attributes, n), Bytes(pt, pt + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(lsw::decrypt(h->eng, *(const lsw::KpAbeSecretKey*)sk, *(const lsw::KpAbeCiphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_lsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = lsw::decrypt_gt(h->eng, *(const lsw::KpAbeSecretKey*)sk, *(const lsw::KpAbeCiphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
+// ---------------------------------------------------------------- aw11
+int32_t rabe_aw11_setup(rabe_host* h, void** gk) {
+  GUARD_BEGIN
+  *gk = new aw11::Aw11GlobalKey(aw11::setup(h->eng, h->rng()));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_authgen(rabe_host* h, const void* gk, const char* const* attributes, size_t n, void** pk, void** msk) {
+  GUARD_BEGIN
+  aw11::Aw11PublicKey p;
+  aw11::Aw11MasterKey m;
+  if (!aw11::authgen(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, strs(attributes, n), &p, &m)) return 1;
+  *pk = new aw11::Aw11PublicKey(p);
+  *msk = new aw11::Aw11MasterKey(m);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_keygen(rabe_host* h, const void* gk, const void* msk, const char* name, const char* const* attributes, size_t n, void** sk) {
+  GUARD_BEGIN
+  *sk = new aw11::Aw11SecretKey(aw11::keygen(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11MasterKey*)msk, name, strs(attributes, n)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_add_to_attribute(rabe_host* h, const void* gk, const void* msk, const char* attribute, void* sk) {
+  GUARD_BEGIN
+  aw11::add_to_attribute(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11MasterKey*)msk, attribute, (aw11::Aw11SecretKey*)sk);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_encrypt(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
+                          const uint8_t* data, size_t len, void** ct) {
+  GUARD_BEGIN
+  std::vector<const aw11::Aw11PublicKey*> v;
+  for (size_t i = 0; i < n_pks; i++) v.push_back((const aw11::Aw11PublicKey*)pks[i]);
+  *ct = new aw11::Aw11Ciphertext(aw11::encrypt(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, v, policy, lang_of(language), Bytes(data, data + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_decrypt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(aw11::decrypt(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, *(const aw11::Aw11Ciphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_aw11_decrypt_gt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = aw11::decrypt_gt(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, *(const aw11::Aw11Ciphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
+// ---------------------------------------------------------------- policy utilities (host only)
+static std::string jstr(const std::string& s) {
+  std::string o = "\"";
+  for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; }
+  return o + "\"";
+}
+static std::string hex32(const Fr& f) {
+  static const char* d = "0123456789abcdef";
+  std::string o;
+  const uint8_t* p = (const uint8_t*)f.l;
+  for (int i = 0; i < 32; i++) { o += d[p[i] >> 4]; o += d[p[i] & 15]; }
+  return o;
+}
+int32_t rabe_policy_parse(const char* policy, int32_t language, int32_t out_language, char** out) {
+  GUARD_BEGIN
+  return give_text(serialize_policy(parse_policy(policy, lang_of(language)), lang_of(out_language)), out);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_msp(const char* policy, int32_t language, char** out) {
+  GUARD_BEGIN
+  AbePolicy m = calculate_msp(parse_policy(policy, lang_of(language)));
+  std::string s = "{\"m\": [";
+  for (size_t i = 0; i < m.m.size(); i++) {
+    s += i ? ", [" : "[";
+    for (size_t j = 0; j < m.m[i].size(); j++) s += (j ? ", " : "") + std::to_string((int)m.m[i][j]);
+    s += "]";
+  }
+  s += "], \"pi\": [";
+  for (size_t i = 0; i < m.pi.size(); i++) s += (i ? ", " : "") + jstr(m.pi[i]);
+  s += "], \"c\": " + std::to_string(m.c) + "}";
+  return give_text(s, out);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_pruned(const char* policy, int32_t language, const char* const* attributes, size_t n, char** out) {
+  GUARD_BEGIN
+  PrunedList l;
+  bool ok = calc_pruned(strs(attributes, n), parse_policy(policy, lang_of(language)), &l);
+  std::string s = std::string("{\"match\": ") + (ok ? "true" : "false") + ", \"list\": [";
+  if (ok) for (size_t i = 0; i < l.size(); i++) s += std::string(i ? ", " : "") + "[" + jstr(l[i].first) + ", " + jstr(l[i].second) + "]";
+  s += "]}";
+  return give_text(s, out);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_traverse(const char* policy, int32_t language, const char* const* attributes, size_t n, int32_t* result) {
+  GUARD_BEGIN
+  *result = traverse_policy(strs(attributes, n), parse_policy(policy, lang_of(language))) ? 1 : 0;
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+static std::string named_json(const NamedFr& v) {
+  std::string s = "[";
+  for (size_t i = 0; i < v.size(); i++) s += std::string(i ? ", " : "") + "[" + jstr(v[i].first) + ", \"" + hex32(v[i].second) + "\"]";
+  return s + "]";
+}
+int32_t rabe_policy_shares(const char* policy, int32_t language, const uint8_t secret[32], const uint8_t* tape, size_t n_tape, char** out) {
+  GUARD_BEGIN
+  std::vector<Fr> t(n_tape);
+  for (size_t i = 0; i < n_tape; i++) memcpy(t[i].l, tape + 32 * i, 32);
+  TapeRng rng(t);
+  NamedFr sh;
+  gen_shares_policy(fr_from_bytes(secret), parse_policy(policy, lang_of(language)), rng, &sh);
+  return give_text(named_json(sh), out);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_coeffs(const char* policy, int32_t language, char** out) {
+  GUARD_BEGIN
+  NamedFr c;
+  calc_coefficients(parse_policy(policy, lang_of(language)), fr_one(), &c);
+  return give_text(named_json(c), out);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_encrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, const uint8_t nonce[12], uint8_t** out, size_t* out_len) {
+  GUARD_BEGIN
+  return give_bytes(encrypt_symmetric(gt, data, len, nonce), out, out_len);
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_decrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) {
+  GUARD_BEGIN
+  Bytes pt;
+  if (!decrypt_symmetric(gt, data, len, &pt)) { set_err(nullptr, "decryption error: aead::Error"); return -1; }
+  return give_bytes(pt, out, out_len);
+  GUARD_END((rabe_host*)nullptr)
+}
+
+}  // extern "C"

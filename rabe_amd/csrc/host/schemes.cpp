@@ -1,0 +1,731 @@
+// Host layer implementation: Engine wrapper + rabe::schemes::{ac17,bsw,lsw,aw11} over the C ABI.
+// String / Fr work happens here exactly where the reference does it on the CPU; every group operation is a
+// batched launch of the HIP engine (no CPU group arithmetic exists in this layer).
+#include "schemes.h"
+
+#include <stdio.h>
+#include <sys/random.h>
+
+namespace rabe {
+
+using namespace host;
+
+// ------------------------------------------------------------------------------------------------ Rng / Engine
+void OsRng::fill(uint8_t* out, size_t n) {
+  size_t off = 0;
+  while (off < n) {
+    ssize_t r = getrandom(out + off, n - off, 0);
+    if (r <= 0) throw RabeError("getrandom failed");
+    off += (size_t)r;
+  }
+}
+
+Engine::Engine(int device) {
+  int32_t rc = rhip_ctx_create(device, &ctx_);
+  if (rc != RHIP_OK) throw RabeError(std::string("no usable HIP device: ") + rhip_last_error(nullptr));
+}
+Engine::~Engine() { rhip_ctx_destroy(ctx_); }
+void Engine::check(int32_t rc, const char* what) const {
+  if (rc != RHIP_OK) throw RabeError(std::string(what) + " failed: " + rhip_last_error(ctx_));
+}
+
+DBuf::DBuf(Engine* e, size_t bytes) : eng_(e), n_(bytes) { e->check(rhip_malloc(e->ctx(), bytes ? bytes : 4, &p_), "rhip_malloc"); }
+DBuf::DBuf(Engine* e, const void* host_data, size_t bytes) : DBuf(e, bytes) {
+  if (bytes) e->check(rhip_upload(e->ctx(), p_, host_data, bytes), "rhip_upload");
+}
+DBuf::~DBuf() { if (p_) rhip_free(eng_->ctx(), p_); }
+DBuf& DBuf::operator=(DBuf&& o) noexcept {
+  if (this != &o) { if (p_) rhip_free(eng_->ctx(), p_); eng_ = o.eng_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; }
+  return *this;
+}
+void DBuf::download(void* host, size_t bytes) const { if (bytes) eng_->check(rhip_download(eng_->ctx(), host, p_, bytes), "rhip_download"); }
+
+template <class OUT, size_t N>
+static std::vector<std::array<uint8_t, N>> unflatten(const std::vector<uint8_t>& raw) {
+  std::vector<std::array<uint8_t, N>> v(raw.size() / N);
+  for (size_t i = 0; i < v.size(); i++) memcpy(v[i].data(), raw.data() + i * N, N);
+  return v;
+}
+template <size_t N>
+static std::vector<std::array<uint8_t, N>> fetch(const DBuf& d, size_t n) {
+  std::vector<uint8_t> raw(n * N);
+  d.download(raw.data(), raw.size());
+  return unflatten<void, N>(raw);
+}
+
+std::vector<G1> Engine::g1_mul(const std::vector<G1>& p, const std::vector<Fr>& k) {
+  size_t n = p.size();
+  auto fp = flatten(p); auto fk = flatten_fr(k);
+  DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 64);
+  check(rhip_g1_mul(ctx_, n, dp.as<rhip_g1>(), dk.as<rhip_fr>(), out.as<rhip_g1>()), "rhip_g1_mul");
+  return fetch<64>(out, n);
+}
+std::vector<G2> Engine::g2_mul(const std::vector<G2>& p, const std::vector<Fr>& k) {
+  size_t n = p.size();
+  auto fp = flatten(p); auto fk = flatten_fr(k);
+  DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 128);
+  check(rhip_g2_mul(ctx_, n, dp.as<rhip_g2>(), dk.as<rhip_fr>(), out.as<rhip_g2>()), "rhip_g2_mul");
+  return fetch<128>(out, n);
+}
+std::vector<Gt> Engine::gt_pow(const std::vector<Gt>& a, const std::vector<Fr>& k) {
+  size_t n = a.size();
+  auto fa = flatten(a); auto fk = flatten_fr(k);
+  DBuf da(this, fa.data(), fa.size()), dk(this, fk.data(), fk.size()), out(this, n * 384);
+  check(rhip_gt_pow(ctx_, n, da.as<rhip_gt>(), dk.as<rhip_fr>(), out.as<rhip_gt>()), "rhip_gt_pow");
+  return fetch<384>(out, n);
+}
+std::vector<Gt> Engine::gt_mul(const std::vector<Gt>& a, const std::vector<Gt>& b) {
+  size_t n = a.size();
+  auto fa = flatten(a); auto fb = flatten(b);
+  DBuf da(this, fa.data(), fa.size()), db(this, fb.data(), fb.size()), out(this, n * 384);
+  check(rhip_gt_mul(ctx_, n, da.as<rhip_gt>(), db.as<rhip_gt>(), out.as<rhip_gt>()), "rhip_gt_mul");
+  return fetch<384>(out, n);
+}
+std::vector<Gt> Engine::pairing(const std::vector<G1>& p, const std::vector<G2>& q) {
+  size_t n = p.size();
+  auto fp = flatten(p); auto fq = flatten(q);
+  DBuf dp(this, fp.data(), fp.size()), dq(this, fq.data(), fq.size()), out(this, n * 384);
+  check(rhip_pairing(ctx_, n, dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()), "rhip_pairing");
+  return fetch<384>(out, n);
+}
+Gt Engine::random_gt(Rng& rng) {
+  if (!have_e_) { e_gen_ = pairing({g1_generator()}, {g2_generator()})[0]; have_e_ = true; }
+  return gt_pow({e_gen_}, {rng.next_fr()})[0];
+}
+
+// small helpers over Level E used by the schemes below
+static std::vector<G2> g2_add(Engine& e, const std::vector<G2>& a, const std::vector<G2>& b) {
+  size_t n = a.size();
+  auto fa = flatten(a); auto fb = flatten(b);
+  DBuf da(&e, fa.data(), fa.size()), db(&e, fb.data(), fb.size()), out(&e, n * 128);
+  e.check(rhip_g2_add(e.ctx(), n, da.as<rhip_g2>(), db.as<rhip_g2>(), out.as<rhip_g2>()), "rhip_g2_add");
+  return fetch<128>(out, n);
+}
+static std::vector<G1> g1_add(Engine& e, const std::vector<G1>& a, const std::vector<G1>& b) {
+  size_t n = a.size();
+  auto fa = flatten(a); auto fb = flatten(b);
+  DBuf da(&e, fa.data(), fa.size()), db(&e, fb.data(), fb.size()), out(&e, n * 64);
+  e.check(rhip_g1_add(e.ctx(), n, da.as<rhip_g1>(), db.as<rhip_g1>(), out.as<rhip_g1>()), "rhip_g1_add");
+  return fetch<64>(out, n);
+}
+// prod_j e(p_j, q_j) with ONE final exponentiation
+static Gt pairing_product(Engine& e, const std::vector<G1>& p, const std::vector<G2>& q) {
+  uint32_t off[2] = {0, (uint32_t)p.size()};
+  auto fp = flatten(p); auto fq = flatten(q);
+  DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off, sizeof off), out(&e, 384);
+  e.check(rhip_pairing_product(e.ctx(), 1, doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()),
+          "rhip_pairing_product");
+  return fetch<384>(out, 1)[0];
+}
+static Gt gt_product(Engine& e, const std::vector<Gt>& v) {
+  if (v.empty()) { Gt one{}; one[0] = 1; return one; }
+  Gt acc = v[0];
+  for (size_t i = 1; i < v.size(); i++) acc = e.gt_mul({acc}, {v[i]})[0];
+  return acc;
+}
+static Fr must_inv(const Fr& a) {
+  Fr o;
+  if (!fr_inv(a, &o)) throw std::runtime_error("called `Option::unwrap()` on a `None` value (Fr::inverse of zero)");
+  return o;
+}
+static PolicyNode parse_or_error(const std::string& policy, PolicyLanguage lang) {
+  try {
+    return parse_policy(policy, lang);
+  } catch (const PolicyError& e) {
+    throw RabeError(std::string("Json Policy Error / parse: ") + e.what());
+  }
+}
+static Bytes seal(Rng& rng, const Gt& msg, const Bytes& plaintext) {       // encrypt_symmetric, aes/mod.rs:10-26
+  uint8_t nonce[12];
+  rng.fill(nonce, 12);
+  return encrypt_symmetric(msg.data(), plaintext.data(), plaintext.size(), nonce);
+}
+static Bytes open_or_error(const Gt& msg, const Bytes& ct) {               // decrypt_symmetric, aes/mod.rs:29-44
+  Bytes out;
+  if (!decrypt_symmetric(msg.data(), ct.data(), ct.size(), &out)) throw RabeError("decryption error: aead::Error");
+  return out;
+}
+
+namespace schemes {
+
+// ================================================================================================ AC17
+namespace ac17 {
+static const size_t ASSUMPTION_SIZE = 2;     // ac17/mod.rs:138
+
+std::pair<Ac17PublicKey, Ac17MasterKey> setup(Engine& eng, Rng& rng) {      // :141-182
+  G1 g = eng.random_g1(rng);
+  G2 h = eng.random_g2(rng);
+  Gt e_gh = eng.pairing({g}, {h})[0];
+  std::vector<Fr> a, b, k;
+  for (size_t i = 0; i < ASSUMPTION_SIZE; i++) { a.push_back(rng.next_fr()); b.push_back(rng.next_fr()); }
+  for (size_t i = 0; i < ASSUMPTION_SIZE + 1; i++) k.push_back(rng.next_fr());
+  std::vector<G2> h_a = eng.g2_mul({h, h}, {a[0], a[1]});
+  h_a.push_back(h);
+  std::vector<G1> g_k = eng.g1_mul({g, g, g}, k);
+  std::vector<Gt> e_gh_ka = eng.gt_pow({e_gh, e_gh}, {fr_add(fr_mul(k[0], a[0]), k[2]), fr_add(fr_mul(k[1], a[1]), k[2])});
+  return {Ac17PublicKey{g, h_a, e_gh_ka}, Ac17MasterKey{g, h, g_k, a, b}};
+}
+
+Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& attributes) {   // :191-264
+  if (attributes.empty()) throw RabeError("empty attributes!");
+  const size_t n = attributes.size();
+  // draw order: r0, r1, sigma per attribute (loop order), sigma'
+  std::vector<Fr> r{rng.next_fr(), rng.next_fr()};
+  std::vector<Fr> sigma;
+  for (size_t i = 0; i < n; i++) sigma.push_back(rng.next_fr());
+  Fr sigma_p = rng.next_fr();
+  std::vector<Fr> H, H01;
+  for (const auto& attr : attributes)
+    for (int l = 0; l < 3; l++)
+      for (int t = 0; t < 2; t++) H.push_back(sha3_hash_fr(attr + std::to_string(l) + std::to_string(t)));
+  for (int l = 0; l < 3; l++)
+    for (int t = 0; t < 2; t++) H01.push_back(sha3_hash_fr(std::string("01") + std::to_string(l) + std::to_string(t)));
+  std::vector<Fr> a_inv{must_inv(msk.a[0]), must_inv(msk.a[1])};
+  rhip_g1_table* gt = nullptr;
+  rhip_g2_table* ht = nullptr;
+  eng.check(rhip_g1_table_create(eng.ctx(), (const rhip_g1*)msk.g.data(), &gt), "rhip_g1_table_create");
+  eng.check(rhip_g2_table_create(eng.ctx(), (const rhip_g2*)msk.h.data(), &ht), "rhip_g2_table_create");
+  auto fgk = flatten(msk.g_k), fa = flatten_fr(a_inv), fb = flatten_fr(msk.b), fH = flatten_fr(H), fH01 = flatten_fr(H01), fr_ = flatten_fr(r),
+       fs = flatten_fr(sigma), fsp = flatten_fr({sigma_p});
+  DBuf dgk(&eng, fgk.data(), fgk.size()), da(&eng, fa.data(), fa.size()), db(&eng, fb.data(), fb.size()), dH(&eng, fH.data(), fH.size()),
+      dH01(&eng, fH01.data(), fH01.size()), dr(&eng, fr_.data(), fr_.size()), ds(&eng, fs.data(), fs.size()), dsp(&eng, fsp.data(), fsp.size());
+  DBuf dk0(&eng, 3 * 128), dk(&eng, n * 3 * 64), dkp(&eng, 3 * 64);
+  int32_t rc = rhip_ac17_cp_keygen_batch(eng.ctx(), gt, ht, dgk.as<rhip_g1>(), da.as<rhip_fr>(), db.as<rhip_fr>(), 1, n, dH.as<rhip_fr>(),
+                                         dH01.as<rhip_fr>(), dr.as<rhip_fr>(), ds.as<rhip_fr>(), dsp.as<rhip_fr>(), dk0.as<rhip_g2>(),
+                                         dk.as<rhip_g1>(), dkp.as<rhip_g1>());
+  std::vector<G2> k0;
+  std::vector<G1> k, kp;
+  if (rc == RHIP_OK) { k0 = fetch<128>(dk0, 3); k = fetch<64>(dk, n * 3); kp = fetch<64>(dkp, 3); }
+  rhip_g1_table_destroy(gt);
+  rhip_g2_table_destroy(ht);
+  eng.check(rc, "rhip_ac17_cp_keygen_batch");
+  Ac17CpSecretKey out;
+  out.attr = attributes;
+  out.sk.k_0 = k0;
+  for (size_t i = 0; i < n; i++) out.sk.k.push_back({attributes[i], {k[3 * i], k[3 * i + 1], k[3 * i + 2]}});
+  out.sk.k_p = kp;
+  return out;
+}
+
+// per-policy Fr table A[row][l][t] (SURVEY.md Appendix B.3 = ac17/mod.rs:305-348 with the hashes pre-combined)
+static std::vector<Fr> policy_table(const AbePolicy& msp) {
+  const size_t cols = msp.m.empty() ? 0 : msp.m[0].size();
+  std::vector<Fr> colh(cols * 6);
+  for (size_t j = 0; j < cols; j++)
+    for (int l = 0; l < 3; l++)
+      for (int t = 0; t < 2; t++)
+        colh[(j * 3 + l) * 2 + t] = sha3_hash_fr(std::string("0") + std::to_string(j + 1) + std::to_string(l) + std::to_string(t));
+  std::vector<Fr> A;
+  for (size_t i = 0; i < msp.m.size(); i++)
+    for (int l = 0; l < 3; l++)
+      for (int t = 0; t < 2; t++) {
+        Fr v = sha3_hash_fr(msp.pi[i] + std::to_string(l) + std::to_string(t));
+        for (size_t j = 0; j < cols; j++) {
+          if (msp.m[i][j] == 1) v = fr_add(v, colh[(j * 3 + l) * 2 + t]);
+          else if (msp.m[i][j] == -1) v = fr_sub(v, colh[(j * 3 + l) * 2 + t]);
+        }
+        A.push_back(v);
+      }
+  return A;
+}
+
+std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies,
+                                               const std::vector<Bytes>& plaintexts, PolicyLanguage language) {
+  const size_t n = policies.size();
+  if (plaintexts.size() != n) throw RabeError("cp_encrypt_batch: policies / plaintexts length mismatch");
+  // host: parse + MSP once per distinct policy string
+  std::map<std::string, size_t> index;
+  std::vector<AbePolicy> msps;
+  std::vector<uint32_t> a_off{0};
+  std::vector<Fr> A;
+  std::vector<size_t> item_pol(n);
+  for (size_t i = 0; i < n; i++) {
+    auto it = index.find(policies[i]);
+    if (it == index.end()) {
+      PolicyNode tree = parse_or_error(policies[i], language);
+      AbePolicy msp = calculate_msp(tree);
+      std::vector<Fr> tab = policy_table(msp);
+      A.insert(A.end(), tab.begin(), tab.end());
+      a_off.push_back(a_off.back() + (uint32_t)msp.m.size());
+      msps.push_back(std::move(msp));
+      it = index.insert({policies[i], msps.size() - 1}).first;
+    }
+    item_pol[i] = it->second;
+  }
+  // randomness in the reference's per-call draw order: s0, s1, msg, nonce -- item after item
+  std::vector<Fr> s;
+  std::vector<Gt> msgs;
+  std::vector<std::array<uint8_t, 12>> nonces(n);
+  for (size_t i = 0; i < n; i++) {
+    s.push_back(rng.next_fr());
+    s.push_back(rng.next_fr());
+    msgs.push_back(eng.random_gt(rng));
+    rng.fill(nonces[i].data(), 12);
+  }
+  std::vector<uint32_t> item_a_off(n), row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) {
+    item_a_off[i] = a_off[item_pol[i]];
+    row_off[i + 1] = row_off[i] + (uint32_t)msps[item_pol[i]].m.size();
+  }
+  const size_t total_rows = row_off[n];
+  rhip_ac17_pk* dpk = nullptr;
+  auto fha = flatten(pk.h_a), fe = flatten(pk.e_gh_ka);
+  eng.check(rhip_ac17_pk_create(eng.ctx(), (const rhip_g1*)pk.g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk),
+            "rhip_ac17_pk_create");
+  auto fA = flatten_fr(A), fs = flatten_fr(s), fm = flatten(msgs);
+  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, item_a_off.data(), n * 4), dro(&eng, row_off.data(), (n + 1) * 4), ds(&eng, fs.data(), fs.size()),
+      dm(&eng, fm.data(), fm.size()), dc0(&eng, n * 3 * 128), dc(&eng, total_rows * 3 * 64), dcp(&eng, n * 384);
+  int32_t rc = rhip_ac17_cp_encrypt_batch(eng.ctx(), dpk, n, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), total_rows,
+                                          ds.as<rhip_fr>(), dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>());
+  std::vector<G2> c0;
+  std::vector<G1> c;
+  std::vector<Gt> cp;
+  if (rc == RHIP_OK) { c0 = fetch<128>(dc0, n * 3); c = fetch<64>(dc, total_rows * 3); cp = fetch<384>(dcp, n); }
+  rhip_ac17_pk_destroy(dpk);
+  eng.check(rc, "rhip_ac17_cp_encrypt_batch");
+  std::vector<Ac17CpCiphertext> out(n);
+  for (size_t i = 0; i < n; i++) {
+    const AbePolicy& msp = msps[item_pol[i]];
+    out[i].policy = {policies[i], language};
+    out[i].ct.c_0 = {c0[3 * i], c0[3 * i + 1], c0[3 * i + 2]};
+    for (size_t r = 0; r < msp.m.size(); r++) {
+      size_t g = (size_t)row_off[i] + r;
+      out[i].ct.c.push_back({msp.pi[r], {c[3 * g], c[3 * g + 1], c[3 * g + 2]}});
+    }
+    out[i].ct.c_p = cp[i];
+    out[i].ct.ct = encrypt_symmetric(msgs[i].data(), plaintexts[i].data(), plaintexts[i].size(), nonces[i].data());
+  }
+  return out;
+}
+
+Ac17CpCiphertext cp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::string& policy, const Bytes& plaintext,
+                            PolicyLanguage language) {
+  return cp_encrypt_batch(eng, rng, pk, {policy}, {plaintext}, language)[0];
+}
+
+// Gt of n decrypt calls; errors[i] non-empty when item i does not decrypt (no group work is done for it)
+static std::vector<Gt> decrypt_gts(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks, const std::vector<const Ac17CpCiphertext*>& cts,
+                                   std::vector<std::string>* errors) {
+  const size_t n = cts.size();
+  errors->assign(n, "");
+  std::vector<uint8_t> ct_c0, ct_c, ct_cp, sk_k0, sk_k, sk_kp;
+  std::vector<uint32_t> ct_row_off{0}, sk_row_off{0}, sk_idx, ct_sel, sk_sel, ct_sel_off{0}, sk_sel_off{0};
+  std::vector<size_t> live;
+  for (size_t i = 0; i < n; i++) {
+    const Ac17CpSecretKey& sk = *sks[i];
+    const Ac17CpCiphertext& ct = *cts[i];
+    PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+    if (!traverse_policy(sk.attr, tree)) { (*errors)[i] = "Error in cp_decrypt: attributes in SK do not match policy in CT."; continue; }
+    PrunedList lst;
+    if (!calc_pruned(sk.attr, tree, &lst)) { (*errors)[i] = "Error: attributes in sk do not match policy in ct."; continue; }
+    // the name-matching loops of :403-414, as index lists
+    for (const auto& cur : lst) {
+      for (size_t r = 0; r < ct.ct.c.size(); r++) if (ct.ct.c[r].first == cur.first) ct_sel.push_back((uint32_t)r);
+      for (size_t r = 0; r < sk.sk.k.size(); r++) if (sk.sk.k[r].first == cur.first) sk_sel.push_back((uint32_t)r);
+    }
+    ct_sel_off.push_back((uint32_t)ct_sel.size());
+    sk_sel_off.push_back((uint32_t)sk_sel.size());
+    for (const auto& x : ct.ct.c_0) ct_c0.insert(ct_c0.end(), x.begin(), x.end());
+    for (const auto& row : ct.ct.c) for (const auto& x : row.second) ct_c.insert(ct_c.end(), x.begin(), x.end());
+    ct_cp.insert(ct_cp.end(), ct.ct.c_p.begin(), ct.ct.c_p.end());
+    ct_row_off.push_back(ct_row_off.back() + (uint32_t)ct.ct.c.size());
+    for (const auto& x : sk.sk.k_0) sk_k0.insert(sk_k0.end(), x.begin(), x.end());
+    for (const auto& row : sk.sk.k) for (const auto& x : row.second) sk_k.insert(sk_k.end(), x.begin(), x.end());
+    for (const auto& x : sk.sk.k_p) sk_kp.insert(sk_kp.end(), x.begin(), x.end());
+    sk_row_off.push_back(sk_row_off.back() + (uint32_t)sk.sk.k.size());
+    sk_idx.push_back((uint32_t)live.size());
+    live.push_back(i);
+  }
+  std::vector<Gt> out(n);
+  const size_t m = live.size();
+  if (!m) return out;
+  DBuf d1(&eng, ct_c0.data(), ct_c0.size()), d2(&eng, ct_c.data(), ct_c.size()), d3(&eng, ct_row_off.data(), ct_row_off.size() * 4),
+      d4(&eng, ct_cp.data(), ct_cp.size()), d5(&eng, sk_k0.data(), sk_k0.size()), d6(&eng, sk_k.data(), sk_k.size()),
+      d7(&eng, sk_row_off.data(), sk_row_off.size() * 4), d8(&eng, sk_kp.data(), sk_kp.size()), d9(&eng, sk_idx.data(), sk_idx.size() * 4),
+      d10(&eng, ct_sel.data(), ct_sel.size() * 4), d11(&eng, ct_sel_off.data(), ct_sel_off.size() * 4), d12(&eng, sk_sel.data(), sk_sel.size() * 4),
+      d13(&eng, sk_sel_off.data(), sk_sel_off.size() * 4), dout(&eng, m * 384);
+  eng.check(rhip_ac17_cp_decrypt_batch(eng.ctx(), m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), d5.as<rhip_g2>(),
+                                       d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
+                                       d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>()),
+            "rhip_ac17_cp_decrypt_batch");
+  std::vector<Gt> got = fetch<384>(dout, m);
+  for (size_t j = 0; j < m; j++) out[live[j]] = got[j];
+  return out;
+}
+
+std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks,
+                                            const std::vector<const Ac17CpCiphertext*>& cts) {
+  std::vector<std::string> errors;
+  std::vector<Gt> gts = decrypt_gts(eng, sks, cts, &errors);
+  std::vector<DecryptResult> out(cts.size());
+  for (size_t i = 0; i < cts.size(); i++) {
+    if (!errors[i].empty()) { out[i] = {false, {}, errors[i]}; continue; }
+    Bytes pt;
+    if (decrypt_symmetric(gts[i].data(), cts[i]->ct.ct.data(), cts[i]->ct.ct.size(), &pt)) out[i] = {true, pt, ""};
+    else out[i] = {false, {}, "decryption error: aead::Error"};
+  }
+  return out;
+}
+Gt cp_decrypt_gt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct) {
+  std::vector<std::string> errors;
+  std::vector<Gt> g = decrypt_gts(eng, {&sk}, {&ct}, &errors);
+  if (!errors[0].empty()) throw RabeError(errors[0]);
+  return g[0];
+}
+Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct) {     // :385-430
+  return open_or_error(cp_decrypt_gt(eng, sk, ct), ct.ct.ct);
+}
+}  // namespace ac17
+
+// ================================================================================================ BSW
+namespace bsw {
+std::pair<CpAbePublicKey, CpAbeMasterKey> setup(Engine& eng, Rng& rng) {       // :92-114
+  G1 g1 = eng.random_g1(rng);
+  G2 g2 = eng.random_g2(rng);
+  Fr beta = rng.next_fr();
+  Fr alpha = rng.next_fr();
+  G1 h = eng.g1_mul({g1}, {beta})[0];
+  std::vector<G2> fa = eng.g2_mul({g2, g2}, {must_inv(beta), alpha});
+  Gt e = eng.pairing({g1}, {fa[1]})[0];
+  return {CpAbePublicKey{g1, g2, h, fa[0], e}, CpAbeMasterKey{beta, fa[1]}};
+}
+bool keygen(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::string>& attributes,
+            CpAbeSecretKey* out) {      // :125-152
+  if (attributes.empty()) return false;
+  Fr r = rng.next_fr();
+  G2 g2_r = eng.g2_mul({pk.g2}, {r})[0];
+  G2 sum = g2_add(eng, {msk.g2_alpha}, {g2_r})[0];
+  out->d = eng.g2_mul({sum}, {must_inv(msk.beta)})[0];
+  out->d_j.clear();
+  std::vector<Fr> rj, hr;
+  for (const auto& j : attributes) {
+    Fr x = rng.next_fr();
+    rj.push_back(x);
+    hr.push_back(fr_mul(sha3_hash_fr(j), x));          // (g2*h(j))*r_j = g2*(h(j) r_j)
+  }
+  std::vector<G1> a1 = eng.g1_mul(std::vector<G1>(attributes.size(), pk.g1), rj);
+  std::vector<G2> a2 = eng.g2_mul(std::vector<G2>(attributes.size(), pk.g2), hr);
+  a2 = g2_add(eng, std::vector<G2>(attributes.size(), g2_r), a2);
+  for (size_t i = 0; i < attributes.size(); i++) out->d_j.push_back({attributes[i], a1[i], a2[i]});
+  return true;
+}
+CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::string& policy, PolicyLanguage language,
+                        const Bytes& plaintext) {       // :217-251
+  Fr secret = rng.next_fr();
+  Gt msg = eng.random_gt(rng);
+  PolicyNode tree = parse_or_error(policy, language);
+  NamedFr shares;
+  gen_shares_policy(secret, tree, rng, &shares);
+  CpAbeCiphertext ct;
+  ct.policy = {policy, language};
+  ct.c = eng.g1_mul({pk.h}, {secret})[0];
+  ct.c_p = eng.gt_mul({eng.gt_pow({pk.e_gg_alpha}, {secret})[0]}, {msg})[0];
+  std::vector<Fr> k1, k2;
+  for (const auto& sh : shares) {
+    k1.push_back(sh.second);
+    k2.push_back(fr_mul(sha3_hash_fr(remove_index(sh.first)), sh.second));
+  }
+  std::vector<G1> p1 = eng.g1_mul(std::vector<G1>(shares.size(), pk.g1), k1);
+  std::vector<G2> p2 = eng.g2_mul(std::vector<G2>(shares.size(), pk.g2), k2);
+  for (size_t i = 0; i < shares.size(); i++) ct.c_y.push_back({shares[i].first, p1[i], p2[i]});
+  ct.data = seal(rng, msg, plaintext);
+  return ct;
+}
+Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) {       // :260-308
+  std::vector<std::string> attr;
+  for (const auto& v : sk.d_j) attr.push_back(v.string);
+  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  if (!traverse_policy(attr, tree)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
+  PrunedList pruned;
+  if (!calc_pruned(attr, tree, &pruned)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
+  NamedFr z;
+  calc_coefficients(tree, fr_one(), &z);
+  // msg = c_p * A / e(c, d),  A = prod ( e(Cy.g1, Dj.g2) / e(Dj.g1, Cy.g2) )^z
+  //     = c_p * FE( ML(-c, d) * prod ML(z Cy.g1, Dj.g2) ML(-z Dj.g1, Cy.g2) )        
+  std::vector<G1> base;
+  std::vector<Fr> scal;
+  std::vector<G2> q;
+  base.push_back(ct.c); scal.push_back(fr_neg(fr_one())); q.push_back(sk.d);
+  for (const auto& pr : pruned) {
+    const CpAbeAttribute* cy = nullptr;
+    const CpAbeAttribute* dj = nullptr;
+    for (const auto& x : ct.c_y) if (x.string == pr.second) { cy = &x; break; }
+    if (!cy) continue;
+    for (const auto& x : sk.d_j) if (x.string == pr.first) { dj = &x; break; }
+    if (!dj) continue;
+    for (const auto& zt : z) {
+      if (zt.first == pr.second) {
+        base.push_back(cy->g1); scal.push_back(zt.second); q.push_back(dj->g2);
+        base.push_back(dj->g1); scal.push_back(fr_neg(zt.second)); q.push_back(cy->g2);
+      }
+    }
+  }
+  std::vector<G1> p = eng.g1_mul(base, scal);
+  Gt prod = pairing_product(eng, p, q);
+  return eng.gt_mul({ct.c_p}, {prod})[0];
+}
+Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.data); }
+}  // namespace bsw
+
+// ================================================================================================ LSW
+namespace lsw {
+std::pair<KpAbePublicKey, KpAbeMasterKey> setup(Engine& eng, Rng& rng) {         // :86-110
+  Fr alpha1 = rng.next_fr(), alpha2 = rng.next_fr(), b = rng.next_fr();
+  Fr alpha = fr_mul(alpha1, alpha2);
+  G1 g1 = eng.random_g1(rng);
+  G2 g2 = eng.random_g2(rng);
+  G1 h_g1 = eng.random_g1(rng);
+  G2 h_g2 = eng.random_g2(rng);
+  std::vector<G1> m = eng.g1_mul({g1, g1, h_g1}, {b, fr_mul(b, b), b});
+  Gt e = eng.gt_pow({eng.pairing({g1}, {g2})[0]}, {alpha})[0];
+  return {KpAbePublicKey{g1, g2, m[0], m[1], m[2], e}, KpAbeMasterKey{alpha1, alpha2, b, h_g1, h_g2}};
+}
+static G1 g1_zero() { G1 z{}; return z; }
+static G2 g2_zero() { G2 z{}; return z; }
+KpAbeSecretKey keygen(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::string& policy,
+                      PolicyLanguage language) {        // :121-170
+  PolicyNode tree = parse_or_error(policy, language);
+  NamedFr shares;
+  gen_shares_policy(msk.alpha1, tree, rng, &shares);
+  KpAbeSecretKey sk;
+  sk.policy = {policy, language};
+  // one `random` per share, in share order (drawn inside the loop at :136)
+  std::vector<G1> b1;
+  std::vector<Fr> k1;
+  std::vector<G2> b2;
+  std::vector<Fr> k2;
+  struct Slot { bool neg; size_t i1, i2; };
+  std::vector<Slot> slots;
+  for (const auto& sh : shares) {
+    std::string striped = remove_index(sh.first);
+    Fr random = rng.next_fr();
+    Slot s{is_negative(striped), b1.size(), b2.size()};
+    if (s.neg) {
+      Fr share_hash = sha3_hash_fr(striped);
+      // d3 = g1*share + g1_b2*random ; d4 = g1_b*(hash*random) + h_g1*random ; d5 = g1*(-random)
+      b1.push_back(pk.g1); k1.push_back(sh.second);
+      b1.push_back(pk.g1_b2); k1.push_back(random);
+      b1.push_back(pk.g1_b); k1.push_back(fr_mul(share_hash, random));
+      b1.push_back(msk.h_g1); k1.push_back(random);
+      b1.push_back(pk.g1); k1.push_back(fr_neg(random));
+    } else {
+      // d1 = g1*(alpha2*share) + (g1*h(y))*random = g1*(alpha2*share + h(y)*random) ; d2 = g2*random
+      b1.push_back(pk.g1); k1.push_back(fr_add(fr_mul(msk.alpha2, sh.second), fr_mul(sha3_hash_fr(striped), random)));
+      b2.push_back(pk.g2); k2.push_back(random);
+    }
+    slots.push_back(s);
+    sk.dj.push_back({striped, g1_zero(), g2_zero(), g1_zero(), g1_zero(), g1_zero()});
+  }
+  std::vector<G1> r1 = b1.empty() ? std::vector<G1>() : eng.g1_mul(b1, k1);
+  std::vector<G2> r2 = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
+  for (size_t i = 0; i < slots.size(); i++) {
+    if (slots[i].neg) {
+      size_t o = slots[i].i1;
+      sk.dj[i].d3 = g1_add(eng, {r1[o]}, {r1[o + 1]})[0];
+      sk.dj[i].d4 = g1_add(eng, {r1[o + 2]}, {r1[o + 3]})[0];
+      sk.dj[i].d5 = r1[o + 4];
+    } else {
+      sk.dj[i].d1 = r1[slots[i].i1];
+      sk.dj[i].d2 = r2[slots[i].i2];
+    }
+  }
+  return sk;
+}
+KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::string>& attributes, const Bytes& plaintext) {   // :180-219
+  if (attributes.empty() || plaintext.empty()) throw RabeError("attributes or data empty");
+  Fr secret = rng.next_fr();
+  std::vector<Fr> sx{secret};
+  for (size_t i = 0; i < attributes.size(); i++) {
+    sx.push_back(rng.next_fr());
+    sx[0] = fr_sub(sx[0], sx[i]);       // the reference's index quirk (:197-200): subtracts sx[i], not the new element
+  }
+  std::vector<G1> base;
+  std::vector<Fr> k;
+  for (size_t i = 0; i < attributes.size(); i++) {
+    Fr h = sha3_hash_fr(attributes[i]);
+    base.push_back(pk.g1); k.push_back(fr_mul(h, secret));                 // (g1*h(a))*secret
+    base.push_back(pk.g1_b); k.push_back(sx[i]);
+    base.push_back(pk.g1_b2); k.push_back(fr_mul(sx[i], h));
+    base.push_back(pk.h_b); k.push_back(sx[i]);
+  }
+  std::vector<G1> r = eng.g1_mul(base, k);
+  Gt msg = eng.random_gt(rng);
+  KpAbeCiphertext ct;
+  ct.e1 = eng.gt_mul({eng.gt_pow({pk.e_gg_alpha}, {secret})[0]}, {msg})[0];
+  ct.e2 = eng.g2_mul({pk.g2}, {secret})[0];
+  for (size_t i = 0; i < attributes.size(); i++) {
+    G1 e3 = g1_add(eng, {r[4 * i + 2]}, {r[4 * i + 3]})[0];
+    ct.ej.push_back({attributes[i], r[4 * i], r[4 * i + 1], e3});
+  }
+  ct.ct = seal(rng, msg, plaintext);
+  return ct;
+}
+Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) {      // :228-290
+  std::vector<std::string> attr;
+  for (const auto& a : ct.ej) attr.push_back(a.name);
+  PolicyNode tree = parse_or_error(sk.policy.first, sk.policy.second);
+  PrunedList list;
+  if (!calc_pruned(attr, tree, &list)) throw RabeError("Error in lsw/decrypt: attributes do not match policy.");
+  NamedFr coeff_list;
+  calc_coefficients(tree, fr_one(), &coeff_list);
+  // prod_t = prod z_y^coeff with z_y = e(D1, e2) / e(E1, D2) for positive leaves; a negative leaf re-uses the
+  // previous z_y (the reference's TODO branch, :265-278).  msg = e1 / prod_t
+  //   = e1 * FE( prod ML(-c*D1, e2) * ML(c*E1, D2) ).
+  std::vector<G1> base;
+  std::vector<Fr> scal;
+  std::vector<G2> q;
+  const KpAbeKeyRow* cur_sk = nullptr;
+  const KpAbeCtRow* cur_ct = nullptr;
+  for (const auto& a : list) {
+    const KpAbeKeyRow* sk_attr = nullptr;
+    const KpAbeCtRow* ct_attr = nullptr;
+    const Fr* coeff = nullptr;
+    for (const auto& x : sk.dj) if (x.name == a.first) { sk_attr = &x; break; }
+    for (const auto& x : ct.ej) if (x.name == a.first) { ct_attr = &x; break; }
+    for (const auto& x : coeff_list) if (x.first == a.second) { coeff = &x.second; break; }
+    if (!sk_attr || !ct_attr || !coeff) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+    if (!is_negative(a.first)) { cur_sk = sk_attr; cur_ct = ct_attr; }
+    if (!cur_sk) continue;            // z_y still Gt::one()
+    base.push_back(cur_sk->d1); scal.push_back(fr_neg(*coeff)); q.push_back(ct.e2);
+    base.push_back(cur_ct->e1); scal.push_back(*coeff); q.push_back(cur_sk->d2);
+  }
+  if (base.empty()) return ct.e1;
+  std::vector<G1> p = eng.g1_mul(base, scal);
+  return eng.gt_mul({ct.e1}, {pairing_product(eng, p, q)})[0];
+}
+Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
+}  // namespace lsw
+
+// ================================================================================================ AW11
+namespace aw11 {
+static std::string upper(const std::string& s) {
+  std::string o = s;
+  for (auto& c : o) if (c >= 'a' && c <= 'z') c = (char)(c - 'a' + 'A');      // ASCII part of str::to_uppercase
+  return o;
+}
+Aw11GlobalKey setup(Engine& eng, Rng& rng) { G1 a = eng.random_g1(rng); G2 b = eng.random_g2(rng); return Aw11GlobalKey{a, b}; }   // :100-108
+bool authgen(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<std::string>& attributes, Aw11PublicKey* pk, Aw11MasterKey* msk) {   // :121-151
+  if (attributes.empty()) return false;
+  pk->attr.clear();
+  msk->attr.clear();
+  std::vector<Fr> alphas, ys;
+  for (const auto& a : attributes) {
+    Fr alpha = rng.next_fr(), y = rng.next_fr();
+    msk->attr.push_back({upper(a), alpha, y});
+    alphas.push_back(alpha);
+    ys.push_back(y);
+  }
+  Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];         // the reference recomputes this constant per attribute (:144)
+  std::vector<Gt> e = eng.gt_pow(std::vector<Gt>(attributes.size(), egg), alphas);
+  std::vector<G2> g = eng.g2_mul(std::vector<G2>(attributes.size(), gk.g2), ys);
+  for (size_t i = 0; i < attributes.size(); i++) pk->attr.push_back({upper(attributes[i]), e[i], g[i]});
+  return true;
+}
+void add_to_attribute(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::string& attribute, Aw11SecretKey* sk) {   // :200-231
+  if (attribute.empty()) throw RabeError("empty _attributes");
+  if (sk->gid.empty()) throw RabeError("empty _gid");
+  const Aw11MkAttr* auth = nullptr;
+  for (const auto& a : msk.attr) if (a.name == attribute) { auth = &a; break; }
+  if (!auth) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+  // g1*alpha + (g1*h(gid))*y = g1*(alpha + h(gid) y)
+  Fr k = fr_add(auth->alpha, fr_mul(sha3_hash_fr(sk->gid), auth->y));
+  sk->attr.push_back({upper(auth->name), eng.g1_mul({gk.g1}, {k})[0]});
+}
+Aw11SecretKey keygen(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::string& name,
+                     const std::vector<std::string>& attributes) {       // :165-190
+  if (attributes.empty()) throw RabeError("empty _attributes");
+  if (name.empty()) throw RabeError("empty _name");
+  Aw11SecretKey sk{name, {}};
+  for (const auto& a : attributes) add_to_attribute(eng, gk, msk, a, &sk);
+  return sk;
+}
+Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::string& policy,
+                       PolicyLanguage language, const Bytes& data) {       // :241-289
+  PolicyNode tree = parse_or_error(policy, language);
+  (void)calculate_msp(tree);           // built and unused in the reference (:253-255) -- but it must not panic
+  Fr s = rng.next_fr();
+  NamedFr s_shares, w_shares;
+  gen_shares_policy(s, tree, rng, &s_shares);
+  gen_shares_policy(fr_zero(), tree, rng, &w_shares);
+  Gt msg = eng.random_gt(rng);
+  Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];
+  Aw11Ciphertext ct;
+  ct.policy = {policy, language};
+  ct.c_0 = eng.gt_mul({msg}, {eng.gt_pow({egg}, {s})[0]})[0];
+  std::vector<Gt> gb;
+  std::vector<Fr> gk_;
+  std::vector<G2> b2;
+  std::vector<Fr> k2;
+  std::vector<std::string> names;
+  for (size_t i = 0; i < s_shares.size(); i++) {
+    Fr r_x = rng.next_fr();
+    std::string up = upper(s_shares[i].first);
+    const Aw11PkAttr* pa = nullptr;
+    std::string want = remove_index(up);
+    for (const auto* pk : pks) {
+      for (const auto& t : pk->attr) if (t.name == want) { pa = &t; break; }
+      if (pa) break;
+    }
+    if (!pa) continue;
+    names.push_back(up);
+    gb.push_back(egg); gk_.push_back(s_shares[i].second);
+    gb.push_back(pa->egg_alpha); gk_.push_back(r_x);
+    b2.push_back(gk.g2); k2.push_back(r_x);
+    b2.push_back(pa->g2_y); k2.push_back(r_x);
+    b2.push_back(gk.g2); k2.push_back(w_shares[i].second);
+  }
+  if (!names.empty()) {
+    std::vector<Gt> ge = eng.gt_pow(gb, gk_);
+    std::vector<G2> g2r = eng.g2_mul(b2, k2);
+    for (size_t i = 0; i < names.size(); i++) {
+      Gt c1 = eng.gt_mul({ge[2 * i]}, {ge[2 * i + 1]})[0];
+      G2 c3 = g2_add(eng, {g2r[3 * i + 1]}, {g2r[3 * i + 2]})[0];
+      ct.c.push_back({names[i], c1, g2r[3 * i], c3});
+    }
+  }
+  ct.ct = seal(rng, msg, data);
+  return ct;
+}
+Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {       // :298-366
+  std::vector<std::string> str_attr;
+  for (const auto& v : sk.attr) str_attr.push_back(v.first);
+  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  if (!traverse_policy(str_attr, tree)) throw RabeError("Error: attributes in sk do not match policy in ct.");
+  PrunedList list;
+  bool ok = calc_pruned(str_attr, tree, &list);
+  NamedFr coeff_list;
+  calc_coefficients(tree, fr_one(), &coeff_list);
+  if (!ok) throw RabeError("Error in aw11/decrypt: attributes in sk do not match policy in ct.");
+  // egg_s = prod ( C1 * e(H, C3) / e(K, C2) )^c ; msg = c_0 / egg_s
+  //       = c_0 * prod C1^(-c) * FE( prod ML(-c H, C3) ML(c K, C2) ),  H = g1*h(gid)        
+  G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];
+  std::vector<G1> base;
+  std::vector<Fr> scal;
+  std::vector<G2> q;
+  std::vector<Gt> c1s;
+  std::vector<Fr> c1k;
+  for (const auto& cur : list) {
+    const std::pair<std::string, G1>* sk_attr = nullptr;
+    const Aw11CtRow* ct_attr = nullptr;
+    const Fr* coeff = nullptr;
+    for (const auto& x : sk.attr) if (x.first == cur.first) { sk_attr = &x; break; }
+    for (const auto& x : ct.c) if (x.name == cur.second) { ct_attr = &x; break; }
+    for (const auto& x : coeff_list) if (x.first == cur.second) { coeff = &x.second; break; }
+    if (!sk_attr || !ct_attr || !coeff) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+    base.push_back(hash); scal.push_back(fr_neg(*coeff)); q.push_back(ct_attr->c3);
+    base.push_back(sk_attr->second); scal.push_back(*coeff); q.push_back(ct_attr->c2);
+    c1s.push_back(ct_attr->c1); c1k.push_back(fr_neg(*coeff));
+  }
+  if (base.empty()) return ct.c_0;
+  std::vector<G1> p = eng.g1_mul(base, scal);
+  Gt pr = pairing_product(eng, p, q);
+  Gt c1p = gt_product(eng, eng.gt_pow(c1s, c1k));
+  return eng.gt_mul({eng.gt_mul({ct.c_0}, {c1p})[0]}, {pr})[0];
+}
+Bytes decrypt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {
+  return open_or_error(decrypt_gt(eng, gk, sk, ct), ct.ct);
+}
+}  // namespace aw11
+
+}  // namespace schemes
+}  // namespace rabe

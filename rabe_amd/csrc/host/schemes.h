@@ -1,0 +1,96 @@
+// rabe::schemes::* in C++: the reference's scheme API (same function names, argument meaning and error
+// behaviour) with the group arithmetic executed by the HIP engine through the C ABI.
+//
+//   ac17  src/schemes/ac17/mod.rs:58-430   setup / cp_keygen / cp_encrypt / cp_decrypt   (+ *_batch)
+//   bsw   src/schemes/bsw/mod.rs:39-318    setup / keygen / encrypt / decrypt
+//   lsw   src/schemes/lsw/mod.rs:40-290    setup / keygen / encrypt / decrypt
+//   aw11  src/schemes/aw11/mod.rs:46-390   setup / authgen / keygen / encrypt / decrypt
+// Struct fields mirror the reference structs one for one.  Every function takes the Engine (GPU context) and,
+// where the reference draws from thread_rng(), an Rng, as its first arguments; the rest is the reference signature.
+#pragma once
+#include "common.h"
+
+namespace rabe { namespace schemes {
+
+typedef std::pair<std::string, PolicyLanguage> PolicyRef;
+
+namespace ac17 {
+struct Ac17PublicKey { G1 g; std::vector<G2> h_a; std::vector<Gt> e_gh_ka; };                  // :62-66
+struct Ac17MasterKey { G1 g; G2 h; std::vector<G1> g_k; std::vector<Fr> a; std::vector<Fr> b; };   // :72-78
+struct Ac17Ciphertext { std::vector<G2> c_0; std::vector<std::pair<std::string, std::vector<G1>>> c; Gt c_p; Bytes ct; };   // :84-89
+struct Ac17CpCiphertext { PolicyRef policy; Ac17Ciphertext ct; };                               // :95-98
+struct Ac17SecretKey { std::vector<G2> k_0; std::vector<std::pair<std::string, std::vector<G1>>> k; std::vector<G1> k_p; };   // :113-117
+struct Ac17CpSecretKey { std::vector<std::string> attr; Ac17SecretKey sk; };                    // :132-135
+
+std::pair<Ac17PublicKey, Ac17MasterKey> setup(Engine& eng, Rng& rng);
+Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& attributes);
+Ac17CpCiphertext cp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::string& policy, const Bytes& plaintext,
+                            PolicyLanguage language);
+Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct);
+// n independent calls in one engine launch set (the reason the engine exists); element i of the result
+// equals cp_encrypt(pk, policies[i], plaintexts[i]) with the randomness drawn item after item.
+std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies,
+                                               const std::vector<Bytes>& plaintexts, PolicyLanguage language);
+// per item: ok flag + plaintext or error text (a non-matching key fails its item, not the batch)
+struct DecryptResult { bool ok; Bytes plaintext; std::string error; };
+std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks,
+                                            const std::vector<const Ac17CpCiphertext*>& cts);
+// the Gt value handed to decrypt_symmetric (parity hook for tests; not part of the reference API)
+Gt cp_decrypt_gt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct);
+}  // namespace ac17
+
+namespace bsw {
+struct CpAbePublicKey { G1 g1; G2 g2; G1 h; G2 f; Gt e_gg_alpha; };            // :43-49
+struct CpAbeMasterKey { Fr beta; G2 g2_alpha; };                                // :55-58
+struct CpAbeAttribute { std::string string; G1 g1; G2 g2; };                    // :85-89
+struct CpAbeCiphertext { PolicyRef policy; G1 c; Gt c_p; std::vector<CpAbeAttribute> c_y; Bytes data; };   // :64-70
+struct CpAbeSecretKey { G2 d; std::vector<CpAbeAttribute> d_j; };               // :76-79
+
+std::pair<CpAbePublicKey, CpAbeMasterKey> setup(Engine& eng, Rng& rng);
+bool keygen(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::string>& attributes,
+            CpAbeSecretKey* out);     // Option<..>: false = None
+CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::string& policy, PolicyLanguage language,
+                        const Bytes& plaintext);
+Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);
+Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);
+}  // namespace bsw
+
+namespace lsw {
+struct KpAbePublicKey { G1 g1; G2 g2; G1 g1_b; G1 g1_b2; G1 h_b; Gt e_gg_alpha; };      // :44-51
+struct KpAbeMasterKey { Fr alpha1; Fr alpha2; Fr b; G1 h_g1; G2 h_g2; };                  // :57-63
+struct KpAbeKeyRow { std::string name; G1 d1; G2 d2; G1 d3; G1 d4; G1 d5; };              // (String, G1, G2, G1, G1, G1) :71
+struct KpAbeSecretKey { PolicyRef policy; std::vector<KpAbeKeyRow> dj; };                 // :69-72
+struct KpAbeCtRow { std::string name; G1 e1; G1 e2; G1 e3; };                             // (String, G1, G1, G1) :81
+struct KpAbeCiphertext { Gt e1; G2 e2; std::vector<KpAbeCtRow> ej; Bytes ct; };           // :78-83
+
+std::pair<KpAbePublicKey, KpAbeMasterKey> setup(Engine& eng, Rng& rng);
+KpAbeSecretKey keygen(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::string& policy,
+                      PolicyLanguage language);
+KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::string>& attributes, const Bytes& plaintext);
+Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct);
+Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct);
+}  // namespace lsw
+
+namespace aw11 {
+struct Aw11GlobalKey { G1 g1; G2 g2; };                                                    // :50-53
+struct Aw11PkAttr { std::string name; Gt egg_alpha; G2 g2_y; };
+struct Aw11PublicKey { std::vector<Aw11PkAttr> attr; };                                    // :59-61
+struct Aw11MkAttr { std::string name; Fr alpha; Fr y; };
+struct Aw11MasterKey { std::vector<Aw11MkAttr> attr; };                                    // :67-69
+struct Aw11CtRow { std::string name; Gt c1; G2 c2; G2 c3; };
+struct Aw11Ciphertext { PolicyRef policy; Gt c_0; std::vector<Aw11CtRow> c; Bytes ct; };   // :75-80
+struct Aw11SecretKey { std::string gid; std::vector<std::pair<std::string, G1>> attr; };   // :86-89
+
+Aw11GlobalKey setup(Engine& eng, Rng& rng);
+bool authgen(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<std::string>& attributes, Aw11PublicKey* pk,
+             Aw11MasterKey* msk);     // Option<..>
+Aw11SecretKey keygen(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::string& name,
+                     const std::vector<std::string>& attributes);
+void add_to_attribute(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::string& attribute, Aw11SecretKey* sk);
+Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::string& policy,
+                       PolicyLanguage language, const Bytes& data);
+Bytes decrypt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct);
+Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct);
+}  // namespace aw11
+
+}}  // namespace rabe::schemes

@@ -1,0 +1,244 @@
+"""ctypes binding of include/rabe_host.h: the C++ host layer (rabe::schemes::* mirror).  Plumbing only."""
+import ctypes
+import json
+
+from .engine import EngineError, load_library
+
+JSON_POLICY, HUMAN_POLICY = 0, 1
+
+KINDS = {"ac17_pk": 1, "ac17_msk": 2, "ac17_cp_sk": 3, "ac17_cp_ct": 4,
+         "bsw_pk": 10, "bsw_msk": 11, "bsw_sk": 12, "bsw_ct": 13,
+         "lsw_pk": 20, "lsw_msk": 21, "lsw_sk": 22, "lsw_ct": 23,
+         "aw11_gk": 30, "aw11_pk": 31, "aw11_msk": 32, "aw11_sk": 33, "aw11_ct": 34}
+
+
+class RabeError(Exception):
+    """`RabeError` of the reference (src/error.rs:19-28)."""
+
+
+class RabePanic(Exception):
+    """A condition on which the reference panics."""
+
+
+def _lib():
+    lib = load_library()
+    lib.rabe_host_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def _check(rc, host=None):
+    if rc == 0:
+        return
+    msg = _lib().rabe_host_last_error(host)
+    msg = msg.decode() if msg else ""
+    if rc == -2:
+        raise RabePanic(msg)
+    raise RabeError(msg)
+
+
+def _strs(items):
+    arr = (ctypes.c_char_p * max(1, len(items)))(*[s.encode("utf-8") for s in items])
+    return arr, ctypes.c_size_t(len(items))
+
+
+def _take_bytes(p, n):
+    out = ctypes.string_at(p, n.value)
+    _lib().rabe_bytes_free(p)
+    return out
+
+
+def _take_text(p):
+    s = ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8")
+    _lib().rabe_bytes_free(p)
+    return s
+
+
+class Obj:
+    """An opaque key / ciphertext object owned by the host layer."""
+
+    def __init__(self, kind, ptr):
+        self.kind, self.ptr = kind, ptr
+
+    def serialize(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib().rabe_obj_serialize(KINDS[self.kind], self.ptr, ctypes.byref(p), ctypes.byref(n)))
+        return _take_bytes(p, n)
+
+    @classmethod
+    def deserialize(cls, kind, data):
+        p = ctypes.c_void_p()
+        _check(_lib().rabe_obj_deserialize(KINDS[kind], data, ctypes.c_size_t(len(data)), ctypes.byref(p)))
+        return cls(kind, p)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib().rabe_obj_free(KINDS[self.kind], self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class Host:
+    """One GPU context + randomness source.  `Host()` fails loudly without a HIP device."""
+
+    def __init__(self, device=0):
+        self.lib = _lib()
+        h = ctypes.c_void_p()
+        rc = self.lib.rabe_host_create(ctypes.c_int32(device), ctypes.byref(h))
+        if rc != 0:
+            raise EngineError("rabe_host_create failed: %s" % (self.lib.rabe_host_last_error(None) or b"").decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.rabe_host_destroy(self.h)
+            self.h = None
+
+    def set_tape(self, fr_values):
+        """Explicit randomness: the following calls draw these Fr integers in the reference's draw order."""
+        data = b"".join(int(v).to_bytes(32, "little") for v in fr_values)
+        _check(self.lib.rabe_host_set_tape(self.h, data, ctypes.c_size_t(len(fr_values))), self.h)
+
+    def clear_tape(self):
+        _check(self.lib.rabe_host_set_tape(self.h, None, ctypes.c_size_t(0)), self.h)
+
+    def call(self, fn, *args):
+        rc = getattr(self.lib, fn)(self.h, *args)
+        if rc == 1:
+            return None
+        _check(rc, self.h)
+        return True
+
+    def out_bytes(self, fn, *args):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self.call(fn, *args, ctypes.byref(p), ctypes.byref(n))
+        return _take_bytes(p, n)
+
+    def out_gt(self, fn, *args):
+        buf = ctypes.create_string_buffer(384)
+        self.call(fn, *args, buf)
+        return buf.raw
+
+
+# ------------------------------------------------------------------ host-only policy utilities
+def policy_parse(policy, language=JSON_POLICY, out_language=JSON_POLICY):
+    p = ctypes.c_void_p()
+    _check(_lib().rabe_policy_parse(policy.encode(), language, out_language, ctypes.byref(p)))
+    return _take_text(p)
+
+
+def policy_msp(policy, language=JSON_POLICY):
+    p = ctypes.c_void_p()
+    _check(_lib().rabe_policy_msp(policy.encode(), language, ctypes.byref(p)))
+    return json.loads(_take_text(p))
+
+
+def policy_pruned(policy, attributes, language=JSON_POLICY):
+    arr, n = _strs(attributes)
+    p = ctypes.c_void_p()
+    _check(_lib().rabe_policy_pruned(policy.encode(), language, arr, n, ctypes.byref(p)))
+    d = json.loads(_take_text(p))
+    return d["match"], [tuple(x) for x in d["list"]]
+
+
+def policy_traverse(policy, attributes, language=JSON_POLICY):
+    arr, n = _strs(attributes)
+    r = ctypes.c_int32()
+    _check(_lib().rabe_policy_traverse(policy.encode(), language, arr, n, ctypes.byref(r)))
+    return bool(r.value)
+
+
+def policy_shares(policy, secret, tape, language=JSON_POLICY):
+    p = ctypes.c_void_p()
+    data = b"".join(int(v).to_bytes(32, "little") for v in tape)
+    _check(_lib().rabe_policy_shares(policy.encode(), language, int(secret).to_bytes(32, "little"), data, ctypes.c_size_t(len(tape)), ctypes.byref(p)))
+    return [(k, int.from_bytes(bytes.fromhex(v), "little")) for k, v in json.loads(_take_text(p))]
+
+
+def policy_coeffs(policy, language=JSON_POLICY):
+    p = ctypes.c_void_p()
+    _check(_lib().rabe_policy_coeffs(policy.encode(), language, ctypes.byref(p)))
+    return [(k, int.from_bytes(bytes.fromhex(v), "little")) for k, v in json.loads(_take_text(p))]
+
+
+def encrypt_symmetric(gt, data, nonce):
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    _check(_lib().rabe_encrypt_symmetric(gt, data, ctypes.c_size_t(len(data)), nonce, ctypes.byref(p), ctypes.byref(n)))
+    return _take_bytes(p, n)
+
+
+def decrypt_symmetric(gt, data):
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    _check(_lib().rabe_decrypt_symmetric(gt, data, ctypes.c_size_t(len(data)), ctypes.byref(p), ctypes.byref(n)))
+    return _take_bytes(p, n)
+
+
+# ------------------------------------------------------------------ parser of the canonical byte form (tests compare it with the oracle)
+class Reader:
+    def __init__(self, b):
+        self.b, self.o = b, 0
+
+    def u8(self):
+        v = self.b[self.o]; self.o += 1; return v
+
+    def u32(self):
+        v = int.from_bytes(self.b[self.o:self.o + 4], "little"); self.o += 4; return v
+
+    def raw(self, n):
+        v = self.b[self.o:self.o + n]; self.o += n; return v
+
+    def s(self):
+        return self.raw(self.u32()).decode("utf-8")
+
+    def vec(self, n):
+        return [self.raw(n) for _ in range(self.u32())]
+
+    def pol(self):
+        return (self.s(), self.u8())
+
+    def done(self):
+        assert self.o == len(self.b)
+
+
+def parse_obj(kind, data):
+    r = Reader(data)
+    if kind == "ac17_pk":
+        o = {"g": r.raw(64), "h_a": r.vec(128), "e_gh_ka": r.vec(384)}
+    elif kind == "ac17_msk":
+        o = {"g": r.raw(64), "h": r.raw(128), "g_k": r.vec(64), "a": r.vec(32), "b": r.vec(32)}
+    elif kind == "ac17_cp_sk":
+        attr = [r.s() for _ in range(r.u32())]
+        o = {"attr": attr, "k_0": r.vec(128), "k": [(r.s(), r.vec(64)) for _ in range(r.u32())], "k_p": r.vec(64)}
+    elif kind == "ac17_cp_ct":
+        o = {"policy": r.pol(), "c_0": r.vec(128), "c": [(r.s(), r.vec(64)) for _ in range(r.u32())], "c_p": r.raw(384), "ct": r.raw(r.u32())}
+    elif kind == "bsw_pk":
+        o = {"g1": r.raw(64), "g2": r.raw(128), "h": r.raw(64), "f": r.raw(128), "e_gg_alpha": r.raw(384)}
+    elif kind == "bsw_msk":
+        o = {"beta": r.raw(32), "g2_alpha": r.raw(128)}
+    elif kind == "bsw_sk":
+        o = {"d": r.raw(128), "d_j": [(r.s(), r.raw(64), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "bsw_ct":
+        o = {"policy": r.pol(), "c": r.raw(64), "c_p": r.raw(384), "c_y": [(r.s(), r.raw(64), r.raw(128)) for _ in range(r.u32())], "data": r.raw(r.u32())}
+    elif kind == "lsw_pk":
+        o = {"g1": r.raw(64), "g2": r.raw(128), "g1_b": r.raw(64), "g1_b2": r.raw(64), "h_b": r.raw(64), "e_gg_alpha": r.raw(384)}
+    elif kind == "lsw_msk":
+        o = {"alpha1": r.raw(32), "alpha2": r.raw(32), "b": r.raw(32), "h_g1": r.raw(64), "h_g2": r.raw(128)}
+    elif kind == "lsw_sk":
+        o = {"policy": r.pol(), "dj": [(r.s(), r.raw(64), r.raw(128), r.raw(64), r.raw(64), r.raw(64)) for _ in range(r.u32())]}
+    elif kind == "lsw_ct":
+        o = {"e1": r.raw(384), "e2": r.raw(128), "ej": [(r.s(), r.raw(64), r.raw(64), r.raw(64)) for _ in range(r.u32())], "ct": r.raw(r.u32())}
+    elif kind == "aw11_gk":
+        o = {"g1": r.raw(64), "g2": r.raw(128)}
+    elif kind == "aw11_pk":
+        o = {"attr": [(r.s(), r.raw(384), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "aw11_msk":
+        o = {"attr": [(r.s(), r.raw(32), r.raw(32)) for _ in range(r.u32())]}
+    elif kind == "aw11_sk":
+        o = {"gid": r.s(), "attr": [(r.s(), r.raw(64)) for _ in range(r.u32())]}
+    elif kind == "aw11_ct":
+        o = {"policy": r.pol(), "c_0": r.raw(384), "c": [(r.s(), r.raw(384), r.raw(128), r.raw(128)) for _ in range(r.u32())], "ct": r.raw(r.u32())}
+    else:
+        raise ValueError(kind)
+    r.done()
+    return o

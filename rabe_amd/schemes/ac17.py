@@ -1,0 +1,60 @@
+"""rabe::schemes::ac17 (src/schemes/ac17/mod.rs:141-430) over the host layer."""
+import ctypes
+
+from ..hostlib import JSON_POLICY, Obj, _strs
+
+
+def setup(host):
+    pk, msk = ctypes.c_void_p(), ctypes.c_void_p()
+    host.call("rabe_ac17_setup", ctypes.byref(pk), ctypes.byref(msk))
+    return Obj("ac17_pk", pk), Obj("ac17_msk", msk)
+
+
+def cp_keygen(host, msk, attributes):
+    arr, n = _strs(attributes)
+    sk = ctypes.c_void_p()
+    host.call("rabe_ac17_cp_keygen", msk.ptr, arr, n, ctypes.byref(sk))
+    return Obj("ac17_cp_sk", sk)
+
+
+def cp_encrypt(host, pk, policy, plaintext, language=JSON_POLICY):
+    ct = ctypes.c_void_p()
+    host.call("rabe_ac17_cp_encrypt", pk.ptr, policy.encode("utf-8"), language, bytes(plaintext), ctypes.c_size_t(len(plaintext)), ctypes.byref(ct))
+    return Obj("ac17_cp_ct", ct)
+
+
+def cp_decrypt(host, sk, ct):
+    return host.out_bytes("rabe_ac17_cp_decrypt", sk.ptr, ct.ptr)
+
+
+def cp_decrypt_gt(host, sk, ct):
+    return host.out_gt("rabe_ac17_cp_decrypt_gt", sk.ptr, ct.ptr)
+
+
+def cp_encrypt_batch(host, pk, policies, plaintexts, language=JSON_POLICY):
+    n = len(policies)
+    pol, _ = _strs(policies)
+    pts = (ctypes.c_char_p * max(1, n))(*[bytes(p) for p in plaintexts])
+    lens = (ctypes.c_size_t * max(1, n))(*[len(p) for p in plaintexts])
+    out = (ctypes.c_void_p * max(1, n))()
+    host.call("rabe_ac17_cp_encrypt_batch", pk.ptr, ctypes.c_size_t(n), pol, language, pts, lens, out)
+    return [Obj("ac17_cp_ct", ctypes.c_void_p(out[i])) for i in range(n)]
+
+
+def cp_decrypt_batch(host, sks, cts):
+    """Returns a list with the plaintext bytes, or None where the key does not satisfy the policy."""
+    n = len(cts)
+    a = (ctypes.c_void_p * max(1, n))(*[s.ptr for s in sks])
+    b = (ctypes.c_void_p * max(1, n))(*[c.ptr for c in cts])
+    status = (ctypes.c_int32 * max(1, n))()
+    pts = (ctypes.c_void_p * max(1, n))()
+    lens = (ctypes.c_size_t * max(1, n))()
+    host.call("rabe_ac17_cp_decrypt_batch", ctypes.c_size_t(n), a, b, status, pts, lens)
+    out = []
+    for i in range(n):
+        if status[i] == 0:
+            out.append(ctypes.string_at(pts[i], lens[i]))
+            host.lib.rabe_bytes_free(ctypes.c_void_p(pts[i]))
+        else:
+            out.append(None)
+    return out

@@ -1,0 +1,46 @@
+"""rabe::schemes::aw11 (src/schemes/aw11/mod.rs:100-390) over the host layer."""
+import ctypes
+
+from ..hostlib import JSON_POLICY, Obj, _strs
+
+
+def setup(host):
+    gk = ctypes.c_void_p()
+    host.call("rabe_aw11_setup", ctypes.byref(gk))
+    return Obj("aw11_gk", gk)
+
+
+def authgen(host, gk, attributes):
+    """Option<(Aw11PublicKey, Aw11MasterKey)>: None for an empty attribute list."""
+    arr, n = _strs(attributes)
+    pk, msk = ctypes.c_void_p(), ctypes.c_void_p()
+    if host.call("rabe_aw11_authgen", gk.ptr, arr, n, ctypes.byref(pk), ctypes.byref(msk)) is None:
+        return None
+    return Obj("aw11_pk", pk), Obj("aw11_msk", msk)
+
+
+def keygen(host, gk, msk, name, attributes):
+    arr, n = _strs(attributes)
+    sk = ctypes.c_void_p()
+    host.call("rabe_aw11_keygen", gk.ptr, msk.ptr, name.encode("utf-8"), arr, n, ctypes.byref(sk))
+    return Obj("aw11_sk", sk)
+
+
+def add_to_attribute(host, gk, msk, attribute, sk):
+    host.call("rabe_aw11_add_to_attribute", gk.ptr, msk.ptr, attribute.encode("utf-8"), sk.ptr)
+
+
+def encrypt(host, gk, pks, policy, language, data):
+    arr = (ctypes.c_void_p * max(1, len(pks)))(*[p.ptr for p in pks])
+    ct = ctypes.c_void_p()
+    host.call("rabe_aw11_encrypt", gk.ptr, arr, ctypes.c_size_t(len(pks)), policy.encode("utf-8"), language, bytes(data),
+              ctypes.c_size_t(len(data)), ctypes.byref(ct))
+    return Obj("aw11_ct", ct)
+
+
+def decrypt(host, gk, sk, ct):
+    return host.out_bytes("rabe_aw11_decrypt", gk.ptr, sk.ptr, ct.ptr)
+
+
+def decrypt_gt(host, gk, sk, ct):
+    return host.out_gt("rabe_aw11_decrypt_gt", gk.ptr, sk.ptr, ct.ptr)

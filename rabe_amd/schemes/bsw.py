@@ -1,0 +1,33 @@
+"""rabe::schemes::bsw (src/schemes/bsw/mod.rs:92-318) over the host layer."""
+import ctypes
+
+from ..hostlib import JSON_POLICY, Obj, _strs
+
+
+def setup(host):
+    pk, msk = ctypes.c_void_p(), ctypes.c_void_p()
+    host.call("rabe_bsw_setup", ctypes.byref(pk), ctypes.byref(msk))
+    return Obj("bsw_pk", pk), Obj("bsw_msk", msk)
+
+
+def keygen(host, pk, msk, attributes):
+    """Option<CpAbeSecretKey>: None for an empty attribute list."""
+    arr, n = _strs(attributes)
+    sk = ctypes.c_void_p()
+    if host.call("rabe_bsw_keygen", pk.ptr, msk.ptr, arr, n, ctypes.byref(sk)) is None:
+        return None
+    return Obj("bsw_sk", sk)
+
+
+def encrypt(host, pk, policy, language, plaintext):
+    ct = ctypes.c_void_p()
+    host.call("rabe_bsw_encrypt", pk.ptr, policy.encode("utf-8"), language, bytes(plaintext), ctypes.c_size_t(len(plaintext)), ctypes.byref(ct))
+    return Obj("bsw_ct", ct)
+
+
+def decrypt(host, sk, ct):
+    return host.out_bytes("rabe_bsw_decrypt", sk.ptr, ct.ptr)
+
+
+def decrypt_gt(host, sk, ct):
+    return host.out_gt("rabe_bsw_decrypt_gt", sk.ptr, ct.ptr)

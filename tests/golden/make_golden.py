@@ -85,13 +85,13 @@ def ac17_cases():
         sk = sch.ac17_cp_keygen(msk, attrs, ListRng(kt))
         et = [rng.fr(), rng.fr()]
         rho = rng.fr_nonzero()
-        msg = bn.gt_pow(E_GEN, rho)
+        msg = bn.gt_pow(E_GEN, rho)       # `rng.gen::<Gt>()` modelled as e(G1::one(), G2::one())^rho
         ct = sch.ac17_cp_encrypt(pk, policy, lang, ListRng(et), msg)
         dec = sch.ac17_cp_decrypt(sk, ct)
         assert dec == msg
         doc["cases"].append({
             "policy": policy, "language": lang, "attrs": attrs,
-            "keygen_tape": [fr(x) for x in kt], "encrypt_tape": [fr(x) for x in et], "msg": gt(msg),
+            "keygen_tape": [fr(x) for x in kt], "encrypt_tape": [fr(x) for x in et], "msg_rho": fr(rho), "msg": gt(msg),
             "sk": {"k_0": [g2(x) for x in sk["sk"]["k_0"]], "k": [[n, [g1(p) for p in v]] for n, v in sk["sk"]["k"]],
                    "k_p": [g1(x) for x in sk["sk"]["k_p"]]},
             "ct": {"c_0": [g2(x) for x in ct["ct"]["c_0"]], "c": [[n, [g1(p) for p in v]] for n, v in ct["ct"]["c"]],
@@ -112,13 +112,14 @@ def bsw_cases():
         kt = [rng.fr() for _ in range(1 + len(attrs))]
         sk = sch.bsw_keygen(pk, msk, attrs, ListRng(kt))
         rec = RecRng(rng.fr() % (1 << 62))
-        msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+        rho = rng.fr_nonzero()
+        msg = bn.gt_pow(E_GEN, rho)
         ct = sch.bsw_encrypt(pk, policy, lang, rec, msg)
         dec = sch.bsw_decrypt(sk, ct)
         assert dec == msg
         doc["cases"].append({
             "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in kt],
-            "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+            "encrypt_tape": [fr(x) for x in rec.log], "msg_rho": fr(rho), "msg": gt(msg),
             "sk": {"d": g2(sk["d"]), "d_j": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in sk["d_j"]]},
             "ct": {"c": g1(ct["c"]), "c_p": gt(ct["c_p"]), "c_y": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in ct["c_y"]]},
             "decrypted": gt(dec)})
@@ -137,7 +138,8 @@ def lsw_cases():
         rk = RecRng(rng.fr() % (1 << 62))
         sk = sch.lsw_keygen(pk, msk, policy, lang, rk)
         re_ = RecRng(rng.fr() % (1 << 62))
-        msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+        rho = rng.fr_nonzero()
+        msg = bn.gt_pow(E_GEN, rho)
         ct = sch.lsw_encrypt(pk, attrs, re_, msg)
         dec = sch.lsw_decrypt(sk, ct)
         assert dec == msg
@@ -146,7 +148,7 @@ def lsw_cases():
             return f(x)
         doc["cases"].append({
             "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in rk.log],
-            "encrypt_tape": [fr(x) for x in re_.log], "msg": gt(msg),
+            "encrypt_tape": [fr(x) for x in re_.log], "msg_rho": fr(rho), "msg": gt(msg),
             "sk": {"dj": [[d[0], g1(d[1]), g2(d[2]), g1(d[3]), g1(d[4]), g1(d[5])] for d in sk["dj"]]},
             "ct": {"e1": gt(ct["e1"]), "e2": g2(ct["e2"]), "ej": [[e[0], g1(e[1]), g1(e[2]), g1(e[3])] for e in ct["ej"]]},
             "decrypted": gt(dec)})
@@ -169,13 +171,14 @@ def aw11_cases():
     sk = sch.aw11_keygen(gk, msk1, "alice", ["A", "B"])
     policy = r'''{"name": "or", "children": [{"name": "C"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}'''
     rec = RecRng(rng.fr() % (1 << 62))
-    msg = bn.gt_pow(E_GEN, rng.fr_nonzero())
+    rho = rng.fr_nonzero()
+    msg = bn.gt_pow(E_GEN, rho)
     ct = sch.aw11_encrypt(gk, [pk1, pk2], policy, pol.JSON, rec, msg)
     dec = sch.aw11_decrypt(gk, sk, ct)
     assert dec == msg
     doc["cases"].append({
         "policy": policy, "language": pol.JSON, "gid": "alice", "key_authority": 0, "key_attrs": ["A", "B"],
-        "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+        "encrypt_tape": [fr(x) for x in rec.log], "msg_rho": fr(rho), "msg": gt(msg),
         "sk": [[n, g1(p)] for n, p in sk["attr"]],
         "ct": {"c_0": gt(ct["c_0"]), "c": [[n, gt(c1), g2(c2), g2(c3)] for n, c1, c2, c3 in ct["c"]]},
         "decrypted": gt(dec)})

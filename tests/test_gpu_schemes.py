@@ -1,0 +1,234 @@
+"""GPU tests of the host layer (rabe::schemes::* mirror): (1) the reference's own round-trip tests, restated;
+(2) bit-exact parity of every key / ciphertext element with the golden vectors (oracle, reference operation
+order) under explicit randomness."""
+import json
+import os
+
+import pytest
+
+from rabe_amd import hostlib as hl
+from rabe_amd.schemes import ac17, aw11, bsw, lsw
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+PLAINTEXT = b"dance like no one's watching, encrypt like everyone is!"     # ac17/mod.rs:764, bsw/mod.rs:331 ...
+
+
+@pytest.fixture(scope="module")
+def host():
+    h = hl.Host(0)
+    yield h
+    h.close()
+
+
+def load(name):
+    with open(os.path.join(HERE, "golden", name + ".json")) as f:
+        return json.load(f)
+
+
+def hb(x):
+    return bytes.fromhex(x)
+
+
+def fri(x):
+    return int.from_bytes(hb(x), "little")
+
+
+LANG = {"json": hl.JSON_POLICY, "human": hl.HUMAN_POLICY}
+
+# ------------------------------------------------------------------------------------------------ reference-style round trips
+
+
+def test_ac17_cp_and_or_or_and_and(host):
+    # ac17/mod.rs:756-809: test_cp_and, test_cp_or, test_cp_or_and_and
+    pk, msk = ac17.setup(host)
+    cases = [('"A" and "B"', ["A", "B"], True), ('"A" and "B"', ["A", "C"], False), ('"A" or "B"', ["B"], True),
+             ('"X" or ("B" and ("A" and "C"))', ["A", "B", "C"], True), ('"X" or ("B" and ("A" and "C"))', ["A", "B"], False)]
+    for policy, attrs, ok in cases:
+        ct = ac17.cp_encrypt(host, pk, policy, PLAINTEXT, hl.HUMAN_POLICY)
+        sk = ac17.cp_keygen(host, msk, attrs)
+        if ok:
+            assert ac17.cp_decrypt(host, sk, ct) == PLAINTEXT
+        else:
+            with pytest.raises(hl.RabeError):
+                ac17.cp_decrypt(host, sk, ct)
+    with pytest.raises(hl.RabeError):
+        ac17.cp_keygen(host, msk, [])                      # "empty attributes!" :197-199
+
+
+def test_ac17_batch_api(host):
+    pk, msk = ac17.setup(host)
+    policies = ['"A" and "B"', '"A" or "C"', '"A" and "B"', '"D" and ("A" or "B")']
+    pts = [PLAINTEXT + bytes([i]) for i in range(4)]
+    cts = ac17.cp_encrypt_batch(host, pk, policies, pts, hl.HUMAN_POLICY)
+    sk_ab = ac17.cp_keygen(host, msk, ["A", "B"])
+    got = ac17.cp_decrypt_batch(host, [sk_ab] * 4, cts)
+    assert got[0] == pts[0] and got[1] == pts[1] and got[2] == pts[2] and got[3] is None
+
+
+def test_bsw_reference_cases(host):
+    # bsw/mod.rs:320-602: or, and (10 attrs), nested, or3, and, dual attributes, and3, or_and; keygen(None)
+    pk, msk = bsw.setup(host)
+    assert bsw.keygen(host, pk, msk, []) is None
+    and10 = '{"name": "and", "children": [%s]}' % ", ".join('{"name": "attr%d"}' % i for i in range(1, 11))
+    nested = '{"name":"and", "children": [{"name": "a2"}, {"name": "a1"}]}'
+    for i in range(3, 9):
+        nested = '{"name":"and", "children":[{"name": "a%d"}, %s]}' % (i, nested)
+    cases = [(r'''{"name": "or", "children": [{"name": "A"}, {"name": "B"}]}''', ["C", "B"], True),
+             (and10, ["attr%d" % i for i in range(1, 11)], True),
+             (and10, ["attr%d" % i for i in range(1, 10)], False),
+             (nested, ["a%d" % i for i in range(1, 9)], True),
+             (r'''{"name": "or", "children": [{"name": "X"}, {"name": "Y"}, {"name": "A"}]}''', ["A", "B", "C"], True),
+             (r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}''', ["A", "B"], True),
+             (r'''{"name": "or", "children": [{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children":  [{"name": "B"}, {"name": "C"}]}]}''', ["B", "C"], True),
+             (r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}, {"name": "C"}]}''', ["A", "B", "C"], True),
+             (r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}, {"name": "C"}]}''', ["A", "B"], False)]
+    for policy, attrs, ok in cases:
+        ct = bsw.encrypt(host, pk, policy, hl.JSON_POLICY, PLAINTEXT)
+        sk = bsw.keygen(host, pk, msk, attrs)
+        if ok:
+            assert bsw.decrypt(host, sk, ct) == PLAINTEXT
+        else:
+            with pytest.raises(hl.RabeError):
+                bsw.decrypt(host, sk, ct)
+
+
+def test_lsw_reference_cases(host):
+    # lsw/mod.rs:292-374: and, or, or_and; non-matching
+    pk, msk = lsw.setup(host)
+    cases = [(r'''{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}''', ["A", "B"], True),
+             (r'''{"name": "or", "children": [{"name": "A"}, {"name": "B"}]}''', ["B", "C"], True),
+             (r'''{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}''', ["B", "C"], True),
+             (r'''{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}''', ["A", "C"], False)]
+    for policy, attrs, ok in cases:
+        sk = lsw.keygen(host, pk, msk, policy, hl.JSON_POLICY)
+        ct = lsw.encrypt(host, pk, attrs, PLAINTEXT)
+        if ok:
+            assert lsw.decrypt(host, sk, ct) == PLAINTEXT
+        else:
+            with pytest.raises(hl.RabeError):
+                lsw.decrypt(host, sk, ct)
+    with pytest.raises(hl.RabeError):
+        lsw.encrypt(host, pk, [], PLAINTEXT)
+
+
+def test_aw11_reference_cases(host):
+    # aw11/mod.rs:392-561: two authorities, and / or policies, add_to_attribute, non-matching key
+    gk = aw11.setup(host)
+    assert aw11.authgen(host, gk, []) is None
+    pk1, msk1 = aw11.authgen(host, gk, ["A", "B"])
+    pk2, msk2 = aw11.authgen(host, gk, ["C", "D"])
+    sk = aw11.keygen(host, gk, msk1, "bob", ["A"])
+    aw11.add_to_attribute(host, gk, msk2, "C", sk)
+    pol_and = r'''{"name": "and", "children": [{"name": "A"}, {"name": "C"}]}'''
+    ct = aw11.encrypt(host, gk, [pk1, pk2], pol_and, hl.JSON_POLICY, PLAINTEXT)
+    assert aw11.decrypt(host, gk, sk, ct) == PLAINTEXT
+    pol_or = r'''{"name": "or", "children": [{"name": "B"}, {"name": "and", "children": [{"name": "A"}, {"name": "C"}]}]}'''
+    ct = aw11.encrypt(host, gk, [pk1, pk2], pol_or, hl.JSON_POLICY, PLAINTEXT)
+    assert aw11.decrypt(host, gk, sk, ct) == PLAINTEXT
+    sk_bad = aw11.keygen(host, gk, msk1, "eve", ["A"])
+    with pytest.raises(hl.RabeError):
+        aw11.decrypt(host, gk, sk_bad, ct)
+    with pytest.raises(hl.RabeError):
+        aw11.keygen(host, gk, msk1, "", ["A"])
+
+
+# ------------------------------------------------------------------------------------------------ parity with the golden vectors
+
+def test_ac17_matches_golden(host):
+    doc = load("ac17")
+    pk_bytes = hb(doc["pk"]["g"]) + (3).to_bytes(4, "little") + b"".join(hb(x) for x in doc["pk"]["h_a"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in doc["pk"]["e_gh_ka"])
+    pk = hl.Obj.deserialize("ac17_pk", pk_bytes)
+    m = doc["msk"]
+    msk_bytes = hb(m["g"]) + hb(m["h"]) + (3).to_bytes(4, "little") + b"".join(hb(x) for x in m["g_k"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in m["a"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in m["b"])
+    msk = hl.Obj.deserialize("ac17_msk", msk_bytes)
+    assert pk.serialize() == pk_bytes and msk.serialize() == msk_bytes
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        sk = ac17.cp_keygen(host, msk, c["attrs"])
+        got = hl.parse_obj("ac17_cp_sk", sk.serialize())
+        assert got["attr"] == c["attrs"]
+        assert got["k_0"] == [hb(x) for x in c["sk"]["k_0"]]
+        assert got["k"] == [(n, [hb(p) for p in v]) for n, v in c["sk"]["k"]]
+        assert got["k_p"] == [hb(x) for x in c["sk"]["k_p"]]
+        host.set_tape([fri(x) for x in c["encrypt_tape"]] + [fri(c["msg_rho"]), 7])
+        ct = ac17.cp_encrypt(host, pk, c["policy"], PLAINTEXT, LANG[c["language"]])
+        g = hl.parse_obj("ac17_cp_ct", ct.serialize())
+        assert g["policy"] == (c["policy"], LANG[c["language"]])
+        assert g["c_0"] == [hb(x) for x in c["ct"]["c_0"]]
+        assert g["c"] == [(n, [hb(p) for p in v]) for n, v in c["ct"]["c"]]
+        assert g["c_p"] == hb(c["ct"]["c_p"])
+        host.clear_tape()
+        assert ac17.cp_decrypt_gt(host, sk, ct) == hb(c["decrypted"])
+        assert ac17.cp_decrypt(host, sk, ct) == PLAINTEXT
+        # the AES layer: nonce came from the tape (low 12 bytes of 7), key = SHA3-256(bytes(msg))
+        assert g["ct"] == hl.encrypt_symmetric(hb(c["msg"]), PLAINTEXT, (7).to_bytes(32, "little")[:12])
+
+
+def test_bsw_matches_golden(host):
+    doc = load("bsw")
+    p = doc["pk"]
+    pk = hl.Obj.deserialize("bsw_pk", hb(p["g1"]) + hb(p["g2"]) + hb(p["h"]) + hb(p["f"]) + hb(p["e_gg_alpha"]))
+    msk = hl.Obj.deserialize("bsw_msk", hb(doc["msk"]["beta"]) + hb(doc["msk"]["g2_alpha"]))
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        sk = bsw.keygen(host, pk, msk, c["attrs"])
+        g = hl.parse_obj("bsw_sk", sk.serialize())
+        assert g["d"] == hb(c["sk"]["d"])
+        assert g["d_j"] == [(n, hb(a), hb(b)) for n, a, b in c["sk"]["d_j"]]
+        et = [fri(x) for x in c["encrypt_tape"]]
+        host.set_tape([et[0], fri(c["msg_rho"])] + et[1:] + [9])          # secret, msg, gate coefficients, nonce
+        ct = bsw.encrypt(host, pk, c["policy"], LANG[c["language"]], PLAINTEXT)
+        g = hl.parse_obj("bsw_ct", ct.serialize())
+        assert g["c"] == hb(c["ct"]["c"]) and g["c_p"] == hb(c["ct"]["c_p"])
+        assert g["c_y"] == [(n, hb(a), hb(b)) for n, a, b in c["ct"]["c_y"]]
+        host.clear_tape()
+        assert bsw.decrypt_gt(host, sk, ct) == hb(c["decrypted"])
+        assert bsw.decrypt(host, sk, ct) == PLAINTEXT
+
+
+def test_lsw_matches_golden(host):
+    doc = load("lsw")
+    p, m = doc["pk"], doc["msk"]
+    pk = hl.Obj.deserialize("lsw_pk", hb(p["g1"]) + hb(p["g2"]) + hb(p["g1_b"]) + hb(p["g1_b2"]) + hb(p["h_b"]) + hb(p["e_gg_alpha"]))
+    msk = hl.Obj.deserialize("lsw_msk", hb(m["alpha1"]) + hb(m["alpha2"]) + hb(m["b"]) + hb(m["h_g1"]) + hb(m["h_g2"]))
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        sk = lsw.keygen(host, pk, msk, c["policy"], LANG[c["language"]])
+        g = hl.parse_obj("lsw_sk", sk.serialize())
+        assert g["dj"] == [(d[0], hb(d[1]), hb(d[2]), hb(d[3]), hb(d[4]), hb(d[5])) for d in c["sk"]["dj"]]
+        host.set_tape([fri(x) for x in c["encrypt_tape"]] + [fri(c["msg_rho"]), 11])   # secret, sx.., msg, nonce
+        ct = lsw.encrypt(host, pk, c["attrs"], PLAINTEXT)
+        g = hl.parse_obj("lsw_ct", ct.serialize())
+        assert g["e1"] == hb(c["ct"]["e1"]) and g["e2"] == hb(c["ct"]["e2"])
+        assert g["ej"] == [(e[0], hb(e[1]), hb(e[2]), hb(e[3])) for e in c["ct"]["ej"]]
+        host.clear_tape()
+        assert lsw.decrypt_gt(host, sk, ct) == hb(c["decrypted"])
+        assert lsw.decrypt(host, sk, ct) == PLAINTEXT
+
+
+def test_aw11_matches_golden(host):
+    doc = load("aw11")
+    gk = hl.Obj.deserialize("aw11_gk", hb(doc["gk"]["g1"]) + hb(doc["gk"]["g2"]))
+    auths = []
+    for a in doc["authorities"]:
+        host.set_tape([fri(x) for x in a["tape"]])
+        pk, msk = aw11.authgen(host, gk, a["attrs"])
+        assert hl.parse_obj("aw11_pk", pk.serialize())["attr"] == [(n, hb(e), hb(y)) for n, e, y in a["pk"]]
+        assert hl.parse_obj("aw11_msk", msk.serialize())["attr"] == [(n, hb(x), hb(y)) for n, x, y in a["msk"]]
+        auths.append((pk, msk))
+    host.clear_tape()
+    for c in doc["cases"]:
+        sk = aw11.keygen(host, gk, auths[c["key_authority"]][1], c["gid"], c["key_attrs"])
+        assert hl.parse_obj("aw11_sk", sk.serialize())["attr"] == [(n, hb(p)) for n, p in c["sk"]]
+        et = [fri(x) for x in c["encrypt_tape"]]
+        n_rows = len(c["ct"]["c"])
+        head = len(et) - n_rows                                            # s + gate coefficients of both sharings
+        host.set_tape(et[:head] + [fri(c["msg_rho"])] + et[head:] + [13])  # ..., msg, r_x per row, nonce
+        ct = aw11.encrypt(host, gk, [a[0] for a in auths], c["policy"], LANG[c["language"]], PLAINTEXT)
+        g = hl.parse_obj("aw11_ct", ct.serialize())
+        assert g["c_0"] == hb(c["ct"]["c_0"])
+        assert g["c"] == [(n, hb(a), hb(b), hb(d)) for n, a, b, d in c["ct"]["c"]]
+        host.clear_tape()
+        assert aw11.decrypt_gt(host, gk, sk, ct) == hb(c["decrypted"])
+        assert aw11.decrypt(host, gk, sk, ct) == PLAINTEXT

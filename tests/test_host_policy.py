@@ -1,0 +1,126 @@
+"""CPU tests of the C++ host layer's string / Fr half (no GPU): the reference's structural KATs
+(msp.rs:157-199, secretsharing/mod.rs:286-324, pest/mod.rs:118-149, tools/mod.rs:76-129) and a fuzz
+comparison against the oracle's independent restatement (oracle/policy.py)."""
+import random
+
+import pytest
+
+from oracle import bn254 as bn
+from oracle import policy as opol
+from oracle.tape import ListRng
+from rabe_amd import build, hostlib as hl
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build()
+
+
+def test_msp_kat():
+    p = r'''{name:"and", children:[{name:"A"}, {name:"or", "children":[{name:"D"}, {name:"and", "children":[{name:"B"},{name:"C"}]}]} ]}'''
+    d = hl.policy_msp(p)
+    assert d["pi"] == ["A", "B", "C", "D"] and d["c"] == 3
+    assert d["m"] == [[1, 1, 0], [0, -1, 1], [0, 0, -1], [0, -1, 0]]
+
+
+def test_pruning_kat():
+    attrs = ["A", "B", "C"]
+    pol1 = r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "D"}]}]}'''
+    pol2 = r'''{"name": "or", "children": [{"name": "C"}, {"name": "and", "children": [{"name": "A"}, {"name": "E"}]}]}'''
+    pol3 = r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "A"}, {"name": "C"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "A"}]}]}'''
+    assert hl.policy_pruned(pol1, attrs) == (True, [("A", "A_68"), ("B", "B_83")])
+    assert hl.policy_pruned(pol2, attrs) == (True, [("C", "C_39")])
+    assert hl.policy_pruned(pol3, attrs) == (True, [("A", "A_68"), ("C", "C_83")])
+
+
+@pytest.mark.parametrize("js,human", [
+    (r'''{"name": "A"}''', "A"),
+    (r'''{"name": "and", "children": [{"name": "B"}, {"name": "C"}]}''', "(B and C)"),
+    (r'''{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}''', "(A or (B and C))"),
+])
+def test_parse_serialize_kat(js, human):
+    assert hl.policy_parse(js, hl.JSON_POLICY, hl.JSON_POLICY) == js
+    assert hl.policy_parse(js, hl.JSON_POLICY, hl.HUMAN_POLICY) == human
+
+
+def test_traverse_truth_table():
+    with pytest.raises(hl.RabeError):
+        hl.policy_parse("what-the-heck?")
+    p1 = r'''{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}'''
+    p2 = r'''{"name": "or", "children": [{"name": "A"}, {"name": "B"}]}'''
+    p3 = r'''{"name": "and", "children": [{"name":"or", "children": [{"name": "C"}, {"name": "D"}]}, {"name": "B"}]}'''
+    s0, s1, s2, s3 = ["X", "Y"], ["A", "B"], ["C", "D"], ["A", "B", "C", "D"]
+    assert [hl.policy_traverse(p1, s) for s in (s0, s1, s2, s3)] == [False, True, False, True]
+    assert [hl.policy_traverse(p2, s) for s in (s1, s2, s3)] == [True, False, True]
+    assert [hl.policy_traverse(p3, s) for s in (s1, s2, s3)] == [False, False, True]
+    assert hl.policy_traverse(p2, []) is False
+
+
+def test_panics_and_errors():
+    with pytest.raises(hl.RabePanic):
+        hl.policy_msp('"A" and "B" and "C"', hl.HUMAN_POLICY)          # lw: AND must be binary
+    with pytest.raises(hl.RabePanic):
+        hl.policy_msp(r'''{"name": "and", "children": [{"name": "A"}]}''')
+    with pytest.raises(hl.RabeError):
+        hl.policy_parse('"A" and "B" or "C"', hl.HUMAN_POLICY)
+    with pytest.raises(hl.RabeError):
+        hl.policy_parse('A and B', hl.HUMAN_POLICY)
+
+
+def _rand_tree(rnd, names, depth=0, binary=False):
+    if depth > 3 or rnd.random() < 0.3:
+        return ("leaf", rnd.choice(names))
+    k = 2 if binary else rnd.randint(2, 4)
+    return (rnd.choice(["and", "or"]), [_rand_tree(rnd, names, depth + 1, binary) for _ in range(k)])
+
+
+def _json(t, rnd):
+    sp = lambda: " " * rnd.randint(0, 2)
+    if t[0] == "leaf":
+        return '{%s"name"%s:%s"%s"%s}' % (sp(), sp(), sp(), t[1], sp())
+    return '{"name":%s"%s",%s"children":%s[%s]}' % (sp(), t[0], sp(), sp(), ("," + sp()).join(_json(c, rnd) for c in t[1]))
+
+
+def _human(t, rnd):
+    if t[0] == "leaf":
+        return '"%s"' % t[1]
+    return "(" + (" %s " % t[0]).join(_human(c, rnd) for c in t[1]) + ")"
+
+
+def test_fuzz_against_oracle_policy():
+    rnd = random.Random(5)
+    names = ["A", "B", "C", "D", "E", "attr-x", "Z9"]
+    for it in range(60):
+        binary = it % 2 == 0
+        t = _rand_tree(rnd, names, binary=binary)
+        if t[0] == "leaf":
+            continue
+        for lang, text in ((hl.JSON_POLICY, _json(t, rnd)), (hl.HUMAN_POLICY, _human(t, rnd))):
+            olang = opol.JSON if lang == hl.JSON_POLICY else opol.HUMAN
+            tree = opol.parse(text, olang)
+            assert hl.policy_parse(text, lang, hl.JSON_POLICY) == opol.serialize_policy(tree, opol.JSON)
+            attrs = rnd.sample(names, rnd.randint(1, len(names)))
+            assert hl.policy_traverse(text, attrs, lang) == opol.traverse_policy(attrs, tree)
+            assert hl.policy_pruned(text, attrs, lang) == opol.calc_pruned(attrs, tree)
+            assert hl.policy_coeffs(text, lang) == opol.calc_coefficients(tree, 1)
+            tape = [rnd.randrange(bn.R) for _ in range(64)]
+            secret = rnd.randrange(bn.R)
+            assert hl.policy_shares(text, secret, tape, lang) == opol.gen_shares_policy(secret, tree, ListRng(tape))
+            if binary:
+                m, pi, c = opol.calculate_msp(tree)
+                d = hl.policy_msp(text, lang)
+                assert (d["m"], d["pi"], d["c"]) == (m, pi, c)
+
+
+def test_symmetric_roundtrip_and_tamper():
+    gt = bytes(range(256)) + bytes(128)
+    nonce = bytes(range(12))
+    ct = hl.encrypt_symmetric(gt, b"dance like no one's watching, encrypt like everyone is!", nonce)
+    assert ct[:12] == nonce and len(ct) == 12 + 55 + 16
+    assert hl.decrypt_symmetric(gt, ct) == b"dance like no one's watching, encrypt like everyone is!"
+    bad = bytearray(ct)
+    bad[20] ^= 1
+    with pytest.raises(hl.RabeError):
+        hl.decrypt_symmetric(gt, bytes(bad))
+    with pytest.raises(hl.RabeError):
+        hl.decrypt_symmetric(bytes(384), ct)          # a different Gt derives a different key
