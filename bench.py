@@ -201,11 +201,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from rabe_amd import shard
+    elapsed = shard.max_over_ranks(t1 - t0)
 
     # ---------------------------------------------------------------- size-independent correctness property on the FULL batch:
     # decrypt(encrypt(msg)) == msg, bit for bit, for every item (oracle parity at small sizes is in tests/)
