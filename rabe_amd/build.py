@@ -31,6 +31,9 @@ def build(force=False, verbose=False):
     if not (force or stale()):
         return LIB
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + SOURCES
+    extra = os.environ.get("RABE_HIPCC_FLAGS")          # kernel-tuning experiments, e.g. -DRB_MIN_WAVES=3
+    if extra:
+        cmd += extra.split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, timeout=1800)

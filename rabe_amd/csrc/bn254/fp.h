@@ -22,6 +22,11 @@
 #define RB_HD __host__ __device__ __forceinline__
 #define RB_FN __host__ __device__ __attribute__((noinline))
 #define RB_HD_NOINLINE RB_FN
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RB_MID __host__ __device__ __forceinline__
+#else
+#define RB_MID RB_FN
+#endif
 
 #if defined(RB_COUNT_MULS) && !defined(__HIP_DEVICE_COMPILE__)
 extern "C" unsigned long long rb_mul_counter;

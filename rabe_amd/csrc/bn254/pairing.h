@@ -27,7 +27,7 @@ struct LineCoeffs {
 
 // Doubling step: T <- 2T, returns the tangent line coefficients.  (Costello et al., as used for
 // D-type twists: cy = -2YZ, cx = 3X^2, c0 = 3b'Z^2 - Y^2.)
-RB_FN LineCoeffs g2hom_double(G2Hom& r) {
+RB_MID LineCoeffs g2hom_double(G2Hom& r) {
   const Fp two_inv = fp_two_inv();
   Fp2 a = fp2_mul_fp(fp2_mul(r.x, r.y), two_inv);
   Fp2 b = fp2_sqr(r.y);
@@ -50,7 +50,7 @@ RB_FN LineCoeffs g2hom_double(G2Hom& r) {
 }
 
 // Addition step: T <- T + Q (Q affine), returns the chord line coefficients.
-RB_FN LineCoeffs g2hom_add(G2Hom& r, const G2Aff& q) {
+RB_MID LineCoeffs g2hom_add(G2Hom& r, const G2Aff& q) {
   Fp2 theta = fp2_sub(r.y, fp2_mul(q.y, r.z));
   Fp2 lambda = fp2_sub(r.x, fp2_mul(q.x, r.z));
   Fp2 c = fp2_sqr(theta);
@@ -92,7 +92,7 @@ RB_HD MillerP miller_p_from_jac(const G1Jac& p) {
   return MillerP{mul(p.x, p.z), p.y, mul(z2, p.z), true};
 }
 
-RB_FN Fp12 ell(const Fp12& f, const LineCoeffs& l, const MillerP& p) {
+RB_MID Fp12 ell(const Fp12& f, const LineCoeffs& l, const MillerP& p) {
   Fp2 l0 = fp2_mul_fp(l.cy, p.py);
   Fp2 l1 = fp2_mul_fp(l.cx, p.px);
   Fp2 l3 = p.scaled ? fp2_mul_fp(l.c0, p.pz3) : l.c0;

@@ -73,7 +73,7 @@ RB_HD Fp6 fp6_mul_v(const Fp6& a) { return Fp6{fp2_mul_xi(a.a2), a.a0, a.a1}; }
 RB_HD bool fp6_eq(const Fp6& a, const Fp6& b) { return fp2_eq(a.a0, b.a0) & fp2_eq(a.a1, b.a1) & fp2_eq(a.a2, b.a2); }
 
 // Karatsuba, 6 Fp2 multiplications.
-RB_FN Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
+RB_MID Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   Fp2 v0 = fp2_mul(a.a0, b.a0);
   Fp2 v1 = fp2_mul(a.a1, b.a1);
   Fp2 v2 = fp2_mul(a.a2, b.a2);
@@ -87,7 +87,7 @@ RB_FN Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   return r;
 }
 // a * (b0 + b1 v): 5 Fp2 multiplications
-RB_FN Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
+RB_MID Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 v0 = fp2_mul(a.a0, b0);
   Fp2 v1 = fp2_mul(a.a1, b1);
   Fp2 t0 = fp2_mul(fp2_add(a.a1, a.a2), b1);                    // a1 b1 + a2 b1
@@ -99,9 +99,9 @@ RB_FN Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
   r.a2 = fp2_add(t2, v1);                                       // a2b0 + a1b1
   return r;
 }
-RB_FN Fp6 fp6_mul_fp2(const Fp6& a, const Fp2& b) { return Fp6{fp2_mul(a.a0, b), fp2_mul(a.a1, b), fp2_mul(a.a2, b)}; }
+RB_MID Fp6 fp6_mul_fp2(const Fp6& a, const Fp2& b) { return Fp6{fp2_mul(a.a0, b), fp2_mul(a.a1, b), fp2_mul(a.a2, b)}; }
 // CH-SQR2
-RB_FN Fp6 fp6_sqr(const Fp6& a) {
+RB_MID Fp6 fp6_sqr(const Fp6& a) {
   Fp2 s0 = fp2_sqr(a.a0);
   Fp2 ab = fp2_mul(a.a0, a.a1);
   Fp2 s1 = fp2_dbl(ab);
@@ -132,7 +132,7 @@ RB_HD Fp12 fp12_one() { return Fp12{fp6_one(), fp6_zero()}; }
 RB_HD bool fp12_eq(const Fp12& a, const Fp12& b) { return fp6_eq(a.c0, b.c0) & fp6_eq(a.c1, b.c1); }
 RB_HD Fp12 fp12_conj(const Fp12& a) { return Fp12{a.c0, fp6_neg(a.c1)}; }
 
-RB_FN Fp12 fp12_mul(const Fp12& a, const Fp12& b) {
+RB_MID Fp12 fp12_mul(const Fp12& a, const Fp12& b) {
   Fp6 t0 = fp6_mul(a.c0, b.c0);
   Fp6 t1 = fp6_mul(a.c1, b.c1);
   Fp6 t2 = fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1));
@@ -142,7 +142,7 @@ RB_FN Fp12 fp12_mul(const Fp12& a, const Fp12& b) {
   return r;
 }
 // complex squaring: 2 Fp6 multiplications
-RB_FN Fp12 fp12_sqr(const Fp12& a) {
+RB_MID Fp12 fp12_sqr(const Fp12& a) {
   Fp6 ab = fp6_mul(a.c0, a.c1);
   Fp6 t = fp6_mul(fp6_add(a.c0, a.c1), fp6_add(a.c0, fp6_mul_v(a.c1)));
   Fp12 r;
@@ -158,7 +158,7 @@ RB_FN Fp12 fp12_inv(const Fp12& a) {
 
 // f * (l0 + l1 w + l3 w^3)  [w^3 = v w]: the sparse line value of the D-type twist.
 // In Fp6[w] the line is c0 = (l0,0,0), c1 = (l1,l3,0).  13 Fp2 multiplications.
-RB_FN Fp12 fp12_mul_by_line(const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l3) {
+RB_MID Fp12 fp12_mul_by_line(const Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l3) {
   Fp6 t0 = fp6_mul_fp2(f.c0, l0);                                 // f0 * c0
   Fp6 t1 = fp6_mul_by_01(f.c1, l1, l3);                           // f1 * c1
   Fp6 t2 = fp6_mul_by_01(fp6_add(f.c0, f.c1), fp2_add(l0, l1), l3);   // (f0+f1)(c0+c1)
@@ -221,7 +221,7 @@ RB_FP_CONST(fp_two_inv, RB_FP_TWO_INV)
 
 // a^p: conjugate each Fp2 coefficient, multiply the coefficient of w^k by gamma1_k = xi^(k(p-1)/6).
 // Coefficient order by w-power: a0:w^0, a1:w^2, a2:w^4 | b0:w^1, b1:w^3, b2:w^5.
-RB_FN Fp12 fp12_frob1(const Fp12& a) {
+RB_MID Fp12 fp12_frob1(const Fp12& a) {
   Fp12 r;
   r.c0.a0 = fp2_conj(a.c0.a0);
   r.c0.a1 = fp2_mul(fp2_conj(a.c0.a1), gamma1_2());
@@ -232,7 +232,7 @@ RB_FN Fp12 fp12_frob1(const Fp12& a) {
   return r;
 }
 // a^(p^2): no conjugation, gamma2_k = xi^(k(p^2-1)/6) lies in Fp.
-RB_FN Fp12 fp12_frob2(const Fp12& a) {
+RB_MID Fp12 fp12_frob2(const Fp12& a) {
   Fp12 r;
   r.c0.a0 = a.c0.a0;
   r.c0.a1 = fp2_mul_fp(a.c0.a1, gamma2_2());
@@ -243,7 +243,7 @@ RB_FN Fp12 fp12_frob2(const Fp12& a) {
   return r;
 }
 // a^(p^3): conjugation, gamma3_k = xi^(k(p^3-1)/6).
-RB_FN Fp12 fp12_frob3(const Fp12& a) {
+RB_MID Fp12 fp12_frob3(const Fp12& a) {
   Fp12 r;
   r.c0.a0 = fp2_conj(a.c0.a0);
   r.c0.a1 = fp2_mul(fp2_conj(a.c0.a1), gamma3_2());
@@ -264,7 +264,7 @@ RB_HD void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   r0 = fp2_add(fp2_mul_xi(t1), t0);                       // a^2 + xi b^2
   r1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1);  // 2ab
 }
-RB_FN Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
+RB_MID Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
   Fp2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2;
   Fp2 z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
   Fp2 t0, t1, t2, t3, t4, t5;

@@ -22,6 +22,15 @@
 
 using namespace rabe::bn254;
 
+// Minimum resident waves per SIMD every kernel is compiled for (second __launch_bounds__ argument).
+// Measured on MI355X: 1 is best -- the Miller / final-exponentiation state
+// (Fq12 accumulator, G2 point, line, temporaries) then lives in the 512-entry VGPR+AGPR file instead of
+// scratch; asking for 2..4 waves caps the budget at 256..128 registers and the extra scratch traffic costs
+// more than the second wave hides (-2 % / -13 % / -20 %).
+#ifndef RB_MIN_WAVES
+#define RB_MIN_WAVES 1
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // context
 struct rhip_ctx {
@@ -249,7 +258,7 @@ __device__ __forceinline__ void ld_scalar(uint32_t k[8], const rhip_fr* p) {
 
 // ------------------------------------------------------------------------------------------------
 // Level E kernels
-__global__ void __launch_bounds__(256) k_fr_op(int op, size_t n, const rhip_fr* a, const rhip_fr* b, rhip_fr* out) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_fr_op(int op, size_t n, const rhip_fr* a, const rhip_fr* b, rhip_fr* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr x = load_fr(a[i].l);
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(256) k_fr_op(int op, size_t n, const rhip_fr* 
   }
   store_fr(out[i].l, r);
 }
-__global__ void __launch_bounds__(256) k_fr_from_be32(size_t n, const uint8_t* dig, rhip_fr* out) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_fr_from_be32(size_t n, const uint8_t* dig, rhip_fr* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t x[8];
@@ -274,63 +283,63 @@ __global__ void __launch_bounds__(256) k_fr_from_be32(size_t n, const uint8_t* d
   }
   store_fr(out[i].l, to_mont_reduce256<FrParams>(x));
 }
-__global__ void __launch_bounds__(256) k_g1_add(size_t n, const rhip_g1* a, const rhip_g1* b, rhip_g1* out, int negate_b) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_add(size_t n, const rhip_g1* a, const rhip_g1* b, rhip_g1* out, int negate_b) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Aff pb = load_g1(b[i].l);
   if (negate_b) pb = aff_neg(pb);
   store_g1(out[i].l, jac_to_aff(jac_add_aff(aff_to_jac(load_g1(a[i].l)), pb)));
 }
-__global__ void __launch_bounds__(256) k_g1_neg(size_t n, const rhip_g1* a, rhip_g1* out) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_neg(size_t n, const rhip_g1* a, rhip_g1* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_g1(out[i].l, aff_neg(load_g1(a[i].l)));
 }
-__global__ void __launch_bounds__(256) k_g1_mul(size_t n, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_mul(size_t n, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
   store_g1(out[i].l, jac_to_aff(jac_mul_binary(load_g1(p[i].l), kk)));
 }
-__global__ void __launch_bounds__(256) k_g1_on_curve(size_t n, const rhip_g1* p, uint32_t* ok) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_on_curve(size_t n, const rhip_g1* p, uint32_t* ok) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ok[i] = aff_on_curve(load_g1(p[i].l)) ? 1u : 0u;
 }
-__global__ void __launch_bounds__(128) k_g2_add(size_t n, const rhip_g2* a, const rhip_g2* b, rhip_g2* out) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_add(size_t n, const rhip_g2* a, const rhip_g2* b, rhip_g2* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_g2(out[i].l, jac_to_aff(jac_add_aff(aff_to_jac(load_g2(a[i].l)), load_g2(b[i].l))));
 }
-__global__ void __launch_bounds__(128) k_g2_neg(size_t n, const rhip_g2* a, rhip_g2* out) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_neg(size_t n, const rhip_g2* a, rhip_g2* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_g2(out[i].l, aff_neg(load_g2(a[i].l)));
 }
-__global__ void __launch_bounds__(128) k_g2_mul(size_t n, const rhip_g2* p, const rhip_fr* k, rhip_g2* out) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_mul(size_t n, const rhip_g2* p, const rhip_fr* k, rhip_g2* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
   store_g2(out[i].l, jac_to_aff(jac_mul_binary(load_g2(p[i].l), kk)));
 }
-__global__ void __launch_bounds__(128) k_g2_on_curve(size_t n, const rhip_g2* p, uint32_t* ok) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_on_curve(size_t n, const rhip_g2* p, uint32_t* ok) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ok[i] = aff_on_curve(load_g2(p[i].l)) ? 1u : 0u;
 }
-__global__ void __launch_bounds__(64) k_gt_mul(size_t n, const rhip_gt* a, const rhip_gt* b, rhip_gt* out) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_mul(size_t n, const rhip_gt* a, const rhip_gt* b, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_gt(out[i].l, fp12_mul(load_gt(a[i].l), load_gt(b[i].l)));
 }
-__global__ void __launch_bounds__(64) k_gt_inv(size_t n, const rhip_gt* a, rhip_gt* out) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_inv(size_t n, const rhip_gt* a, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_gt(out[i].l, fp12_inv(load_gt(a[i].l)));
 }
-__global__ void __launch_bounds__(64) k_gt_pow(size_t n, const rhip_gt* a, const rhip_fr* k, rhip_gt* out) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_pow(size_t n, const rhip_gt* a, const rhip_fr* k, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(64) k_gt_pow(size_t n, const rhip_gt* a, const
 // ------------------------------------------------------------------------------------------------
 // pairing: Miller loops (one lane per pair) then one final exponentiation per item
 // p_kind: 0 = affine canonical rhip_g1 input, 1 = Jacobian Montgomery G1JM input (no inversion was done)
-__global__ void __launch_bounds__(64) k_miller(size_t n, const rhip_g1* p, const rhip_g2* q, GtM* out) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller(size_t n, const rhip_g1* p, const rhip_g2* q, GtM* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Aff P = load_g1(p[i].l);
@@ -349,7 +358,7 @@ __global__ void __launch_bounds__(64) k_miller(size_t n, const rhip_g1* p, const
   st_gt_m(out + i, f);
 }
 // out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical
-__global__ void __launch_bounds__(64) k_final_exp(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
                                                   const rhip_gt* mul_in, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
@@ -388,21 +397,21 @@ __device__ __forceinline__ void window_scalar(uint32_t k[8], int w, int d) {
     default: k[7] = v; break;
   }
 }
-__global__ void __launch_bounds__(256) k_table_build_g1(const rhip_g1* base, G1M* tbl) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_table_build_g1(const rhip_g1* base, G1M* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= TBL_WINDOWS * TBL_DIGITS) return;
   uint32_t k[8];
   window_scalar(k, t / TBL_DIGITS, t % TBL_DIGITS + 1);
   st_g1_m(tbl + t, jac_to_aff(jac_mul_binary(load_g1(base->l), k)));
 }
-__global__ void __launch_bounds__(128) k_table_build_g2(const rhip_g2* base, G2M* tbl) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_build_g2(const rhip_g2* base, G2M* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= TBL_WINDOWS * TBL_DIGITS) return;
   uint32_t k[8];
   window_scalar(k, t / TBL_DIGITS, t % TBL_DIGITS + 1);
   st_g2_m(tbl + t, jac_to_aff(jac_mul_binary(load_g2(base->l), k)));
 }
-__global__ void __launch_bounds__(64) k_table_build_gt(const rhip_gt* base, GtM* tbl) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_build_gt(const rhip_gt* base, GtM* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= TBL_WINDOWS * TBL_DIGITS) return;
   uint32_t k[8];
@@ -454,21 +463,21 @@ __device__ __noinline__ Fp12 table_pow_gt(const GtM* tbl, const uint32_t k[8]) {
   }
   return acc;
 }
-__global__ void __launch_bounds__(256) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
   store_g1(out[i].l, jac_to_aff(table_mul_g1(tbl, kk)));
 }
-__global__ void __launch_bounds__(128) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
   store_g2(out[i].l, jac_to_aff(table_mul_g2(tbl, kk)));
 }
-__global__ void __launch_bounds__(64) k_table_pow_gt(const GtM* tbl, size_t n, const rhip_fr* k, rhip_gt* out) {
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_pow_gt(const GtM* tbl, size_t n, const rhip_fr* k, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
@@ -505,7 +514,7 @@ __device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac
 // one lane per ciphertext row (items may carry different policies):
 //   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
 //   row_off[i] <= row < row_off[i+1] and a = item_A_off[item] + (row - row_off[item]).
-__global__ void __launch_bounds__(256) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
                                                        const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_rows) return;
@@ -531,7 +540,7 @@ __global__ void __launch_bounds__(256) k_ac17_enc_rows(const G1M* g_tbl, size_t 
   store3_g1(c + t * 3, pt[0], pt[1], pt[2]);
 }
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
-__global__ void __launch_bounds__(128) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
                                                      const rhip_fr* s, rhip_g2* c0) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * 3) return;
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(128) k_ac17_enc_c0(const G2M* t0, const G2M* t
   store_g2(c0[t].l, jac_to_aff(table_mul_g2(tbl, kk)));
 }
 // one lane per item: c_p = e_gh_ka0^s0 * e_gh_ka1^s1 * msg
-__global__ void __launch_bounds__(64) k_ac17_enc_cp(const GtM* e0, const GtM* e1, size_t n_items, const rhip_fr* s,
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0, const GtM* e1, size_t n_items, const rhip_fr* s,
                                                     const rhip_gt* msg, rhip_gt* cp) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(64) k_ac17_enc_cp(const GtM* e0, const GtM* e1
 // keygen: one lane per (item, y <= n_attrs); y == n_attrs is the k_p row.
 //   K[y][t]  = g * ((sum_l H[y][l][t]*br_l + sigma_y) * a_t^-1),  K[y][2] = g * (-sigma_y)
 //   k_p[t]   = g_k[t] + g * ((sum_l H01[l][t]*br_l + sigma') * a_t^-1), k_p[2] = g_k[2] + g*(-sigma')
-__global__ void __launch_bounds__(256) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
                                                           size_t n_items, size_t n_attrs, const rhip_fr* H, const rhip_fr* H01,
                                                           const rhip_fr* r, const rhip_fr* sigma, const rhip_fr* sigma_p,
                                                           rhip_g1* k_out, rhip_g1* kp_out) {
@@ -600,7 +609,7 @@ __global__ void __launch_bounds__(256) k_ac17_keygen_rows(const G1M* g_tbl, cons
   store3_g1(dst, pt[0], pt[1], pt[2]);
 }
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
-__global__ void __launch_bounds__(128) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * 3) return;
   size_t item = t / 3;
@@ -616,7 +625,7 @@ __global__ void __launch_bounds__(128) k_ac17_keygen_k0(const G2M* h_tbl, const 
 //   i < 3 : P = sum_{x in ct_sel} C[x][i],                 Q = k_0[i]      (prod2, :416)
 //   i >= 3: P = -(k_p[i-3] + sum_{x in sk_sel} K[x][i-3]), Q = c_0[i-3]    (prod1^-1, :415,418)
 // P stays Jacobian (the line is scaled by Z^3 instead of inverting).
-__global__ void __launch_bounds__(64) k_ac17_dec_miller(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
                                                         const rhip_g2* sk_k0, const rhip_g1* sk_k, const uint32_t* sk_row_off,
                                                         const rhip_g1* sk_kp, const uint32_t* sk_idx, const uint32_t* ct_sel,
                                                         const uint32_t* ct_sel_off, const uint32_t* sk_sel, const uint32_t* sk_sel_off,
@@ -649,7 +658,7 @@ __global__ void __launch_bounds__(64) k_ac17_dec_miller(size_t n_items, const rh
 // ------------------------------------------------------------------------------------------------
 // integer-multiply issue-rate calibration (roofline denominator)
 template <int VARIANT>
-__global__ void __launch_bounds__(256) k_calibrate(uint32_t iters, uint32_t seed, uint32_t* sink) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_calibrate(uint32_t iters, uint32_t seed, uint32_t* sink) {
   uint32_t a = seed + threadIdx.x * 2654435761u, b = seed ^ (blockIdx.x * 40503u + 77u);
   uint64_t x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a * 3u, x5 = b * 5u, x6 = a * 7u, x7 = b * 9u;
   if (VARIANT == 5) {

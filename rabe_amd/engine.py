@@ -17,7 +17,8 @@ class EngineError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "librabe_hip.so")
+    # RABE_HIP_LIB selects an alternative build of the same library (kernel-tuning A/B runs)
+    return os.environ.get("RABE_HIP_LIB") or os.path.join(HERE, "librabe_hip.so")
 
 
 _LIB = None
