@@ -61,7 +61,7 @@ RB_HD Jac<F> aff_to_jac(const Aff<F>& p) {
 
 // dbl-2009-l (a = 0): 2M + 5S
 template <class F>
-RB_FN Jac<F> jac_dbl(const Jac<F>& p) {
+RB_MID Jac<F> jac_dbl(const Jac<F>& p) {
   F A = fsqr(p.x);
   F B = fsqr(p.y);
   F C = fsqr(B);
@@ -79,7 +79,7 @@ RB_FN Jac<F> jac_dbl(const Jac<F>& p) {
 
 // madd-2007-bl: Jacobian + affine, 7M + 4S, all special cases handled.
 template <class F>
-RB_FN Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
+RB_MID Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
   if (aff_is_inf(q)) return p;
   if (jac_is_inf(p)) return Jac<F>{q.x, q.y, fone<F>()};
   F Z1Z1 = fsqr(p.z);
@@ -105,7 +105,7 @@ RB_FN Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
 
 // add-2007-bl: Jacobian + Jacobian, 11M + 5S.
 template <class F>
-RB_FN Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+RB_MID Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   if (jac_is_inf(q)) return p;
   if (jac_is_inf(p)) return q;
   F Z1Z1 = fsqr(p.z);

@@ -27,6 +27,11 @@ using namespace rabe::bn254;
 // (Fq12 accumulator, G2 point, line, temporaries) then lives in the 512-entry VGPR+AGPR file instead of
 // scratch; asking for 2..4 waves caps the budget at 256..128 registers and the extra scratch traffic costs
 // more than the second wave hides (-2 % / -13 % / -20 %).
+// G1-only kernels carry a small state (a Jacobian accumulator and a table entry); they are compiled for
+// more resident waves so table-gather and dependent-issue latency overlap.
+#ifndef RB_G1_WAVES
+#define RB_G1_WAVES 4
+#endif
 #ifndef RB_MIN_WAVES
 #define RB_MIN_WAVES 1
 #endif
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_fr_from_be32(size_t n, co
   }
   store_fr(out[i].l, to_mont_reduce256<FrParams>(x));
 }
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_add(size_t n, const rhip_g1* a, const rhip_g1* b, rhip_g1* out, int negate_b) {
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_g1_add(size_t n, const rhip_g1* a, const rhip_g1* b, rhip_g1* out, int negate_b) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Aff pb = load_g1(b[i].l);
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_neg(size_t n, const rh
   if (i >= n) return;
   store_g1(out[i].l, aff_neg(load_g1(a[i].l)));
 }
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_mul(size_t n, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_g1_mul(size_t n, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
@@ -463,7 +468,7 @@ __device__ __noinline__ Fp12 table_pow_gt(const GtM* tbl, const uint32_t k[8]) {
   }
   return acc;
 }
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out) {
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t kk[8];
@@ -514,7 +519,7 @@ __device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac
 // one lane per ciphertext row (items may carry different policies):
 //   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
 //   row_off[i] <= row < row_off[i+1] and a = item_A_off[item] + (row - row_off[item]).
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
                                                        const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_rows) return;
@@ -571,7 +576,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0,
 // keygen: one lane per (item, y <= n_attrs); y == n_attrs is the k_p row.
 //   K[y][t]  = g * ((sum_l H[y][l][t]*br_l + sigma_y) * a_t^-1),  K[y][2] = g * (-sigma_y)
 //   k_p[t]   = g_k[t] + g * ((sum_l H01[l][t]*br_l + sigma') * a_t^-1), k_p[2] = g_k[2] + g*(-sigma')
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
                                                           size_t n_items, size_t n_attrs, const rhip_fr* H, const rhip_fr* H01,
                                                           const rhip_fr* r, const rhip_fr* sigma, const rhip_fr* sigma_p,
                                                           rhip_g1* k_out, rhip_g1* kp_out) {
