@@ -204,9 +204,120 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
   for (int i = 0; i < 8; i++) r[i] = t[i];
   cond_sub_mod<M>(r, 0);
 }
+// Two / three INDEPENDENT Montgomery multiplications in lockstep.  A single multiplication is one serial
+// dependency chain (mad -> addc -> mad ...); a kernel that runs one wave per SIMD (the Miller loop and the
+// final exponentiation keep ~500 registers of state) cannot hide that latency with other waves, so the Fp2
+// routines interleave their independent Fp products instead: each step issues N mads then N addcs on N
+// accumulators, with the carries in N different SGPR pairs.
+#define RB_MAC2(A0, O0, X0, Y0, A1, O1, X1, Y1)                                                       \
+  asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %2, %5, %8, %9, %2\n\t"                      \
+      "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
+      : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "=&s"(c0_), "=&s"(c1_)                                \
+      : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1))
+#define RB_MAC2_S(A0, O0, X0, A1, O1, X1, Y)                                                          \
+  asm("v_mad_u64_u32 %0, %4, %6, %8, %0\n\tv_mad_u64_u32 %2, %5, %7, %8, %2\n\t"                      \
+      "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
+      : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "=&s"(c0_), "=&s"(c1_)                                \
+      : "v"(X0), "v"(X1), "s"(Y))
+#define RB_MAC3(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2)                                       \
+  asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\tv_mad_u64_u32 %2, %7, %11, %12, %2\n\t"                   \
+      "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"                                                        \
+      "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
+      "v_addc_co_u32_e64 %5, %8, 0, %5, %8"                                                           \
+      : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "+v"(A2), "+v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
+      : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "v"(X2), "v"(Y2))
+#define RB_MAC3_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y)                                              \
+  asm("v_mad_u64_u32 %0, %6, %9, %12, %0\n\tv_mad_u64_u32 %2, %7, %10, %12, %2\n\t"                   \
+      "v_mad_u64_u32 %4, %8, %11, %12, %4\n\t"                                                        \
+      "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
+      "v_addc_co_u32_e64 %5, %8, 0, %5, %8"                                                           \
+      : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "+v"(A2), "+v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
+      : "v"(X0), "v"(X1), "v"(X2), "s"(Y))
+
+template <class M, class A>
+RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
+  uint32_t m0[8], m1[8];
+  uint64_t acc0 = 0, acc1 = 0, c0_, c1_;
+  uint32_t ovf0 = 0, ovf1 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+#pragma unroll
+    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) {
+      { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i]; RB_MAC2(acc0, ovf0, x0, y0, acc1, ovf1, x1, y1); }
+      if (i < k || k >= 8) {
+        if (!(k < 8 && i == k)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y); }
+      }
+    }
+    if (k < 8) {
+      m0[k] = (uint32_t)acc0 * M::INV;
+      m1[k] = (uint32_t)acc1 * M::INV;
+      { const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0); RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y); }
+    } else {
+      r0[k - 8] = (uint32_t)acc0;
+      r1[k - 8] = (uint32_t)acc1;
+    }
+    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
+    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
+  }
+  cond_sub_mod<M>(r0, 0);
+  cond_sub_mod<M>(r1, 0);
+}
+template <class M, class A>
+RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, const A& b0, const A& a1, const A& b1, const A& a2,
+                         const A& b2) {
+  uint32_t m0[8], m1[8], m2[8];
+  uint64_t acc0 = 0, acc1 = 0, acc2 = 0, c0_, c1_, c2_;
+  uint32_t ovf0 = 0, ovf1 = 0, ovf2 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+#pragma unroll
+    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) {
+      { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
+        RB_MAC3(acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2); }
+      if (!(k < 8 && i == k)) {
+        const uint32_t x0 = m0[i], x1 = m1[i], x2 = m2[i], y = M::mod(k - i);
+        RB_MAC3_S(acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y);
+      }
+    }
+    if (k < 8) {
+      m0[k] = (uint32_t)acc0 * M::INV;
+      m1[k] = (uint32_t)acc1 * M::INV;
+      m2[k] = (uint32_t)acc2 * M::INV;
+      { const uint32_t x0 = m0[k], x1 = m1[k], x2 = m2[k], y = M::mod(0); RB_MAC3_S(acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y); }
+    } else {
+      r0[k - 8] = (uint32_t)acc0;
+      r1[k - 8] = (uint32_t)acc1;
+      r2[k - 8] = (uint32_t)acc2;
+    }
+    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
+    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
+    acc2 = (acc2 >> 32) | ((uint64_t)ovf2 << 32); ovf2 = 0;
+  }
+  cond_sub_mod<M>(r0, 0);
+  cond_sub_mod<M>(r1, 0);
+  cond_sub_mod<M>(r2, 0);
+}
+#undef RB_MAC2
+#undef RB_MAC2_S
+#undef RB_MAC3
+#undef RB_MAC3_S
 #undef RB_MAC
 #undef RB_MAC_S
 #else
+// host: the interleaved forms are just independent multiplications
+template <class M, class A, class B> RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b);
+template <class M, class A>
+RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
+  mont_mul_raw<M>(r0, a0, b0);
+  mont_mul_raw<M>(r1, a1, b1);
+}
+template <class M, class A>
+RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, const A& b0, const A& a1, const A& b1, const A& a2,
+                         const A& b2) {
+  mont_mul_raw<M>(r0, a0, b0);
+  mont_mul_raw<M>(r1, a1, b1);
+  mont_mul_raw<M>(r2, a2, b2);
+}
 // portable form (host build of the same headers: tests/hostsim)
 template <class M, class A, class B>
 RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
@@ -261,6 +372,24 @@ RB_HD Mont<M> mul_inl(const Mont<M>& a, const Mont<M>& b) {
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   return r;
+}
+// N independent products at once (see mont_mul2_raw / mont_mul3_raw)
+template <class M>
+RB_HD void mul2_inl(Mont<M>& r0, Mont<M>& r1, const Mont<M>& a0, const Mont<M>& b0, const Mont<M>& a1, const Mont<M>& b1) {
+  RB_COUNT_ONE_MUL(); RB_COUNT_ONE_MUL();
+  uint32_t t0[8], t1[8];
+  mont_mul2_raw<M>(t0, t1, a0.v, b0.v, a1.v, b1.v);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r0.v[i] = t0[i]; r1.v[i] = t1[i]; }
+}
+template <class M>
+RB_HD void mul3_inl(Mont<M>& r0, Mont<M>& r1, Mont<M>& r2, const Mont<M>& a0, const Mont<M>& b0, const Mont<M>& a1, const Mont<M>& b1,
+                    const Mont<M>& a2, const Mont<M>& b2) {
+  RB_COUNT_ONE_MUL(); RB_COUNT_ONE_MUL(); RB_COUNT_ONE_MUL();
+  uint32_t t0[8], t1[8], t2[8];
+  mont_mul3_raw<M>(t0, t1, t2, a0.v, b0.v, a1.v, b1.v, a2.v, b2.v);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r0.v[i] = t0[i]; r1.v[i] = t1[i]; r2.v[i] = t2[i]; }
 }
 // out-of-line form: operands and result travel in VGPRs
 template <class M>

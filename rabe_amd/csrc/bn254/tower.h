@@ -25,9 +25,8 @@ RB_HD Fp2 fp2_conj(const Fp2& a) { return Fp2{a.c0, neg(a.c1)}; }
 
 // Karatsuba: 3 Fp multiplications.  Out of line; the four Fp operands travel in 32 VGPRs.
 RB_FN Fp2 fp2_mul_regs(Fp a0, Fp a1, Fp b0, Fp b1) {
-  Fp t0 = mul_inl(a0, b0);
-  Fp t1 = mul_inl(a1, b1);
-  Fp t2 = mul_inl(add(a0, a1), add(b0, b1));
+  Fp t0, t1, t2;
+  mul3_inl(t0, t1, t2, a0, b0, a1, b1, add(a0, a1), add(b0, b1));     // three independent products, interleaved
   Fp2 r;
   r.c0 = sub(t0, t1);
   r.c1 = sub(sub(t2, t0), t1);
@@ -36,12 +35,16 @@ RB_FN Fp2 fp2_mul_regs(Fp a0, Fp a1, Fp b0, Fp b1) {
 RB_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) { return fp2_mul_regs(a.c0, a.c1, b.c0, b.c1); }
 // (a0+a1)(a0-a1) + 2 a0 a1 u: 2 Fp multiplications.
 RB_FN Fp2 fp2_sqr_regs(Fp a0, Fp a1) {
-  Fp t0 = mul_inl(add(a0, a1), sub(a0, a1));
-  Fp t1 = mul_inl(a0, a1);
+  Fp t0, t1;
+  mul2_inl(t0, t1, add(a0, a1), sub(a0, a1), a0, a1);
   return Fp2{t0, dbl(t1)};
 }
 RB_HD Fp2 fp2_sqr(const Fp2& a) { return fp2_sqr_regs(a.c0, a.c1); }
-RB_FN Fp2 fp2_mul_fp_regs(Fp a0, Fp a1, Fp k) { return Fp2{mul_inl(a0, k), mul_inl(a1, k)}; }
+RB_FN Fp2 fp2_mul_fp_regs(Fp a0, Fp a1, Fp k) {
+  Fp2 r;
+  mul2_inl(r.c0, r.c1, a0, k, a1, k);
+  return r;
+}
 RB_HD Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { return fp2_mul_fp_regs(a.c0, a.c1, k); }
 // (c0 + c1 u)(9 + u) = (9 c0 - c1) + (c0 + 9 c1) u
 RB_HD Fp2 fp2_mul_xi(const Fp2& a) {
