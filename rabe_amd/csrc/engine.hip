@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, 
 // fixed-base tables: T[w][d-1] = (d * 256^w) * base, d = 1..255, w = 0..31, affine Montgomery.
 #define TBL_WINDOWS 32
 #define TBL_DIGITS 255
-struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; };
+struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; G1M* dev16; };   // dev: 8-bit windows; dev16: optional 16-bit windows
 struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; };
 struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; };
 
@@ -408,6 +408,20 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_table_build_g1(const rhip
   uint32_t k[8];
   window_scalar(k, t / TBL_DIGITS, t % TBL_DIGITS + 1);
   st_g1_m(tbl + t, jac_to_aff(jac_mul_binary(load_g1(base->l), k)));
+}
+// 16-bit windows for the hot G1 base (AC17's g: 150 fixed-base multiplications per encrypt):
+//   T16[w][d-1] = (d * 65536^w) * base = T8[2w][d & 255] + T8[2w+1][d >> 8],  d = 1..65535, w = 0..15   (67 MB)
+#define TBL16_WINDOWS 16
+#define TBL16_DIGITS 65535
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_build_g1_w16(const G1M* t8, G1M* t16) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)TBL16_WINDOWS * TBL16_DIGITS) return;
+  const uint32_t w = (uint32_t)(t / TBL16_DIGITS), d = (uint32_t)(t % TBL16_DIGITS) + 1;
+  const uint32_t lo = d & 255u, hi = d >> 8;
+  G1Jac acc = jac_inf<Fp>();
+  if (lo) acc = jac_add_aff(acc, ld_g1_m(t8 + (2 * w) * TBL_DIGITS + (lo - 1)));
+  if (hi) acc = jac_add_aff(acc, ld_g1_m(t8 + (2 * w + 1) * TBL_DIGITS + (hi - 1)));
+  st_g1_m(t16 + t, jac_to_aff(acc));
 }
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_build_g2(const rhip_g2* base, G2M* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,6 +458,35 @@ __device__ __noinline__ G1Jac table_mul_g1(const G1M* tbl, const uint32_t k[8]) 
   for (int w = 0; w < TBL_WINDOWS; w++) {
     uint32_t d = scalar_byte(k, w);
     if (d) acc = jac_add_aff(acc, ld_g1_m(tbl + w * TBL_DIGITS + (d - 1)));
+  }
+  return acc;
+}
+// 16-bit digits: 16 mixed additions; the next entry is fetched while the current addition runs
+__device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[8]) {
+  G1Jac acc = jac_inf<Fp>();
+  uint32_t d = k[0] & 0xffffu;
+  G1Aff e = ld_g1_m(tbl + (d ? d - 1 : 0));
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    const uint32_t dcur = d;
+    const G1Aff ecur = e;
+    if (w + 1 < TBL16_WINDOWS) {
+      const int wn = w + 1;
+      uint32_t word;
+      switch (wn >> 1) {
+        case 0: word = k[0]; break;
+        case 1: word = k[1]; break;
+        case 2: word = k[2]; break;
+        case 3: word = k[3]; break;
+        case 4: word = k[4]; break;
+        case 5: word = k[5]; break;
+        case 6: word = k[6]; break;
+        default: word = k[7]; break;
+      }
+      d = (wn & 1) ? (word >> 16) : (word & 0xffffu);
+      e = ld_g1_m(tbl + (size_t)wn * TBL16_DIGITS + (d ? d - 1 : 0));
+    }
+    if (dcur) acc = jac_add_aff(acc, ecur);
   }
   return acc;
 }
@@ -520,7 +563,8 @@ __device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac
 //   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
 //   row_off[i] <= row < row_off[i+1] and a = item_A_off[item] + (row - row_off[item]).
 __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
-                                                       const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c) {
+                                                       const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c,
+                                                       int w16) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_rows) return;
   // binary search for the item owning row t (row_off is non-decreasing, row_off[n_items] = total_rows)
@@ -539,7 +583,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g
     Fr k = add(mul(s0, a0), mul(s1, a1));
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
-    G1Jac r = table_mul_g1(g_tbl, kk);
+    G1Jac r = w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (l == 0) pt[0] = r; else if (l == 1) pt[1] = r; else pt[2] = r;
   }
   store3_g1(c + t * 3, pt[0], pt[1], pt[2]);
@@ -860,6 +904,7 @@ static int32_t table_create(rhip_ctx* ctx, const BASE* host_base, TBL** out, KER
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipFree(dbase));
   TBL* t = new TBL();
+  memset((void*)t, 0, sizeof(TBL));
   t->ctx = ctx;
   t->dev = dev;
   *out = t;
@@ -874,7 +919,20 @@ extern "C" int32_t rhip_g2_table_create(rhip_ctx* ctx, const rhip_g2* b, rhip_g2
 extern "C" int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* b, rhip_gt_table** out) {
   return table_create<rhip_gt_table, GtM>(ctx, b, out, k_table_build_gt, 64);
 }
-extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
+extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) { if (t) { (void)hipFree(t->dev); if (t->dev16) (void)hipFree(t->dev16); delete t; } }
+// adds the 16-bit-window table (67 MB) to an existing G1 table
+extern "C" int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t) {
+  NEED(ctx);
+  if (!t) return RHIP_ERR_ARG;
+  if (t->dev16) return RHIP_OK;
+  G1M* d16 = nullptr;
+  const size_t n = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  HIP_TRY(ctx, hipMalloc((void**)&d16, sizeof(G1M) * n));
+  KLAUNCH(ctx, "k_table_build_g1_w16", k_table_build_g1_w16, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const G1M*)t->dev, d16);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t->dev16 = d16;
+  return RHIP_OK;
+}
 extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
 extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
 extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size_t n, const rhip_fr* k, rhip_g1* out) {
@@ -917,6 +975,7 @@ extern "C" int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* g, const rh
   for (int i = 0; i < 3; i++) pk->h_a[i] = nullptr;
   for (int i = 0; i < 2; i++) pk->e[i] = nullptr;
   int32_t rc = rhip_g1_table_create(ctx, g, &pk->g);
+  if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->g);
   for (int i = 0; i < 3 && !rc; i++) rc = rhip_g2_table_create(ctx, h_a + i, &pk->h_a[i]);
   for (int i = 0; i < 2 && !rc; i++) rc = rhip_gt_table_create(ctx, e + i, &pk->e[i]);
   if (rc) { rhip_ac17_pk_destroy(pk); return rc; }
@@ -930,8 +989,8 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
   if (!pk) return RHIP_ERR_ARG;
   if (!n_items) return RHIP_OK;
   if (total_rows) {
-    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, (const G1M*)pk->g->dev,
-                       n_items, total_rows, A, item_A_off, ct_row_off, s, c);
+    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, (const G1M*)(pk->g->dev16 ? pk->g->dev16 : pk->g->dev),
+                       n_items, total_rows, A, item_A_off, ct_row_off, s, c, pk->g->dev16 ? 1 : 0);
   }
   KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
                      (const G2M*)pk->h_a[1]->dev, (const G2M*)pk->h_a[2]->dev, n_items, s, c0);
