@@ -113,6 +113,8 @@ int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* host_base, rhip_gt_ta
 /* adds 16-bit windows (16 x 65535 entries, 67 MB) to a G1 table: halves the additions of rhip_g1_table_mul-style
  * kernels; rhip_ac17_pk_create does this for the public generator g */
 int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t);
+/* the same for a Gt base (16 x 65535 x 384 B = 402 MB): halves the multiplications of a fixed-base Gt power */
+int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t);
 void rhip_g1_table_destroy(rhip_g1_table* t);
 void rhip_g2_table_destroy(rhip_g2_table* t);
 void rhip_gt_table_destroy(rhip_gt_table* t);

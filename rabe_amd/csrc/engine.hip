@@ -383,9 +383,11 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, 
 // fixed-base tables: T[w][d-1] = (d * 256^w) * base, d = 1..255, w = 0..31, affine Montgomery.
 #define TBL_WINDOWS 32
 #define TBL_DIGITS 255
+#define TBL16_WINDOWS 16
+#define TBL16_DIGITS 65535
 struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; G1M* dev16; };   // dev: 8-bit windows; dev16: optional 16-bit windows
 struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; };
-struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; };
+struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optional 16-bit windows (402 MB)
 
 __device__ __forceinline__ void window_scalar(uint32_t k[8], int w, int d) {
 #pragma unroll
@@ -411,8 +413,6 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_table_build_g1(const rhip
 }
 // 16-bit windows for the hot G1 base (AC17's g: 150 fixed-base multiplications per encrypt):
 //   T16[w][d-1] = (d * 65536^w) * base = T8[2w][d & 255] + T8[2w+1][d >> 8],  d = 1..65535, w = 0..15   (67 MB)
-#define TBL16_WINDOWS 16
-#define TBL16_DIGITS 65535
 __global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_build_g1_w16(const G1M* t8, G1M* t16) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)TBL16_WINDOWS * TBL16_DIGITS) return;
@@ -438,6 +438,43 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_build_gt(const rhip_
   st_gt_m(tbl + t, gt_pow_binary(load_gt(base->l), k));
 }
 
+// 16-bit windows for Gt powers of public-key constants: T16[w][d-1] = base^(d * 65536^w) = T8[2w][d&255] * T8[2w+1][d>>8]
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_build_gt_w16(const GtM* t8, GtM* t16) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)TBL16_WINDOWS * TBL16_DIGITS) return;
+  const uint32_t w = (uint32_t)(t / TBL16_DIGITS), d = (uint32_t)(t % TBL16_DIGITS) + 1;
+  const uint32_t lo = d & 255u, hi = d >> 8;
+  Fp12 r;
+  if (lo && hi) r = fp12_mul(ld_gt_m(t8 + (2 * w) * TBL_DIGITS + (lo - 1)), ld_gt_m(t8 + (2 * w + 1) * TBL_DIGITS + (hi - 1)));
+  else if (lo) r = ld_gt_m(t8 + (2 * w) * TBL_DIGITS + (lo - 1));
+  else r = ld_gt_m(t8 + (2 * w + 1) * TBL_DIGITS + (hi - 1));
+  st_gt_m(t16 + t, r);
+}
+__device__ __noinline__ Fp12 table_pow_gt_w16(const GtM* tbl, const uint32_t k[8]) {
+  Fp12 acc = fp12_one();
+  bool first = true;
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    uint32_t word;
+    switch (w >> 1) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+    if (d) {
+      Fp12 e = ld_gt_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1));
+      acc = first ? e : fp12_mul(acc, e);
+      first = false;
+    }
+  }
+  return acc;
+}
 __device__ __forceinline__ uint32_t scalar_byte(const uint32_t k[8], int w) {
   uint32_t word;
   switch (w >> 2) {
@@ -607,13 +644,13 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0
 }
 // one lane per item: c_p = e_gh_ka0^s0 * e_gh_ka1^s1 * msg
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0, const GtM* e1, size_t n_items, const rhip_fr* s,
-                                                    const rhip_gt* msg, rhip_gt* cp) {
+                                                    const rhip_gt* msg, rhip_gt* cp, int w16) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   uint32_t k0[8], k1[8];
   ld_scalar(k0, s + 2 * i);
   ld_scalar(k1, s + 2 * i + 1);
-  Fp12 r = fp12_mul(table_pow_gt(e0, k0), table_pow_gt(e1, k1));
+  Fp12 r = w16 ? fp12_mul(table_pow_gt_w16(e0, k0), table_pow_gt_w16(e1, k1)) : fp12_mul(table_pow_gt(e0, k0), table_pow_gt(e1, k1));
   store_gt(cp[i].l, fp12_mul(r, load_gt(msg[i].l)));
 }
 
@@ -934,7 +971,19 @@ extern "C" int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t) {
   return RHIP_OK;
 }
 extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
-extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
+extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { (void)hipFree(t->dev); if (t->dev16) (void)hipFree(t->dev16); delete t; } }
+extern "C" int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t) {
+  NEED(ctx);
+  if (!t) return RHIP_ERR_ARG;
+  if (t->dev16) return RHIP_OK;
+  GtM* d16 = nullptr;
+  const size_t n = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  HIP_TRY(ctx, hipMalloc((void**)&d16, sizeof(GtM) * n));
+  KLAUNCH(ctx, "k_table_build_gt_w16", k_table_build_gt_w16, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, (const GtM*)t->dev, d16);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t->dev16 = d16;
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size_t n, const rhip_fr* k, rhip_g1* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
@@ -977,7 +1026,10 @@ extern "C" int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* g, const rh
   int32_t rc = rhip_g1_table_create(ctx, g, &pk->g);
   if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->g);
   for (int i = 0; i < 3 && !rc; i++) rc = rhip_g2_table_create(ctx, h_a + i, &pk->h_a[i]);
-  for (int i = 0; i < 2 && !rc; i++) rc = rhip_gt_table_create(ctx, e + i, &pk->e[i]);
+  for (int i = 0; i < 2 && !rc; i++) {
+    rc = rhip_gt_table_create(ctx, e + i, &pk->e[i]);
+    if (!rc) rc = rhip_gt_table_add_w16(ctx, pk->e[i]);
+  }
   if (rc) { rhip_ac17_pk_destroy(pk); return rc; }
   *out = pk;
   return RHIP_OK;
@@ -994,8 +1046,10 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
   }
   KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
                      (const G2M*)pk->h_a[1]->dev, (const G2M*)pk->h_a[2]->dev, n_items, s, c0);
-  KLAUNCH(ctx, "k_ac17_enc_cp", k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, (const GtM*)pk->e[0]->dev,
-                     (const GtM*)pk->e[1]->dev, n_items, s, msg, cp);
+  const bool gt16 = pk->e[0]->dev16 && pk->e[1]->dev16;
+  KLAUNCH(ctx, "k_ac17_enc_cp", k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream,
+          (const GtM*)(gt16 ? pk->e[0]->dev16 : pk->e[0]->dev), (const GtM*)(gt16 ? pk->e[1]->dev16 : pk->e[1]->dev), n_items, s, msg, cp,
+          gt16 ? 1 : 0);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table* g_table, const rhip_g2_table* h_table, const rhip_g1* g_k,
