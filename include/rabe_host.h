@@ -20,7 +20,7 @@ extern "C" {
 typedef struct rabe_host rabe_host;
 
 enum {   /* object kinds for rabe_obj_free / rabe_obj_serialize / rabe_obj_deserialize */
-  RABE_AC17_PK = 1, RABE_AC17_MSK = 2, RABE_AC17_CP_SK = 3, RABE_AC17_CP_CT = 4,
+  RABE_AC17_PK = 1, RABE_AC17_MSK = 2, RABE_AC17_CP_SK = 3, RABE_AC17_CP_CT = 4, RABE_AC17_KP_SK = 5, RABE_AC17_KP_CT = 6,
   RABE_BSW_PK = 10, RABE_BSW_MSK = 11, RABE_BSW_SK = 12, RABE_BSW_CT = 13,
   RABE_LSW_PK = 20, RABE_LSW_MSK = 21, RABE_LSW_SK = 22, RABE_LSW_CT = 23,
   RABE_AW11_GK = 30, RABE_AW11_PK = 31, RABE_AW11_MSK = 32, RABE_AW11_SK = 33, RABE_AW11_CT = 34
@@ -53,9 +53,16 @@ int32_t rabe_ac17_cp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const
 int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                    uint8_t** plaintexts, size_t* lens);
 
+/* KP-ABE variant (src/schemes/ac17/mod.rs:439-675) */
+int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, int32_t language, void** sk);
+int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct);
+int32_t rabe_ac17_kp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+
 /* ---- bsw (src/schemes/bsw/mod.rs:92-318) */
 int32_t rabe_bsw_setup(rabe_host* h, void** pk, void** msk);
 int32_t rabe_bsw_keygen(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, size_t n, void** sk);
+int32_t rabe_bsw_delegate(rabe_host* h, const void* pk, const void* sk, const char* const* subset, size_t n, void** out_sk);
 int32_t rabe_bsw_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct);
 int32_t rabe_bsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_bsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);

@@ -158,6 +158,101 @@ def ac17_cp_decrypt(sk, ct):
     return bn.gt_mul(ct["ct"]["c_p"], bn.gt_mul(prod2, bn.gt_inv(prod1)))
 
 
+def ac17_kp_keygen(msk, policy, language, rng):
+    """ac17/mod.rs:439-547.  Draw order: r0, r1 (:455-459), sigma'_1..sigma'_{c-1} (:471-474), then sigma_i per row (:481)."""
+    tree = pol.parse(policy, language)
+    m, pi, _c = pol.calculate_msp(tree)
+    num_cols, num_rows = len(m[0]), len(m)
+    r = [rng.fr() for _ in range(ASSUMPTION_SIZE)]
+    br = [msk["b"][i] * r[i] % bn.R for i in range(ASSUMPTION_SIZE)] + [sum(r) % bn.R]
+    k_0 = [bn.g2_mul(msk["h"], br[i]) for i in range(ASSUMPTION_SIZE + 1)]
+    sigma_prime = [rng.fr() for _ in range(num_cols - 1)]
+    a, g = msk["a"], msk["g"]
+    k = []
+    for i in range(num_rows):
+        key = []
+        sigma_attr = rng.fr()
+        for t in range(ASSUMPTION_SIZE):
+            prod = None
+            a_t = bn.fr_inv(a[t])
+            for l in range(ASSUMPTION_SIZE + 1):
+                prod = bn.g1_add(prod, bn.g1_mul(sha3_hash_g1(g, pi[i] + str(l) + str(t)), br[l] * a_t % bn.R))
+            prod = bn.g1_add(prod, bn.g1_mul(g, sigma_attr * a_t % bn.R))
+            if m[i][0] == 1:
+                prod = bn.g1_add(prod, msk["g_k"][t])
+            elif m[i][0] == -1:
+                prod = bn.g1_sub(prod, msk["g_k"][t])
+            temp = None                                   # NOT reset per column: accumulates across j (:496-516)
+            for j in range(1, num_cols):
+                for l in range(ASSUMPTION_SIZE + 1):
+                    temp = bn.g1_add(temp, bn.g1_mul(sha3_hash_g1(g, "0" + str(j) + str(l) + str(t)), br[l] * a_t % bn.R))
+                temp = bn.g1_add(temp, bn.g1_mul(g, (-sigma_prime[j - 1]) % bn.R))
+                if m[i][j] == 1:
+                    prod = bn.g1_add(prod, temp)
+                elif m[i][j] == -1:
+                    prod = bn.g1_sub(prod, temp)
+            key.append(prod)
+        sk_i3 = bn.g1_mul(g, (-sigma_attr) % bn.R)
+        if m[i][0] == 1:
+            sk_i3 = bn.g1_add(sk_i3, msk["g_k"][ASSUMPTION_SIZE])
+        elif m[i][0] == -1:
+            sk_i3 = bn.g1_sub(sk_i3, msk["g_k"][ASSUMPTION_SIZE])
+        for j in range(1, num_cols):
+            if m[i][j] == 1:
+                sk_i3 = bn.g1_add(sk_i3, bn.g1_mul(g, (-sigma_prime[j - 1]) % bn.R))
+            elif m[i][j] == -1:
+                sk_i3 = bn.g1_sub(sk_i3, bn.g1_mul(g, (-sigma_prime[j - 1]) % bn.R))
+        key.append(sk_i3)
+        k.append((pi[i], key))
+    return {"policy": (policy, language), "sk": {"k_0": k_0, "k": k, "k_p": []}}
+
+
+def ac17_kp_encrypt(pk, attributes, rng, msg):
+    """ac17/mod.rs:556-616."""
+    s = [rng.fr() for _ in range(ASSUMPTION_SIZE)]
+    ssum = sum(s) % bn.R
+    c_0 = [bn.g2_mul(pk["h_a"][i], s[i]) for i in range(ASSUMPTION_SIZE)]
+    c_0.append(bn.g2_mul(pk["h_a"][ASSUMPTION_SIZE], ssum))
+    c = []
+    for attr in attributes:
+        ct = []
+        for l in range(ASSUMPTION_SIZE + 1):
+            prod = None
+            for t in range(ASSUMPTION_SIZE):
+                prod = bn.g1_add(prod, bn.g1_mul(sha3_hash_g1(pk["g"], attr + str(l) + str(t)), s[t]))
+            ct.append(prod)
+        c.append((attr, ct))
+    c_p = bn.GT_ONE
+    for i in range(ASSUMPTION_SIZE):
+        c_p = bn.gt_mul(c_p, bn.gt_pow(pk["e_gh_ka"][i], s[i]))
+    return {"attr": list(attributes), "ct": {"c_0": c_0, "c": c, "c_p": bn.gt_mul(c_p, msg)}}
+
+
+def ac17_kp_decrypt(sk, ct):
+    """ac17/mod.rs:625-675."""
+    tree = pol.parse(sk["policy"][0], sk["policy"][1])
+    if not pol.traverse_policy(ct["attr"], tree):
+        raise ValueError("Error in kp_decrypt: attributes in ct do not match policy in sk.")
+    ok, lst = pol.calc_pruned(ct["attr"], tree)
+    if not ok:
+        raise ValueError("Error in kp_decrypt: pruned attributes in sk do not match policy in ct.")
+    prod1 = bn.GT_ONE
+    prod2 = bn.GT_ONE
+    for i in range(ASSUMPTION_SIZE + 1):
+        prod_h = None
+        prod_g = None
+        for cur in lst:
+            for name, vec in ct["ct"]["c"]:
+                if name == cur[0]:
+                    prod_g = bn.g1_add(prod_g, vec[i])
+            for name, vec in sk["sk"]["k"]:
+                if name == cur[0]:
+                    prod_h = bn.g1_add(prod_h, vec[i])
+        prod1 = bn.gt_mul(prod1, bn.pairing(prod_h, ct["ct"]["c_0"][i]))
+        prod2 = bn.gt_mul(prod2, bn.pairing(prod_g, sk["sk"]["k_0"][i]))
+    return bn.gt_mul(ct["ct"]["c_p"], bn.gt_mul(prod2, bn.gt_inv(prod1)))
+
+
 # ============================================================================= BSW
 
 def bsw_setup(rng):
@@ -188,6 +283,24 @@ def bsw_keygen(pk, msk, attributes, rng):
                     "g1": bn.g1_mul(pk["g1"], r_j),
                     "g2": bn.g2_add(g2_r, bn.g2_mul(sha3_hash_g2(pk["g2"], j), r_j))})
     return {"d": d, "d_j": d_j}
+
+
+def bsw_delegate(pk, sk, subset, rng):
+    """bsw/mod.rs:162-206.  Draw order: r (:185), then r_j per delegated attribute (:190)."""
+    attr_str = [v["string"] for v in sk["d_j"]]
+    if not set(subset).issubset(set(attr_str)):
+        return None
+    if len(subset) == 0:
+        return None
+    r = rng.fr()
+    d_j = []
+    for attr in subset:
+        r_j = rng.fr()
+        old = next(x for x in sk["d_j"] if x["string"] == attr)
+        d_j.append({"string": attr,
+                    "g1": bn.g1_add(old["g1"], bn.g1_mul(pk["g1"], r_j)),
+                    "g2": bn.g2_add(bn.g2_add(old["g2"], bn.g2_mul(sha3_hash_g2(pk["g2"], attr), r_j)), bn.g2_mul(pk["g2"], r))})
+    return {"d": bn.g2_add(sk["d"], bn.g2_mul(pk["f"], r)), "d_j": d_j}
 
 
 def bsw_encrypt(pk, policy, language, rng, msg):

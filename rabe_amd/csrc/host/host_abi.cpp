@@ -74,6 +74,9 @@ static void ser(W& w, int32_t kind, const void* o) {
                             w.vec(x.sk.k_0); w_named(w, x.sk.k); w.vec(x.sk.k_p); break; }
     case RABE_AC17_CP_CT: { auto& x = *(const ac17::Ac17CpCiphertext*)o; w.pol(x.policy); w.vec(x.ct.c_0); w_named(w, x.ct.c); w.el(x.ct.c_p);
                             w.bytes(x.ct.ct); break; }
+    case RABE_AC17_KP_SK: { auto& x = *(const ac17::Ac17KpSecretKey*)o; w.pol(x.policy); w.vec(x.sk.k_0); w_named(w, x.sk.k); w.vec(x.sk.k_p); break; }
+    case RABE_AC17_KP_CT: { auto& x = *(const ac17::Ac17KpCiphertext*)o; w.u32((uint32_t)x.attr.size()); for (auto& a : x.attr) w.str(a);
+                            w.vec(x.ct.c_0); w_named(w, x.ct.c); w.el(x.ct.c_p); w.bytes(x.ct.ct); break; }
     case RABE_BSW_PK: { auto& x = *(const bsw::CpAbePublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.h); w.el(x.f); w.el(x.e_gg_alpha); break; }
     case RABE_BSW_MSK: { auto& x = *(const bsw::CpAbeMasterKey*)o; w.fr(x.beta); w.el(x.g2_alpha); break; }
     case RABE_BSW_SK: { auto& x = *(const bsw::CpAbeSecretKey*)o; w.el(x.d); w.u32((uint32_t)x.d_j.size());
@@ -106,6 +109,9 @@ static void* deser(R& r, int32_t kind) {
                             x->sk.k_0 = r.vec<128>(); x->sk.k = r_named(r); x->sk.k_p = r.vec<64>(); return x; }
     case RABE_AC17_CP_CT: { auto* x = new ac17::Ac17CpCiphertext(); x->policy = r.pol(); x->ct.c_0 = r.vec<128>(); x->ct.c = r_named(r);
                             x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return x; }
+    case RABE_AC17_KP_SK: { auto* x = new ac17::Ac17KpSecretKey(); x->policy = r.pol(); x->sk.k_0 = r.vec<128>(); x->sk.k = r_named(r); x->sk.k_p = r.vec<64>(); return x; }
+    case RABE_AC17_KP_CT: { auto* x = new ac17::Ac17KpCiphertext(); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
+                            x->ct.c_0 = r.vec<128>(); x->ct.c = r_named(r); x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return x; }
     case RABE_BSW_PK: { auto* x = new bsw::CpAbePublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->h = r.el<64>(); x->f = r.el<128>(); x->e_gg_alpha = r.el<384>(); return x; }
     case RABE_BSW_MSK: { auto* x = new bsw::CpAbeMasterKey(); x->beta = r.fr(); x->g2_alpha = r.el<128>(); return x; }
     case RABE_BSW_SK: { auto* x = new bsw::CpAbeSecretKey(); x->d = r.el<128>(); uint32_t c = r.u32();
@@ -184,6 +190,8 @@ void rabe_obj_free(int32_t kind, void* o) {
     case RABE_AC17_MSK: delete (ac17::Ac17MasterKey*)o; break;
     case RABE_AC17_CP_SK: delete (ac17::Ac17CpSecretKey*)o; break;
     case RABE_AC17_CP_CT: delete (ac17::Ac17CpCiphertext*)o; break;
+    case RABE_AC17_KP_SK: delete (ac17::Ac17KpSecretKey*)o; break;
+    case RABE_AC17_KP_CT: delete (ac17::Ac17KpCiphertext*)o; break;
     case RABE_BSW_PK: delete (bsw::CpAbePublicKey*)o; break;
     case RABE_BSW_MSK: delete (bsw::CpAbeMasterKey*)o; break;
     case RABE_BSW_SK: delete (bsw::CpAbeSecretKey*)o; break;
@@ -276,7 +284,40 @@ int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sk
   GUARD_END(h)
 }
 
+int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, int32_t language, void** sk) {
+  GUARD_BEGIN
+  *sk = new ac17::Ac17KpSecretKey(ac17::kp_keygen(h->eng, h->rng(), *(const ac17::Ac17MasterKey*)msk, policy, lang_of(language)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct) {
+  GUARD_BEGIN
+  *ct = new ac17::Ac17KpCiphertext(ac17::kp_encrypt(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, strs(attributes, n), Bytes(data, data + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_kp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(ac17::kp_decrypt(h->eng, *(const ac17::Ac17KpSecretKey*)sk, *(const ac17::Ac17KpCiphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = ac17::kp_decrypt_gt(h->eng, *(const ac17::Ac17KpSecretKey*)sk, *(const ac17::Ac17KpCiphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
 // ---------------------------------------------------------------- bsw
+int32_t rabe_bsw_delegate(rabe_host* h, const void* pk, const void* sk, const char* const* subset, size_t n, void** out_sk) {
+  GUARD_BEGIN
+  bsw::CpAbeSecretKey out;
+  if (!bsw::delegate(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, *(const bsw::CpAbeSecretKey*)sk, strs(subset, n), &out)) return 1;
+  *out_sk = new bsw::CpAbeSecretKey(out);
+  return 0;
+  GUARD_END(h)
+}
 int32_t rabe_bsw_setup(rabe_host* h, void** pk, void** msk) {
   GUARD_BEGIN
   auto r = bsw::setup(h->eng, h->rng());

@@ -303,36 +303,45 @@ Ac17CpCiphertext cp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, cons
   return cp_encrypt_batch(eng, rng, pk, {policy}, {plaintext}, language)[0];
 }
 
+// One decrypt call, abstracted over CP (:385-430) and KP (:625-675): the attribute list that must satisfy the
+// policy, the policy, the ciphertext body and the key body (KP keys have no k_p: three points at infinity).
+struct DecItem {
+  const std::vector<std::string>* attrs;
+  const PolicyRef* policy;
+  const Ac17Ciphertext* ct;
+  const Ac17SecretKey* sk;
+  const char* err_traverse;
+  const char* err_pruned;
+};
 // Gt of n decrypt calls; errors[i] non-empty when item i does not decrypt (no group work is done for it)
-static std::vector<Gt> decrypt_gts(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks, const std::vector<const Ac17CpCiphertext*>& cts,
-                                   std::vector<std::string>* errors) {
-  const size_t n = cts.size();
+static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& items, std::vector<std::string>* errors) {
+  const size_t n = items.size();
   errors->assign(n, "");
   std::vector<uint8_t> ct_c0, ct_c, ct_cp, sk_k0, sk_k, sk_kp;
   std::vector<uint32_t> ct_row_off{0}, sk_row_off{0}, sk_idx, ct_sel, sk_sel, ct_sel_off{0}, sk_sel_off{0};
   std::vector<size_t> live;
   for (size_t i = 0; i < n; i++) {
-    const Ac17CpSecretKey& sk = *sks[i];
-    const Ac17CpCiphertext& ct = *cts[i];
-    PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
-    if (!traverse_policy(sk.attr, tree)) { (*errors)[i] = "Error in cp_decrypt: attributes in SK do not match policy in CT."; continue; }
+    const DecItem& it = items[i];
+    PolicyNode tree = parse_or_error(it.policy->first, it.policy->second);
+    if (!traverse_policy(*it.attrs, tree)) { (*errors)[i] = it.err_traverse; continue; }
     PrunedList lst;
-    if (!calc_pruned(sk.attr, tree, &lst)) { (*errors)[i] = "Error: attributes in sk do not match policy in ct."; continue; }
-    // the name-matching loops of :403-414, as index lists
+    if (!calc_pruned(*it.attrs, tree, &lst)) { (*errors)[i] = it.err_pruned; continue; }
+    // the name-matching loops of :403-414 / :643-654, as index lists
     for (const auto& cur : lst) {
-      for (size_t r = 0; r < ct.ct.c.size(); r++) if (ct.ct.c[r].first == cur.first) ct_sel.push_back((uint32_t)r);
-      for (size_t r = 0; r < sk.sk.k.size(); r++) if (sk.sk.k[r].first == cur.first) sk_sel.push_back((uint32_t)r);
+      for (size_t r = 0; r < it.ct->c.size(); r++) if (it.ct->c[r].first == cur.first) ct_sel.push_back((uint32_t)r);
+      for (size_t r = 0; r < it.sk->k.size(); r++) if (it.sk->k[r].first == cur.first) sk_sel.push_back((uint32_t)r);
     }
     ct_sel_off.push_back((uint32_t)ct_sel.size());
     sk_sel_off.push_back((uint32_t)sk_sel.size());
-    for (const auto& x : ct.ct.c_0) ct_c0.insert(ct_c0.end(), x.begin(), x.end());
-    for (const auto& row : ct.ct.c) for (const auto& x : row.second) ct_c.insert(ct_c.end(), x.begin(), x.end());
-    ct_cp.insert(ct_cp.end(), ct.ct.c_p.begin(), ct.ct.c_p.end());
-    ct_row_off.push_back(ct_row_off.back() + (uint32_t)ct.ct.c.size());
-    for (const auto& x : sk.sk.k_0) sk_k0.insert(sk_k0.end(), x.begin(), x.end());
-    for (const auto& row : sk.sk.k) for (const auto& x : row.second) sk_k.insert(sk_k.end(), x.begin(), x.end());
-    for (const auto& x : sk.sk.k_p) sk_kp.insert(sk_kp.end(), x.begin(), x.end());
-    sk_row_off.push_back(sk_row_off.back() + (uint32_t)sk.sk.k.size());
+    for (const auto& x : it.ct->c_0) ct_c0.insert(ct_c0.end(), x.begin(), x.end());
+    for (const auto& row : it.ct->c) for (const auto& x : row.second) ct_c.insert(ct_c.end(), x.begin(), x.end());
+    ct_cp.insert(ct_cp.end(), it.ct->c_p.begin(), it.ct->c_p.end());
+    ct_row_off.push_back(ct_row_off.back() + (uint32_t)it.ct->c.size());
+    for (const auto& x : it.sk->k_0) sk_k0.insert(sk_k0.end(), x.begin(), x.end());
+    for (const auto& row : it.sk->k) for (const auto& x : row.second) sk_k.insert(sk_k.end(), x.begin(), x.end());
+    if (it.sk->k_p.size() == 3) { for (const auto& x : it.sk->k_p) sk_kp.insert(sk_kp.end(), x.begin(), x.end()); }
+    else sk_kp.insert(sk_kp.end(), 3 * 64, 0);        // KP: prod_h starts from G1::zero()
+    sk_row_off.push_back(sk_row_off.back() + (uint32_t)it.sk->k.size());
     sk_idx.push_back((uint32_t)live.size());
     live.push_back(i);
   }
@@ -351,6 +360,14 @@ static std::vector<Gt> decrypt_gts(Engine& eng, const std::vector<const Ac17CpSe
   std::vector<Gt> got = fetch<384>(dout, m);
   for (size_t j = 0; j < m; j++) out[live[j]] = got[j];
   return out;
+}
+static std::vector<Gt> decrypt_gts(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks, const std::vector<const Ac17CpCiphertext*>& cts,
+                                   std::vector<std::string>* errors) {
+  std::vector<DecItem> items;
+  for (size_t i = 0; i < cts.size(); i++)
+    items.push_back({&sks[i]->attr, &cts[i]->policy, &cts[i]->ct, &sks[i]->sk, "Error in cp_decrypt: attributes in SK do not match policy in CT.",
+                     "Error: attributes in sk do not match policy in ct."});
+  return decrypt_items(eng, items, errors);
 }
 
 std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks,
@@ -375,6 +392,113 @@ Gt cp_decrypt_gt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext&
 Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct) {     // :385-430
   return open_or_error(cp_decrypt_gt(eng, sk, ct), ct.ct.ct);
 }
+
+// ---------------------------------------------------------------------------------------------- KP-ABE
+Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang) {   // :439-547
+  PolicyNode tree = parse_or_error(policy, lang);
+  AbePolicy msp = calculate_msp(tree);
+  const size_t cols = msp.m[0].size(), rows = msp.m.size();
+  // draw order: r0, r1 (:455-459); sigma'_1..sigma'_{c-1} (:471-474); sigma_i per row (:481)
+  Fr r0 = rng.next_fr(), r1 = rng.next_fr();
+  Fr br[3] = {fr_mul(msk.b[0], r0), fr_mul(msk.b[1], r1), fr_add(r0, r1)};
+  std::vector<Fr> sigma_prime;
+  for (size_t j = 0; j + 1 < cols; j++) sigma_prime.push_back(rng.next_fr());
+  std::vector<Fr> sigma;
+  for (size_t i = 0; i < rows; i++) sigma.push_back(rng.next_fr());
+  Fr a_inv[2] = {must_inv(msk.a[0]), must_inv(msk.a[1])};
+  // T[j][t] = sum_{j' <= j} ( sum_l h("0"||j'||l||t) br_l / a_t - sigma'_{j'-1} ): the reference's `_temp` is declared
+  // outside the column loop and never reset (:496), so it accumulates over the columns -- restated verbatim.
+  std::vector<Fr> T(cols * 2, fr_zero());
+  for (int t = 0; t < 2; t++) {
+    Fr acc = fr_zero();
+    for (size_t j = 1; j < cols; j++) {
+      Fr hsum = fr_zero();
+      for (int l = 0; l < 3; l++)
+        hsum = fr_add(hsum, fr_mul(sha3_hash_fr(std::string("0") + std::to_string(j) + std::to_string(l) + std::to_string(t)), br[l]));
+      acc = fr_add(acc, fr_sub(fr_mul(hsum, a_inv[t]), sigma_prime[j - 1]));
+      T[j * 2 + t] = acc;
+    }
+  }
+  std::vector<Fr> scal;
+  for (size_t i = 0; i < rows; i++) {
+    for (int t = 0; t < 2; t++) {
+      Fr hsum = sigma[i];
+      for (int l = 0; l < 3; l++) hsum = fr_add(hsum, fr_mul(sha3_hash_fr(msp.pi[i] + std::to_string(l) + std::to_string(t)), br[l]));
+      Fr k = fr_mul(hsum, a_inv[t]);
+      for (size_t j = 1; j < cols; j++) {
+        if (msp.m[i][j] == 1) k = fr_add(k, T[j * 2 + t]);
+        else if (msp.m[i][j] == -1) k = fr_sub(k, T[j * 2 + t]);
+      }
+      scal.push_back(k);
+    }
+    Fr k3 = fr_neg(sigma[i]);
+    for (size_t j = 1; j < cols; j++) {
+      if (msp.m[i][j] == 1) k3 = fr_sub(k3, sigma_prime[j - 1]);
+      else if (msp.m[i][j] == -1) k3 = fr_add(k3, sigma_prime[j - 1]);
+    }
+    scal.push_back(k3);
+  }
+  std::vector<G1> pts = eng.g1_mul(std::vector<G1>(scal.size(), msk.g), scal);
+  // +/- g_k[t] where the first MSP column is +/-1
+  std::vector<G1> add_a, add_b;
+  std::vector<size_t> where;
+  std::vector<G1> neg_gk = eng.g1_mul(msk.g_k, std::vector<Fr>(3, fr_neg(fr_one())));
+  for (size_t i = 0; i < rows; i++)
+    for (int t = 0; t < 3; t++)
+      if (msp.m[i][0] != 0) { add_a.push_back(pts[3 * i + t]); add_b.push_back(msp.m[i][0] == 1 ? msk.g_k[t] : neg_gk[t]); where.push_back(3 * i + t); }
+  if (!where.empty()) {
+    std::vector<G1> sum = g1_add(eng, add_a, add_b);
+    for (size_t q = 0; q < where.size(); q++) pts[where[q]] = sum[q];
+  }
+  Ac17KpSecretKey out;
+  out.policy = {policy, lang};
+  out.sk.k_0 = eng.g2_mul({msk.h, msk.h, msk.h}, {br[0], br[1], br[2]});
+  for (size_t i = 0; i < rows; i++) out.sk.k.push_back({msp.pi[i], {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}});
+  return out;
+}
+
+Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data) {   // :556-616
+  const size_t rows = attributes.size();
+  Fr s0 = rng.next_fr(), s1 = rng.next_fr();
+  Gt msg = eng.random_gt(rng);
+  // C[y][l] = g*(s0 h(y||l||0) + s1 h(y||l||1)): the CP row kernel with a table of plain label hashes
+  std::vector<Fr> A;
+  for (const auto& a : attributes)
+    for (int l = 0; l < 3; l++)
+      for (int t = 0; t < 2; t++) A.push_back(sha3_hash_fr(a + std::to_string(l) + std::to_string(t)));
+  rhip_ac17_pk* dpk = nullptr;
+  auto fha = flatten(pk.h_a), fe = flatten(pk.e_gh_ka);
+  eng.check(rhip_ac17_pk_create(eng.ctx(), (const rhip_g1*)pk.g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk),
+            "rhip_ac17_pk_create");
+  uint32_t zero = 0, row_off[2] = {0, (uint32_t)rows};
+  auto fA = flatten_fr(A), fs = flatten_fr({s0, s1});
+  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, &zero, 4), dro(&eng, row_off, 8), ds(&eng, fs.data(), fs.size()), dm(&eng, msg.data(), 384),
+      dc0(&eng, 3 * 128), dc(&eng, rows * 3 * 64), dcp(&eng, 384);
+  int32_t rc = rhip_ac17_cp_encrypt_batch(eng.ctx(), dpk, 1, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), rows, ds.as<rhip_fr>(),
+                                          dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>());
+  std::vector<G2> c0;
+  std::vector<G1> c;
+  std::vector<Gt> cp;
+  if (rc == RHIP_OK) { c0 = fetch<128>(dc0, 3); c = fetch<64>(dc, rows * 3); cp = fetch<384>(dcp, 1); }
+  rhip_ac17_pk_destroy(dpk);
+  eng.check(rc, "rhip_ac17_cp_encrypt_batch");
+  Ac17KpCiphertext out;
+  out.attr = attributes;
+  out.ct.c_0 = c0;
+  for (size_t i = 0; i < rows; i++) out.ct.c.push_back({attributes[i], {c[3 * i], c[3 * i + 1], c[3 * i + 2]}});
+  out.ct.c_p = cp[0];
+  out.ct.ct = seal(rng, msg, data);
+  return out;
+}
+Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct) {      // :625-675
+  std::vector<std::string> errors;
+  std::vector<DecItem> items{{&ct.attr, &sk.policy, &ct.ct, &sk.sk, "Error in kp_decrypt: attributes in ct do not match policy in sk.",
+                              "Error in kp_decrypt: pruned attributes in sk do not match policy in ct."}};
+  std::vector<Gt> g = decrypt_items(eng, items, &errors);
+  if (!errors[0].empty()) throw RabeError(errors[0]);
+  return g[0];
+}
+Bytes kp_decrypt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct) { return open_or_error(kp_decrypt_gt(eng, sk, ct), ct.ct.ct); }
 }  // namespace ac17
 
 // ================================================================================================ BSW
@@ -407,6 +531,31 @@ bool keygen(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKe
   std::vector<G2> a2 = eng.g2_mul(std::vector<G2>(attributes.size(), pk.g2), hr);
   a2 = g2_add(eng, std::vector<G2>(attributes.size(), g2_r), a2);
   for (size_t i = 0; i < attributes.size(); i++) out->d_j.push_back({attributes[i], a1[i], a2[i]});
+  return true;
+}
+bool delegate(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeSecretKey& sk, const std::vector<std::string>& subset,
+              CpAbeSecretKey* out) {       // :162-206
+  for (const auto& a : subset) {            // is_subset (tools/mod.rs:24-28)
+    bool found = false;
+    for (const auto& d : sk.d_j) if (d.string == a) { found = true; break; }
+    if (!found) return false;
+  }
+  if (subset.empty()) return false;
+  Fr r = rng.next_fr();
+  std::vector<G1> old1;
+  std::vector<G2> old2;
+  std::vector<Fr> rj, hr;
+  for (const auto& a : subset) {
+    Fr x = rng.next_fr();
+    rj.push_back(x);
+    hr.push_back(fr_add(fr_mul(sha3_hash_fr(a), x), r));        // (g2*h(a))*r_j + g2*r = g2*(h(a) r_j + r)
+    for (const auto& d : sk.d_j) if (d.string == a) { old1.push_back(d.g1); old2.push_back(d.g2); break; }
+  }
+  std::vector<G1> n1 = g1_add(eng, old1, eng.g1_mul(std::vector<G1>(subset.size(), pk.g1), rj));
+  std::vector<G2> n2 = g2_add(eng, old2, eng.g2_mul(std::vector<G2>(subset.size(), pk.g2), hr));
+  out->d = g2_add(eng, {sk.d}, {eng.g2_mul({pk.f}, {r})[0]})[0];
+  out->d_j.clear();
+  for (size_t i = 0; i < subset.size(); i++) out->d_j.push_back({subset[i], n1[i], n2[i]});
   return true;
 }
 CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::string& policy, PolicyLanguage language,

@@ -21,6 +21,8 @@ struct Ac17Ciphertext { std::vector<G2> c_0; std::vector<std::pair<std::string, 
 struct Ac17CpCiphertext { PolicyRef policy; Ac17Ciphertext ct; };                               // :95-98
 struct Ac17SecretKey { std::vector<G2> k_0; std::vector<std::pair<std::string, std::vector<G1>>> k; std::vector<G1> k_p; };   // :113-117
 struct Ac17CpSecretKey { std::vector<std::string> attr; Ac17SecretKey sk; };                    // :132-135
+struct Ac17KpCiphertext { std::vector<std::string> attr; Ac17Ciphertext ct; };                  // :104-107
+struct Ac17KpSecretKey { PolicyRef policy; Ac17SecretKey sk; };                                 // :123-126
 
 std::pair<Ac17PublicKey, Ac17MasterKey> setup(Engine& eng, Rng& rng);
 Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& attributes);
@@ -37,6 +39,11 @@ std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const
                                             const std::vector<const Ac17CpCiphertext*>& cts);
 // the Gt value handed to decrypt_symmetric (parity hook for tests; not part of the reference API)
 Gt cp_decrypt_gt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct);
+// KP-ABE variant (:439-675), same kernels
+Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang);
+Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data);
+Bytes kp_decrypt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
+Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
 }  // namespace ac17
 
 namespace bsw {
@@ -49,6 +56,8 @@ struct CpAbeSecretKey { G2 d; std::vector<CpAbeAttribute> d_j; };               
 std::pair<CpAbePublicKey, CpAbeMasterKey> setup(Engine& eng, Rng& rng);
 bool keygen(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::string>& attributes,
             CpAbeSecretKey* out);     // Option<..>: false = None
+bool delegate(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeSecretKey& sk, const std::vector<std::string>& subset,
+              CpAbeSecretKey* out);   // :162-206, Option<..>
 CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::string& policy, PolicyLanguage language,
                         const Bytes& plaintext);
 Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);

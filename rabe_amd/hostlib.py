@@ -6,7 +6,7 @@ from .engine import EngineError, load_library
 
 JSON_POLICY, HUMAN_POLICY = 0, 1
 
-KINDS = {"ac17_pk": 1, "ac17_msk": 2, "ac17_cp_sk": 3, "ac17_cp_ct": 4,
+KINDS = {"ac17_pk": 1, "ac17_msk": 2, "ac17_cp_sk": 3, "ac17_cp_ct": 4, "ac17_kp_sk": 5, "ac17_kp_ct": 6,
          "bsw_pk": 10, "bsw_msk": 11, "bsw_sk": 12, "bsw_ct": 13,
          "lsw_pk": 20, "lsw_msk": 21, "lsw_sk": 22, "lsw_ct": 23,
          "aw11_gk": 30, "aw11_pk": 31, "aw11_msk": 32, "aw11_sk": 33, "aw11_ct": 34}
@@ -212,6 +212,11 @@ def parse_obj(kind, data):
         o = {"attr": attr, "k_0": r.vec(128), "k": [(r.s(), r.vec(64)) for _ in range(r.u32())], "k_p": r.vec(64)}
     elif kind == "ac17_cp_ct":
         o = {"policy": r.pol(), "c_0": r.vec(128), "c": [(r.s(), r.vec(64)) for _ in range(r.u32())], "c_p": r.raw(384), "ct": r.raw(r.u32())}
+    elif kind == "ac17_kp_sk":
+        o = {"policy": r.pol(), "k_0": r.vec(128), "k": [(r.s(), r.vec(64)) for _ in range(r.u32())], "k_p": r.vec(64)}
+    elif kind == "ac17_kp_ct":
+        attr = [r.s() for _ in range(r.u32())]
+        o = {"attr": attr, "c_0": r.vec(128), "c": [(r.s(), r.vec(64)) for _ in range(r.u32())], "c_p": r.raw(384), "ct": r.raw(r.u32())}
     elif kind == "bsw_pk":
         o = {"g1": r.raw(64), "g2": r.raw(128), "h": r.raw(64), "f": r.raw(128), "e_gg_alpha": r.raw(384)}
     elif kind == "bsw_msk":

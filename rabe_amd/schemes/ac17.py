@@ -58,3 +58,25 @@ def cp_decrypt_batch(host, sks, cts):
         else:
             out.append(None)
     return out
+
+
+# ---- KP-ABE variant (src/schemes/ac17/mod.rs:439-675)
+def kp_keygen(host, msk, policy, language=JSON_POLICY):
+    sk = ctypes.c_void_p()
+    host.call("rabe_ac17_kp_keygen", msk.ptr, policy.encode("utf-8"), language, ctypes.byref(sk))
+    return Obj("ac17_kp_sk", sk)
+
+
+def kp_encrypt(host, pk, attributes, data):
+    arr, n = _strs(attributes)
+    ct = ctypes.c_void_p()
+    host.call("rabe_ac17_kp_encrypt", pk.ptr, arr, n, bytes(data), ctypes.c_size_t(len(data)), ctypes.byref(ct))
+    return Obj("ac17_kp_ct", ct)
+
+
+def kp_decrypt(host, sk, ct):
+    return host.out_bytes("rabe_ac17_kp_decrypt", sk.ptr, ct.ptr)
+
+
+def kp_decrypt_gt(host, sk, ct):
+    return host.out_gt("rabe_ac17_kp_decrypt_gt", sk.ptr, ct.ptr)

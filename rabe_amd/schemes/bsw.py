@@ -19,6 +19,15 @@ def keygen(host, pk, msk, attributes):
     return Obj("bsw_sk", sk)
 
 
+def delegate(host, pk, sk, subset):
+    """Option<CpAbeSecretKey>: None when `subset` is empty or not a subset of the key's attributes (:162-206)."""
+    arr, n = _strs(subset)
+    out = ctypes.c_void_p()
+    if host.call("rabe_bsw_delegate", pk.ptr, sk.ptr, arr, n, ctypes.byref(out)) is None:
+        return None
+    return Obj("bsw_sk", out)
+
+
 def encrypt(host, pk, policy, language, plaintext):
     ct = ctypes.c_void_p()
     host.call("rabe_bsw_encrypt", pk.ptr, policy.encode("utf-8"), language, bytes(plaintext), ctypes.c_size_t(len(plaintext)), ctypes.byref(ct))

@@ -185,8 +185,66 @@ def aw11_cases():
     return doc
 
 
+def ac17_kp_cases():
+    """KP-ABE variant (ac17/mod.rs:439-675); the second policy has 3 MSP columns, which pins the reference's
+    un-reset `_temp` accumulation across columns (:496-516)."""
+    rng = SeededRng(21)
+    pk, msk = sch.ac17_setup(rng)
+    doc = {"pk": {"g": g1(pk["g"]), "h_a": [g2(x) for x in pk["h_a"]], "e_gh_ka": [gt(x) for x in pk["e_gh_ka"]]},
+           "msk": {"g": g1(msk["g"]), "h": g2(msk["h"]), "g_k": [g1(x) for x in msk["g_k"]], "a": [fr(x) for x in msk["a"]],
+                   "b": [fr(x) for x in msk["b"]]}, "cases": []}
+    cases = [(r'''{"name": "or", "children": [{"name": "X"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}''', pol.JSON, ["A", "B"]),
+             ('"A" and ("B" and ("C" or "D"))', pol.HUMAN, ["A", "B", "D"])]
+    for policy, lang, attrs in cases:
+        rk = RecRng(rng.fr() % (1 << 62))
+        sk = sch.ac17_kp_keygen(msk, policy, lang, rk)
+        et = [rng.fr(), rng.fr()]
+        rho = rng.fr_nonzero()
+        msg = bn.gt_pow(E_GEN, rho)
+        ct = sch.ac17_kp_encrypt(pk, attrs, ListRng(et), msg)
+        dec = sch.ac17_kp_decrypt(sk, ct)
+        doc["cases"].append({
+            "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in rk.log],
+            "encrypt_tape": [fr(x) for x in et], "msg_rho": fr(rho), "msg": gt(msg),
+            "sk": {"k_0": [g2(x) for x in sk["sk"]["k_0"]], "k": [[n, [g1(p) for p in v]] for n, v in sk["sk"]["k"]]},
+            "ct": {"c_0": [g2(x) for x in ct["ct"]["c_0"]], "c": [[n, [g1(p) for p in v]] for n, v in ct["ct"]["c"]], "c_p": gt(ct["ct"]["c_p"])},
+            "decrypted": gt(dec), "decrypts_to_msg": dec == msg})
+    return doc
+
+
+def bsw_delegate_cases():
+    """bsw::delegate (bsw/mod.rs:162-206; reference test delegate_ab :569-602)."""
+    rng = SeededRng(22)
+    pk, msk = sch.bsw_setup(rng)
+    doc = {"pk": {"g1": g1(pk["g1"]), "g2": g2(pk["g2"]), "h": g1(pk["h"]), "f": g2(pk["f"]), "e_gg_alpha": gt(pk["e_gg_alpha"])},
+           "msk": {"beta": fr(msk["beta"]), "g2_alpha": g2(msk["g2_alpha"])}, "cases": []}
+    kt = [rng.fr() for _ in range(4)]
+    sk = sch.bsw_keygen(pk, msk, ["A", "B", "C"], ListRng(kt))
+    dt = [rng.fr() for _ in range(3)]
+    dsk = sch.bsw_delegate(pk, sk, ["A", "B"], ListRng(dt))
+    policy = r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}'''
+    rec = RecRng(rng.fr() % (1 << 62))
+    rho = rng.fr_nonzero()
+    msg = bn.gt_pow(E_GEN, rho)
+    ct = sch.bsw_encrypt(pk, policy, pol.JSON, rec, msg)
+    dec = sch.bsw_decrypt(dsk, ct)
+    assert dec == msg
+    doc["cases"].append({
+        "attrs": ["A", "B", "C"], "keygen_tape": [fr(x) for x in kt], "subset": ["A", "B"], "delegate_tape": [fr(x) for x in dt],
+        "policy": policy, "language": pol.JSON, "encrypt_tape": [fr(x) for x in rec.log], "msg_rho": fr(rho), "msg": gt(msg),
+        "sk": {"d": g2(sk["d"]), "d_j": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in sk["d_j"]]},
+        "delegated": {"d": g2(dsk["d"]), "d_j": [[x["string"], g1(x["g1"]), g2(x["g2"])] for x in dsk["d_j"]]},
+        "decrypted": gt(dec)})
+    return doc
+
+
 def main():
-    for name, fn in (("bn254_primitives", primitives), ("ac17", ac17_cases), ("bsw", bsw_cases), ("lsw", lsw_cases), ("aw11", aw11_cases)):
+    import sys as _sys
+    only = set(_sys.argv[1:])
+    for name, fn in (("bn254_primitives", primitives), ("ac17", ac17_cases), ("bsw", bsw_cases), ("lsw", lsw_cases), ("aw11", aw11_cases),
+                     ("ac17_kp", ac17_kp_cases), ("bsw_delegate", bsw_delegate_cases)):
+        if only and name not in only:
+            continue
         doc = fn()
         path = os.path.join(HERE, name + ".json")
         with open(path, "w") as f:

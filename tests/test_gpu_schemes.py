@@ -232,3 +232,59 @@ def test_aw11_matches_golden(host):
         host.clear_tape()
         assert aw11.decrypt_gt(host, gk, sk, ct) == hb(c["decrypted"])
         assert aw11.decrypt(host, gk, sk, ct) == PLAINTEXT
+
+
+def test_ac17_kp_reference_cases_and_golden(host):
+    # ac17/mod.rs:677-754 (kp_and, kp_or_and, kp_or, non-matching) + golden parity (3-column MSP pins the `_temp` quirk)
+    pk, msk = ac17.setup(host)
+    pol_ = r'''{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}'''
+    sk = ac17.kp_keygen(host, msk, pol_, hl.JSON_POLICY)
+    assert ac17.kp_decrypt(host, sk, ac17.kp_encrypt(host, pk, ["B", "C"], PLAINTEXT)) == PLAINTEXT
+    assert ac17.kp_decrypt(host, sk, ac17.kp_encrypt(host, pk, ["A"], PLAINTEXT)) == PLAINTEXT
+    with pytest.raises(hl.RabeError):
+        ac17.kp_decrypt(host, sk, ac17.kp_encrypt(host, pk, ["B", "D"], PLAINTEXT))
+    doc = load("ac17_kp")
+    pkb = hb(doc["pk"]["g"]) + (3).to_bytes(4, "little") + b"".join(hb(x) for x in doc["pk"]["h_a"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in doc["pk"]["e_gh_ka"])
+    m = doc["msk"]
+    mskb = hb(m["g"]) + hb(m["h"]) + (3).to_bytes(4, "little") + b"".join(hb(x) for x in m["g_k"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in m["a"]) + (2).to_bytes(4, "little") + b"".join(hb(x) for x in m["b"])
+    gpk, gmsk = hl.Obj.deserialize("ac17_pk", pkb), hl.Obj.deserialize("ac17_msk", mskb)
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        sk = ac17.kp_keygen(host, gmsk, c["policy"], LANG[c["language"]])
+        g = hl.parse_obj("ac17_kp_sk", sk.serialize())
+        assert g["k_0"] == [hb(x) for x in c["sk"]["k_0"]]
+        assert g["k"] == [(n, [hb(p) for p in v]) for n, v in c["sk"]["k"]]
+        assert g["k_p"] == []
+        host.set_tape([fri(x) for x in c["encrypt_tape"]] + [fri(c["msg_rho"]), 5])
+        ct = ac17.kp_encrypt(host, gpk, c["attrs"], PLAINTEXT)
+        g = hl.parse_obj("ac17_kp_ct", ct.serialize())
+        assert g["attr"] == c["attrs"]
+        assert g["c_0"] == [hb(x) for x in c["ct"]["c_0"]]
+        assert g["c"] == [(n, [hb(p) for p in v]) for n, v in c["ct"]["c"]]
+        assert g["c_p"] == hb(c["ct"]["c_p"])
+        host.clear_tape()
+        assert ac17.kp_decrypt_gt(host, sk, ct) == hb(c["decrypted"])
+        assert ac17.kp_decrypt(host, sk, ct) == PLAINTEXT
+
+
+def test_bsw_delegate_matches_golden(host):
+    doc = load("bsw_delegate")
+    p = doc["pk"]
+    pk = hl.Obj.deserialize("bsw_pk", hb(p["g1"]) + hb(p["g2"]) + hb(p["h"]) + hb(p["f"]) + hb(p["e_gg_alpha"]))
+    msk = hl.Obj.deserialize("bsw_msk", hb(doc["msk"]["beta"]) + hb(doc["msk"]["g2_alpha"]))
+    c = doc["cases"][0]
+    host.set_tape([fri(x) for x in c["keygen_tape"]])
+    sk = bsw.keygen(host, pk, msk, c["attrs"])
+    host.set_tape([fri(x) for x in c["delegate_tape"]])
+    dsk = bsw.delegate(host, pk, sk, c["subset"])
+    g = hl.parse_obj("bsw_sk", dsk.serialize())
+    assert g["d"] == hb(c["delegated"]["d"])
+    assert g["d_j"] == [(n, hb(a), hb(b)) for n, a, b in c["delegated"]["d_j"]]
+    et = [fri(x) for x in c["encrypt_tape"]]
+    host.set_tape([et[0], fri(c["msg_rho"])] + et[1:] + [3])
+    ct = bsw.encrypt(host, pk, c["policy"], LANG[c["language"]], PLAINTEXT)
+    host.clear_tape()
+    assert bsw.decrypt_gt(host, dsk, ct) == hb(c["decrypted"])
+    assert bsw.decrypt(host, dsk, ct) == PLAINTEXT
+    assert bsw.delegate(host, pk, sk, ["A", "Z"]) is None          # not a subset -> None (:173-176)
+    assert bsw.delegate(host, pk, sk, []) is None

@@ -72,3 +72,23 @@ def test_aw11_two_authorities():
     policy = r'''{"name": "or", "children": [{"name": "C"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}'''
     ct = sch.aw11_encrypt(gk, [pk1, pk2], policy, pol.JSON, rng, msg)
     assert sch.aw11_decrypt(gk, sk, ct) == msg
+
+
+def test_ac17_kp_and_delegate():
+    # ac17/mod.rs:677-754 (kp_and, kp_or ...) and bsw/mod.rs:569-602 (delegate_ab)
+    rng = SeededRng(15)
+    pk, msk = sch.ac17_setup(rng)
+    msg = gt_sample(rng)
+    policy = r'''{"name": "or", "children": [{"name": "X"}, {"name": "and", "children": [{"name": "A"}, {"name": "B"}]}]}'''
+    sk = sch.ac17_kp_keygen(msk, policy, pol.JSON, rng)
+    ct = sch.ac17_kp_encrypt(pk, ["A", "B"], rng, msg)
+    assert sch.ac17_kp_decrypt(sk, ct) == msg
+    ct_bad = sch.ac17_kp_encrypt(pk, ["A", "C"], rng, msg)
+    with pytest.raises(ValueError):
+        sch.ac17_kp_decrypt(sk, ct_bad)
+    bpk, bmsk = sch.bsw_setup(rng)
+    bsk = sch.bsw_keygen(bpk, bmsk, ["A", "B", "C"], rng)
+    dsk = sch.bsw_delegate(bpk, bsk, ["A", "B"], rng)
+    bct = sch.bsw_encrypt(bpk, r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}''', pol.JSON, rng, msg)
+    assert sch.bsw_decrypt(dsk, bct) == msg
+    assert sch.bsw_delegate(bpk, bsk, ["A", "Z"], rng) is None
