@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
+    ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
+                    help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items for the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -80,6 +82,7 @@ def main():
     n_cu, dev_name = eng.device_info()
     stream = torch.cuda.Stream(device=local_rank)
     eng.set_stream(stream.cuda_stream)
+    eng.set_pairing_mode(args.pairing_mode)
 
     rnd = random.Random(args.seed * 1000003 + rank)
     R = hp.R_ORDER
@@ -164,6 +167,7 @@ def main():
         e2 = Engine(local_rank)
         st2 = torch.cuda.Stream(device=local_rank)
         e2.set_stream(st2.cuda_stream)
+        e2.set_pairing_mode(args.pairing_mode)
         lanes_ctx.append(e2)
         streams.append(st2)
     bufs = [(e_.alloc(B * 3 * 128), e_.alloc(total_rows * 3 * 64), e_.alloc(B * 384), e_.alloc(B * 384)) for e_ in lanes_ctx]
@@ -223,7 +227,7 @@ def main():
                                % (args.attrs, args.policies, B),
                    "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": total_rows // B,
                    "pruned_leaves_avg": round(len(ct_sel_all) / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
-                   "steps_in_flight": S,
+                   "steps_in_flight": S, "pairing_mode": args.pairing_mode,
                    "parallelism": "batch-sharded x%d (no data-path collective)" % world, "device": dev_name},
     }
 
@@ -245,11 +249,13 @@ def main():
         ms_c, ops_c = eng.calibrate(0, 20000)
         peak_tmac = ops_c / (ms_c * 1e-3) / 1e12
         m_avg = len(ct_sel_all) / B
-        lanes = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_enc_rows": total_rows,
+        lanes = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 6, "k_final_exp_c3": B, "k_ac17_enc_rows": total_rows,
                  "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
         alg = {"k_ac17_dec_miller": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL,
+               "k_ac17_dec_miller_c3": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL, "k_final_exp_c3": 9000 + 6 * 54,
                "k_final_exp": 9000 + 6 * 54, "k_ac17_enc_rows": 3 * 352, "k_ac17_enc_c0": 1056, "k_ac17_enc_cp": 2 * 1700 + 54}
-        impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54}
+        impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
+                "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # HBM side (reported, not binding): algorithmic bytes of the whole step

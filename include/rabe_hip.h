@@ -57,6 +57,9 @@ const char* rhip_last_error(rhip_ctx* ctx);
  * rhip_ctx_timing_read drains the record as "kernel_name total_ms launches\n" lines. */
 int32_t rhip_ctx_timing(rhip_ctx* ctx, int32_t enable);
 int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len);
+/* pairing kernels: 0 = auto (three cooperating lanes per pairing for launches that would under-fill the chip,
+ * one lane per pairing otherwise), 1 = always one lane, 3 = always three lanes.  Results are identical. */
+int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode);
 /* number of compute units / device name of the context's GPU */
 int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len);
 

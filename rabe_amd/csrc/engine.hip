@@ -19,6 +19,7 @@
 
 #include "../../include/rabe_hip.h"
 #include "bn254/io.h"
+#include "bn254/coop3.h"
 
 using namespace rabe::bn254;
 
@@ -48,6 +49,7 @@ struct rhip_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
+  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
   bool timing = false;
   struct Pending { std::string name; hipEvent_t e0, e1; };
   std::vector<Pending> pending;
@@ -377,6 +379,69 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, 
   Fp12 e = final_exponentiation(f);
   if (mul_in) e = fp12_mul(load_gt(mul_in[i].l), e);
   store_gt(out[i].l, e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// three-lane cooperative pairing kernels (bn254/coop3.h): a wave holds 21 triples (lane 63 idles); the all-gather
+// inside a triple is ds_bpermute (__shfl) limb by limb -- structural, so the values never leave registers.
+struct DevComm {
+  int L;      // role inside the triple
+  int base;   // first lane of the triple
+  __device__ __forceinline__ Fp g(const Fp& x, int src) const {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl((int)x.v[i], src);
+    return r;
+  }
+  __device__ __forceinline__ Fp2 g(const Fp2& x, int src) const { return Fp2{g(x.c0, src), g(x.c1, src)}; }
+  __device__ __forceinline__ Fp6 g(const Fp6& x, int src) const { return Fp6{g(x.a0, src), g(x.a1, src), g(x.a2, src)}; }
+  __device__ __forceinline__ Fp4Pair g(const Fp4Pair& x, int src) const { return Fp4Pair{g(x.r0, src), g(x.r1, src)}; }
+  __device__ __forceinline__ Fp2Pair g(const Fp2Pair& x, int src) const { return Fp2Pair{g(x.p, src), g(x.q, src)}; }
+  template <class T>
+  __device__ __forceinline__ void gather(const T& mine, T* out) const {
+    out[0] = g(mine, base);
+    out[1] = g(mine, base + 1);
+    out[2] = g(mine, base + 2);
+  }
+};
+#define C3_TRIPLES_PER_WAVE 21
+__device__ __forceinline__ void st_gt_m_third(GtM* p, const Fp12& a, int L) {
+  // each lane of the triple stores one third of the (replicated) value: Fq2 coefficients 2L and 2L+1
+  const Fp2 x = sel3(L, a.c0.a0, a.c0.a2, a.c1.a1);
+  const Fp2 y = sel3(L, a.c0.a1, a.c1.a0, a.c1.a2);
+  st_fp2_m(p->l + 32 * L, x);
+  st_fp2_m(p->l + 32 * L + 16, y);
+}
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_c3(size_t n, const rhip_g1* p, const rhip_g2* q, GtM* out) {
+  const int lane = threadIdx.x;
+  const size_t pair = (size_t)blockIdx.x * C3_TRIPLES_PER_WAVE + lane / 3;
+  if (lane >= 3 * C3_TRIPLES_PER_WAVE || pair >= n) return;
+  DevComm cm{lane % 3, lane - lane % 3};
+  G1Aff P = load_g1(p[pair].l);
+  Fp12 f = c3_miller_loop(cm, miller_p_from_aff(P), aff_is_inf(P), load_g2(q[pair].l));
+  st_gt_m_third(out + pair, f, cm.L);
+}
+// product of an item's Miller values + cooperative final exponentiation, one triple per item
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp_c3(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
+                                                                  const rhip_gt* mul_in, rhip_gt* out) {
+  const int lane = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * C3_TRIPLES_PER_WAVE + lane / 3;
+  if (lane >= 3 * C3_TRIPLES_PER_WAVE || i >= n_items) return;
+  DevComm cm{lane % 3, lane - lane % 3};
+  uint32_t lo = off ? off[i] : (uint32_t)(i * stride);
+  uint32_t hi = off ? off[i + 1] : (uint32_t)((i + 1) * stride);
+  Fp12 f = fp12_one();
+  for (uint32_t j = lo; j < hi; j++) {
+    Fp12 m = ld_gt_m(mill + j);
+    f = (j == lo) ? m : c3_fp12_mul(cm, f, m);
+  }
+  Fp12 e = c3_final_exponentiation(cm, f);
+  if (mul_in) e = c3_fp12_mul(cm, load_gt(mul_in[i].l), e);
+  // canonical store, one third per lane
+  const Fp2 x = sel3(cm.L, e.c0.a0, e.c0.a2, e.c1.a1);
+  const Fp2 y = sel3(cm.L, e.c0.a1, e.c1.a0, e.c1.a2);
+  store_fp2(out[i].l + 32 * cm.L, x);
+  store_fp2(out[i].l + 32 * cm.L + 16, y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,6 +806,40 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller(size_t n_i
   st_gt_m(mill + t, f);
 }
 
+// three-lane variant of k_ac17_dec_miller: triple = (item, i < 6); the (short) G1 row sums are replicated in the
+// three lanes, the Miller loop is cooperative.
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller_c3(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+                                                                        const uint32_t* ct_row_off, const rhip_g2* sk_k0, const rhip_g1* sk_k,
+                                                                        const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx,
+                                                                        const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
+                                                                        const uint32_t* sk_sel_off, GtM* mill) {
+  const int lane = threadIdx.x;
+  const size_t t = (size_t)blockIdx.x * C3_TRIPLES_PER_WAVE + lane / 3;
+  if (lane >= 3 * C3_TRIPLES_PER_WAVE || t >= n_items * 6) return;
+  DevComm cm{lane % 3, lane - lane % 3};
+  size_t item = t / 6;
+  int i = (int)(t % 6);
+  const uint32_t sk = sk_idx[item];
+  G1Jac acc = jac_inf<Fp>();
+  G2Aff Q;
+  if (i < 3) {
+    const uint32_t base = ct_row_off[item];
+    for (uint32_t j = ct_sel_off[item]; j < ct_sel_off[item + 1]; j++)
+      acc = jac_add_aff(acc, load_g1(ct_c[(size_t)(base + ct_sel[j]) * 3 + i].l));
+    Q = load_g2(sk_k0[(size_t)sk * 3 + i].l);
+  } else {
+    const int ii = i - 3;
+    const uint32_t base = sk_row_off[sk];
+    acc = aff_to_jac(load_g1(sk_kp[(size_t)sk * 3 + ii].l));
+    for (uint32_t j = sk_sel_off[item]; j < sk_sel_off[item + 1]; j++)
+      acc = jac_add_aff(acc, load_g1(sk_k[(size_t)(base + sk_sel[j]) * 3 + ii].l));
+    acc = jac_neg(acc);
+    Q = load_g2(ct_c0[item * 3 + ii].l);
+  }
+  Fp12 f = c3_miller_loop(cm, miller_p_from_jac(acc), jac_is_inf(acc), Q);
+  st_gt_m_third(mill + t, f, cm.L);
+}
+
 // ------------------------------------------------------------------------------------------------
 // integer-multiply issue-rate calibration (roofline denominator)
 template <int VARIANT>
@@ -908,6 +1007,20 @@ extern "C" int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* a, const 
   KLAUNCH(ctx, "k_gt_pow", k_gt_pow, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, k, out);
   return RHIP_OK;
 }
+// Which pairing kernels a launch uses.  Measured on MI355X (profiles/README.md): per wave the three-lane kernels are
+// 1.3x faster (Miller 8.4 ms vs 11.1 ms, final exponentiation 8.5 vs 11.6) but cost 2.3x the SIMD time, and at one
+// wave per SIMD (512 registers of replicated state) more than 21 504 pairs need a second round.  So "auto" uses them
+// only for small launches, where latency is all that matters; throughput-sized batches keep one lane per pairing.
+static bool use_c3(const rhip_ctx* ctx, size_t n_pairs) {
+  if (ctx->pairing_mode == 1) return false;
+  if (ctx->pairing_mode == 3) return true;
+  return n_pairs * 3 <= (size_t)ctx->n_cu * 4 * 63 / 4;      // at most a quarter of the SIMDs busy with one lane each
+}
+extern "C" int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode) {
+  if (!ctx || (mode != 0 && mode != 1 && mode != 3)) return RHIP_ERR_ARG;
+  ctx->pairing_mode = mode;
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* off, size_t n_pairs, const rhip_g1* p,
                                         const rhip_g2* q, rhip_gt* out) {
   NEED(ctx);
@@ -915,6 +1028,13 @@ extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uin
   int32_t rc = ensure_scratch(ctx, (n_pairs ? n_pairs : 1) * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
+  if (use_c3(ctx, n_pairs)) {
+    if (n_pairs)
+      KLAUNCH(ctx, "k_miller_c3", k_miller_c3, dim3(blocks_for(n_pairs, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
+    KLAUNCH(ctx, "k_final_exp_c3", k_final_exp_c3, dim3(blocks_for(n_items, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_items, off, 1u,
+            (const GtM*)mill, (const rhip_gt*)nullptr, out);
+    return RHIP_OK;
+  }
   if (n_pairs) {
     KLAUNCH(ctx, "k_miller", k_miller, dim3(blocks_for(n_pairs, 64)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
   }
@@ -1075,6 +1195,13 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
   int32_t rc = ensure_scratch(ctx, n_items * 6 * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
+  if (use_c3(ctx, n_items * 6)) {
+    KLAUNCH(ctx, "k_ac17_dec_miller_c3", k_ac17_dec_miller_c3, dim3(blocks_for(n_items * 6, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream,
+            n_items, ct_c0, ct_c, ct_row_off, sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
+    KLAUNCH(ctx, "k_final_exp_c3", k_final_exp_c3, dim3(blocks_for(n_items, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_items,
+            (const uint32_t*)nullptr, 6u, (const GtM*)mill, ct_cp, out);
+    return RHIP_OK;
+  }
   KLAUNCH(ctx, "k_ac17_dec_miller", k_ac17_dec_miller, dim3(blocks_for(n_items * 6, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
                      sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 6u,

@@ -130,6 +130,10 @@ class Engine:
     def set_stream(self, hip_stream_ptr):
         self._check(self.lib.rhip_ctx_set_stream(self.ctx, ctypes.c_void_p(hip_stream_ptr)))
 
+    def set_pairing_mode(self, mode):
+        """0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (same results)."""
+        self._check(self.lib.rhip_ctx_set_pairing_mode(self.ctx, ctypes.c_int32(mode)))
+
     def timing(self, enable):
         self._check(self.lib.rhip_ctx_timing(self.ctx, ctypes.c_int32(1 if enable else 0)))
 

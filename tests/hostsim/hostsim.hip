@@ -3,6 +3,8 @@
 // Built with `hipcc --cuda-host-only`; never loaded by the product (rabe_amd/), which only ever
 // launches the same functions as HIP kernels.
 #include "../../rabe_amd/csrc/bn254/io.h"
+#include "../../rabe_amd/csrc/bn254/coop3.h"
+#include <pthread.h>
 #include <string.h>
 
 using namespace rabe::bn254;
@@ -77,5 +79,54 @@ void hs_pairing_jac(const uint32_t* p, const uint32_t* zscale, const uint32_t* q
   store_gt(out, final_exponentiation(miller_loop(miller_p_from_jac(J), aff_is_inf(P), load_g2(q))));
 }
 void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
+
+
+}  // extern "C"
+
+// ---- three-lane cooperative pairing (coop3.h) emulated with three host threads: the all-gather is a shared
+// buffer between two barriers, everything else is the exact code the device lanes run.
+struct HostShared { pthread_barrier_t bar; unsigned char slot[3][1024]; };
+struct HostComm {
+  int L;
+  HostShared* sh;
+  template <class T>
+  void gather(const T& mine, T* out) {
+    static_assert(sizeof(T) <= 1024, "slot too small");
+    memcpy(sh->slot[L], &mine, sizeof(T));
+    pthread_barrier_wait(&sh->bar);
+    for (int r = 0; r < 3; r++) memcpy(&out[r], sh->slot[r], sizeof(T));
+    pthread_barrier_wait(&sh->bar);
+  }
+};
+struct C3Job { int L; HostShared* sh; const uint32_t *p, *zs, *q; int mode; Fp12 out; };
+static void* c3_worker(void* arg) {
+  C3Job* j = (C3Job*)arg;
+  HostComm cm{j->L, j->sh};
+  G1Aff P = load_g1(j->p);
+  MillerP mp = miller_p_from_aff(P);
+  if (j->zs) {
+    Fp z = load_fp(j->zs);
+    Fp z2 = sqr(z);
+    G1Jac J{mul(P.x, z2), mul(P.y, mul(z2, z)), z};
+    mp = miller_p_from_jac(J);
+  }
+  Fp12 f = c3_miller_loop(cm, mp, aff_is_inf(P), load_g2(j->q));
+  if (j->mode == 1) f = c3_final_exponentiation(cm, f);
+  j->out = f;
+  return nullptr;
+}
+extern "C" {
+// mode 0: Miller value, mode 1: full pairing.  Returns 1 if the three lanes agree; writes lane 0's value.
+int hs_c3_pairing(const uint32_t* p, const uint32_t* zscale, const uint32_t* q, int mode, uint32_t* out) {
+  HostShared sh;
+  pthread_barrier_init(&sh.bar, nullptr, 3);
+  C3Job jobs[3];
+  pthread_t th[3];
+  for (int L = 0; L < 3; L++) { jobs[L] = C3Job{L, &sh, p, zscale, q, mode, Fp12{}}; pthread_create(&th[L], nullptr, c3_worker, &jobs[L]); }
+  for (int L = 0; L < 3; L++) pthread_join(th[L], nullptr);
+  pthread_barrier_destroy(&sh.bar);
+  store_gt(out, jobs[0].out);
+  return fp12_eq(jobs[0].out, jobs[1].out) && fp12_eq(jobs[0].out, jobs[2].out);
+}
 
 }  // extern "C"

@@ -153,3 +153,22 @@ def test_pairing_matches_oracle():
     # Gt pow
     k = RND.randrange(bn.R)
     assert call("hs_gt_pow", bn.gt_to_le(want), le(k), out=384) == bn.gt_to_le(bn.gt_pow(want, k))
+
+
+def test_three_lane_cooperative_pairing_equals_single_lane():
+    """coop3.h: the Miller value and the pairing computed by a triple of lanes (three host threads, all-gather
+    emulated) are bit-identical in all three lanes and equal to the one-lane code / the oracle."""
+    k1, k2 = RND.randrange(1, bn.R), RND.randrange(1, bn.R)
+    p = bn.g1_mul(bn.G1_GEN, k1)
+    q = bn.g2_mul(bn.G2_GEN, k2)
+    P, Q = b2c(bn.g1_to_le(p)), b2c(bn.g2_to_le(q))
+    out = buf(384)
+    assert HS.hs_c3_pairing(P, None, Q, 0, out) == 1
+    assert bytes(out) == call("hs_miller", bn.g1_to_le(p), bn.g2_to_le(q), out=384)      # same Miller value, not just same pairing
+    assert HS.hs_c3_pairing(P, None, Q, 1, out) == 1
+    assert bytes(out) == bn.gt_to_le(bn.gt_pow(bn.pairing(bn.G1_GEN, bn.G2_GEN), k1 * k2 % bn.R))
+    z = b2c(le(rand_fp()))
+    assert HS.hs_c3_pairing(P, z, Q, 1, out) == 1                                         # Jacobian P path
+    assert bytes(out) == bn.gt_to_le(bn.gt_pow(bn.pairing(bn.G1_GEN, bn.G2_GEN), k1 * k2 % bn.R))
+    assert HS.hs_c3_pairing(b2c(bytes(64)), None, Q, 1, out) == 1
+    assert bytes(out) == bn.gt_to_le(bn.GT_ONE)
