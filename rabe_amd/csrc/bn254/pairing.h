@@ -124,12 +124,19 @@ RB_FN Fp12 miller_loop(const MillerP& p, bool p_is_inf, const G2Aff& q) {
   return f;
 }
 
+// Out-of-line forms for the final exponentiation: it juggles ~6 live Fq12 values (more than the register file
+// holds), so inlining every product only multiplies spill code; as calls, each product's temporaries are private
+// to its own frame and the exponentiation keeps a small, explicit set of locals.
+RB_FN Fp12 fp12_mul_fn(const Fp12& a, const Fp12& b) { return fp12_mul(a, b); }
+RB_FN Fp12 fp12_cyclotomic_sqr_fn(const Fp12& a) { return fp12_cyclotomic_sqr(a); }
+RB_FN Fp12 fp12_frob_fn(const Fp12& a, int k) { return k == 1 ? fp12_frob1(a) : (k == 2 ? fp12_frob2(a) : fp12_frob3(a)); }
+
 // f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).
 RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {
   Fp12 acc = f;   // top bit (bit 62)
   for (int i = 61; i >= 0; i--) {
-    acc = fp12_cyclotomic_sqr(acc);
-    if ((RB_BN_U >> i) & 1ull) acc = fp12_mul(acc, f);
+    acc = fp12_cyclotomic_sqr_fn(acc);
+    if ((RB_BN_U >> i) & 1ull) acc = fp12_mul_fn(acc, f);
   }
   return acc;
 }
@@ -138,31 +145,20 @@ RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {
 // chain, whose exponent is 2u(6u^2+3u+1) * (p^4-p^2+1)/r (oracle/bn254.py FINAL_EXP documents the choice).
 RB_FN Fp12 final_exponentiation(const Fp12& f_in) {
   // easy part
-  Fp12 f = fp12_mul(fp12_conj(f_in), fp12_inv(f_in));   // f^(p^6-1)
-  f = fp12_mul(fp12_frob2(f), f);                       // ^(p^2+1)
-  // hard part; in the cyclotomic subgroup inversion is conjugation, exp_by_neg_z(x) = conj(x^u)
-  Fp12 a = fp12_conj(fp12_cyclotomic_exp_u(f));
-  Fp12 b = fp12_cyclotomic_sqr(a);
-  Fp12 c = fp12_cyclotomic_sqr(b);
-  Fp12 d = fp12_mul(c, b);
-  Fp12 e = fp12_conj(fp12_cyclotomic_exp_u(d));
-  Fp12 ff = fp12_cyclotomic_sqr(e);
-  Fp12 g = fp12_conj(fp12_cyclotomic_exp_u(ff));
-  Fp12 h = fp12_conj(d);
-  Fp12 i = fp12_conj(g);
-  Fp12 j = fp12_mul(i, e);
-  Fp12 k = fp12_mul(j, h);
-  Fp12 l = fp12_mul(k, b);
-  Fp12 m = fp12_mul(k, e);
-  Fp12 n = fp12_mul(m, f);
-  Fp12 o = fp12_frob1(l);
-  Fp12 pp = fp12_mul(o, n);
-  Fp12 q = fp12_frob2(k);
-  Fp12 r = fp12_mul(q, pp);
-  Fp12 s = fp12_conj(f);
-  Fp12 t = fp12_mul(s, l);
-  Fp12 uu = fp12_frob3(t);
-  return fp12_mul(uu, r);
+  Fp12 f = fp12_mul_fn(fp12_conj(f_in), fp12_inv(f_in));   // f^(p^6-1)
+  f = fp12_mul_fn(fp12_frob_fn(f, 2), f);                       // ^(p^2+1)
+  // hard part; in the cyclotomic subgroup inversion is conjugation, exp_by_neg_z(x) = conj(x^u).
+  // libff names (a..v) in the comments; temporaries are folded so that few Fq12 values are live at once.
+  Fp12 b = fp12_cyclotomic_sqr_fn(fp12_conj(fp12_cyclotomic_exp_u(f)));      // a = f^-u ; b = a^2
+  Fp12 d = fp12_mul_fn(fp12_cyclotomic_sqr_fn(b), b);                           // c = b^2 ; d = c*b
+  Fp12 e = fp12_conj(fp12_cyclotomic_exp_u(d));                           // e = d^-u
+  Fp12 g = fp12_conj(fp12_cyclotomic_exp_u(fp12_cyclotomic_sqr_fn(e)));      // f' = e^2 ; g = f'^-u
+  Fp12 k = fp12_mul_fn(fp12_mul_fn(fp12_conj(g), e), fp12_conj(d));             // i = g^-1 ; j = i*e ; h = d^-1 ; k = j*h
+  Fp12 l = fp12_mul_fn(k, b);                                                // l = k*b
+  Fp12 n = fp12_mul_fn(fp12_mul_fn(k, e), f);                                   // m = k*e ; n = m*f
+  Fp12 r = fp12_mul_fn(fp12_frob_fn(k, 2), fp12_mul_fn(fp12_frob_fn(l, 1), n));           // o = l^p ; p = o*n ; q = k^(p^2) ; r = q*p
+  Fp12 t = fp12_mul_fn(fp12_conj(f), l);                                     // s = f^-1 ; t = s*l
+  return fp12_mul_fn(fp12_frob_fn(t, 3), r);                                      // u = t^(p^3) ; v = u*r
 }
 
 // Gt exponentiation by a canonical little-endian scalar (`Gt::pow(Fr)`), binary, cyclotomic squarings.

@@ -26,7 +26,12 @@ RB_HD Fp2 fp2_conj(const Fp2& a) { return Fp2{a.c0, neg(a.c1)}; }
 // Karatsuba: 3 Fp multiplications.  Out of line; the four Fp operands travel in 32 VGPRs.
 RB_FN Fp2 fp2_mul_regs(Fp a0, Fp a1, Fp b0, Fp b1) {
   Fp t0, t1, t2;
+#ifdef RB_FP2_MUL_2WAY
+  mul2_inl(t0, t1, a0, b0, a1, b1);
+  t2 = mul_inl(add(a0, a1), add(b0, b1));
+#else
   mul3_inl(t0, t1, t2, a0, b0, a1, b1, add(a0, a1), add(b0, b1));     // three independent products, interleaved
+#endif
   Fp2 r;
   r.c0 = sub(t0, t1);
   r.c1 = sub(sub(t2, t0), t1);
