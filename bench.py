@@ -24,6 +24,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# One hardware queue per in-flight batch (HIP's default is 4); must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
 G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
@@ -45,13 +47,13 @@ IMPL_FINAL_EXP_FPMUL = 8940
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="items per step per GPU")
     ap.add_argument("--attrs", type=int, default=50)
     ap.add_argument("--policies", type=int, default=16)
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")

@@ -644,14 +644,97 @@ struct rhip_ac17_pk {
   rhip_gt_table* e[2];
 };
 
-// three Jacobian points -> affine canonical with ONE field inversion (Montgomery's trick)
-__device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac& b, const G1Jac& c) {
+// ---- batched inversion across a 256-thread block (Montgomery's trick over LDS + one wave-level scan).
+// Every thread of the block contributes one non-zero Fp value and gets its inverse back; the block pays ONE
+// field inversion (361 multiplications, executed by wave 0 while the other waves wait at the barrier and free
+// their issue slots for other resident blocks) instead of one per thread.
+__device__ __forceinline__ Fp shfl_up_fp(const Fp& x, int d) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_up((int)x.v[i], d);
+  return r;
+}
+__device__ __forceinline__ Fp shfl_down_fp(const Fp& x, int d) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d);
+  return r;
+}
+__device__ __forceinline__ Fp shfl_fp(const Fp& x, int src) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl((int)x.v[i], src);
+  return r;
+}
+__device__ __forceinline__ Fp sel_fp(bool c, const Fp& a, const Fp& b) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// sh: 8 x 256 words (limb-major, conflict-free).  All 256 threads must call this.
+__device__ __noinline__ Fp block_batch_inverse_256(uint32_t (*sh)[256], const Fp& mine) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sh[i][tid] = mine.v[i];
+  __syncthreads();
+  if (tid < 64) {
+    Fp p[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) p[e].v[i] = sh[i][4 * tid + e];
+    const Fp q1 = mul(p[0], p[1]);
+    const Fp q2 = mul(q1, p[2]);
+    const Fp q3 = mul(q2, p[3]);
+    // inclusive prefix / suffix products of q3 over the 64 lanes
+    Fp pre = q3, suf = q3;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      Fp u = shfl_up_fp(pre, d);
+      Fp w = shfl_down_fp(suf, d);
+      Fp pu = mul(pre, u);
+      Fp sw = mul(suf, w);
+      pre = sel_fp(tid >= d, pu, pre);
+      suf = sel_fp(tid + d < 64, sw, suf);
+    }
+    const Fp total_inv = inv(shfl_fp(pre, 63));
+    // exclusive prefix / suffix
+    Fp ex_pre = shfl_up_fp(pre, 1), ex_suf = shfl_down_fp(suf, 1);
+    ex_pre = sel_fp(tid >= 1, ex_pre, one<FpParams>());
+    ex_suf = sel_fp(tid < 63, ex_suf, one<FpParams>());
+    const Fp iq3 = mul(total_inv, mul(ex_pre, ex_suf));       // 1 / q3 of this lane
+    const Fp ip3 = mul(iq3, q2);
+    const Fp iq2 = mul(iq3, p[3]);
+    const Fp ip2 = mul(iq2, q1);
+    const Fp iq1 = mul(iq2, p[2]);
+    const Fp ip1 = mul(iq1, p[0]);
+    const Fp ip0 = mul(iq1, p[1]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      sh[i][4 * tid] = ip0.v[i];
+      sh[i][4 * tid + 1] = ip1.v[i];
+      sh[i][4 * tid + 2] = ip2.v[i];
+      sh[i][4 * tid + 3] = ip3.v[i];
+    }
+  }
+  __syncthreads();
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = sh[i][tid];
+  return r;
+}
+
+// three Jacobian points -> affine canonical with ONE field inversion per BLOCK (Montgomery's trick twice:
+// over the thread's three z's, then over the block's 256 products).  Inactive threads pass active = false.
+__device__ __noinline__ void store3_g1_block(uint32_t (*sh)[256], bool active, rhip_g1* out, const G1Jac& a, const G1Jac& b, const G1Jac& c) {
   // infinity has z = 0: substitute 1 so the product stays invertible, emit zeros for that slot
-  const bool ia = jac_is_inf(a), ib = jac_is_inf(b), ic = jac_is_inf(c);
+  const bool ia = !active || jac_is_inf(a), ib = !active || jac_is_inf(b), ic = !active || jac_is_inf(c);
   Fp za = ia ? one<FpParams>() : a.z, zb = ib ? one<FpParams>() : b.z, zc = ic ? one<FpParams>() : c.z;
   Fp ab = mul(za, zb);
   Fp abc = mul(ab, zc);
-  Fp inv_abc = inv(abc);
+  Fp inv_abc = block_batch_inverse_256(sh, abc);
+  if (!active) return;
   Fp zc_inv = mul(inv_abc, ab);
   Fp inv_ab = mul(inv_abc, zc);
   Fp zb_inv = mul(inv_ab, za);
@@ -667,8 +750,10 @@ __device__ __noinline__ void store3_g1(rhip_g1* out, const G1Jac& a, const G1Jac
 __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
                                                        const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c,
                                                        int w16) {
+  __shared__ uint32_t sh[8][256];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total_rows) return;
+  const bool active = t < total_rows;
+  if (!active) t = total_rows - 1;          // inactive lanes shadow the last row (no stores) and still join the block inversion
   // binary search for the item owning row t (row_off is non-decreasing, row_off[n_items] = total_rows)
   size_t lo = 0, hi = n_items;
   while (hi - lo > 1) {
@@ -688,7 +773,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g
     G1Jac r = w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (l == 0) pt[0] = r; else if (l == 1) pt[1] = r; else pt[2] = r;
   }
-  store3_g1(c + t * 3, pt[0], pt[1], pt[2]);
+  store3_g1_block(sh, active, c + t * 3, pt[0], pt[1], pt[2]);
 }
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
@@ -726,9 +811,11 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M
                                                           size_t n_items, size_t n_attrs, const rhip_fr* H, const rhip_fr* H01,
                                                           const rhip_fr* r, const rhip_fr* sigma, const rhip_fr* sigma_p,
                                                           rhip_g1* k_out, rhip_g1* kp_out) {
+  __shared__ uint32_t sh[8][256];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = n_attrs + 1;
-  if (t >= n_items * per) return;
+  const bool active = t < n_items * per;
+  if (!active) t = n_items * per - 1;
   size_t item = t / per, y = t % per;
   const bool is_kp = (y == n_attrs);
   Fr r0 = load_fr(r[2 * item].l), r1 = load_fr(r[2 * item + 1].l);
@@ -757,7 +844,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M
     if (tt == 0) pt[0] = rj; else if (tt == 1) pt[1] = rj; else pt[2] = rj;
   }
   rhip_g1* dst = is_kp ? (kp_out + item * 3) : (k_out + (item * n_attrs + y) * 3);
-  store3_g1(dst, pt[0], pt[1], pt[2]);
+  store3_g1_block(sh, active, dst, pt[0], pt[1], pt[2]);
 }
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0) {
