@@ -245,7 +245,14 @@ def main():
         tim = eng.timing_read()
         eng.timing(False)
         per_kernel = {kname: ms / cnt for kname, (ms, cnt) in tim.items()}
-        dom = max(per_kernel, key=lambda kk: per_kernel[kk])
+        # "dominant" = the kernel that consumes the most SIMD time (duration x SIMDs it occupies): the pairing
+        # kernels run one 64-lane wave per SIMD, so a launch of n lanes occupies min(n/64, #SIMDs) of them.
+        n_simd = n_cu * 4
+        lane_count = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 18, "k_final_exp_c3": B * 3,
+                      "k_ac17_enc_rows": total_rows, "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
+        waves_per_simd = {"k_ac17_enc_rows": 4}
+        simd_ms = {kk: v * min(n_simd, lane_count.get(kk, 0) / 64.0 / waves_per_simd.get(kk, 1)) for kk, v in per_kernel.items()}
+        dom = max(simd_ms, key=lambda kk: simd_ms[kk])
         dom_ms = per_kernel[dom]
         # peak: dependent-free v_mad_u64_u32 issue rate measured live on this chip
         ms_c, ops_c = eng.calibrate(0, 20000)
@@ -273,6 +280,8 @@ def main():
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
                     "peak_GBps": 8000},
             "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
+            "kernels_simd_share": {kk: round(v / sum(simd_ms.values()), 3) for kk, v in sorted(simd_ms.items(), key=lambda x: -x[1])},
+            "dominant_by": "SIMD time = duration x occupied SIMDs (one batch at a time, HIP events on the launch stream)",
         }
         # ------------------------------------------------------------ CPU baseline (oracle = reference-order restatement; checker only)
         if world == 1 and not args.no_cpu_baseline:

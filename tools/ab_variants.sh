@@ -2,8 +2,8 @@
 # A/B of engine builds under build/variants/*.so: same bench, interleaved
 for rep in 1 2; do
 for f in build/variants/*.so; do
-  for s in 1 4; do
-    RABE_HIP_LIB=$PWD/$f timeout 600 python bench.py --steps 24 --warmup 1 --no-cpu-baseline --inflight $s 2>/dev/null | python -c "
+  for s in 1 8; do
+    RABE_HIP_LIB=$PWD/$f timeout 600 python bench.py --steps 48 --warmup 1 --no-cpu-baseline --inflight $s 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['roofline']['kernels_ms']
