@@ -25,6 +25,16 @@ RB_HD Fp2 fp2_conj(const Fp2& a) { return Fp2{a.c0, neg(a.c1)}; }
 
 // Karatsuba: 3 Fp multiplications.  Out of line; the four Fp operands travel in 32 VGPRs.
 RB_FN Fp2 fp2_mul_regs(Fp a0, Fp a1, Fp b0, Fp b1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RB_NO_LAZY_FP2)
+  // lazy reduction: 3 plain products + 2 Montgomery reductions (fp.h: fp2_mul_lazy_raw); same canonical result
+  RB_COUNT_ONE_MUL(); RB_COUNT_ONE_MUL(); RB_COUNT_ONE_MUL();
+  uint32_t c0[8], c1[8];
+  fp2_mul_lazy_raw(c0, c1, a0.v, a1.v, b0.v, b1.v);
+  Fp2 rl;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { rl.c0.v[i] = c0[i]; rl.c1.v[i] = c1[i]; }
+  return rl;
+#else
   Fp t0, t1, t2;
 #ifdef RB_FP2_MUL_2WAY
   mul2_inl(t0, t1, a0, b0, a1, b1);
@@ -36,6 +46,7 @@ RB_FN Fp2 fp2_mul_regs(Fp a0, Fp a1, Fp b0, Fp b1) {
   r.c0 = sub(t0, t1);
   r.c1 = sub(sub(t2, t0), t1);
   return r;
+#endif
 }
 RB_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) { return fp2_mul_regs(a.c0, a.c1, b.c0, b.c1); }
 // (a0+a1)(a0-a1) + 2 a0 a1 u: 2 Fp multiplications.
