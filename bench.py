@@ -40,7 +40,8 @@ G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
 MAC_PER_FPMUL = 136
 SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
 SURVEY_MIXED_ADD_FPMUL = 11
-IMPL_MILLER_FPMUL = 9950            # tools/count_muls.py: miller_loop with Jacobian P
+IMPL_MILLER_FPMUL = 8983            # tools/count_muls.py: miller_loop (NAF chain) with Jacobian P
+IMPL_MILLER2_FPMUL = 12763          # tools/count_muls.py: miller_loop_pair (A replays prepared lines, B Jacobian), two pairings
 IMPL_FINAL_EXP_FPMUL = 8940
 
 
@@ -57,6 +58,8 @@ def parse_args():
                     help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
+    ap.add_argument("--no-prepared-sk", action="store_true",
+                    help="decrypt without the per-key prepared lines (6 independent Miller loops per item)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items for the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -176,14 +179,22 @@ def main():
     dc0, dc, dcp, dout = bufs[0]
     step_no = [0]
 
+    # the key is loaded once: Miller-loop lines of k_0 (rhip_ac17_sk_prepare), reused by every decryption with it
+    sk_lines = None if args.no_prepared_sk else E.Ac17SkLines(eng, 1, dk0)
+    eng.sync()
+
     def step():
         i = step_no[0] % S
         step_no[0] += 1
         e_ = lanes_ctx[i]
         c0_, c_, cp_, out_ = bufs[i]
         E.ac17_encrypt_dev(e_, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds, dmsg, c0_, c_, cp_)
-        E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
-                           d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
+        if sk_lines is None:
+            E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
+                               d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
+        else:
+            E.ac17_decrypt_prepared_dev(e_, B, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
+                                        d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
 
     def sync_all():
         for e_ in lanes_ctx:
@@ -248,7 +259,7 @@ def main():
         # "dominant" = the kernel that consumes the most SIMD time (duration x SIMDs it occupies): the pairing
         # kernels run one 64-lane wave per SIMD, so a launch of n lanes occupies min(n/64, #SIMDs) of them.
         n_simd = n_cu * 4
-        lane_count = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 18, "k_final_exp_c3": B * 3,
+        lane_count = {"k_ac17_dec_miller": B * 6, "k_ac17_dec_miller2": B * 3, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 18, "k_final_exp_c3": B * 3,
                       "k_ac17_enc_rows": total_rows, "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
         waves_per_simd = {"k_ac17_enc_rows": 4}
         simd_ms = {kk: v * min(n_simd, lane_count.get(kk, 0) / 64.0 / waves_per_simd.get(kk, 1)) for kk, v in per_kernel.items()}
@@ -258,12 +269,13 @@ def main():
         ms_c, ops_c = eng.calibrate(0, 20000)
         peak_tmac = ops_c / (ms_c * 1e-3) / 1e12
         m_avg = len(ct_sel_all) / B
-        lanes = {"k_ac17_dec_miller": B * 6, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 6, "k_final_exp_c3": B, "k_ac17_enc_rows": total_rows,
+        lanes = {"k_ac17_dec_miller": B * 6, "k_ac17_dec_miller2": B * 3, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 6, "k_final_exp_c3": B, "k_ac17_enc_rows": total_rows,
                  "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
         alg = {"k_ac17_dec_miller": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL,
+               "k_ac17_dec_miller2": 2 * (SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL),
                "k_ac17_dec_miller_c3": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL, "k_final_exp_c3": 9000 + 6 * 54,
                "k_final_exp": 9000 + 6 * 54, "k_ac17_enc_rows": 3 * 352, "k_ac17_enc_c0": 1056, "k_ac17_enc_cp": 2 * 1700 + 54}
-        impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
+        impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_ac17_dec_miller2": IMPL_MILLER2_FPMUL + 2 * m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0

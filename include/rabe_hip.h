@@ -180,6 +180,21 @@ int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items,
                                    const uint32_t* dev_sk_sel, const uint32_t* dev_sk_sel_off /*[n_items+1]*/,
                                    rhip_gt* dev_out /*[n_items]*/);
 
+/* Prepared secret keys.  k_0 is fixed per key, so the G2 side of the three pairings e(.., k_0[j]) of cp_decrypt (:416)
+ * -- the Miller-loop line coefficients -- is computed once per key and replayed by every decryption with it (the
+ * role of rabe-bn's G2 precomputation inside `pairing`; 3 x 88 x 192 B per key).  rhip_ac17_cp_decrypt_batch_prepared
+ * takes the handle in place of dev_sk_k0 and returns exactly the values of rhip_ac17_cp_decrypt_batch; it runs the two
+ * pairings of each index j on one accumulator (3 lanes per item, one Fq12 squaring per doubling step for both). */
+typedef struct rhip_ac17_sk_lines rhip_ac17_sk_lines;
+int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g2* dev_sk_k0 /*[n_sk][3]*/, rhip_ac17_sk_lines** out);
+void rhip_ac17_sk_lines_destroy(rhip_ac17_sk_lines* p);
+int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_items,
+                                            const rhip_g2* dev_ct_c0, const rhip_g1* dev_ct_c, const uint32_t* dev_ct_row_off,
+                                            const rhip_gt* dev_ct_cp, const rhip_ac17_sk_lines* sk_lines,
+                                            const rhip_g1* dev_sk_k, const uint32_t* dev_sk_row_off, const rhip_g1* dev_sk_kp,
+                                            const uint32_t* dev_sk_idx, const uint32_t* dev_ct_sel, const uint32_t* dev_ct_sel_off,
+                                            const uint32_t* dev_sk_sel, const uint32_t* dev_sk_sel_off, rhip_gt* dev_out);
+
 /* ---- measurement helper: integer-multiply issue-rate microbenchmark (the roofline denominator) --
  * Runs `iters` dependent-free v_mad_u64_u32 per lane on every CU and returns elapsed milliseconds
  * and the number of multiply-adds executed. */

@@ -212,12 +212,15 @@ RB_FN Fp12 c3_miller_loop(COMM& cm, const MillerP& p, bool p_is_inf, const G2Aff
   Fp12 f = fp12_one();
   if (p_is_inf || aff_is_inf(q)) return f;      // uniform within the triple (all three lanes hold the same inputs)
   G2Hom t{q.x, q.y, fp2_one()};
-  for (int i = RB_ATE_LOOP_BITS - 2; i >= 0; i--) {
+  const G2Aff qn = aff_neg(q);
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {       // same NAF chain as miller_loop()
     f = c3_fp12_sqr(cm, f);
     LineCoeffs l = c3_g2hom_double(cm, t);
     f = c3_ell(cm, f, l, p);
-    if ((RB_ATE_LOOP_LO >> i) & 1ull) {
-      LineCoeffs la = c3_g2hom_add(cm, t, q);
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) {
+      LineCoeffs la = c3_g2hom_add(cm, t, pos ? q : qn);
       f = c3_ell(cm, f, la, p);
     }
   }

@@ -104,14 +104,18 @@ RB_FN Fp12 miller_loop(const MillerP& p, bool p_is_inf, const G2Aff& q) {
   Fp12 f = fp12_one();
   if (p_is_inf || aff_is_inf(q)) return f;
   G2Hom t{q.x, q.y, fp2_one()};
-  // 6u+2 has 65 bits; the top bit (bit 64) is consumed by initialising T = Q.
-  for (int i = RB_ATE_LOOP_BITS - 2; i >= 0; i--) {
+  // 6u+2 in non-adjacent form (66 digits, 22 non-zero): the leading digit is consumed by T = Q, then 65 doubling
+  // steps and 21 addition steps with +Q or -Q.  The value differs from the binary chain's only by vertical-line
+  // factors in Fq6, which the final exponentiation removes (zcash bn / libff use the same NAF chain).
+  const G2Aff qn = aff_neg(q);
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
     f = fp12_sqr(f);
     LineCoeffs l = g2hom_double(t);
     f = ell(f, l, p);
-    const uint32_t bit = (uint32_t)((RB_ATE_LOOP_LO >> i) & 1ull);
-    if (bit) {
-      LineCoeffs la = g2hom_add(t, q);
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) {
+      LineCoeffs la = g2hom_add(t, pos ? q : qn);
       f = ell(f, la, p);
     }
   }
@@ -130,6 +134,90 @@ RB_FN Fp12 miller_loop(const MillerP& p, bool p_is_inf, const G2Aff& q) {
 RB_FN Fp12 fp12_mul_fn(const Fp12& a, const Fp12& b) { return fp12_mul(a, b); }
 RB_FN Fp12 fp12_cyclotomic_sqr_fn(const Fp12& a) { return fp12_cyclotomic_sqr(a); }
 RB_FN Fp12 fp12_frob_fn(const Fp12& a, int k) { return k == 1 ? fp12_frob1(a) : (k == 2 ? fp12_frob2(a) : fp12_frob3(a)); }
+
+// ---- prepared G2 argument: when Q is fixed (a secret key's k_0, a public key element) the G2 arithmetic of the
+// Miller loop does not depend on P, so its line coefficients are computed once per Q and replayed
+// (the role of `G2Precomp` in the zcash-bn lineage).  88 triples (65 doublings + 21 additions + 2 Frobenius steps).
+#define RB_MILLER_LINES (RB_ATE_NAF_LEN - 1 + RB_ATE_NAF_ADDS + 2)
+RB_FN void g2_prepare_lines(const G2Aff& q, LineCoeffs* out) {
+  int n = 0;
+  if (aff_is_inf(q)) {
+    for (int i = 0; i < RB_MILLER_LINES; i++) out[i] = LineCoeffs{fp2_zero(), fp2_zero(), fp2_zero()};
+    return;
+  }
+  G2Hom t{q.x, q.y, fp2_one()};
+  const G2Aff qn = aff_neg(q);
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    out[n++] = g2hom_double(t);
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) out[n++] = g2hom_add(t, pos ? q : qn);
+  }
+  G2Aff q1 = g2_frob1(q);
+  G2Aff q2 = aff_neg(g2_frob2(q));
+  out[n++] = g2hom_add(t, q1);
+  out[n++] = g2hom_add(t, q2);
+}
+// LOAD is a functor  LineCoeffs operator()(int k)  fetching triple k (device: global memory, host: array)
+template <class LOAD>
+RB_FN Fp12 miller_loop_prepared(const MillerP& p, bool p_is_inf, bool q_is_inf, LOAD load) {
+  Fp12 f = fp12_one();
+  if (p_is_inf || q_is_inf) return f;
+  int n = 0;
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    f = fp12_sqr(f);
+    f = ell(f, load(n++), p);
+    const bool nz = (i < 64) && (((RB_ATE_NAF_POS | RB_ATE_NAF_NEG) >> i) & 1ull);
+    if (nz) f = ell(f, load(n++), p);
+  }
+  f = ell(f, load(n++), p);
+  f = ell(f, load(n++), p);
+  return f;
+}
+
+// Two pairings on one accumulator: the Fq12 squaring of every doubling step is paid once for both.  Pairing A
+// replays prepared lines (fixed Q), pairing B walks its own G2 point.  A pairing with an argument at infinity
+// contributes 1 (its steps are skipped).  Result = miller(pa, A) * miller(pb, qb) up to Fq6 factors.
+template <class LOAD>
+RB_FN Fp12 miller_loop_pair(const MillerP& pa, bool skip_a, LOAD load, const MillerP& pb, bool pb_is_inf, const G2Aff& qb) {
+  const bool skip_b = pb_is_inf || aff_is_inf(qb);
+  Fp12 f = fp12_one();
+  G2Hom t{qb.x, qb.y, fp2_one()};
+  const G2Aff qn = aff_neg(qb);
+  int n = 0;
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    f = fp12_sqr(f);
+    if (!skip_a) f = ell(f, load(n), pa);
+    n++;
+    if (!skip_b) {
+      LineCoeffs l = g2hom_double(t);
+      f = ell(f, l, pb);
+    }
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) {
+      if (!skip_a) f = ell(f, load(n), pa);
+      n++;
+      if (!skip_b) {
+        LineCoeffs la = g2hom_add(t, pos ? qb : qn);
+        f = ell(f, la, pb);
+      }
+    }
+  }
+  if (!skip_a) {
+    f = ell(f, load(n), pa);
+    f = ell(f, load(n + 1), pa);
+  }
+  if (!skip_b) {
+    G2Aff q1 = g2_frob1(qb);
+    G2Aff q2 = aff_neg(g2_frob2(qb));
+    LineCoeffs l1 = g2hom_add(t, q1);
+    f = ell(f, l1, pb);
+    LineCoeffs l2 = g2hom_add(t, q2);
+    f = ell(f, l2, pb);
+  }
+  return f;
+}
 
 // f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).
 RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {

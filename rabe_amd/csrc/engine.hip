@@ -893,6 +893,80 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller(size_t n_i
   st_gt_m(mill + t, f);
 }
 
+// ---- prepared secret keys: the Miller-loop line coefficients of k_0[j] (fixed per key) are computed once
+// (rhip_ac17_sk_prepare) and replayed by every decryption with that key.
+struct LineM { uint32_t l[48]; };   // cy, cx, c0 (Fq2 each), Montgomery
+struct rhip_ac17_sk_lines {
+  rhip_ctx* ctx;
+  size_t n_sk;
+  LineM* lines;      // [n_sk * 3][RB_MILLER_LINES]
+  uint8_t* q_inf;    // [n_sk * 3]
+};
+struct DevLineLoad {
+  const LineM* base;
+  __device__ __forceinline__ LineCoeffs operator()(int k) const {
+    const uint32_t* p = base[k].l;
+    return LineCoeffs{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
+  }
+};
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_g2_prepare_lines(size_t n, const rhip_g2* q, LineM* lines, uint8_t* q_inf) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const G2Aff Q = load_g2(q[t].l);
+  q_inf[t] = aff_is_inf(Q) ? 1 : 0;
+  LineM* out = lines + t * RB_MILLER_LINES;
+  if (aff_is_inf(Q)) return;
+  // same walk as g2_prepare_lines (bn254/pairing.h), stored as it goes
+  G2Hom T{Q.x, Q.y, fp2_one()};
+  const G2Aff Qn = aff_neg(Q);
+  int n_out = 0;
+  auto put = [&](const LineCoeffs& l) {
+    uint32_t* p = out[n_out++].l;
+    st_fp2_m(p, l.cy); st_fp2_m(p + 16, l.cx); st_fp2_m(p + 32, l.c0);
+  };
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    put(g2hom_double(T));
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) put(g2hom_add(T, pos ? Q : Qn));
+  }
+  put(g2hom_add(T, g2_frob1(Q)));
+  put(g2hom_add(T, aff_neg(g2_frob2(Q))));
+}
+// decrypt with a prepared key: one lane per (item, j < 3) runs BOTH pairings of index j on one accumulator
+//   A: P = sum_{x in ct_sel} C[x][j],                 Q = k_0[j]   (prepared lines)
+//   B: P = -(k_p[j] + sum_{x in sk_sel} K[x][j]),     Q = c_0[j]
+// so each doubling step pays one Fq12 squaring instead of two and no G2 arithmetic for A.
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller2(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+                                                                      const uint32_t* ct_row_off, const LineM* sk_lines, const uint8_t* sk_qinf,
+                                                                      const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp,
+                                                                      const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,
+                                                                      const uint32_t* sk_sel, const uint32_t* sk_sel_off, GtM* mill) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items * 3) return;
+  const size_t item = t / 3;
+  const int j = (int)(t % 3);
+  const uint32_t sk = sk_idx[item];
+  G1Jac pa = jac_inf<Fp>();
+  {
+    const uint32_t base = ct_row_off[item];
+    for (uint32_t x = ct_sel_off[item]; x < ct_sel_off[item + 1]; x++)
+      pa = jac_add_aff(pa, load_g1(ct_c[(size_t)(base + ct_sel[x]) * 3 + j].l));
+  }
+  G1Jac pb = aff_to_jac(load_g1(sk_kp[(size_t)sk * 3 + j].l));
+  {
+    const uint32_t base = sk_row_off[sk];
+    for (uint32_t x = sk_sel_off[item]; x < sk_sel_off[item + 1]; x++)
+      pb = jac_add_aff(pb, load_g1(sk_k[(size_t)(base + sk_sel[x]) * 3 + j].l));
+    pb = jac_neg(pb);
+  }
+  const size_t lj = (size_t)sk * 3 + j;
+  const bool skip_a = jac_is_inf(pa) || sk_qinf[lj];
+  const G2Aff QB = load_g2(ct_c0[item * 3 + j].l);
+  Fp12 f = miller_loop_pair(miller_p_from_jac(pa), skip_a, DevLineLoad{sk_lines + lj * RB_MILLER_LINES}, miller_p_from_jac(pb), jac_is_inf(pb), QB);
+  st_gt_m(mill + t, f);
+}
+
 // three-lane variant of k_ac17_dec_miller: triple = (item, i < 6); the (short) G1 row sums are replicated in the
 // three lanes, the Miller loop is cooperative.
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller_c3(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
@@ -1293,5 +1367,44 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
                      sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 6u,
                      (const GtM*)mill, ct_cp, out);
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g2* sk_k0, rhip_ac17_sk_lines** out) {
+  NEED(ctx);
+  if (!out || !n_sk || !sk_k0) return RHIP_ERR_ARG;
+  rhip_ac17_sk_lines* p = new rhip_ac17_sk_lines{ctx, n_sk, nullptr, nullptr};
+  hipError_t e = hipMalloc((void**)&p->lines, n_sk * 3 * RB_MILLER_LINES * sizeof(LineM));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->q_inf, n_sk * 3);
+  if (e != hipSuccess) {
+    if (p->lines) (void)hipFree(p->lines);
+    delete p;
+    return fail(ctx, e, "rhip_ac17_sk_prepare: hipMalloc");
+  }
+  KLAUNCH(ctx, "k_g2_prepare_lines", k_g2_prepare_lines, dim3(blocks_for(n_sk * 3, 64)), dim3(64), 0, ctx->stream, n_sk * 3, sk_k0, p->lines, p->q_inf);
+  *out = p;
+  return RHIP_OK;
+}
+extern "C" void rhip_ac17_sk_lines_destroy(rhip_ac17_sk_lines* p) {
+  if (!p) return;
+  (void)hipFree(p->lines);
+  (void)hipFree(p->q_inf);
+  delete p;
+}
+extern "C" int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+                                                       const uint32_t* ct_row_off, const rhip_gt* ct_cp, const rhip_ac17_sk_lines* sk_lines,
+                                                       const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp,
+                                                       const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,
+                                                       const uint32_t* sk_sel, const uint32_t* sk_sel_off, rhip_gt* out) {
+  NEED(ctx);
+  if (!sk_lines) return RHIP_ERR_ARG;
+  if (!n_items) return RHIP_OK;
+  int32_t rc = ensure_scratch(ctx, n_items * 3 * sizeof(GtM));
+  if (rc) return rc;
+  GtM* mill = (GtM*)ctx->scratch;
+  KLAUNCH(ctx, "k_ac17_dec_miller2", k_ac17_dec_miller2, dim3(blocks_for(n_items * 3, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
+          (const LineM*)sk_lines->lines, (const uint8_t*)sk_lines->q_inf, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off,
+          mill);
+  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 3u,
+          (const GtM*)mill, ct_cp, out);
   return RHIP_OK;
 }

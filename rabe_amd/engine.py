@@ -269,3 +269,24 @@ def ac17_decrypt_dev(eng, n_items, dct_c0, dct_c, dct_row_off, dct_cp, dsk_k0, d
     eng._check(eng.lib.rhip_ac17_cp_decrypt_batch(eng.ctx, _sz(n_items), dct_c0.ptr, dct_c.ptr, dct_row_off.ptr, dct_cp.ptr,
                                                   dsk_k0.ptr, dsk_k.ptr, dsk_row_off.ptr, dsk_kp.ptr, dsk_idx.ptr,
                                                   dct_sel.ptr, dct_sel_off.ptr, dsk_sel.ptr, dsk_sel_off.ptr, dout.ptr))
+
+
+class Ac17SkLines:
+    """Prepared Miller-loop lines of n_sk secret keys' k_0 (rhip_ac17_sk_prepare)."""
+
+    def __init__(self, eng, n_sk, dsk_k0):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_ac17_sk_prepare(eng.ctx, _sz(n_sk), dsk_k0.ptr, ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_ac17_sk_lines_destroy(self.h)
+            self.h = None
+
+
+def ac17_decrypt_prepared_dev(eng, n_items, dct_c0, dct_c, dct_row_off, dct_cp, sk_lines, dsk_k, dsk_row_off, dsk_kp, dsk_idx,
+                              dct_sel, dct_sel_off, dsk_sel, dsk_sel_off, dout):
+    eng._check(eng.lib.rhip_ac17_cp_decrypt_batch_prepared(eng.ctx, _sz(n_items), dct_c0.ptr, dct_c.ptr, dct_row_off.ptr, dct_cp.ptr,
+                                                           sk_lines.h, dsk_k.ptr, dsk_row_off.ptr, dsk_kp.ptr, dsk_idx.ptr,
+                                                           dct_sel.ptr, dct_sel_off.ptr, dsk_sel.ptr, dsk_sel_off.ptr, dout.ptr))

@@ -78,6 +78,32 @@ void hs_pairing_jac(const uint32_t* p, const uint32_t* zscale, const uint32_t* q
   G1Jac J{mul(P.x, z2), mul(P.y, mul(z2, z)), z};
   store_gt(out, final_exponentiation(miller_loop(miller_p_from_jac(J), aff_is_inf(P), load_g2(q))));
 }
+struct HostLineLoad { const LineCoeffs* l; LineCoeffs operator()(int k) const { return l[k]; } };
+void hs_pairing_prepared(const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff P = load_g1(p);
+  G2Aff Q = load_g2(q);
+  LineCoeffs lines[RB_MILLER_LINES];
+  g2_prepare_lines(Q, lines);
+  store_gt(out, final_exponentiation(miller_loop_prepared(miller_p_from_aff(P), aff_is_inf(P), aff_is_inf(Q), HostLineLoad{lines})));
+}
+void hs_g2_prepare(const uint32_t* q, uint32_t* out /* first line, 48 words */) {
+  LineCoeffs lines[RB_MILLER_LINES];
+  g2_prepare_lines(load_g2(q), lines);
+  store_fp2(out, lines[0].cy); store_fp2(out + 16, lines[0].cx); store_fp2(out + 32, lines[0].c0);
+}
+// FE( miller_pair(pa, prepared qa; pb, qb) ) = e(pa, qa) * e(pb, qb)
+void hs_pairing_pair(const uint32_t* pa, const uint32_t* qa, const uint32_t* pb, const uint32_t* qb, uint32_t* out) {
+  G1Aff PA = load_g1(pa), PB = load_g1(pb);
+  G2Aff QA = load_g2(qa), QB = load_g2(qb);
+  LineCoeffs lines[RB_MILLER_LINES];
+  g2_prepare_lines(QA, lines);
+  // B enters Jacobian-scaled like the decrypt kernel's row sums: (x z^2, y z^3, z) with z = 3
+  Fp z = add(add(one<FpParams>(), one<FpParams>()), one<FpParams>());
+  Fp z2 = sqr(z);
+  G1Jac JB{mul(PB.x, z2), mul(PB.y, mul(z2, z)), aff_is_inf(PB) ? zero<FpParams>() : z};
+  store_gt(out, final_exponentiation(miller_loop_pair(miller_p_from_aff(PA), aff_is_inf(PA) || aff_is_inf(QA), HostLineLoad{lines},
+                                                      miller_p_from_jac(JB), jac_is_inf(JB), QB)));
+}
 void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
 
 

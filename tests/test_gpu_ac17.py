@@ -118,6 +118,15 @@ def test_cp_decrypt_roundtrip_and_reference(env, policy, lang, attrs):
                        eng.upload_u32(ct_sel * n_items), eng.upload_u32([i * len(ct_sel) for i in range(n_items + 1)]),
                        eng.upload_u32(sk_sel * n_items), eng.upload_u32([i * len(sk_sel) for i in range(n_items + 1)]), dout)
     out = eng.download(dout)
+    # prepared-key path (k_0 lines computed once, paired Miller loops): identical bytes
+    lines = E.Ac17SkLines(eng, 1, dsk_k0)
+    dout2 = eng.alloc(n_items * 384)
+    E.ac17_decrypt_prepared_dev(eng, n_items, dc0, dc, eng.upload_u32([i * n_rows for i in range(n_items + 1)]), dcp,
+                                lines, dsk_k, eng.upload_u32([0, len(attrs)]), dsk_kp, eng.upload_u32([0] * n_items),
+                                eng.upload_u32(ct_sel * n_items), eng.upload_u32([i * len(ct_sel) for i in range(n_items + 1)]),
+                                eng.upload_u32(sk_sel * n_items), eng.upload_u32([i * len(sk_sel) for i in range(n_items + 1)]), dout2)
+    assert eng.download(dout2) == out
+    lines.destroy()
     # round trip: the decrypted Gt is the encrypted msg
     for i, msg in enumerate(msgs):
         assert out[i * 384:(i + 1) * 384] == bn.gt_to_le(msg)

@@ -172,3 +172,27 @@ def test_three_lane_cooperative_pairing_equals_single_lane():
     assert bytes(out) == bn.gt_to_le(bn.gt_pow(bn.pairing(bn.G1_GEN, bn.G2_GEN), k1 * k2 % bn.R))
     assert HS.hs_c3_pairing(b2c(bytes(64)), None, Q, 1, out) == 1
     assert bytes(out) == bn.gt_to_le(bn.GT_ONE)
+
+
+def test_prepared_g2_pairing():
+    k1, k2 = RND.randrange(1, bn.R), RND.randrange(1, bn.R)
+    p, q = bn.g1_mul(bn.G1_GEN, k1), bn.g2_mul(bn.G2_GEN, k2)
+    want = bn.gt_to_le(bn.gt_pow(bn.pairing(bn.G1_GEN, bn.G2_GEN), k1 * k2 % bn.R))
+    assert call("hs_pairing_prepared", bn.g1_to_le(p), bn.g2_to_le(q), out=384) == want
+    assert call("hs_pairing_prepared", bytes(64), bn.g2_to_le(q), out=384) == bn.gt_to_le(bn.GT_ONE)
+    assert call("hs_pairing_prepared", bn.g1_to_le(p), bytes(128), out=384) == bn.gt_to_le(bn.GT_ONE)
+
+
+def test_paired_miller_loop():
+    ks = [RND.randrange(1, bn.R) for _ in range(4)]
+    pa, pb = bn.g1_mul(bn.G1_GEN, ks[0]), bn.g1_mul(bn.G1_GEN, ks[2])
+    qa, qb = bn.g2_mul(bn.G2_GEN, ks[1]), bn.g2_mul(bn.G2_GEN, ks[3])
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    z64, z128 = bytes(64), bytes(128)
+    enc = lambda p, q: (bn.g1_to_le(p), bn.g2_to_le(q))
+    assert call("hs_pairing_pair", *enc(pa, qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, (ks[0] * ks[1] + ks[2] * ks[3]) % bn.R))
+    assert call("hs_pairing_pair", z64, bn.g2_to_le(qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
+    assert call("hs_pairing_pair", bn.g1_to_le(pa), z128, *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
+    assert call("hs_pairing_pair", *enc(pa, qa), z64, bn.g2_to_le(qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
+    assert call("hs_pairing_pair", *enc(pa, qa), bn.g1_to_le(pb), z128, out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
+    assert call("hs_pairing_pair", z64, z128, z64, z128, out=384) == bn.gt_to_le(bn.GT_ONE)

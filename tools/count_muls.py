@@ -41,6 +41,9 @@ base_io = count("hs_fp_add", le(1), le(2), out=32)           # load/store conver
 res["io_fp_roundtrip(2 loads + 1 store)"] = base_io
 res["miller_loop(affine P) incl. 6 loads 12 stores"] = count("hs_miller", P, Q)
 res["miller_loop(jacobian P) + final_exp"] = count("hs_pairing_jac", P, le(rnd.randrange(bn.P)), Q)
+res["pairing via prepared lines (affine P) + final_exp incl. line preparation"] = count("hs_pairing_prepared", P, Q)
+res["paired miller (A prepared incl. preparation, B jacobian) + final_exp"] = count("hs_pairing_pair", P, Q, P, Q)
+res["g2_prepare_lines (88 line triples) incl. io"] = count("hs_g2_prepare", Q, out=192)
 m = (ctypes.c_uint32 * 96)()
 HS.hs_miller(b2c(P), b2c(Q), m)
 res["final_exponentiation incl. 12 loads 12 stores"] = count("hs_final_exp", bytes(m))
