@@ -58,6 +58,9 @@ def parse_args():
                     help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
+    ap.add_argument("--g-window", type=int, default=16,
+                    help="window width (bits) of the fixed-base table of g: 16 (67 MB), or 17..27 signed digits (24: 5.4 GB, 26: 19 GB)")
+    ap.add_argument("--only-encrypt", action="store_true", help="diagnostic: skip the decrypt half of every step (value is then not the metric)")
     ap.add_argument("--no-prepared-sk", action="store_true",
                     help="decrypt without the per-key prepared lines (6 independent Miller loops per item)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,6 +110,8 @@ def main():
     e_gh = eng.pairing([g], [h])[0]
     e_gh_ka = eng.gt_pow([e_gh] * 2, [le(k[i] * a[i] + k[2]) for i in range(2)])
     pk = E.Ac17Pk(eng, g, h_a, e_gh_ka)
+    if args.g_window > 16:
+        pk.set_g_window(args.g_window)
 
     # ---------------------------------------------------------------- secret key with all attributes (ac17::cp_keygen, :191-264)
     attrs = ["a%d" % (i + 1) for i in range(args.attrs)]
@@ -189,6 +194,8 @@ def main():
         e_ = lanes_ctx[i]
         c0_, c_, cp_, out_ = bufs[i]
         E.ac17_encrypt_dev(e_, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds, dmsg, c0_, c_, cp_)
+        if args.only_encrypt:
+            return
         if sk_lines is None:
             E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
                                d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)

@@ -116,6 +116,10 @@ int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* host_base, rhip_gt_ta
 /* adds 16-bit windows (16 x 65535 entries, 67 MB) to a G1 table: halves the additions of rhip_g1_table_mul-style
  * kernels; rhip_ac17_pk_create does this for the public generator g */
 int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t);
+/* adds signed w_bits-wide windows (17 <= w_bits <= 27): a fixed-base multiplication then costs ceil(254 / w_bits)
+ * mixed additions (11 at 24 bits, 10 at 26) for 64 B x 2^(w_bits-1) x ceil(254 / w_bits) of HBM (5.4 GB at 24 bits,
+ * 19 GB at 26) -- memory traded for work on a 288 GB part.  Results are the same group elements, hence the same bytes. */
+int32_t rhip_g1_table_add_wide(rhip_ctx* ctx, rhip_g1_table* t, int32_t w_bits);
 /* the same for a Gt base (16 x 65535 x 384 B = 402 MB): halves the multiplications of a fixed-base Gt power */
 int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t);
 void rhip_g1_table_destroy(rhip_g1_table* t);
@@ -131,6 +135,8 @@ int32_t rhip_gt_table_pow(rhip_ctx* ctx, const rhip_gt_table* t, size_t n, const
 typedef struct rhip_ac17_pk rhip_ac17_pk;
 int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* host_g, const rhip_g2* host_h_a /*[3]*/,
                             const rhip_gt* host_e_gh_ka /*[2]*/, rhip_ac17_pk** out);
+/* switches the public generator's table of pk to signed w_bits-wide windows (rhip_g1_table_add_wide) */
+int32_t rhip_ac17_pk_set_g_window(rhip_ctx* ctx, rhip_ac17_pk* pk, int32_t w_bits);
 void rhip_ac17_pk_destroy(rhip_ac17_pk* pk);
 
 /* Group arithmetic of n_items calls of ac17::cp_encrypt (src/schemes/ac17/mod.rs:274-376).

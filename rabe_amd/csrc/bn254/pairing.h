@@ -249,6 +249,75 @@ RB_FN Fp12 final_exponentiation(const Fp12& f_in) {
   return fp12_mul_fn(fp12_frob_fn(t, 3), r);                                      // u = t^(p^3) ; v = u*r
 }
 
+// ---- the same final exponentiation over an explicit workspace.
+// On the device every Fq12 that is live across a call has to sit in memory anyway (96 registers do not travel
+// through a call); letting the compiler put them in stack frames made k_final_exp the kernel with the largest
+// scratch frame, and the HSA runtime sizes each hardware queue's scratch for the largest frame x every wave slot
+// of the chip (32 GB in total over all queues), which capped the number of batches in flight.  Here the values
+// live in numbered workspace slots the caller provides (global memory sized by the actual lane count, coalesced
+// [slot][word][lane]); each operation loads its operands, works in registers and stores its result.
+// WS provides  Fp12 ld(int slot) const  and  void st(int slot, const Fp12&) const.
+enum { FE_F = 0, FE_B, FE_D, FE_E, FE_K, FE_L, FE_T0, FE_T1, FE_SLOTS };
+template <class WS> RB_FN void wsx_mul(WS ws, int dst, int a, bool conj_a, int b, bool conj_b) {
+  Fp12 x = ws.ld(a), y = ws.ld(b);
+  if (conj_a) x = fp12_conj(x);
+  if (conj_b) y = fp12_conj(y);
+  ws.st(dst, fp12_mul(x, y));
+}
+template <class WS> RB_FN void wsx_csqr(WS ws, int dst, int a, bool conj_a) {
+  Fp12 x = ws.ld(a);
+  if (conj_a) x = fp12_conj(x);
+  ws.st(dst, fp12_cyclotomic_sqr(x));
+}
+template <class WS> RB_FN void wsx_frob_mul(WS ws, int dst, int a, int k, int b) {   // dst = a^(p^k) * b
+  Fp12 x = ws.ld(a);
+  x = (k == 1) ? fp12_frob1(x) : (k == 2) ? fp12_frob2(x) : fp12_frob3(x);
+  ws.st(dst, fp12_mul(x, ws.ld(b)));
+}
+template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) { ws.st(dst, fp12_inv(ws.ld(a))); }
+// dst = a^(2^n) * (b >= 0 ? b : 1): a run of cyclotomic squarings and the multiplication that ends it stay in registers
+template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b) {
+  Fp12 x = ws.ld(a);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) x = fp12_cyclotomic_sqr(x);
+  if (b >= 0) x = fp12_mul(x, ws.ld(b));
+  ws.st(dst, x);
+}
+template <class WS> RB_FN void wsx_exp_u(WS ws, int dst, int src) {   // dst = src^u, dst != src
+  int cur = src, n = 0;
+  for (int i = 61; i >= 0; i--) {
+    n++;
+    if ((RB_BN_U >> i) & 1ull) {
+      wsx_sqrn_mul(ws, dst, cur, n, src);
+      cur = dst;
+      n = 0;
+    }
+  }
+  if (n) wsx_sqrn_mul(ws, dst, cur, n, -1);
+}
+// in: slot FE_T0 = the Miller value; out: slot FE_T1.  Same chain as final_exponentiation above.
+template <class WS> RB_FN void final_exponentiation_ws(WS ws) {
+  wsx_inv(ws, FE_T1, FE_T0);
+  wsx_mul(ws, FE_T1, FE_T0, true, FE_T1, false);       // f^(p^6-1) = conj(f) * f^-1
+  wsx_frob_mul(ws, FE_F, FE_T1, 2, FE_T1);             // ^(p^2+1)                                   F
+  wsx_exp_u(ws, FE_T0, FE_F);                          // f^u        (a = conj of it)
+  wsx_csqr(ws, FE_B, FE_T0, true);                     // b = a^2                                    B
+  wsx_csqr(ws, FE_T0, FE_B, false);                    // c = b^2
+  wsx_mul(ws, FE_D, FE_T0, false, FE_B, false);        // d = c*b                                    D
+  wsx_exp_u(ws, FE_E, FE_D);                           // d^u        (e = conj of it)
+  wsx_csqr(ws, FE_T0, FE_E, true);                     // f' = e^2
+  wsx_exp_u(ws, FE_T1, FE_T0);                         // f'^u = conj(g) = i
+  wsx_mul(ws, FE_T0, FE_T1, false, FE_E, true);        // j = i*e
+  wsx_mul(ws, FE_K, FE_T0, false, FE_D, true);         // k = j*h, h = d^-1                          K
+  wsx_mul(ws, FE_L, FE_K, false, FE_B, false);         // l = k*b                                    L
+  wsx_mul(ws, FE_T0, FE_K, false, FE_E, true);         // m = k*e
+  wsx_mul(ws, FE_T0, FE_T0, false, FE_F, false);       // n = m*f
+  wsx_frob_mul(ws, FE_T1, FE_L, 1, FE_T0);             // p = l^p * n
+  wsx_frob_mul(ws, FE_T0, FE_K, 2, FE_T1);             // r = k^(p^2) * p
+  wsx_mul(ws, FE_T1, FE_F, true, FE_L, false);         // t = f^-1 * l
+  wsx_frob_mul(ws, FE_T1, FE_T1, 3, FE_T0);            // v = t^(p^3) * r
+}
+
 // Gt exponentiation by a canonical little-endian scalar (`Gt::pow(Fr)`), binary, cyclotomic squarings.
 // Valid for elements of Gt (unitary); the reference only ever raises pairing outputs.
 RB_FN Fp12 gt_pow_binary(const Fp12& base, const uint32_t k[8]) {

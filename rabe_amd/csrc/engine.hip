@@ -48,6 +48,9 @@ struct rhip_ctx {
   // grow-only device scratch (Miller values between k_miller and k_final_exp)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // grow-only workspace of k_final_exp (FE_SLOTS Fq12 per lane, [slot][word][lane])
+  void* fe_ws = nullptr;
+  size_t fe_ws_bytes = 0;
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
   int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
   bool timing = false;
@@ -104,6 +107,19 @@ static int32_t ensure_scratch(rhip_ctx* ctx, size_t bytes) {
   return RHIP_OK;
 }
 
+static int32_t ensure_fe_ws(rhip_ctx* ctx, size_t bytes) {
+  if (ctx->fe_ws_bytes >= bytes) return RHIP_OK;
+  if (ctx->fe_ws) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->fe_ws));
+    ctx->fe_ws = nullptr;
+    ctx->fe_ws_bytes = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->fe_ws, bytes));
+  ctx->fe_ws_bytes = bytes;
+  return RHIP_OK;
+}
+
 static std::string g_create_err;   // diagnostics for a failed rhip_ctx_create (no ctx exists yet)
 static int32_t create_fail(const char* what, hipError_t e) {
   g_create_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -138,6 +154,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->fe_ws) (void)hipFree(ctx->fe_ws);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -364,22 +381,58 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller(size_t n, const rhi
   Fp12 f = miller_loop(miller_p_from_aff(P), aff_is_inf(P), load_g2(q[i].l));
   st_gt_m(out + i, f);
 }
-// out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical
+// out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical.
+// The exponentiation's Fq12 values live in the context's workspace (final_exponentiation_ws, bn254/pairing.h).
+struct DevWs {
+  uint4* base;         // + lane; [slot][quad of words][lane]: one 16-byte access per lane, contiguous over the wave
+  size_t stride;       // lanes (padded to 64)
+  __device__ __forceinline__ Fp12 ld(int slot) const {
+    const uint4* p = base + (size_t)slot * 24 * stride;
+    Fp12 r;
+    Fp2* c[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const uint4 q0 = p[(size_t)(4 * j) * stride], q1 = p[(size_t)(4 * j + 1) * stride];
+      const uint4 q2 = p[(size_t)(4 * j + 2) * stride], q3 = p[(size_t)(4 * j + 3) * stride];
+      c[j]->c0.v[0] = q0.x; c[j]->c0.v[1] = q0.y; c[j]->c0.v[2] = q0.z; c[j]->c0.v[3] = q0.w;
+      c[j]->c0.v[4] = q1.x; c[j]->c0.v[5] = q1.y; c[j]->c0.v[6] = q1.z; c[j]->c0.v[7] = q1.w;
+      c[j]->c1.v[0] = q2.x; c[j]->c1.v[1] = q2.y; c[j]->c1.v[2] = q2.z; c[j]->c1.v[3] = q2.w;
+      c[j]->c1.v[4] = q3.x; c[j]->c1.v[5] = q3.y; c[j]->c1.v[6] = q3.z; c[j]->c1.v[7] = q3.w;
+    }
+    return r;
+  }
+  __device__ __forceinline__ void st(int slot, const Fp12& a) const {
+    uint4* p = base + (size_t)slot * 24 * stride;
+    const Fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      p[(size_t)(4 * j) * stride] = make_uint4(c[j]->c0.v[0], c[j]->c0.v[1], c[j]->c0.v[2], c[j]->c0.v[3]);
+      p[(size_t)(4 * j + 1) * stride] = make_uint4(c[j]->c0.v[4], c[j]->c0.v[5], c[j]->c0.v[6], c[j]->c0.v[7]);
+      p[(size_t)(4 * j + 2) * stride] = make_uint4(c[j]->c1.v[0], c[j]->c1.v[1], c[j]->c1.v[2], c[j]->c1.v[3]);
+      p[(size_t)(4 * j + 3) * stride] = make_uint4(c[j]->c1.v[4], c[j]->c1.v[5], c[j]->c1.v[6], c[j]->c1.v[7]);
+    }
+  }
+};
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
-                                                  const rhip_gt* mul_in, rhip_gt* out) {
+                                                  const rhip_gt* mul_in, rhip_gt* out, uint32_t* ws_base, size_t ws_stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
-  uint32_t lo = off ? off[i] : (uint32_t)(i * stride);
-  uint32_t hi = off ? off[i + 1] : (uint32_t)((i + 1) * stride);
-  Fp12 f = fp12_one();
-  for (uint32_t j = lo; j < hi; j++) {
-    Fp12 m = ld_gt_m(mill + j);
-    f = (j == lo) ? m : fp12_mul(f, m);
+  const size_t lo = off ? off[i] : i * stride, hi = off ? off[i + 1] : (i + 1) * stride;
+  const DevWs ws{(uint4*)ws_base + i, ws_stride};
+  if (lo == hi) ws.st(FE_T0, fp12_one());
+  for (size_t j = lo; j < hi; j++) {
+    ws.st(j == lo ? FE_T0 : FE_T1, ld_gt_m(mill + j));
+    if (j != lo) wsx_mul(ws, FE_T0, FE_T0, false, FE_T1, false);
   }
-  Fp12 e = final_exponentiation(f);
-  if (mul_in) e = fp12_mul(load_gt(mul_in[i].l), e);
-  store_gt(out[i].l, e);
+  final_exponentiation_ws(ws);
+  if (mul_in) {
+    ws.st(FE_T0, load_gt(mul_in[i].l));
+    wsx_mul(ws, FE_T1, FE_T0, false, FE_T1, false);
+  }
+  store_gt(out[i].l, ws.ld(FE_T1));
 }
+static int32_t launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
+                                rhip_gt* out);
 
 // ------------------------------------------------------------------------------------------------
 // three-lane cooperative pairing kernels (bn254/coop3.h): a wave holds 21 triples (lane 63 idles); the all-gather
@@ -450,7 +503,16 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp_c3(size_t n_item
 #define TBL_DIGITS 255
 #define TBL16_WINDOWS 16
 #define TBL16_DIGITS 65535
-struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; G1M* dev16; };   // dev: 8-bit windows; dev16: optional 16-bit windows
+// dev: 8-bit windows; dev16: optional 16-bit windows; wide: optional signed w-bit windows (17 <= w <= 27)
+struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; G1M* dev16; G1M* wide; int wide_bits; };
+// signed w-bit windows: k = sum_i d_i 2^(w i), -2^(w-1) < d_i <= 2^(w-1); T[i][|d|-1] = (|d| 2^(w i)) * base, the sign is
+// applied to y on the fly.  n = ceil(254 / w) windows of 2^(w-1) entries (the top one only needs 2^(254-w(n-1)) of them).
+__host__ __device__ inline int wide_windows(int w) { return (254 + w - 1) / w; }
+__host__ __device__ inline size_t wide_count(int w, int i) {
+  const int n = wide_windows(w);
+  return (i < n - 1) ? ((size_t)1 << (w - 1)) : ((size_t)1 << (254 - w * (n - 1)));
+}
+__host__ __device__ inline size_t wide_offset(int w, int i) { return (size_t)i << (w - 1); }   // windows below the top are full
 struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; };
 struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optional 16-bit windows (402 MB)
 
@@ -487,6 +549,25 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_build_g1_w16(const G
   if (lo) acc = jac_add_aff(acc, ld_g1_m(t8 + (2 * w) * TBL_DIGITS + (lo - 1)));
   if (hi) acc = jac_add_aff(acc, ld_g1_m(t8 + (2 * w + 1) * TBL_DIGITS + (hi - 1)));
   st_g1_m(t16 + t, jac_to_aff(acc));
+}
+__device__ __noinline__ G1Jac table_mul_g1(const G1M* tbl, const uint32_t k[8]);
+__device__ __noinline__ Fp block_batch_inverse_256(uint32_t (*sh)[256], const Fp& mine);
+// wide table, window i: entry d-1 = (d << (w i)) * base via the 8-bit table, one field inversion per block
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_build_g1_wide(const G1M* t8, G1M* out, int w, int i, size_t count) {
+  __shared__ uint32_t sh[8][256];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < count;
+  if (!active) t = count - 1;
+  // m = (t + 1) << (w i), < 2^255
+  const uint64_t d = (uint64_t)t + 1;
+  const int b = w * i, word = b >> 5, sh_ = b & 31;
+  const uint64_t lo = d << sh_;                       // d < 2^27, sh_ < 32: fits 64 bits
+  uint32_t m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) m[j] = (j == word) ? (uint32_t)lo : (j == word + 1) ? (uint32_t)(lo >> 32) : 0u;
+  const G1Jac r = table_mul_g1(t8, m);
+  const Fp zinv = block_batch_inverse_256(sh, r.z);     // never infinity: 0 < m, m is not a multiple of r
+  if (active) st_g1_m(out + t, jac_to_aff_with_zinv(r, zinv));
 }
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_build_g2(const rhip_g2* base, G2M* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -588,7 +669,52 @@ __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[
       d = (wn & 1) ? (word >> 16) : (word & 0xffffu);
       e = ld_g1_m(tbl + (size_t)wn * TBL16_DIGITS + (d ? d - 1 : 0));
     }
-    if (dcur) acc = jac_add_aff(acc, ecur);
+    if (dcur) acc = g1_madd_inl(acc, ecur);
+  }
+  return acc;
+}
+// signed w-bit digits: ceil(254/w) mixed additions (11 for w = 24, 10 for w = 26); the digit's sign flips y
+__device__ __forceinline__ uint32_t scalar_bits(const uint32_t k[8], int b, int w) {
+  const int word = b >> 5, sh = b & 31;
+  uint32_t lo, hi;
+  switch (word) {
+    case 0: lo = k[0]; hi = k[1]; break;
+    case 1: lo = k[1]; hi = k[2]; break;
+    case 2: lo = k[2]; hi = k[3]; break;
+    case 3: lo = k[3]; hi = k[4]; break;
+    case 4: lo = k[4]; hi = k[5]; break;
+    case 5: lo = k[5]; hi = k[6]; break;
+    case 6: lo = k[6]; hi = k[7]; break;
+    default: lo = k[7]; hi = 0; break;
+  }
+  const uint64_t v = (((uint64_t)hi << 32) | lo) >> sh;
+  return (uint32_t)v & ((1u << w) - 1u);
+}
+__device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uint32_t k[8], int w) {
+  const int n = wide_windows(w);
+  const uint32_t half = 1u << (w - 1);
+  G1Jac acc = jac_inf<Fp>();
+  uint32_t raw = scalar_bits(k, 0, w);
+  uint32_t carry = raw > half ? 1u : 0u;
+  uint32_t mag = carry ? (1u << w) - raw : raw;
+  bool neg_ = carry != 0;
+  G1Aff e = ld_g1_m(tbl + (mag ? mag - 1 : 0));
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const uint32_t mcur = mag;
+    const bool ncur = neg_;
+    G1Aff ecur = e;
+    if (i + 1 < n) {
+      raw = scalar_bits(k, w * (i + 1), w) + carry;
+      carry = raw > half ? 1u : 0u;
+      mag = carry ? (1u << w) - raw : raw;
+      neg_ = carry != 0;
+      e = ld_g1_m(tbl + wide_offset(w, i + 1) + (mag ? mag - 1 : 0));
+    }
+    if (mcur) {
+      if (ncur) ecur.y = neg(ecur.y);
+      acc = g1_madd_inl(acc, ecur);
+    }
   }
   return acc;
 }
@@ -770,7 +896,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g
     Fr k = add(mul(s0, a0), mul(s1, a1));
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
-    G1Jac r = w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
+    G1Jac r = (w16 > 16) ? table_mul_g1_wide(g_tbl, kk, w16) : w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (l == 0) pt[0] = r; else if (l == 1) pt[1] = r; else pt[2] = r;
   }
   store3_g1_block(sh, active, c + t * 3, pt[0], pt[1], pt[2]);
@@ -1172,6 +1298,15 @@ extern "C" int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* a, const 
 // 1.3x faster (Miller 8.4 ms vs 11.1 ms, final exponentiation 8.5 vs 11.6) but cost 2.3x the SIMD time, and at one
 // wave per SIMD (512 registers of replicated state) more than 21 504 pairs need a second round.  So "auto" uses them
 // only for small launches, where latency is all that matters; throughput-sized batches keep one lane per pairing.
+static int32_t launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
+                                rhip_gt* out) {
+  const size_t lanes = (n_items + 63) / 64 * 64;
+  int32_t rc = ensure_fe_ws(ctx, lanes * FE_SLOTS * 96 * sizeof(uint32_t));
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
+          (uint32_t*)ctx->fe_ws, lanes);
+  return RHIP_OK;
+}
 static bool use_c3(const rhip_ctx* ctx, size_t n_pairs) {
   if (ctx->pairing_mode == 1) return false;
   if (ctx->pairing_mode == 3) return true;
@@ -1199,9 +1334,8 @@ extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uin
   if (n_pairs) {
     KLAUNCH(ctx, "k_miller", k_miller, dim3(blocks_for(n_pairs, 64)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
   }
-  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, 1u, (const GtM*)mill,
+  return launch_final_exp(ctx, n_items, off, 1u, (const GtM*)mill,
                      (const rhip_gt*)nullptr, out);
-  return RHIP_OK;
 }
 extern "C" int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* p, const rhip_g2* q, rhip_gt* out) {
   return rhip_pairing_product(ctx, n, nullptr, n, p, q, out);
@@ -1237,7 +1371,35 @@ extern "C" int32_t rhip_g2_table_create(rhip_ctx* ctx, const rhip_g2* b, rhip_g2
 extern "C" int32_t rhip_gt_table_create(rhip_ctx* ctx, const rhip_gt* b, rhip_gt_table** out) {
   return table_create<rhip_gt_table, GtM>(ctx, b, out, k_table_build_gt, 64);
 }
-extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) { if (t) { (void)hipFree(t->dev); if (t->dev16) (void)hipFree(t->dev16); delete t; } }
+extern "C" void rhip_g1_table_destroy(rhip_g1_table* t) {
+  if (!t) return;
+  (void)hipFree(t->dev);
+  if (t->dev16) (void)hipFree(t->dev16);
+  if (t->wide) (void)hipFree(t->wide);
+  delete t;
+}
+// adds signed w_bits-wide windows (17..27): ceil(254/w) additions per multiplication for ~ 64 B x 2^(w-1) x ceil(254/w)
+// of HBM (w = 24: 11 additions, 5.4 GB; w = 26: 10 additions, 19 GB) -- the 288 GB part trades memory for work
+extern "C" int32_t rhip_g1_table_add_wide(rhip_ctx* ctx, rhip_g1_table* t, int32_t w_bits) {
+  NEED(ctx);
+  if (!t || w_bits < 17 || w_bits > 27) return RHIP_ERR_ARG;
+  if (t->wide && t->wide_bits == w_bits) return RHIP_OK;
+  if (t->wide) { (void)hipFree(t->wide); t->wide = nullptr; t->wide_bits = 0; }
+  const int n = wide_windows(w_bits);
+  const size_t total = wide_offset(w_bits, n - 1) + wide_count(w_bits, n - 1);
+  G1M* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(G1M) * total));
+  for (int i = 0; i < n; i++) {
+    const size_t cnt = wide_count(w_bits, i);
+    KLAUNCH(ctx, "k_table_build_g1_wide", k_table_build_g1_wide, dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (const G1M*)t->dev,
+            d + wide_offset(w_bits, i), (int)w_bits, i, cnt);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t->wide = d;
+  t->wide_bits = w_bits;
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_ac17_pk_set_g_window(rhip_ctx* ctx, rhip_ac17_pk* pk, int32_t w_bits);
 // adds the 16-bit-window table (67 MB) to an existing G1 table
 extern "C" int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t) {
   NEED(ctx);
@@ -1315,6 +1477,11 @@ extern "C" int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* g, const rh
   *out = pk;
   return RHIP_OK;
 }
+extern "C" int32_t rhip_ac17_pk_set_g_window(rhip_ctx* ctx, rhip_ac17_pk* pk, int32_t w_bits) {
+  NEED(ctx);
+  if (!pk) return RHIP_ERR_ARG;
+  return rhip_g1_table_add_wide(ctx, pk->g, w_bits);
+}
 extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* A,
                                               const uint32_t* item_A_off, const uint32_t* ct_row_off, size_t total_rows,
                                               const rhip_fr* s, const rhip_gt* msg, rhip_g2* c0, rhip_g1* c, rhip_gt* cp) {
@@ -1322,8 +1489,10 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
   if (!pk) return RHIP_ERR_ARG;
   if (!n_items) return RHIP_OK;
   if (total_rows) {
-    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, (const G1M*)(pk->g->dev16 ? pk->g->dev16 : pk->g->dev),
-                       n_items, total_rows, A, item_A_off, ct_row_off, s, c, pk->g->dev16 ? 1 : 0);
+    const rhip_g1_table* g = pk->g;
+    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream,
+            (const G1M*)(g->wide ? g->wide : g->dev16 ? g->dev16 : g->dev), n_items, total_rows, A, item_A_off, ct_row_off, s, c,
+            g->wide ? g->wide_bits : g->dev16 ? 1 : 0);
   }
   KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
                      (const G2M*)pk->h_a[1]->dev, (const G2M*)pk->h_a[2]->dev, n_items, s, c0);
@@ -1365,9 +1534,8 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
   }
   KLAUNCH(ctx, "k_ac17_dec_miller", k_ac17_dec_miller, dim3(blocks_for(n_items * 6, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
                      sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
-  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 6u,
+  return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, 6u,
                      (const GtM*)mill, ct_cp, out);
-  return RHIP_OK;
 }
 extern "C" int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g2* sk_k0, rhip_ac17_sk_lines** out) {
   NEED(ctx);
@@ -1404,7 +1572,6 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_i
   KLAUNCH(ctx, "k_ac17_dec_miller2", k_ac17_dec_miller2, dim3(blocks_for(n_items * 3, 64)), dim3(64), 0, ctx->stream, n_items, ct_c0, ct_c, ct_row_off,
           (const LineM*)sk_lines->lines, (const uint8_t*)sk_lines->q_inf, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off,
           mill);
-  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, (const uint32_t*)nullptr, 3u,
+  return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, 3u,
           (const GtM*)mill, ct_cp, out);
-  return RHIP_OK;
 }

@@ -243,6 +243,10 @@ class Ac17Pk:
         self.h = ctypes.c_void_p()
         eng._check(eng.lib.rhip_ac17_pk_create(eng.ctx, bytes(g), b"".join(h_a), b"".join(e_gh_ka), ctypes.byref(self.h)))
 
+    def set_g_window(self, w_bits):
+        """signed w_bits-wide windows for g (rhip_ac17_pk_set_g_window): fewer additions per row, more HBM"""
+        self.eng._check(self.eng.lib.rhip_ac17_pk_set_g_window(self.eng.ctx, self.h, ctypes.c_int32(int(w_bits))))
+
     def destroy(self):
         if self.h:
             self.eng.lib.rhip_ac17_pk_destroy(self.h)

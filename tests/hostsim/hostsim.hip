@@ -44,6 +44,13 @@ void hs_fp12_mul_by_line(const uint32_t* f, const uint32_t* l0, const uint32_t* 
 void hs_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   store_g1(out, jac_to_aff(jac_add_aff(aff_to_jac(load_g1(a)), load_g1(b))));
 }
+void hs_g1_madd_inl(const uint32_t* a, const uint32_t* b, const uint32_t* zscale, uint32_t* out) {
+  Fp z = load_fp(zscale);
+  G1Aff pa = load_g1(a);
+  Fp z2 = sqr(z);
+  G1Jac ja = aff_is_inf(pa) ? jac_inf<Fp>() : G1Jac{mul(pa.x, z2), mul(pa.y, mul(z2, z)), z};
+  store_g1(out, jac_to_aff(g1_madd_inl(ja, load_g1(b))));
+}
 void hs_g1_add_jac(const uint32_t* a, const uint32_t* b, const uint32_t* zscale, uint32_t* out) {
   // exercise the Jacobian+Jacobian path with non-trivial Z on both sides: scale (x,y,1) -> (x z^2, y z^3, z)
   Fp z = load_fp(zscale);
@@ -85,6 +92,17 @@ void hs_pairing_prepared(const uint32_t* p, const uint32_t* q, uint32_t* out) {
   LineCoeffs lines[RB_MILLER_LINES];
   g2_prepare_lines(Q, lines);
   store_gt(out, final_exponentiation(miller_loop_prepared(miller_p_from_aff(P), aff_is_inf(P), aff_is_inf(Q), HostLineLoad{lines})));
+}
+struct HostWs {
+  Fp12* slots;
+  Fp12 ld(int i) const { return slots[i]; }
+  void st(int i, const Fp12& v) const { slots[i] = v; }
+};
+void hs_final_exp_ws(const uint32_t* f, uint32_t* out) {
+  Fp12 slots[FE_SLOTS];
+  slots[FE_T0] = load_gt(f);
+  final_exponentiation_ws(HostWs{slots});
+  store_gt(out, slots[FE_T1]);
 }
 void hs_g2_prepare(const uint32_t* q, uint32_t* out /* first line, 48 words */) {
   LineCoeffs lines[RB_MILLER_LINES];

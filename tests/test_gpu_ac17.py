@@ -136,3 +136,34 @@ def test_cp_decrypt_roundtrip_and_reference(env, policy, lang, attrs):
                  "c": [(pi[r], [bn.g1_from_le(c[(r * 3 + l) * 64:(r * 3 + l + 1) * 64]) for l in range(3)]) for r in range(n_rows)],
                  "c_p": bn.gt_from_le(cp[:384])}}
     assert bn.gt_to_le(sch.ac17_cp_decrypt(sk, ct)) == out[:384]
+
+
+@pytest.mark.parametrize("w_bits", [17, 19, 22])
+def test_cp_encrypt_rows_with_wide_signed_windows(w_bits):
+    """signed w-bit fixed-base windows for g (rhip_ac17_pk_set_g_window): the same ciphertext bytes as the
+    16-bit tables, which the tests above pin to the oracle.  Scalars with extreme digits included."""
+    from rabe_amd import Engine
+    from rabe_amd import engine as E
+    eng = Engine(0)
+    rng = SeededRng(77 + w_bits)
+    pk, _msk = sch.ac17_setup(rng)
+    dpk = E.Ac17Pk(eng, bn.g1_to_le(pk["g"]), [bn.g2_to_le(x) for x in pk["h_a"]], [bn.gt_to_le(x) for x in pk["e_gh_ka"]])
+    policy, lang, _ = POLICIES[2]
+    e_gen = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    half = 1 << (w_bits - 1)
+    edge = [sum(half << (w_bits * i) for i in range(254 // w_bits)) % bn.R,             # every digit exactly 2^(w-1)
+            sum((half + 1) << (w_bits * i) for i in range(254 // w_bits)) % bn.R,       # every digit just above: all negative with carries
+            bn.R - 1, 1, (1 << 253) + 12345]
+    items = [(rng.fr(), rng.fr()) for _ in range(3)] + [(edge[i], edge[(i + 1) % len(edge)]) for i in range(len(edge))]
+    msgs = [bn.gt_pow(e_gen, rng.fr_nonzero()) for _ in items]
+    pi, c0, c, cp, _ = gpu_encrypt(eng, E, dpk, policy, lang, items, msgs)
+    dpk.set_g_window(w_bits)
+    pi2, c0w, cw, cpw, _ = gpu_encrypt(eng, E, dpk, policy, lang, items, msgs)
+    assert (pi2, c0w, cpw) == (pi, c0, cp)
+    assert cw == c
+    # and directly against the oracle for the first item
+    ct = sch.ac17_cp_encrypt(pk, policy, lang, ListRng(list(items[0])), msgs[0])
+    n_rows = len(pi)
+    assert cw[:n_rows * 192] == b"".join(bn.g1_to_le(p) for _, vec in ct["ct"]["c"] for p in vec)
+    dpk.destroy()
+    eng.close()

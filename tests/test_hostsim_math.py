@@ -116,6 +116,7 @@ def test_g1_g2_ops():
         p1, p2 = bn.g1_mul(bn.G1_GEN, k1), bn.g1_mul(bn.G1_GEN, k2)
         assert call("hs_g1_add", bn.g1_to_le(p1), bn.g1_to_le(p2), out=64) == bn.g1_to_le(bn.g1_add(p1, p2))
         assert call("hs_g1_add_jac", bn.g1_to_le(p1), bn.g1_to_le(p2), le(rand_fp()), out=64) == bn.g1_to_le(bn.g1_add(p1, p2))
+        assert call("hs_g1_madd_inl", bn.g1_to_le(p1), bn.g1_to_le(p2), le(rand_fp()), out=64) == bn.g1_to_le(bn.g1_add(p1, p2))
         assert call("hs_g1_mul", bn.g1_to_le(p1), le(k2), out=64) == bn.g1_to_le(bn.g1_mul(p1, k2))
         q1, q2 = bn.g2_mul(bn.G2_GEN, k1), bn.g2_mul(bn.G2_GEN, k2)
         assert call("hs_g2_add", bn.g2_to_le(q1), bn.g2_to_le(q2), out=128) == bn.g2_to_le(bn.g2_add(q1, q2))
@@ -127,6 +128,11 @@ def test_g1_g2_ops():
     assert call("hs_g1_add", bn.g1_to_le(p1), bytes(64), out=64) == bn.g1_to_le(p1)
     assert call("hs_g1_add", bytes(64), bn.g1_to_le(p1), out=64) == bn.g1_to_le(p1)
     assert call("hs_g1_add_jac", bn.g1_to_le(p1), bn.g1_to_le(p1), le(7), out=64) == bn.g1_to_le(bn.g1_mul(bn.G1_GEN, 10))
+    # the table kernels' expanded mixed addition: the same special cases
+    assert call("hs_g1_madd_inl", bn.g1_to_le(p1), bn.g1_to_le(p1), le(7), out=64) == bn.g1_to_le(bn.g1_mul(bn.G1_GEN, 10))
+    assert call("hs_g1_madd_inl", bn.g1_to_le(p1), bn.g1_to_le(bn.g1_neg(p1)), le(7), out=64) == bytes(64)
+    assert call("hs_g1_madd_inl", bn.g1_to_le(p1), bytes(64), le(7), out=64) == bn.g1_to_le(p1)
+    assert call("hs_g1_madd_inl", bytes(64), bn.g1_to_le(p1), le(7), out=64) == bn.g1_to_le(p1)
     assert call("hs_g1_mul", bn.g1_to_le(p1), le(0), out=64) == bytes(64)
     assert call("hs_g1_mul", bn.g1_to_le(p1), le(bn.R), out=64) == bytes(64)
     assert HS.hs_g1_on_curve(b2c(bn.g1_to_le(p1))) == 1
@@ -196,3 +202,10 @@ def test_paired_miller_loop():
     assert call("hs_pairing_pair", *enc(pa, qa), z64, bn.g2_to_le(qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
     assert call("hs_pairing_pair", *enc(pa, qa), bn.g1_to_le(pb), z128, out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
     assert call("hs_pairing_pair", z64, z128, z64, z128, out=384) == bn.gt_to_le(bn.GT_ONE)
+
+
+def test_final_exponentiation_over_workspace_slots():
+    k1, k2 = RND.randrange(1, bn.R), RND.randrange(1, bn.R)
+    p, q = bn.g1_mul(bn.G1_GEN, k1), bn.g2_mul(bn.G2_GEN, k2)
+    m = call("hs_miller", bn.g1_to_le(p), bn.g2_to_le(q), out=384)
+    assert call("hs_final_exp_ws", m, out=384) == call("hs_final_exp", m, out=384) == bn.gt_to_le(bn.pairing(p, q))
