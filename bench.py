@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # One hardware queue per in-flight batch (HIP's default is 4); must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
 G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
@@ -48,17 +48,17 @@ IMPL_FINAL_EXP_FPMUL = 8940
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="items per step per GPU")
     ap.add_argument("--attrs", type=int, default=50)
     ap.add_argument("--policies", type=int, default=16)
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=20,
                     help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
-    ap.add_argument("--g-window", type=int, default=16,
+    ap.add_argument("--g-window", type=int, default=26,
                     help="window width (bits) of the fixed-base table of g: 16 (67 MB), or 17..27 signed digits (24: 5.4 GB, 26: 19 GB)")
     ap.add_argument("--only-encrypt", action="store_true", help="diagnostic: skip the decrypt half of every step (value is then not the metric)")
     ap.add_argument("--no-prepared-sk", action="store_true",

@@ -219,6 +219,66 @@ RB_FN Fp12 miller_loop_pair(const MillerP& pa, bool skip_a, LOAD load, const Mil
   return f;
 }
 
+// The same paired loop with the loop-invariant / once-per-step values parked outside the register file.
+// The pairing kernels run one wave per SIMD with the whole 512-entry register file, and still the accumulator, the
+// G2 point, both P's, Q and the Fq12 temporaries do not fit; what the compiler spills goes to scratch (HBM-backed,
+// ~1 us per reload with nothing else on the SIMD to hide it).  With one wave per SIMD each wave also owns a quarter
+// of the CU's 160 KB LDS, so the values that are touched once per step -- P_A, P_B (scaled for Jacobian input),
+// Q_B and the running point T -- are parked there explicitly and fetched right where they are used.
+// PARK provides  Fp ld(int i) const  /  void st(int i, const Fp&) const  for i < PK_FPS.
+enum { PK_PA = 0, PK_PB = 3, PK_QB = 6, PK_T = 10, PK_FPS = 16 };
+template <class PARK> RB_HD Fp2 pk_ld2(PARK pk, int i) { return Fp2{pk.ld(i), pk.ld(i + 1)}; }
+template <class PARK> RB_HD void pk_st2(PARK pk, int i, const Fp2& a) { pk.st(i, a.c0); pk.st(i + 1, a.c1); }
+template <class PARK> RB_HD MillerP pk_ld_p(PARK pk, int i) { return MillerP{pk.ld(i), pk.ld(i + 1), pk.ld(i + 2), true}; }
+template <class PARK> RB_HD void pk_st_p(PARK pk, int i, const MillerP& p) { pk.st(i, p.px); pk.st(i + 1, p.py); pk.st(i + 2, p.pz3); }
+template <class PARK> RB_HD G2Hom pk_ld_t(PARK pk) { return G2Hom{pk_ld2(pk, PK_T), pk_ld2(pk, PK_T + 2), pk_ld2(pk, PK_T + 4)}; }
+template <class PARK> RB_HD void pk_st_t(PARK pk, const G2Hom& t) { pk_st2(pk, PK_T, t.x); pk_st2(pk, PK_T + 2, t.y); pk_st2(pk, PK_T + 4, t.z); }
+// caller parks P_A at PK_PA, P_B at PK_PB (pk_st_p) and Q_B at PK_QB (x, y); skip_b must already include Q_B = infinity
+template <class LOAD, class PARK>
+RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b) {
+  Fp12 f = fp12_one();
+  pk_st_t(pk, G2Hom{pk_ld2(pk, PK_QB), pk_ld2(pk, PK_QB + 2), fp2_one()});
+  int n = 0;
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    f = fp12_sqr(f);
+    if (!skip_a) f = ell(f, load(n), pk_ld_p(pk, PK_PA));
+    n++;
+    if (!skip_b) {
+      G2Hom t = pk_ld_t(pk);
+      LineCoeffs l = g2hom_double(t);
+      pk_st_t(pk, t);
+      f = ell(f, l, pk_ld_p(pk, PK_PB));
+    }
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) {
+      if (!skip_a) f = ell(f, load(n), pk_ld_p(pk, PK_PA));
+      n++;
+      if (!skip_b) {
+        G2Hom t = pk_ld_t(pk);
+        G2Aff q{pk_ld2(pk, PK_QB), pk_ld2(pk, PK_QB + 2)};
+        if (ngt) q.y = fp2_neg(q.y);
+        LineCoeffs la = g2hom_add(t, q);
+        pk_st_t(pk, t);
+        f = ell(f, la, pk_ld_p(pk, PK_PB));
+      }
+    }
+  }
+  if (!skip_a) {
+    f = ell(f, load(n), pk_ld_p(pk, PK_PA));
+    f = ell(f, load(n + 1), pk_ld_p(pk, PK_PA));
+  }
+  if (!skip_b) {
+    G2Hom t = pk_ld_t(pk);
+    const G2Aff qb{pk_ld2(pk, PK_QB), pk_ld2(pk, PK_QB + 2)};
+    LineCoeffs l1 = g2hom_add(t, g2_frob1(qb));
+    f = ell(f, l1, pk_ld_p(pk, PK_PB));
+    LineCoeffs l2 = g2hom_add(t, aff_neg(g2_frob2(qb)));
+    f = ell(f, l2, pk_ld_p(pk, PK_PB));
+  }
+  return f;
+}
+
 // f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).
 RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {
   Fp12 acc = f;   // top bit (bit 62)

@@ -1059,6 +1059,22 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_g2_prepare_lines(size_t n,
   put(g2hom_add(T, g2_frob1(Q)));
   put(g2hom_add(T, aff_neg(g2_frob2(Q))));
 }
+// LDS parking space of the paired Miller loop (bn254/pairing.h: miller_loop_pair_parked): Fp i of this lane =
+// quads 2i, 2i+1 of column `lane`; consecutive lanes are 16 bytes apart, so ds_read_b128 / ds_write_b128 run conflict-free.
+struct LdsPark {
+  uint4* col;
+  __device__ __forceinline__ Fp ld(int i) const {
+    const uint4 q0 = col[(2 * i) * 64], q1 = col[(2 * i + 1) * 64];
+    Fp r;
+    r.v[0] = q0.x; r.v[1] = q0.y; r.v[2] = q0.z; r.v[3] = q0.w;
+    r.v[4] = q1.x; r.v[5] = q1.y; r.v[6] = q1.z; r.v[7] = q1.w;
+    return r;
+  }
+  __device__ __forceinline__ void st(int i, const Fp& a) const {
+    col[(2 * i) * 64] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    col[(2 * i + 1) * 64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+  }
+};
 // decrypt with a prepared key: one lane per (item, j < 3) runs BOTH pairings of index j on one accumulator
 //   A: P = sum_{x in ct_sel} C[x][j],                 Q = k_0[j]   (prepared lines)
 //   B: P = -(k_p[j] + sum_{x in sk_sel} K[x][j]),     Q = c_0[j]
@@ -1068,6 +1084,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller2(size_t n_
                                                                       const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp,
                                                                       const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,
                                                                       const uint32_t* sk_sel, const uint32_t* sk_sel_off, GtM* mill) {
+  __shared__ uint4 park[2 * PK_FPS][64];   // 32 KB: the block is one wave and owns a quarter of the CU's LDS
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * 3) return;
   const size_t item = t / 3;
@@ -1089,7 +1106,13 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_dec_miller2(size_t n_
   const size_t lj = (size_t)sk * 3 + j;
   const bool skip_a = jac_is_inf(pa) || sk_qinf[lj];
   const G2Aff QB = load_g2(ct_c0[item * 3 + j].l);
-  Fp12 f = miller_loop_pair(miller_p_from_jac(pa), skip_a, DevLineLoad{sk_lines + lj * RB_MILLER_LINES}, miller_p_from_jac(pb), jac_is_inf(pb), QB);
+  const bool skip_b = jac_is_inf(pb) || aff_is_inf(QB);
+  const LdsPark pk{&park[0][threadIdx.x]};
+  pk_st_p(pk, PK_PA, miller_p_from_jac(pa));
+  pk_st_p(pk, PK_PB, miller_p_from_jac(pb));
+  pk_st2(pk, PK_QB, QB.x);
+  pk_st2(pk, PK_QB + 2, QB.y);
+  Fp12 f = miller_loop_pair_parked(pk, skip_a, DevLineLoad{sk_lines + lj * RB_MILLER_LINES}, skip_b);
   st_gt_m(mill + t, f);
 }
 

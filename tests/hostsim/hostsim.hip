@@ -122,6 +122,30 @@ void hs_pairing_pair(const uint32_t* pa, const uint32_t* qa, const uint32_t* pb,
   store_gt(out, final_exponentiation(miller_loop_pair(miller_p_from_aff(PA), aff_is_inf(PA) || aff_is_inf(QA), HostLineLoad{lines},
                                                       miller_p_from_jac(JB), jac_is_inf(JB), QB)));
 }
+struct HostPark {
+  Fp* a;
+  Fp ld(int i) const { return a[i]; }
+  void st(int i, const Fp& v) const { a[i] = v; }
+};
+// the parked form of hs_pairing_pair (both P's enter Jacobian-scaled)
+void hs_pairing_pair_parked(const uint32_t* pa, const uint32_t* qa, const uint32_t* pb, const uint32_t* qb, uint32_t* out) {
+  G1Aff PA = load_g1(pa), PB = load_g1(pb);
+  G2Aff QA = load_g2(qa), QB = load_g2(qb);
+  LineCoeffs lines[RB_MILLER_LINES];
+  g2_prepare_lines(QA, lines);
+  Fp z = add(add(one<FpParams>(), one<FpParams>()), one<FpParams>());
+  Fp z2 = sqr(z);
+  G1Jac JA{mul(PA.x, z2), mul(PA.y, mul(z2, z)), aff_is_inf(PA) ? zero<FpParams>() : z};
+  G1Jac JB{mul(PB.x, z2), mul(PB.y, mul(z2, z)), aff_is_inf(PB) ? zero<FpParams>() : z};
+  Fp park[PK_FPS];
+  HostPark pk{park};
+  pk_st_p(pk, PK_PA, miller_p_from_jac(JA));
+  pk_st_p(pk, PK_PB, miller_p_from_jac(JB));
+  pk_st2(pk, PK_QB, QB.x);
+  pk_st2(pk, PK_QB + 2, QB.y);
+  store_gt(out, final_exponentiation(miller_loop_pair_parked(pk, jac_is_inf(JA) || aff_is_inf(QA), HostLineLoad{lines},
+                                                             jac_is_inf(JB) || aff_is_inf(QB))));
+}
 void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
 
 

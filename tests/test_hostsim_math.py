@@ -189,19 +189,20 @@ def test_prepared_g2_pairing():
     assert call("hs_pairing_prepared", bn.g1_to_le(p), bytes(128), out=384) == bn.gt_to_le(bn.GT_ONE)
 
 
-def test_paired_miller_loop():
+@pytest.mark.parametrize("fn", ["hs_pairing_pair", "hs_pairing_pair_parked"])
+def test_paired_miller_loop(fn):
     ks = [RND.randrange(1, bn.R) for _ in range(4)]
     pa, pb = bn.g1_mul(bn.G1_GEN, ks[0]), bn.g1_mul(bn.G1_GEN, ks[2])
     qa, qb = bn.g2_mul(bn.G2_GEN, ks[1]), bn.g2_mul(bn.G2_GEN, ks[3])
     e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
     z64, z128 = bytes(64), bytes(128)
     enc = lambda p, q: (bn.g1_to_le(p), bn.g2_to_le(q))
-    assert call("hs_pairing_pair", *enc(pa, qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, (ks[0] * ks[1] + ks[2] * ks[3]) % bn.R))
-    assert call("hs_pairing_pair", z64, bn.g2_to_le(qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
-    assert call("hs_pairing_pair", bn.g1_to_le(pa), z128, *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
-    assert call("hs_pairing_pair", *enc(pa, qa), z64, bn.g2_to_le(qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
-    assert call("hs_pairing_pair", *enc(pa, qa), bn.g1_to_le(pb), z128, out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
-    assert call("hs_pairing_pair", z64, z128, z64, z128, out=384) == bn.gt_to_le(bn.GT_ONE)
+    assert call(fn, *enc(pa, qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, (ks[0] * ks[1] + ks[2] * ks[3]) % bn.R))
+    assert call(fn, z64, bn.g2_to_le(qa), *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
+    assert call(fn, bn.g1_to_le(pa), z128, *enc(pb, qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[2] * ks[3] % bn.R))
+    assert call(fn, *enc(pa, qa), z64, bn.g2_to_le(qb), out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
+    assert call(fn, *enc(pa, qa), bn.g1_to_le(pb), z128, out=384) == bn.gt_to_le(bn.gt_pow(e, ks[0] * ks[1] % bn.R))
+    assert call(fn, z64, z128, z64, z128, out=384) == bn.gt_to_le(bn.GT_ONE)
 
 
 def test_final_exponentiation_over_workspace_slots():

@@ -13,7 +13,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r["Kernel_Name"].split("(")[0]
         if r["Counter_Name"] == c:
             agg[k] += float(r["Counter_Value"]); cnt[k] += 1
-    for k in ("k_ac17_dec_miller", "k_final_exp", "k_ac17_enc_rows", "k_ac17_enc_cp", "k_ac17_enc_c0"):
+    for k in ("k_ac17_dec_miller2", "k_ac17_dec_miller", "k_final_exp", "k_ac17_enc_rows", "k_ac17_enc_cp", "k_ac17_enc_c0"):
         if cnt[k]:
             print("%s %s per launch: %.1f KB-units (x1024 B = %.2f MB)" % (c, k, agg[k] / cnt[k], agg[k] / cnt[k] * 1024 / 1e6))
 PY
