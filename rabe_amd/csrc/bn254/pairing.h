@@ -99,6 +99,17 @@ RB_MID Fp12 ell(const Fp12& f, const LineCoeffs& l, const MillerP& p) {
   return fp12_mul_by_line(f, l0, l1, l3);
 }
 
+// f * line_A(P_A) * line_B(P_B)
+RB_MID Fp12 ell2(const Fp12& f, const LineCoeffs& la, const MillerP& pa, const LineCoeffs& lb, const MillerP& pb) {
+  Fp2 a0 = fp2_mul_fp(la.cy, pa.py);
+  Fp2 a1 = fp2_mul_fp(la.cx, pa.px);
+  Fp2 a3 = pa.scaled ? fp2_mul_fp(la.c0, pa.pz3) : la.c0;
+  Fp2 b0 = fp2_mul_fp(lb.cy, pb.py);
+  Fp2 b1 = fp2_mul_fp(lb.cx, pb.px);
+  Fp2 b3 = pb.scaled ? fp2_mul_fp(lb.c0, pb.pz3) : lb.c0;
+  return fp12_mul_by_two_lines(f, a0, a1, a3, b0, b1, b3);
+}
+
 // Miller loop.  Either argument at infinity gives 1 (as `pairing` does for zero inputs).
 RB_FN Fp12 miller_loop(const MillerP& p, bool p_is_inf, const G2Aff& q) {
   Fp12 f = fp12_one();
@@ -238,30 +249,39 @@ template <class LOAD, class PARK>
 RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b) {
   Fp12 f = fp12_one();
   pk_st_t(pk, G2Hom{pk_ld2(pk, PK_QB), pk_ld2(pk, PK_QB + 2), fp2_one()});
+  const bool both = !skip_a && !skip_b;
   int n = 0;
   for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
     f = fp12_sqr(f);
-    if (!skip_a) f = ell(f, load(n), pk_ld_p(pk, PK_PA));
-    n++;
-    if (!skip_b) {
+    if (both) {
+      G2Hom t = pk_ld_t(pk);
+      LineCoeffs l = g2hom_double(t);
+      pk_st_t(pk, t);
+      f = ell2(f, load(n), pk_ld_p(pk, PK_PA), l, pk_ld_p(pk, PK_PB));
+    } else if (!skip_a) {
+      f = ell(f, load(n), pk_ld_p(pk, PK_PA));
+    } else if (!skip_b) {
       G2Hom t = pk_ld_t(pk);
       LineCoeffs l = g2hom_double(t);
       pk_st_t(pk, t);
       f = ell(f, l, pk_ld_p(pk, PK_PB));
     }
+    n++;
     const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
     const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
     if (pos | ngt) {
-      if (!skip_a) f = ell(f, load(n), pk_ld_p(pk, PK_PA));
-      n++;
+      LineCoeffs lb;
       if (!skip_b) {
         G2Hom t = pk_ld_t(pk);
         G2Aff q{pk_ld2(pk, PK_QB), pk_ld2(pk, PK_QB + 2)};
         if (ngt) q.y = fp2_neg(q.y);
-        LineCoeffs la = g2hom_add(t, q);
+        lb = g2hom_add(t, q);
         pk_st_t(pk, t);
-        f = ell(f, la, pk_ld_p(pk, PK_PB));
       }
+      if (both) f = ell2(f, load(n), pk_ld_p(pk, PK_PA), lb, pk_ld_p(pk, PK_PB));
+      else if (!skip_a) f = ell(f, load(n), pk_ld_p(pk, PK_PA));
+      else if (!skip_b) f = ell(f, lb, pk_ld_p(pk, PK_PB));
+      n++;
     }
   }
   if (!skip_a) {

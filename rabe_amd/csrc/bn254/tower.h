@@ -187,6 +187,26 @@ RB_MID Fp12 fp12_mul_by_line(const Fp12& f, const Fp2& l0, const Fp2& l1, const 
   return r;
 }
 
+// f * (a0 + a1 w + a3 w^3) * (b0 + b1 w + b3 w^3): the two sparse lines are multiplied first (6 Fp2 products, the
+// result has c1.a2 = 0), then one 17-product multiplication -- 23 instead of 2 x 13.
+//   lineA * lineB = (a0b0 + xi a3b3, a1b1, a1b3 + a3b1) + (a0b1 + a1b0, a0b3 + a3b0, 0) w
+RB_MID Fp12 fp12_mul_by_two_lines(const Fp12& f, const Fp2& a0, const Fp2& a1, const Fp2& a3, const Fp2& b0, const Fp2& b1, const Fp2& b3) {
+  Fp2 m00 = fp2_mul(a0, b0);
+  Fp2 m11 = fp2_mul(a1, b1);
+  Fp2 m33 = fp2_mul(a3, b3);
+  Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a1), fp2_add(b0, b1)), m00), m11);
+  Fp2 x03 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a3), fp2_add(b0, b3)), m00), m33);
+  Fp2 x13 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a1, a3), fp2_add(b1, b3)), m11), m33);
+  Fp6 p0{fp2_add(m00, fp2_mul_xi(m33)), m11, x13};
+  Fp6 t0 = fp6_mul(f.c0, p0);
+  Fp6 t1 = fp6_mul_by_01(f.c1, x01, x03);
+  Fp6 t2 = fp6_mul(fp6_add(f.c0, f.c1), Fp6{fp2_add(p0.a0, x01), fp2_add(p0.a1, x03), p0.a2});
+  Fp12 r;
+  r.c0 = fp6_add(t0, fp6_mul_v(t1));
+  r.c1 = fp6_sub(fp6_sub(t2, t0), t1);
+  return r;
+}
+
 // ---------------------------------------------------------------------------- Frobenius
 #define RB_FP_CONST(name, ...)                          \
   RB_HD Fp name() {                                    \
