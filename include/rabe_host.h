@@ -66,6 +66,12 @@ int32_t rabe_bsw_delegate(rabe_host* h, const void* pk, const void* sk, const ch
 int32_t rabe_bsw_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct);
 int32_t rabe_bsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_bsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* n independent encrypt / decrypt calls, the group work of all items in one launch per operation type
+ * (BASELINE config 3); conventions as rabe_ac17_cp_{encrypt,decrypt}_batch */
+int32_t rabe_bsw_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* policies, int32_t language,
+                               const uint8_t* const* plaintexts, const size_t* lens, void** cts);
+int32_t rabe_bsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                               uint8_t** plaintexts, size_t* lens);
 
 /* ---- lsw (src/schemes/lsw/mod.rs:86-290) */
 int32_t rabe_lsw_setup(rabe_host* h, void** pk, void** msk);
@@ -73,6 +79,10 @@ int32_t rabe_lsw_keygen(rabe_host* h, const void* pk, const void* msk, const cha
 int32_t rabe_lsw_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* plaintext, size_t len, void** ct);
 int32_t rabe_lsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_lsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* BASELINE config 4: n keygen / decrypt calls in one launch set */
+int32_t rabe_lsw_keygen_batch(rabe_host* h, const void* pk, const void* msk, size_t n, const char* const* policies, int32_t language, void** sks);
+int32_t rabe_lsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                               uint8_t** plaintexts, size_t* lens);
 
 /* ---- aw11 (src/schemes/aw11/mod.rs:100-390) */
 int32_t rabe_aw11_setup(rabe_host* h, void** gk);
@@ -83,6 +93,11 @@ int32_t rabe_aw11_encrypt(rabe_host* h, const void* gk, const void* const* pks, 
                           const uint8_t* data, size_t len, void** ct);
 int32_t rabe_aw11_decrypt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_aw11_decrypt_gt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* BASELINE config 5: n encrypt / decrypt calls in one launch set (all items encrypt under the same authority keys) */
+int32_t rabe_aw11_encrypt_batch(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, size_t n, const char* const* policies,
+                                int32_t language, const uint8_t* const* datas, const size_t* lens, void** cts);
+int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                                uint8_t** plaintexts, size_t* lens);
 
 /* ---- host-only policy utilities (no GPU needed): results as small JSON texts, free with rabe_bytes_free.
  *   rabe_policy_parse      -> serialize_policy(parse(policy, language), out_language)       pest/mod.rs:40-114

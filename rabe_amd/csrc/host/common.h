@@ -121,6 +121,7 @@ class Engine {
   G2 random_g2(Rng& rng) { return g2_mul({g2_generator()}, {rng.next_fr()})[0]; }
   // `rng.gen::<Gt>()`: e(G1::one(), G2::one()) ^ Fr::random
   Gt random_gt(Rng& rng);
+  const Gt& gt_generator();     // e(G1::one(), G2::one()), computed once
 
  private:
   rhip_ctx* ctx_ = nullptr;

@@ -149,6 +149,22 @@ static int32_t give_bytes(const Bytes& b, uint8_t** out, size_t* len) {
   *len = b.size();
   return 0;
 }
+
+template <class R>
+static void give_results(rabe_host* h, const std::vector<R>& r, int32_t* status, uint8_t** plaintexts, size_t* lens) {
+  for (size_t i = 0; i < r.size(); i++) {
+    status[i] = r[i].ok ? 0 : -1;
+    plaintexts[i] = nullptr;
+    lens[i] = 0;
+    if (r[i].ok) give_bytes(r[i].plaintext, &plaintexts[i], &lens[i]);
+    else set_err(h, r[i].error);
+  }
+}
+static std::vector<Bytes> byte_items(const uint8_t* const* data, const size_t* lens, size_t n) {
+  std::vector<Bytes> v;
+  for (size_t i = 0; i < n; i++) v.push_back(Bytes(data[i], data[i] + lens[i]));
+  return v;
+}
 static int32_t give_text(const std::string& s, char** out) {
   *out = (char*)malloc(s.size() + 1);
   if (!*out) return -1;
@@ -353,6 +369,25 @@ int32_t rabe_bsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_
   GUARD_END(h)
 }
 
+int32_t rabe_bsw_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* policies, int32_t language,
+                               const uint8_t* const* plaintexts, const size_t* lens, void** cts) {
+  GUARD_BEGIN
+  auto r = bsw::encrypt_batch(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, strs(policies, n), lang_of(language), byte_items(plaintexts, lens, n));
+  for (size_t i = 0; i < n; i++) cts[i] = new bsw::CpAbeCiphertext(r[i]);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                               size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const bsw::CpAbeSecretKey*> s;
+  std::vector<const bsw::CpAbeCiphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const bsw::CpAbeSecretKey*)sks[i]); c.push_back((const bsw::CpAbeCiphertext*)cts[i]); }
+  give_results(h, bsw::decrypt_batch(h->eng, s, c), status, plaintexts, lens);
+  return 0;
+  GUARD_END(h)
+}
+
 // ---------------------------------------------------------------- lsw
 int32_t rabe_lsw_setup(rabe_host* h, void** pk, void** msk) {
   GUARD_BEGIN
@@ -383,6 +418,24 @@ int32_t rabe_lsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_
   GUARD_BEGIN
   Gt g = lsw::decrypt_gt(h->eng, *(const lsw::KpAbeSecretKey*)sk, *(const lsw::KpAbeCiphertext*)ct);
   memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
+int32_t rabe_lsw_keygen_batch(rabe_host* h, const void* pk, const void* msk, size_t n, const char* const* policies, int32_t language, void** sks) {
+  GUARD_BEGIN
+  auto r = lsw::keygen_batch(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, *(const lsw::KpAbeMasterKey*)msk, strs(policies, n), lang_of(language));
+  for (size_t i = 0; i < n; i++) sks[i] = new lsw::KpAbeSecretKey(r[i]);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                               size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const lsw::KpAbeSecretKey*> s;
+  std::vector<const lsw::KpAbeCiphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const lsw::KpAbeSecretKey*)sks[i]); c.push_back((const lsw::KpAbeCiphertext*)cts[i]); }
+  give_results(h, lsw::decrypt_batch(h->eng, s, c), status, plaintexts, lens);
   return 0;
   GUARD_END(h)
 }
@@ -434,6 +487,27 @@ int32_t rabe_aw11_decrypt_gt(rabe_host* h, const void* gk, const void* sk, const
   GUARD_BEGIN
   Gt g = aw11::decrypt_gt(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, *(const aw11::Aw11Ciphertext*)ct);
   memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+
+int32_t rabe_aw11_encrypt_batch(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, size_t n, const char* const* policies,
+                                int32_t language, const uint8_t* const* datas, const size_t* lens, void** cts) {
+  GUARD_BEGIN
+  std::vector<const aw11::Aw11PublicKey*> v;
+  for (size_t i = 0; i < n_pks; i++) v.push_back((const aw11::Aw11PublicKey*)pks[i]);
+  auto r = aw11::encrypt_batch(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, v, strs(policies, n), lang_of(language), byte_items(datas, lens, n));
+  for (size_t i = 0; i < n; i++) cts[i] = new aw11::Aw11Ciphertext(r[i]);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                                uint8_t** plaintexts, size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const aw11::Aw11SecretKey*> s;
+  std::vector<const aw11::Aw11Ciphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const aw11::Aw11SecretKey*)sks[i]); c.push_back((const aw11::Aw11Ciphertext*)cts[i]); }
+  give_results(h, aw11::decrypt_batch(h->eng, *(const aw11::Aw11GlobalKey*)gk, s, c), status, plaintexts, lens);
   return 0;
   GUARD_END(h)
 }

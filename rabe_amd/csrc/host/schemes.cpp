@@ -88,9 +88,13 @@ std::vector<Gt> Engine::pairing(const std::vector<G1>& p, const std::vector<G2>&
   check(rhip_pairing(ctx_, n, dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()), "rhip_pairing");
   return fetch<384>(out, n);
 }
-Gt Engine::random_gt(Rng& rng) {
+const Gt& Engine::gt_generator() {
   if (!have_e_) { e_gen_ = pairing({g1_generator()}, {g2_generator()})[0]; have_e_ = true; }
-  return gt_pow({e_gen_}, {rng.next_fr()})[0];
+  return e_gen_;
+}
+Gt Engine::random_gt(Rng& rng) {
+  Gt g = gt_generator();
+  return gt_pow({g}, {rng.next_fr()})[0];
 }
 
 // small helpers over Level E used by the schemes below
@@ -107,21 +111,6 @@ static std::vector<G1> g1_add(Engine& e, const std::vector<G1>& a, const std::ve
   DBuf da(&e, fa.data(), fa.size()), db(&e, fb.data(), fb.size()), out(&e, n * 64);
   e.check(rhip_g1_add(e.ctx(), n, da.as<rhip_g1>(), db.as<rhip_g1>(), out.as<rhip_g1>()), "rhip_g1_add");
   return fetch<64>(out, n);
-}
-// prod_j e(p_j, q_j) with ONE final exponentiation
-static Gt pairing_product(Engine& e, const std::vector<G1>& p, const std::vector<G2>& q) {
-  uint32_t off[2] = {0, (uint32_t)p.size()};
-  auto fp = flatten(p); auto fq = flatten(q);
-  DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off, sizeof off), out(&e, 384);
-  e.check(rhip_pairing_product(e.ctx(), 1, doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()),
-          "rhip_pairing_product");
-  return fetch<384>(out, 1)[0];
-}
-static Gt gt_product(Engine& e, const std::vector<Gt>& v) {
-  if (v.empty()) { Gt one{}; one[0] = 1; return one; }
-  Gt acc = v[0];
-  for (size_t i = 1; i < v.size(); i++) acc = e.gt_mul({acc}, {v[i]})[0];
-  return acc;
 }
 static Fr must_inv(const Fr& a) {
   Fr o;
@@ -144,6 +133,94 @@ static Bytes open_or_error(const Gt& msg, const Bytes& ct) {               // de
   Bytes out;
   if (!decrypt_symmetric(msg.data(), ct.data(), ct.size(), &out)) throw RabeError("decryption error: aead::Error");
   return out;
+}
+
+// ---- batched decryption tail shared by bsw / lsw / aw11: item i yields
+//   lead_i * prod_j gbase_ij^gexp_ij * FE( prod_j ML(scal_ij * base_ij, q_ij) )
+// with ONE g1_mul, ONE pairing-product launch (one final exponentiation per item) and ONE gt_pow for the whole batch.
+struct PairingJob {
+  std::vector<G1> base;
+  std::vector<Fr> scal;
+  std::vector<G2> q;
+  std::vector<Gt> gbase;
+  std::vector<Fr> gexp;
+  Gt lead;
+  bool failed = false;
+  std::string error;
+};
+static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>& jobs) {
+  std::vector<size_t> live;
+  for (size_t i = 0; i < jobs.size(); i++) if (!jobs[i].failed) live.push_back(i);
+  std::vector<Gt> out(jobs.size());
+  if (live.empty()) return out;
+  std::vector<G1> base;
+  std::vector<Fr> scal;
+  std::vector<G2> q;
+  std::vector<Gt> gb;
+  std::vector<Fr> gk;
+  std::vector<uint32_t> off{0};
+  for (size_t i : live) {
+    const PairingJob& j = jobs[i];
+    base.insert(base.end(), j.base.begin(), j.base.end());
+    scal.insert(scal.end(), j.scal.begin(), j.scal.end());
+    q.insert(q.end(), j.q.begin(), j.q.end());
+    gb.insert(gb.end(), j.gbase.begin(), j.gbase.end());
+    gk.insert(gk.end(), j.gexp.begin(), j.gexp.end());
+    off.push_back((uint32_t)base.size());
+  }
+  std::vector<Gt> acc(live.size());
+  for (size_t t = 0; t < live.size(); t++) acc[t] = jobs[live[t]].lead;
+  if (!base.empty()) {
+    std::vector<G1> p = e.g1_mul(base, scal);
+    auto fp = flatten(p); auto fq = flatten(q);
+    DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off.data(), off.size() * 4), dout(&e, live.size() * 384);
+    e.check(rhip_pairing_product(e.ctx(), live.size(), doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), dout.as<rhip_gt>()),
+            "rhip_pairing_product");
+    acc = e.gt_mul(acc, fetch<384>(dout, live.size()));
+  }
+  if (!gb.empty()) {
+    std::vector<Gt> pw = e.gt_pow(gb, gk);
+    // fold each item's factors: round r multiplies the r-th factor of every item that still has one
+    std::vector<size_t> start(live.size());
+    size_t pos = 0, rounds = 0;
+    for (size_t t = 0; t < live.size(); t++) { start[t] = pos; pos += jobs[live[t]].gbase.size(); rounds = std::max(rounds, jobs[live[t]].gbase.size()); }
+    for (size_t r = 0; r < rounds; r++) {
+      std::vector<Gt> a, b;
+      std::vector<size_t> who;
+      for (size_t t = 0; t < live.size(); t++)
+        if (r < jobs[live[t]].gbase.size()) { a.push_back(acc[t]); b.push_back(pw[start[t] + r]); who.push_back(t); }
+      std::vector<Gt> m = e.gt_mul(a, b);
+      for (size_t x = 0; x < who.size(); x++) acc[who[x]] = m[x];
+    }
+  }
+  for (size_t t = 0; t < live.size(); t++) out[live[t]] = acc[t];
+  return out;
+}
+static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vector<PairingJob>& jobs, const std::vector<const Bytes*>& sealed) {
+  std::vector<Gt> gts = run_pairing_jobs(e, jobs);
+  std::vector<schemes::DecryptResult> out(jobs.size());
+  for (size_t i = 0; i < jobs.size(); i++) {
+    if (jobs[i].failed) { out[i] = {false, {}, jobs[i].error}; continue; }
+    Bytes pt;
+    if (decrypt_symmetric(gts[i].data(), sealed[i]->data(), sealed[i]->size(), &pt)) out[i] = {true, pt, ""};
+    else out[i] = {false, {}, "decryption error: aead::Error"};
+  }
+  return out;
+}
+// plan(i, &job) fills job i or throws RabeError (-> that item fails); panics (std::runtime_error) propagate like the reference's
+template <class PLAN>
+static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
+  std::vector<PairingJob> jobs(n);
+  for (size_t i = 0; i < n; i++) {
+    try {
+      plan(i, &jobs[i]);
+    } catch (const RabeError& ex) {
+      jobs[i] = PairingJob();
+      jobs[i].failed = true;
+      jobs[i].error = ex.what();
+    }
+  }
+  return jobs;
 }
 
 namespace schemes {
@@ -580,7 +657,7 @@ CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const s
   ct.data = seal(rng, msg, plaintext);
   return ct;
 }
-Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) {       // :260-308
+static void plan_decrypt(const CpAbeSecretKey& sk, const CpAbeCiphertext& ct, PairingJob* job) {       // :260-308
   std::vector<std::string> attr;
   for (const auto& v : sk.d_j) attr.push_back(v.string);
   PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
@@ -591,9 +668,10 @@ Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) 
   calc_coefficients(tree, fr_one(), &z);
   // msg = c_p * A / e(c, d),  A = prod ( e(Cy.g1, Dj.g2) / e(Dj.g1, Cy.g2) )^z
   //     = c_p * FE( ML(-c, d) * prod ML(z Cy.g1, Dj.g2) ML(-z Dj.g1, Cy.g2) )        
-  std::vector<G1> base;
-  std::vector<Fr> scal;
-  std::vector<G2> q;
+  std::vector<G1>& base = job->base;
+  std::vector<Fr>& scal = job->scal;
+  std::vector<G2>& q = job->q;
+  job->lead = ct.c_p;
   base.push_back(ct.c); scal.push_back(fr_neg(fr_one())); q.push_back(sk.d);
   for (const auto& pr : pruned) {
     const CpAbeAttribute* cy = nullptr;
@@ -609,11 +687,64 @@ Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) 
       }
     }
   }
-  std::vector<G1> p = eng.g1_mul(base, scal);
-  Gt prod = pairing_product(eng, p, q);
-  return eng.gt_mul({ct.c_p}, {prod})[0];
+}
+Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) {
+  std::vector<PairingJob> jobs(1);
+  plan_decrypt(sk, ct, &jobs[0]);
+  return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.data); }
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const CpAbeSecretKey*>& sks, const std::vector<const CpAbeCiphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(*sks[i], *cts[i], j); });
+  std::vector<const Bytes*> sealed;
+  for (const auto* c : cts) sealed.push_back(&c->data);
+  return open_jobs(eng, jobs, sealed);
+}
+std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies,
+                                           PolicyLanguage language, const std::vector<Bytes>& plaintexts) {
+  if (policies.size() != plaintexts.size()) throw RabeError("encrypt_batch: policies and plaintexts differ in length");
+  const size_t n = policies.size();
+  std::vector<CpAbeCiphertext> cts(n);
+  // plan: every draw of item i before any draw of item i+1, in encrypt's order (secret, msg, gate coefficients, nonce)
+  struct Item { NamedFr shares; std::array<uint8_t, 12> nonce; size_t o1, o2; };
+  std::vector<Item> items(n);
+  std::vector<G1> b1; std::vector<Fr> k1;
+  std::vector<G2> b2; std::vector<Fr> k2;
+  std::vector<Gt> bt; std::vector<Fr> kt;
+  for (size_t i = 0; i < n; i++) {
+    Fr secret = rng.next_fr();
+    Fr msg_k = rng.next_fr();
+    PolicyNode tree = parse_or_error(policies[i], language);
+    gen_shares_policy(secret, tree, rng, &items[i].shares);
+    rng.fill(items[i].nonce.data(), 12);
+    cts[i].policy = {policies[i], language};
+    items[i].o1 = b1.size();
+    items[i].o2 = b2.size();
+    b1.push_back(pk.h); k1.push_back(secret);
+    bt.push_back(pk.e_gg_alpha); kt.push_back(secret);
+    bt.push_back(eng.gt_generator()); kt.push_back(msg_k);
+    for (const auto& sh : items[i].shares) {
+      b1.push_back(pk.g1); k1.push_back(sh.second);
+      b2.push_back(pk.g2); k2.push_back(fr_mul(sha3_hash_fr(remove_index(sh.first)), sh.second));
+    }
+  }
+  if (!n) return cts;
+  std::vector<G1> r1 = eng.g1_mul(b1, k1);
+  std::vector<G2> r2 = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
+  std::vector<Gt> rt = eng.gt_pow(bt, kt);
+  std::vector<Gt> ea, msg;
+  for (size_t i = 0; i < n; i++) { ea.push_back(rt[2 * i]); msg.push_back(rt[2 * i + 1]); }
+  std::vector<Gt> cp = eng.gt_mul(ea, msg);
+  for (size_t i = 0; i < n; i++) {
+    cts[i].c = r1[items[i].o1];
+    cts[i].c_p = cp[i];
+    for (size_t y = 0; y < items[i].shares.size(); y++)
+      cts[i].c_y.push_back({items[i].shares[y].first, r1[items[i].o1 + 1 + y], r2[items[i].o2 + y]});
+    cts[i].data = encrypt_symmetric(msg[i].data(), plaintexts[i].data(), plaintexts[i].size(), items[i].nonce.data());
+  }
+  return cts;
+}
 }  // namespace bsw
 
 // ================================================================================================ LSW
@@ -631,54 +762,68 @@ std::pair<KpAbePublicKey, KpAbeMasterKey> setup(Engine& eng, Rng& rng) {        
 }
 static G1 g1_zero() { G1 z{}; return z; }
 static G2 g2_zero() { G2 z{}; return z; }
-KpAbeSecretKey keygen(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::string& policy,
-                      PolicyLanguage language) {        // :121-170
-  PolicyNode tree = parse_or_error(policy, language);
-  NamedFr shares;
-  gen_shares_policy(msk.alpha1, tree, rng, &shares);
-  KpAbeSecretKey sk;
-  sk.policy = {policy, language};
-  // one `random` per share, in share order (drawn inside the loop at :136)
+std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk,
+                                         const std::vector<std::string>& policies, PolicyLanguage language) {        // :121-170, n times
+  std::vector<KpAbeSecretKey> sks(policies.size());
+  // all items' scalar multiplications in one launch per group; one `random` per share, in share order (drawn
+  // inside the loop at :136), every draw of item i before item i+1
   std::vector<G1> b1;
   std::vector<Fr> k1;
   std::vector<G2> b2;
   std::vector<Fr> k2;
-  struct Slot { bool neg; size_t i1, i2; };
+  struct Slot { size_t item, row; bool neg; size_t i1, i2; };
   std::vector<Slot> slots;
-  for (const auto& sh : shares) {
-    std::string striped = remove_index(sh.first);
-    Fr random = rng.next_fr();
-    Slot s{is_negative(striped), b1.size(), b2.size()};
-    if (s.neg) {
-      Fr share_hash = sha3_hash_fr(striped);
-      // d3 = g1*share + g1_b2*random ; d4 = g1_b*(hash*random) + h_g1*random ; d5 = g1*(-random)
-      b1.push_back(pk.g1); k1.push_back(sh.second);
-      b1.push_back(pk.g1_b2); k1.push_back(random);
-      b1.push_back(pk.g1_b); k1.push_back(fr_mul(share_hash, random));
-      b1.push_back(msk.h_g1); k1.push_back(random);
-      b1.push_back(pk.g1); k1.push_back(fr_neg(random));
-    } else {
-      // d1 = g1*(alpha2*share) + (g1*h(y))*random = g1*(alpha2*share + h(y)*random) ; d2 = g2*random
-      b1.push_back(pk.g1); k1.push_back(fr_add(fr_mul(msk.alpha2, sh.second), fr_mul(sha3_hash_fr(striped), random)));
-      b2.push_back(pk.g2); k2.push_back(random);
+  for (size_t it = 0; it < policies.size(); it++) {
+    PolicyNode tree = parse_or_error(policies[it], language);
+    NamedFr shares;
+    gen_shares_policy(msk.alpha1, tree, rng, &shares);
+    KpAbeSecretKey& sk = sks[it];
+    sk.policy = {policies[it], language};
+    for (const auto& sh : shares) {
+      std::string striped = remove_index(sh.first);
+      Fr random = rng.next_fr();
+      Slot s{it, sk.dj.size(), is_negative(striped), b1.size(), b2.size()};
+      if (s.neg) {
+        Fr share_hash = sha3_hash_fr(striped);
+        // d3 = g1*share + g1_b2*random ; d4 = g1_b*(hash*random) + h_g1*random ; d5 = g1*(-random)
+        b1.push_back(pk.g1); k1.push_back(sh.second);
+        b1.push_back(pk.g1_b2); k1.push_back(random);
+        b1.push_back(pk.g1_b); k1.push_back(fr_mul(share_hash, random));
+        b1.push_back(msk.h_g1); k1.push_back(random);
+        b1.push_back(pk.g1); k1.push_back(fr_neg(random));
+      } else {
+        // d1 = g1*(alpha2*share) + (g1*h(y))*random = g1*(alpha2*share + h(y)*random) ; d2 = g2*random
+        b1.push_back(pk.g1); k1.push_back(fr_add(fr_mul(msk.alpha2, sh.second), fr_mul(sha3_hash_fr(striped), random)));
+        b2.push_back(pk.g2); k2.push_back(random);
+      }
+      slots.push_back(s);
+      sk.dj.push_back({striped, g1_zero(), g2_zero(), g1_zero(), g1_zero(), g1_zero()});
     }
-    slots.push_back(s);
-    sk.dj.push_back({striped, g1_zero(), g2_zero(), g1_zero(), g1_zero(), g1_zero()});
   }
   std::vector<G1> r1 = b1.empty() ? std::vector<G1>() : eng.g1_mul(b1, k1);
   std::vector<G2> r2 = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
-  for (size_t i = 0; i < slots.size(); i++) {
-    if (slots[i].neg) {
-      size_t o = slots[i].i1;
-      sk.dj[i].d3 = g1_add(eng, {r1[o]}, {r1[o + 1]})[0];
-      sk.dj[i].d4 = g1_add(eng, {r1[o + 2]}, {r1[o + 3]})[0];
-      sk.dj[i].d5 = r1[o + 4];
+  std::vector<G1> sa, sb;
+  for (const auto& sl : slots)
+    if (sl.neg) { sa.push_back(r1[sl.i1]); sb.push_back(r1[sl.i1 + 1]); sa.push_back(r1[sl.i1 + 2]); sb.push_back(r1[sl.i1 + 3]); }
+  std::vector<G1> sums = sa.empty() ? std::vector<G1>() : g1_add(eng, sa, sb);
+  size_t ns = 0;
+  for (const auto& sl : slots) {
+    KpAbeKeyRow& row = sks[sl.item].dj[sl.row];
+    if (sl.neg) {
+      row.d3 = sums[ns];
+      row.d4 = sums[ns + 1];
+      row.d5 = r1[sl.i1 + 4];
+      ns += 2;
     } else {
-      sk.dj[i].d1 = r1[slots[i].i1];
-      sk.dj[i].d2 = r2[slots[i].i2];
+      row.d1 = r1[sl.i1];
+      row.d2 = r2[sl.i2];
     }
   }
-  return sk;
+  return sks;
+}
+KpAbeSecretKey keygen(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::string& policy,
+                      PolicyLanguage language) {        // :121-170
+  return keygen_batch(eng, rng, pk, msk, {policy}, language)[0];
 }
 KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::string>& attributes, const Bytes& plaintext) {   // :180-219
   if (attributes.empty() || plaintext.empty()) throw RabeError("attributes or data empty");
@@ -709,7 +854,7 @@ KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const s
   ct.ct = seal(rng, msg, plaintext);
   return ct;
 }
-Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) {      // :228-290
+static void plan_decrypt(const KpAbeSecretKey& sk, const KpAbeCiphertext& ct, PairingJob* job) {      // :228-290
   std::vector<std::string> attr;
   for (const auto& a : ct.ej) attr.push_back(a.name);
   PolicyNode tree = parse_or_error(sk.policy.first, sk.policy.second);
@@ -720,9 +865,10 @@ Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) 
   // prod_t = prod z_y^coeff with z_y = e(D1, e2) / e(E1, D2) for positive leaves; a negative leaf re-uses the
   // previous z_y (the reference's TODO branch, :265-278).  msg = e1 / prod_t
   //   = e1 * FE( prod ML(-c*D1, e2) * ML(c*E1, D2) ).
-  std::vector<G1> base;
-  std::vector<Fr> scal;
-  std::vector<G2> q;
+  std::vector<G1>& base = job->base;
+  std::vector<Fr>& scal = job->scal;
+  std::vector<G2>& q = job->q;
+  job->lead = ct.e1;
   const KpAbeKeyRow* cur_sk = nullptr;
   const KpAbeCtRow* cur_ct = nullptr;
   for (const auto& a : list) {
@@ -738,11 +884,21 @@ Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) 
     base.push_back(cur_sk->d1); scal.push_back(fr_neg(*coeff)); q.push_back(ct.e2);
     base.push_back(cur_ct->e1); scal.push_back(*coeff); q.push_back(cur_sk->d2);
   }
-  if (base.empty()) return ct.e1;
-  std::vector<G1> p = eng.g1_mul(base, scal);
-  return eng.gt_mul({ct.e1}, {pairing_product(eng, p, q)})[0];
+}
+Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) {
+  std::vector<PairingJob> jobs(1);
+  plan_decrypt(sk, ct, &jobs[0]);
+  if (jobs[0].base.empty()) return ct.e1;
+  return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const KpAbeSecretKey*>& sks, const std::vector<const KpAbeCiphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(*sks[i], *cts[i], j); });
+  std::vector<const Bytes*> sealed;
+  for (const auto* c : cts) sealed.push_back(&c->ct);
+  return open_jobs(eng, jobs, sealed);
+}
 }  // namespace lsw
 
 // ================================================================================================ AW11
@@ -788,54 +944,80 @@ Aw11SecretKey keygen(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& 
   for (const auto& a : attributes) add_to_attribute(eng, gk, msk, a, &sk);
   return sk;
 }
-Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::string& policy,
-                       PolicyLanguage language, const Bytes& data) {       // :241-289
-  PolicyNode tree = parse_or_error(policy, language);
-  (void)calculate_msp(tree);           // built and unused in the reference (:253-255) -- but it must not panic
-  Fr s = rng.next_fr();
-  NamedFr s_shares, w_shares;
-  gen_shares_policy(s, tree, rng, &s_shares);
-  gen_shares_policy(fr_zero(), tree, rng, &w_shares);
-  Gt msg = eng.random_gt(rng);
-  Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];
-  Aw11Ciphertext ct;
-  ct.policy = {policy, language};
-  ct.c_0 = eng.gt_mul({msg}, {eng.gt_pow({egg}, {s})[0]})[0];
+std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks,
+                                          const std::vector<std::string>& policies, PolicyLanguage language, const std::vector<Bytes>& datas) {   // :241-289, n times
+  if (policies.size() != datas.size()) throw RabeError("encrypt_batch: policies and datas differ in length");
+  const size_t n = policies.size();
+  std::vector<Aw11Ciphertext> cts(n);
+  if (!n) return cts;
+  Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];          // the reference recomputes this constant per call (:264)
+  struct Item { std::vector<std::string> names; std::array<uint8_t, 12> nonce; size_t ot, o2; };
+  std::vector<Item> items(n);
   std::vector<Gt> gb;
   std::vector<Fr> gk_;
   std::vector<G2> b2;
   std::vector<Fr> k2;
-  std::vector<std::string> names;
-  for (size_t i = 0; i < s_shares.size(); i++) {
-    Fr r_x = rng.next_fr();
-    std::string up = upper(s_shares[i].first);
-    const Aw11PkAttr* pa = nullptr;
-    std::string want = remove_index(up);
-    for (const auto* pk : pks) {
-      for (const auto& t : pk->attr) if (t.name == want) { pa = &t; break; }
-      if (pa) break;
+  for (size_t it = 0; it < n; it++) {
+    PolicyNode tree = parse_or_error(policies[it], language);
+    (void)calculate_msp(tree);           // built and unused in the reference (:253-255) -- but it must not panic
+    Fr s = rng.next_fr();
+    NamedFr s_shares, w_shares;
+    gen_shares_policy(s, tree, rng, &s_shares);
+    gen_shares_policy(fr_zero(), tree, rng, &w_shares);
+    Fr msg_k = rng.next_fr();
+    cts[it].policy = {policies[it], language};
+    items[it].ot = gb.size();
+    items[it].o2 = b2.size();
+    gb.push_back(eng.gt_generator()); gk_.push_back(msg_k);       // msg
+    gb.push_back(egg); gk_.push_back(s);                          // egg^s
+    for (size_t i = 0; i < s_shares.size(); i++) {
+      Fr r_x = rng.next_fr();
+      std::string up = upper(s_shares[i].first);
+      const Aw11PkAttr* pa = nullptr;
+      std::string want = remove_index(up);
+      for (const auto* pk : pks) {
+        for (const auto& t : pk->attr) if (t.name == want) { pa = &t; break; }
+        if (pa) break;
+      }
+      if (!pa) continue;
+      items[it].names.push_back(up);
+      gb.push_back(egg); gk_.push_back(s_shares[i].second);
+      gb.push_back(pa->egg_alpha); gk_.push_back(r_x);
+      b2.push_back(gk.g2); k2.push_back(r_x);
+      b2.push_back(pa->g2_y); k2.push_back(r_x);
+      b2.push_back(gk.g2); k2.push_back(w_shares[i].second);
     }
-    if (!pa) continue;
-    names.push_back(up);
-    gb.push_back(egg); gk_.push_back(s_shares[i].second);
-    gb.push_back(pa->egg_alpha); gk_.push_back(r_x);
-    b2.push_back(gk.g2); k2.push_back(r_x);
-    b2.push_back(pa->g2_y); k2.push_back(r_x);
-    b2.push_back(gk.g2); k2.push_back(w_shares[i].second);
+    rng.fill(items[it].nonce.data(), 12);
   }
-  if (!names.empty()) {
-    std::vector<Gt> ge = eng.gt_pow(gb, gk_);
-    std::vector<G2> g2r = eng.g2_mul(b2, k2);
-    for (size_t i = 0; i < names.size(); i++) {
-      Gt c1 = eng.gt_mul({ge[2 * i]}, {ge[2 * i + 1]})[0];
-      G2 c3 = g2_add(eng, {g2r[3 * i + 1]}, {g2r[3 * i + 2]})[0];
-      ct.c.push_back({names[i], c1, g2r[3 * i], c3});
+  std::vector<Gt> ge = eng.gt_pow(gb, gk_);
+  std::vector<G2> g2r = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
+  // c_0 = msg * egg^s and every row's c1 = egg^share * egg_alpha^r_x in one gt_mul; every row's c3 in one g2_add
+  std::vector<Gt> ma, mb;
+  std::vector<G2> aa, ab;
+  for (size_t it = 0; it < n; it++) {
+    const size_t ot = items[it].ot, o2 = items[it].o2;
+    ma.push_back(ge[ot]); mb.push_back(ge[ot + 1]);
+    for (size_t i = 0; i < items[it].names.size(); i++) {
+      ma.push_back(ge[ot + 2 + 2 * i]); mb.push_back(ge[ot + 3 + 2 * i]);
+      aa.push_back(g2r[o2 + 3 * i + 1]); ab.push_back(g2r[o2 + 3 * i + 2]);
     }
   }
-  ct.ct = seal(rng, msg, data);
-  return ct;
+  std::vector<Gt> mm = eng.gt_mul(ma, mb);
+  std::vector<G2> c3 = aa.empty() ? std::vector<G2>() : g2_add(eng, aa, ab);
+  size_t pm = 0, p3 = 0;
+  for (size_t it = 0; it < n; it++) {
+    cts[it].c_0 = mm[pm++];
+    for (size_t i = 0; i < items[it].names.size(); i++)
+      cts[it].c.push_back({items[it].names[i], mm[pm++], g2r[items[it].o2 + 3 * i], c3[p3++]});
+    cts[it].ct = encrypt_symmetric(ge[items[it].ot].data(), datas[it].data(), datas[it].size(), items[it].nonce.data());
+  }
+  return cts;
 }
-Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {       // :298-366
+Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::string& policy,
+                       PolicyLanguage language, const Bytes& data) {       // :241-289
+  return encrypt_batch(eng, rng, gk, pks, {policy}, language, {data})[0];
+}
+static void plan_decrypt(const G1& hash, const Aw11SecretKey& sk, const Aw11Ciphertext& ct, PairingJob* job) {       // :298-366
   std::vector<std::string> str_attr;
   for (const auto& v : sk.attr) str_attr.push_back(v.first);
   PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
@@ -847,12 +1029,12 @@ Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, con
   if (!ok) throw RabeError("Error in aw11/decrypt: attributes in sk do not match policy in ct.");
   // egg_s = prod ( C1 * e(H, C3) / e(K, C2) )^c ; msg = c_0 / egg_s
   //       = c_0 * prod C1^(-c) * FE( prod ML(-c H, C3) ML(c K, C2) ),  H = g1*h(gid)        
-  G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];
-  std::vector<G1> base;
-  std::vector<Fr> scal;
-  std::vector<G2> q;
-  std::vector<Gt> c1s;
-  std::vector<Fr> c1k;
+  std::vector<G1>& base = job->base;
+  std::vector<Fr>& scal = job->scal;
+  std::vector<G2>& q = job->q;
+  std::vector<Gt>& c1s = job->gbase;
+  std::vector<Fr>& c1k = job->gexp;
+  job->lead = ct.c_0;
   for (const auto& cur : list) {
     const std::pair<std::string, G1>* sk_attr = nullptr;
     const Aw11CtRow* ct_attr = nullptr;
@@ -865,14 +1047,28 @@ Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, con
     base.push_back(sk_attr->second); scal.push_back(*coeff); q.push_back(ct_attr->c2);
     c1s.push_back(ct_attr->c1); c1k.push_back(fr_neg(*coeff));
   }
-  if (base.empty()) return ct.c_0;
-  std::vector<G1> p = eng.g1_mul(base, scal);
-  Gt pr = pairing_product(eng, p, q);
-  Gt c1p = gt_product(eng, eng.gt_pow(c1s, c1k));
-  return eng.gt_mul({eng.gt_mul({ct.c_0}, {c1p})[0]}, {pr})[0];
+}
+Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {
+  G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];
+  std::vector<PairingJob> jobs(1);
+  plan_decrypt(hash, sk, ct, &jobs[0]);
+  if (jobs[0].base.empty()) return ct.c_0;
+  return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {
   return open_or_error(decrypt_gt(eng, gk, sk, ct), ct.ct);
+}
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, const std::vector<const Aw11SecretKey*>& sks,
+                                         const std::vector<const Aw11Ciphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
+  // H(gid) = g1 * h(gid) for every key, one launch
+  std::vector<Fr> hk;
+  for (const auto* sk : sks) hk.push_back(sha3_hash_fr(sk->gid));
+  std::vector<G1> hashes = sks.empty() ? std::vector<G1>() : eng.g1_mul(std::vector<G1>(sks.size(), gk.g1), hk);
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(hashes[i], *sks[i], *cts[i], j); });
+  std::vector<const Bytes*> sealed;
+  for (const auto* c : cts) sealed.push_back(&c->ct);
+  return open_jobs(eng, jobs, sealed);
 }
 }  // namespace aw11
 

@@ -13,6 +13,8 @@
 namespace rabe { namespace schemes {
 
 typedef std::pair<std::string, PolicyLanguage> PolicyRef;
+// per item of a *_decrypt_batch: ok flag + plaintext or error text (a non-matching key fails its item, not the batch)
+struct DecryptResult { bool ok; Bytes plaintext; std::string error; };
 
 namespace ac17 {
 struct Ac17PublicKey { G1 g; std::vector<G2> h_a; std::vector<Gt> e_gh_ka; };                  // :62-66
@@ -33,8 +35,7 @@ Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext&
 // equals cp_encrypt(pk, policies[i], plaintexts[i]) with the randomness drawn item after item.
 std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies,
                                                const std::vector<Bytes>& plaintexts, PolicyLanguage language);
-// per item: ok flag + plaintext or error text (a non-matching key fails its item, not the batch)
-struct DecryptResult { bool ok; Bytes plaintext; std::string error; };
+typedef schemes::DecryptResult DecryptResult;
 std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks,
                                             const std::vector<const Ac17CpCiphertext*>& cts);
 // the Gt value handed to decrypt_symmetric (parity hook for tests; not part of the reference API)
@@ -62,6 +63,12 @@ CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const s
                         const Bytes& plaintext);
 Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);
 Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);
+// n independent calls with the group work of all items concatenated into one launch per operation type
+// (BASELINE config 3: batch 4096); element i equals encrypt(pk, policies[i], plaintexts[i]) / decrypt(sks[i], cts[i])
+// with the randomness drawn item after item.
+std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies,
+                                           PolicyLanguage language, const std::vector<Bytes>& plaintexts);
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const CpAbeSecretKey*>& sks, const std::vector<const CpAbeCiphertext*>& cts);
 }  // namespace bsw
 
 namespace lsw {
@@ -78,6 +85,10 @@ KpAbeSecretKey keygen(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpA
 KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::string>& attributes, const Bytes& plaintext);
 Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct);
 Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct);
+// BASELINE config 4 (keygen + decrypt, batch 16384): n independent calls, one launch per operation type
+std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk,
+                                         const std::vector<std::string>& policies, PolicyLanguage language);
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const KpAbeSecretKey*>& sks, const std::vector<const KpAbeCiphertext*>& cts);
 }  // namespace lsw
 
 namespace aw11 {
@@ -100,6 +111,11 @@ Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std
                        PolicyLanguage language, const Bytes& data);
 Bytes decrypt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct);
 Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct);
+// BASELINE config 5 (batch 8192): n independent calls, one launch per operation type
+std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks,
+                                          const std::vector<std::string>& policies, PolicyLanguage language, const std::vector<Bytes>& datas);
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, const std::vector<const Aw11SecretKey*>& sks,
+                                         const std::vector<const Aw11Ciphertext*>& cts);
 }  // namespace aw11
 
 }}  // namespace rabe::schemes

@@ -122,6 +122,33 @@ class Host:
 
 
 # ------------------------------------------------------------------ host-only policy utilities
+def batch_items(datas):
+    """ctypes arrays (pointers, lengths) for a list of byte strings"""
+    n = len(datas)
+    ptrs = (ctypes.c_char_p * max(1, n))(*[bytes(p) for p in datas])
+    lens = (ctypes.c_size_t * max(1, n))(*[len(p) for p in datas])
+    return ptrs, lens
+
+
+def batch_decrypt(host, fn, pre_args, sks, cts):
+    """Shared tail of the *_decrypt_batch wrappers: list of plaintexts, None where the key does not satisfy the policy."""
+    n = len(cts)
+    a = (ctypes.c_void_p * max(1, n))(*[s.ptr for s in sks])
+    b = (ctypes.c_void_p * max(1, n))(*[c.ptr for c in cts])
+    status = (ctypes.c_int32 * max(1, n))()
+    pts = (ctypes.c_void_p * max(1, n))()
+    lens = (ctypes.c_size_t * max(1, n))()
+    host.call(fn, *pre_args, ctypes.c_size_t(n), a, b, status, pts, lens)
+    out = []
+    for i in range(n):
+        if status[i] == 0:
+            out.append(ctypes.string_at(pts[i], lens[i]))
+            host.lib.rabe_bytes_free(ctypes.c_void_p(pts[i]))
+        else:
+            out.append(None)
+    return out
+
+
 def policy_parse(policy, language=JSON_POLICY, out_language=JSON_POLICY):
     p = ctypes.c_void_p()
     _check(_lib().rabe_policy_parse(policy.encode(), language, out_language, ctypes.byref(p)))

@@ -1,7 +1,7 @@
 """rabe::schemes::aw11 (src/schemes/aw11/mod.rs:100-390) over the host layer."""
 import ctypes
 
-from ..hostlib import JSON_POLICY, Obj, _strs
+from ..hostlib import JSON_POLICY, Obj, _strs, batch_decrypt, batch_items
 
 
 def setup(host):
@@ -44,3 +44,18 @@ def decrypt(host, gk, sk, ct):
 
 def decrypt_gt(host, gk, sk, ct):
     return host.out_gt("rabe_aw11_decrypt_gt", gk.ptr, sk.ptr, ct.ptr)
+
+
+def encrypt_batch(host, gk, pks, policies, language, datas):
+    """n independent encrypt calls under the same authority keys, one launch per operation type (BASELINE config 5)"""
+    n = len(policies)
+    arr = (ctypes.c_void_p * max(1, len(pks)))(*[p.ptr for p in pks])
+    pol, _ = _strs(policies)
+    pts, lens = batch_items(datas)
+    out = (ctypes.c_void_p * max(1, n))()
+    host.call("rabe_aw11_encrypt_batch", gk.ptr, arr, ctypes.c_size_t(len(pks)), ctypes.c_size_t(n), pol, language, pts, lens, out)
+    return [Obj("aw11_ct", ctypes.c_void_p(out[i])) for i in range(n)]
+
+
+def decrypt_batch(host, gk, sks, cts):
+    return batch_decrypt(host, "rabe_aw11_decrypt_batch", (gk.ptr,), sks, cts)

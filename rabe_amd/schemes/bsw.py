@@ -1,7 +1,7 @@
 """rabe::schemes::bsw (src/schemes/bsw/mod.rs:92-318) over the host layer."""
 import ctypes
 
-from ..hostlib import JSON_POLICY, Obj, _strs
+from ..hostlib import JSON_POLICY, Obj, _strs, batch_decrypt, batch_items
 
 
 def setup(host):
@@ -40,3 +40,17 @@ def decrypt(host, sk, ct):
 
 def decrypt_gt(host, sk, ct):
     return host.out_gt("rabe_bsw_decrypt_gt", sk.ptr, ct.ptr)
+
+
+def encrypt_batch(host, pk, policies, language, plaintexts):
+    """n independent encrypt calls, one launch per operation type (BASELINE config 3)"""
+    n = len(policies)
+    pol, _ = _strs(policies)
+    pts, lens = batch_items(plaintexts)
+    out = (ctypes.c_void_p * max(1, n))()
+    host.call("rabe_bsw_encrypt_batch", pk.ptr, ctypes.c_size_t(n), pol, language, pts, lens, out)
+    return [Obj("bsw_ct", ctypes.c_void_p(out[i])) for i in range(n)]
+
+
+def decrypt_batch(host, sks, cts):
+    return batch_decrypt(host, "rabe_bsw_decrypt_batch", (), sks, cts)

@@ -1,7 +1,7 @@
 """rabe::schemes::lsw (src/schemes/lsw/mod.rs:86-290) over the host layer."""
 import ctypes
 
-from ..hostlib import JSON_POLICY, Obj, _strs
+from ..hostlib import JSON_POLICY, Obj, _strs, batch_decrypt
 
 
 def setup(host):
@@ -29,3 +29,16 @@ def decrypt(host, sk, ct):
 
 def decrypt_gt(host, sk, ct):
     return host.out_gt("rabe_lsw_decrypt_gt", sk.ptr, ct.ptr)
+
+
+def keygen_batch(host, pk, msk, policies, language=JSON_POLICY):
+    """n independent keygen calls, one launch per operation type (BASELINE config 4)"""
+    n = len(policies)
+    pol, _ = _strs(policies)
+    out = (ctypes.c_void_p * max(1, n))()
+    host.call("rabe_lsw_keygen_batch", pk.ptr, msk.ptr, ctypes.c_size_t(n), pol, language, out)
+    return [Obj("lsw_sk", ctypes.c_void_p(out[i])) for i in range(n)]
+
+
+def decrypt_batch(host, sks, cts):
+    return batch_decrypt(host, "rabe_lsw_decrypt_batch", (), sks, cts)

@@ -16,15 +16,21 @@ def lib():
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "rabe_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rhip_[a-z0-9_]+)\s*\(", text)))
+    out = set()
+    for header, prefix in (("rabe_hip.h", "rhip_"), ("rabe_host.h", "rabe_")):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text))
+    return sorted(out)
 
 
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     for must in ["rhip_ctx_create", "rhip_pairing_product", "rhip_ac17_cp_encrypt_batch", "rhip_ac17_cp_decrypt_batch",
-                 "rhip_ac17_cp_keygen_batch", "rhip_g1_table_mul", "rhip_gt_pow"]:
+                 "rhip_ac17_cp_keygen_batch", "rhip_g1_table_mul", "rhip_gt_pow", "rhip_ac17_sk_prepare",
+                 "rhip_ac17_cp_decrypt_batch_prepared", "rhip_g1_table_add_wide", "rabe_ac17_cp_encrypt_batch", "rabe_bsw_encrypt_batch",
+                 "rabe_bsw_decrypt_batch", "rabe_lsw_keygen_batch", "rabe_lsw_decrypt_batch", "rabe_aw11_encrypt_batch",
+                 "rabe_aw11_decrypt_batch"]:
         assert must in syms
 
 

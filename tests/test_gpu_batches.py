@@ -1,0 +1,92 @@
+"""Batch entry points of bsw / lsw / aw11 (BASELINE configs 3-5 ask for batches): on the same randomness tape,
+item i of a *_batch call is byte-identical to the i-th of n single calls (which tests/test_gpu_schemes.py and
+the golden vectors pin to the oracle), and a key that does not satisfy its item's policy fails that item only."""
+import random
+
+import pytest
+
+from rabe_amd import hostlib as hl
+from rabe_amd.schemes import aw11, bsw, lsw
+
+pytestmark = pytest.mark.gpu
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+PTS = [b"item %d: dance like no one's watching" % i for i in range(5)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    h = hl.Host(0)
+    yield h
+    h.close()
+
+
+def tape(seed, n=4000):
+    rnd = random.Random(seed)
+    return [rnd.randrange(1, R) for _ in range(n)]
+
+
+def leaf(a):
+    return '{"name": "%s"}' % a
+
+
+def gate(op, *ch):
+    return '{"name": "%s", "children": [%s]}' % (op, ", ".join(ch))
+
+
+def test_bsw_encrypt_decrypt_batch(host):
+    pk, msk = bsw.setup(host)
+    attrs = ["A", "B", "C", "D"]
+    sk = bsw.keygen(host, pk, msk, attrs)
+    sk_ab = bsw.keygen(host, pk, msk, ["A", "B"])
+    policies = [gate("and", leaf("A"), leaf("B")), gate("or", leaf("C"), gate("and", leaf("A"), leaf("D"))),
+                gate("and", leaf("A"), leaf("B"), leaf("C"), leaf("D")), leaf("B"), gate("and", leaf("C"), leaf("D"))]
+    t = tape(3)
+    host.set_tape(t)
+    batch = bsw.encrypt_batch(host, pk, policies, hl.JSON_POLICY, PTS)
+    host.set_tape(t)
+    singles = [bsw.encrypt(host, pk, p, hl.JSON_POLICY, pt) for p, pt in zip(policies, PTS)]
+    host.clear_tape()
+    assert [c.serialize() for c in batch] == [c.serialize() for c in singles]
+    assert bsw.decrypt_batch(host, [sk] * 5, batch) == PTS
+    # sk_ab satisfies items 0 and 3 only
+    assert bsw.decrypt_batch(host, [sk_ab] * 5, batch) == [PTS[0], None, None, PTS[3], None]
+    assert bsw.decrypt_batch(host, [], []) == []
+
+
+def test_lsw_keygen_decrypt_batch(host):
+    pk, msk = lsw.setup(host)
+    policies = [gate("and", leaf("A"), leaf("B")), gate("or", leaf("C"), gate("and", leaf("A"), leaf("D"))), leaf("B"),
+                gate("and", leaf("A"), gate("or", leaf("B"), leaf("E")), leaf("C"))]
+    t = tape(4)
+    host.set_tape(t)
+    batch = lsw.keygen_batch(host, pk, msk, policies, hl.JSON_POLICY)
+    host.set_tape(t)
+    singles = [lsw.keygen(host, pk, msk, p, hl.JSON_POLICY) for p in policies]
+    host.clear_tape()
+    assert [k.serialize() for k in batch] == [k.serialize() for k in singles]
+    ct_abc = lsw.encrypt(host, pk, ["A", "B", "C"], PTS[0])
+    ct_b = lsw.encrypt(host, pk, ["B"], PTS[1])
+    assert lsw.decrypt_batch(host, batch, [ct_abc] * 4) == [PTS[0]] * 4
+    assert lsw.decrypt_batch(host, batch, [ct_b] * 4) == [None, None, PTS[1], None]
+    assert lsw.decrypt_batch(host, batch[:2] + batch[2:], [ct_abc, ct_b, ct_b, ct_abc]) == [PTS[0], None, PTS[1], PTS[0]]
+
+
+def test_aw11_encrypt_decrypt_batch(host):
+    gk = aw11.setup(host)
+    pk1, msk1 = aw11.authgen(host, gk, ["A", "B"])
+    pk2, msk2 = aw11.authgen(host, gk, ["C", "D"])
+    alice = aw11.keygen(host, gk, msk1, "alice", ["A", "B"])
+    for a in ("C", "D"):
+        aw11.add_to_attribute(host, gk, msk2, a, alice)
+    bob = aw11.keygen(host, gk, msk1, "bob", ["A"])
+    policies = [gate("and", leaf("A"), leaf("C")), gate("or", leaf("D"), gate("and", leaf("A"), leaf("B"))), leaf("A"),
+                gate("and", gate("and", leaf("A"), leaf("B")), gate("and", leaf("C"), leaf("D")))]
+    t = tape(5)
+    host.set_tape(t)
+    batch = aw11.encrypt_batch(host, gk, [pk1, pk2], policies, hl.JSON_POLICY, PTS[:4])
+    host.set_tape(t)
+    singles = [aw11.encrypt(host, gk, [pk1, pk2], p, hl.JSON_POLICY, pt) for p, pt in zip(policies, PTS)]
+    host.clear_tape()
+    assert [c.serialize() for c in batch] == [c.serialize() for c in singles]
+    assert aw11.decrypt_batch(host, gk, [alice] * 4, batch) == PTS[:4]
+    assert aw11.decrypt_batch(host, gk, [bob, alice, bob, bob], batch) == [None, PTS[1], PTS[2], None]
