@@ -41,7 +41,7 @@ MAC_PER_FPMUL = 136
 SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
 SURVEY_MIXED_ADD_FPMUL = 11
 IMPL_MILLER_FPMUL = 8983            # tools/count_muls.py: miller_loop (NAF chain) with Jacobian P
-IMPL_MILLER2_FPMUL = 12763          # tools/count_muls.py: miller_loop_pair (A replays prepared lines, B Jacobian), two pairings
+IMPL_MILLER2_FPMUL = 12170          # tools/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
 IMPL_FINAL_EXP_FPMUL = 8940
 
 

@@ -43,6 +43,7 @@ res["miller_loop(affine P) incl. 6 loads 12 stores"] = count("hs_miller", P, Q)
 res["miller_loop(jacobian P) + final_exp"] = count("hs_pairing_jac", P, le(rnd.randrange(bn.P)), Q)
 res["pairing via prepared lines (affine P) + final_exp incl. line preparation"] = count("hs_pairing_prepared", P, Q)
 res["paired miller (A prepared incl. preparation, B jacobian) + final_exp"] = count("hs_pairing_pair", P, Q, P, Q)
+res["paired miller, parked + merged lines (as k_ac17_dec_miller2) incl. preparation + final_exp"] = count("hs_pairing_pair_parked", P, Q, P, Q)
 res["g2_prepare_lines (88 line triples) incl. io"] = count("hs_g2_prepare", Q, out=192)
 m = (ctypes.c_uint32 * 96)()
 HS.hs_miller(b2c(P), b2c(Q), m)
