@@ -354,7 +354,12 @@ template <class WS> RB_FN void wsx_frob_mul(WS ws, int dst, int a, int k, int b)
   x = (k == 1) ? fp12_frob1(x) : (k == 2) ? fp12_frob2(x) : fp12_frob3(x);
   ws.st(dst, fp12_mul(x, ws.ld(b)));
 }
-template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) { ws.st(dst, fp12_inv(ws.ld(a))); }
+template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) {      // fp12_inv with the Fq12 operand / result kept out of stack frames
+  const Fp12 x = ws.ld(a);
+  const Fp6 t = fp6_sub(fp6_sqr(x.c0), fp6_mul_v(fp6_sqr(x.c1)));
+  const Fp6 ti = fp6_inv(t);
+  ws.st(dst, Fp12{fp6_mul(x.c0, ti), fp6_neg(fp6_mul(x.c1, ti))});
+}
 // dst = a^(2^n) * (b >= 0 ? b : 1): a run of cyclotomic squarings and the multiplication that ends it stay in registers
 template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b) {
   Fp12 x = ws.ld(a);
