@@ -122,11 +122,25 @@ class Engine {
   // `rng.gen::<Gt>()`: e(G1::one(), G2::one()) ^ Fr::random
   Gt random_gt(Rng& rng);
   const Gt& gt_generator();     // e(G1::one(), G2::one()), computed once
+  // Calls whose operands repeat one base many times (the schemes multiply public-key elements by per-row scalars)
+  // are served from per-base window tables built on first use and cached here: 32 mixed additions per element
+  // instead of 254 doublings + ~127 additions.  Same group elements, hence the same bytes.  Building a table costs
+  // 8 160 variable-base multiplications, so it pays for itself from a few thousand elements per base on (Gt: more).
+  size_t fixed_base_min = 4096;   // G1 / G2 elements sharing one base in one call; Gt uses twice that
 
  private:
   rhip_ctx* ctx_ = nullptr;
   bool have_e_ = false;
   Gt e_gen_;
+  std::map<std::string, rhip_g1_table*> t1_;
+  std::map<std::string, rhip_g2_table*> t2_;
+  std::map<std::string, rhip_gt_table*> tt_;
+  void destroy_table(rhip_g1_table* t);
+  void destroy_table(rhip_g2_table* t);
+  void destroy_table(rhip_gt_table* t);
+  template <size_t N, class TBL, class CREATE, class MUL, class GENERIC>
+  std::vector<std::array<uint8_t, N>> mul_grouped(const std::vector<std::array<uint8_t, N>>& p, const std::vector<Fr>& k,
+                                                   std::map<std::string, TBL*>& cache, CREATE create, MUL mul, GENERIC generic);
 };
 
 template <class T, size_t N>

@@ -190,6 +190,11 @@ int32_t rabe_host_create(int32_t device, rabe_host** out) {
 }
 void rabe_host_destroy(rabe_host* h) { delete h; }
 const char* rabe_host_last_error(rabe_host* h) { return h ? h->err.c_str() : g_err.c_str(); }
+int32_t rabe_host_set_fixed_base_min(rabe_host* h, size_t n) {
+  if (!h) return -1;
+  h->eng.fixed_base_min = n ? n : 1;
+  return 0;
+}
 int32_t rabe_host_set_tape(rabe_host* h, const uint8_t* fr_le32, size_t n) {
   if (!h) return -1;
   if (!n) { h->tape.reset(); return 0; }

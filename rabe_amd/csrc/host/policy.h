@@ -357,17 +357,26 @@ inline void gen_shares_policy(const Fr& secret, const PolicyNode& n, FrSource& r
   for (size_t i = 0; i < cnt; i++) gen_shares_policy(shares[i + 1], n.children[i], rng, out);
 }
 inline std::vector<Fr> recover_coefficients(const std::vector<Fr>& list) {     // Lagrange at 0, :60-72
-  std::vector<Fr> out;
-  for (const Fr& i : list) {
-    Fr res = fr_one();
-    for (const Fr& j : list) {
-      if (i != j) {
-        Fr inv;
-        if (!fr_inv(fr_sub(i, j), &inv)) throw PolicyPanic("recover_coefficients: inverse of zero");
-        res = fr_mul(res, fr_mul(fr_sub(fr_zero(), j), inv));
+  // res_i = prod_{j != i} (0 - j) / (i - j).  The reference inverts every (i - j) (k^2 inversions); the same field
+  // element is num_i * (prod_j (i - j))^-1, and the k denominators share ONE inversion (Montgomery's trick).
+  const size_t k = list.size();
+  std::vector<Fr> num(k, fr_one()), den(k, fr_one());
+  for (size_t a = 0; a < k; a++) {
+    for (size_t b = 0; b < k; b++) {
+      if (list[a] != list[b]) {
+        num[a] = fr_mul(num[a], fr_sub(fr_zero(), list[b]));
+        den[a] = fr_mul(den[a], fr_sub(list[a], list[b]));
       }
     }
-    out.push_back(res);
+  }
+  std::vector<Fr> prefix(k + 1, fr_one());
+  for (size_t a = 0; a < k; a++) prefix[a + 1] = fr_mul(prefix[a], den[a]);
+  Fr inv_all;
+  if (!fr_inv(prefix[k], &inv_all)) throw PolicyPanic("recover_coefficients: inverse of zero");
+  std::vector<Fr> out(k);
+  for (size_t a = k; a-- > 0;) {
+    out[a] = fr_mul(num[a], fr_mul(inv_all, prefix[a]));
+    inv_all = fr_mul(inv_all, den[a]);
   }
   return out;
 }

@@ -2,6 +2,7 @@
 // String / Fr work happens here exactly where the reference does it on the CPU; every group operation is a
 // batched launch of the HIP engine (no CPU group arithmetic exists in this layer).
 #include "schemes.h"
+#include <algorithm>
 
 #include <stdio.h>
 #include <sys/random.h>
@@ -24,7 +25,12 @@ Engine::Engine(int device) {
   int32_t rc = rhip_ctx_create(device, &ctx_);
   if (rc != RHIP_OK) throw RabeError(std::string("no usable HIP device: ") + rhip_last_error(nullptr));
 }
-Engine::~Engine() { rhip_ctx_destroy(ctx_); }
+Engine::~Engine() {
+  for (auto& c : t1_) rhip_g1_table_destroy(c.second);
+  for (auto& c : t2_) rhip_g2_table_destroy(c.second);
+  for (auto& c : tt_) rhip_gt_table_destroy(c.second);
+  rhip_ctx_destroy(ctx_);
+}
 void Engine::check(int32_t rc, const char* what) const {
   if (rc != RHIP_OK) throw RabeError(std::string(what) + " failed: " + rhip_last_error(ctx_));
 }
@@ -53,26 +59,88 @@ static std::vector<std::array<uint8_t, N>> fetch(const DBuf& d, size_t n) {
   return unflatten<void, N>(raw);
 }
 
+// ---- fixed-base fast path (common.h): partition the operands by base; groups of >= fixed_base_min elements go
+// through a cached window table, the rest through the generic variable-base kernel
+template <size_t N, class TBL, class CREATE, class MUL, class GENERIC>
+std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::array<uint8_t, N>>& p, const std::vector<Fr>& k,
+                                                         std::map<std::string, TBL*>& cache, CREATE create, MUL mul, GENERIC generic) {
+  const size_t n = p.size();
+  std::vector<std::array<uint8_t, N>> out(n);
+  if (!n) return out;
+  std::map<std::string, std::vector<size_t>> groups;
+  for (size_t i = 0; i < n; i++) groups[std::string((const char*)p[i].data(), N)].push_back(i);
+  std::vector<size_t> rest;
+  for (auto& g : groups) {
+    std::vector<size_t>& idx = g.second;
+    const bool cached = cache.count(g.first) != 0;
+    const size_t need = (N == 384 && fixed_base_min > 1) ? 2 * fixed_base_min : fixed_base_min;
+    if (idx.size() < need && !cached) { rest.insert(rest.end(), idx.begin(), idx.end()); continue; }
+    if (!cached) {
+      if (cache.size() >= 64) {                       // bounded: drop everything rather than track recency
+        for (auto& c : cache) this->destroy_table(c.second);
+        cache.clear();
+      }
+      TBL* t = nullptr;
+      check(create(ctx_, p[idx[0]].data(), &t), "fixed-base table build");
+      cache[g.first] = t;
+    }
+    std::vector<Fr> kk;
+    for (size_t i : idx) kk.push_back(k[i]);
+    auto fk = flatten_fr(kk);
+    DBuf dk(this, fk.data(), fk.size()), dout(this, idx.size() * N);
+    check(mul(ctx_, cache[g.first], idx.size(), dk.as<rhip_fr>(), dout.ptr()), "fixed-base table multiplication");
+    auto r = fetch<N>(dout, idx.size());
+    for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = r[j];
+  }
+  if (!rest.empty()) {
+    std::sort(rest.begin(), rest.end());
+    std::vector<std::array<uint8_t, N>> rp;
+    std::vector<Fr> rk;
+    for (size_t i : rest) { rp.push_back(p[i]); rk.push_back(k[i]); }
+    auto r = generic(rp, rk);
+    for (size_t j = 0; j < rest.size(); j++) out[rest[j]] = r[j];
+  }
+  return out;
+}
+void Engine::destroy_table(rhip_g1_table* t) { rhip_g1_table_destroy(t); }
+void Engine::destroy_table(rhip_g2_table* t) { rhip_g2_table_destroy(t); }
+void Engine::destroy_table(rhip_gt_table* t) { rhip_gt_table_destroy(t); }
+
 std::vector<G1> Engine::g1_mul(const std::vector<G1>& p, const std::vector<Fr>& k) {
-  size_t n = p.size();
-  auto fp = flatten(p); auto fk = flatten_fr(k);
-  DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 64);
-  check(rhip_g1_mul(ctx_, n, dp.as<rhip_g1>(), dk.as<rhip_fr>(), out.as<rhip_g1>()), "rhip_g1_mul");
-  return fetch<64>(out, n);
+  return mul_grouped<64>(p, k, t1_,
+      [](rhip_ctx* c, const uint8_t* b, rhip_g1_table** t) { return rhip_g1_table_create(c, (const rhip_g1*)b, t); },
+      [](rhip_ctx* c, const rhip_g1_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_g1_table_mul(c, t, n, dk, (rhip_g1*)o); },
+      [this](const std::vector<G1>& rp, const std::vector<Fr>& rk) {
+        size_t n = rp.size();
+        auto fp = flatten(rp); auto fk = flatten_fr(rk);
+        DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 64);
+        check(rhip_g1_mul(ctx_, n, dp.as<rhip_g1>(), dk.as<rhip_fr>(), out.as<rhip_g1>()), "rhip_g1_mul");
+        return fetch<64>(out, n);
+      });
 }
 std::vector<G2> Engine::g2_mul(const std::vector<G2>& p, const std::vector<Fr>& k) {
-  size_t n = p.size();
-  auto fp = flatten(p); auto fk = flatten_fr(k);
-  DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 128);
-  check(rhip_g2_mul(ctx_, n, dp.as<rhip_g2>(), dk.as<rhip_fr>(), out.as<rhip_g2>()), "rhip_g2_mul");
-  return fetch<128>(out, n);
+  return mul_grouped<128>(p, k, t2_,
+      [](rhip_ctx* c, const uint8_t* b, rhip_g2_table** t) { return rhip_g2_table_create(c, (const rhip_g2*)b, t); },
+      [](rhip_ctx* c, const rhip_g2_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_g2_table_mul(c, t, n, dk, (rhip_g2*)o); },
+      [this](const std::vector<G2>& rp, const std::vector<Fr>& rk) {
+        size_t n = rp.size();
+        auto fp = flatten(rp); auto fk = flatten_fr(rk);
+        DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 128);
+        check(rhip_g2_mul(ctx_, n, dp.as<rhip_g2>(), dk.as<rhip_fr>(), out.as<rhip_g2>()), "rhip_g2_mul");
+        return fetch<128>(out, n);
+      });
 }
 std::vector<Gt> Engine::gt_pow(const std::vector<Gt>& a, const std::vector<Fr>& k) {
-  size_t n = a.size();
-  auto fa = flatten(a); auto fk = flatten_fr(k);
-  DBuf da(this, fa.data(), fa.size()), dk(this, fk.data(), fk.size()), out(this, n * 384);
-  check(rhip_gt_pow(ctx_, n, da.as<rhip_gt>(), dk.as<rhip_fr>(), out.as<rhip_gt>()), "rhip_gt_pow");
-  return fetch<384>(out, n);
+  return mul_grouped<384>(a, k, tt_,
+      [](rhip_ctx* c, const uint8_t* b, rhip_gt_table** t) { return rhip_gt_table_create(c, (const rhip_gt*)b, t); },
+      [](rhip_ctx* c, const rhip_gt_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_gt_table_pow(c, t, n, dk, (rhip_gt*)o); },
+      [this](const std::vector<Gt>& ra, const std::vector<Fr>& rk) {
+        size_t n = ra.size();
+        auto fa = flatten(ra); auto fk = flatten_fr(rk);
+        DBuf da(this, fa.data(), fa.size()), dk(this, fk.data(), fk.size()), out(this, n * 384);
+        check(rhip_gt_pow(ctx_, n, da.as<rhip_gt>(), dk.as<rhip_fr>(), out.as<rhip_gt>()), "rhip_gt_pow");
+        return fetch<384>(out, n);
+      });
 }
 std::vector<Gt> Engine::gt_mul(const std::vector<Gt>& a, const std::vector<Gt>& b) {
   size_t n = a.size();
@@ -207,6 +275,22 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
   }
   return out;
 }
+// Items of one batch usually repeat a few policies: the parsed tree and its Lagrange coefficients (pure functions of
+// the policy text) are computed once per distinct (text, language) within a call.
+struct PolicyMemo {
+  struct Entry { PolicyNode tree; NamedFr coeff; };
+  std::map<std::pair<std::string, int>, std::shared_ptr<Entry>> m;
+  const Entry& get(const std::string& policy, PolicyLanguage lang) {
+    auto key = std::make_pair(policy, (int)lang);
+    auto it = m.find(key);
+    if (it != m.end()) return *it->second;
+    auto e = std::make_shared<Entry>();
+    e->tree = parse_or_error(policy, lang);
+    calc_coefficients(e->tree, fr_one(), &e->coeff);
+    m[key] = e;
+    return *e;
+  }
+};
 // plan(i, &job) fills job i or throws RabeError (-> that item fails); panics (std::runtime_error) propagate like the reference's
 template <class PLAN>
 static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
@@ -657,15 +741,15 @@ CpAbeCiphertext encrypt(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const s
   ct.data = seal(rng, msg, plaintext);
   return ct;
 }
-static void plan_decrypt(const CpAbeSecretKey& sk, const CpAbeCiphertext& ct, PairingJob* job) {       // :260-308
+static void plan_decrypt(PolicyMemo& memo, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct, PairingJob* job) {       // :260-308
   std::vector<std::string> attr;
   for (const auto& v : sk.d_j) attr.push_back(v.string);
-  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  const PolicyMemo::Entry& pe = memo.get(ct.policy.first, ct.policy.second);
+  const PolicyNode& tree = pe.tree;
   if (!traverse_policy(attr, tree)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
   PrunedList pruned;
   if (!calc_pruned(attr, tree, &pruned)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
-  NamedFr z;
-  calc_coefficients(tree, fr_one(), &z);
+  const NamedFr& z = pe.coeff;
   // msg = c_p * A / e(c, d),  A = prod ( e(Cy.g1, Dj.g2) / e(Dj.g1, Cy.g2) )^z
   //     = c_p * FE( ML(-c, d) * prod ML(z Cy.g1, Dj.g2) ML(-z Dj.g1, Cy.g2) )        
   std::vector<G1>& base = job->base;
@@ -690,13 +774,15 @@ static void plan_decrypt(const CpAbeSecretKey& sk, const CpAbeCiphertext& ct, Pa
 }
 Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) {
   std::vector<PairingJob> jobs(1);
-  plan_decrypt(sk, ct, &jobs[0]);
+  PolicyMemo memo;
+  plan_decrypt(memo, sk, ct, &jobs[0]);
   return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.data); }
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const CpAbeSecretKey*>& sks, const std::vector<const CpAbeCiphertext*>& cts) {
   if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
-  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(*sks[i], *cts[i], j); });
+  PolicyMemo memo;
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(memo, *sks[i], *cts[i], j); });
   std::vector<const Bytes*> sealed;
   for (const auto* c : cts) sealed.push_back(&c->data);
   return open_jobs(eng, jobs, sealed);
@@ -854,14 +940,14 @@ KpAbeCiphertext encrypt(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const s
   ct.ct = seal(rng, msg, plaintext);
   return ct;
 }
-static void plan_decrypt(const KpAbeSecretKey& sk, const KpAbeCiphertext& ct, PairingJob* job) {      // :228-290
+static void plan_decrypt(PolicyMemo& memo, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct, PairingJob* job) {      // :228-290
   std::vector<std::string> attr;
   for (const auto& a : ct.ej) attr.push_back(a.name);
-  PolicyNode tree = parse_or_error(sk.policy.first, sk.policy.second);
+  const PolicyMemo::Entry& pe = memo.get(sk.policy.first, sk.policy.second);
+  const PolicyNode& tree = pe.tree;
   PrunedList list;
   if (!calc_pruned(attr, tree, &list)) throw RabeError("Error in lsw/decrypt: attributes do not match policy.");
-  NamedFr coeff_list;
-  calc_coefficients(tree, fr_one(), &coeff_list);
+  const NamedFr& coeff_list = pe.coeff;
   // prod_t = prod z_y^coeff with z_y = e(D1, e2) / e(E1, D2) for positive leaves; a negative leaf re-uses the
   // previous z_y (the reference's TODO branch, :265-278).  msg = e1 / prod_t
   //   = e1 * FE( prod ML(-c*D1, e2) * ML(c*E1, D2) ).
@@ -887,14 +973,16 @@ static void plan_decrypt(const KpAbeSecretKey& sk, const KpAbeCiphertext& ct, Pa
 }
 Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) {
   std::vector<PairingJob> jobs(1);
-  plan_decrypt(sk, ct, &jobs[0]);
+  PolicyMemo memo;
+  plan_decrypt(memo, sk, ct, &jobs[0]);
   if (jobs[0].base.empty()) return ct.e1;
   return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const KpAbeSecretKey*>& sks, const std::vector<const KpAbeCiphertext*>& cts) {
   if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
-  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(*sks[i], *cts[i], j); });
+  PolicyMemo memo;
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(memo, *sks[i], *cts[i], j); });
   std::vector<const Bytes*> sealed;
   for (const auto* c : cts) sealed.push_back(&c->ct);
   return open_jobs(eng, jobs, sealed);
@@ -1017,15 +1105,15 @@ Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std
                        PolicyLanguage language, const Bytes& data) {       // :241-289
   return encrypt_batch(eng, rng, gk, pks, {policy}, language, {data})[0];
 }
-static void plan_decrypt(const G1& hash, const Aw11SecretKey& sk, const Aw11Ciphertext& ct, PairingJob* job) {       // :298-366
+static void plan_decrypt(PolicyMemo& memo, const G1& hash, const Aw11SecretKey& sk, const Aw11Ciphertext& ct, PairingJob* job) {       // :298-366
   std::vector<std::string> str_attr;
   for (const auto& v : sk.attr) str_attr.push_back(v.first);
-  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  const PolicyMemo::Entry& pe = memo.get(ct.policy.first, ct.policy.second);
+  const PolicyNode& tree = pe.tree;
   if (!traverse_policy(str_attr, tree)) throw RabeError("Error: attributes in sk do not match policy in ct.");
   PrunedList list;
   bool ok = calc_pruned(str_attr, tree, &list);
-  NamedFr coeff_list;
-  calc_coefficients(tree, fr_one(), &coeff_list);
+  const NamedFr& coeff_list = pe.coeff;
   if (!ok) throw RabeError("Error in aw11/decrypt: attributes in sk do not match policy in ct.");
   // egg_s = prod ( C1 * e(H, C3) / e(K, C2) )^c ; msg = c_0 / egg_s
   //       = c_0 * prod C1^(-c) * FE( prod ML(-c H, C3) ML(c K, C2) ),  H = g1*h(gid)        
@@ -1051,7 +1139,8 @@ static void plan_decrypt(const G1& hash, const Aw11SecretKey& sk, const Aw11Ciph
 Gt decrypt_gt(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, const Aw11Ciphertext& ct) {
   G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];
   std::vector<PairingJob> jobs(1);
-  plan_decrypt(hash, sk, ct, &jobs[0]);
+  PolicyMemo memo;
+  plan_decrypt(memo, hash, sk, ct, &jobs[0]);
   if (jobs[0].base.empty()) return ct.c_0;
   return run_pairing_jobs(eng, jobs)[0];
 }
@@ -1065,7 +1154,8 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, c
   std::vector<Fr> hk;
   for (const auto* sk : sks) hk.push_back(sha3_hash_fr(sk->gid));
   std::vector<G1> hashes = sks.empty() ? std::vector<G1>() : eng.g1_mul(std::vector<G1>(sks.size(), gk.g1), hk);
-  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(hashes[i], *sks[i], *cts[i], j); });
+  PolicyMemo memo;
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(memo, hashes[i], *sks[i], *cts[i], j); });
   std::vector<const Bytes*> sealed;
   for (const auto* c : cts) sealed.push_back(&c->ct);
   return open_jobs(eng, jobs, sealed);

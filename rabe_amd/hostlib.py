@@ -100,6 +100,10 @@ class Host:
         data = b"".join(int(v).to_bytes(32, "little") for v in fr_values)
         _check(self.lib.rabe_host_set_tape(self.h, data, ctypes.c_size_t(len(fr_values))), self.h)
 
+    def set_fixed_base_min(self, n):
+        """elements sharing one base before G*Fr / Gt^Fr calls switch to a cached fixed-base table (results are the same)"""
+        _check(self.lib.rabe_host_set_fixed_base_min(self.h, ctypes.c_size_t(int(n))), self.h)
+
     def clear_tape(self):
         _check(self.lib.rabe_host_set_tape(self.h, None, ctypes.c_size_t(0)), self.h)
 

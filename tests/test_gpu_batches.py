@@ -90,3 +90,28 @@ def test_aw11_encrypt_decrypt_batch(host):
     assert [c.serialize() for c in batch] == [c.serialize() for c in singles]
     assert aw11.decrypt_batch(host, gk, [alice] * 4, batch) == PTS[:4]
     assert aw11.decrypt_batch(host, gk, [bob, alice, bob, bob], batch) == [None, PTS[1], PTS[2], None]
+
+
+def test_fixed_base_tables_do_not_change_results(host):
+    """The host layer serves repeated-base G*Fr / Gt^Fr from cached window tables once a call is large enough;
+    forcing the table path and forcing the generic path must give identical bytes (bsw, lsw, aw11 on one tape)."""
+    pk, msk = bsw.setup(host)
+    lpk, lmsk = lsw.setup(host)
+    gk = aw11.setup(host)
+    apk, amsk = aw11.authgen(host, gk, ["A", "B", "C"])
+    policy = gate("and", leaf("A"), gate("or", leaf("B"), leaf("C")))
+    outs = []
+    for n_min in (1, 1 << 40):
+        host.set_fixed_base_min(n_min)
+        host.set_tape(tape(9))
+        ct = bsw.encrypt(host, pk, policy, hl.JSON_POLICY, PTS[0])
+        sk = bsw.keygen(host, pk, msk, ["A", "B"])
+        lsk = lsw.keygen(host, lpk, lmsk, policy, hl.JSON_POLICY)
+        lct = lsw.encrypt(host, lpk, ["A", "C"], PTS[1])
+        act = aw11.encrypt(host, gk, [apk], policy, hl.JSON_POLICY, PTS[2])
+        host.clear_tape()
+        outs.append([x.serialize() for x in (ct, sk, lsk, lct, act)])
+        assert bsw.decrypt(host, sk, ct) == PTS[0]
+        assert lsw.decrypt(host, lsk, lct) == PTS[1]
+    host.set_fixed_base_min(4096)
+    assert outs[0] == outs[1]
