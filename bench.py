@@ -42,7 +42,7 @@ SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 6
 SURVEY_MIXED_ADD_FPMUL = 11
 IMPL_MILLER_FPMUL = 8983            # tools/count_muls.py: miller_loop (NAF chain) with Jacobian P
 IMPL_MILLER2_FPMUL = 12170          # tools/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
-IMPL_FINAL_EXP_FPMUL = 8940
+IMPL_FINAL_EXP_FPMUL = 7553         # tools/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
 
 
 def parse_args():

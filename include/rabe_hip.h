@@ -120,6 +120,8 @@ int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t);
  * mixed additions (11 at 24 bits, 10 at 26) for 64 B x 2^(w_bits-1) x ceil(254 / w_bits) of HBM (5.4 GB at 24 bits,
  * 19 GB at 26) -- memory traded for work on a 288 GB part.  Results are the same group elements, hence the same bytes. */
 int32_t rhip_g1_table_add_wide(rhip_ctx* ctx, rhip_g1_table* t, int32_t w_bits);
+/* the same for a G2 base (16 x 65535 x 128 B = 134 MB; rhip_ac17_pk_create does this for h_a[0..2]) */
+int32_t rhip_g2_table_add_w16(rhip_ctx* ctx, rhip_g2_table* t);
 /* the same for a Gt base (16 x 65535 x 384 B = 402 MB): halves the multiplications of a fixed-base Gt power */
 int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t);
 void rhip_g1_table_destroy(rhip_g1_table* t);

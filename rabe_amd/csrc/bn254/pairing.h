@@ -360,38 +360,45 @@ template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) {      // fp12_inv
   const Fp6 ti = fp6_inv(t);
   ws.st(dst, Fp12{fp6_mul(x.c0, ti), fp6_neg(fp6_mul(x.c1, ti))});
 }
-// dst = a^(2^n) * (b >= 0 ? b : 1): a run of cyclotomic squarings and the multiplication that ends it stay in registers
-template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b) {
+// dst = a^(2^n) * (b >= 0 ? b (conjugated if conj_b) : 1): a run of cyclotomic squarings and the multiplication that
+// ends it stay in registers
+template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b, bool conj_b) {
   Fp12 x = ws.ld(a);
 #pragma unroll 1
   for (int i = 0; i < n; i++) x = fp12_cyclotomic_sqr(x);
-  if (b >= 0) x = fp12_mul(x, ws.ld(b));
+  if (b >= 0) {
+    Fp12 y = ws.ld(b);
+    if (conj_b) y = fp12_conj(y);
+    x = fp12_mul(x, y);
+  }
   ws.st(dst, x);
 }
-template <class WS> RB_FN void wsx_exp_u(WS ws, int dst, int src) {   // dst = src^u, dst != src
-  int cur = src, n = 0;
-  for (int i = 61; i >= 0; i--) {
-    n++;
-    if ((RB_BN_U >> i) & 1ull) {
-      wsx_sqrn_mul(ws, dst, cur, n, src);
-      cur = dst;
-      n = 0;
-    }
+// dst = src^u over the width-3 NAF of u (digits +-1, +-3; an inverse in the cyclotomic subgroup is a conjugation):
+// 62 squarings + 17 multiplications + f^3, instead of 62 + 27 for the binary chain.  dst, src, cube distinct slots.
+template <class WS> RB_FN void wsx_exp_u(WS ws, int dst, int src, int cube) {
+  constexpr signed char SQ[RB_U_WNAF_STEPS] = RB_U_WNAF_SQ;
+  constexpr signed char DG[RB_U_WNAF_STEPS] = RB_U_WNAF_DG;
+  wsx_sqrn_mul(ws, cube, src, 1, src, false);               // f^3 = f^2 * f
+  int cur = (RB_U_WNAF_TOP == 3) ? cube : src;
+  for (int i = 0; i < RB_U_WNAF_STEPS; i++) {
+    const int d = DG[i];
+    wsx_sqrn_mul(ws, dst, cur, SQ[i], (d == 1 || d == -1) ? src : cube, d < 0);
+    cur = dst;
   }
-  if (n) wsx_sqrn_mul(ws, dst, cur, n, -1);
+  if (RB_U_WNAF_TAIL) wsx_sqrn_mul(ws, dst, cur, RB_U_WNAF_TAIL, -1, false);
 }
 // in: slot FE_T0 = the Miller value; out: slot FE_T1.  Same chain as final_exponentiation above.
 template <class WS> RB_FN void final_exponentiation_ws(WS ws) {
   wsx_inv(ws, FE_T1, FE_T0);
   wsx_mul(ws, FE_T1, FE_T0, true, FE_T1, false);       // f^(p^6-1) = conj(f) * f^-1
   wsx_frob_mul(ws, FE_F, FE_T1, 2, FE_T1);             // ^(p^2+1)                                   F
-  wsx_exp_u(ws, FE_T0, FE_F);                          // f^u        (a = conj of it)
+  wsx_exp_u(ws, FE_T0, FE_F, FE_T1);                   // f^u        (a = conj of it)
   wsx_csqr(ws, FE_B, FE_T0, true);                     // b = a^2                                    B
   wsx_csqr(ws, FE_T0, FE_B, false);                    // c = b^2
   wsx_mul(ws, FE_D, FE_T0, false, FE_B, false);        // d = c*b                                    D
-  wsx_exp_u(ws, FE_E, FE_D);                           // d^u        (e = conj of it)
+  wsx_exp_u(ws, FE_E, FE_D, FE_T1);                    // d^u        (e = conj of it)
   wsx_csqr(ws, FE_T0, FE_E, true);                     // f' = e^2
-  wsx_exp_u(ws, FE_T1, FE_T0);                         // f'^u = conj(g) = i
+  wsx_exp_u(ws, FE_T1, FE_T0, FE_K);                   // f'^u = conj(g) = i
   wsx_mul(ws, FE_T0, FE_T1, false, FE_E, true);        // j = i*e
   wsx_mul(ws, FE_K, FE_T0, false, FE_D, true);         // k = j*h, h = d^-1                          K
   wsx_mul(ws, FE_L, FE_K, false, FE_B, false);         // l = k*b                                    L

@@ -513,7 +513,7 @@ __host__ __device__ inline size_t wide_count(int w, int i) {
   return (i < n - 1) ? ((size_t)1 << (w - 1)) : ((size_t)1 << (254 - w * (n - 1)));
 }
 __host__ __device__ inline size_t wide_offset(int w, int i) { return (size_t)i << (w - 1); }   // windows below the top are full
-struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; };
+struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; G2M* dev16; };   // dev16: optional 16-bit windows (134 MB)
 struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optional 16-bit windows (402 MB)
 
 __device__ __forceinline__ void window_scalar(uint32_t k[8], int w, int d) {
@@ -568,6 +568,17 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_build_g1_wide(const 
   const G1Jac r = table_mul_g1(t8, m);
   const Fp zinv = block_batch_inverse_256(sh, r.z);     // never infinity: 0 < m, m is not a multiple of r
   if (active) st_g1_m(out + t, jac_to_aff_with_zinv(r, zinv));
+}
+// the same for a G2 base (AC17's h_a[j]): T16[w][d-1] = T8[2w][d & 255] + T8[2w+1][d >> 8]   (134 MB)
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_build_g2_w16(const G2M* t8, G2M* t16) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)TBL16_WINDOWS * TBL16_DIGITS) return;
+  const uint32_t w = (uint32_t)(t / TBL16_DIGITS), d = (uint32_t)(t % TBL16_DIGITS) + 1;
+  const uint32_t lo = d & 255u, hi = d >> 8;
+  G2Jac acc = jac_inf<Fp2>();
+  if (lo) acc = jac_add_aff(acc, ld_g2_m(t8 + (2 * w) * TBL_DIGITS + (lo - 1)));
+  if (hi) acc = jac_add_aff(acc, ld_g2_m(t8 + (2 * w + 1) * TBL_DIGITS + (hi - 1)));
+  st_g2_m(t16 + t, jac_to_aff(acc));
 }
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_build_g2(const rhip_g2* base, G2M* tbl) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -723,6 +734,26 @@ __device__ __noinline__ G2Jac table_mul_g2(const G2M* tbl, const uint32_t k[8]) 
   for (int w = 0; w < TBL_WINDOWS; w++) {
     uint32_t d = scalar_byte(k, w);
     if (d) acc = jac_add_aff(acc, ld_g2_m(tbl + w * TBL_DIGITS + (d - 1)));
+  }
+  return acc;
+}
+__device__ __noinline__ G2Jac table_mul_g2_w16(const G2M* tbl, const uint32_t k[8]) {
+  G2Jac acc = jac_inf<Fp2>();
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    uint32_t word;
+    switch (w >> 1) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+    if (d) acc = jac_add_aff(acc, ld_g2_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1)));
   }
   return acc;
 }
@@ -903,7 +934,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g
 }
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
-                                                     const rhip_fr* s, rhip_g2* c0) {
+                                                     const rhip_fr* s, rhip_g2* c0, int w16) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * 3) return;
   size_t item = t / 3;
@@ -916,7 +947,7 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0
     from_mont<FrParams>(kk, sum);
   }
   const G2M* tbl = (j == 0) ? t0 : (j == 1) ? t1 : t2;
-  store_g2(c0[t].l, jac_to_aff(table_mul_g2(tbl, kk)));
+  store_g2(c0[t].l, jac_to_aff(w16 ? table_mul_g2_w16(tbl, kk) : table_mul_g2(tbl, kk)));
 }
 // one lane per item: c_p = e_gh_ka0^s0 * e_gh_ka1^s1 * msg
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0, const GtM* e1, size_t n_items, const rhip_fr* s,
@@ -1436,7 +1467,19 @@ extern "C" int32_t rhip_g1_table_add_w16(rhip_ctx* ctx, rhip_g1_table* t) {
   t->dev16 = d16;
   return RHIP_OK;
 }
-extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { (void)hipFree(t->dev); delete t; } }
+extern "C" void rhip_g2_table_destroy(rhip_g2_table* t) { if (t) { (void)hipFree(t->dev); if (t->dev16) (void)hipFree(t->dev16); delete t; } }
+extern "C" int32_t rhip_g2_table_add_w16(rhip_ctx* ctx, rhip_g2_table* t) {
+  NEED(ctx);
+  if (!t) return RHIP_ERR_ARG;
+  if (t->dev16) return RHIP_OK;
+  G2M* d16 = nullptr;
+  const size_t n = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  HIP_TRY(ctx, hipMalloc((void**)&d16, sizeof(G2M) * n));
+  KLAUNCH(ctx, "k_table_build_g2_w16", k_table_build_g2_w16, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, (const G2M*)t->dev, d16);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t->dev16 = d16;
+  return RHIP_OK;
+}
 extern "C" void rhip_gt_table_destroy(rhip_gt_table* t) { if (t) { (void)hipFree(t->dev); if (t->dev16) (void)hipFree(t->dev16); delete t; } }
 extern "C" int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t) {
   NEED(ctx);
@@ -1491,7 +1534,10 @@ extern "C" int32_t rhip_ac17_pk_create(rhip_ctx* ctx, const rhip_g1* g, const rh
   for (int i = 0; i < 2; i++) pk->e[i] = nullptr;
   int32_t rc = rhip_g1_table_create(ctx, g, &pk->g);
   if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->g);
-  for (int i = 0; i < 3 && !rc; i++) rc = rhip_g2_table_create(ctx, h_a + i, &pk->h_a[i]);
+  for (int i = 0; i < 3 && !rc; i++) {
+    rc = rhip_g2_table_create(ctx, h_a + i, &pk->h_a[i]);
+    if (!rc) rc = rhip_g2_table_add_w16(ctx, pk->h_a[i]);
+  }
   for (int i = 0; i < 2 && !rc; i++) {
     rc = rhip_gt_table_create(ctx, e + i, &pk->e[i]);
     if (!rc) rc = rhip_gt_table_add_w16(ctx, pk->e[i]);
@@ -1517,8 +1563,10 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
             (const G1M*)(g->wide ? g->wide : g->dev16 ? g->dev16 : g->dev), n_items, total_rows, A, item_A_off, ct_row_off, s, c,
             g->wide ? g->wide_bits : g->dev16 ? 1 : 0);
   }
-  KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)pk->h_a[0]->dev,
-                     (const G2M*)pk->h_a[1]->dev, (const G2M*)pk->h_a[2]->dev, n_items, s, c0);
+  const bool g2w16 = pk->h_a[0]->dev16 && pk->h_a[1]->dev16 && pk->h_a[2]->dev16;
+  KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream,
+          (const G2M*)(g2w16 ? pk->h_a[0]->dev16 : pk->h_a[0]->dev), (const G2M*)(g2w16 ? pk->h_a[1]->dev16 : pk->h_a[1]->dev),
+          (const G2M*)(g2w16 ? pk->h_a[2]->dev16 : pk->h_a[2]->dev), n_items, s, c0, g2w16 ? 1 : 0);
   const bool gt16 = pk->e[0]->dev16 && pk->e[1]->dev16;
   KLAUNCH(ctx, "k_ac17_enc_cp", k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream,
           (const GtM*)(gt16 ? pk->e[0]->dev16 : pk->e[0]->dev), (const GtM*)(gt16 ? pk->e[1]->dev16 : pk->e[1]->dev), n_items, s, msg, cp,

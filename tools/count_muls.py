@@ -48,6 +48,7 @@ res["g2_prepare_lines (88 line triples) incl. io"] = count("hs_g2_prepare", Q, o
 m = (ctypes.c_uint32 * 96)()
 HS.hs_miller(b2c(P), b2c(Q), m)
 res["final_exponentiation incl. 12 loads 12 stores"] = count("hs_final_exp", bytes(m))
+res["final_exponentiation over workspace slots, wNAF(3) chain (as k_final_exp) incl. 12 loads 12 stores"] = count("hs_final_exp_ws", bytes(m))
 f = bn.gt_to_le(bn.pairing(p, q))
 res["fp12_mul incl. 24 loads 12 stores"] = count("hs_fp12_mul", f, f)
 res["fp12_cyclotomic_sqr incl. 12 loads 12 stores"] = count("hs_fp12_cyclotomic_sqr", f)
