@@ -882,15 +882,79 @@ __device__ __noinline__ Fp block_batch_inverse_256(uint32_t (*sh)[256], const Fp
   return r;
 }
 
+// Block size of the G1 row kernels = the group that shares one field inversion.  The inversion (361 multiplications,
+// executed by wave 0 while the block's other waves wait at the barrier) is a fixed cost per block: 28 % of the block's
+// issue slots at 256 threads (4 waves x ~340 multiplications of useful work each), 15 % at 512, 8 % at 1024.
+#ifndef RB_ROWS_BLOCK
+#define RB_ROWS_BLOCK 512
+#endif
+// Generalisation of block_batch_inverse_256 to NT = 64 E threads: lane j of wave 0 owns elements j, j + 64, ...,
+// j + 64 (E - 1) (conflict-free), keeps their running products in a second LDS array, joins the 64-lane scan, and
+// back-substitutes.  lds: 2 x 8 x NT words.  All NT threads must call this.
+template <int NT>
+__device__ __noinline__ Fp block_batch_inverse_n(uint32_t* lds, const Fp& mine) {
+  uint32_t (*val)[NT] = (uint32_t (*)[NT])lds;
+  uint32_t (*pre)[NT] = (uint32_t (*)[NT])(lds + 8 * NT);
+  constexpr int E = NT / 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) val[i][tid] = mine.v[i];
+  __syncthreads();
+  if (tid < 64) {
+    Fp run;
+#pragma unroll
+    for (int i = 0; i < 8; i++) run.v[i] = val[i][tid];
+#pragma unroll 1
+    for (int e = 1; e < E; e++) {
+      Fp v;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { pre[i][tid + 64 * (e - 1)] = run.v[i]; v.v[i] = val[i][tid + 64 * e]; }
+      run = mul(run, v);
+    }
+    Fp prefix = run, suffix = run;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      Fp u = shfl_up_fp(prefix, d);
+      Fp w = shfl_down_fp(suffix, d);
+      Fp pu = mul(prefix, u);
+      Fp sw = mul(suffix, w);
+      prefix = sel_fp(tid >= d, pu, prefix);
+      suffix = sel_fp(tid + d < 64, sw, suffix);
+    }
+    const Fp total_inv = inv(shfl_fp(prefix, 63));
+    Fp ex_pre = shfl_up_fp(prefix, 1), ex_suf = shfl_down_fp(suffix, 1);
+    ex_pre = sel_fp(tid >= 1, ex_pre, one<FpParams>());
+    ex_suf = sel_fp(tid < 63, ex_suf, one<FpParams>());
+    Fp inv_run = mul(total_inv, mul(ex_pre, ex_suf));       // 1 / (product of this lane's E elements)
+#pragma unroll 1
+    for (int e = E - 1; e >= 1; e--) {
+      Fp v, p;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { v.v[i] = val[i][tid + 64 * e]; p.v[i] = pre[i][tid + 64 * (e - 1)]; }
+      const Fp r = mul(inv_run, p);                          // 1 / v_e
+      inv_run = mul(inv_run, v);                             // 1 / (v_0 .. v_{e-1})
+#pragma unroll
+      for (int i = 0; i < 8; i++) val[i][tid + 64 * e] = r.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) val[i][tid] = inv_run.v[i];
+  }
+  __syncthreads();
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = val[i][tid];
+  return r;
+}
+
 // three Jacobian points -> affine canonical with ONE field inversion per BLOCK (Montgomery's trick twice:
-// over the thread's three z's, then over the block's 256 products).  Inactive threads pass active = false.
-__device__ __noinline__ void store3_g1_block(uint32_t (*sh)[256], bool active, rhip_g1* out, const G1Jac& a, const G1Jac& b, const G1Jac& c) {
+// over the thread's three z's, then over the block's products).  Inactive threads pass active = false.
+__device__ __noinline__ void store3_g1_block(uint32_t* lds, bool active, rhip_g1* out, const G1Jac& a, const G1Jac& b, const G1Jac& c) {
   // infinity has z = 0: substitute 1 so the product stays invertible, emit zeros for that slot
   const bool ia = !active || jac_is_inf(a), ib = !active || jac_is_inf(b), ic = !active || jac_is_inf(c);
   Fp za = ia ? one<FpParams>() : a.z, zb = ib ? one<FpParams>() : b.z, zc = ic ? one<FpParams>() : c.z;
   Fp ab = mul(za, zb);
   Fp abc = mul(ab, zc);
-  Fp inv_abc = block_batch_inverse_256(sh, abc);
+  Fp inv_abc = block_batch_inverse_n<RB_ROWS_BLOCK>(lds, abc);
   if (!active) return;
   Fp zc_inv = mul(inv_abc, ab);
   Fp inv_ab = mul(inv_abc, zc);
@@ -904,10 +968,10 @@ __device__ __noinline__ void store3_g1_block(uint32_t (*sh)[256], bool active, r
 // one lane per ciphertext row (items may carry different policies):
 //   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
 //   row_off[i] <= row < row_off[i+1] and a = item_A_off[item] + (row - row_off[item]).
-__global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
+__global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_enc_rows(const G1M* g_tbl, size_t n_items, size_t total_rows, const rhip_fr* A,
                                                        const uint32_t* item_A_off, const uint32_t* row_off, const rhip_fr* s, rhip_g1* c,
                                                        int w16) {
-  __shared__ uint32_t sh[8][256];
+  __shared__ uint32_t sh[2 * 8 * RB_ROWS_BLOCK];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = t < total_rows;
   if (!active) t = total_rows - 1;          // inactive lanes shadow the last row (no stores) and still join the block inversion
@@ -964,11 +1028,11 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0,
 // keygen: one lane per (item, y <= n_attrs); y == n_attrs is the k_p row.
 //   K[y][t]  = g * ((sum_l H[y][l][t]*br_l + sigma_y) * a_t^-1),  K[y][2] = g * (-sigma_y)
 //   k_p[t]   = g_k[t] + g * ((sum_l H01[l][t]*br_l + sigma') * a_t^-1), k_p[2] = g_k[2] + g*(-sigma')
-__global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
+__global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_keygen_rows(const G1M* g_tbl, const rhip_g1* g_k, const rhip_fr* a_inv, const rhip_fr* b,
                                                           size_t n_items, size_t n_attrs, const rhip_fr* H, const rhip_fr* H01,
                                                           const rhip_fr* r, const rhip_fr* sigma, const rhip_fr* sigma_p,
-                                                          rhip_g1* k_out, rhip_g1* kp_out) {
-  __shared__ uint32_t sh[8][256];
+                                                          rhip_g1* k_out, rhip_g1* kp_out, int w16) {
+  __shared__ uint32_t sh[2 * 8 * RB_ROWS_BLOCK];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = n_attrs + 1;
   const bool active = t < n_items * per;
@@ -996,7 +1060,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M
     }
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
-    G1Jac rj = table_mul_g1(g_tbl, kk);
+    G1Jac rj = (w16 > 16) ? table_mul_g1_wide(g_tbl, kk, w16) : w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (is_kp) rj = jac_add_aff(rj, load_g1(g_k[tt].l));
     if (tt == 0) pt[0] = rj; else if (tt == 1) pt[1] = rj; else pt[2] = rj;
   }
@@ -1004,7 +1068,8 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_ac17_keygen_rows(const G1M
   store3_g1_block(sh, active, dst, pt[0], pt[1], pt[2]);
 }
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0,
+                                                                      int w16) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * 3) return;
   size_t item = t / 3;
@@ -1013,7 +1078,7 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M*
   Fr k = (j == 0) ? mul(load_fr(b[0].l), r0) : (j == 1) ? mul(load_fr(b[1].l), r1) : add(r0, r1);
   uint32_t kk[8];
   from_mont<FrParams>(kk, k);
-  store_g2(k0[t].l, jac_to_aff(table_mul_g2(h_tbl, kk)));
+  store_g2(k0[t].l, jac_to_aff(w16 ? table_mul_g2_w16(h_tbl, kk) : table_mul_g2(h_tbl, kk)));
 }
 
 // decrypt: one lane per (item, i < 6).
@@ -1559,7 +1624,7 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
   if (!n_items) return RHIP_OK;
   if (total_rows) {
     const rhip_g1_table* g = pk->g;
-    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream,
+    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, RB_ROWS_BLOCK)), dim3(RB_ROWS_BLOCK), 0, ctx->stream,
             (const G1M*)(g->wide ? g->wide : g->dev16 ? g->dev16 : g->dev), n_items, total_rows, A, item_A_off, ct_row_off, s, c,
             g->wide ? g->wide_bits : g->dev16 ? 1 : 0);
   }
@@ -1580,10 +1645,11 @@ extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table*
   NEED(ctx);
   if (!g_table || !h_table) return RHIP_ERR_ARG;
   if (!n_items) return RHIP_OK;
-  KLAUNCH(ctx, "k_ac17_keygen_rows", k_ac17_keygen_rows, dim3(blocks_for(n_items * (n_attrs + 1), 256)), dim3(256), 0, ctx->stream,
-                     (const G1M*)g_table->dev, g_k, a_inv, b, n_items, n_attrs, H, H01, r, sigma, sigma_p, k, kp);
-  KLAUNCH(ctx, "k_ac17_keygen_k0", k_ac17_keygen_k0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream, (const G2M*)h_table->dev, b,
-                     n_items, r, k0);
+  KLAUNCH(ctx, "k_ac17_keygen_rows", k_ac17_keygen_rows, dim3(blocks_for(n_items * (n_attrs + 1), RB_ROWS_BLOCK)), dim3(RB_ROWS_BLOCK), 0, ctx->stream,
+                     (const G1M*)(g_table->wide ? g_table->wide : g_table->dev16 ? g_table->dev16 : g_table->dev), g_k, a_inv, b, n_items, n_attrs, H, H01,
+                     r, sigma, sigma_p, k, kp, g_table->wide ? g_table->wide_bits : g_table->dev16 ? 1 : 0);
+  KLAUNCH(ctx, "k_ac17_keygen_k0", k_ac17_keygen_k0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream,
+          (const G2M*)(h_table->dev16 ? h_table->dev16 : h_table->dev), b, n_items, r, k0, h_table->dev16 ? 1 : 0);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,

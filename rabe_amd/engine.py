@@ -228,6 +228,15 @@ class _Table:
         raw = eng.download(out, n * sz)
         return [raw[i * sz:(i + 1) * sz] for i in range(n)]
 
+    def add_w16(self):
+        """16-bit windows beside the 8-bit ones (rhip_{g1,g2,gt}_table_add_w16)"""
+        self.eng._check(getattr(self.eng.lib, "rhip_%s_table_add_w16" % self.kind)(self.eng.ctx, self.h))
+
+    def add_wide(self, w_bits):
+        """signed w_bits-wide windows (G1 only, rhip_g1_table_add_wide)"""
+        assert self.kind == "g1"
+        self.eng._check(self.eng.lib.rhip_g1_table_add_wide(self.eng.ctx, self.h, ctypes.c_int32(int(w_bits))))
+
     def destroy(self):
         if self.h:
             getattr(self.eng.lib, "rhip_%s_table_destroy" % self.kind)(self.h)

@@ -88,6 +88,14 @@ def test_cp_keygen_matches_reference_order(env):
     dsigp = eng.upload(host.le(sigp) * n_items)
     dk0, dk, dkp = eng.alloc(n_items * 384), eng.alloc(n_items * len(attrs) * 192), eng.alloc(n_items * 192)
     E.ac17_keygen_dev(eng, g_tab, h_tab, dgk, dainv, db, n_items, len(attrs), eng.upload(H), eng.upload(H01), dr, dsig, dsigp, dk0, dk, dkp)
+    first = (eng.download(dk0), eng.download(dk), eng.download(dkp))
+    # the same launch over 16-bit windows (g, h) and then signed 18-bit windows for g: identical key bytes
+    g_tab.add_w16(); h_tab.add_w16()
+    E.ac17_keygen_dev(eng, g_tab, h_tab, dgk, dainv, db, n_items, len(attrs), eng.upload(H), eng.upload(H01), dr, dsig, dsigp, dk0, dk, dkp)
+    assert (eng.download(dk0), eng.download(dk), eng.download(dkp)) == first
+    g_tab.add_wide(18)
+    E.ac17_keygen_dev(eng, g_tab, h_tab, dgk, dainv, db, n_items, len(attrs), eng.upload(H), eng.upload(H01), dr, dsig, dsigp, dk0, dk, dkp)
+    assert (eng.download(dk0), eng.download(dk), eng.download(dkp)) == first
     k0, k, kp = eng.download(dk0), eng.download(dk), eng.download(dkp)
     w_k0 = b"".join(bn.g2_to_le(x) for x in want["sk"]["k_0"])
     w_k = b"".join(bn.g1_to_le(p) for _, vec in want["sk"]["k"] for p in vec)
