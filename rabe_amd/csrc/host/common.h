@@ -126,6 +126,8 @@ class Engine {
   // are served from per-base window tables built on first use and cached here: 32 mixed additions per element
   // instead of 254 doublings + ~127 additions.  Same group elements, hence the same bytes.  Building a table costs
   // 8 160 variable-base multiplications, so it pays for itself from a few thousand elements per base on (Gt: more).
+  // device tables of AC17 public keys (g, h_a[3], e_gh_ka[2]; ~1.3 GB each with the 16-bit windows), built on first use
+  rhip_ac17_pk* ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka);
   size_t fixed_base_min = 4096;   // G1 / G2 elements sharing one base in one call; Gt uses twice that
 
  private:
@@ -135,6 +137,7 @@ class Engine {
   std::map<std::string, rhip_g1_table*> t1_;
   std::map<std::string, rhip_g2_table*> t2_;
   std::map<std::string, rhip_gt_table*> tt_;
+  std::map<std::string, rhip_ac17_pk*> pk17_;
   void destroy_table(rhip_g1_table* t);
   void destroy_table(rhip_g2_table* t);
   void destroy_table(rhip_gt_table* t);

@@ -25,7 +25,24 @@ Engine::Engine(int device) {
   int32_t rc = rhip_ctx_create(device, &ctx_);
   if (rc != RHIP_OK) throw RabeError(std::string("no usable HIP device: ") + rhip_last_error(nullptr));
 }
+rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka) {
+  auto fha = flatten(h_a), fe = flatten(e_gh_ka);
+  std::string key((const char*)g.data(), g.size());
+  key.append((const char*)fha.data(), fha.size());
+  key.append((const char*)fe.data(), fe.size());
+  auto it = pk17_.find(key);
+  if (it != pk17_.end()) return it->second;
+  if (pk17_.size() >= 4) {                       // bounded: each entry holds ~1.3 GB of tables
+    for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
+    pk17_.clear();
+  }
+  rhip_ac17_pk* dpk = nullptr;
+  check(rhip_ac17_pk_create(ctx_, (const rhip_g1*)g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk), "rhip_ac17_pk_create");
+  pk17_[key] = dpk;
+  return dpk;
+}
 Engine::~Engine() {
+  for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
   for (auto& c : t1_) rhip_g1_table_destroy(c.second);
   for (auto& c : t2_) rhip_g2_table_destroy(c.second);
   for (auto& c : tt_) rhip_gt_table_destroy(c.second);
@@ -429,10 +446,7 @@ std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17
     row_off[i + 1] = row_off[i] + (uint32_t)msps[item_pol[i]].m.size();
   }
   const size_t total_rows = row_off[n];
-  rhip_ac17_pk* dpk = nullptr;
-  auto fha = flatten(pk.h_a), fe = flatten(pk.e_gh_ka);
-  eng.check(rhip_ac17_pk_create(eng.ctx(), (const rhip_g1*)pk.g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk),
-            "rhip_ac17_pk_create");
+  rhip_ac17_pk* dpk = eng.ac17_pk(pk.g, pk.h_a, pk.e_gh_ka);
   auto fA = flatten_fr(A), fs = flatten_fr(s), fm = flatten(msgs);
   DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, item_a_off.data(), n * 4), dro(&eng, row_off.data(), (n + 1) * 4), ds(&eng, fs.data(), fs.size()),
       dm(&eng, fm.data(), fm.size()), dc0(&eng, n * 3 * 128), dc(&eng, total_rows * 3 * 64), dcp(&eng, n * 384);
@@ -442,7 +456,6 @@ std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17
   std::vector<G1> c;
   std::vector<Gt> cp;
   if (rc == RHIP_OK) { c0 = fetch<128>(dc0, n * 3); c = fetch<64>(dc, total_rows * 3); cp = fetch<384>(dcp, n); }
-  rhip_ac17_pk_destroy(dpk);
   eng.check(rc, "rhip_ac17_cp_encrypt_batch");
   std::vector<Ac17CpCiphertext> out(n);
   for (size_t i = 0; i < n; i++) {
@@ -481,6 +494,7 @@ static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& it
   std::vector<uint8_t> ct_c0, ct_c, ct_cp, sk_k0, sk_k, sk_kp;
   std::vector<uint32_t> ct_row_off{0}, sk_row_off{0}, sk_idx, ct_sel, sk_sel, ct_sel_off{0}, sk_sel_off{0};
   std::vector<size_t> live;
+  std::map<const Ac17SecretKey*, uint32_t> key_slot;       // items that share a key object share its device copy (and its prepared lines)
   for (size_t i = 0; i < n; i++) {
     const DecItem& it = items[i];
     PolicyNode tree = parse_or_error(it.policy->first, it.policy->second);
@@ -498,12 +512,16 @@ static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& it
     for (const auto& row : it.ct->c) for (const auto& x : row.second) ct_c.insert(ct_c.end(), x.begin(), x.end());
     ct_cp.insert(ct_cp.end(), it.ct->c_p.begin(), it.ct->c_p.end());
     ct_row_off.push_back(ct_row_off.back() + (uint32_t)it.ct->c.size());
-    for (const auto& x : it.sk->k_0) sk_k0.insert(sk_k0.end(), x.begin(), x.end());
-    for (const auto& row : it.sk->k) for (const auto& x : row.second) sk_k.insert(sk_k.end(), x.begin(), x.end());
-    if (it.sk->k_p.size() == 3) { for (const auto& x : it.sk->k_p) sk_kp.insert(sk_kp.end(), x.begin(), x.end()); }
-    else sk_kp.insert(sk_kp.end(), 3 * 64, 0);        // KP: prod_h starts from G1::zero()
-    sk_row_off.push_back(sk_row_off.back() + (uint32_t)it.sk->k.size());
-    sk_idx.push_back((uint32_t)live.size());
+    auto slot = key_slot.find(it.sk);
+    if (slot == key_slot.end()) {
+      slot = key_slot.emplace(it.sk, (uint32_t)key_slot.size()).first;
+      for (const auto& x : it.sk->k_0) sk_k0.insert(sk_k0.end(), x.begin(), x.end());
+      for (const auto& row : it.sk->k) for (const auto& x : row.second) sk_k.insert(sk_k.end(), x.begin(), x.end());
+      if (it.sk->k_p.size() == 3) { for (const auto& x : it.sk->k_p) sk_kp.insert(sk_kp.end(), x.begin(), x.end()); }
+      else sk_kp.insert(sk_kp.end(), 3 * 64, 0);        // KP: prod_h starts from G1::zero()
+      sk_row_off.push_back(sk_row_off.back() + (uint32_t)it.sk->k.size());
+    }
+    sk_idx.push_back(slot->second);
     live.push_back(i);
   }
   std::vector<Gt> out(n);
@@ -514,10 +532,22 @@ static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& it
       d7(&eng, sk_row_off.data(), sk_row_off.size() * 4), d8(&eng, sk_kp.data(), sk_kp.size()), d9(&eng, sk_idx.data(), sk_idx.size() * 4),
       d10(&eng, ct_sel.data(), ct_sel.size() * 4), d11(&eng, ct_sel_off.data(), ct_sel_off.size() * 4), d12(&eng, sk_sel.data(), sk_sel.size() * 4),
       d13(&eng, sk_sel_off.data(), sk_sel_off.size() * 4), dout(&eng, m * 384);
-  eng.check(rhip_ac17_cp_decrypt_batch(eng.ctx(), m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), d5.as<rhip_g2>(),
-                                       d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
-                                       d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>()),
-            "rhip_ac17_cp_decrypt_batch");
+  if (m >= 64) {
+    // throughput path: the keys' k_0 lines are prepared once for the call, each (item, j) lane runs both pairings
+    rhip_ac17_sk_lines* lines = nullptr;
+    eng.check(rhip_ac17_sk_prepare(eng.ctx(), key_slot.size(), d5.as<rhip_g2>(), &lines), "rhip_ac17_sk_prepare");
+    int32_t rc = rhip_ac17_cp_decrypt_batch_prepared(eng.ctx(), m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), lines,
+                                                     d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
+                                                     d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>());
+    if (rc == RHIP_OK) rc = rhip_sync(eng.ctx());
+    rhip_ac17_sk_lines_destroy(lines);
+    eng.check(rc, "rhip_ac17_cp_decrypt_batch_prepared");
+  } else {
+    eng.check(rhip_ac17_cp_decrypt_batch(eng.ctx(), m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), d5.as<rhip_g2>(),
+                                         d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
+                                         d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>()),
+              "rhip_ac17_cp_decrypt_batch");
+  }
   std::vector<Gt> got = fetch<384>(dout, m);
   for (size_t j = 0; j < m; j++) out[live[j]] = got[j];
   return out;
@@ -627,10 +657,7 @@ Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, cons
   for (const auto& a : attributes)
     for (int l = 0; l < 3; l++)
       for (int t = 0; t < 2; t++) A.push_back(sha3_hash_fr(a + std::to_string(l) + std::to_string(t)));
-  rhip_ac17_pk* dpk = nullptr;
-  auto fha = flatten(pk.h_a), fe = flatten(pk.e_gh_ka);
-  eng.check(rhip_ac17_pk_create(eng.ctx(), (const rhip_g1*)pk.g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk),
-            "rhip_ac17_pk_create");
+  rhip_ac17_pk* dpk = eng.ac17_pk(pk.g, pk.h_a, pk.e_gh_ka);
   uint32_t zero = 0, row_off[2] = {0, (uint32_t)rows};
   auto fA = flatten_fr(A), fs = flatten_fr({s0, s1});
   DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, &zero, 4), dro(&eng, row_off, 8), ds(&eng, fs.data(), fs.size()), dm(&eng, msg.data(), 384),
@@ -641,7 +668,6 @@ Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, cons
   std::vector<G1> c;
   std::vector<Gt> cp;
   if (rc == RHIP_OK) { c0 = fetch<128>(dc0, 3); c = fetch<64>(dc, rows * 3); cp = fetch<384>(dcp, 1); }
-  rhip_ac17_pk_destroy(dpk);
   eng.check(rc, "rhip_ac17_cp_encrypt_batch");
   Ac17KpCiphertext out;
   out.attr = attributes;

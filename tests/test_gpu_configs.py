@@ -40,7 +40,25 @@ def test_config2_ac17_fifty_attributes_batch(host):
     items = [policies[i % 4] for i in range(32)]
     pts = [PT + bytes([i]) for i in range(32)]
     cts = ac17.cp_encrypt_batch(host, pk, items, pts, hl.JSON_POLICY)
-    assert ac17.cp_decrypt_batch(host, [sk] * 32, cts) == pts
+    assert ac17.cp_decrypt_batch(host, [sk] * 32, cts) == pts          # < 64 items: six independent Miller loops per item
+    # >= 64 items: the host layer prepares each distinct key once and runs the paired Miller kernel; two keys
+    # alternate, a third one (one attribute short of most policies) fails its items only
+    sk2 = ac17.cp_keygen(host, msk, attrs)
+    sk_few = ac17.cp_keygen(host, msk, attrs[:1])
+    n = 96
+    items = [policies[i % 4] for i in range(n)]
+    pts = [PT + bytes([i]) for i in range(n)]
+    cts = ac17.cp_encrypt_batch(host, pk, items, pts, hl.JSON_POLICY)
+    keys = [sk_few if i % 7 == 3 else (sk if i % 2 else sk2) for i in range(n)]
+    singles = []
+    for k, c in zip(keys, cts):
+        try:
+            singles.append(ac17.cp_decrypt(host, k, c))
+        except hl.RabeError:
+            singles.append(None)
+    got = ac17.cp_decrypt_batch(host, keys, cts)
+    assert got == singles
+    assert [g for i, g in enumerate(got) if i % 7 != 3] == [p for i, p in enumerate(pts) if i % 7 != 3]
 
 
 def test_config3_bsw_hundred_leaf_tree(host):
