@@ -288,6 +288,7 @@ def main():
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # HBM side (reported, not binding): algorithmic bytes of the whole step
         alg_bytes = B * (2 * 32 + 384) + total_rows * 192 * 2 + B * (384 + 384) * 2 + len(ct_sel_all) * 4 * 2 + B * 384
+        traffic, traffic_src = pmc_traffic(dom)
         result["roofline"] = {
             "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
             "kernel_ms": round(dom_ms, 4), "achieved": round(achieved, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
@@ -295,7 +296,8 @@ def main():
             "work": "algorithmic Fp-muls/lane (SURVEY 8d) x 136 MAC32 x lanes = %.3e MAC32 per launch" % macs,
             "achieved_impl_count": round(lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL / (dom_ms * 1e-3) / 1e12, 4)
             if dom_ms > 0 else None,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
+            "traffic_source": traffic_src,
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
                     "peak_GBps": 8000},
             "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
@@ -316,6 +318,24 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/pmc_traffic.sh writes them; rocprofv3
+    cannot run inside the bench).  None when no summary names the kernel."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
+    for f in reversed(files):
+        tot, seen = 0.0, 0
+        for line in open(f):
+            m = re.match(r"(FETCH_SIZE|WRITE_SIZE) (\S+) per launch: ([0-9.]+) KB-units", line)
+            if m and m.group(2) == kernel:
+                tot += float(m.group(3)) * 1024.0
+                seen += 1
+        if seen == 2:
+            return round(tot), "profiles/" + os.path.basename(f)
+    return None, None
 
 
 def cpu_baseline(args, tree):

@@ -356,6 +356,29 @@ inline void gen_shares_policy(const Fr& secret, const PolicyNode& n, FrSource& r
   std::vector<Fr> shares = gen_shares(secret, k, cnt, rng);
   for (size_t i = 0; i < cnt; i++) gen_shares_policy(shares[i + 1], n.children[i], rng, out);
 }
+// how many Fr values gen_shares_policy draws for this tree (k - 1 per gate, k = #children for AND, 1 for OR), and its
+// leaf count: lets a batch pull every item's randomness from the generator in order and do the arithmetic in parallel
+inline size_t count_share_draws(const PolicyNode& n) {
+  if (n.type == PolicyType::Leaf) return 0;
+  size_t c = (n.type == PolicyType::And) ? n.children.size() - 1 : 0;
+  for (const auto& ch : n.children) c += count_share_draws(ch);
+  return c;
+}
+inline size_t count_leaves(const PolicyNode& n) {
+  if (n.type == PolicyType::Leaf) return 1;
+  size_t c = 0;
+  for (const auto& ch : n.children) c += count_leaves(ch);
+  return c;
+}
+struct VecFrSource : FrSource {          // replays pre-drawn values
+  const Fr* v;
+  size_t n, pos = 0;
+  VecFrSource(const Fr* values, size_t count) : v(values), n(count) {}
+  Fr next_fr() override {
+    if (pos >= n) throw PolicyPanic("pre-drawn randomness exhausted");
+    return v[pos++];
+  }
+};
 inline std::vector<Fr> recover_coefficients(const std::vector<Fr>& list) {     // Lagrange at 0, :60-72
   // res_i = prod_{j != i} (0 - j) / (i - j).  The reference inverts every (i - j) (k^2 inversions); the same field
   // element is num_i * (prod_j (i - j))^-1, and the k denominators share ONE inversion (Montgomery's trick).

@@ -3,6 +3,11 @@
 // batched launch of the HIP engine (no CPU group arithmetic exists in this layer).
 #include "schemes.h"
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include <stdio.h>
 #include <sys/random.h>
@@ -292,12 +297,41 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
   }
   return out;
 }
+// Host-side planning of a batch (share generation, hashing, pruning: string and Fr work) runs on all cores; the
+// randomness is pulled from the generator beforehand, item after item, so results do not depend on the thread count.
+static void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;
+  if (n < 16 || nt < 2) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  std::atomic<size_t> next{0};
+  std::exception_ptr first;
+  std::mutex mu;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) {
+    th.emplace_back([&]() {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n) return;
+        try {
+          fn(i);
+        } catch (...) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!first) first = std::current_exception();
+        }
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  if (first) std::rethrow_exception(first);
+}
 // Items of one batch usually repeat a few policies: the parsed tree and its Lagrange coefficients (pure functions of
 // the policy text) are computed once per distinct (text, language) within a call.
 struct PolicyMemo {
   struct Entry { PolicyNode tree; NamedFr coeff; };
   std::map<std::pair<std::string, int>, std::shared_ptr<Entry>> m;
+  std::mutex mu;
   const Entry& get(const std::string& policy, PolicyLanguage lang) {
+    std::lock_guard<std::mutex> g(mu);
     auto key = std::make_pair(policy, (int)lang);
     auto it = m.find(key);
     if (it != m.end()) return *it->second;
@@ -312,7 +346,7 @@ struct PolicyMemo {
 template <class PLAN>
 static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
   std::vector<PairingJob> jobs(n);
-  for (size_t i = 0; i < n; i++) {
+  parallel_for(n, [&](size_t i) {
     try {
       plan(i, &jobs[i]);
     } catch (const RabeError& ex) {
@@ -320,7 +354,7 @@ static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
       jobs[i].failed = true;
       jobs[i].error = ex.what();
     }
-  }
+  });
   return jobs;
 }
 
@@ -431,15 +465,15 @@ std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17
     item_pol[i] = it->second;
   }
   // randomness in the reference's per-call draw order: s0, s1, msg, nonce -- item after item
-  std::vector<Fr> s;
-  std::vector<Gt> msgs;
+  std::vector<Fr> s, msg_k;
   std::vector<std::array<uint8_t, 12>> nonces(n);
   for (size_t i = 0; i < n; i++) {
     s.push_back(rng.next_fr());
     s.push_back(rng.next_fr());
-    msgs.push_back(eng.random_gt(rng));
+    msg_k.push_back(rng.next_fr());                    // rng.gen::<Gt>() = e(G1::one(), G2::one())^Fr::random
     rng.fill(nonces[i].data(), 12);
   }
+  std::vector<Gt> msgs = n ? eng.gt_pow(std::vector<Gt>(n, eng.gt_generator()), msg_k) : std::vector<Gt>();   // one launch for the batch
   std::vector<uint32_t> item_a_off(n), row_off(n + 1, 0);
   for (size_t i = 0; i < n; i++) {
     item_a_off[i] = a_off[item_pol[i]];
@@ -819,26 +853,39 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
   const size_t n = policies.size();
   std::vector<CpAbeCiphertext> cts(n);
   // plan: every draw of item i before any draw of item i+1, in encrypt's order (secret, msg, gate coefficients, nonce)
-  struct Item { NamedFr shares; std::array<uint8_t, 12> nonce; size_t o1, o2; };
+  struct Item { NamedFr shares; std::array<uint8_t, 12> nonce; size_t o1, o2; Fr secret, msg_k; const PolicyNode* tree; std::vector<Fr> draws;
+                std::vector<Fr> k2; };
   std::vector<Item> items(n);
+  PolicyMemo memo;
+  for (size_t i = 0; i < n; i++) {              // sequential: the generator is consumed in encrypt's order
+    Item& it = items[i];
+    it.secret = rng.next_fr();
+    it.msg_k = rng.next_fr();
+    it.tree = &memo.get(policies[i], language).tree;
+    const size_t nd = count_share_draws(*it.tree);
+    for (size_t d = 0; d < nd; d++) it.draws.push_back(rng.next_fr());
+    rng.fill(it.nonce.data(), 12);
+    cts[i].policy = {policies[i], language};
+  }
+  parallel_for(n, [&](size_t i) {               // parallel: shares and label hashes
+    Item& it = items[i];
+    VecFrSource src(it.draws.data(), it.draws.size());
+    gen_shares_policy(it.secret, *it.tree, src, &it.shares);
+    for (const auto& sh : it.shares) it.k2.push_back(fr_mul(sha3_hash_fr(remove_index(sh.first)), sh.second));
+  });
   std::vector<G1> b1; std::vector<Fr> k1;
   std::vector<G2> b2; std::vector<Fr> k2;
   std::vector<Gt> bt; std::vector<Fr> kt;
   for (size_t i = 0; i < n; i++) {
-    Fr secret = rng.next_fr();
-    Fr msg_k = rng.next_fr();
-    PolicyNode tree = parse_or_error(policies[i], language);
-    gen_shares_policy(secret, tree, rng, &items[i].shares);
-    rng.fill(items[i].nonce.data(), 12);
-    cts[i].policy = {policies[i], language};
-    items[i].o1 = b1.size();
-    items[i].o2 = b2.size();
-    b1.push_back(pk.h); k1.push_back(secret);
-    bt.push_back(pk.e_gg_alpha); kt.push_back(secret);
-    bt.push_back(eng.gt_generator()); kt.push_back(msg_k);
-    for (const auto& sh : items[i].shares) {
-      b1.push_back(pk.g1); k1.push_back(sh.second);
-      b2.push_back(pk.g2); k2.push_back(fr_mul(sha3_hash_fr(remove_index(sh.first)), sh.second));
+    Item& it = items[i];
+    it.o1 = b1.size();
+    it.o2 = b2.size();
+    b1.push_back(pk.h); k1.push_back(it.secret);
+    bt.push_back(pk.e_gg_alpha); kt.push_back(it.secret);
+    bt.push_back(eng.gt_generator()); kt.push_back(it.msg_k);
+    for (size_t y = 0; y < it.shares.size(); y++) {
+      b1.push_back(pk.g1); k1.push_back(it.shares[y].second);
+      b2.push_back(pk.g2); k2.push_back(it.k2[y]);
     }
   }
   if (!n) return cts;
@@ -876,24 +923,35 @@ static G1 g1_zero() { G1 z{}; return z; }
 static G2 g2_zero() { G2 z{}; return z; }
 std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk,
                                          const std::vector<std::string>& policies, PolicyLanguage language) {        // :121-170, n times
-  std::vector<KpAbeSecretKey> sks(policies.size());
-  // all items' scalar multiplications in one launch per group; one `random` per share, in share order (drawn
-  // inside the loop at :136), every draw of item i before item i+1
-  std::vector<G1> b1;
-  std::vector<Fr> k1;
-  std::vector<G2> b2;
-  std::vector<Fr> k2;
+  const size_t n = policies.size();
+  std::vector<KpAbeSecretKey> sks(n);
+  // all items' scalar multiplications in one launch per group.  Draw order per item: the gate coefficients of
+  // gen_shares_policy, then one `random` per share in share order (drawn inside the loop at :136); every draw of
+  // item i before item i+1 (sequential), the arithmetic on all cores.
   struct Slot { size_t item, row; bool neg; size_t i1, i2; };
-  std::vector<Slot> slots;
-  for (size_t it = 0; it < policies.size(); it++) {
-    PolicyNode tree = parse_or_error(policies[it], language);
+  struct Item { const PolicyNode* tree; std::vector<Fr> draws; std::vector<G1> b1; std::vector<Fr> k1; std::vector<G2> b2; std::vector<Fr> k2;
+                std::vector<Slot> slots; };
+  std::vector<Item> items(n);
+  PolicyMemo memo;
+  for (size_t it = 0; it < n; it++) {
+    items[it].tree = &memo.get(policies[it], language).tree;
+    const size_t nd = count_share_draws(*items[it].tree) + count_leaves(*items[it].tree);
+    for (size_t d = 0; d < nd; d++) items[it].draws.push_back(rng.next_fr());
+    sks[it].policy = {policies[it], language};
+  }
+  parallel_for(n, [&](size_t it) {
+    Item& im = items[it];
+    VecFrSource src(im.draws.data(), im.draws.size());
     NamedFr shares;
-    gen_shares_policy(msk.alpha1, tree, rng, &shares);
+    gen_shares_policy(msk.alpha1, *im.tree, src, &shares);
     KpAbeSecretKey& sk = sks[it];
-    sk.policy = {policies[it], language};
+    std::vector<G1>& b1 = im.b1;
+    std::vector<Fr>& k1 = im.k1;
+    std::vector<G2>& b2 = im.b2;
+    std::vector<Fr>& k2 = im.k2;
     for (const auto& sh : shares) {
       std::string striped = remove_index(sh.first);
-      Fr random = rng.next_fr();
+      Fr random = src.next_fr();
       Slot s{it, sk.dj.size(), is_negative(striped), b1.size(), b2.size()};
       if (s.neg) {
         Fr share_hash = sha3_hash_fr(striped);
@@ -908,9 +966,22 @@ std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePubli
         b1.push_back(pk.g1); k1.push_back(fr_add(fr_mul(msk.alpha2, sh.second), fr_mul(sha3_hash_fr(striped), random)));
         b2.push_back(pk.g2); k2.push_back(random);
       }
-      slots.push_back(s);
+      im.slots.push_back(s);
       sk.dj.push_back({striped, g1_zero(), g2_zero(), g1_zero(), g1_zero(), g1_zero()});
     }
+  });
+  std::vector<G1> b1;
+  std::vector<Fr> k1;
+  std::vector<G2> b2;
+  std::vector<Fr> k2;
+  std::vector<Slot> slots;
+  for (size_t it = 0; it < n; it++) {
+    Item& im = items[it];
+    for (Slot s : im.slots) { s.i1 += b1.size(); s.i2 += b2.size(); slots.push_back(s); }
+    b1.insert(b1.end(), im.b1.begin(), im.b1.end());
+    k1.insert(k1.end(), im.k1.begin(), im.k1.end());
+    b2.insert(b2.end(), im.b2.begin(), im.b2.end());
+    k2.insert(k2.end(), im.k2.begin(), im.k2.end());
   }
   std::vector<G1> r1 = b1.empty() ? std::vector<G1>() : eng.g1_mul(b1, k1);
   std::vector<G2> r2 = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
@@ -1065,27 +1136,35 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
   std::vector<Aw11Ciphertext> cts(n);
   if (!n) return cts;
   Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];          // the reference recomputes this constant per call (:264)
-  struct Item { std::vector<std::string> names; std::array<uint8_t, 12> nonce; size_t ot, o2; };
+  struct Item { std::vector<std::string> names; std::array<uint8_t, 12> nonce; size_t ot, o2; const PolicyNode* tree; Fr s, msg_k;
+                std::vector<Fr> draws; std::vector<Gt> gb; std::vector<Fr> gk; std::vector<G2> b2; std::vector<Fr> k2; };
   std::vector<Item> items(n);
-  std::vector<Gt> gb;
-  std::vector<Fr> gk_;
-  std::vector<G2> b2;
-  std::vector<Fr> k2;
+  PolicyMemo memo;
+  // sequential: the generator in encrypt's order -- s, gate coefficients of the s-shares, of the 0-shares, msg, one r_x per
+  // share, nonce
   for (size_t it = 0; it < n; it++) {
-    PolicyNode tree = parse_or_error(policies[it], language);
-    (void)calculate_msp(tree);           // built and unused in the reference (:253-255) -- but it must not panic
-    Fr s = rng.next_fr();
-    NamedFr s_shares, w_shares;
-    gen_shares_policy(s, tree, rng, &s_shares);
-    gen_shares_policy(fr_zero(), tree, rng, &w_shares);
-    Fr msg_k = rng.next_fr();
+    Item& im = items[it];
+    im.tree = &memo.get(policies[it], language).tree;
+    (void)calculate_msp(*im.tree);           // built and unused in the reference (:253-255) -- but it must not panic
+    im.s = rng.next_fr();
+    const size_t nd = count_share_draws(*im.tree), nl = count_leaves(*im.tree);
+    for (size_t d = 0; d < 2 * nd; d++) im.draws.push_back(rng.next_fr());
+    im.msg_k = rng.next_fr();
+    for (size_t d = 0; d < nl; d++) im.draws.push_back(rng.next_fr());
+    rng.fill(im.nonce.data(), 12);
     cts[it].policy = {policies[it], language};
-    items[it].ot = gb.size();
-    items[it].o2 = b2.size();
-    gb.push_back(eng.gt_generator()); gk_.push_back(msg_k);       // msg
-    gb.push_back(egg); gk_.push_back(s);                          // egg^s
+  }
+  const Gt e_gen = eng.gt_generator();
+  parallel_for(n, [&](size_t it) {
+    Item& im = items[it];
+    VecFrSource src(im.draws.data(), im.draws.size());
+    NamedFr s_shares, w_shares;
+    gen_shares_policy(im.s, *im.tree, src, &s_shares);
+    gen_shares_policy(fr_zero(), *im.tree, src, &w_shares);
+    im.gb.push_back(e_gen); im.gk.push_back(im.msg_k);                    // msg
+    im.gb.push_back(egg); im.gk.push_back(im.s);                          // egg^s
     for (size_t i = 0; i < s_shares.size(); i++) {
-      Fr r_x = rng.next_fr();
+      Fr r_x = src.next_fr();
       std::string up = upper(s_shares[i].first);
       const Aw11PkAttr* pa = nullptr;
       std::string want = remove_index(up);
@@ -1094,14 +1173,26 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
         if (pa) break;
       }
       if (!pa) continue;
-      items[it].names.push_back(up);
-      gb.push_back(egg); gk_.push_back(s_shares[i].second);
-      gb.push_back(pa->egg_alpha); gk_.push_back(r_x);
-      b2.push_back(gk.g2); k2.push_back(r_x);
-      b2.push_back(pa->g2_y); k2.push_back(r_x);
-      b2.push_back(gk.g2); k2.push_back(w_shares[i].second);
+      im.names.push_back(up);
+      im.gb.push_back(egg); im.gk.push_back(s_shares[i].second);
+      im.gb.push_back(pa->egg_alpha); im.gk.push_back(r_x);
+      im.b2.push_back(gk.g2); im.k2.push_back(r_x);
+      im.b2.push_back(pa->g2_y); im.k2.push_back(r_x);
+      im.b2.push_back(gk.g2); im.k2.push_back(w_shares[i].second);
     }
-    rng.fill(items[it].nonce.data(), 12);
+  });
+  std::vector<Gt> gb;
+  std::vector<Fr> gk_;
+  std::vector<G2> b2;
+  std::vector<Fr> k2;
+  for (size_t it = 0; it < n; it++) {
+    Item& im = items[it];
+    im.ot = gb.size();
+    im.o2 = b2.size();
+    gb.insert(gb.end(), im.gb.begin(), im.gb.end());
+    gk_.insert(gk_.end(), im.gk.begin(), im.gk.end());
+    b2.insert(b2.end(), im.b2.begin(), im.b2.end());
+    k2.insert(k2.end(), im.k2.begin(), im.k2.end());
   }
   std::vector<Gt> ge = eng.gt_pow(gb, gk_);
   std::vector<G2> g2r = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);

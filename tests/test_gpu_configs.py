@@ -110,3 +110,63 @@ def test_config5_aw11_ten_authorities_twenty_attributes(host):
     sk_few = aw11.keygen(host, gk, auth[0][1], "bob", names[:20])
     with pytest.raises(hl.RabeError):
         aw11.decrypt(host, gk, sk_few, ct)
+
+
+# ---- BASELINE configs 3-5 at their full per-GPU batch sizes: the size-independent property
+# decrypt(encrypt(x)) == x for every item of the batch, through the batch entry points.
+def test_config3_bsw_full_batch_round_trip(host):
+    n = 4096
+    attrs = ["b%d" % i for i in range(100)]
+    flat = '{"name": "and", "children": [%s]}' % ", ".join('{"name": "%s"}' % a for a in attrs)
+    pk, msk = bsw.setup(host)
+    sk = bsw.keygen(host, pk, msk, attrs)
+    pts = [PT + i.to_bytes(2, "little") for i in range(n)]
+    cts = bsw.encrypt_batch(host, pk, [flat] * n, hl.JSON_POLICY, pts)
+    assert bsw.decrypt_batch(host, [sk] * n, cts) == pts
+
+
+def test_config4_lsw_full_per_gpu_batch_round_trip(host):
+    n = 16384 // 8          # config 4 shards 16384 items over 8 GPUs
+    attrs = ["c%d" % i for i in range(200)]
+    policy = '{"name": "and", "children": [%s]}' % ", ".join('{"name": "%s"}' % a for a in attrs)
+    pk, msk = lsw.setup(host)
+    ct = lsw.encrypt(host, pk, attrs, PT)
+    sks = lsw.keygen_batch(host, pk, msk, [policy] * n, hl.JSON_POLICY)      # the config's timed op: keygen ...
+    assert lsw.decrypt_batch(host, sks, [ct] * n) == [PT] * n                # ... + decrypt, every fresh key must open it
+
+
+def test_config5_aw11_full_per_gpu_batch_round_trip(host):
+    n = 8192 // 8
+    gk = aw11.setup(host)
+    auth, names = [], []
+    for a in range(10):
+        nm = ["AUTH%dX%d" % (a, k) for k in range(20)]
+        names += nm
+        auth.append(aw11.authgen(host, gk, nm))
+
+    def nest(ns):
+        if len(ns) == 1:
+            return '{"name": "%s"}' % ns[0]
+        h = len(ns) // 2
+        return '{"name": "and", "children": [%s, %s]}' % (nest(ns[:h]), nest(ns[h:]))
+    policy = nest(names)
+    sk = aw11.keygen(host, gk, auth[0][1], "alice", names[:20])
+    for a in range(1, 10):
+        for nm in names[20 * a:20 * a + 20]:
+            aw11.add_to_attribute(host, gk, auth[a][1], nm, sk)
+    pts = [PT + i.to_bytes(2, "little") for i in range(n)]
+    cts = aw11.encrypt_batch(host, gk, [p for p, _ in auth], [policy] * n, hl.JSON_POLICY, pts)
+    assert aw11.decrypt_batch(host, gk, [sk] * n, cts) == pts
+
+
+def test_config2_ac17_full_batch_round_trip_through_the_host_layer(host):
+    """bench.py drives config 2 at the device level; this is the same batch through rabe::schemes::ac17's batch API."""
+    n = 4096
+    rnd = random.Random(22)
+    attrs = ["a%d" % (i + 1) for i in range(50)]
+    pk, msk = ac17.setup(host)
+    sk = ac17.cp_keygen(host, msk, attrs)
+    policies = [hp.to_json(hp.random_binary_tree(attrs, rnd)) for _ in range(16)]
+    pts = [PT + i.to_bytes(2, "little") for i in range(n)]
+    cts = ac17.cp_encrypt_batch(host, pk, [policies[i % 16] for i in range(n)], pts, hl.JSON_POLICY)
+    assert ac17.cp_decrypt_batch(host, [sk] * n, cts) == pts
