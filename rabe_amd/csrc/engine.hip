@@ -996,11 +996,24 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_enc_rows(co
   }
   store3_g1_block(sh, active, c + t * 3, pt[0], pt[1], pt[2]);
 }
+// G2 Jacobian -> affine canonical with ONE Fp inversion per 128-thread block: 1 / (a + b u) = (a - b u) / (a^2 + b^2),
+// and the norms a^2 + b^2 of the block's 128 z's are inverted together.  All 128 threads must call this.
+__device__ __noinline__ void store_g2_block128(uint32_t* lds, bool active, rhip_g2* out, const G2Jac& r) {
+  const bool inf = !active || jac_is_inf(r);
+  const Fp norm = inf ? one<FpParams>() : add(sqr(r.z.c0), sqr(r.z.c1));
+  const Fp ninv = block_batch_inverse_n<128>(lds, norm);
+  if (!active) return;
+  if (inf) { store_g2(out->l, aff_inf<Fp2>()); return; }
+  const Fp2 zinv{mul(r.z.c0, ninv), neg(mul(r.z.c1, ninv))};
+  store_g2(out->l, jac_to_aff_with_zinv(r, zinv));
+}
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
                                                      const rhip_fr* s, rhip_g2* c0, int w16) {
+  __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_items * 3) return;
+  const bool active = t < n_items * 3;
+  if (!active) t = n_items * 3 - 1;         // shadow lanes join the block inversion, store nothing
   size_t item = t / 3;
   int j = (int)(t % 3);
   uint32_t kk[8];
@@ -1011,7 +1024,7 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0
     from_mont<FrParams>(kk, sum);
   }
   const G2M* tbl = (j == 0) ? t0 : (j == 1) ? t1 : t2;
-  store_g2(c0[t].l, jac_to_aff(w16 ? table_mul_g2_w16(tbl, kk) : table_mul_g2(tbl, kk)));
+  store_g2_block128(lds, active, c0 + t, w16 ? table_mul_g2_w16(tbl, kk) : table_mul_g2(tbl, kk));
 }
 // one lane per item: c_p = e_gh_ka0^s0 * e_gh_ka1^s1 * msg
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0, const GtM* e1, size_t n_items, const rhip_fr* s,
@@ -1070,15 +1083,17 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_keygen_rows
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0,
                                                                       int w16) {
+  __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_items * 3) return;
+  const bool active = t < n_items * 3;
+  if (!active) t = n_items * 3 - 1;
   size_t item = t / 3;
   int j = (int)(t % 3);
   Fr r0 = load_fr(r[2 * item].l), r1 = load_fr(r[2 * item + 1].l);
   Fr k = (j == 0) ? mul(load_fr(b[0].l), r0) : (j == 1) ? mul(load_fr(b[1].l), r1) : add(r0, r1);
   uint32_t kk[8];
   from_mont<FrParams>(kk, k);
-  store_g2(k0[t].l, jac_to_aff(w16 ? table_mul_g2_w16(h_tbl, kk) : table_mul_g2(h_tbl, kk)));
+  store_g2_block128(lds, active, k0 + t, w16 ? table_mul_g2_w16(h_tbl, kk) : table_mul_g2(h_tbl, kk));
 }
 
 // decrypt: one lane per (item, i < 6).
