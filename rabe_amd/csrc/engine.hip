@@ -2,13 +2,15 @@
 //
 // Kernel map (one lane = one independent group operation; integer VALU bound, no MFMA):
 //   k_fr_op, k_g*_add/neg/mul, k_gt_*            Level E element batches (rabe_bn operator semantics)
-//   k_table_build_{g1,g2,gt}                     8-bit window tables of a fixed base, built once per key
+//   k_table_build_{g1,g2,gt}[_w16], _g1_wide      window tables of a fixed base (8 / 16 bits; signed up to 27 bits for G1), once per key
 //   k_table_mul_{g1,g2}, k_table_pow_gt          fixed-base scalar multiplication / Gt power
 //   k_miller                                      one Miller loop per lane (P affine or Jacobian)
-//   k_final_exp                                   product of an item's Miller values + ONE final exponentiation
+//   k_final_exp                                   product of an item's Miller values + ONE final exponentiation (workspace slots)
 //   k_ac17_enc_rows / _c0 / _cp                  ac17::cp_encrypt  (src/schemes/ac17/mod.rs:274-376)
 //   k_ac17_keygen_rows / _k0                     ac17::cp_keygen   (:191-264)
-//   k_ac17_dec_miller (+ k_final_exp)            ac17::cp_decrypt  (:385-430)
+//   k_ac17_dec_miller (+ k_final_exp)            ac17::cp_decrypt  (:385-430), six independent Miller loops per item
+//   k_g2_prepare_lines, k_ac17_dec_miller2       the same with a prepared key: two pairings per lane on one accumulator
+//   k_*_c3                                        three cooperating lanes per pairing (small launches)
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -770,19 +772,30 @@ __device__ __noinline__ Fp12 table_pow_gt(const GtM* tbl, const uint32_t k[8]) {
   }
   return acc;
 }
-__global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out) {
+template <int NT> __device__ __noinline__ Fp block_batch_inverse_n(uint32_t* lds, const Fp& mine);
+__device__ __noinline__ void store_g2_block128(uint32_t* lds, bool active, rhip_g2* out, const G2Jac& r);
+// out[i] = k[i] * base from the 8-bit (or, when present, 16-bit) window table; one field inversion per block
+__global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_mul_g1(const G1M* tbl, size_t n, const rhip_fr* k, rhip_g1* out, int w16) {
+  __shared__ uint32_t lds[2 * 8 * 256];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool active = i < n;
+  if (!active) i = n - 1;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  store_g1(out[i].l, jac_to_aff(table_mul_g1(tbl, kk)));
+  const G1Jac r = w16 ? table_mul_g1_w16(tbl, kk) : table_mul_g1(tbl, kk);
+  const bool inf = !active || jac_is_inf(r);
+  const Fp zinv = block_batch_inverse_n<256>(lds, inf ? one<FpParams>() : r.z);
+  if (!active) return;
+  store_g1(out[i].l, inf ? aff_inf<Fp>() : jac_to_aff_with_zinv(r, zinv));
 }
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out, int w16) {
+  __shared__ uint32_t lds[2 * 8 * 128];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool active = i < n;
+  if (!active) i = n - 1;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  store_g2(out[i].l, jac_to_aff(table_mul_g2(tbl, kk)));
+  store_g2_block128(lds, active, out + i, w16 ? table_mul_g2_w16(tbl, kk) : table_mul_g2(tbl, kk));
 }
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_pow_gt(const GtM* tbl, size_t n, const rhip_fr* k, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1577,14 +1590,16 @@ extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  KLAUNCH(ctx, "k_table_mul_g1", k_table_mul_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, (const G1M*)t->dev, n, k, out);
+  KLAUNCH(ctx, "k_table_mul_g1", k_table_mul_g1, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream,
+          (const G1M*)(t->dev16 ? t->dev16 : t->dev), n, k, out, t->dev16 ? 1 : 0);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_g2_table_mul(rhip_ctx* ctx, const rhip_g2_table* t, size_t n, const rhip_fr* k, rhip_g2* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
-  KLAUNCH(ctx, "k_table_mul_g2", k_table_mul_g2, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, (const G2M*)t->dev, n, k, out);
+  KLAUNCH(ctx, "k_table_mul_g2", k_table_mul_g2, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream,
+          (const G2M*)(t->dev16 ? t->dev16 : t->dev), n, k, out, t->dev16 ? 1 : 0);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_table_pow(rhip_ctx* ctx, const rhip_gt_table* t, size_t n, const rhip_fr* k, rhip_gt* out) {
