@@ -15,6 +15,7 @@ path is modular big-integer arithmetic, neither HBM- nor MFMA-bound -- DESIGN.md
 `cpu_baseline` times the oracle's reference-order restatement on the host CPU (rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import random
@@ -60,6 +61,8 @@ def parse_args():
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
     ap.add_argument("--g-window", type=int, default=26,
                     help="window width (bits) of the fixed-base table of g: 16 (67 MB), or 17..27 signed digits (24: 5.4 GB, 26: 19 GB)")
+    ap.add_argument("--no-host-io-leg", action="store_true",
+                    help="skip the informational second timed region in which every step also moves its inputs and outputs over PCIe")
     ap.add_argument("--only-encrypt", action="store_true", help="diagnostic: skip the decrypt half of every step (value is then not the metric)")
     ap.add_argument("--no-prepared-sk", action="store_true",
                     help="decrypt without the per-key prepared lines (6 independent Miller loops per item)")
@@ -250,6 +253,66 @@ def main():
                    "steps_in_flight": S, "pairing_mode": args.pairing_mode,
                    "parallelism": "batch-sharded x%d (no data-path collective)" % world, "device": dev_name},
     }
+
+    # ---------------------------------------------------------------- informational: the same steps with host buffers
+    # (inputs s, msg uploaded; ciphertext c_0, c, c_p and the decrypted Gt downloaded; pinned memory, copies ordered on
+    # each batch's own stream so that they overlap the other batches' kernels).  Never `value`.
+    if not args.no_host_io_leg and not args.only_encrypt:
+        n_s, n_msg = 2 * B * 32, B * 384
+        sizes_out = (B * 3 * 128, total_rows * 3 * 64, B * 384, B * 384)
+        io = []
+        for e_ in lanes_ctx:
+            h_in = (e_.host_alloc(n_s), e_.host_alloc(n_msg))
+            h_out = tuple(e_.host_alloc(z) for z in sizes_out)
+            io.append((e_.alloc(n_s), e_.alloc(n_msg), h_in, h_out))
+        hs, hm = eng.download(ds), eng.download(dmsg)
+        for (_, _, h_in, _) in io:
+            ctypes.memmove(h_in[0], hs, n_s)
+            ctypes.memmove(h_in[1], hm, n_msg)
+
+        def step_io():
+            i = step_no[0] % S
+            step_no[0] += 1
+            e_ = lanes_ctx[i]
+            c0_, c_, cp_, out_ = bufs[i]
+            ds_, dmsg_, h_in, h_out = io[i]
+            e_.upload_async(ds_, h_in[0], n_s)
+            e_.upload_async(dmsg_, h_in[1], n_msg)
+            E.ac17_encrypt_dev(e_, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds_, dmsg_, c0_, c_, cp_)
+            e_.download_async(h_out[0], c0_, sizes_out[0])
+            e_.download_async(h_out[1], c_, sizes_out[1])
+            e_.download_async(h_out[2], cp_, sizes_out[2])
+            if sk_lines is None:
+                E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
+                                   d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
+            else:
+                E.ac17_decrypt_prepared_dev(e_, B, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
+                                            d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
+            e_.download_async(h_out[3], out_, sizes_out[3])
+
+        step_no[0] = 0
+        for _ in range(S):
+            step_io()
+        sync_all()
+        barrier()
+        step_no[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_io()
+        sync_all()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        el_io = shard.max_over_ranks(t1 - t0)
+        ok_io = all(ctypes.string_at(io[i][3][3], sizes_out[3]) == want for i in range(S))
+        per_step = n_s + n_msg + sum(sizes_out)
+        result["host_io_leg"] = {"ops_per_s": round(world * B * args.steps / el_io, 2), "ms_per_step": round(1e3 * el_io / args.steps, 3),
+                                 "pcie_bytes_per_step": per_step, "pcie_GBps": round(per_step * args.steps / el_io / 1e9, 2),
+                                 "roundtrip_bit_exact": ok_io,
+                                 "note": "inputs uploaded and all outputs downloaded every step (pinned host memory, stream-ordered copies)"}
+        for i, e_ in enumerate(lanes_ctx):
+            for hp_ in io[i][2] + io[i][3]:
+                e_.host_free(hp_)
 
     if rank == 0:
         # ------------------------------------------------------------ roofline of the dominant kernel (HIP events on the launch stream)

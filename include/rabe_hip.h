@@ -68,6 +68,12 @@ int32_t rhip_malloc(rhip_ctx* ctx, size_t bytes, void** dev);
 int32_t rhip_free(rhip_ctx* ctx, void* dev);
 int32_t rhip_upload(rhip_ctx* ctx, void* dev, const void* host, size_t bytes);
 int32_t rhip_download(rhip_ctx* ctx, void* host, const void* dev, size_t bytes);
+/* Pinned host memory and copies that are only ordered on the context's stream (rhip_sync waits for them): a caller with
+ * several contexts overlaps the PCIe traffic of one batch with the kernels of the others. */
+int32_t rhip_host_alloc(rhip_ctx* ctx, size_t bytes, void** host);
+int32_t rhip_host_free(rhip_ctx* ctx, void* host);
+int32_t rhip_upload_async(rhip_ctx* ctx, void* dev, const void* host_pinned, size_t bytes);
+int32_t rhip_download_async(rhip_ctx* ctx, void* host_pinned, const void* dev, size_t bytes);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------
  * rabe_bn surface replaced ("rabe_bn API surface actually used"):

@@ -242,6 +242,29 @@ extern "C" int32_t rhip_download(rhip_ctx* ctx, void* host, const void* dev, siz
   return RHIP_OK;
 }
 
+// pinned host memory + copies that are only ordered on the context's stream (rhip_sync waits): lets a caller overlap
+// the PCIe traffic of one batch with the kernels of the others
+extern "C" int32_t rhip_host_alloc(rhip_ctx* ctx, size_t bytes, void** host) {
+  if (!ctx || !host) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipHostMalloc(host, bytes ? bytes : 4, hipHostMallocDefault));
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_host_free(rhip_ctx* ctx, void* host) {
+  if (!ctx) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipHostFree(host));
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_upload_async(rhip_ctx* ctx, void* dev, const void* host, size_t bytes) {
+  if (!ctx) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  if (!ctx) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return RHIP_OK;
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // ------------------------------------------------------------------------------------------------

@@ -197,6 +197,21 @@ class Engine:
         raw = self.download(out, n_items * GT)
         return [raw[i * GT:(i + 1) * GT] for i in range(n_items)]
 
+    # ------------------------------------------------------------------ pinned host buffers / stream-ordered copies
+    def host_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self.lib.rhip_host_alloc(self.ctx, ctypes.c_size_t(nbytes), ctypes.byref(p)))
+        return p
+
+    def host_free(self, p):
+        self._check(self.lib.rhip_host_free(self.ctx, p))
+
+    def upload_async(self, dev, host_ptr, nbytes):
+        self._check(self.lib.rhip_upload_async(self.ctx, dev.ptr, host_ptr, ctypes.c_size_t(nbytes)))
+
+    def download_async(self, host_ptr, dev, nbytes):
+        self._check(self.lib.rhip_download_async(self.ctx, host_ptr, dev.ptr, ctypes.c_size_t(nbytes)))
+
     # ------------------------------------------------------------------ tables
     def g1_table(self, base): return _Table(self, "g1", base)
     def g2_table(self, base): return _Table(self, "g2", base)
