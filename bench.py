@@ -373,6 +373,12 @@ def main():
                 result["cpu_baseline"] = cpu_baseline(args, trees[0])
             except Exception as ex:  # the GPU number must still be reported
                 result["cpu_baseline"] = {"error": repr(ex)}
+            try:
+                mc = cpu_baseline_multicore(args, trees[0])
+                if mc:
+                    result["cpu_baseline_multicore"] = mc
+            except Exception as ex:
+                result["cpu_baseline_multicore"] = {"error": repr(ex)}
         print(json.dumps(result), flush=True)
 
     pk.destroy()
@@ -399,6 +405,43 @@ def pmc_traffic(kernel):
         if seen == 2:
             return round(tot), "profiles/" + os.path.basename(f)
     return None, None
+
+
+def cpu_baseline_multicore(args, tree):
+    """The same C restatement on several host cores at once (independent processes, a few items each): what a
+    multi-threaded caller of the single-threaded reference would get.  Informational, beside cpu_baseline.
+    Plain subprocesses with a hard deadline -- nothing here can hold up the GPU result."""
+    import subprocess
+    from rabe_amd import hostprep as hp
+    from oracle import cport
+    if not cport.available():
+        return None
+    procs = max(2, min(32, (os.cpu_count() or 2) // 2))
+    per = 6
+    policy = hp.to_json(tree)
+    code = ("import sys, json; sys.path.insert(0, %r); from oracle import cport; "
+            "o, dt = cport.ac17_encdec(%r, %d, %d, seed=int(sys.argv[1])); print(json.dumps([len(o), dt]))" % (ROOT, policy, args.attrs, per))
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    t0 = time.perf_counter()
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(args.seed + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+          for i in range(procs)]
+    deadline = t0 + 120.0
+    done = []
+    for pr in ps:
+        try:
+            out, _ = pr.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+            done.append(json.loads(out.decode().strip().splitlines()[-1]))
+        except Exception:
+            pr.kill()
+    wall = time.perf_counter() - t0
+    if not done:
+        return None
+    n = sum(d[0] for d in done)
+    busy = max(d[1] for d in done)
+    return {"value": round(n / busy, 3), "unit": "ops/s", "cores": len(done), "kind": "port",
+            "sample": "%d processes x %d AC17 encrypt+decrypt at %d attributes, slowest process %.1f s in its timed loop (%.1f s wall with "
+                      "interpreter start-up and key set-up); same C restatement as cpu_baseline" % (len(done), per, args.attrs, busy, wall)}
 
 
 def cpu_baseline(args, tree):
