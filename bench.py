@@ -361,6 +361,7 @@ def main():
             if dom_ms > 0 else None,
             "traffic": traffic, "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
             "traffic_source": traffic_src,
+            "valu_issue": pmc_valu_issue(dom, lanes.get(dom, 0), impl.get(dom, alg.get(dom, 0))),
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
                     "peak_GBps": 8000},
             "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
@@ -405,6 +406,29 @@ def pmc_traffic(kernel):
         if seen == 2:
             return round(tot), "profiles/" + os.path.basename(f)
     return None, None
+
+
+def pmc_valu_issue(kernel, n_lanes, fpmul_per_lane):
+    """VALU issue-slot occupancy of `kernel` from the newest committed SQ-counter summary (tools/pmc_sq.sh): VALU
+    instructions per wave issue slot (SQ_WAVE_CYCLES counts 4-cycle slots), and the same with the second slot of every
+    half-rate v_mad_u64_u32 added (64 + 43 MADs per Fp multiplication-equivalent of the lazy Fq2 arithmetic)."""
+    import glob
+    import re
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")))):
+        vals, cur = {}, None
+        for line in open(f):
+            if not line.startswith(" "):
+                cur = line.strip()
+                continue
+            m = re.match(r"\s+(SQ_\w+)\s+([0-9.e+]+) per launch", line)
+            if m and cur == kernel:
+                vals[m.group(1)] = float(m.group(2))
+        if "SQ_INSTS_VALU" in vals and vals.get("SQ_WAVE_CYCLES"):
+            mads = n_lanes * fpmul_per_lane * 107.0 / 64.0          # per-wave MAD count x waves
+            return {"valu_per_slot": round(vals["SQ_INSTS_VALU"] / vals["SQ_WAVE_CYCLES"], 3),
+                    "valu_slots_incl_mad_second_slot": round((vals["SQ_INSTS_VALU"] + mads) / vals["SQ_WAVE_CYCLES"], 3),
+                    "source": "profiles/" + os.path.basename(f)}
+    return None
 
 
 def cpu_baseline_multicore(args, tree):
