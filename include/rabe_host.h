@@ -23,7 +23,8 @@ enum {   /* object kinds for rabe_obj_free / rabe_obj_serialize / rabe_obj_deser
   RABE_AC17_PK = 1, RABE_AC17_MSK = 2, RABE_AC17_CP_SK = 3, RABE_AC17_CP_CT = 4, RABE_AC17_KP_SK = 5, RABE_AC17_KP_CT = 6,
   RABE_BSW_PK = 10, RABE_BSW_MSK = 11, RABE_BSW_SK = 12, RABE_BSW_CT = 13,
   RABE_LSW_PK = 20, RABE_LSW_MSK = 21, RABE_LSW_SK = 22, RABE_LSW_CT = 23,
-  RABE_AW11_GK = 30, RABE_AW11_PK = 31, RABE_AW11_MSK = 32, RABE_AW11_SK = 33, RABE_AW11_CT = 34
+  RABE_AW11_GK = 30, RABE_AW11_PK = 31, RABE_AW11_MSK = 32, RABE_AW11_SK = 33, RABE_AW11_CT = 34,
+  RABE_GHW11_PK = 40, RABE_GHW11_MSK = 41, RABE_GHW11_SK = 42, RABE_GHW11_TK = 43, RABE_GHW11_RK = 44, RABE_GHW11_CT = 45, RABE_GHW11_TCT = 46
 };
 enum { RABE_JSON_POLICY = 0, RABE_HUMAN_POLICY = 1 };   /* PolicyLanguage, src/utils/policy/pest/mod.rs:18-23 */
 
@@ -102,6 +103,19 @@ int32_t rabe_aw11_encrypt_batch(rabe_host* h, const void* gk, const void* const*
                                 int32_t language, const uint8_t* const* datas, const size_t* lens, void** cts);
 int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                 uint8_t** plaintexts, size_t* lens);
+
+/* ---- ghw11, CP-ABE with outsourced decryption (src/schemes/ghw11/mod.rs:92-305): `transform` is the server's part
+ * (m + 2 pairings per ciphertext), `decrypt_out` the client's (one Gt power) */
+int32_t rabe_ghw11_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_ghw11_keygen(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, size_t n, void** sk);
+int32_t rabe_ghw11_tkgen(rabe_host* h, const void* sk, void** tk, void** rk);
+int32_t rabe_ghw11_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_ghw11_transform(rabe_host* h, const void* ct, const void* tk, void** tct);
+/* n independent transforms in one launch set; status[i] = 0 ok / -1 (tk i does not satisfy ct i; tcts[i] = NULL) */
+int32_t rabe_ghw11_transform_batch(rabe_host* h, size_t n, const void* const* cts, const void* const* tks, int32_t* status, void** tcts);
+/* `data` of the reference's decrypt_out is the ciphertext's data field: pass the ciphertext object */
+int32_t rabe_ghw11_decrypt_out(rabe_host* h, const void* tct, const void* rk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_ghw11_decrypt_out_gt(rabe_host* h, const void* tct, const void* rk, uint8_t out_gt[384]);
 
 /* ---- host-only policy utilities (no GPU needed): results as small JSON texts, free with rabe_bytes_free.
  *   rabe_policy_parse      -> serialize_policy(parse(policy, language), out_language)       pest/mod.rs:40-114

@@ -520,3 +520,83 @@ def aw11_decrypt(gk, sk, ct):
         coeff = next(c[1] for c in coeff_list if c[0] == name_col)
         egg_s = bn.gt_mul(egg_s, bn.gt_pow(bn.gt_mul(num, bn.gt_inv(dem)), coeff))
     return bn.gt_mul(ct["c_0"], bn.gt_inv(egg_s))
+
+
+# ============================================================================= GHW11 (outsourced decryption)
+
+def ghw11_setup(rng):
+    """ghw11/mod.rs:92-111 (draws: g1, g2, a, alpha)."""
+    g1 = bn.g1_mul(bn.G1_GEN, rng.fr())
+    g2 = bn.g2_mul(bn.G2_GEN, rng.fr())
+    a = rng.fr()
+    g1_a = bn.g1_mul(g1, a)
+    g2_a = bn.g2_mul(g2, a)
+    alpha = rng.fr()
+    e_gg_alpha = bn.gt_pow(bn.pairing(g1, g2), alpha)
+    g2_alpha = bn.g2_mul(g2, alpha)
+    pk = {"g1": g1, "g2": g2, "g1_a": g1_a, "g2_a": g2_a, "e_gg_alpha": e_gg_alpha}
+    return pk, {"g2_alpha": g2_alpha, "pk": pk}
+
+
+def ghw11_keygen(pk, msk, attributes, rng):
+    """ghw11/mod.rs:123-152; None for an empty attribute list."""
+    if not attributes:
+        return None
+    r = rng.fr()
+    g2_r = bn.g2_mul(pk["g2"], r)
+    k = bn.g2_add(msk["g2_alpha"], bn.g2_mul(pk["g2_a"], r))
+    attr_key = [{"string": j, "k_x": bn.g2_mul(sha3_hash_g2(pk["g2"], j), r)} for j in attributes]
+    return {"k": k, "l": g2_r, "attr_key": attr_key}
+
+
+def ghw11_tkgen(sk, rng):
+    """ghw11/mod.rs:156-180: (transform key, retrieve key z)."""
+    z = rng.fr()
+    z_inv = bn.fr_inv(z)
+    tk = {"k_z": bn.g2_mul(sk["k"], z_inv), "l_z": bn.g2_mul(sk["l"], z_inv),
+          "attr_key_z": [{"string": a["string"], "k_x": bn.g2_mul(a["k_x"], z_inv)} for a in sk["attr_key"]]}
+    return tk, {"z": z}
+
+
+def ghw11_encrypt(pk, policy, language, rng, msg):
+    """ghw11/mod.rs:192-228: secret first, the Gt `msg` second (supplied by the caller), the gate coefficients, then one t_i per share."""
+    secret = rng.fr()
+    tree = pol.parse(policy, language)
+    shares = pol.gen_shares_policy(secret, tree, rng)
+    c = bn.gt_mul(bn.gt_pow(pk["e_gg_alpha"], secret), msg)
+    c1 = bn.g1_mul(pk["g1"], secret)
+    ci_di = []
+    for node, i_val in shares:
+        t_i = rng.fr()
+        j = pol.remove_index(node)
+        ci = bn.g1_add(bn.g1_mul(pk["g1_a"], i_val), bn.g1_mul(sha3_hash_g1(pk["g1"], j), (-t_i) % bn.R))
+        ci_di.append((node, ci, bn.g1_mul(pk["g1"], t_i)))
+    return {"policy": (policy, language), "c": c, "c1": c1, "ci_di": ci_di}
+
+
+def ghw11_transform(ct, tk):
+    """ghw11/mod.rs:231-295: the outsourced part -- m + 2 pairings, 2m G1 multiplications."""
+    attr = [v["string"] for v in tk["attr_key_z"]]
+    tree = pol.parse(ct["policy"][0], ct["policy"][1])
+    if not pol.traverse_policy(attr, tree):
+        raise ValueError("Error: attributes in tk do not match policy in ct.")
+    ok, lst = pol.calc_pruned(attr, tree)
+    coeff_list = pol.calc_coefficients(tree, 1)
+    if not ok:
+        raise ValueError("Error in Ghw11/decrypt: attributes in sk do not match policy in ct.")
+    t = bn.GT_ONE
+    ci_wi = None          # G1::zero()
+    for name, name_col in lst:
+        coeff = next(c for n, c in coeff_list if n == name_col)
+        tk_attr = next(a for a in tk["attr_key_z"] if a["string"] == name)
+        ct_attr = next(a for a in ct["ci_di"] if a[0] == name_col)
+        ci_wi = bn.g1_add(ci_wi, bn.g1_mul(ct_attr[1], coeff))
+        t = bn.gt_mul(t, bn.pairing(bn.g1_mul(ct_attr[2], coeff), tk_attr["k_x"]))
+    t = bn.gt_mul(t, bn.pairing(ci_wi, tk["l_z"]))
+    t = bn.gt_mul(bn.pairing(ct["c1"], tk["k_z"]), bn.gt_inv(t))
+    return {"c": ct["c"], "t": t}
+
+
+def ghw11_decrypt_out(pct, rk):
+    """ghw11/mod.rs:298-305: the client's part, one Gt power.  Returns the Gt handed to decrypt_symmetric."""
+    return bn.gt_mul(pct["c"], bn.gt_inv(bn.gt_pow(pct["t"], rk["z"])))

@@ -98,6 +98,16 @@ static void ser(W& w, int32_t kind, const void* o) {
                          for (auto& a : x.attr) { w.str(a.first); w.el(a.second); } break; }
     case RABE_AW11_CT: { auto& x = *(const aw11::Aw11Ciphertext*)o; w.pol(x.policy); w.el(x.c_0); w.u32((uint32_t)x.c.size());
                          for (auto& c : x.c) { w.str(c.name); w.el(c.c1); w.el(c.c2); w.el(c.c3); } w.bytes(x.ct); break; }
+    case RABE_GHW11_PK: { auto& x = *(const ghw11::Ghw11PublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.g1_a); w.el(x.g2_a); w.el(x.e_gg_alpha); break; }
+    case RABE_GHW11_MSK: { auto& x = *(const ghw11::Ghw11MasterKey*)o; w.el(x.g2_alpha); ser(w, RABE_GHW11_PK, &x.pk); break; }
+    case RABE_GHW11_SK: { auto& x = *(const ghw11::Ghw11SecretKey*)o; w.el(x.k); w.el(x.l); w.u32((uint32_t)x.attr_key.size());
+                          for (auto& a : x.attr_key) { w.str(a.string); w.el(a.k_x); } break; }
+    case RABE_GHW11_TK: { auto& x = *(const ghw11::Ghw11TransformKey*)o; w.el(x.k_z); w.el(x.l_z); w.u32((uint32_t)x.attr_key_z.size());
+                          for (auto& a : x.attr_key_z) { w.str(a.string); w.el(a.k_x); } break; }
+    case RABE_GHW11_RK: { auto& x = *(const ghw11::Ghw11RetrieveKey*)o; w.fr(x.z); break; }
+    case RABE_GHW11_CT: { auto& x = *(const ghw11::Ghw11Ciphertext*)o; w.pol(x.policy); w.el(x.c); w.el(x.c1); w.u32((uint32_t)x.ci_di.size());
+                          for (auto& r : x.ci_di) { w.str(r.name); w.el(r.c); w.el(r.d); } w.bytes(x.data); break; }
+    case RABE_GHW11_TCT: { auto& x = *(const ghw11::Ghw11TransformCiphertext*)o; w.el(x.c); w.el(x.t); break; }
     default: throw RabeError("serialize: unknown object kind");
   }
 }
@@ -138,6 +148,19 @@ static void* deser(R& r, int32_t kind) {
     case RABE_AW11_CT: { auto* x = new aw11::Aw11Ciphertext(); x->policy = r.pol(); x->c_0 = r.el<384>(); uint32_t c = r.u32();
                          for (uint32_t i = 0; i < c; i++) { aw11::Aw11CtRow t; t.name = r.str(); t.c1 = r.el<384>(); t.c2 = r.el<128>(); t.c3 = r.el<128>(); x->c.push_back(t); }
                          x->ct = r.bytes(); return x; }
+    case RABE_GHW11_PK: { auto* x = new ghw11::Ghw11PublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_a = r.el<64>(); x->g2_a = r.el<128>();
+                          x->e_gg_alpha = r.el<384>(); return x; }
+    case RABE_GHW11_MSK: { auto* x = new ghw11::Ghw11MasterKey(); x->g2_alpha = r.el<128>(); auto* pk = (ghw11::Ghw11PublicKey*)deser(r, RABE_GHW11_PK);
+                           x->pk = *pk; delete pk; return x; }
+    case RABE_GHW11_SK: { auto* x = new ghw11::Ghw11SecretKey(); x->k = r.el<128>(); x->l = r.el<128>(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key.push_back(a); } return x; }
+    case RABE_GHW11_TK: { auto* x = new ghw11::Ghw11TransformKey(); x->k_z = r.el<128>(); x->l_z = r.el<128>(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key_z.push_back(a); } return x; }
+    case RABE_GHW11_RK: { auto* x = new ghw11::Ghw11RetrieveKey(); x->z = r.fr(); return x; }
+    case RABE_GHW11_CT: { auto* x = new ghw11::Ghw11Ciphertext(); x->policy = r.pol(); x->c = r.el<384>(); x->c1 = r.el<64>(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11CtRow t; t.name = r.str(); t.c = r.el<64>(); t.d = r.el<64>(); x->ci_di.push_back(t); }
+                          x->data = r.bytes(); return x; }
+    case RABE_GHW11_TCT: { auto* x = new ghw11::Ghw11TransformCiphertext(); x->c = r.el<384>(); x->t = r.el<384>(); return x; }
     default: throw RabeError("deserialize: unknown object kind");
   }
 }
@@ -226,6 +249,13 @@ void rabe_obj_free(int32_t kind, void* o) {
     case RABE_AW11_MSK: delete (aw11::Aw11MasterKey*)o; break;
     case RABE_AW11_SK: delete (aw11::Aw11SecretKey*)o; break;
     case RABE_AW11_CT: delete (aw11::Aw11Ciphertext*)o; break;
+    case RABE_GHW11_PK: delete (ghw11::Ghw11PublicKey*)o; break;
+    case RABE_GHW11_MSK: delete (ghw11::Ghw11MasterKey*)o; break;
+    case RABE_GHW11_SK: delete (ghw11::Ghw11SecretKey*)o; break;
+    case RABE_GHW11_TK: delete (ghw11::Ghw11TransformKey*)o; break;
+    case RABE_GHW11_RK: delete (ghw11::Ghw11RetrieveKey*)o; break;
+    case RABE_GHW11_CT: delete (ghw11::Ghw11Ciphertext*)o; break;
+    case RABE_GHW11_TCT: delete (ghw11::Ghw11TransformCiphertext*)o; break;
     default: break;
   }
 }
@@ -513,6 +543,72 @@ int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const vo
   std::vector<const aw11::Aw11Ciphertext*> c;
   for (size_t i = 0; i < n; i++) { s.push_back((const aw11::Aw11SecretKey*)sks[i]); c.push_back((const aw11::Aw11Ciphertext*)cts[i]); }
   give_results(h, aw11::decrypt_batch(h->eng, *(const aw11::Aw11GlobalKey*)gk, s, c), status, plaintexts, lens);
+  return 0;
+  GUARD_END(h)
+}
+
+// ---------------------------------------------------------------- ghw11
+int32_t rabe_ghw11_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = ghw11::setup(h->eng, h->rng());
+  *pk = new ghw11::Ghw11PublicKey(r.first);
+  *msk = new ghw11::Ghw11MasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_keygen(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, size_t n, void** sk) {
+  GUARD_BEGIN
+  ghw11::Ghw11SecretKey out;
+  if (!ghw11::keygen(h->eng, h->rng(), *(const ghw11::Ghw11PublicKey*)pk, *(const ghw11::Ghw11MasterKey*)msk, strs(attributes, n), &out)) return 1;
+  *sk = new ghw11::Ghw11SecretKey(out);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_tkgen(rabe_host* h, const void* sk, void** tk, void** rk) {
+  GUARD_BEGIN
+  auto r = ghw11::tkgen(h->eng, h->rng(), *(const ghw11::Ghw11SecretKey*)sk);
+  *tk = new ghw11::Ghw11TransformKey(r.first);
+  *rk = new ghw11::Ghw11RetrieveKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* plaintext, size_t len, void** ct) {
+  GUARD_BEGIN
+  *ct = new ghw11::Ghw11Ciphertext(ghw11::encrypt(h->eng, h->rng(), *(const ghw11::Ghw11PublicKey*)pk, policy, lang_of(language), Bytes(plaintext, plaintext + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_transform(rabe_host* h, const void* ct, const void* tk, void** tct) {
+  GUARD_BEGIN
+  *tct = new ghw11::Ghw11TransformCiphertext(ghw11::transform(h->eng, *(const ghw11::Ghw11Ciphertext*)ct, *(const ghw11::Ghw11TransformKey*)tk));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_transform_batch(rabe_host* h, size_t n, const void* const* cts, const void* const* tks, int32_t* status, void** tcts) {
+  GUARD_BEGIN
+  std::vector<const ghw11::Ghw11Ciphertext*> c;
+  std::vector<const ghw11::Ghw11TransformKey*> t;
+  for (size_t i = 0; i < n; i++) { c.push_back((const ghw11::Ghw11Ciphertext*)cts[i]); t.push_back((const ghw11::Ghw11TransformKey*)tks[i]); }
+  std::vector<std::string> errors;
+  auto r = ghw11::transform_batch(h->eng, c, t, &errors);
+  for (size_t i = 0; i < n; i++) {
+    status[i] = errors[i].empty() ? 0 : -1;
+    tcts[i] = errors[i].empty() ? new ghw11::Ghw11TransformCiphertext(r[i]) : nullptr;
+    if (!errors[i].empty()) set_err(h, errors[i]);
+  }
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_decrypt_out(rabe_host* h, const void* tct, const void* rk, const void* ct, uint8_t** plaintext, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(ghw11::decrypt_out(h->eng, *(const ghw11::Ghw11TransformCiphertext*)tct, *(const ghw11::Ghw11RetrieveKey*)rk,
+                                       ((const ghw11::Ghw11Ciphertext*)ct)->data), plaintext, len);
+  GUARD_END(h)
+}
+int32_t rabe_ghw11_decrypt_out_gt(rabe_host* h, const void* tct, const void* rk, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = ghw11::decrypt_out_gt(h->eng, *(const ghw11::Ghw11TransformCiphertext*)tct, *(const ghw11::Ghw11RetrieveKey*)rk);
+  memcpy(out_gt, g.data(), 384);
   return 0;
   GUARD_END(h)
 }

@@ -234,10 +234,35 @@ struct PairingJob {
   std::vector<G2> q;
   std::vector<Gt> gbase;
   std::vector<Fr> gexp;
+  // one more pair whose G1 argument is a sum: ML(sum_j sscal_j * sbase_j, sq)   (ghw11: e(sum_i w_i C_i, L))
+  std::vector<G1> sbase;
+  std::vector<Fr> sscal;
+  G2 sq;
   Gt lead;
+  bool lead_one = false;      // lead = 1 (no leading factor)
   bool failed = false;
   std::string error;
 };
+// sum of each group's points: pairwise additions, one rhip_g1_add launch per tree level for all groups together
+static std::vector<G1> g1_group_sums(Engine& e, std::vector<std::vector<G1>> groups) {
+  for (;;) {
+    std::vector<G1> a, b;
+    for (auto& g : groups)
+      for (size_t i = 0; i + 1 < g.size(); i += 2) { a.push_back(g[i]); b.push_back(g[i + 1]); }
+    if (a.empty()) break;
+    std::vector<G1> s = g1_add(e, a, b);
+    size_t pos = 0;
+    for (auto& g : groups) {
+      std::vector<G1> next;
+      for (size_t i = 0; i + 1 < g.size(); i += 2) next.push_back(s[pos++]);
+      if (g.size() & 1) next.push_back(g.back());
+      g.swap(next);
+    }
+  }
+  std::vector<G1> out;
+  for (auto& g : groups) { G1 z{}; out.push_back(g.empty() ? z : g[0]); }
+  return out;
+}
 static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>& jobs) {
   std::vector<size_t> live;
   for (size_t i = 0; i < jobs.size(); i++) if (!jobs[i].failed) live.push_back(i);
@@ -245,23 +270,47 @@ static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>
   if (live.empty()) return out;
   std::vector<G1> base;
   std::vector<Fr> scal;
-  std::vector<G2> q;
   std::vector<Gt> gb;
   std::vector<Fr> gk;
-  std::vector<uint32_t> off{0};
+  bool any_sum = false;
   for (size_t i : live) {
     const PairingJob& j = jobs[i];
     base.insert(base.end(), j.base.begin(), j.base.end());
     scal.insert(scal.end(), j.scal.begin(), j.scal.end());
-    q.insert(q.end(), j.q.begin(), j.q.end());
+    base.insert(base.end(), j.sbase.begin(), j.sbase.end());
+    scal.insert(scal.end(), j.sscal.begin(), j.sscal.end());
     gb.insert(gb.end(), j.gbase.begin(), j.gbase.end());
     gk.insert(gk.end(), j.gexp.begin(), j.gexp.end());
-    off.push_back((uint32_t)base.size());
+    any_sum = any_sum || !j.sbase.empty();
   }
+  Gt gt_one{};
+  gt_one[0] = 1;
   std::vector<Gt> acc(live.size());
-  for (size_t t = 0; t < live.size(); t++) acc[t] = jobs[live[t]].lead;
+  for (size_t t = 0; t < live.size(); t++) acc[t] = jobs[live[t]].lead_one ? gt_one : jobs[live[t]].lead;
   if (!base.empty()) {
-    std::vector<G1> p = e.g1_mul(base, scal);
+    std::vector<G1> scaled = e.g1_mul(base, scal);
+    // per item: its plain pairs, then (if any) the pair with the summed G1 argument
+    std::vector<G1> p;
+    std::vector<G2> q;
+    std::vector<uint32_t> off{0};
+    std::vector<std::vector<G1>> groups;
+    size_t pos = 0;
+    for (size_t i : live) {
+      const PairingJob& j = jobs[i];
+      pos += j.base.size();
+      groups.push_back(std::vector<G1>(scaled.begin() + pos, scaled.begin() + pos + j.sbase.size()));
+      pos += j.sbase.size();
+    }
+    std::vector<G1> sums = any_sum ? g1_group_sums(e, groups) : std::vector<G1>();
+    pos = 0;
+    for (size_t t = 0; t < live.size(); t++) {
+      const PairingJob& j = jobs[live[t]];
+      p.insert(p.end(), scaled.begin() + pos, scaled.begin() + pos + j.base.size());
+      q.insert(q.end(), j.q.begin(), j.q.end());
+      pos += j.base.size() + j.sbase.size();
+      if (!j.sbase.empty()) { p.push_back(sums[t]); q.push_back(j.sq); }
+      off.push_back((uint32_t)p.size());
+    }
     auto fp = flatten(p); auto fq = flatten(q);
     DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off.data(), off.size() * 4), dout(&e, live.size() * 384);
     e.check(rhip_pairing_product(e.ctx(), live.size(), doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), dout.as<rhip_gt>()),
@@ -1278,6 +1327,129 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, c
   return open_jobs(eng, jobs, sealed);
 }
 }  // namespace aw11
+
+// ================================================================================================ GHW11
+namespace ghw11 {
+std::pair<Ghw11PublicKey, Ghw11MasterKey> setup(Engine& eng, Rng& rng) {        // :92-111
+  G1 g1 = eng.random_g1(rng);
+  G2 g2 = eng.random_g2(rng);
+  Fr a = rng.next_fr();
+  G1 g1_a = eng.g1_mul({g1}, {a})[0];
+  Fr alpha = rng.next_fr();
+  std::vector<G2> m = eng.g2_mul({g2, g2}, {a, alpha});
+  Gt e = eng.gt_pow({eng.pairing({g1}, {g2})[0]}, {alpha})[0];
+  Ghw11PublicKey pk{g1, g2, g1_a, m[0], e};
+  return {pk, Ghw11MasterKey{m[1], pk}};
+}
+bool keygen(Engine& eng, Rng& rng, const Ghw11PublicKey& pk, const Ghw11MasterKey& msk, const std::vector<std::string>& attributes,
+            Ghw11SecretKey* out) {       // :123-152
+  if (attributes.empty()) return false;
+  Fr r = rng.next_fr();
+  // L = g2*r ; K = g2_alpha + g2_a*r ; K_x = (g2*h(x))*r = g2*(h(x) r)
+  std::vector<G2> base{pk.g2, pk.g2_a};
+  std::vector<Fr> k{r, r};
+  for (const auto& j : attributes) { base.push_back(pk.g2); k.push_back(fr_mul(sha3_hash_fr(j), r)); }
+  std::vector<G2> m = eng.g2_mul(base, k);
+  out->l = m[0];
+  out->k = g2_add(eng, {msk.g2_alpha}, {m[1]})[0];
+  out->attr_key.clear();
+  for (size_t i = 0; i < attributes.size(); i++) out->attr_key.push_back({attributes[i], m[2 + i]});
+  return true;
+}
+std::pair<Ghw11TransformKey, Ghw11RetrieveKey> tkgen(Engine& eng, Rng& rng, const Ghw11SecretKey& sk) {     // :156-180
+  Fr z = rng.next_fr();
+  Fr z_inv = must_inv(z);
+  std::vector<G2> base{sk.k, sk.l};
+  for (const auto& a : sk.attr_key) base.push_back(a.k_x);
+  std::vector<G2> m = eng.g2_mul(base, std::vector<Fr>(base.size(), z_inv));
+  Ghw11TransformKey tk{m[0], m[1], {}};
+  for (size_t i = 0; i < sk.attr_key.size(); i++) tk.attr_key_z.push_back({sk.attr_key[i].string, m[2 + i]});
+  return {tk, Ghw11RetrieveKey{z}};
+}
+Ghw11Ciphertext encrypt(Engine& eng, Rng& rng, const Ghw11PublicKey& pk, const std::string& policy, PolicyLanguage language,
+                        const Bytes& plaintext) {       // :192-228
+  Fr secret = rng.next_fr();
+  Fr msg_k = rng.next_fr();                       // rng.gen::<Gt>()
+  PolicyNode tree = parse_or_error(policy, language);
+  NamedFr shares;
+  gen_shares_policy(secret, tree, rng, &shares);
+  // C_i = g1_a*share - (g1*h(j))*t_i = g1_a*share + g1*(-h(j) t_i) ; D_i = g1*t_i
+  std::vector<G1> base{pk.g1};
+  std::vector<Fr> k{secret};
+  for (const auto& sh : shares) {
+    Fr t_i = rng.next_fr();
+    base.push_back(pk.g1_a); k.push_back(sh.second);
+    base.push_back(pk.g1); k.push_back(fr_neg(fr_mul(sha3_hash_fr(remove_index(sh.first)), t_i)));
+    base.push_back(pk.g1); k.push_back(t_i);
+  }
+  std::vector<G1> m = eng.g1_mul(base, k);
+  std::vector<Gt> pw = eng.gt_pow({pk.e_gg_alpha, eng.gt_generator()}, {secret, msg_k});
+  Ghw11Ciphertext ct;
+  ct.policy = {policy, language};
+  ct.c = eng.gt_mul({pw[0]}, {pw[1]})[0];
+  ct.c1 = m[0];
+  std::vector<G1> ca, cb;
+  for (size_t i = 0; i < shares.size(); i++) { ca.push_back(m[1 + 3 * i]); cb.push_back(m[2 + 3 * i]); }
+  std::vector<G1> ci = shares.empty() ? std::vector<G1>() : g1_add(eng, ca, cb);
+  for (size_t i = 0; i < shares.size(); i++) ct.ci_di.push_back({shares[i].first, ci[i], m[3 + 3 * i]});
+  ct.data = seal(rng, pw[1], plaintext);
+  return ct;
+}
+static void plan_transform(PolicyMemo& memo, const Ghw11Ciphertext& ct, const Ghw11TransformKey& tk, PairingJob* job) {      // :231-295
+  std::vector<std::string> attr;
+  for (const auto& v : tk.attr_key_z) attr.push_back(v.string);
+  const PolicyMemo::Entry& pe = memo.get(ct.policy.first, ct.policy.second);
+  if (!traverse_policy(attr, pe.tree)) throw RabeError("Error: attributes in tk do not match policy in ct.");
+  PrunedList list;
+  bool ok = calc_pruned(attr, pe.tree, &list);
+  if (!ok) throw RabeError("Error in Ghw11/decrypt: attributes in sk do not match policy in ct.");
+  // t = e(c1, k_z) / ( prod_i e(w_i D_i, K_i) * e(sum_i w_i C_i, l_z) )
+  //   = FE( ML(c1, k_z) * prod_i ML(-w_i D_i, K_i) * ML(sum_i (-w_i) C_i, l_z) )
+  job->lead_one = true;
+  job->base.push_back(ct.c1); job->scal.push_back(fr_one()); job->q.push_back(tk.k_z);
+  for (const auto& cur : list) {
+    const Fr* coeff = nullptr;
+    const Ghw11Attribute* tk_attr = nullptr;
+    const Ghw11CtRow* ct_attr = nullptr;
+    for (const auto& x : pe.coeff) if (x.first == cur.second) { coeff = &x.second; break; }
+    for (const auto& x : tk.attr_key_z) if (x.string == cur.first) { tk_attr = &x; break; }
+    for (const auto& x : ct.ci_di) if (x.name == cur.second) { ct_attr = &x; break; }
+    if (!coeff || !tk_attr || !ct_attr) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+    const Fr nw = fr_neg(*coeff);
+    job->base.push_back(ct_attr->d); job->scal.push_back(nw); job->q.push_back(tk_attr->k_x);
+    job->sbase.push_back(ct_attr->c); job->sscal.push_back(nw);
+  }
+  job->sq = tk.l_z;
+}
+std::vector<Ghw11TransformCiphertext> transform_batch(Engine& eng, const std::vector<const Ghw11Ciphertext*>& cts,
+                                                      const std::vector<const Ghw11TransformKey*>& tks, std::vector<std::string>* errors) {
+  if (cts.size() != tks.size()) throw RabeError("transform_batch: cts and tks differ in length");
+  PolicyMemo memo;
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_transform(memo, *cts[i], *tks[i], j); });
+  std::vector<Gt> t = run_pairing_jobs(eng, jobs);
+  std::vector<Ghw11TransformCiphertext> out(cts.size());
+  if (errors) errors->assign(cts.size(), "");
+  for (size_t i = 0; i < cts.size(); i++) {
+    if (jobs[i].failed) { if (errors) (*errors)[i] = jobs[i].error; continue; }
+    out[i] = Ghw11TransformCiphertext{cts[i]->c, t[i]};
+  }
+  return out;
+}
+Ghw11TransformCiphertext transform(Engine& eng, const Ghw11Ciphertext& ct, const Ghw11TransformKey& tk) {
+  std::vector<std::string> errors;
+  auto r = transform_batch(eng, {&ct}, {&tk}, &errors);
+  if (!errors[0].empty()) throw RabeError(errors[0]);
+  return r[0];
+}
+Gt decrypt_out_gt(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk) {       // :298-305
+  // msg = c * (t^z)^-1 = c * t^(-z)   (Gt has order r)
+  Gt p = eng.gt_pow({pct.t}, {fr_neg(rk.z)})[0];
+  return eng.gt_mul({pct.c}, {p})[0];
+}
+Bytes decrypt_out(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk, const Bytes& data) {
+  return open_or_error(decrypt_out_gt(eng, pct, rk), data);
+}
+}  // namespace ghw11
 
 }  // namespace schemes
 }  // namespace rabe

@@ -118,4 +118,29 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, c
                                          const std::vector<const Aw11Ciphertext*>& cts);
 }  // namespace aw11
 
+namespace ghw11 {
+struct Ghw11PublicKey { G1 g1; G2 g2; G1 g1_a; G2 g2_a; Gt e_gg_alpha; };                  // :19-28
+struct Ghw11MasterKey { G2 g2_alpha; Ghw11PublicKey pk; };                                 // :30-36
+struct Ghw11Attribute { std::string string; G2 k_x; };                                     // :52-57
+struct Ghw11SecretKey { G2 k; G2 l; std::vector<Ghw11Attribute> attr_key; };               // :38-49
+struct Ghw11TransformKey { G2 k_z; G2 l_z; std::vector<Ghw11Attribute> attr_key_z; };     // :59-66
+struct Ghw11RetrieveKey { Fr z; };                                                         // :68-73
+struct Ghw11CtRow { std::string name; G1 c; G1 d; };                                       // (String, G1, G1) :82
+struct Ghw11Ciphertext { PolicyRef policy; Gt c; G1 c1; std::vector<Ghw11CtRow> ci_di; Bytes data; };   // :75-84
+struct Ghw11TransformCiphertext { Gt c; Gt t; };                                           // :86-91
+
+std::pair<Ghw11PublicKey, Ghw11MasterKey> setup(Engine& eng, Rng& rng);
+bool keygen(Engine& eng, Rng& rng, const Ghw11PublicKey& pk, const Ghw11MasterKey& msk, const std::vector<std::string>& attributes,
+            Ghw11SecretKey* out);       // Option<..>: false = None
+std::pair<Ghw11TransformKey, Ghw11RetrieveKey> tkgen(Engine& eng, Rng& rng, const Ghw11SecretKey& sk);
+Ghw11Ciphertext encrypt(Engine& eng, Rng& rng, const Ghw11PublicKey& pk, const std::string& policy, PolicyLanguage language, const Bytes& plaintext);
+// the outsourced part: m + 2 pairings (one final exponentiation) and 2m G1 multiplications per ciphertext
+Ghw11TransformCiphertext transform(Engine& eng, const Ghw11Ciphertext& ct, const Ghw11TransformKey& tk);
+// "decrypt-as-a-service": n independent transforms in one launch set; ok[i] false (with errors[i]) where tk i does not satisfy ct i
+std::vector<Ghw11TransformCiphertext> transform_batch(Engine& eng, const std::vector<const Ghw11Ciphertext*>& cts,
+                                                      const std::vector<const Ghw11TransformKey*>& tks, std::vector<std::string>* errors);
+Gt decrypt_out_gt(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk);
+Bytes decrypt_out(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk, const Bytes& data);
+}  // namespace ghw11
+
 }}  // namespace rabe::schemes

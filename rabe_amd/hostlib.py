@@ -9,7 +9,8 @@ JSON_POLICY, HUMAN_POLICY = 0, 1
 KINDS = {"ac17_pk": 1, "ac17_msk": 2, "ac17_cp_sk": 3, "ac17_cp_ct": 4, "ac17_kp_sk": 5, "ac17_kp_ct": 6,
          "bsw_pk": 10, "bsw_msk": 11, "bsw_sk": 12, "bsw_ct": 13,
          "lsw_pk": 20, "lsw_msk": 21, "lsw_sk": 22, "lsw_ct": 23,
-         "aw11_gk": 30, "aw11_pk": 31, "aw11_msk": 32, "aw11_sk": 33, "aw11_ct": 34}
+         "aw11_gk": 30, "aw11_pk": 31, "aw11_msk": 32, "aw11_sk": 33, "aw11_ct": 34,
+         "ghw11_pk": 40, "ghw11_msk": 41, "ghw11_sk": 42, "ghw11_tk": 43, "ghw11_rk": 44, "ghw11_ct": 45, "ghw11_tct": 46}
 
 
 class RabeError(Exception):
@@ -274,6 +275,20 @@ def parse_obj(kind, data):
         o = {"gid": r.s(), "attr": [(r.s(), r.raw(64)) for _ in range(r.u32())]}
     elif kind == "aw11_ct":
         o = {"policy": r.pol(), "c_0": r.raw(384), "c": [(r.s(), r.raw(384), r.raw(128), r.raw(128)) for _ in range(r.u32())], "ct": r.raw(r.u32())}
+    elif kind == "ghw11_pk":
+        o = {"g1": r.raw(64), "g2": r.raw(128), "g1_a": r.raw(64), "g2_a": r.raw(128), "e_gg_alpha": r.raw(384)}
+    elif kind == "ghw11_msk":
+        o = {"g2_alpha": r.raw(128), "pk": {"g1": r.raw(64), "g2": r.raw(128), "g1_a": r.raw(64), "g2_a": r.raw(128), "e_gg_alpha": r.raw(384)}}
+    elif kind == "ghw11_sk":
+        o = {"k": r.raw(128), "l": r.raw(128), "attr_key": [(r.s(), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "ghw11_tk":
+        o = {"k_z": r.raw(128), "l_z": r.raw(128), "attr_key_z": [(r.s(), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "ghw11_rk":
+        o = {"z": r.raw(32)}
+    elif kind == "ghw11_ct":
+        o = {"policy": r.pol(), "c": r.raw(384), "c1": r.raw(64), "ci_di": [(r.s(), r.raw(64), r.raw(64)) for _ in range(r.u32())], "data": r.raw(r.u32())}
+    elif kind == "ghw11_tct":
+        o = {"c": r.raw(384), "t": r.raw(384)}
     else:
         raise ValueError(kind)
     r.done()

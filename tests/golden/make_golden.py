@@ -238,11 +238,44 @@ def bsw_delegate_cases():
     return doc
 
 
+def ghw11_cases():
+    """ghw11 (ghw11/mod.rs:92-305; reference tests or / and / or_and :308-449): keygen -> tkgen -> encrypt -> transform -> decrypt_out."""
+    rng = SeededRng(23)
+    pk, msk = sch.ghw11_setup(rng)
+
+    def pkd(p):
+        return {"g1": g1(p["g1"]), "g2": g2(p["g2"]), "g1_a": g1(p["g1_a"]), "g2_a": g2(p["g2_a"]), "e_gg_alpha": gt(p["e_gg_alpha"])}
+    doc = {"pk": pkd(pk), "msk": {"g2_alpha": g2(msk["g2_alpha"])}, "cases": []}
+    cases = [(r'''{"name": "or", "children": [{"name": "A"}, {"name": "B"}]}''', pol.JSON, ["D", "B"]),
+             (r'''{"name": "and", "children": [{"name": "A"}, {"name": "B"}, {"name": "C"}]}''', pol.JSON, ["A", "B", "C"]),
+             ('"X" or ("B" and "C")', pol.HUMAN, ["B", "C", "D"])]
+    for policy, lang, attrs in cases:
+        kt = [rng.fr()]
+        sk = sch.ghw11_keygen(pk, msk, attrs, ListRng(kt))
+        zt = [rng.fr_nonzero()]
+        tk, rk = sch.ghw11_tkgen(sk, ListRng(zt))
+        rec = RecRng(rng.fr() % (1 << 62))
+        rho = rng.fr_nonzero()
+        msg = bn.gt_pow(E_GEN, rho)
+        ct = sch.ghw11_encrypt(pk, policy, lang, rec, msg)
+        pct = sch.ghw11_transform(ct, tk)
+        dec = sch.ghw11_decrypt_out(pct, rk)
+        assert dec == msg
+        doc["cases"].append({
+            "policy": policy, "language": lang, "attrs": attrs, "keygen_tape": [fr(x) for x in kt], "tkgen_tape": [fr(x) for x in zt],
+            "encrypt_tape": [fr(x) for x in rec.log], "msg_rho": fr(rho), "msg": gt(msg),
+            "sk": {"k": g2(sk["k"]), "l": g2(sk["l"]), "attr_key": [[a["string"], g2(a["k_x"])] for a in sk["attr_key"]]},
+            "tk": {"k_z": g2(tk["k_z"]), "l_z": g2(tk["l_z"]), "attr_key_z": [[a["string"], g2(a["k_x"])] for a in tk["attr_key_z"]]},
+            "ct": {"c": gt(ct["c"]), "c1": g1(ct["c1"]), "ci_di": [[n, g1(c), g1(d)] for n, c, d in ct["ci_di"]]},
+            "t": gt(pct["t"]), "decrypted": gt(dec)})
+    return doc
+
+
 def main():
     import sys as _sys
     only = set(_sys.argv[1:])
     for name, fn in (("bn254_primitives", primitives), ("ac17", ac17_cases), ("bsw", bsw_cases), ("lsw", lsw_cases), ("aw11", aw11_cases),
-                     ("ac17_kp", ac17_kp_cases), ("bsw_delegate", bsw_delegate_cases)):
+                     ("ac17_kp", ac17_kp_cases), ("bsw_delegate", bsw_delegate_cases), ("ghw11", ghw11_cases)):
         if only and name not in only:
             continue
         doc = fn()
