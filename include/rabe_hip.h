@@ -198,7 +198,8 @@ int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items,
  * -- the Miller-loop line coefficients -- is computed once per key and replayed by every decryption with it (the
  * role of rabe-bn's G2 precomputation inside `pairing`; 3 x 88 x 192 B per key).  rhip_ac17_cp_decrypt_batch_prepared
  * takes the handle in place of dev_sk_k0 and returns exactly the values of rhip_ac17_cp_decrypt_batch; it runs the two
- * pairings of each index j on one accumulator (3 lanes per item, one Fq12 squaring per doubling step for both). */
+ * pairings of each index j on one accumulator (3 lanes per item, one Fq12 squaring per doubling step for both).
+ * rhip_ac17_sk_prepare returns after the lines are complete, so the handle may be used from any context at once. */
 typedef struct rhip_ac17_sk_lines rhip_ac17_sk_lines;
 int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g2* dev_sk_k0 /*[n_sk][3]*/, rhip_ac17_sk_lines** out);
 void rhip_ac17_sk_lines_destroy(rhip_ac17_sk_lines* p);

@@ -1727,6 +1727,7 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, 6u,
                      (const GtM*)mill, ct_cp, out);
 }
+extern "C" void rhip_ac17_sk_lines_destroy(rhip_ac17_sk_lines* p);
 extern "C" int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g2* sk_k0, rhip_ac17_sk_lines** out) {
   NEED(ctx);
   if (!out || !n_sk || !sk_k0) return RHIP_ERR_ARG;
@@ -1739,6 +1740,9 @@ extern "C" int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g
     return fail(ctx, e, "rhip_ac17_sk_prepare: hipMalloc");
   }
   KLAUNCH(ctx, "k_g2_prepare_lines", k_g2_prepare_lines, dim3(blocks_for(n_sk * 3, 64)), dim3(64), 0, ctx->stream, n_sk * 3, sk_k0, p->lines, p->q_inf);
+  // the handle is read by decrypt calls of ANY context (other streams): it must be complete when it is handed out
+  hipError_t es = hipStreamSynchronize(ctx->stream);
+  if (es != hipSuccess) { rhip_ac17_sk_lines_destroy(p); return fail(ctx, es, "rhip_ac17_sk_prepare: sync"); }
   *out = p;
   return RHIP_OK;
 }
