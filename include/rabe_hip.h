@@ -109,6 +109,22 @@ int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, const rhip_g
 int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* dev_off, size_t n_pairs,
                              const rhip_g1* dev_p, const rhip_g2* dev_q, rhip_gt* dev_out);
 
+/* ---- Level E, host-value forms: ONE element per call, host pointers (upload, launch, download).  These are what an
+ * operator-overloading replacement of the `rabe_bn` crate binds (`impl Mul<Fr> for G1`, `pairing(p, q)`, ...; see
+ * INTEGRATION.md section 2 and integration/rabe-bn-shim/): whole-program parity runs of unmodified rabe, not throughput. */
+int32_t rhip_host_fr_op(rhip_ctx* ctx, int32_t op, const rhip_fr* a, const rhip_fr* b /* NULL for NEG / INV */, rhip_fr* out);
+int32_t rhip_host_fr_from_be32_reduce(rhip_ctx* ctx, const uint8_t digest[32], rhip_fr* out);
+int32_t rhip_host_g1_add(rhip_ctx* ctx, const rhip_g1* a, const rhip_g1* b, rhip_g1* out);
+int32_t rhip_host_g1_neg(rhip_ctx* ctx, const rhip_g1* a, rhip_g1* out);
+int32_t rhip_host_g1_mul(rhip_ctx* ctx, const rhip_g1* p, const rhip_fr* k, rhip_g1* out);
+int32_t rhip_host_g2_add(rhip_ctx* ctx, const rhip_g2* a, const rhip_g2* b, rhip_g2* out);
+int32_t rhip_host_g2_neg(rhip_ctx* ctx, const rhip_g2* a, rhip_g2* out);
+int32_t rhip_host_g2_mul(rhip_ctx* ctx, const rhip_g2* p, const rhip_fr* k, rhip_g2* out);
+int32_t rhip_host_gt_mul(rhip_ctx* ctx, const rhip_gt* a, const rhip_gt* b, rhip_gt* out);
+int32_t rhip_host_gt_inv(rhip_ctx* ctx, const rhip_gt* a, rhip_gt* out);
+int32_t rhip_host_gt_pow(rhip_ctx* ctx, const rhip_gt* a, const rhip_fr* k, rhip_gt* out);
+int32_t rhip_host_pairing(rhip_ctx* ctx, const rhip_g1* p, const rhip_g2* q, rhip_gt* out);
+
 /* ---- fixed-base tables (per public key; resident in HBM) --------------------------------------
  * Every G1/G2 element the schemes create is a known-scalar multiple of a generator from the public
  * key (hash-to-group is g * Fr(SHA3(label)), src/utils/hash/mod.rs:10-20), and every Gt power is of a

@@ -1512,6 +1512,102 @@ extern "C" int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* p, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Host-value forms of the Level E operators (one element, host pointers): what an operator-overloading `rabe_bn`
+// replacement binds.  Upload, one launch, download -- for parity runs, not throughput.
+struct HostOpBuf {
+  rhip_ctx* ctx;
+  uint8_t* d = nullptr;
+  explicit HostOpBuf(rhip_ctx* c) : ctx(c) {}
+  ~HostOpBuf() { if (d) (void)hipFree(d); }
+  int32_t init(size_t bytes) { HIP_TRY(ctx, hipMalloc((void**)&d, bytes)); return RHIP_OK; }
+  int32_t put(size_t off, const void* src, size_t n) { HIP_TRY(ctx, hipMemcpyAsync(d + off, src, n, hipMemcpyHostToDevice, ctx->stream)); return RHIP_OK; }
+  int32_t get(void* dst, size_t off, size_t n) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RHIP_OK;
+  }
+};
+#define HOSTOP_BEGIN(total)                 \
+  NEED(ctx);                                \
+  HostOpBuf hb(ctx);                        \
+  int32_t rc = hb.init(total);              \
+  if (rc) return rc;
+#define HOSTOP_TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+extern "C" int32_t rhip_host_fr_op(rhip_ctx* ctx, int32_t op, const rhip_fr* a, const rhip_fr* b, rhip_fr* out) {
+  HOSTOP_BEGIN(96)
+  HOSTOP_TRY(hb.put(0, a, 32));
+  if (b) HOSTOP_TRY(hb.put(32, b, 32));
+  HOSTOP_TRY(rhip_fr_op(ctx, op, 1, (const rhip_fr*)hb.d, (const rhip_fr*)(hb.d + 32), (rhip_fr*)(hb.d + 64)));
+  return hb.get(out, 64, 32);
+}
+extern "C" int32_t rhip_host_fr_from_be32_reduce(rhip_ctx* ctx, const uint8_t digest[32], rhip_fr* out) {
+  HOSTOP_BEGIN(64)
+  HOSTOP_TRY(hb.put(0, digest, 32));
+  HOSTOP_TRY(rhip_fr_from_be32_reduce(ctx, 1, hb.d, (rhip_fr*)(hb.d + 32)));
+  return hb.get(out, 32, 32);
+}
+extern "C" int32_t rhip_host_g1_add(rhip_ctx* ctx, const rhip_g1* a, const rhip_g1* b, rhip_g1* out) {
+  HOSTOP_BEGIN(192)
+  HOSTOP_TRY(hb.put(0, a, 64)); HOSTOP_TRY(hb.put(64, b, 64));
+  HOSTOP_TRY(rhip_g1_add(ctx, 1, (const rhip_g1*)hb.d, (const rhip_g1*)(hb.d + 64), (rhip_g1*)(hb.d + 128)));
+  return hb.get(out, 128, 64);
+}
+extern "C" int32_t rhip_host_g1_neg(rhip_ctx* ctx, const rhip_g1* a, rhip_g1* out) {
+  HOSTOP_BEGIN(128)
+  HOSTOP_TRY(hb.put(0, a, 64));
+  HOSTOP_TRY(rhip_g1_neg(ctx, 1, (const rhip_g1*)hb.d, (rhip_g1*)(hb.d + 64)));
+  return hb.get(out, 64, 64);
+}
+extern "C" int32_t rhip_host_g1_mul(rhip_ctx* ctx, const rhip_g1* p, const rhip_fr* k, rhip_g1* out) {
+  HOSTOP_BEGIN(160)
+  HOSTOP_TRY(hb.put(0, p, 64)); HOSTOP_TRY(hb.put(64, k, 32));
+  HOSTOP_TRY(rhip_g1_mul(ctx, 1, (const rhip_g1*)hb.d, (const rhip_fr*)(hb.d + 64), (rhip_g1*)(hb.d + 96)));
+  return hb.get(out, 96, 64);
+}
+extern "C" int32_t rhip_host_g2_add(rhip_ctx* ctx, const rhip_g2* a, const rhip_g2* b, rhip_g2* out) {
+  HOSTOP_BEGIN(384)
+  HOSTOP_TRY(hb.put(0, a, 128)); HOSTOP_TRY(hb.put(128, b, 128));
+  HOSTOP_TRY(rhip_g2_add(ctx, 1, (const rhip_g2*)hb.d, (const rhip_g2*)(hb.d + 128), (rhip_g2*)(hb.d + 256)));
+  return hb.get(out, 256, 128);
+}
+extern "C" int32_t rhip_host_g2_neg(rhip_ctx* ctx, const rhip_g2* a, rhip_g2* out) {
+  HOSTOP_BEGIN(256)
+  HOSTOP_TRY(hb.put(0, a, 128));
+  HOSTOP_TRY(rhip_g2_neg(ctx, 1, (const rhip_g2*)hb.d, (rhip_g2*)(hb.d + 128)));
+  return hb.get(out, 128, 128);
+}
+extern "C" int32_t rhip_host_g2_mul(rhip_ctx* ctx, const rhip_g2* p, const rhip_fr* k, rhip_g2* out) {
+  HOSTOP_BEGIN(288)
+  HOSTOP_TRY(hb.put(0, p, 128)); HOSTOP_TRY(hb.put(128, k, 32));
+  HOSTOP_TRY(rhip_g2_mul(ctx, 1, (const rhip_g2*)hb.d, (const rhip_fr*)(hb.d + 128), (rhip_g2*)(hb.d + 160)));
+  return hb.get(out, 160, 128);
+}
+extern "C" int32_t rhip_host_gt_mul(rhip_ctx* ctx, const rhip_gt* a, const rhip_gt* b, rhip_gt* out) {
+  HOSTOP_BEGIN(1152)
+  HOSTOP_TRY(hb.put(0, a, 384)); HOSTOP_TRY(hb.put(384, b, 384));
+  HOSTOP_TRY(rhip_gt_mul(ctx, 1, (const rhip_gt*)hb.d, (const rhip_gt*)(hb.d + 384), (rhip_gt*)(hb.d + 768)));
+  return hb.get(out, 768, 384);
+}
+extern "C" int32_t rhip_host_gt_inv(rhip_ctx* ctx, const rhip_gt* a, rhip_gt* out) {
+  HOSTOP_BEGIN(768)
+  HOSTOP_TRY(hb.put(0, a, 384));
+  HOSTOP_TRY(rhip_gt_inv(ctx, 1, (const rhip_gt*)hb.d, (rhip_gt*)(hb.d + 384)));
+  return hb.get(out, 384, 384);
+}
+extern "C" int32_t rhip_host_gt_pow(rhip_ctx* ctx, const rhip_gt* a, const rhip_fr* k, rhip_gt* out) {
+  HOSTOP_BEGIN(800)
+  HOSTOP_TRY(hb.put(0, a, 384)); HOSTOP_TRY(hb.put(384, k, 32));
+  HOSTOP_TRY(rhip_gt_pow(ctx, 1, (const rhip_gt*)hb.d, (const rhip_fr*)(hb.d + 384), (rhip_gt*)(hb.d + 416)));
+  return hb.get(out, 416, 384);
+}
+extern "C" int32_t rhip_host_pairing(rhip_ctx* ctx, const rhip_g1* p, const rhip_g2* q, rhip_gt* out) {
+  HOSTOP_BEGIN(576)
+  HOSTOP_TRY(hb.put(0, p, 64)); HOSTOP_TRY(hb.put(64, q, 128));
+  HOSTOP_TRY(rhip_pairing(ctx, 1, (const rhip_g1*)hb.d, (const rhip_g2*)(hb.d + 64), (rhip_gt*)(hb.d + 192)));
+  return hb.get(out, 192, 384);
+}
+
+// ------------------------------------------------------------------------------------------------
 // tables
 template <class TBL, class ENTRY, class BASE, class KERN>
 static int32_t table_create(rhip_ctx* ctx, const BASE* host_base, TBL** out, KERN kern, unsigned bs) {
