@@ -541,17 +541,18 @@ std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17
   if (rc == RHIP_OK) { c0 = fetch<128>(dc0, n * 3); c = fetch<64>(dc, total_rows * 3); cp = fetch<384>(dcp, n); }
   eng.check(rc, "rhip_ac17_cp_encrypt_batch");
   std::vector<Ac17CpCiphertext> out(n);
-  for (size_t i = 0; i < n; i++) {
+  parallel_for(n, [&](size_t i) {               // struct assembly + KDF + AES-GCM per item, on all cores
     const AbePolicy& msp = msps[item_pol[i]];
     out[i].policy = {policies[i], language};
     out[i].ct.c_0 = {c0[3 * i], c0[3 * i + 1], c0[3 * i + 2]};
+    out[i].ct.c.reserve(msp.m.size());
     for (size_t r = 0; r < msp.m.size(); r++) {
       size_t g = (size_t)row_off[i] + r;
       out[i].ct.c.push_back({msp.pi[r], {c[3 * g], c[3 * g + 1], c[3 * g + 2]}});
     }
     out[i].ct.c_p = cp[i];
     out[i].ct.ct = encrypt_symmetric(msgs[i].data(), plaintexts[i].data(), plaintexts[i].size(), nonces[i].data());
-  }
+  });
   return out;
 }
 
@@ -578,17 +579,27 @@ static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& it
   std::vector<uint32_t> ct_row_off{0}, sk_row_off{0}, sk_idx, ct_sel, sk_sel, ct_sel_off{0}, sk_sel_off{0};
   std::vector<size_t> live;
   std::map<const Ac17SecretKey*, uint32_t> key_slot;       // items that share a key object share its device copy (and its prepared lines)
-  for (size_t i = 0; i < n; i++) {
+  // per item, on all cores: parse (once per distinct policy), traverse, prune, and the name-matching loops of
+  // :403-414 / :643-654 as index lists
+  struct Plan { std::vector<uint32_t> ct_sel, sk_sel; };
+  std::vector<Plan> plans(n);
+  PolicyMemo memo;
+  parallel_for(n, [&](size_t i) {
     const DecItem& it = items[i];
-    PolicyNode tree = parse_or_error(it.policy->first, it.policy->second);
-    if (!traverse_policy(*it.attrs, tree)) { (*errors)[i] = it.err_traverse; continue; }
+    const PolicyNode& tree = memo.get(it.policy->first, it.policy->second).tree;
+    if (!traverse_policy(*it.attrs, tree)) { (*errors)[i] = it.err_traverse; return; }
     PrunedList lst;
-    if (!calc_pruned(*it.attrs, tree, &lst)) { (*errors)[i] = it.err_pruned; continue; }
-    // the name-matching loops of :403-414 / :643-654, as index lists
+    if (!calc_pruned(*it.attrs, tree, &lst)) { (*errors)[i] = it.err_pruned; return; }
     for (const auto& cur : lst) {
-      for (size_t r = 0; r < it.ct->c.size(); r++) if (it.ct->c[r].first == cur.first) ct_sel.push_back((uint32_t)r);
-      for (size_t r = 0; r < it.sk->k.size(); r++) if (it.sk->k[r].first == cur.first) sk_sel.push_back((uint32_t)r);
+      for (size_t r = 0; r < it.ct->c.size(); r++) if (it.ct->c[r].first == cur.first) plans[i].ct_sel.push_back((uint32_t)r);
+      for (size_t r = 0; r < it.sk->k.size(); r++) if (it.sk->k[r].first == cur.first) plans[i].sk_sel.push_back((uint32_t)r);
     }
+  });
+  for (size_t i = 0; i < n; i++) {
+    if (!(*errors)[i].empty()) continue;
+    const DecItem& it = items[i];
+    ct_sel.insert(ct_sel.end(), plans[i].ct_sel.begin(), plans[i].ct_sel.end());
+    sk_sel.insert(sk_sel.end(), plans[i].sk_sel.begin(), plans[i].sk_sel.end());
     ct_sel_off.push_back((uint32_t)ct_sel.size());
     sk_sel_off.push_back((uint32_t)sk_sel.size());
     for (const auto& x : it.ct->c_0) ct_c0.insert(ct_c0.end(), x.begin(), x.end());
