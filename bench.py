@@ -49,7 +49,7 @@ IMPL_FINAL_EXP_FPMUL = 7553         # tools/count_muls.py: final_exponentiation_
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--steps", type=int, default=800)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="items per step per GPU")
     ap.add_argument("--attrs", type=int, default=50)
