@@ -63,6 +63,11 @@ int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, i
 int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct);
 int32_t rabe_ac17_kp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* n independent kp_encrypt / kp_decrypt calls in one launch set; item i's attributes are the next counts[i] entries of `attributes` */
+int32_t rabe_ac17_kp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* attributes, const size_t* counts,
+                                   const uint8_t* const* datas, const size_t* lens, void** cts);
+int32_t rabe_ac17_kp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
+                                   uint8_t** plaintexts, size_t* lens);
 
 /* ---- bsw (src/schemes/bsw/mod.rs:92-318) */
 int32_t rabe_bsw_setup(rabe_host* h, void** pk, void** msk);

@@ -360,6 +360,28 @@ int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, ui
   GUARD_END(h)
 }
 
+int32_t rabe_ac17_kp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* attributes, const size_t* counts,
+                                   const uint8_t* const* datas, const size_t* lens, void** cts) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets;
+  size_t pos = 0;
+  for (size_t i = 0; i < n; i++) { sets.push_back(strs(attributes + pos, counts[i])); pos += counts[i]; }
+  auto r = ac17::kp_encrypt_batch(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, sets, byte_items(datas, lens, n));
+  for (size_t i = 0; i < n; i++) cts[i] = new ac17::Ac17KpCiphertext(r[i]);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_kp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                                   size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const ac17::Ac17KpSecretKey*> s;
+  std::vector<const ac17::Ac17KpCiphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const ac17::Ac17KpSecretKey*)sks[i]); c.push_back((const ac17::Ac17KpCiphertext*)cts[i]); }
+  give_results(h, ac17::kp_decrypt_batch(h->eng, s, c), status, plaintexts, lens);
+  return 0;
+  GUARD_END(h)
+}
+
 // ---------------------------------------------------------------- bsw
 int32_t rabe_bsw_delegate(rabe_host* h, const void* pk, const void* sk, const char* const* subset, size_t n, void** out_sk) {
   GUARD_BEGIN

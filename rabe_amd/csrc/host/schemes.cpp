@@ -742,33 +742,74 @@ Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
   return out;
 }
 
-Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data) {   // :556-616
-  const size_t rows = attributes.size();
-  Fr s0 = rng.next_fr(), s1 = rng.next_fr();
-  Gt msg = eng.random_gt(rng);
-  // C[y][l] = g*(s0 h(y||l||0) + s1 h(y||l||1)): the CP row kernel with a table of plain label hashes
-  std::vector<Fr> A;
-  for (const auto& a : attributes)
-    for (int l = 0; l < 3; l++)
-      for (int t = 0; t < 2; t++) A.push_back(sha3_hash_fr(a + std::to_string(l) + std::to_string(t)));
+std::vector<Ac17KpCiphertext> kp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& attribute_sets,
+                                               const std::vector<Bytes>& datas) {   // :556-616, n times
+  if (attribute_sets.size() != datas.size()) throw RabeError("kp_encrypt_batch: attribute sets / datas length mismatch");
+  const size_t n = attribute_sets.size();
+  std::vector<Ac17KpCiphertext> out(n);
+  if (!n) return out;
+  // draw order per call: s0, s1, msg, nonce -- item after item
+  std::vector<Fr> s, msg_k;
+  std::vector<std::array<uint8_t, 12>> nonces(n);
+  for (size_t i = 0; i < n; i++) {
+    s.push_back(rng.next_fr());
+    s.push_back(rng.next_fr());
+    msg_k.push_back(rng.next_fr());
+    rng.fill(nonces[i].data(), 12);
+  }
+  // C[y][l] = g*(s0 h(y||l||0) + s1 h(y||l||1)): the CP row kernel with a table of plain label hashes, one block of rows per item
+  std::vector<uint32_t> item_a_off(n), row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) { item_a_off[i] = row_off[i]; row_off[i + 1] = row_off[i] + (uint32_t)attribute_sets[i].size(); }
+  const size_t total_rows = row_off[n];
+  std::vector<Fr> A(total_rows * 6);
+  parallel_for(n, [&](size_t i) {
+    for (size_t y = 0; y < attribute_sets[i].size(); y++)
+      for (int l = 0; l < 3; l++)
+        for (int t = 0; t < 2; t++)
+          A[((size_t)row_off[i] + y) * 6 + l * 2 + t] = sha3_hash_fr(attribute_sets[i][y] + std::to_string(l) + std::to_string(t));
+  });
+  std::vector<Gt> msgs = eng.gt_pow(std::vector<Gt>(n, eng.gt_generator()), msg_k);
   rhip_ac17_pk* dpk = eng.ac17_pk(pk.g, pk.h_a, pk.e_gh_ka);
-  uint32_t zero = 0, row_off[2] = {0, (uint32_t)rows};
-  auto fA = flatten_fr(A), fs = flatten_fr({s0, s1});
-  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, &zero, 4), dro(&eng, row_off, 8), ds(&eng, fs.data(), fs.size()), dm(&eng, msg.data(), 384),
-      dc0(&eng, 3 * 128), dc(&eng, rows * 3 * 64), dcp(&eng, 384);
-  int32_t rc = rhip_ac17_cp_encrypt_batch(eng.ctx(), dpk, 1, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), rows, ds.as<rhip_fr>(),
-                                          dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>());
+  auto fA = flatten_fr(A), fs = flatten_fr(s), fm = flatten(msgs);
+  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, item_a_off.data(), n * 4), dro(&eng, row_off.data(), (n + 1) * 4), ds(&eng, fs.data(), fs.size()),
+      dm(&eng, fm.data(), fm.size()), dc0(&eng, n * 3 * 128), dc(&eng, total_rows * 3 * 64), dcp(&eng, n * 384);
+  int32_t rc = rhip_ac17_cp_encrypt_batch(eng.ctx(), dpk, n, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), total_rows,
+                                          ds.as<rhip_fr>(), dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>());
   std::vector<G2> c0;
   std::vector<G1> c;
   std::vector<Gt> cp;
-  if (rc == RHIP_OK) { c0 = fetch<128>(dc0, 3); c = fetch<64>(dc, rows * 3); cp = fetch<384>(dcp, 1); }
+  if (rc == RHIP_OK) { c0 = fetch<128>(dc0, n * 3); c = fetch<64>(dc, total_rows * 3); cp = fetch<384>(dcp, n); }
   eng.check(rc, "rhip_ac17_cp_encrypt_batch");
-  Ac17KpCiphertext out;
-  out.attr = attributes;
-  out.ct.c_0 = c0;
-  for (size_t i = 0; i < rows; i++) out.ct.c.push_back({attributes[i], {c[3 * i], c[3 * i + 1], c[3 * i + 2]}});
-  out.ct.c_p = cp[0];
-  out.ct.ct = seal(rng, msg, data);
+  parallel_for(n, [&](size_t i) {
+    out[i].attr = attribute_sets[i];
+    out[i].ct.c_0 = {c0[3 * i], c0[3 * i + 1], c0[3 * i + 2]};
+    for (size_t y = 0; y < attribute_sets[i].size(); y++) {
+      size_t g = (size_t)row_off[i] + y;
+      out[i].ct.c.push_back({attribute_sets[i][y], {c[3 * g], c[3 * g + 1], c[3 * g + 2]}});
+    }
+    out[i].ct.c_p = cp[i];
+    out[i].ct.ct = encrypt_symmetric(msgs[i].data(), datas[i].data(), datas[i].size(), nonces[i].data());
+  });
+  return out;
+}
+Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data) {   // :556-616
+  return kp_encrypt_batch(eng, rng, pk, {attributes}, {data})[0];
+}
+std::vector<DecryptResult> kp_decrypt_batch(Engine& eng, const std::vector<const Ac17KpSecretKey*>& sks, const std::vector<const Ac17KpCiphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("kp_decrypt_batch: sks and cts differ in length");
+  std::vector<DecItem> items;
+  for (size_t i = 0; i < cts.size(); i++)
+    items.push_back({&cts[i]->attr, &sks[i]->policy, &cts[i]->ct, &sks[i]->sk, "Error in kp_decrypt: attributes in ct do not match policy in sk.",
+                     "Error in kp_decrypt: pruned attributes in sk do not match policy in ct."});
+  std::vector<std::string> errors;
+  std::vector<Gt> g = decrypt_items(eng, items, &errors);
+  std::vector<DecryptResult> out(cts.size());
+  for (size_t i = 0; i < cts.size(); i++) {
+    if (!errors[i].empty()) { out[i] = {false, {}, errors[i]}; continue; }
+    Bytes pt;
+    if (decrypt_symmetric(g[i].data(), cts[i]->ct.ct.data(), cts[i]->ct.ct.size(), &pt)) out[i] = {true, pt, ""};
+    else out[i] = {false, {}, "decryption error: aead::Error"};
+  }
   return out;
 }
 Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct) {      // :625-675

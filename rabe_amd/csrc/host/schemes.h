@@ -45,6 +45,9 @@ Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
 Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data);
 Bytes kp_decrypt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
 Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
+std::vector<Ac17KpCiphertext> kp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& attribute_sets,
+                                               const std::vector<Bytes>& datas);
+std::vector<DecryptResult> kp_decrypt_batch(Engine& eng, const std::vector<const Ac17KpSecretKey*>& sks, const std::vector<const Ac17KpCiphertext*>& cts);
 }  // namespace ac17
 
 namespace bsw {

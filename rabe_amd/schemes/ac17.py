@@ -1,7 +1,7 @@
 """rabe::schemes::ac17 (src/schemes/ac17/mod.rs:141-430) over the host layer."""
 import ctypes
 
-from ..hostlib import JSON_POLICY, Obj, _strs
+from ..hostlib import JSON_POLICY, Obj, _strs, batch_decrypt, batch_items
 
 
 def setup(host):
@@ -80,3 +80,19 @@ def kp_decrypt(host, sk, ct):
 
 def kp_decrypt_gt(host, sk, ct):
     return host.out_gt("rabe_ac17_kp_decrypt_gt", sk.ptr, ct.ptr)
+
+
+def kp_encrypt_batch(host, pk, attribute_sets, datas):
+    """n independent kp_encrypt calls in one launch set"""
+    n = len(attribute_sets)
+    flat = [a for s in attribute_sets for a in s]
+    arr, _ = _strs(flat)
+    counts = (ctypes.c_size_t * max(1, n))(*[len(s) for s in attribute_sets])
+    pts, lens = batch_items(datas)
+    out = (ctypes.c_void_p * max(1, n))()
+    host.call("rabe_ac17_kp_encrypt_batch", pk.ptr, ctypes.c_size_t(n), arr, counts, pts, lens, out)
+    return [Obj("ac17_kp_ct", ctypes.c_void_p(out[i])) for i in range(n)]
+
+
+def kp_decrypt_batch(host, sks, cts):
+    return batch_decrypt(host, "rabe_ac17_kp_decrypt_batch", (), sks, cts)

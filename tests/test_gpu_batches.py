@@ -115,3 +115,21 @@ def test_fixed_base_tables_do_not_change_results(host):
         assert lsw.decrypt(host, lsk, lct) == PTS[1]
     host.set_fixed_base_min(4096)
     assert outs[0] == outs[1]
+
+
+def test_ac17_kp_encrypt_decrypt_batch(host):
+    from rabe_amd.schemes import ac17
+    pk, msk = ac17.setup(host)
+    policies = [gate("and", leaf("A"), leaf("B")), gate("or", leaf("C"), gate("and", leaf("A"), leaf("D")))]
+    sks = [ac17.kp_keygen(host, msk, p, hl.JSON_POLICY) for p in policies]
+    sets = [["A", "B"], ["C"], ["A", "B", "C", "D"], ["D"], ["A", "D"]]
+    t = tape(6)
+    host.set_tape(t)
+    batch = ac17.kp_encrypt_batch(host, pk, sets, PTS)
+    host.set_tape(t)
+    singles = [ac17.kp_encrypt(host, pk, s, pt) for s, pt in zip(sets, PTS)]
+    host.clear_tape()
+    assert [c.serialize() for c in batch] == [c.serialize() for c in singles]
+    # key 0 ("A" and "B") opens items 0 and 2; key 1 (C or (A and D)) opens items 1, 2 and 4
+    assert ac17.kp_decrypt_batch(host, [sks[0]] * 5, batch) == [PTS[0], None, PTS[2], None, None]
+    assert ac17.kp_decrypt_batch(host, [sks[1]] * 5, batch) == [None, PTS[1], PTS[2], None, PTS[4]]
