@@ -81,7 +81,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # nccl (= RCCL) on the GPUs; RABE_DIST_BACKEND=gloo lets several ranks share one GPU for a functional check
+        dist.init_process_group(backend=os.environ.get("RABE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     torch.cuda.set_device(local_rank)
 
@@ -236,7 +237,7 @@ def main():
     want = eng.download(dmsg)
     ok = all(lanes_ctx[i].download(bufs[i][3]) == want for i in range(S))
     if world > 1:
-        f = torch.tensor([1 if ok else 0], device="cuda")
+        f = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
 
