@@ -146,7 +146,7 @@ def test_cp_decrypt_roundtrip_and_reference(env, policy, lang, attrs):
     assert bn.gt_to_le(sch.ac17_cp_decrypt(sk, ct)) == out[:384]
 
 
-@pytest.mark.parametrize("w_bits", [17, 19, 22])
+@pytest.mark.parametrize("w_bits", [17, 19, 22, 26])          # 26 = bench.py's default (19 GB table)
 def test_cp_encrypt_rows_with_wide_signed_windows(w_bits):
     """signed w-bit fixed-base windows for g (rhip_ac17_pk_set_g_window): the same ciphertext bytes as the
     16-bit tables, which the tests above pin to the oracle.  Scalars with extreme digits included."""
