@@ -265,6 +265,18 @@ extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* de
   return RHIP_OK;
 }
 
+// work submitted to `ctx` after this call starts only when everything submitted to `other` so far has finished
+extern "C" int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other) {
+  if (!ctx || !other) return RHIP_ERR_ARG;
+  hipEvent_t ev;
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, other->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+  (void)hipEventDestroy(ev);                 // released by the runtime once the recorded work has completed
+  if (e != hipSuccess) return fail(ctx, e, "rhip_ctx_wait_for");
+  return RHIP_OK;
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // ------------------------------------------------------------------------------------------------

@@ -206,6 +206,10 @@ class Engine:
     def host_free(self, p):
         self._check(self.lib.rhip_host_free(self.ctx, p))
 
+    def wait_for(self, other):
+        """order this context's future work after everything submitted to `other` so far (no host wait)"""
+        self._check(self.lib.rhip_ctx_wait_for(self.ctx, other.ctx))
+
     def upload_async(self, dev, host_ptr, nbytes):
         self._check(self.lib.rhip_upload_async(self.ctx, dev.ptr, host_ptr, ctypes.c_size_t(nbytes)))
 
