@@ -37,13 +37,13 @@ G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
 
 # Algorithmic work, in Fp multiplications (1 Fp mul = 136 32x32 multiply-adds: 8-limb CIOS), per lane:
 #   SURVEY.md 8d constants (the "algorithmic minimum" the roofline is priced against) and the
-#   instrumented counts of this engine's own code (tools/count_muls.py).
+#   instrumented counts of this engine's own code (tests/count_muls.py).
 MAC_PER_FPMUL = 136
 SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
 SURVEY_MIXED_ADD_FPMUL = 11
-IMPL_MILLER_FPMUL = 8983            # tools/count_muls.py: miller_loop (NAF chain) with Jacobian P
-IMPL_MILLER2_FPMUL = 12170          # tools/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
-IMPL_FINAL_EXP_FPMUL = 7553         # tools/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
+IMPL_MILLER_FPMUL = 8983            # tests/count_muls.py: miller_loop (NAF chain) with Jacobian P
+IMPL_MILLER2_FPMUL = 12170          # tests/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
+IMPL_FINAL_EXP_FPMUL = 7553         # tests/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
 
 
 def parse_args():
