@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_pow(size_t n, const rhi
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  store_gt(out[i].l, gt_pow_binary(load_gt(a[i].l), kk));
+  store_gt(out[i].l, gt_pow_window(load_gt(a[i].l), kk));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_build_gt(const rhip_
   if (t >= TBL_WINDOWS * TBL_DIGITS) return;
   uint32_t k[8];
   window_scalar(k, t / TBL_DIGITS, t % TBL_DIGITS + 1);
-  st_gt_m(tbl + t, gt_pow_binary(load_gt(base->l), k));
+  st_gt_m(tbl + t, gt_pow_window(load_gt(base->l), k));
 }
 
 // 16-bit windows for Gt powers of public-key constants: T16[w][d-1] = base^(d * 65536^w) = T8[2w][d&255] * T8[2w+1][d>>8]

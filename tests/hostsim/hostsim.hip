@@ -147,6 +147,7 @@ void hs_pairing_pair_parked(const uint32_t* pa, const uint32_t* qa, const uint32
                                                              jac_is_inf(JB) || aff_is_inf(QB))));
 }
 void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
+void hs_gt_pow_window(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_window(load_gt(a), k)); }
 
 
 }  // extern "C"

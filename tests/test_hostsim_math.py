@@ -210,3 +210,14 @@ def test_final_exponentiation_over_workspace_slots():
     p, q = bn.g1_mul(bn.G1_GEN, k1), bn.g2_mul(bn.G2_GEN, k2)
     m = call("hs_miller", bn.g1_to_le(p), bn.g2_to_le(q), out=384)
     assert call("hs_final_exp_ws", m, out=384) == call("hs_final_exp", m, out=384) == bn.gt_to_le(bn.pairing(p, q))
+
+
+def test_gt_pow_signed_window_equals_binary():
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    f = bn.gt_to_le(bn.gt_pow(e, RND.randrange(1, bn.R)))
+    for k in [0, 1, 7, 8, 9, 15, 16, 0x88888888, bn.R - 1, bn.R, (1 << 256) - 1, RND.randrange(bn.R), RND.randrange(bn.R),
+              int("8" * 64, 16), int("7" * 64, 16), int("f" * 63, 16)]:
+        kb = (k % (1 << 256)).to_bytes(32, "little")
+        assert call("hs_gt_pow_window", f, kb, out=384) == call("hs_gt_pow", f, kb, out=384)
+    k = RND.randrange(bn.R)
+    assert call("hs_gt_pow_window", f, le(k), out=384) == bn.gt_to_le(bn.gt_pow(bn.gt_from_le(f), k))
