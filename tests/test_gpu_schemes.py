@@ -288,3 +288,57 @@ def test_bsw_delegate_matches_golden(host):
     assert bsw.decrypt(host, dsk, ct) == PLAINTEXT
     assert bsw.delegate(host, pk, sk, ["A", "Z"]) is None          # not a subset -> None (:173-176)
     assert bsw.delegate(host, pk, sk, []) is None
+
+
+def test_ac17_reference_quirks_against_the_oracle(host):
+    """AC17 labels are plain concatenations (attribute "01" collides with the k_p label "01"+l+t,
+    row label "A1"+"0"+t with column-ish text, rows sort lexicographically "a10" < "a2"), and a policy may name an
+    attribute twice.  The engine must reproduce whatever the reference's order of operations gives: compare the host
+    layer with the oracle's statement-by-statement restatement on one tape."""
+    import random as _random
+    from oracle import bn254 as bn
+    from oracle import policy as opol
+    from oracle import schemes as sch
+    from oracle.tape import ListRng
+    rnd = _random.Random(77)
+    R = bn.R
+    pk, msk = ac17.setup(host)
+    opk = hl.parse_obj("ac17_pk", pk.serialize())
+    omsk = hl.parse_obj("ac17_msk", msk.serialize())
+    o_pk = {"g": bn.g1_from_le(opk["g"]), "h_a": [bn.g2_from_le(x) for x in opk["h_a"]], "e_gh_ka": [bn.gt_from_le(x) for x in opk["e_gh_ka"]]}
+    o_msk = {"g": bn.g1_from_le(omsk["g"]), "h": bn.g2_from_le(omsk["h"]), "g_k": [bn.g1_from_le(x) for x in omsk["g_k"]],
+             "a": [int.from_bytes(x, "little") for x in omsk["a"]], "b": [int.from_bytes(x, "little") for x in omsk["b"]]}
+    e_gen = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    # (policy, key attributes, does the reference's own algorithm recover the message?)
+    cases = [('"01" and "A1"', ["01", "A1"], True),                              # label collisions
+             ('("a10" and "a2") and ("a1" or "A")', ["a1", "a10", "a2"], True),    # lexicographic row order, OR branch
+             # the same attribute on two leaves: the name-matching loops (:403-414) add both "A" rows once per pruned entry,
+             # so the reference does NOT recover msg -- and neither may the engine
+             ('"A" and ("B" or "A")', ["A"], False)]
+    for policy, attrs, recovers in cases:
+        kt = [rnd.randrange(1, R) for _ in range(3 + len(attrs))]
+        host.set_tape(kt)
+        sk = ac17.cp_keygen(host, msk, attrs)
+        want_sk = sch.ac17_cp_keygen(o_msk, attrs, ListRng(kt))
+        got = hl.parse_obj("ac17_cp_sk", sk.serialize())
+        assert got["k_0"] == [bn.g2_to_le(x) for x in want_sk["sk"]["k_0"]]
+        assert got["k"] == [(n, [bn.g1_to_le(p) for p in v]) for n, v in want_sk["sk"]["k"]]
+        assert got["k_p"] == [bn.g1_to_le(x) for x in want_sk["sk"]["k_p"]]
+        s0, s1, rho = rnd.randrange(1, R), rnd.randrange(1, R), rnd.randrange(1, R)
+        host.set_tape([s0, s1, rho, 5])
+        ct = ac17.cp_encrypt(host, pk, policy, PLAINTEXT, hl.HUMAN_POLICY)
+        host.clear_tape()
+        msg = bn.gt_pow(e_gen, rho)
+        want_ct = sch.ac17_cp_encrypt(o_pk, policy, opol.HUMAN, ListRng([s0, s1]), msg)
+        g = hl.parse_obj("ac17_cp_ct", ct.serialize())
+        assert g["c_0"] == [bn.g2_to_le(x) for x in want_ct["ct"]["c_0"]]
+        assert g["c"] == [(n, [bn.g1_to_le(p) for p in v]) for n, v in want_ct["ct"]["c"]]
+        assert g["c_p"] == bn.gt_to_le(want_ct["ct"]["c_p"])
+        got_gt = ac17.cp_decrypt_gt(host, sk, ct)
+        assert got_gt == bn.gt_to_le(sch.ac17_cp_decrypt(want_sk, want_ct))
+        assert (got_gt == bn.gt_to_le(msg)) == recovers
+        if recovers:
+            assert ac17.cp_decrypt(host, sk, ct) == PLAINTEXT
+        else:
+            with pytest.raises(hl.RabeError):
+                ac17.cp_decrypt(host, sk, ct)          # "decryption error: aead::Error", as in the reference
