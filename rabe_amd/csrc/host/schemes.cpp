@@ -8,6 +8,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 #include <stdio.h>
 #include <sys/random.h>
@@ -89,8 +90,20 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
   const size_t n = p.size();
   std::vector<std::array<uint8_t, N>> out(n);
   if (!n) return out;
-  std::map<std::string, std::vector<size_t>> groups;
-  for (size_t i = 0; i < n; i++) groups[std::string((const char*)p[i].data(), N)].push_back(i);
+  // group the operands by base value without copying them: keys point into `p`
+  struct Key { const uint8_t* b; };
+  struct KeyHash {
+    size_t operator()(const Key& k) const {
+      uint64_t h = 1469598103934665603ull;
+      for (size_t i = 0; i + 8 <= N; i += 8) { uint64_t w; memcpy(&w, k.b + i, 8); h = (h ^ w) * 1099511628211ull; }
+      return (size_t)h;
+    }
+  };
+  struct KeyEq { bool operator()(const Key& a, const Key& b) const { return memcmp(a.b, b.b, N) == 0; } };
+  std::unordered_map<Key, std::vector<size_t>, KeyHash, KeyEq> by_base;
+  for (size_t i = 0; i < n; i++) by_base[Key{p[i].data()}].push_back(i);
+  std::map<std::string, std::vector<size_t>> groups;           // few entries; ordered, so that the launch order is deterministic
+  for (auto& g : by_base) groups[std::string((const char*)g.first.b, N)].swap(g.second);
   std::vector<size_t> rest;
   for (auto& g : groups) {
     std::vector<size_t>& idx = g.second;
