@@ -136,6 +136,10 @@ int32_t rabe_policy_pruned(const char* policy, int32_t language, const char* con
 int32_t rabe_policy_traverse(const char* policy, int32_t language, const char* const* attributes, size_t n, int32_t* result);
 int32_t rabe_policy_shares(const char* policy, int32_t language, const uint8_t secret_le32[32], const uint8_t* tape_le32, size_t n_tape, char** out);
 int32_t rabe_policy_coeffs(const char* policy, int32_t language, char** out);
+/* sha3_hash_fr (src/utils/hash/mod.rs:23-31): Fr::from_slice(SHA3-256(label)), little-endian canonical */
+int32_t rabe_hash_fr(const char* label, uint8_t out_le32[32]);
+/* test hook: x mod r of a 512-bit little-endian x by the fast path and by plain long division */
+int32_t rabe_fr_reduce512(const uint8_t in_le64[64], uint8_t out_fast[32], uint8_t out_division[32]);
 /* KDF + AES-256-GCM of src/utils/aes/mod.rs with an explicit nonce; out = nonce || ct || tag */
 int32_t rabe_encrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, const uint8_t nonce[12], uint8_t** out, size_t* out_len);
 int32_t rabe_decrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);

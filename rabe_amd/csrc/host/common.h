@@ -53,6 +53,9 @@ struct Rng : host::FrSource {
   virtual void fill(uint8_t* out, size_t n) = 0;
 };
 struct OsRng : Rng {
+  // getrandom(2) in 4 KB refills: a batch draws hundreds of thousands of Fr values, one system call each would dominate it
+  uint8_t pool[4096];
+  size_t pool_pos = sizeof(pool);
   void fill(uint8_t* out, size_t n) override;
   Fr next_fr() override {
     uint8_t b[64];

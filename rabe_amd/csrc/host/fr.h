@@ -88,6 +88,23 @@ inline void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
   if (t[4] || geq(t, MOD)) sub_raw(r, t, MOD); else memcpy(r, t, 32);
 }
 }  // namespace frdetail
+namespace frdetail {
+// x mod r for a 512-bit x = hi 2^256 + lo: both halves are brought below r by subtraction (2^256 < 6 r), then
+// hi * 2^256 mod r is one Montgomery multiplication by R^2.  (reduce512 above is the bit-by-bit long division it replaces
+// on the hot paths -- every hash-to-Fr and every random Fr goes through here; tests compare the two.)
+inline void reduce256(uint64_t x[4]) { while (geq(x, MOD)) sub_raw(x, x, MOD); }
+inline void reduce512_fast(uint64_t out[4], const uint64_t in[8]) {
+  uint64_t lo[4], hi[4], t[4];
+  memcpy(lo, in, 32);
+  memcpy(hi, in + 4, 32);
+  reduce256(lo);
+  reduce256(hi);
+  mont_mul(t, hi, R2);                     // hi * R^2 / R = hi * 2^256 mod r
+  uint64_t c = 0;
+  for (int i = 0; i < 4; i++) { u128 s = (u128)t[i] + lo[i] + c; out[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+  if (c || geq(out, MOD)) sub_raw(out, out, MOD);
+}
+}  // namespace frdetail
 inline Fr fr_mul(const Fr& a, const Fr& b) {
   Fr t, r;
   frdetail::mont_mul(t.l, a.l, b.l);            // a*b/R
@@ -116,7 +133,7 @@ inline Fr fr_from_be32_reduce(const uint8_t d[32]) {
   uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; i++) { uint64_t w = 0; for (int j = 0; j < 8; j++) w = (w << 8) | d[(3 - i) * 8 + j]; t[i] = w; }
   Fr r;
-  frdetail::reduce512(r.l, t);
+  frdetail::reduce512_fast(r.l, t);
   return r;
 }
 // 64 uniformly random bytes -> Fr (`Fr::random`: 512 random bits mod r, SURVEY.md 8c assumption (iv))
@@ -124,7 +141,7 @@ inline Fr fr_from_le64_reduce(const uint8_t b[64]) {
   uint64_t t[8];
   memcpy(t, b, 64);
   Fr r;
-  frdetail::reduce512(r.l, t);
+  frdetail::reduce512_fast(r.l, t);
   return r;
 }
 // sha3_hash_fr (src/utils/hash/mod.rs:23-31)

@@ -635,6 +635,22 @@ int32_t rabe_ghw11_decrypt_out_gt(rabe_host* h, const void* tct, const void* rk,
   GUARD_END(h)
 }
 
+// sha3_hash_fr (src/utils/hash/mod.rs:23-31) and, for the tests, the two 512-bit reductions side by side
+int32_t rabe_hash_fr(const char* label, uint8_t out_le32[32]) {
+  Fr f = sha3_hash_fr(label);
+  memcpy(out_le32, f.l, 32);
+  return 0;
+}
+int32_t rabe_fr_reduce512(const uint8_t in_le64[64], uint8_t out_fast[32], uint8_t out_division[32]) {
+  uint64_t t[8], a[4], b[4];
+  memcpy(t, in_le64, 64);
+  frdetail::reduce512_fast(a, t);
+  frdetail::reduce512(b, t);
+  memcpy(out_fast, a, 32);
+  memcpy(out_division, b, 32);
+  return 0;
+}
+
 // ---------------------------------------------------------------- policy utilities (host only)
 static std::string jstr(const std::string& s) {
   std::string o = "\"";

@@ -4,6 +4,7 @@
 #include "schemes.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -19,11 +20,22 @@ using namespace host;
 
 // ------------------------------------------------------------------------------------------------ Rng / Engine
 void OsRng::fill(uint8_t* out, size_t n) {
-  size_t off = 0;
-  while (off < n) {
-    ssize_t r = getrandom(out + off, n - off, 0);
-    if (r <= 0) throw RabeError("getrandom failed");
-    off += (size_t)r;
+  while (n) {
+    if (pool_pos == sizeof(pool)) {
+      size_t off = 0;
+      while (off < sizeof(pool)) {
+        ssize_t r = getrandom(pool + off, sizeof(pool) - off, 0);
+        if (r <= 0) throw RabeError("getrandom failed");
+        off += (size_t)r;
+      }
+      pool_pos = 0;
+    }
+    size_t k = std::min(n, sizeof(pool) - pool_pos);
+    memcpy(out, pool + pool_pos, k);
+    memset(pool + pool_pos, 0, k);            // consumed randomness does not linger
+    pool_pos += k;
+    out += k;
+    n -= k;
   }
 }
 
@@ -361,6 +373,19 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
 }
 // Host-side planning of a batch (share generation, hashing, pruning: string and Fr work) runs on all cores; the
 // randomness is pulled from the generator beforehand, item after item, so results do not depend on the thread count.
+// RABE_HOST_TIMING=1: stage timings of the batch entry points on stderr (development aid)
+struct StageTimer {
+  bool on;
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(const char* w) : on(getenv("RABE_HOST_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* stage) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host-timing] %s: %s %.1f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 static void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
   unsigned nt = std::thread::hardware_concurrency();
   if (nt > 32) nt = 32;
@@ -389,7 +414,7 @@ static void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
 // Items of one batch usually repeat a few policies: the parsed tree and its Lagrange coefficients (pure functions of
 // the policy text) are computed once per distinct (text, language) within a call.
 struct PolicyMemo {
-  struct Entry { PolicyNode tree; NamedFr coeff; };
+  struct Entry { PolicyNode tree; NamedFr coeff; bool msp_checked = false; };
   std::map<std::pair<std::string, int>, std::shared_ptr<Entry>> m;
   std::mutex mu;
   const Entry& get(const std::string& policy, PolicyLanguage lang) {
@@ -1249,7 +1274,9 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
   const size_t n = policies.size();
   std::vector<Aw11Ciphertext> cts(n);
   if (!n) return cts;
+  StageTimer tm("aw11::encrypt_batch");
   Gt egg = eng.pairing({gk.g1}, {gk.g2})[0];          // the reference recomputes this constant per call (:264)
+  tm.lap("pairing");
   struct Item { std::vector<std::string> names; std::array<uint8_t, 12> nonce; size_t ot, o2; const PolicyNode* tree; Fr s, msg_k;
                 std::vector<Fr> draws; std::vector<Gt> gb; std::vector<Fr> gk; std::vector<G2> b2; std::vector<Fr> k2; };
   std::vector<Item> items(n);
@@ -1258,8 +1285,9 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
   // share, nonce
   for (size_t it = 0; it < n; it++) {
     Item& im = items[it];
-    im.tree = &memo.get(policies[it], language).tree;
-    (void)calculate_msp(*im.tree);           // built and unused in the reference (:253-255) -- but it must not panic
+    PolicyMemo::Entry& pe = const_cast<PolicyMemo::Entry&>(memo.get(policies[it], language));
+    im.tree = &pe.tree;
+    if (!pe.msp_checked) { (void)calculate_msp(pe.tree); pe.msp_checked = true; }   // built and unused in the reference (:253-255) -- but it must not panic
     im.s = rng.next_fr();
     const size_t nd = count_share_draws(*im.tree), nl = count_leaves(*im.tree);
     for (size_t d = 0; d < 2 * nd; d++) im.draws.push_back(rng.next_fr());
@@ -1268,6 +1296,7 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
     rng.fill(im.nonce.data(), 12);
     cts[it].policy = {policies[it], language};
   }
+  tm.lap("draws (sequential)");
   const Gt e_gen = eng.gt_generator();
   parallel_for(n, [&](size_t it) {
     Item& im = items[it];
@@ -1308,8 +1337,11 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
     b2.insert(b2.end(), im.b2.begin(), im.b2.end());
     k2.insert(k2.end(), im.k2.begin(), im.k2.end());
   }
+  tm.lap("shares + concat");
   std::vector<Gt> ge = eng.gt_pow(gb, gk_);
+  tm.lap("gt_pow");
   std::vector<G2> g2r = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
+  tm.lap("g2_mul");
   // c_0 = msg * egg^s and every row's c1 = egg^share * egg_alpha^r_x in one gt_mul; every row's c3 in one g2_add
   std::vector<Gt> ma, mb;
   std::vector<G2> aa, ab;
@@ -1321,8 +1353,11 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
       aa.push_back(g2r[o2 + 3 * i + 1]); ab.push_back(g2r[o2 + 3 * i + 2]);
     }
   }
+  tm.lap("gather");
   std::vector<Gt> mm = eng.gt_mul(ma, mb);
+  tm.lap("gt_mul");
   std::vector<G2> c3 = aa.empty() ? std::vector<G2>() : g2_add(eng, aa, ab);
+  tm.lap("g2_add");
   size_t pm = 0, p3 = 0;
   for (size_t it = 0; it < n; it++) {
     cts[it].c_0 = mm[pm++];
@@ -1330,6 +1365,7 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
       cts[it].c.push_back({items[it].names[i], mm[pm++], g2r[items[it].o2 + 3 * i], c3[p3++]});
     cts[it].ct = encrypt_symmetric(ge[items[it].ot].data(), datas[it].data(), datas[it].size(), items[it].nonce.data());
   }
+  tm.lap("assemble");
   return cts;
 }
 Aw11Ciphertext encrypt(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::string& policy,

@@ -124,3 +124,20 @@ def test_symmetric_roundtrip_and_tamper():
         hl.decrypt_symmetric(gt, bytes(bad))
     with pytest.raises(hl.RabeError):
         hl.decrypt_symmetric(bytes(384), ct)          # a different Gt derives a different key
+
+
+def test_hash_to_fr_and_wide_reduction():
+    """sha3_hash_fr of the host layer against the oracle, and the fast 512-bit reduction against long division."""
+    import ctypes
+    from oracle import schemes as osch
+    lib = hl._lib()
+    rnd = random.Random(11)
+    for label in ["A", "a10", "0111", "attr-x21", "", "ü-umlaut", "x" * 300]:
+        o = ctypes.create_string_buffer(32)
+        assert lib.rabe_hash_fr(label.encode("utf-8"), o) == 0
+        assert int.from_bytes(o.raw, "little") == osch.sha3_hash_fr(label)
+    edge = [0, 1, bn.R - 1, bn.R, bn.R + 1, (1 << 256) - 1, 1 << 256, (1 << 512) - 1, bn.R << 256, (bn.R << 256) + bn.R - 1]
+    for x in edge + [rnd.getrandbits(512) for _ in range(200)]:
+        a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        lib.rabe_fr_reduce512(x.to_bytes(64, "little"), a, b)
+        assert int.from_bytes(a.raw, "little") == int.from_bytes(b.raw, "little") == x % bn.R
