@@ -112,16 +112,42 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
     }
   };
   struct KeyEq { bool operator()(const Key& a, const Key& b) const { return memcmp(a.b, b.b, N) == 0; } };
-  std::unordered_map<Key, std::vector<size_t>, KeyHash, KeyEq> by_base;
-  for (size_t i = 0; i < n; i++) by_base[Key{p[i].data()}].push_back(i);
-  std::map<std::string, std::vector<size_t>> groups;           // few entries; ordered, so that the launch order is deterministic
-  for (auto& g : by_base) groups[std::string((const char*)g.first.b, N)].swap(g.second);
+  // pass 1: how often does each base occur (no per-base allocation: most calls carry all-distinct bases)
+  std::unordered_map<Key, uint32_t, KeyHash, KeyEq> count;
+  count.reserve(n);
+  for (size_t i = 0; i < n; i++) count[Key{p[i].data()}]++;
+  // bases that repeat often enough, or already have a table, leave the generic path
+  const size_t need = (N == 384 && fixed_base_min > 1) ? 2 * fixed_base_min : fixed_base_min;
+  std::unordered_map<Key, size_t, KeyHash, KeyEq> slot;       // base -> index into `lists`
+  std::vector<std::vector<size_t>> lists;
+  for (auto& g : count)
+    if (g.second >= need) { slot[g.first] = lists.size(); lists.emplace_back(); }
+  std::vector<std::string> cached_keys;                        // keeps the Key pointers below alive
+  cached_keys.reserve(cache.size());
+  for (auto& c : cache) cached_keys.push_back(c.first);
+  for (auto& ck : cached_keys) {
+    Key k2{(const uint8_t*)ck.data()};
+    if (count.count(k2) && !slot.count(k2)) { slot[k2] = lists.size(); lists.emplace_back(); }
+  }
+  // pass 2: distribute
   std::vector<size_t> rest;
-  for (auto& g : groups) {
-    std::vector<size_t>& idx = g.second;
-    const bool cached = cache.count(g.first) != 0;
-    const size_t need = (N == 384 && fixed_base_min > 1) ? 2 * fixed_base_min : fixed_base_min;
-    if (idx.size() < need && !cached) { rest.insert(rest.end(), idx.begin(), idx.end()); continue; }
+  if (slot.empty()) {
+    rest.resize(n);
+    for (size_t i = 0; i < n; i++) rest[i] = i;
+  } else {
+    for (size_t i = 0; i < n; i++) {
+      auto it = slot.find(Key{p[i].data()});
+      if (it == slot.end()) rest.push_back(i); else lists[it->second].push_back(i);
+    }
+  }
+  // groups in order of first appearance: a deterministic launch sequence
+  std::vector<std::pair<size_t, const std::vector<size_t>*>> big;
+  for (auto& l : lists) if (!l.empty()) big.push_back({l[0], &l});
+  std::sort(big.begin(), big.end());
+  for (auto& bg : big) {
+    const std::vector<size_t>& idx = *bg.second;
+    const std::string key((const char*)p[idx[0]].data(), N);
+    const bool cached = cache.count(key) != 0;
     if (!cached) {
       if (cache.size() >= 64) {                       // bounded: drop everything rather than track recency
         for (auto& c : cache) this->destroy_table(c.second);
@@ -129,18 +155,20 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
       }
       TBL* t = nullptr;
       check(create(ctx_, p[idx[0]].data(), &t), "fixed-base table build");
-      cache[g.first] = t;
+      cache[key] = t;
     }
     std::vector<Fr> kk;
     for (size_t i : idx) kk.push_back(k[i]);
     auto fk = flatten_fr(kk);
     DBuf dk(this, fk.data(), fk.size()), dout(this, idx.size() * N);
-    check(mul(ctx_, cache[g.first], idx.size(), dk.as<rhip_fr>(), dout.ptr()), "fixed-base table multiplication");
+    check(mul(ctx_, cache[key], idx.size(), dk.as<rhip_fr>(), dout.ptr()), "fixed-base table multiplication");
     auto r = fetch<N>(dout, idx.size());
     for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = r[j];
   }
+  if (rest.size() == n) {                       // nothing repeated: hand the call through untouched
+    return generic(p, k);
+  }
   if (!rest.empty()) {
-    std::sort(rest.begin(), rest.end());
     std::vector<std::array<uint8_t, N>> rp;
     std::vector<Fr> rk;
     for (size_t i : rest) { rp.push_back(p[i]); rk.push_back(k[i]); }
@@ -250,6 +278,19 @@ static Bytes open_or_error(const Gt& msg, const Bytes& ct) {               // de
   return out;
 }
 
+// RABE_HOST_TIMING=1: stage timings of the batch entry points on stderr (development aid)
+struct StageTimer {
+  bool on;
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(const char* w) : on(getenv("RABE_HOST_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* stage) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host-timing] %s: %s %.1f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 // ---- batched decryption tail shared by bsw / lsw / aw11: item i yields
 //   lead_i * prod_j gbase_ij^gexp_ij * FE( prod_j ML(scal_ij * base_ij, q_ij) )
 // with ONE g1_mul, ONE pairing-product launch (one final exponentiation per item) and ONE gt_pow for the whole batch.
@@ -289,6 +330,7 @@ static std::vector<G1> g1_group_sums(Engine& e, std::vector<std::vector<G1>> gro
   return out;
 }
 static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>& jobs) {
+  StageTimer tm("run_pairing_jobs");
   std::vector<size_t> live;
   for (size_t i = 0; i < jobs.size(); i++) if (!jobs[i].failed) live.push_back(i);
   std::vector<Gt> out(jobs.size());
@@ -313,7 +355,9 @@ static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>
   std::vector<Gt> acc(live.size());
   for (size_t t = 0; t < live.size(); t++) acc[t] = jobs[live[t]].lead_one ? gt_one : jobs[live[t]].lead;
   if (!base.empty()) {
+    tm.lap("concat");
     std::vector<G1> scaled = e.g1_mul(base, scal);
+    tm.lap("g1_mul");
     // per item: its plain pairs, then (if any) the pair with the summed G1 argument
     std::vector<G1> p;
     std::vector<G2> q;
@@ -336,11 +380,13 @@ static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>
       if (!j.sbase.empty()) { p.push_back(sums[t]); q.push_back(j.sq); }
       off.push_back((uint32_t)p.size());
     }
+    tm.lap("sums + pair lists");
     auto fp = flatten(p); auto fq = flatten(q);
     DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off.data(), off.size() * 4), dout(&e, live.size() * 384);
     e.check(rhip_pairing_product(e.ctx(), live.size(), doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), dout.as<rhip_gt>()),
             "rhip_pairing_product");
     acc = e.gt_mul(acc, fetch<384>(dout, live.size()));
+    tm.lap("pairing product + gt_mul");
   }
   if (!gb.empty()) {
     std::vector<Gt> pw = e.gt_pow(gb, gk);
@@ -358,6 +404,7 @@ static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>
     }
   }
   for (size_t t = 0; t < live.size(); t++) out[live[t]] = acc[t];
+  tm.lap("gt powers + fold");
   return out;
 }
 static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vector<PairingJob>& jobs, const std::vector<const Bytes*>& sealed) {
@@ -373,19 +420,6 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
 }
 // Host-side planning of a batch (share generation, hashing, pruning: string and Fr work) runs on all cores; the
 // randomness is pulled from the generator beforehand, item after item, so results do not depend on the thread count.
-// RABE_HOST_TIMING=1: stage timings of the batch entry points on stderr (development aid)
-struct StageTimer {
-  bool on;
-  const char* what;
-  std::chrono::steady_clock::time_point t0;
-  explicit StageTimer(const char* w) : on(getenv("RABE_HOST_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
-  void lap(const char* stage) {
-    if (!on) return;
-    auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[host-timing] %s: %s %.1f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
-  }
-};
 static void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
   unsigned nt = std::thread::hardware_concurrency();
   if (nt > 32) nt = 32;
@@ -432,6 +466,7 @@ struct PolicyMemo {
 // plan(i, &job) fills job i or throws RabeError (-> that item fails); panics (std::runtime_error) propagate like the reference's
 template <class PLAN>
 static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
+  StageTimer tm("plan_jobs");
   std::vector<PairingJob> jobs(n);
   parallel_for(n, [&](size_t i) {
     try {
@@ -442,6 +477,7 @@ static std::vector<PairingJob> plan_jobs(size_t n, PLAN plan) {
       jobs[i].error = ex.what();
     }
   });
+  tm.lap("plan (parallel)");
   return jobs;
 }
 
