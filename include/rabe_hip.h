@@ -103,6 +103,8 @@ int32_t rhip_g1_on_curve(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, uint32_t
 int32_t rhip_g2_on_curve(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
 
 int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_gt* dev_b, rhip_gt* dev_out);
+/* out[i] = product of a[off[i] .. off[i+1]) (1 for an empty segment): the Gt accumulation loops of aw11::decrypt :320-352 */
+int32_t rhip_gt_product(rhip_ctx* ctx, size_t n_items, const uint32_t* dev_off /*[n_items+1]*/, const rhip_gt* dev_a, rhip_gt* dev_out);
 int32_t rhip_gt_inv(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, rhip_gt* dev_out);
 int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_fr* dev_k, rhip_gt* dev_out);
 

@@ -395,6 +395,17 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_mul(size_t n, const rhi
   if (i >= n) return;
   store_gt(out[i].l, fp12_mul(load_gt(a[i].l), load_gt(b[i].l)));
 }
+// out[i] = prod_{j in [off[i], off[i+1])} a[j]   (1 for an empty segment)
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_product(size_t n_items, const uint32_t* off, const rhip_gt* a, rhip_gt* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  Fp12 acc = fp12_one();
+  for (uint32_t j = off[i]; j < off[i + 1]; j++) {
+    Fp12 m = load_gt(a[j].l);
+    acc = (j == off[i]) ? m : fp12_mul_fn(acc, m);
+  }
+  store_gt(out[i].l, acc);
+}
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_inv(size_t n, const rhip_gt* a, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1462,6 +1473,12 @@ extern "C" int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* a, const 
   NEED(ctx);
   if (!n) return RHIP_OK;
   KLAUNCH(ctx, "k_gt_mul", k_gt_mul, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, b, out);
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_gt_product(rhip_ctx* ctx, size_t n_items, const uint32_t* off, const rhip_gt* a, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  KLAUNCH(ctx, "k_gt_product", k_gt_product, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, a, out);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_inv(rhip_ctx* ctx, size_t n, const rhip_gt* a, rhip_gt* out) {
