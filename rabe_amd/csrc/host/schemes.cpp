@@ -1234,7 +1234,8 @@ static void plan_decrypt(PolicyMemo& memo, const KpAbeSecretKey& sk, const KpAbe
     if (!sk_attr || !ct_attr || !coeff) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
     if (!is_negative(a.first)) { cur_sk = sk_attr; cur_ct = ct_attr; }
     if (!cur_sk) continue;            // z_y still Gt::one()
-    base.push_back(cur_sk->d1); scal.push_back(fr_neg(*coeff)); q.push_back(ct.e2);
+    // every e(-c D1, e2) shares its G2 argument: prod_x e(-c_x D1_x, e2) = e(sum_x -c_x D1_x, e2) -- one Miller loop for all
+    job->sbase.push_back(cur_sk->d1); job->sscal.push_back(fr_neg(*coeff)); job->sq = ct.e2;
     base.push_back(cur_ct->e1); scal.push_back(*coeff); q.push_back(cur_sk->d2);
   }
 }
@@ -1242,7 +1243,7 @@ Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) 
   std::vector<PairingJob> jobs(1);
   PolicyMemo memo;
   plan_decrypt(memo, sk, ct, &jobs[0]);
-  if (jobs[0].base.empty()) return ct.e1;
+  if (jobs[0].base.empty() && jobs[0].sbase.empty()) return ct.e1;
   return run_pairing_jobs(eng, jobs)[0];
 }
 Bytes decrypt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
