@@ -1,32 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py -- AC17 CP-ABE encrypt+decrypt throughput on MI355X (BASELINE.json metric, config 2).
+"""bench.py -- ABE ops/s on MI355X (BASELINE.json metric).  Default: config 2, AC17 CP-ABE encrypt+decrypt.
 
 One step = one pass of the hot path over one batch: `--batch` (4096) independent
 ac17::cp_encrypt + ac17::cp_decrypt group-arithmetic calls at `--attrs` (50) attributes, 16 distinct
 random binary AND/OR policies x 256 items, one public key, one secret key holding all attributes
 (SURVEY.md 8d config 2).  Inputs (randomness s0,s1 and the Gt message per item, policy tables, key
 material, selection lists) are resident in HBM before the timed region; ciphertexts go
-encrypt -> HBM -> decrypt without touching the host.  N>1: the batch definition is per rank
-(weak scaling), ranks are independent (no data-path collective); the only collective is the
-max-over-ranks of the elapsed time.
+encrypt -> HBM -> decrypt without touching the host.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (integer-VALU bound: the
-path is modular big-integer arithmetic, neither HBM- nor MFMA-bound -- DESIGN.md section 5);
-`cpu_baseline` times the oracle's reference-order restatement on the host CPU (rank 0, N=1 only).
+Steps are submitted in GROUPS: up to `--group` (16) steps' batches lie contiguously in HBM and go through the
+engine as ONE launch set (16 x 4096 items: 3072 Miller waves = 3 full rounds of the chip's 1024 SIMDs, 1024
+final-exponentiation waves = one round), so a single launch fills the chip; `--inflight` (2) groups are kept in
+flight on separate streams only to cover launch tails.  No hardware-queue tuning is involved.
+
+N > 1 (`--gpus N`): one process per GPU.  Launched by torch.distributed.run the ranks come from the environment;
+started plainly (`python bench.py --gpus N`) the script spawns the N ranks itself.  The global batch (N x batch
+items per step, one global randomness stream) is cut with rabe_amd.shard.shard_range; ranks are independent on the
+timed path (weak scaling, no data-path collective); after the timed region the fixed-size result records are
+gathered with ONE all_gather_into_tensor on device (RCCL) and rank 0 checks them against the unsharded order.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (integer-VALU bound: the path is modular
+big-integer arithmetic, neither HBM- nor MFMA-bound -- DESIGN.md section 5), measured on a launch that fills the
+chip; `cpu_baseline` times the oracle's reference-order restatement on the host CPU (rank 0, N=1 only).
 """
 import argparse
 import ctypes
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# One hardware queue per in-flight batch (HIP's default is 4); must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+# No GPU_MAX_HW_QUEUES override by default (HIP's 4 hardware queues are enough for 2 groups in flight);
+# --hw-queues N sets it for experiments and must act before the HIP runtime initialises.
+for _i, _a in enumerate(sys.argv):
+    if _a == "--hw-queues" and _i + 1 < len(sys.argv):
+        os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[_i + 1]
+    elif _a.startswith("--hw-queues="):
+        os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
 
 G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
 G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
@@ -49,14 +65,18 @@ IMPL_FINAL_EXP_FPMUL = 7553         # tests/count_muls.py: final_exponentiation_
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="items per step per GPU")
-    ap.add_argument("--attrs", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[N-1]")
+    ap.add_argument("--batch", type=int, default=0, help="items per step per GPU (0 = the config's: 4096 / 4096 / 2048 / 1024)")
+    ap.add_argument("--attrs", type=int, default=0, help="attributes (0 = the config's: 50 / 100 / 200 / 200)")
     ap.add_argument("--policies", type=int, default=16)
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=20,
-                    help="independent steps (batches) in flight on separate HIP streams; 1 = strictly one batch at a time")
+    ap.add_argument("--group", type=int, default=16, help="steps submitted as ONE launch set (their batches are contiguous in HBM)")
+    ap.add_argument("--inflight", type=int, default=2, help="groups in flight on separate HIP streams (covers launch tails)")
+    ap.add_argument("--min-time", type=float, default=1.0,
+                    help="the K-step timed region is repeated until this many seconds have been timed; every region times exactly --steps steps")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for experiments (0 = leave the HIP default)")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
     ap.add_argument("--g-window", type=int, default=26,
@@ -67,12 +87,74 @@ def parse_args():
     ap.add_argument("--no-prepared-sk", action="store_true",
                     help="decrypt without the per-key prepared lines (6 independent Miller loops per item)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-object-api", action="store_true", help="skip the informational object-level (rabe_* C++ host layer) leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items for the CPU baseline (0 = auto)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------- rank spawning
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay rank 0's line.
+    On a box with fewer than N GPUs the ranks share devices (LOCAL_RANK modulo the device count) and rendezvous over
+    gloo -- RCCL refuses two ranks on one device; that mode exists for functional checks of the N > 1 path."""
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    assert n_dev > 0, "bench.py needs a GPU (the engine has no CPU fallback)"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r % n_dev), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        if n_dev < args.gpus:
+            env["RABE_DIST_BACKEND"] = "gloo"
+            env["RABE_SHARED_DEVICE"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+class ExtBuf:
+    """A device buffer owned by a torch tensor (so that torch.distributed can gather it), seen as an engine buffer."""
+
+    def __init__(self, torch_mod, nbytes, device):
+        self.t = torch_mod.empty(max(int(nbytes), 4), dtype=torch_mod.uint8, device=device)
+        self.ptr = ctypes.c_void_p(self.t.data_ptr())
+        self.nbytes = int(nbytes)
+
+
+def split_steps(k, gmax):
+    """K steps -> group sizes (nearly equal, each <= gmax, as few groups as possible)."""
+    n = (k + gmax - 1) // gmax
+    base, extra = divmod(k, n)
+    return [base + (1 if i < extra else 0) for i in range(n)]
+
+
+def same_on_all_ranks(flag):
+    """rank 0's decision, everywhere (loop control of the repeated timed regions)"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=0)
+    return bool(t.item())
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     import torch
     import torch.distributed as dist
 
@@ -85,37 +167,51 @@ def main():
         dist.init_process_group(backend=os.environ.get("RABE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     torch.cuda.set_device(local_rank)
+    if args.config != 2:
+        from rabe_amd import bench_schemes
+        return bench_schemes.run(args, world, rank, local_rank)
 
     from rabe_amd import Engine
     from rabe_amd import engine as E
     from rabe_amd import hostprep as hp
+    from rabe_amd import shard
 
+    args.batch = args.batch or 4096
+    args.attrs = args.attrs or 50
     eng = Engine(local_rank)
     n_cu, dev_name = eng.device_info()
     stream = torch.cuda.Stream(device=local_rank)
     eng.set_stream(stream.cuda_stream)
     eng.set_pairing_mode(args.pairing_mode)
+    dev = torch.device("cuda", local_rank)
 
-    rnd = random.Random(args.seed * 1000003 + rank)
+    krnd = random.Random(args.seed * 1000003)          # key material: the same on every rank (one public key, one secret key)
     R = hp.R_ORDER
     le = hp.fr_le
 
-    def rfr():
-        return rnd.randrange(1, R)
+    def kfr():
+        return krnd.randrange(1, R)
 
     # ---------------------------------------------------------------- key material (ac17::setup, :141-182) via Level E ops
-    a = [rfr(), rfr()]
-    b = [rfr(), rfr()]
-    k = [rfr(), rfr(), rfr()]
-    g = eng.g1_mul([G1_GEN], [le(rfr())])[0]
-    h = eng.g2_mul([G2_GEN], [le(rfr())])[0]
+    a = [kfr(), kfr()]
+    b = [kfr(), kfr()]
+    k = [kfr(), kfr(), kfr()]
+    g = eng.g1_mul([G1_GEN], [le(kfr())])[0]
+    h = eng.g2_mul([G2_GEN], [le(kfr())])[0]
     h_a = eng.g2_mul([h, h], [le(a[0]), le(a[1])]) + [h]
     g_k = eng.g1_mul([g] * 3, [le(x) for x in k])
     e_gh = eng.pairing([g], [h])[0]
     e_gh_ka = eng.gt_pow([e_gh] * 2, [le(k[i] * a[i] + k[2]) for i in range(2)])
+    eng.sync()
+    t_tab = time.perf_counter()
     pk = E.Ac17Pk(eng, g, h_a, e_gh_ka)
     if args.g_window > 16:
         pk.set_g_window(args.g_window)
+    eng.sync()
+    table_build_ms = 1e3 * (time.perf_counter() - t_tab)
+    gw = args.g_window
+    g_table_bytes = 64 * (16 * 65535 if gw <= 16 else sum(E.wide_count(gw, i) for i in range(E.wide_windows(gw))))
+    table_bytes = g_table_bytes + 64 * 32 * 255 + (64 * 16 * 65535 if gw > 16 else 0) + 3 * 128 * (32 * 255 + 16 * 65535) + 2 * 384 * (32 * 255 + 16 * 65535)
 
     # ---------------------------------------------------------------- secret key with all attributes (ac17::cp_keygen, :191-264)
     attrs = ["a%d" % (i + 1) for i in range(args.attrs)]
@@ -124,12 +220,13 @@ def main():
     dk0, dk, dkp = eng.alloc(3 * 128), eng.alloc(len(attrs) * 3 * 64), eng.alloc(3 * 64)
     E.ac17_keygen_dev(eng, g_tab, h_tab, eng.upload(b"".join(g_k)), eng.upload(b"".join(le(pow(x, R - 2, R)) for x in a)),
                       eng.upload(b"".join(le(x) for x in b)), 1, len(attrs), eng.upload(H), eng.upload(H01),
-                      eng.upload(le(rfr()) + le(rfr())), eng.upload(b"".join(le(rfr()) for _ in attrs)), eng.upload(le(rfr())),
+                      eng.upload(le(kfr()) + le(kfr())), eng.upload(b"".join(le(kfr()) for _ in attrs)), eng.upload(le(kfr())),
                       dk0, dk, dkp)
 
     # ---------------------------------------------------------------- policies (host: parse/MSP/prune are string work)
     prnd = random.Random(args.seed)          # the same policies on every rank
     trees = [hp.random_binary_tree(attrs, prnd) for _ in range(args.policies)]
+    t_prep = time.perf_counter()
     tables, sels, pol_rows, nnz = [], [], [], []
     for t in trees:
         pi, A, z = hp.ac17_policy_table(t)
@@ -139,42 +236,56 @@ def main():
         sels.append((ct_sel, sk_sel))
         pol_rows.append(len(pi))
         nnz.append(z)
+    host_prep_ms_per_policy = 1e3 * (time.perf_counter() - t_prep) / len(trees)
     A_off = [0]
     for r_ in pol_rows:
         A_off.append(A_off[-1] + r_)
     dA = eng.upload(b"".join(tables))
 
+    # ---------------------------------------------------------------- the groups: up to G steps' batches contiguous in HBM
     B = args.batch
-    item_pol = [i % args.policies for i in range(B)]
+    sizes = split_steps(args.steps, max(1, min(args.group, args.steps)))
+    G = max(sizes)
+    GB = G * B
+    item_pol = [i % args.policies for i in range(GB)]
     ct_row_off = [0]
     ct_sel_all, sk_sel_all, ct_sel_off, sk_sel_off = [], [], [0], [0]
-    for i in range(B):
+    for i in range(GB):
         p_ = item_pol[i]
         ct_row_off.append(ct_row_off[-1] + pol_rows[p_])
         ct_sel_all += sels[p_][0]
         sk_sel_all += sels[p_][1]
         ct_sel_off.append(len(ct_sel_all))
         sk_sel_off.append(len(sk_sel_all))
-    total_rows = ct_row_off[-1]
+    rows_per_batch = ct_row_off[B]
+    assert all(ct_row_off[(j + 1) * B] == (j + 1) * rows_per_batch for j in range(G)), "batch must be a multiple of the policy count"
+    sel_per_batch = ct_sel_off[B]
     d_item_A_off = eng.upload_u32([A_off[p_] for p_ in item_pol])
     d_ct_row_off = eng.upload_u32(ct_row_off)
     d_ct_sel, d_ct_sel_off = eng.upload_u32(ct_sel_all), eng.upload_u32(ct_sel_off)
     d_sk_sel, d_sk_sel_off = eng.upload_u32(sk_sel_all), eng.upload_u32(sk_sel_off)
-    d_sk_idx = eng.upload_u32([0] * B)
+    d_sk_idx = eng.upload_u32([0] * GB)
     d_sk_row_off = eng.upload_u32([0, len(attrs)])
 
-    # per-item randomness: s0, s1 and the Gt message msg = e_gh^rho (computed on the GPU, untimed)
-    ds = eng.upload(b"".join(le(rfr()) for _ in range(2 * B)))
+    # per-item randomness of the GLOBAL batch (world x B items per step, one stream): this rank owns [lo, hi); step slot j
+    # of a group uses the same per-step inputs shifted by j, so that the slots differ
+    lo, hi = shard.shard_range(world * B, rank, world)
+    assert hi - lo == B
+    irnd = random.Random(args.seed * 7919 + 13)
+    s_all = [irnd.randrange(1, R) for _ in range(world * B * 2)]
+    rho_all = [irnd.randrange(1, R) for _ in range(world * B)]
+    s_loc, rho_loc = s_all[2 * lo:2 * hi], rho_all[lo:hi]
+    s_grp = [((s_loc[2 * (i % B) + j] + (i // B)) % R) or 1 for i in range(GB) for j in range(2)]
+    rho_grp = [((rho_loc[i % B] + (i // B)) % R) or 1 for i in range(GB)]
+    ds = eng.upload(b"".join(le(x) for x in s_grp))
     e_tab = eng.gt_table(e_gh)
-    dmsg = eng.alloc(B * 384)
-    drho = eng.upload(b"".join(le(rfr()) for _ in range(B)))
-    eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, e_tab.h, E._sz(B), drho.ptr, dmsg.ptr))
+    dmsg = eng.alloc(GB * 384)
+    drho = eng.upload(b"".join(le(x) for x in rho_grp))
+    eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, e_tab.h, E._sz(GB), drho.ptr, dmsg.ptr))
 
-    # Steps are independent batches: up to `inflight` of them are pipelined on separate HIP streams (each
-    # lane = its own engine context, stream, scratch and output buffers; inputs and key tables are shared,
-    # read-only).  The kernels of one batch are latency-bound at 4096 items (384 Miller waves on 1024
-    # SIMDs), so overlapping batches is what fills the chip.
-    S = max(1, min(args.inflight, args.steps))
+    # `inflight` groups in flight: each lane = its own engine context, stream, scratch and output buffers; inputs and key
+    # tables are shared, read-only
+    S = max(1, min(args.inflight, len(sizes)))
     lanes_ctx = [eng]
     streams = [stream]
     for _ in range(S - 1):
@@ -184,28 +295,35 @@ def main():
         e2.set_pairing_mode(args.pairing_mode)
         lanes_ctx.append(e2)
         streams.append(st2)
-    bufs = [(e_.alloc(B * 3 * 128), e_.alloc(total_rows * 3 * 64), e_.alloc(B * 384), e_.alloc(B * 384)) for e_ in lanes_ctx]
-    dc0, dc, dcp, dout = bufs[0]
-    step_no = [0]
+    total_rows = ct_row_off[GB]
+    bufs = [(e_.alloc(GB * 3 * 128), e_.alloc(total_rows * 3 * 64), e_.alloc(GB * 384), ExtBuf(torch, GB * 384, dev)) for e_ in lanes_ctx]
+    launch_no = [0]
 
     # the key is loaded once: Miller-loop lines of k_0 (rhip_ac17_sk_prepare), reused by every decryption with it
     sk_lines = None if args.no_prepared_sk else E.Ac17SkLines(eng, 1, dk0)
     eng.sync()
 
-    def step():
-        i = step_no[0] % S
-        step_no[0] += 1
+    def submit(g_steps, lane=None):
+        """one launch set over g_steps contiguous batches"""
+        i = launch_no[0] % S if lane is None else lane
+        launch_no[0] += 1
         e_ = lanes_ctx[i]
         c0_, c_, cp_, out_ = bufs[i]
-        E.ac17_encrypt_dev(e_, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds, dmsg, c0_, c_, cp_)
+        n = g_steps * B
+        E.ac17_encrypt_dev(e_, pk, n, dA, d_item_A_off, d_ct_row_off, g_steps * rows_per_batch, ds, dmsg, c0_, c_, cp_)
         if args.only_encrypt:
             return
         if sk_lines is None:
-            E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
+            E.ac17_decrypt_dev(e_, n, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
                                d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
         else:
-            E.ac17_decrypt_prepared_dev(e_, B, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
+            E.ac17_decrypt_prepared_dev(e_, n, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
                                         d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
+
+    def run_steps():
+        launch_no[0] = 0
+        for g_ in sizes:
+            submit(g_)
 
     def sync_all():
         for e_ in lanes_ctx:
@@ -215,52 +333,87 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # ---------------------------------------------------------------- timed region
-    for _ in range(max(args.warmup, 1) * S if args.warmup else 0):
-        step()
+    # ---------------------------------------------------------------- timed region(s): EXACTLY --steps steps each
+    if args.warmup:
+        for _ in range((args.warmup + args.steps - 1) // args.steps):
+            run_steps()
     sync_all()
     torch.cuda.synchronize()
-    barrier()
-    step_no[0] = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    from rabe_amd import shard
-    elapsed = shard.max_over_ranks(t1 - t0)
+    regions = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run_steps()
+        sync_all()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        regions.append(shard.max_over_ranks(t1 - t0))
+        if not same_on_all_ranks(sum(regions) < args.min_time and len(regions) < 200):
+            break
+    elapsed = sum(regions) / len(regions)
 
     # ---------------------------------------------------------------- size-independent correctness property on the FULL batch:
-    # decrypt(encrypt(msg)) == msg, bit for bit, for every item (oracle parity at small sizes is in tests/)
+    # decrypt(encrypt(msg)) == msg, bit for bit, for every item of every group slot (oracle parity at small sizes is in tests/)
     want = eng.download(dmsg)
-    ok = all(lanes_ctx[i].download(bufs[i][3]) == want for i in range(S))
+    used = {}
+    for j, g_ in enumerate(sizes):
+        used[j % S] = g_                # the LAST group a lane ran is what its buffer holds
+    ok = all(bufs[i][3].t[:g_ * B * 384].cpu().numpy().tobytes() == want[:g_ * B * 384] for i, g_ in used.items())
+    gather = None
     if world > 1:
         f = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
+        # the trivial gather: every rank's first-slot result records (B x 384 B) in ONE all_gather_into_tensor on device;
+        # rank 0 recomputes the unsharded batch's messages from the global randomness stream and compares in global order
+        mine = bufs[0][3].t[:B * 384]
+        src = mine if dist.get_backend() == "nccl" else mine.cpu()
+        allrec = torch.empty(world * B * 384, dtype=torch.uint8, device=src.device)
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        dist.all_gather_into_tensor(allrec, src)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg0
+        if rank == 0:
+            dall = eng.alloc(world * B * 384)
+            dr_all = eng.upload(b"".join(le(x) for x in rho_all))
+            eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, e_tab.h, E._sz(world * B), dr_all.ptr, dall.ptr))
+            gather = {"collective": "all_gather_into_tensor", "backend": dist.get_backend(), "bytes_per_rank": B * 384,
+                      "ms": round(1e3 * tg, 3), "matches_unsharded_order": allrec.cpu().numpy().tobytes() == eng.download(dall)}
 
     value = world * B * args.steps / elapsed
     result = {
         "metric": "ABE ops/sec (AC17 CP-ABE encrypt+decrypt)", "value": round(value, 2), "unit": "ops/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fp/Fr Montgomery, 8x32)",
         "data": "synthetic", "roundtrip_bit_exact": ok,
+        "timed_regions": {"count": len(regions), "steps_each": args.steps, "ms_min": round(1e3 * min(regions), 3),
+                          "ms_mean": round(1e3 * elapsed, 3), "ms_max": round(1e3 * max(regions), 3),
+                          "note": "every region times exactly --steps steps between barrier + synchronize; repeated until --min-time s are covered; value uses the mean"},
         "config": {"workload": "AC17 CP-ABE, %d-attribute random binary AND/OR MSP policies (%d distinct), batch %d encrypt+decrypt per GPU"
                                % (args.attrs, args.policies, B),
-                   "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": total_rows // B,
-                   "pruned_leaves_avg": round(len(ct_sel_all) / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
-                   "steps_in_flight": S, "pairing_mode": args.pairing_mode,
+                   "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": rows_per_batch // B,
+                   "pruned_leaves_avg": round(sel_per_batch / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
+                   "steps_per_launch_set": sizes, "launch_sets_in_flight": S, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"),
+                   "pairing_mode": args.pairing_mode,
                    "parallelism": "batch-sharded x%d (no data-path collective)" % world, "device": dev_name},
+        "tables": {"bytes_per_public_key": table_bytes, "g_window_bits": gw, "g_table_bytes": g_table_bytes,
+                   "build_ms_per_public_key": round(table_build_ms, 1),
+                   "break_even_ops": round(table_build_ms * 1e-3 * value / max(world, 1)),
+                   "note": "built once per public key, untimed; break_even_ops = encrypt+decrypt cycles that take as long as the build at the measured rate; "
+                           "every rank builds its own replica (about as long as a broadcast of the same bytes over xGMI would take)"},
+        "host_prep_ms_per_policy": round(host_prep_ms_per_policy, 3),
     }
+    if gather is not None:
+        result["gather"] = gather
 
     # ---------------------------------------------------------------- informational: the same steps with host buffers
-    # (inputs s, msg uploaded; ciphertext c_0, c, c_p and the decrypted Gt downloaded; pinned memory, copies ordered on
-    # each batch's own stream so that they overlap the other batches' kernels).  Never `value`.
-    if not args.no_host_io_leg and not args.only_encrypt:
-        n_s, n_msg = 2 * B * 32, B * 384
-        sizes_out = (B * 3 * 128, total_rows * 3 * 64, B * 384, B * 384)
+    # (inputs s, msg uploaded; ciphertext c_0, c, c_p and the decrypted Gt downloaded; pinned memory, copies on a copy
+    # stream per group in flight, ordered by events).  Never `value`.
+    if not args.no_host_io_leg and not args.only_encrypt and not os.environ.get("RABE_SHARED_DEVICE"):
+        n_s, n_msg = 2 * GB * 32, GB * 384
+        sizes_out = (GB * 3 * 128, total_rows * 3 * 64, GB * 384, GB * 384)
         io = []
         for e_ in lanes_ctx:
             h_in = (e_.host_alloc(n_s), e_.host_alloc(n_msg))
@@ -270,8 +423,6 @@ def main():
         for (_, _, h_in, _) in io:
             ctypes.memmove(h_in[0], hs, n_s)
             ctypes.memmove(h_in[1], hm, n_msg)
-
-        # one copy context per batch in flight: it drains the outputs while the compute context runs on
         copy_ctx = []
         for _ in lanes_ctx:
             c2 = Engine(local_rank)
@@ -279,55 +430,56 @@ def main():
             c2.set_stream(st3.cuda_stream)
             copy_ctx.append((c2, st3))
 
-        def step_io():
-            i = step_no[0] % S
-            step_no[0] += 1
+        def submit_io(g_steps):
+            i = launch_no[0] % S
+            launch_no[0] += 1
             e_ = lanes_ctx[i]
             cpy = copy_ctx[i][0]
             c0_, c_, cp_, out_ = bufs[i]
             ds_, dmsg_, h_in, h_out = io[i]
+            n = g_steps * B
             e_.wait_for(cpy)                               # the previous round's downloads of these buffers are done
-            e_.upload_async(ds_, h_in[0], n_s)
-            e_.upload_async(dmsg_, h_in[1], n_msg)
-            E.ac17_encrypt_dev(e_, pk, B, dA, d_item_A_off, d_ct_row_off, total_rows, ds_, dmsg_, c0_, c_, cp_)
+            e_.upload_async(ds_, h_in[0], 2 * n * 32)
+            e_.upload_async(dmsg_, h_in[1], n * 384)
+            E.ac17_encrypt_dev(e_, pk, n, dA, d_item_A_off, d_ct_row_off, g_steps * rows_per_batch, ds_, dmsg_, c0_, c_, cp_)
             cpy.wait_for(e_)
-            cpy.download_async(h_out[0], c0_, sizes_out[0])
-            cpy.download_async(h_out[1], c_, sizes_out[1])
-            cpy.download_async(h_out[2], cp_, sizes_out[2])
+            cpy.download_async(h_out[0], c0_, n * 3 * 128)
+            cpy.download_async(h_out[1], c_, g_steps * rows_per_batch * 3 * 64)
+            cpy.download_async(h_out[2], cp_, n * 384)
             if sk_lines is None:
-                E.ac17_decrypt_dev(e_, B, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
+                E.ac17_decrypt_dev(e_, n, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
                                    d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
             else:
-                E.ac17_decrypt_prepared_dev(e_, B, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
+                E.ac17_decrypt_prepared_dev(e_, n, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
                                             d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
             cpy.wait_for(e_)
-            cpy.download_async(h_out[3], out_, sizes_out[3])
+            cpy.download_async(h_out[3], out_, n * 384)
 
-        def sync_io():
+        def run_io():
+            launch_no[0] = 0
+            for g_ in sizes:
+                submit_io(g_)
             sync_all()
             for c2, _ in copy_ctx:
                 c2.sync()
 
-        step_no[0] = 0
-        for _ in range(S):
-            step_io()
-        sync_io()
+        run_io()
         barrier()
-        step_no[0] = 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_io()
-        sync_io()
+        reps_io = 0
+        while same_on_all_ranks(reps_io < 1 or (time.perf_counter() - t0 < 0.5 * args.min_time and reps_io < 50)):
+            run_io()
+            reps_io += 1
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
-        el_io = shard.max_over_ranks(t1 - t0)
-        ok_io = all(ctypes.string_at(io[i][3][3], sizes_out[3]) == want for i in range(S))
-        per_step = n_s + n_msg + sum(sizes_out)
+        el_io = shard.max_over_ranks(t1 - t0) / reps_io
+        ok_io = all(ctypes.string_at(io[i][3][3], g_ * B * 384) == want[:g_ * B * 384] for i, g_ in used.items())
+        per_step = (2 * 32 + 384 + 3 * 128 + 384 + 384) * B + rows_per_batch * 3 * 64
         result["host_io_leg"] = {"ops_per_s": round(world * B * args.steps / el_io, 2), "ms_per_step": round(1e3 * el_io / args.steps, 3),
                                  "pcie_bytes_per_step": per_step, "pcie_GBps": round(per_step * args.steps / el_io / 1e9, 2),
                                  "roundtrip_bit_exact": ok_io,
-                                 "note": "inputs uploaded and all outputs downloaded every step (pinned host memory; downloads on a copy stream per batch in flight, ordered by events)"}
+                                 "note": "inputs uploaded and all outputs downloaded every step (pinned host memory; downloads on a copy stream per group in flight, ordered by events)"}
         for i, e_ in enumerate(lanes_ctx):
             for hp_ in io[i][2] + io[i][3]:
                 e_.host_free(hp_)
@@ -335,32 +487,27 @@ def main():
             c2.close()
 
     if rank == 0:
-        # ------------------------------------------------------------ roofline of the dominant kernel (HIP events on the launch stream)
+        # ------------------------------------------------------------ roofline of the dominant kernel: HIP events on the launch
+        # stream around every kernel of ONE full group (G x B items, nothing else running) -- the launch fills the chip
         eng.timing(True)
         eng.timing_read()
         reps = 3
-        for _ in range(reps):          # one batch at a time on lane 0: per-kernel durations without overlap
-            step_no[0] = 0
-            step()
+        for _ in range(reps):
+            submit(G, lane=0)
             eng.sync()
         tim = eng.timing_read()
         eng.timing(False)
         per_kernel = {kname: ms / cnt for kname, (ms, cnt) in tim.items()}
-        # "dominant" = the kernel that consumes the most SIMD time (duration x SIMDs it occupies): the pairing
-        # kernels run one 64-lane wave per SIMD, so a launch of n lanes occupies min(n/64, #SIMDs) of them.
-        n_simd = n_cu * 4
-        lane_count = {"k_ac17_dec_miller": B * 6, "k_ac17_dec_miller2": B * 3, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 18, "k_final_exp_c3": B * 3,
-                      "k_ac17_enc_rows": total_rows, "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
-        waves_per_simd = {"k_ac17_enc_rows": 4}
-        simd_ms = {kk: v * min(n_simd, lane_count.get(kk, 0) / 64.0 / waves_per_simd.get(kk, 1)) for kk, v in per_kernel.items()}
-        dom = max(simd_ms, key=lambda kk: simd_ms[kk])
+        dom = max(per_kernel, key=lambda kk: per_kernel[kk])
         dom_ms = per_kernel[dom]
         # peak: dependent-free v_mad_u64_u32 issue rate measured live on this chip
         ms_c, ops_c = eng.calibrate(0, 20000)
         peak_tmac = ops_c / (ms_c * 1e-3) / 1e12
-        m_avg = len(ct_sel_all) / B
-        lanes = {"k_ac17_dec_miller": B * 6, "k_ac17_dec_miller2": B * 3, "k_final_exp": B, "k_ac17_dec_miller_c3": B * 6, "k_final_exp_c3": B, "k_ac17_enc_rows": total_rows,
-                 "k_ac17_enc_c0": B * 3, "k_ac17_enc_cp": B}
+        m_avg = sel_per_batch / B
+        NB = G * B
+        rows_g = G * rows_per_batch
+        lanes = {"k_ac17_dec_miller": NB * 6, "k_ac17_dec_miller2": NB * 3, "k_final_exp": NB, "k_ac17_dec_miller_c3": NB * 6, "k_final_exp_c3": NB,
+                 "k_ac17_enc_rows": rows_g, "k_ac17_enc_c0": NB * 3, "k_ac17_enc_cp": NB}
         alg = {"k_ac17_dec_miller": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL,
                "k_ac17_dec_miller2": 2 * (SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL),
                "k_ac17_dec_miller_c3": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL, "k_final_exp_c3": 9000 + 6 * 54,
@@ -369,25 +516,36 @@ def main():
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # whole step against the same peak: SURVEY 8d's 0.12 M Fp-mul per op (16.4 M MAC32)
+        step_macs = 0.12e6 * MAC_PER_FPMUL * B
         # HBM side (reported, not binding): algorithmic bytes of the whole step
-        alg_bytes = B * (2 * 32 + 384) + total_rows * 192 * 2 + B * (384 + 384) * 2 + len(ct_sel_all) * 4 * 2 + B * 384
+        alg_bytes = B * (2 * 32 + 384) + rows_per_batch * 192 * 2 + B * (384 + 384) * 2 + sel_per_batch * 4 * 2 + B * 384
         traffic, traffic_src = pmc_traffic(dom)
         result["roofline"] = {
             "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
-            "kernel_ms": round(dom_ms, 4), "achieved": round(achieved, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
+            "kernel_ms": round(dom_ms, 4), "items_per_launch": NB, "steps_per_launch": G,
+            "kernel_ms_per_step": round(dom_ms / G, 4),
+            "achieved": round(achieved, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
             "frac": round(achieved / peak_tmac, 4) if peak_tmac else None,
             "work": "algorithmic Fp-muls/lane (SURVEY 8d) x 136 MAC32 x lanes = %.3e MAC32 per launch" % macs,
             "achieved_impl_count": round(lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL / (dom_ms * 1e-3) / 1e12, 4)
             if dom_ms > 0 else None,
+            "whole_step_frac": round(step_macs / (elapsed / args.steps) / 1e12 / peak_tmac, 4) if peak_tmac else None,
             "traffic": traffic, "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
             "traffic_source": traffic_src,
-            "valu_issue": pmc_valu_issue(dom, lanes.get(dom, 0), impl.get(dom, alg.get(dom, 0))),
+            "valu_issue": pmc_valu_issue(dom),
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
                     "peak_GBps": 8000},
             "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
-            "kernels_simd_share": {kk: round(v / sum(simd_ms.values()), 3) for kk, v in sorted(simd_ms.items(), key=lambda x: -x[1])},
-            "dominant_by": "SIMD time = duration x occupied SIMDs (one batch at a time, HIP events on the launch stream)",
+            "kernels_ms_sum_per_step": round(sum(per_kernel.values()) / G, 4),
+            "dominant_by": "duration of one launch over a full group (every launch occupies all SIMDs); HIP events on the launch stream, nothing else running",
         }
+        # ------------------------------------------------------------ the same config through the object-level host layer (rabe_*)
+        if world == 1 and not args.no_object_api:
+            try:
+                result["object_api"] = object_api_leg(args, trees)
+            except Exception as ex:
+                result["object_api"] = {"error": repr(ex)}
         # ------------------------------------------------------------ CPU baseline (oracle = reference-order restatement; checker only)
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -410,6 +568,36 @@ def main():
         dist.destroy_process_group()
 
 
+def object_api_leg(args, trees):
+    """AC17 config 2 through the reference-shaped object API of the C++ host layer (rabe_ac17_cp_{encrypt,decrypt}_batch:
+    policy strings and plaintext bytes in, ciphertext objects out, AES-GCM sealing included) -- what a caller of the
+    scheme functions sees, per-item host work (parse, MSP, pruning, KDF + AES) inside the timed region."""
+    from rabe_amd import hostlib as hl
+    from rabe_amd import hostprep as hp
+    from rabe_amd.schemes import ac17
+    host = hl.Host(0)
+    try:
+        attrs = ["a%d" % (i + 1) for i in range(args.attrs)]
+        pk, msk = ac17.setup(host)
+        sk = ac17.cp_keygen(host, msk, attrs)
+        pols = [hp.to_json(t) for t in trees]
+        n = args.batch
+        items = [pols[i % len(pols)] for i in range(n)]
+        pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
+        ac17.cp_decrypt_batch(host, [sk] * 64, ac17.cp_encrypt_batch(host, pk, items[:64], pts[:64], hl.JSON_POLICY))   # tables, prepared key
+        t0 = time.perf_counter()
+        cts = ac17.cp_encrypt_batch(host, pk, items, pts, hl.JSON_POLICY)
+        t1 = time.perf_counter()
+        out = ac17.cp_decrypt_batch(host, [sk] * n, cts)
+        t2 = time.perf_counter()
+        return {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "batch": n,
+                "plaintexts_match": out == pts,
+                "note": "rabe_ac17_cp_{encrypt,decrypt}_batch through ctypes: policy text + plaintext bytes -> ciphertext objects -> plaintext bytes; "
+                        "parse/MSP/pruning/KDF/AES-GCM and object assembly are inside the timed region"}
+    finally:
+        host.close()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/pmc_traffic.sh writes them; rocprofv3
     cannot run inside the bench).  None when no summary names the kernel."""
@@ -428,10 +616,9 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def pmc_valu_issue(kernel, n_lanes, fpmul_per_lane):
+def pmc_valu_issue(kernel):
     """VALU issue-slot occupancy of `kernel` from the newest committed SQ-counter summary (tools/pmc_sq.sh): VALU
-    instructions per wave issue slot (SQ_WAVE_CYCLES counts 4-cycle slots), and the same with the second slot of every
-    half-rate v_mad_u64_u32 added (64 + 43 MADs per Fp multiplication-equivalent of the lazy Fq2 arithmetic)."""
+    instructions per wave issue slot (SQ_WAVE_CYCLES counts 4-cycle slots)."""
     import glob
     import re
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")))):
@@ -444,10 +631,8 @@ def pmc_valu_issue(kernel, n_lanes, fpmul_per_lane):
             if m and cur == kernel:
                 vals[m.group(1)] = float(m.group(2))
         if "SQ_INSTS_VALU" in vals and vals.get("SQ_WAVE_CYCLES"):
-            mads = n_lanes * fpmul_per_lane * 107.0 / 64.0          # per-wave MAD count x waves
             return {"valu_per_slot": round(vals["SQ_INSTS_VALU"] / vals["SQ_WAVE_CYCLES"], 3),
-                    "valu_slots_incl_mad_second_slot": round((vals["SQ_INSTS_VALU"] + mads) / vals["SQ_WAVE_CYCLES"], 3),
-                    "source": "profiles/" + os.path.basename(f)}
+                    "valu_insts_per_launch": vals["SQ_INSTS_VALU"], "source": "profiles/" + os.path.basename(f)}
     return None
 
 
@@ -455,7 +640,6 @@ def cpu_baseline_multicore(args, tree):
     """The same C restatement on several host cores at once (independent processes, a few items each): what a
     multi-threaded caller of the single-threaded reference would get.  Informational, beside cpu_baseline.
     Plain subprocesses with a hard deadline -- nothing here can hold up the GPU result."""
-    import subprocess
     from rabe_amd import hostprep as hp
     from oracle import cport
     if not cport.available():
@@ -498,13 +682,15 @@ def cpu_baseline(args, tree):
     except Exception:
         have_c = False
     if have_c:
-        n = args.cpu_sample or 48
+        n = args.cpu_sample or 96
         _outs, dt = cport.ac17_encdec(policy, args.attrs, n, seed=args.seed)
         return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
                 "sample": "%d AC17 encrypt+decrypt (policy parse + MSP + group loops) at %d attributes in %.1f s; C restatement "
                           "of the reference's operation order (oracle/c/rabe_ref.c: binary double-and-add for every G*Fr, "
                           "per-row hash-to-group, one final exponentiation per pairing), single thread like the reference"
-                          % (n, args.attrs, dt)}
+                          % (n, args.attrs, dt),
+                "note": "includes the per-item host work (parse, MSP, hashing) that the GPU `value` keeps outside its timed region; "
+                        "object_api is the GPU path at the same boundary"}
     # pure-Python big-int oracle: one item at a reduced attribute count scaled linearly in the encrypt part
     from oracle import bn254 as bn
     from oracle import policy as pol

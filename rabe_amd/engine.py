@@ -285,6 +285,17 @@ def _sz(n):
     return ctypes.c_size_t(int(n))
 
 
+def wide_windows(w):
+    """number of signed w-bit windows of a 254-bit scalar (engine.hip: wide_windows)"""
+    return (254 + w - 1) // w
+
+
+def wide_count(w, i):
+    """entries of window i of the signed w-bit table (engine.hip: wide_count)"""
+    n = wide_windows(w)
+    return (1 << (w - 1)) if i < n - 1 else (1 << (254 - w * (n - 1)))
+
+
 def ac17_encrypt_dev(eng, pk, n_items, dA, ditem_A_off, dct_row_off, total_rows, ds, dmsg, dc0, dc, dcp):
     eng._check(eng.lib.rhip_ac17_cp_encrypt_batch(eng.ctx, pk.h, _sz(n_items), dA.ptr, ditem_A_off.ptr, dct_row_off.ptr,
                                                   _sz(total_rows), ds.ptr, dmsg.ptr, dc0.ptr, dc.ptr, dcp.ptr))
