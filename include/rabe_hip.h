@@ -232,6 +232,65 @@ int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_items,
                                             const uint32_t* dev_sk_idx, const uint32_t* dev_ct_sel, const uint32_t* dev_ct_sel_off,
                                             const uint32_t* dev_sk_sel, const uint32_t* dev_sk_sel_off, rhip_gt* dev_out);
 
+/* ---- prepared G2 arguments (generic form of rhip_ac17_sk_prepare) -----------------------------------------------
+ * The Miller-loop line coefficients of n G2 points (88 triples of Fq2 each, 16.9 KB per point): what `pairing` spends on
+ * the G2 side, paid once for a G2 element that many pairings share (a secret key's components, a public key element).
+ * Returns after the lines are complete, so the handle may be used from any context. */
+typedef struct rhip_g2_lines rhip_g2_lines;
+int32_t rhip_g2_lines_prepare(rhip_ctx* ctx, size_t n, const rhip_g2* dev_q, rhip_g2_lines** out);
+void rhip_g2_lines_destroy(rhip_g2_lines* p);
+
+/* ---- Level B: BSW CP-ABE (src/schemes/bsw/mod.rs) ---------------------------------------------------------------
+ * Flattened policy trees (the host has parsed the policy text; everything below is numbers).  The leaves of a policy
+ * are numbered in DFS order -- the order gen_shares_policy emits shares (src/utils/secretsharing/mod.rs:82-122) --
+ * and the tables of all distinct policies of a batch are concatenated:
+ *   path_off[leaf .. leaf+1]      the leaf's path entries, root first
+ *   path_gate[e], path_x[e]       "child number x (1-based) of gate `gate`" (gate numbered relative to the policy's first gate)
+ *   gate_k[g]                     threshold of gate g: its child count for AND, 1 for OR (:98-110)
+ *   gate_coef_off[g]              where the gate's k-1 polynomial coefficients start in an item's draw list (DFS pre-order,
+ *                                 the reference's draw order :128-134)
+ *   leaf_hash[leaf]               Fr(SHA3(name)) of the leaf's attribute (src/utils/hash/mod.rs:23-31)
+ * Item i uses the policy whose first leaf row / first gate row are item_tree_leaf[i] / item_tree_gate[i], owns output
+ * leaf rows [item_leaf_off[i], item_leaf_off[i+1]) and the draws coef[item_coef_off[i] ..].
+ */
+typedef struct rhip_bsw_pk rhip_bsw_pk;       /* window tables of g1, g2, h, e_gg_alpha (CpAbePublicKey, bsw/mod.rs:43-49) */
+int32_t rhip_bsw_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, const rhip_g1* host_h,
+                           const rhip_gt* host_e_gg_alpha, rhip_bsw_pk** out);
+void rhip_bsw_pk_destroy(rhip_bsw_pk* pk);
+/* Group arithmetic of n_items calls of bsw::encrypt (bsw/mod.rs:217-251): explicit randomness per item = secret (:228),
+ * the Gt `msg` (:229) and the gate coefficients.  Outputs: c = h * secret, c_p = e_gg_alpha^secret * msg, and per leaf
+ * row (g1 * q_y, (g2 * h(name_y)) * q_y) with q_y the leaf's share of `secret`. */
+int32_t rhip_bsw_encrypt_batch(rhip_ctx* ctx, const rhip_bsw_pk* pk, size_t n_items, size_t total_leaves,
+                               const uint32_t* dev_item_leaf_off /*[n_items+1]*/, const uint32_t* dev_item_tree_leaf /*[n_items]*/,
+                               const uint32_t* dev_item_tree_gate /*[n_items]*/, const uint32_t* dev_path_off, const uint32_t* dev_path_gate,
+                               const uint32_t* dev_path_x, const uint32_t* dev_gate_k, const uint32_t* dev_gate_coef_off,
+                               const rhip_fr* dev_leaf_hash, const rhip_fr* dev_secret /*[n_items]*/, const rhip_fr* dev_coef,
+                               const uint32_t* dev_item_coef_off /*[n_items]*/, const rhip_gt* dev_msg /*[n_items]*/,
+                               rhip_g1* dev_c /*[n_items]*/, rhip_gt* dev_cp /*[n_items]*/, rhip_g1* dev_cy_g1 /*[total_leaves]*/,
+                               rhip_g2* dev_cy_g2 /*[total_leaves]*/);
+/* Group arithmetic of n_items calls of bsw::decrypt (bsw/mod.rs:260-318).  The host has run traverse_policy / calc_pruned /
+ * calc_coefficients (string and Fr work, per distinct (policy, key attribute set)) and hands over selection tables: entry e
+ * names a pruned leaf by its row in the ciphertext (sel_ct_leaf, relative to the item's first leaf row), the matching
+ * attribute row of the key (sel_sk_attr, relative to the key's first row) and the leaf's Lagrange coefficient z
+ * (sel_coeff).  Item i uses entries sel_start[i] .. sel_start[i] + m_i - 1 and owns pairs [pair_off[i], pair_off[i+1]),
+ * pair_off[i+1] - pair_off[i] = 2 m_i + 1 (max_pairs = the largest such count).  Ciphertext i: c, c_p and leaf rows
+ * [ct_leaf_off[i], ct_leaf_off[i+1]); key sk_idx[i]: d and attribute rows [sk_attr_off[k], sk_attr_off[k+1]).
+ *   out[i] = c_p * FE( ML(-c, d) * prod_e ML(z_e Cy.g1, Dj.g2) ML(-z_e Dj.g1, Cy.g2) )     
+ * i.e. the Gt handed to decrypt_symmetric (:308-311).  sk_lines (optional, rhip_bsw_sk_prepare): prepared lines of the
+ * keys' G2 components -- the same values, without the G2 arithmetic of the key-side pairings. */
+typedef struct rhip_bsw_sk_lines rhip_bsw_sk_lines;
+int32_t rhip_bsw_sk_prepare(rhip_ctx* ctx, size_t n_sk, size_t total_attrs, const rhip_g2* dev_sk_d /*[n_sk]*/,
+                            const rhip_g2* dev_sk_dj_g2 /*[total_attrs]*/, rhip_bsw_sk_lines** out);
+void rhip_bsw_sk_lines_destroy(rhip_bsw_sk_lines* p);
+int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs,
+                               const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                               const uint32_t* dev_sel_ct_leaf, const uint32_t* dev_sel_sk_attr, const rhip_fr* dev_sel_coeff,
+                               const rhip_g1* dev_ct_c /*[n_items]*/, const rhip_gt* dev_ct_cp /*[n_items]*/,
+                               const rhip_g1* dev_ct_cy_g1, const rhip_g2* dev_ct_cy_g2, const uint32_t* dev_ct_leaf_off /*[n_items+1]*/,
+                               const rhip_g2* dev_sk_d /*[n_sk]*/, const rhip_g1* dev_sk_dj_g1, const rhip_g2* dev_sk_dj_g2,
+                               const uint32_t* dev_sk_attr_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items]*/,
+                               const rhip_bsw_sk_lines* sk_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- measurement helper: integer-multiply issue-rate microbenchmark (the roofline denominator) --
  * Runs `iters` dependent-free v_mad_u64_u32 per lane on every CU and returns elapsed milliseconds
  * and the number of multiply-adds executed. */

@@ -1,7 +1,9 @@
-"""Compiles the HIP engine for gfx950 in-tree: rabe_amd/csrc/engine.hip -> rabe_amd/librabe_hip.so.
+"""Compiles the HIP engine for gfx950 in-tree: rabe_amd/csrc/*.hip + host/*.cpp -> rabe_amd/librabe_hip.so.
 
-hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the snapshot.
+hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the snapshot.  The translation
+units are compiled in parallel (objects under build/obj, git-ignored) and linked into one shared library.
 """
+import concurrent.futures
 import os
 import subprocess
 import sys
@@ -9,34 +11,61 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
-SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "host", "schemes.cpp"), os.path.join(CSRC, "host", "host_abi.cpp")]
+OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
+SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "host", "schemes.cpp"),
+           os.path.join(CSRC, "host", "host_abi.cpp")]
 
 
-def _deps():
+def _headers():
     inc = os.path.join(os.path.dirname(HERE), "include")
-    deps = list(SOURCES) + [os.path.join(inc, "rabe_hip.h"), os.path.join(inc, "rabe_host.h")]
+    deps = [os.path.join(inc, "rabe_hip.h"), os.path.join(inc, "rabe_host.h")]
     for root, _dirs, files in os.walk(CSRC):
-        deps += [os.path.join(root, f) for f in files]
+        deps += [os.path.join(root, f) for f in files if f.endswith(".h")]
     return deps
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src) + ".o")
+
+
+def _flags():
+    extra = os.environ.get("RABE_HIPCC_FLAGS")          # kernel-tuning experiments, e.g. -DRB_MIN_WAVES=3
+    return extra.split() if extra else []
 
 
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    return any(os.path.getmtime(d) > t for d in _headers() + [s for s in SOURCES if os.path.exists(s)])
+
+
+def _compile(src, verbose):
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src)] + _flags()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, timeout=3000)
 
 
 def build(force=False, verbose=False):
     if not (force or stale()):
         return LIB
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + SOURCES
-    extra = os.environ.get("RABE_HIPCC_FLAGS")          # kernel-tuning experiments, e.g. -DRB_MIN_WAVES=3
-    if extra:
-        cmd += extra.split()
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    flags_tag = os.path.join(OBJ, ".flags")
+    same_flags = os.path.exists(flags_tag) and open(flags_tag).read() == " ".join(_flags())
+    todo = [s for s in srcs if force or not same_flags or not os.path.exists(_obj(s))
+            or os.path.getmtime(_obj(s)) < max(hdr_t, os.path.getmtime(s))]
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 2))) as ex:
+            for f in [ex.submit(_compile, s, verbose) for s in todo]:
+                f.result()
+    open(flags_tag, "w").write(" ".join(_flags()))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in srcs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, timeout=1800)
+    subprocess.run(cmd, check=True, timeout=600)
     return LIB
 
 

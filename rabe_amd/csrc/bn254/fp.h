@@ -20,7 +20,7 @@
 //             curve, pairing steps) is a function taking references -- its operands are 48..96 dwords
 //             and the memory traffic is <5% of the multiplications inside.
 #define RB_HD __host__ __device__ __forceinline__
-#define RB_FN __host__ __device__ __attribute__((noinline))
+#define RB_FN __host__ __device__ inline __attribute__((noinline))
 #define RB_HD_NOINLINE RB_FN
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RB_MID __host__ __device__ __forceinline__

@@ -299,6 +299,84 @@ RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b)
   return f;
 }
 
+// ---- any number of pairings on one accumulator: f = prod_j miller(P_j, Q_j) (up to Fq6 factors the final
+// exponentiation removes).  The Fq12 squaring of a doubling step is paid once for all of the lane's pairs, and the
+// lines of two neighbouring pairs are multiplied together first (ell2).  A pair either walks its own G2 point
+// (MP_WALK: the running point T_j lives outside the register file, fetched and written back around its step) or
+// replays prepared lines of a fixed Q (MP_LINES: no G2 arithmetic at all); MP_SKIP pairs contribute 1 (an argument
+// at infinity).  This is what bsw / lsw / aw11 decrypt need: the 2m+1 pairings of one ciphertext multiply into one
+// value (src/schemes/bsw/mod.rs:291-294,308; lsw/mod.rs:275-280; aw11/mod.rs:340-350).
+// ACC provides:
+//   int count() const                         pairs of this lane
+//   int kind(int j) const                     MP_WALK / MP_LINES / MP_SKIP
+//   MillerP p(int j) const                    the G1 argument (affine: scaled = false)
+//   G2Aff q(int j) const                      MP_WALK: the G2 argument
+//   LineCoeffs line(int j, int n) const       MP_LINES: prepared triple n (order of g2_prepare_lines)
+//   G2Hom ld_t(int j) const / void st_t(int j, const G2Hom&) const      MP_WALK: the running point
+enum { MP_WALK = 0, MP_LINES = 1, MP_SKIP = 2 };
+enum { MS_DBL = 0, MS_ADD_POS, MS_ADD_NEG, MS_FROB1, MS_FROB2 };
+template <class ACC>
+RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, LineCoeffs& l) {
+  const int kind = acc.kind(j);
+  if (kind == MP_SKIP) return false;
+  if (kind == MP_LINES) { l = acc.line(j, ln); return true; }
+  G2Hom t = acc.ld_t(j);
+  if (mode == MS_DBL) {
+    l = g2hom_double(t);
+  } else {
+    G2Aff q = acc.q(j);
+    if (mode == MS_ADD_NEG) q.y = fp2_neg(q.y);
+    else if (mode == MS_FROB1) q = g2_frob1(q);
+    else if (mode == MS_FROB2) q = aff_neg(g2_frob2(q));
+    l = g2hom_add(t, q);
+  }
+  acc.st_t(j, t);
+  return true;
+}
+template <class ACC>
+RB_FN Fp12 miller_loop_multi(ACC acc) {
+  const int n = acc.count();
+  Fp12 f = fp12_one();
+  for (int j = 0; j < n; j++) {
+    if (acc.kind(j) == MP_WALK) {
+      const G2Aff q = acc.q(j);
+      acc.st_t(j, G2Hom{q.x, q.y, fp2_one()});
+    }
+  }
+  // one loop over the RB_MILLER_LINES line events (65 doublings, 21 additions, 2 Frobenius additions) so that the step
+  // body below exists once in the instruction stream
+  int i = RB_ATE_NAF_LEN - 2;
+  bool add_pending = false;
+  for (int ln = 0; ln < RB_MILLER_LINES; ln++) {
+    int mode;
+    if (i >= 0) {
+      const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+      const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+      if (!add_pending) {
+        f = fp12_sqr(f);
+        mode = MS_DBL;
+        if (pos | ngt) add_pending = true; else i--;
+      } else {
+        mode = pos ? MS_ADD_POS : MS_ADD_NEG;
+        add_pending = false;
+        i--;
+      }
+    } else {
+      mode = (i == -1) ? MS_FROB1 : MS_FROB2;
+      i--;
+    }
+    for (int j = 0; j < n; j += 2) {
+      LineCoeffs la, lb;
+      const bool ha = miller_multi_line(acc, j, mode, ln, la);
+      const bool hb = (j + 1 < n) && miller_multi_line(acc, j + 1, mode, ln, lb);
+      if (ha && hb) f = ell2(f, la, acc.p(j), lb, acc.p(j + 1));
+      else if (ha) f = ell(f, la, acc.p(j));
+      else if (hb) f = ell(f, lb, acc.p(j + 1));
+    }
+  }
+  return f;
+}
+
 // f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).
 RB_FN Fp12 fp12_cyclotomic_exp_u(const Fp12& f) {
   Fp12 acc = f;   // top bit (bit 62)

@@ -1,0 +1,521 @@
+// Shared between the engine's translation units (engine.hip: Level E, tables, AC17; engine_jobs.hip: the generic
+// pairing-job kernels and the BSW / LSW / AW11 Level B entry points).  Device code is not linked across translation
+// units (no -fgpu-rdc): every __device__ function here is static or inline and compiled into each unit that uses it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rabe_hip.h"
+#include "bn254/io.h"
+#include "bn254/coop3.h"
+
+using namespace rabe::bn254;
+// Minimum resident waves per SIMD every kernel is compiled for (second __launch_bounds__ argument).
+// Measured on MI355X: 1 is best -- the Miller / final-exponentiation state
+// (Fq12 accumulator, G2 point, line, temporaries) then lives in the 512-entry VGPR+AGPR file instead of
+// scratch; asking for 2..4 waves caps the budget at 256..128 registers and the extra scratch traffic costs
+// more than the second wave hides (-2 % / -13 % / -20 %).
+// G1-only kernels carry a small state (a Jacobian accumulator and a table entry); they are compiled for
+// more resident waves so table-gather and dependent-issue latency overlap.
+#ifndef RB_G1_WAVES
+#define RB_G1_WAVES 4
+#endif
+#ifndef RB_MIN_WAVES
+#define RB_MIN_WAVES 1
+#endif
+// ------------------------------------------------------------------------------------------------
+// context
+struct rhip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int n_cu = 0;
+  // grow-only device scratch (Miller values between k_miller and k_final_exp)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // grow-only workspace of k_final_exp (FE_SLOTS Fq12 per lane, [slot][word][lane])
+  void* fe_ws = nullptr;
+  size_t fe_ws_bytes = 0;
+  // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
+  enum { N_WORK = 8 };
+  void* work[N_WORK] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t work_bytes[N_WORK] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
+  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
+  bool timing = false;
+  struct Pending { std::string name; hipEvent_t e0, e1; };
+  std::vector<Pending> pending;
+};
+// defined in engine.hip
+void rhip_ktime_begin(rhip_ctx* ctx, const char* name);
+void rhip_ktime_end(rhip_ctx* ctx);
+int32_t rhip_fail(rhip_ctx* ctx, hipError_t e, const char* what);
+int32_t rhip_ensure_scratch(rhip_ctx* ctx, size_t bytes);
+int32_t rhip_ensure_fe_ws(rhip_ctx* ctx, size_t bytes);
+int32_t rhip_ensure_work(rhip_ctx* ctx, int slot, size_t bytes, void** out);
+#define ktime_begin rhip_ktime_begin
+#define ktime_end rhip_ktime_end
+#define fail rhip_fail
+#define ensure_scratch rhip_ensure_scratch
+#define ensure_fe_ws rhip_ensure_fe_ws
+#define KLAUNCH(ctx, NAME, ...)            \
+  do {                                     \
+    ktime_begin(ctx, NAME);                \
+    hipLaunchKernelGGL(__VA_ARGS__);       \
+    ktime_end(ctx);                        \
+    LAUNCH_CHECK(ctx, NAME);               \
+  } while (0)
+
+#define HIP_TRY(ctx, call)                                   \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return fail(ctx, e__, #call);     \
+  } while (0)
+#define LAUNCH_CHECK(ctx, name)                              \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return fail(ctx, e__, name);      \
+  } while (0)
+
+#define NEED(ctx) do { if (!(ctx)) return RHIP_ERR_ARG; } while (0)
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------------
+// internal (Montgomery) storage of points / Gt values in HBM
+struct G1M { uint32_t l[16]; };   // x, y Montgomery
+struct G2M { uint32_t l[32]; };
+struct G1JM { uint32_t l[24]; };  // Jacobian x, y, z Montgomery
+struct GtM { uint32_t l[96]; };
+
+__device__ __forceinline__ Fp ld_fp_m(const uint32_t* p) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ void st_fp_m(uint32_t* p, const Fp& a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[i] = a.v[i];
+}
+__device__ __forceinline__ Fp2 ld_fp2_m(const uint32_t* p) { return Fp2{ld_fp_m(p), ld_fp_m(p + 8)}; }
+__device__ __forceinline__ void st_fp2_m(uint32_t* p, const Fp2& a) { st_fp_m(p, a.c0); st_fp_m(p + 8, a.c1); }
+__device__ __forceinline__ G1Aff ld_g1_m(const G1M* p) { return G1Aff{ld_fp_m(p->l), ld_fp_m(p->l + 8)}; }
+__device__ __forceinline__ void st_g1_m(G1M* p, const G1Aff& a) { st_fp_m(p->l, a.x); st_fp_m(p->l + 8, a.y); }
+__device__ __forceinline__ G2Aff ld_g2_m(const G2M* p) { return G2Aff{ld_fp2_m(p->l), ld_fp2_m(p->l + 16)}; }
+__device__ __forceinline__ void st_g2_m(G2M* p, const G2Aff& a) { st_fp2_m(p->l, a.x); st_fp2_m(p->l + 16, a.y); }
+static __device__ __noinline__ Fp12 ld_gt_m(const GtM* p) {
+  Fp12 r;
+  r.c0.a0 = ld_fp2_m(p->l);      r.c0.a1 = ld_fp2_m(p->l + 16); r.c0.a2 = ld_fp2_m(p->l + 32);
+  r.c1.a0 = ld_fp2_m(p->l + 48); r.c1.a1 = ld_fp2_m(p->l + 64); r.c1.a2 = ld_fp2_m(p->l + 80);
+  return r;
+}
+static __device__ __noinline__ void st_gt_m(GtM* p, const Fp12& a) {
+  st_fp2_m(p->l, a.c0.a0);      st_fp2_m(p->l + 16, a.c0.a1); st_fp2_m(p->l + 32, a.c0.a2);
+  st_fp2_m(p->l + 48, a.c1.a0); st_fp2_m(p->l + 64, a.c1.a1); st_fp2_m(p->l + 80, a.c1.a2);
+}
+__device__ __forceinline__ void ld_scalar(uint32_t k[8], const rhip_fr* p) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = p->l[i];
+}
+
+// out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical.
+// The exponentiation's Fq12 values live in the context's workspace (final_exponentiation_ws, bn254/pairing.h).
+struct DevWs {
+  uint4* base;         // + lane; [slot][quad of words][lane]: one 16-byte access per lane, contiguous over the wave
+  size_t stride;       // lanes (padded to 64)
+  __device__ __forceinline__ Fp12 ld(int slot) const {
+    const uint4* p = base + (size_t)slot * 24 * stride;
+    Fp12 r;
+    Fp2* c[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const uint4 q0 = p[(size_t)(4 * j) * stride], q1 = p[(size_t)(4 * j + 1) * stride];
+      const uint4 q2 = p[(size_t)(4 * j + 2) * stride], q3 = p[(size_t)(4 * j + 3) * stride];
+      c[j]->c0.v[0] = q0.x; c[j]->c0.v[1] = q0.y; c[j]->c0.v[2] = q0.z; c[j]->c0.v[3] = q0.w;
+      c[j]->c0.v[4] = q1.x; c[j]->c0.v[5] = q1.y; c[j]->c0.v[6] = q1.z; c[j]->c0.v[7] = q1.w;
+      c[j]->c1.v[0] = q2.x; c[j]->c1.v[1] = q2.y; c[j]->c1.v[2] = q2.z; c[j]->c1.v[3] = q2.w;
+      c[j]->c1.v[4] = q3.x; c[j]->c1.v[5] = q3.y; c[j]->c1.v[6] = q3.z; c[j]->c1.v[7] = q3.w;
+    }
+    return r;
+  }
+  __device__ __forceinline__ void st(int slot, const Fp12& a) const {
+    uint4* p = base + (size_t)slot * 24 * stride;
+    const Fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      p[(size_t)(4 * j) * stride] = make_uint4(c[j]->c0.v[0], c[j]->c0.v[1], c[j]->c0.v[2], c[j]->c0.v[3]);
+      p[(size_t)(4 * j + 1) * stride] = make_uint4(c[j]->c0.v[4], c[j]->c0.v[5], c[j]->c0.v[6], c[j]->c0.v[7]);
+      p[(size_t)(4 * j + 2) * stride] = make_uint4(c[j]->c1.v[0], c[j]->c1.v[1], c[j]->c1.v[2], c[j]->c1.v[3]);
+      p[(size_t)(4 * j + 3) * stride] = make_uint4(c[j]->c1.v[4], c[j]->c1.v[5], c[j]->c1.v[6], c[j]->c1.v[7]);
+    }
+  }
+};
+struct GtM;
+int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
+                              rhip_gt* out);
+#define launch_final_exp rhip_launch_final_exp
+// ------------------------------------------------------------------------------------------------
+// fixed-base tables: T[w][d-1] = (d * 256^w) * base, d = 1..255, w = 0..31, affine Montgomery.
+#define TBL_WINDOWS 32
+#define TBL_DIGITS 255
+#define TBL16_WINDOWS 16
+#define TBL16_DIGITS 65535
+// dev: 8-bit windows; dev16: optional 16-bit windows; wide: optional signed w-bit windows (17 <= w <= 27)
+struct rhip_g1_table { rhip_ctx* ctx; G1M* dev; G1M* dev16; G1M* wide; int wide_bits; };
+// signed w-bit windows: k = sum_i d_i 2^(w i), -2^(w-1) < d_i <= 2^(w-1); T[i][|d|-1] = (|d| 2^(w i)) * base, the sign is
+// applied to y on the fly.  n = ceil(254 / w) windows of 2^(w-1) entries (the top one only needs 2^(254-w(n-1)) of them).
+__host__ __device__ inline int wide_windows(int w) { return (254 + w - 1) / w; }
+__host__ __device__ inline size_t wide_count(int w, int i) {
+  const int n = wide_windows(w);
+  return (i < n - 1) ? ((size_t)1 << (w - 1)) : ((size_t)1 << (254 - w * (n - 1)));
+}
+__host__ __device__ inline size_t wide_offset(int w, int i) { return (size_t)i << (w - 1); }   // windows below the top are full
+struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; G2M* dev16; };   // dev16: optional 16-bit windows (134 MB)
+struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optional 16-bit windows (402 MB)
+
+static __device__ __noinline__ Fp12 table_pow_gt_w16(const GtM* tbl, const uint32_t k[8]) {
+  Fp12 acc = fp12_one();
+  bool first = true;
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    uint32_t word;
+    switch (w >> 1) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+    if (d) {
+      Fp12 e = ld_gt_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1));
+      acc = first ? e : fp12_mul(acc, e);
+      first = false;
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ uint32_t scalar_byte(const uint32_t k[8], int w) {
+  uint32_t word;
+  switch (w >> 2) {
+    case 0: word = k[0]; break;
+    case 1: word = k[1]; break;
+    case 2: word = k[2]; break;
+    case 3: word = k[3]; break;
+    case 4: word = k[4]; break;
+    case 5: word = k[5]; break;
+    case 6: word = k[6]; break;
+    default: word = k[7]; break;
+  }
+  return (word >> (8 * (w & 3))) & 255u;
+}
+// sum of <= 32 table entries selected by the bytes of the canonical scalar k
+static __device__ __noinline__ G1Jac table_mul_g1(const G1M* tbl, const uint32_t k[8]) {
+  G1Jac acc = jac_inf<Fp>();
+  for (int w = 0; w < TBL_WINDOWS; w++) {
+    uint32_t d = scalar_byte(k, w);
+    if (d) acc = jac_add_aff(acc, ld_g1_m(tbl + w * TBL_DIGITS + (d - 1)));
+  }
+  return acc;
+}
+// 16-bit digits: 16 mixed additions; the next entry is fetched while the current addition runs
+static __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[8]) {
+  G1Jac acc = jac_inf<Fp>();
+  uint32_t d = k[0] & 0xffffu;
+  G1Aff e = ld_g1_m(tbl + (d ? d - 1 : 0));
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    const uint32_t dcur = d;
+    const G1Aff ecur = e;
+    if (w + 1 < TBL16_WINDOWS) {
+      const int wn = w + 1;
+      uint32_t word;
+      switch (wn >> 1) {
+        case 0: word = k[0]; break;
+        case 1: word = k[1]; break;
+        case 2: word = k[2]; break;
+        case 3: word = k[3]; break;
+        case 4: word = k[4]; break;
+        case 5: word = k[5]; break;
+        case 6: word = k[6]; break;
+        default: word = k[7]; break;
+      }
+      d = (wn & 1) ? (word >> 16) : (word & 0xffffu);
+      e = ld_g1_m(tbl + (size_t)wn * TBL16_DIGITS + (d ? d - 1 : 0));
+    }
+    if (dcur) acc = g1_madd_inl(acc, ecur);
+  }
+  return acc;
+}
+// signed w-bit digits: ceil(254/w) mixed additions (11 for w = 24, 10 for w = 26); the digit's sign flips y
+__device__ __forceinline__ uint32_t scalar_bits(const uint32_t k[8], int b, int w) {
+  const int word = b >> 5, sh = b & 31;
+  uint32_t lo, hi;
+  switch (word) {
+    case 0: lo = k[0]; hi = k[1]; break;
+    case 1: lo = k[1]; hi = k[2]; break;
+    case 2: lo = k[2]; hi = k[3]; break;
+    case 3: lo = k[3]; hi = k[4]; break;
+    case 4: lo = k[4]; hi = k[5]; break;
+    case 5: lo = k[5]; hi = k[6]; break;
+    case 6: lo = k[6]; hi = k[7]; break;
+    default: lo = k[7]; hi = 0; break;
+  }
+  const uint64_t v = (((uint64_t)hi << 32) | lo) >> sh;
+  return (uint32_t)v & ((1u << w) - 1u);
+}
+static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uint32_t k[8], int w) {
+  const int n = wide_windows(w);
+  const uint32_t half = 1u << (w - 1);
+  G1Jac acc = jac_inf<Fp>();
+  uint32_t raw = scalar_bits(k, 0, w);
+  uint32_t carry = raw > half ? 1u : 0u;
+  uint32_t mag = carry ? (1u << w) - raw : raw;
+  bool neg_ = carry != 0;
+  G1Aff e = ld_g1_m(tbl + (mag ? mag - 1 : 0));
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const uint32_t mcur = mag;
+    const bool ncur = neg_;
+    G1Aff ecur = e;
+    if (i + 1 < n) {
+      raw = scalar_bits(k, w * (i + 1), w) + carry;
+      carry = raw > half ? 1u : 0u;
+      mag = carry ? (1u << w) - raw : raw;
+      neg_ = carry != 0;
+      e = ld_g1_m(tbl + wide_offset(w, i + 1) + (mag ? mag - 1 : 0));
+    }
+    if (mcur) {
+      if (ncur) ecur.y = neg(ecur.y);
+      acc = g1_madd_inl(acc, ecur);
+    }
+  }
+  return acc;
+}
+static __device__ __noinline__ G2Jac table_mul_g2(const G2M* tbl, const uint32_t k[8]) {
+  G2Jac acc = jac_inf<Fp2>();
+  for (int w = 0; w < TBL_WINDOWS; w++) {
+    uint32_t d = scalar_byte(k, w);
+    if (d) acc = jac_add_aff(acc, ld_g2_m(tbl + w * TBL_DIGITS + (d - 1)));
+  }
+  return acc;
+}
+static __device__ __noinline__ G2Jac table_mul_g2_w16(const G2M* tbl, const uint32_t k[8]) {
+  G2Jac acc = jac_inf<Fp2>();
+#pragma unroll 1
+  for (int w = 0; w < TBL16_WINDOWS; w++) {
+    uint32_t word;
+    switch (w >> 1) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
+    }
+    const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+    if (d) acc = jac_add_aff(acc, ld_g2_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1)));
+  }
+  return acc;
+}
+static __device__ __noinline__ Fp12 table_pow_gt(const GtM* tbl, const uint32_t k[8]) {
+  Fp12 acc = fp12_one();
+  bool first = true;
+  for (int w = 0; w < TBL_WINDOWS; w++) {
+    uint32_t d = scalar_byte(k, w);
+    if (d) {
+      Fp12 e = ld_gt_m(tbl + w * TBL_DIGITS + (d - 1));
+      acc = first ? e : fp12_mul(acc, e);
+      first = false;
+    }
+  }
+  return acc;
+}
+// ---- batched inversion across a 256-thread block (Montgomery's trick over LDS + one wave-level scan).
+// Every thread of the block contributes one non-zero Fp value and gets its inverse back; the block pays ONE
+// field inversion (361 multiplications, executed by wave 0 while the other waves wait at the barrier and free
+// their issue slots for other resident blocks) instead of one per thread.
+__device__ __forceinline__ Fp shfl_up_fp(const Fp& x, int d) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_up((int)x.v[i], d);
+  return r;
+}
+__device__ __forceinline__ Fp shfl_down_fp(const Fp& x, int d) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d);
+  return r;
+}
+__device__ __forceinline__ Fp shfl_fp(const Fp& x, int src) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl((int)x.v[i], src);
+  return r;
+}
+__device__ __forceinline__ Fp sel_fp(bool c, const Fp& a, const Fp& b) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// sh: 8 x 256 words (limb-major, conflict-free).  All 256 threads must call this.
+static __device__ __noinline__ Fp block_batch_inverse_256(uint32_t (*sh)[256], const Fp& mine) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sh[i][tid] = mine.v[i];
+  __syncthreads();
+  if (tid < 64) {
+    Fp p[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) p[e].v[i] = sh[i][4 * tid + e];
+    const Fp q1 = mul(p[0], p[1]);
+    const Fp q2 = mul(q1, p[2]);
+    const Fp q3 = mul(q2, p[3]);
+    // inclusive prefix / suffix products of q3 over the 64 lanes
+    Fp pre = q3, suf = q3;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      Fp u = shfl_up_fp(pre, d);
+      Fp w = shfl_down_fp(suf, d);
+      Fp pu = mul(pre, u);
+      Fp sw = mul(suf, w);
+      pre = sel_fp(tid >= d, pu, pre);
+      suf = sel_fp(tid + d < 64, sw, suf);
+    }
+    const Fp total_inv = inv(shfl_fp(pre, 63));
+    // exclusive prefix / suffix
+    Fp ex_pre = shfl_up_fp(pre, 1), ex_suf = shfl_down_fp(suf, 1);
+    ex_pre = sel_fp(tid >= 1, ex_pre, one<FpParams>());
+    ex_suf = sel_fp(tid < 63, ex_suf, one<FpParams>());
+    const Fp iq3 = mul(total_inv, mul(ex_pre, ex_suf));       // 1 / q3 of this lane
+    const Fp ip3 = mul(iq3, q2);
+    const Fp iq2 = mul(iq3, p[3]);
+    const Fp ip2 = mul(iq2, q1);
+    const Fp iq1 = mul(iq2, p[2]);
+    const Fp ip1 = mul(iq1, p[0]);
+    const Fp ip0 = mul(iq1, p[1]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      sh[i][4 * tid] = ip0.v[i];
+      sh[i][4 * tid + 1] = ip1.v[i];
+      sh[i][4 * tid + 2] = ip2.v[i];
+      sh[i][4 * tid + 3] = ip3.v[i];
+    }
+  }
+  __syncthreads();
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = sh[i][tid];
+  return r;
+}
+
+// Block size of the G1 row kernels = the group that shares one field inversion.  The inversion (361 multiplications,
+// executed by wave 0 while the block's other waves wait at the barrier) is a fixed cost per block: 28 % of the block's
+// issue slots at 256 threads (4 waves x ~340 multiplications of useful work each), 15 % at 512, 8 % at 1024.
+#ifndef RB_ROWS_BLOCK
+#define RB_ROWS_BLOCK 512
+#endif
+// Generalisation of block_batch_inverse_256 to NT = 64 E threads: lane j of wave 0 owns elements j, j + 64, ...,
+// j + 64 (E - 1) (conflict-free), keeps their running products in a second LDS array, joins the 64-lane scan, and
+// back-substitutes.  lds: 2 x 8 x NT words.  All NT threads must call this.
+template <int NT>
+__device__ __noinline__ Fp block_batch_inverse_n(uint32_t* lds, const Fp& mine) {
+  uint32_t (*val)[NT] = (uint32_t (*)[NT])lds;
+  uint32_t (*pre)[NT] = (uint32_t (*)[NT])(lds + 8 * NT);
+  constexpr int E = NT / 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) val[i][tid] = mine.v[i];
+  __syncthreads();
+  if (tid < 64) {
+    Fp run;
+#pragma unroll
+    for (int i = 0; i < 8; i++) run.v[i] = val[i][tid];
+#pragma unroll 1
+    for (int e = 1; e < E; e++) {
+      Fp v;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { pre[i][tid + 64 * (e - 1)] = run.v[i]; v.v[i] = val[i][tid + 64 * e]; }
+      run = mul(run, v);
+    }
+    Fp prefix = run, suffix = run;
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+      Fp u = shfl_up_fp(prefix, d);
+      Fp w = shfl_down_fp(suffix, d);
+      Fp pu = mul(prefix, u);
+      Fp sw = mul(suffix, w);
+      prefix = sel_fp(tid >= d, pu, prefix);
+      suffix = sel_fp(tid + d < 64, sw, suffix);
+    }
+    const Fp total_inv = inv(shfl_fp(prefix, 63));
+    Fp ex_pre = shfl_up_fp(prefix, 1), ex_suf = shfl_down_fp(suffix, 1);
+    ex_pre = sel_fp(tid >= 1, ex_pre, one<FpParams>());
+    ex_suf = sel_fp(tid < 63, ex_suf, one<FpParams>());
+    Fp inv_run = mul(total_inv, mul(ex_pre, ex_suf));       // 1 / (product of this lane's E elements)
+#pragma unroll 1
+    for (int e = E - 1; e >= 1; e--) {
+      Fp v, p;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { v.v[i] = val[i][tid + 64 * e]; p.v[i] = pre[i][tid + 64 * (e - 1)]; }
+      const Fp r = mul(inv_run, p);                          // 1 / v_e
+      inv_run = mul(inv_run, v);                             // 1 / (v_0 .. v_{e-1})
+#pragma unroll
+      for (int i = 0; i < 8; i++) val[i][tid + 64 * e] = r.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) val[i][tid] = inv_run.v[i];
+  }
+  __syncthreads();
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = val[i][tid];
+  return r;
+}
+// G2 Jacobian -> affine canonical with ONE Fp inversion per 128-thread block: 1 / (a + b u) = (a - b u) / (a^2 + b^2),
+// and the norms a^2 + b^2 of the block's 128 z's are inverted together.  All 128 threads must call this.
+static __device__ __noinline__ void store_g2_block128(uint32_t* lds, bool active, rhip_g2* out, const G2Jac& r) {
+  const bool inf = !active || jac_is_inf(r);
+  const Fp norm = inf ? one<FpParams>() : add(sqr(r.z.c0), sqr(r.z.c1));
+  const Fp ninv = block_batch_inverse_n<128>(lds, norm);
+  if (!active) return;
+  if (inf) { store_g2(out->l, aff_inf<Fp2>()); return; }
+  const Fp2 zinv{mul(r.z.c0, ninv), neg(mul(r.z.c1, ninv))};
+  store_g2(out->l, jac_to_aff_with_zinv(r, zinv));
+}
+// ---- prepared secret keys: the Miller-loop line coefficients of k_0[j] (fixed per key) are computed once
+// (rhip_ac17_sk_prepare) and replayed by every decryption with that key.
+struct LineM { uint32_t l[48]; };   // cy, cx, c0 (Fq2 each), Montgomery
+struct rhip_ac17_sk_lines {
+  rhip_ctx* ctx;
+  size_t n_sk;
+  LineM* lines;      // [n_sk * 3][RB_MILLER_LINES]
+  uint8_t* q_inf;    // [n_sk * 3]
+};
+// prepared lines of n arbitrary G2 points (rhip_g2_lines_prepare): lines[i * RB_MILLER_LINES + k]
+struct rhip_g2_lines {
+  rhip_ctx* ctx;
+  size_t n;
+  LineM* lines;
+  uint8_t* q_inf;    // [n]
+};
+struct DevLineLoad {
+  const LineM* base;
+  __device__ __forceinline__ LineCoeffs operator()(int k) const {
+    const uint32_t* p = base[k].l;
+    return LineCoeffs{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
+  }
+};

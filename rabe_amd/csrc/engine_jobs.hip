@@ -1,0 +1,429 @@
+// rabe_amd engine, second translation unit: the device-resident Level B paths of bsw / lsw / aw11.
+//
+// Every decrypt of those schemes is a product of pairings with coefficient-folded G1 arguments (SURVEY.md Appendix
+// B.4 / B.5), so one set of kernels carries all three:
+//   k_*_dec_pairs        scheme-specific gather: base point + Lagrange coefficient of every pair of every item,
+//                        variable-base multiplication over the NAF of the coefficient (bn254/curve.h: jac_mul_naf),
+//                        affine Montgomery output with one field inversion per block; the pair's G2 argument is either
+//                        copied (a walking pair) or named by its prepared-line block
+//   k_msm_g1 / k_msm_g2  sums  sum_j k_j P_j  with shared doublings (jac_msm_naf): lsw's e(sum -c_y D1_y, e2),
+//                        aw11's e(-H(gid), sum c_x C3_x)
+//   k_miller_multi       lane = (item, chunk of its pairs): ALL pairs of the chunk on one Fq12 accumulator
+//                        (bn254/pairing.h: miller_loop_multi); running G2 points in a coalesced global workspace
+//   k_final_exp          (engine.hip) product of the item's few chunk values + ONE final exponentiation
+// and the encrypt / keygen sides are Fr kernels (share generation over flattened policy trees) in front of the
+// fixed-base table kernels of engine.hip.
+// There is no CPU fallback anywhere in this file.
+#include "engine_internal.h"
+
+// ------------------------------------------------------------------------------------------------ small device helpers
+__device__ __forceinline__ Fp ld_fp_q(const uint4* p) {
+  const uint4 a = p[0], b = p[1];
+  Fp r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_fp_q(uint4* p, const Fp& a) {
+  p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+// Montgomery records are 64 / 128 / 192 bytes and 16-byte aligned: 128-bit accesses
+__device__ __forceinline__ G1Aff ld_g1_q(const G1M* p) { const uint4* q = (const uint4*)p; return G1Aff{ld_fp_q(q), ld_fp_q(q + 2)}; }
+__device__ __forceinline__ void st_g1_q(G1M* p, const G1Aff& a) { uint4* q = (uint4*)p; st_fp_q(q, a.x); st_fp_q(q + 2, a.y); }
+__device__ __forceinline__ G2Aff ld_g2_q(const G2M* p) {
+  const uint4* q = (const uint4*)p;
+  return G2Aff{Fp2{ld_fp_q(q), ld_fp_q(q + 2)}, Fp2{ld_fp_q(q + 4), ld_fp_q(q + 6)}};
+}
+__device__ __forceinline__ void st_g2_q(G2M* p, const G2Aff& a) {
+  uint4* q = (uint4*)p;
+  st_fp_q(q, a.x.c0); st_fp_q(q + 2, a.x.c1); st_fp_q(q + 4, a.y.c0); st_fp_q(q + 6, a.y.c1);
+}
+// item owning flat index t: the i with off[i] <= t < off[i+1] (off non-decreasing, off[n] > t)
+__device__ __forceinline__ size_t owner_of(const uint32_t* off, size_t n, size_t t) {
+  size_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// k > (r-1)/2 for a canonical k < r: then r - k is the shorter scalar and the base is negated instead
+__device__ __forceinline__ bool fr_above_half(const uint32_t k[8]) {
+  // (r-1)/2 = r >> 1 (r is odd)
+  bool gt = false, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    const uint32_t h = (FrParams::mod(i) >> 1) | (i < 7 ? (FrParams::mod(i + 1) << 31) : 0u);
+    if (!decided && k[i] != h) { gt = k[i] > h; decided = true; }
+  }
+  return gt;
+}
+__device__ __forceinline__ void fr_negate_canon(uint32_t k[8]) {      // k <- r - k for 0 < k < r
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = subb32(FrParams::mod(i), k[i], borrow);
+}
+// scalar and sign in the shorter form: returns true when the base has to be negated
+__device__ __forceinline__ bool fr_shorten(uint32_t k[8]) {
+  if (!fr_above_half(k)) return false;
+  fr_negate_canon(k);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ pair lists
+// A batch's pairs after the gather kernel: P (affine Montgomery), Q (affine Montgomery, walking pairs only) and
+// qref: RHIP_Q_WALK, RHIP_Q_SKIP (an argument at infinity: the pair contributes 1) or the prepared-line block of Q.
+#define RHIP_Q_WALK 0xFFFFFFFFu
+#define RHIP_Q_SKIP 0xFFFFFFFEu
+struct PairLists {
+  G1M* P;
+  G2M* Q;
+  uint32_t* qref;
+};
+static int32_t alloc_pair_lists(rhip_ctx* ctx, size_t total_pairs, PairLists* pl) {
+  void* p = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 0, total_pairs * sizeof(G1M), &p);
+  if (rc) return rc;
+  pl->P = (G1M*)p;
+  rc = rhip_ensure_work(ctx, 1, total_pairs * sizeof(G2M), &p);
+  if (rc) return rc;
+  pl->Q = (G2M*)p;
+  rc = rhip_ensure_work(ctx, 2, total_pairs * sizeof(uint32_t), &p);
+  if (rc) return rc;
+  pl->qref = (uint32_t*)p;
+  return RHIP_OK;
+}
+
+// k * base (or k * -base), affine Montgomery, one field inversion per 256-thread block.  All threads must call this.
+#define RB_PAIRS_BLOCK 256
+__device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Aff base, uint32_t k[8], bool negate, G1M* out, bool* is_inf) {
+  if (fr_shorten(k)) negate = !negate;
+  if (negate) base.y = neg(base.y);
+  const G1Jac r = jac_mul_naf(base, k);
+  const bool inf = !active || jac_is_inf(r);
+  const Fp zinv = block_batch_inverse_n<RB_PAIRS_BLOCK>(lds, inf ? one<FpParams>() : r.z);
+  *is_inf = inf;
+  if (active && !inf) st_g1_q(out, jac_to_aff_with_zinv(r, zinv));
+}
+
+// ------------------------------------------------------------------------------------------------ the multi-pairing kernel
+struct DevMultiAcc {
+  const G1M* P;
+  const G2M* Q;
+  const uint32_t* qref;
+  const LineM* lines;
+  int cnt;
+  uint4* ws;          // + lane; running point of pair j: quads [12 j, 12 j + 12) at stride `stride`
+  size_t stride;
+  __device__ __forceinline__ int count() const { return cnt; }
+  __device__ __forceinline__ int kind(int j) const {
+    const uint32_t v = qref[j];
+    return v == RHIP_Q_WALK ? MP_WALK : v == RHIP_Q_SKIP ? MP_SKIP : MP_LINES;
+  }
+  __device__ __forceinline__ MillerP p(int j) const {
+    const G1Aff a = ld_g1_q(P + j);
+    return MillerP{a.x, a.y, a.y, false};
+  }
+  __device__ __forceinline__ G2Aff q(int j) const { return ld_g2_q(Q + j); }
+  __device__ __forceinline__ LineCoeffs line(int j, int n) const {
+    const uint4* p = (const uint4*)(lines + (size_t)qref[j] * RB_MILLER_LINES + n);
+    return LineCoeffs{Fp2{ld_fp_q(p), ld_fp_q(p + 2)}, Fp2{ld_fp_q(p + 4), ld_fp_q(p + 6)}, Fp2{ld_fp_q(p + 8), ld_fp_q(p + 10)}};
+  }
+  __device__ __forceinline__ Fp ld1(const uint4* p) const {
+    const uint4 a = p[0], b = p[stride];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+  }
+  __device__ __forceinline__ void st1(uint4* p, const Fp& a) const {
+    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    p[stride] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+  }
+  __device__ __forceinline__ G2Hom ld_t(int j) const {
+    const uint4* p = ws + (size_t)(12 * j) * stride;
+    G2Hom t;
+    t.x = Fp2{ld1(p), ld1(p + 2 * stride)};
+    t.y = Fp2{ld1(p + 4 * stride), ld1(p + 6 * stride)};
+    t.z = Fp2{ld1(p + 8 * stride), ld1(p + 10 * stride)};
+    return t;
+  }
+  __device__ __forceinline__ void st_t(int j, const G2Hom& t) const {
+    uint4* p = ws + (size_t)(12 * j) * stride;
+    st1(p, t.x.c0); st1(p + 2 * stride, t.x.c1);
+    st1(p + 4 * stride, t.y.c0); st1(p + 6 * stride, t.y.c1);
+    st1(p + 8 * stride, t.z.c0); st1(p + 10 * stride, t.z.c1);
+  }
+};
+// lane t = chunk * n_items + item: a wave holds 64 items at the same chunk position, so that batches of equally shaped
+// items run without divergence and read the same prepared lines.  Chunk c of an item = its pairs
+// [pair_off[item] + c C, min(pair_off[item] + (c+1) C, pair_off[item+1])).  Output: mill[item * L + c].
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, const G1M* P,
+                                                                  const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
+                                                                  GtM* mill) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items * L) return;
+  const size_t c = t / n_items, item = t % n_items;
+  const uint32_t lo = pair_off[item], hi = pair_off[item + 1];
+  const uint64_t first = (uint64_t)lo + (uint64_t)c * C;
+  int cnt = 0;
+  if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
+  const DevMultiAcc acc{P + first, Q + first, qref + first, lines, cnt, ws + t, ws_stride};
+  const Fp12 f = miller_loop_multi(acc);
+  st_gt_m(mill + item * L + c, f);
+}
+// chunking of a batch: C pairs per lane (even, so that lines are merged two by two), L lanes per item
+static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs, uint32_t* L, uint32_t* C) {
+  if (max_pairs < 1) max_pairs = 1;
+  const size_t simds = (size_t)ctx->n_cu * 4;
+  size_t c = 16;                                        // the shared squaring is then ~5 % of a lane's work
+  // small batches: more, shorter lanes until the chip is covered once (one wave per SIMD)
+  while (c > 2 && n_items * ((max_pairs + c - 1) / c) < simds * 64) c -= 2;
+  size_t l = (max_pairs + c - 1) / c;
+  c = (max_pairs + l - 1) / l;
+  if (c & 1) c++;
+  l = (max_pairs + c - 1) / c;
+  *L = (uint32_t)l;
+  *C = (uint32_t)c;
+}
+// Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
+static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, const PairLists& pl, const LineM* lines,
+                              const rhip_gt* mul_in, rhip_gt* out) {
+  uint32_t L, C;
+  choose_chunks(ctx, n_items, max_pairs, &L, &C);
+  const size_t lanes = n_items * L;
+  const size_t lanes_pad = (lanes + 63) / 64 * 64;
+  void* ws = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 3, lanes_pad * C * 12 * sizeof(uint4), &ws);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, lanes * sizeof(GtM));
+  if (rc) return rc;
+  GtM* mill = (GtM*)ctx->scratch;
+  KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, 64)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, (const G1M*)pl.P,
+          (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, lanes_pad, mill);
+  return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
+}
+
+// ------------------------------------------------------------------------------------------------ share generation
+// gen_shares_policy (src/utils/secretsharing/mod.rs:82-141) over a flattened policy: leaf `y` of a policy owns the
+// path entries [path_off[y], path_off[y+1]) from the root down; entry e says "child number x[e] (1-based) of gate
+// gate[e]".  Gate g has threshold k[g] (AND over n children: n, OR: 1) and consumed k[g] - 1 coefficient draws starting
+// at coef_off[g] of the item's draw list (DFS pre-order, the reference's draw order :128-134).  The share handed to
+// child x of a gate with secret s is  s + a_1 x + ... + a_(k-1) x^(k-1)  (:135-138, `polynomial` :215-221).
+struct TreeTables {
+  const uint32_t* path_off;     // [leaves + 1]
+  const uint32_t* path_gate;    // gate index relative to the policy's first gate
+  const uint32_t* path_x;
+  const uint32_t* gate_k;       // [gates]
+  const uint32_t* gate_coef_off;
+};
+__device__ __noinline__ Fr share_of_leaf(const TreeTables& tt, uint32_t leaf /* global leaf row of the policy tables */, uint32_t gate0,
+                                         const rhip_fr* coef /* the item's draws */, Fr secret) {
+  Fr s = secret;
+  for (uint32_t e = tt.path_off[leaf]; e < tt.path_off[leaf + 1]; e++) {
+    const uint32_t g = gate0 + tt.path_gate[e];
+    const uint32_t k = tt.gate_k[g];
+    if (k <= 1) continue;                                   // OR: every child gets the secret
+    uint32_t xs[8] = {tt.path_x[e], 0, 0, 0, 0, 0, 0, 0};
+    const Fr x = to_mont<FrParams>(xs);
+    const rhip_fr* a = coef + tt.gate_coef_off[g];          // a_1 .. a_(k-1)
+    Fr acc = load_fr(a[k - 2].l);
+    for (int j = (int)k - 3; j >= 0; j--) acc = add(mul(acc, x), load_fr(a[j].l));
+    s = add(mul(acc, x), s);
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------ BSW CP-ABE
+struct rhip_bsw_pk {
+  rhip_ctx* ctx;
+  rhip_g1_table* g1;
+  rhip_g2_table* g2;
+  rhip_g1_table* h;
+  rhip_gt_table* e;
+};
+extern "C" void rhip_bsw_pk_destroy(rhip_bsw_pk* pk) {
+  if (!pk) return;
+  rhip_g1_table_destroy(pk->g1);
+  rhip_g2_table_destroy(pk->g2);
+  rhip_g1_table_destroy(pk->h);
+  rhip_gt_table_destroy(pk->e);
+  delete pk;
+}
+extern "C" int32_t rhip_bsw_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const rhip_g2* g2, const rhip_g1* h, const rhip_gt* e_gg_alpha,
+                                      rhip_bsw_pk** out) {
+  if (!ctx || !g1 || !g2 || !h || !e_gg_alpha || !out) return RHIP_ERR_ARG;
+  *out = nullptr;
+  rhip_bsw_pk* pk = new rhip_bsw_pk{ctx, nullptr, nullptr, nullptr, nullptr};
+  int32_t rc = rhip_g1_table_create(ctx, g1, &pk->g1);
+  if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->g1);
+  if (!rc) rc = rhip_g2_table_create(ctx, g2, &pk->g2);
+  if (!rc) rc = rhip_g2_table_add_w16(ctx, pk->g2);
+  if (!rc) rc = rhip_g1_table_create(ctx, h, &pk->h);
+  if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->h);
+  if (!rc) rc = rhip_gt_table_create(ctx, e_gg_alpha, &pk->e);
+  if (!rc) rc = rhip_gt_table_add_w16(ctx, pk->e);
+  if (rc) { rhip_bsw_pk_destroy(pk); return rc; }
+  *out = pk;
+  return RHIP_OK;
+}
+// one lane per (item, leaf): q_y and h(name_y) * q_y  (bsw/mod.rs:236-243: g1 * q_y, (g2 * h(name)) * q_y)
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_bsw_enc_scalars(size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                                                      const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, TreeTables tt,
+                                                                      const rhip_fr* leaf_hash, const rhip_fr* secret, const rhip_fr* coef,
+                                                                      const uint32_t* item_coef_off, rhip_fr* kq, rhip_fr* khq) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_leaves) return;
+  const size_t item = owner_of(item_leaf_off, n_items, t);
+  const uint32_t leaf = item_tree_leaf[item] + (uint32_t)(t - item_leaf_off[item]);
+  const Fr q = share_of_leaf(tt, leaf, item_tree_gate[item], coef + item_coef_off[item], load_fr(secret[item].l));
+  store_fr(kq[t].l, q);
+  store_fr(khq[t].l, mul(q, load_fr(leaf_hash[leaf].l)));
+}
+// out[i] = base^k[i] * m[i] from the 16-bit (or 8-bit) window table
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_pow_gt_mul(const GtM* tbl, int w16, size_t n, const rhip_fr* k, const rhip_gt* m, rhip_gt* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t kk[8];
+  ld_scalar(kk, k + i);
+  const Fp12 p = w16 ? table_pow_gt_w16(tbl, kk) : table_pow_gt(tbl, kk);
+  store_gt(out[i].l, fp12_mul(p, load_gt(m[i].l)));
+}
+extern "C" int32_t rhip_bsw_encrypt_batch(rhip_ctx* ctx, const rhip_bsw_pk* pk, size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                          const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, const uint32_t* path_off,
+                                          const uint32_t* path_gate, const uint32_t* path_x, const uint32_t* gate_k, const uint32_t* gate_coef_off,
+                                          const rhip_fr* leaf_hash, const rhip_fr* secret, const rhip_fr* coef, const uint32_t* item_coef_off,
+                                          const rhip_gt* msg, rhip_g1* c, rhip_gt* cp, rhip_g1* cy_g1, rhip_g2* cy_g2) {
+  NEED(ctx);
+  if (!pk) return RHIP_ERR_ARG;
+  if (!n_items) return RHIP_OK;
+  void* w = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 4, (total_leaves ? total_leaves : 1) * 2 * sizeof(rhip_fr), &w);
+  if (rc) return rc;
+  rhip_fr* kq = (rhip_fr*)w;
+  rhip_fr* khq = kq + total_leaves;
+  if (total_leaves) {
+    const TreeTables tt{path_off, path_gate, path_x, gate_k, gate_coef_off};
+    KLAUNCH(ctx, "k_bsw_enc_scalars", k_bsw_enc_scalars, dim3(blocks_for(total_leaves, 256)), dim3(256), 0, ctx->stream, n_items, total_leaves,
+            item_leaf_off, item_tree_leaf, item_tree_gate, tt, leaf_hash, secret, coef, item_coef_off, kq, khq);
+    rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, kq, cy_g1);
+    if (rc) return rc;
+    rc = rhip_g2_table_mul(ctx, pk->g2, total_leaves, khq, cy_g2);
+    if (rc) return rc;
+  }
+  rc = rhip_g1_table_mul(ctx, pk->h, n_items, secret, c);
+  if (rc) return rc;
+  const rhip_gt_table* et = pk->e;
+  KLAUNCH(ctx, "k_table_pow_gt_mul", k_table_pow_gt_mul, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream,
+          (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0, n_items, secret, msg, cp);
+  return RHIP_OK;
+}
+
+// decrypt: the pairs of item i are [pair_off[i], pair_off[i+1]) = 2 m_i + 1 of them; pair 2s / 2s+1 belong to selected
+// leaf s (entry e = sel_start[i] + s of the selection tables), the last one is e(-c, d):
+//   2s   : P =  z_e * Cy.g1,  Q = Dj.g2     (key side: prepared lines when the key was prepared)
+//   2s+1 : P = -z_e * Dj.g1,  Q = Cy.g2
+//   2m   : P = -c,            Q = d
+// (msg = c_p * FE(prod), bsw/mod.rs:282-308 restated in SURVEY.md Appendix B.4)
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+                                                                    const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
+                                                                    const rhip_g1* ct_c, const rhip_g1* ct_cy_g1, const rhip_g2* ct_cy_g2,
+                                                                    const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
+                                                                    const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
+                                                                    uint32_t lines_d_base, int prepared, const uint8_t* line_inf, G1M* P, G2M* Q,
+                                                                    uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < total_pairs;
+  if (!active) t = total_pairs - 1;
+  const size_t item = owner_of(pair_off, n_items, t);
+  const uint32_t j = (uint32_t)(t - pair_off[item]);
+  const uint32_t m = (pair_off[item + 1] - pair_off[item] - 1) >> 1;
+  const uint32_t sk = sk_idx[item];
+  G1Aff base;
+  uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  bool negate;
+  const rhip_g2* qsrc;
+  uint32_t line = RHIP_Q_WALK;
+  if (j == 2 * m) {
+    base = load_g1(ct_c[item].l);
+    negate = true;
+    qsrc = sk_d + sk;
+    if (prepared) line = lines_d_base + sk;
+  } else {
+    const uint32_t e = sel_start[item] + (j >> 1);
+    const uint32_t leaf = ct_leaf_off[item] + sel_ct_leaf[e];
+    const uint32_t attr = sk_attr_off[sk] + sel_sk_attr[e];
+    ld_scalar(k, sel_coeff + e);
+    if ((j & 1) == 0) {
+      base = load_g1(ct_cy_g1[leaf].l);
+      negate = false;
+      qsrc = sk_dj_g2 + attr;
+      if (prepared) line = attr;
+    } else {
+      base = load_g1(sk_dj_g1[attr].l);
+      negate = true;
+      qsrc = ct_cy_g2 + leaf;
+    }
+  }
+  bool p_inf;
+  scale_and_store(lds, active, base, k, negate, P + t, &p_inf);
+  if (!active) return;
+  if (line != RHIP_Q_WALK) {
+    qref[t] = (p_inf || line_inf[line]) ? RHIP_Q_SKIP : line;
+  } else {
+    const G2Aff q = load_g2(qsrc->l);
+    const bool skip = p_inf || aff_is_inf(q);
+    if (!skip) st_g2_q(Q + t, q);
+    qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+  }
+}
+// prepared keys: lines of every key's d_j.g2 (blocks 0 .. total_attrs-1, the index space of dev_sk_dj_g2) and d (blocks
+// total_attrs + key)
+struct rhip_bsw_sk_lines {
+  rhip_g2_lines* l;
+  size_t total_attrs;
+  size_t n_sk;
+};
+extern "C" void rhip_bsw_sk_lines_destroy(rhip_bsw_sk_lines* p) {
+  if (!p) return;
+  rhip_g2_lines_destroy(p->l);
+  delete p;
+}
+extern "C" int32_t rhip_bsw_sk_prepare(rhip_ctx* ctx, size_t n_sk, size_t total_attrs, const rhip_g2* sk_d, const rhip_g2* sk_dj_g2,
+                                       rhip_bsw_sk_lines** out) {
+  NEED(ctx);
+  if (!out || !n_sk || !sk_d || (total_attrs && !sk_dj_g2)) return RHIP_ERR_ARG;
+  *out = nullptr;
+  rhip_g2* cat = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&cat, (total_attrs + n_sk) * sizeof(rhip_g2)));
+  hipError_t e = hipSuccess;
+  if (total_attrs) e = hipMemcpyAsync(cat, sk_dj_g2, total_attrs * sizeof(rhip_g2), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(cat + total_attrs, sk_d, n_sk * sizeof(rhip_g2), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(cat); return fail(ctx, e, "rhip_bsw_sk_prepare: copy"); }
+  rhip_g2_lines* l = nullptr;
+  const int32_t rc = rhip_g2_lines_prepare(ctx, total_attrs + n_sk, cat, &l);      // synchronises the stream
+  (void)hipFree(cat);
+  if (rc) return rc;
+  *out = new rhip_bsw_sk_lines{l, total_attrs, n_sk};
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, const uint32_t* pair_off,
+                                          const uint32_t* sel_start, const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr,
+                                          const rhip_fr* sel_coeff, const rhip_g1* ct_c, const rhip_gt* ct_cp, const rhip_g1* ct_cy_g1,
+                                          const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
+                                          const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
+                                          const rhip_bsw_sk_lines* sk_lines, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (!total_pairs || !pair_off) return RHIP_ERR_ARG;
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
+          sk_attr_off, sk_idx, (uint32_t)(sk_lines ? sk_lines->total_attrs : 0), sk_lines ? 1 : 0,
+          (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
+}

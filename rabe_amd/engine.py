@@ -333,3 +333,85 @@ def ac17_decrypt_prepared_dev(eng, n_items, dct_c0, dct_c, dct_row_off, dct_cp, 
     eng._check(eng.lib.rhip_ac17_cp_decrypt_batch_prepared(eng.ctx, _sz(n_items), dct_c0.ptr, dct_c.ptr, dct_row_off.ptr, dct_cp.ptr,
                                                            sk_lines.h, dsk_k.ptr, dsk_row_off.ptr, dsk_kp.ptr, dsk_idx.ptr,
                                                            dct_sel.ptr, dct_sel_off.ptr, dsk_sel.ptr, dsk_sel_off.ptr, dout.ptr))
+
+
+# ---------------------------------------------------------------------- Level B: bsw / lsw / aw11 (device-buffer level)
+def _p(x):
+    """DevBuf / handle / None -> pointer argument"""
+    if x is None:
+        return ctypes.c_void_p(0)
+    if hasattr(x, "ptr"):
+        return x.ptr
+    if hasattr(x, "h"):
+        return x.h
+    return x
+
+
+class DevTreeTables:
+    """hostprep.TreeTables uploaded once (flattened policy trees: include/rabe_hip.h)."""
+
+    def __init__(self, eng, tt):
+        self.tt = tt
+        self.path_off = eng.upload_u32(tt.path_off)
+        self.path_gate = eng.upload_u32(tt.path_gate or [0])
+        self.path_x = eng.upload_u32(tt.path_x or [0])
+        self.gate_k = eng.upload_u32(tt.gate_k or [0])
+        self.gate_coef_off = eng.upload_u32(tt.gate_coef_off or [0])
+        self.leaf_hash = eng.upload(b"".join(fr_bytes(h) for h in tt.leaf_hash))
+
+
+class G2Lines:
+    """Prepared Miller-loop lines of n G2 points (rhip_g2_lines_prepare)."""
+
+    def __init__(self, eng, n, dq):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_g2_lines_prepare(eng.ctx, _sz(n), dq.ptr, ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_g2_lines_destroy(self.h)
+            self.h = None
+
+
+class BswPk:
+    """Device tables of a CpAbePublicKey (g1, g2, h, e_gg_alpha)."""
+
+    def __init__(self, eng, g1, g2, h, e_gg_alpha):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_bsw_pk_create(eng.ctx, bytes(g1), bytes(g2), bytes(h), bytes(e_gg_alpha), ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_bsw_pk_destroy(self.h)
+            self.h = None
+
+
+class BswSkLines:
+    def __init__(self, eng, n_sk, total_attrs, dsk_d, dsk_dj_g2):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_bsw_sk_prepare(eng.ctx, _sz(n_sk), _sz(total_attrs), dsk_d.ptr, dsk_dj_g2.ptr, ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_bsw_sk_lines_destroy(self.h)
+            self.h = None
+
+
+def bsw_encrypt_dev(eng, pk, n_items, total_leaves, d_item_leaf_off, d_item_tree_leaf, d_item_tree_gate, dtt, d_secret, d_coef,
+                    d_item_coef_off, d_msg, d_c, d_cp, d_cy_g1, d_cy_g2):
+    eng._check(eng.lib.rhip_bsw_encrypt_batch(eng.ctx, pk.h, _sz(n_items), _sz(total_leaves), _p(d_item_leaf_off), _p(d_item_tree_leaf),
+                                              _p(d_item_tree_gate), _p(dtt.path_off), _p(dtt.path_gate), _p(dtt.path_x), _p(dtt.gate_k),
+                                              _p(dtt.gate_coef_off), _p(dtt.leaf_hash), _p(d_secret), _p(d_coef), _p(d_item_coef_off),
+                                              _p(d_msg), _p(d_c), _p(d_cp), _p(d_cy_g1), _p(d_cy_g2)))
+
+
+def bsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, d_pair_off, d_sel_start, d_sel_ct_leaf, d_sel_sk_attr, d_sel_coeff,
+                    d_ct_c, d_ct_cp, d_ct_cy_g1, d_ct_cy_g2, d_ct_leaf_off, d_sk_d, d_sk_dj_g1, d_sk_dj_g2, d_sk_attr_off, d_sk_idx,
+                    sk_lines, d_out):
+    eng._check(eng.lib.rhip_bsw_decrypt_batch(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _p(d_pair_off), _p(d_sel_start),
+                                              _p(d_sel_ct_leaf), _p(d_sel_sk_attr), _p(d_sel_coeff), _p(d_ct_c), _p(d_ct_cp), _p(d_ct_cy_g1),
+                                              _p(d_ct_cy_g2), _p(d_ct_leaf_off), _p(d_sk_d), _p(d_sk_dj_g1), _p(d_sk_dj_g2),
+                                              _p(d_sk_attr_off), _p(d_sk_idx), _p(sk_lines), _p(d_out)))

@@ -149,3 +149,113 @@ def random_binary_tree(names, rnd, p_and=0.5):
     k = rnd.randrange(1, len(names))
     op = "and" if rnd.random() < p_and else "or"
     return (op, [random_binary_tree(names[:k], rnd, p_and), random_binary_tree(names[k:], rnd, p_and)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Flattened policy trees for the device-level bsw / lsw / aw11 paths (include/rabe_hip.h, "Flattened policy trees"):
+# what gen_shares_policy / calc_coefficients / calc_pruned (src/utils/secretsharing/mod.rs:9-199) walk, as index tables.
+def flatten_tree(tree):
+    """Leaves in DFS order (= the order gen_shares_policy emits shares), each with its root-to-leaf path of
+    (gate, 1-based child number); gates in DFS pre-order with their threshold and the offset of their k-1 polynomial
+    coefficients in the per-item draw list (the reference's draw order, secretsharing/mod.rs:128-134)."""
+    names, path_off, path_gate, path_x, gate_k, gate_coef_off = [], [0], [], [], [], []
+    n_coef = [0]
+
+    def walk(node, path):
+        if node[0] == "leaf":
+            names.append(node[1])
+            for g, x in path:
+                path_gate.append(g)
+                path_x.append(x)
+            path_off.append(len(path_gate))
+            return
+        ch = node[1]
+        if len(ch) < 2:
+            raise ValueError("Invalid policy (%s with just a single child)" % node[0].upper())
+        g = len(gate_k)
+        k = len(ch) if node[0] == "and" else 1
+        gate_k.append(k)
+        gate_coef_off.append(n_coef[0])
+        n_coef[0] += k - 1
+        for i, c in enumerate(ch):
+            walk(c, path + [(g, i + 1)])
+
+    walk(tree, [])
+    return {"names": names, "path_off": path_off, "path_gate": path_gate, "path_x": path_x, "gate_k": gate_k,
+            "gate_coef_off": gate_coef_off, "n_coef": n_coef[0]}
+
+
+def lagrange_at_zero(k):
+    """recover_coefficients over the points 1..k (secretsharing/mod.rs:60-72)"""
+    out = []
+    for i in range(1, k + 1):
+        res = 1
+        for j in range(1, k + 1):
+            if i != j:
+                res = res * ((0 - j) * pow(i - j, R_ORDER - 2, R_ORDER)) % R_ORDER
+        out.append(res % R_ORDER)
+    return out
+
+
+def leaf_coefficients(tree, coeff=1):
+    """calc_coefficients (secretsharing/mod.rs:9-57): the reconstruction coefficient of every leaf, DFS order"""
+    if tree[0] == "leaf":
+        return [coeff % R_ORDER]
+    ch = tree[1]
+    lag = lagrange_at_zero(len(ch)) if tree[0] == "and" else [1] * len(ch)
+    out = []
+    for i, c in enumerate(ch):
+        out += leaf_coefficients(c, coeff * lag[i] % R_ORDER)
+    return out
+
+
+def pruned_leaf_indices(attrs, tree):
+    """calc_pruned (secretsharing/mod.rs:143-199) by DFS leaf index: all children of AND, the first satisfying child of OR"""
+    counter = [0]
+
+    def walk(node):
+        if node[0] == "leaf":
+            i = counter[0]
+            counter[0] += 1
+            return (True, [i]) if node[1] in attrs else (False, [])
+        if node[0] == "and":
+            ok, acc = True, []
+            for c in node[1]:
+                f, l = walk(c)
+                ok = ok and f
+                if ok:
+                    acc += l
+            return (ok, acc if ok else [])
+        res = None
+        for c in node[1]:
+            f, l = walk(c)                  # later children are still walked: the leaf numbering must advance
+            if f and res is None:
+                res = l
+        return (True, res) if res is not None else (False, [])
+
+    return walk(tree)
+
+
+class TreeTables:
+    """The flattened tables of several distinct policies, concatenated (what rhip_bsw_encrypt_batch & co. take)."""
+
+    def __init__(self, trees, hash_leaf=lambda name: h_fr(name)):
+        self.flat = [flatten_tree(t) for t in trees]
+        self.first_leaf, self.first_gate = [], []
+        self.path_off, self.path_gate, self.path_x, self.gate_k, self.gate_coef_off, self.leaf_hash = [0], [], [], [], [], []
+        for f in self.flat:
+            self.first_leaf.append(len(self.leaf_hash))
+            self.first_gate.append(len(self.gate_k))
+            base = len(self.path_gate)
+            self.path_off += [base + o for o in f["path_off"][1:]]
+            self.path_gate += f["path_gate"]
+            self.path_x += f["path_x"]
+            self.gate_k += f["gate_k"]
+            self.gate_coef_off += f["gate_coef_off"]
+            self.leaf_hash += [hash_leaf(n) for n in f["names"]]
+
+    def n_leaves(self, p):
+        return len(self.flat[p]["names"])
+
+    def n_coef(self, p):
+        return self.flat[p]["n_coef"]

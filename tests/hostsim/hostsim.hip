@@ -146,6 +146,71 @@ void hs_pairing_pair_parked(const uint32_t* pa, const uint32_t* qa, const uint32
   store_gt(out, final_exponentiation(miller_loop_pair_parked(pk, jac_is_inf(JA) || aff_is_inf(QA), HostLineLoad{lines},
                                                              jac_is_inf(JB) || aff_is_inf(QB))));
 }
+
+void hs_g1_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_naf(load_g1(p), k))); }
+void hs_g2_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g2(out, jac_to_aff(jac_mul_naf(load_g2(p), k))); }
+}
+// host accessors of the multi-pairing loop / the shared-doubling MSM (the device ones live in engine_jobs.hip)
+struct HostMultiAcc {
+  int n;
+  const int* kinds;
+  const G1Aff* P;
+  const G2Aff* Q;
+  const LineCoeffs* lines;     // [n][RB_MILLER_LINES]
+  G2Hom* T;
+  int count() const { return n; }
+  int kind(int j) const { return kinds[j]; }
+  MillerP p(int j) const { return miller_p_from_aff(P[j]); }
+  G2Aff q(int j) const { return Q[j]; }
+  LineCoeffs line(int j, int k) const { return lines[j * RB_MILLER_LINES + k]; }
+  G2Hom ld_t(int j) const { return T[j]; }
+  void st_t(int j, const G2Hom& t) const { T[j] = t; }
+};
+template <class F>
+struct HostTerms {
+  int n;
+  const Aff<F>* b;
+  const uint32_t* pos;
+  const uint32_t* neg;
+  int count() const { return n; }
+  Aff<F> base(int j) const { return b[j]; }
+  uint32_t pos_word(int j, int w) const { return pos[8 * j + w]; }
+  uint32_t neg_word(int j, int w) const { return neg[8 * j + w]; }
+};
+extern "C" {
+// FE( miller_loop_multi ) over n pairs; kinds[j]: 0 walk, 1 prepared lines, 2 skip.  p: n x 16 words, q: n x 32 words.
+void hs_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff* P = new G1Aff[n];
+  G2Aff* Q = new G2Aff[n];
+  LineCoeffs* lines = new LineCoeffs[(size_t)n * RB_MILLER_LINES];
+  G2Hom* T = new G2Hom[n];
+  int* kk = new int[n];
+  for (int j = 0; j < n; j++) {
+    P[j] = load_g1(p + 16 * j);
+    Q[j] = load_g2(q + 32 * j);
+    kk[j] = kinds[j];
+    if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
+    if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
+  }
+  store_gt(out, final_exponentiation(miller_loop_multi(HostMultiAcc{n, kk, P, Q, lines, T})));
+  delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
+}
+void hs_g1_msm(int n, const uint32_t* p, const uint32_t* k, uint32_t* out) {
+  G1Aff* P = new G1Aff[n];
+  uint32_t* pos = new uint32_t[8 * n];
+  uint32_t* neg = new uint32_t[8 * n];
+  for (int j = 0; j < n; j++) { P[j] = load_g1(p + 16 * j); naf_masks(k + 8 * j, pos + 8 * j, neg + 8 * j); }
+  store_g1(out, jac_to_aff(jac_msm_naf<Fp>(HostTerms<Fp>{n, P, pos, neg})));
+  delete[] P; delete[] pos; delete[] neg;
+}
+void hs_g2_msm(int n, const uint32_t* p, const uint32_t* k, uint32_t* out) {
+  G2Aff* P = new G2Aff[n];
+  uint32_t* pos = new uint32_t[8 * n];
+  uint32_t* neg = new uint32_t[8 * n];
+  for (int j = 0; j < n; j++) { P[j] = load_g2(p + 32 * j); naf_masks(k + 8 * j, pos + 8 * j, neg + 8 * j); }
+  store_g2(out, jac_to_aff(jac_msm_naf<Fp2>(HostTerms<Fp2>{n, P, pos, neg})));
+  delete[] P; delete[] pos; delete[] neg;
+}
 void hs_gt_pow(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_binary(load_gt(a), k)); }
 void hs_gt_pow_window(const uint32_t* a, const uint32_t* k, uint32_t* out) { store_gt(out, gt_pow_window(load_gt(a), k)); }
 

@@ -221,3 +221,59 @@ def test_gt_pow_signed_window_equals_binary():
         assert call("hs_gt_pow_window", f, kb, out=384) == call("hs_gt_pow", f, kb, out=384)
     k = RND.randrange(bn.R)
     assert call("hs_gt_pow_window", f, le(k), out=384) == bn.gt_to_le(bn.gt_pow(bn.gt_from_le(f), k))
+
+
+def test_naf_scalar_multiplication_equals_oracle():
+    """jac_mul_naf (curve.h): the engine's variable-base multiplication over the NAF of k"""
+    p = bn.g1_mul(bn.G1_GEN, RND.randrange(1, bn.R))
+    q = bn.g2_mul(bn.G2_GEN, RND.randrange(1, bn.R))
+    for k in [0, 1, 2, 3, 5, 7, 0xFFFFFFFF, 1 << 32, (1 << 64) - 1, bn.R - 1, bn.R - 2, (bn.R - 1) // 2, int("a" * 63, 16) % bn.R,
+              int("5" * 63, 16) % bn.R] + [RND.randrange(bn.R) for _ in range(6)]:
+        assert call("hs_g1_mul_naf", bn.g1_to_le(p), le(k), out=64) == bn.g1_to_le(bn.g1_mul(p, k)), hex(k)
+    for k in [0, 1, 3, bn.R - 1, RND.randrange(bn.R), RND.randrange(bn.R)]:
+        assert call("hs_g2_mul_naf", bn.g2_to_le(q), le(k), out=128) == bn.g2_to_le(bn.g2_mul(q, k)), hex(k)
+    assert call("hs_g1_mul_naf", bytes(64), le(5), out=64) == bytes(64)
+
+
+def test_shared_doubling_msm_equals_sum_of_products():
+    """jac_msm_naf (curve.h): Straus over the NAFs -- lsw's sum of c_y * D1_y, aw11's sum of c_x * C3_x"""
+    n = 7
+    ps = [bn.g1_mul(bn.G1_GEN, RND.randrange(1, bn.R)) for _ in range(n)]
+    ks = [RND.randrange(bn.R) for _ in range(n - 3)] + [0, 1, bn.R - 1]
+    ps[2] = ps[1]                                   # equal bases: the doubling case inside the mixed addition
+    ks[2] = ks[1]
+    want = None
+    for p, k in zip(ps, ks):
+        want = bn.g1_add(want, bn.g1_mul(p, k)) if want is not None else bn.g1_mul(p, k)
+    o = buf(64)
+    HS.hs_g1_msm(n, b2c(b"".join(bn.g1_to_le(p) for p in ps)), b2c(b"".join(le(k) for k in ks)), o)
+    assert bytes(o) == bn.g1_to_le(want)
+    # cancelling terms: k P + (r - k) P = infinity
+    HS.hs_g1_msm(2, b2c(bn.g1_to_le(ps[0]) * 2), b2c(le(ks[0]) + le(bn.R - ks[0])), o)
+    assert bytes(o) == bytes(64)
+    qs = [bn.g2_mul(bn.G2_GEN, RND.randrange(1, bn.R)) for _ in range(3)]
+    k2 = [RND.randrange(bn.R) for _ in range(3)]
+    want = None
+    for q, k in zip(qs, k2):
+        want = bn.g2_add(want, bn.g2_mul(q, k)) if want is not None else bn.g2_mul(q, k)
+    o2 = buf(128)
+    HS.hs_g2_msm(3, b2c(b"".join(bn.g2_to_le(q) for q in qs)), b2c(b"".join(le(k) for k in k2)), o2)
+    assert bytes(o2) == bn.g2_to_le(want)
+
+
+@pytest.mark.parametrize("n,kinds", [(1, [0]), (1, [1]), (2, [1, 0]), (3, [0, 0, 1]), (5, [1, 0, 1, 0, 1]), (4, [0, 2, 1, 0])])
+def test_multi_pairing_on_one_accumulator(n, kinds):
+    """miller_loop_multi (pairing.h): n pairings on one accumulator, walking / prepared / skipped pairs mixed"""
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    ks = [(RND.randrange(1, bn.R), RND.randrange(1, bn.R)) for _ in range(n)]
+    p = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, a)) for a, _ in ks)
+    q = b"".join(bn.g2_to_le(bn.g2_mul(bn.G2_GEN, b)) for _, b in ks)
+    exp = sum(a * b for (a, b), kd in zip(ks, kinds) if kd != 2) % bn.R
+    o = buf(384)
+    HS.hs_pairing_multi(n, (ctypes.c_int * n)(*kinds), b2c(p), b2c(q), o)
+    assert bytes(o) == bn.gt_to_le(bn.gt_pow(e, exp))
+    if n >= 2:      # an argument at infinity contributes 1
+        p2 = bytes(64) + p[64:]
+        HS.hs_pairing_multi(n, (ctypes.c_int * n)(*kinds), b2c(p2), b2c(q), o)
+        exp2 = sum(a * b for i, ((a, b), kd) in enumerate(zip(ks, kinds)) if kd != 2 and i != 0) % bn.R
+        assert bytes(o) == bn.gt_to_le(bn.gt_pow(e, exp2))
