@@ -44,17 +44,11 @@ for _i, _a in enumerate(sys.argv):
     elif _a.startswith("--hw-queues="):
         os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
 
-G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
-G2_GEN = b"".join(int(v).to_bytes(32, "little") for v in (
-    10857046999023057135944570762232829481370756359578518086990519993285655852781,
-    11559732032986387107991004021392285783925812861821192530917403151452391805634,
-    8495653923123431417604973247489272438418190587263600148770280649306958101930,
-    4082367875863433681332203403145435568316851327593401208105741076214120093531))
+from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, same_on_all_ranks, split_steps, timed_regions  # noqa: E402
 
 # Algorithmic work, in Fp multiplications (1 Fp mul = 136 32x32 multiply-adds: 8-limb CIOS), per lane:
 #   SURVEY.md 8d constants (the "algorithmic minimum" the roofline is priced against) and the
 #   instrumented counts of this engine's own code (tests/count_muls.py).
-MAC_PER_FPMUL = 136
 SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
 SURVEY_MIXED_ADD_FPMUL = 11
 IMPL_MILLER_FPMUL = 8983            # tests/count_muls.py: miller_loop (NAF chain) with Jacobian P
@@ -71,6 +65,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="items per step per GPU (0 = the config's: 4096 / 4096 / 2048 / 1024)")
     ap.add_argument("--attrs", type=int, default=0, help="attributes (0 = the config's: 50 / 100 / 200 / 200)")
     ap.add_argument("--policies", type=int, default=16)
+    ap.add_argument("--tree", default="flat", choices=["flat", "nested", "mixed"],
+                    help="configs 3-5: shape of the access tree (flat n-ary AND / balanced binary ANDs / AND over two-leaf ORs)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--group", type=int, default=16, help="steps submitted as ONE launch set (their batches are contiguous in HBM)")
     ap.add_argument("--inflight", type=int, default=2, help="groups in flight on separate HIP streams (covers launch tails)")
@@ -121,34 +117,6 @@ def spawn_ranks(args):
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     sys.exit(rc)
-
-
-class ExtBuf:
-    """A device buffer owned by a torch tensor (so that torch.distributed can gather it), seen as an engine buffer."""
-
-    def __init__(self, torch_mod, nbytes, device):
-        self.t = torch_mod.empty(max(int(nbytes), 4), dtype=torch_mod.uint8, device=device)
-        self.ptr = ctypes.c_void_p(self.t.data_ptr())
-        self.nbytes = int(nbytes)
-
-
-def split_steps(k, gmax):
-    """K steps -> group sizes (nearly equal, each <= gmax, as few groups as possible)."""
-    n = (k + gmax - 1) // gmax
-    base, extra = divmod(k, n)
-    return [base + (1 if i < extra else 0) for i in range(n)]
-
-
-def same_on_all_ranks(flag):
-    """rank 0's decision, everywhere (loop control of the repeated timed regions)"""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return bool(flag)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
-    dist.broadcast(t, src=0)
-    return bool(t.item())
 
 
 def main():
@@ -339,18 +307,7 @@ def main():
             run_steps()
     sync_all()
     torch.cuda.synchronize()
-    regions = []
-    while True:
-        barrier()
-        t0 = time.perf_counter()
-        run_steps()
-        sync_all()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        barrier()
-        regions.append(shard.max_over_ranks(t1 - t0))
-        if not same_on_all_ranks(sum(regions) < args.min_time and len(regions) < 200):
-            break
+    regions = timed_regions(run_steps, sync_all, args.min_time)
     elapsed = sum(regions) / len(regions)
 
     # ---------------------------------------------------------------- size-independent correctness property on the FULL batch:
@@ -388,9 +345,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fp/Fr Montgomery, 8x32)",
         "data": "synthetic", "roundtrip_bit_exact": ok,
-        "timed_regions": {"count": len(regions), "steps_each": args.steps, "ms_min": round(1e3 * min(regions), 3),
-                          "ms_mean": round(1e3 * elapsed, 3), "ms_max": round(1e3 * max(regions), 3),
-                          "note": "every region times exactly --steps steps between barrier + synchronize; repeated until --min-time s are covered; value uses the mean"},
+        "timed_regions": regions_summary(regions, args.steps),
         "config": {"workload": "AC17 CP-ABE, %d-attribute random binary AND/OR MSP policies (%d distinct), batch %d encrypt+decrypt per GPU"
                                % (args.attrs, args.policies, B),
                    "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": rows_per_batch // B,

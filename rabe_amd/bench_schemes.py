@@ -1,0 +1,327 @@
+"""bench.py --config 3 / 4 / 5: BASELINE.json configs[2..4] on the device-resident Level B paths.
+
+  3  BSW CP-ABE, 100-attribute access tree, batch 4096 encrypt+decrypt               (bsw/mod.rs:217-318)
+  4  LSW KP-ABE keygen+decrypt, 200 attributes, batch 16384 over 8 GPUs (2048 / GPU)   (lsw/mod.rs:121-290)
+  5  AW11 multi-authority, 10 authorities x 20 attributes, batch 8192 over 8 GPUs      (aw11/mod.rs:241-366)
+
+Same contract and JSON schema as config 2 (bench.py): inputs resident in HBM (key material, flattened policy tables,
+selection tables, per-item explicit randomness), one step = one pass over one batch, steps submitted in groups that are
+contiguous in HBM, exactly-K-step timed regions, decrypt(encrypt(msg)) == msg checked bit for bit on every item."""
+import json
+import os
+import random
+import time
+
+from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, split_steps, timed_regions
+
+
+def run(args, world, rank, local_rank):
+    cls = {3: BswBench}.get(args.config)
+    if cls is None:
+        raise SystemExit("bench.py --config %d: the device-resident path of this scheme is not built yet" % args.config)
+    return SchemeRunner(cls, args, world, rank, local_rank).run()
+
+
+class SchemeRunner:
+    def __init__(self, cls, args, world, rank, local_rank):
+        import torch
+        from rabe_amd import Engine
+        self.torch = torch
+        self.args, self.world, self.rank, self.local_rank = args, world, rank, local_rank
+        self.eng = Engine(local_rank)
+        self.n_cu, self.dev_name = self.eng.device_info()
+        self.stream = torch.cuda.Stream(device=local_rank)
+        self.eng.set_stream(self.stream.cuda_stream)
+        self.dev = torch.device("cuda", local_rank)
+        self.bench = cls(self)
+
+    def new_lane(self):
+        from rabe_amd import Engine
+        e2 = Engine(self.local_rank)
+        st = self.torch.cuda.Stream(device=self.local_rank)
+        e2.set_stream(st.cuda_stream)
+        self._streams.append(st)
+        return e2
+
+    def run(self):
+        import torch
+        import torch.distributed as dist
+        args, world, rank, eng, b = self.args, self.world, self.rank, self.eng, self.bench
+        sizes = split_steps(args.steps, max(1, min(b.default_group if args.group == 16 else args.group, args.steps)))
+        G = max(sizes)
+        S = max(1, min(args.inflight, len(sizes)))
+        self._streams = [self.stream]
+        lanes = [eng] + [self.new_lane() for _ in range(S - 1)]
+        b.prepare(G, lanes)
+        launch_no = [0]
+
+        def run_steps():
+            launch_no[0] = 0
+            for g_ in sizes:
+                b.submit(launch_no[0] % S, g_)
+                launch_no[0] += 1
+
+        def sync_all():
+            for e_ in lanes:
+                e_.sync()
+
+        if args.warmup:
+            for _ in range((args.warmup + args.steps - 1) // args.steps):
+                run_steps()
+        sync_all()
+        torch.cuda.synchronize()
+        regions = timed_regions(run_steps, sync_all, args.min_time)
+        elapsed = sum(regions) / len(regions)
+        used = {}
+        for j, g_ in enumerate(sizes):
+            used[j % S] = g_
+        ok = all(b.check(i, g_) for i, g_ in used.items())
+        if world > 1:
+            f = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            ok = bool(f.item())
+        B = b.B
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": b.metric, "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (BN254 Fp/Fr Montgomery, 8x32)", "data": "synthetic", "roundtrip_bit_exact": ok,
+            "timed_regions": regions_summary(regions, args.steps),
+            "config": dict(b.describe(), batch_per_gpu=B, steps_per_launch_set=sizes, launch_sets_in_flight=S,
+                           hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default"),
+                           parallelism="batch-sharded x%d (no data-path collective)" % world, device=self.dev_name),
+        }
+        if rank == 0:
+            eng.timing(True)
+            eng.timing_read()
+            for _ in range(2):
+                b.submit(0, G)
+                eng.sync()
+            tim = eng.timing_read()
+            eng.timing(False)
+            per_kernel = {k: ms / cnt * b.launches_per_submit.get(k, 1) for k, (ms, cnt) in tim.items()}
+            dom = max(per_kernel, key=lambda k: per_kernel[k])
+            ms_c, ops_c = eng.calibrate(0, 20000)
+            peak = ops_c / (ms_c * 1e-3) / 1e12
+            alg = b.algorithmic_fpmul_per_item()          # {kernel: SURVEY 8d Fp-mul per item carried by that kernel}
+            macs = alg.get(dom, 0) * MAC_PER_FPMUL * G * B
+            achieved = macs / (per_kernel[dom] * 1e-3) / 1e12 if per_kernel[dom] > 0 else 0.0
+            traffic, tsrc = pmc_traffic(dom, args.config)
+            result["roofline"] = {
+                "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom, "kernel_ms": round(per_kernel[dom], 4),
+                "items_per_launch": G * B, "steps_per_launch": G, "kernel_ms_per_step": round(per_kernel[dom] / G, 4),
+                "achieved": round(achieved, 4), "peak": round(peak, 3), "unit": "TMAC32/s", "frac": round(achieved / peak, 4) if peak else None,
+                "work": "SURVEY 8d algorithmic Fp-muls per item carried by this kernel (%.3g) x 136 MAC32 x items = %.3e MAC32 per launch" % (alg.get(dom, 0), macs),
+                "whole_step_frac": round(b.survey_fpmul_per_item * MAC_PER_FPMUL * B / (elapsed / args.steps) / 1e12 / peak, 4) if peak else None,
+                "whole_step_work": "SURVEY 8d: %.3g M Fp-mul per op" % (b.survey_fpmul_per_item / 1e6),
+                "traffic": traffic, "traffic_source": tsrc,
+                "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
+                "hbm": {"algorithmic_bytes_per_step": b.algorithmic_bytes_per_step(),
+                        "GBps_at_measured_step": round(b.algorithmic_bytes_per_step() / (elapsed / args.steps) / 1e9, 3), "peak_GBps": 8000},
+                "kernels_ms": {k: round(v, 4) for k, v in sorted(per_kernel.items(), key=lambda x: -x[1])},
+                "kernels_ms_sum_per_step": round(sum(per_kernel.values()) / G, 4),
+                "dominant_by": "duration of the kernel's launches for one full group, HIP events on the launch stream, nothing else running",
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    result["cpu_baseline"] = b.cpu_baseline()
+                except Exception as ex:
+                    result["cpu_baseline"] = {"error": repr(ex)}
+            print(json.dumps(result), flush=True)
+        b.close()
+        for e_ in lanes[1:]:
+            e_.close()
+        eng.close()
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, config):
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in reversed(sorted(glob.glob(os.path.join(root, "profiles", "*_cfg%d_pmc_traffic.txt" % config)))):
+        tot, seen = 0.0, 0
+        for line in open(f):
+            m = re.match(r"(FETCH_SIZE|WRITE_SIZE) (\S+) per launch: ([0-9.]+) KB-units", line)
+            if m and m.group(2) == kernel:
+                tot += float(m.group(3)) * 1024.0
+                seen += 1
+        if seen == 2:
+            return round(tot), "profiles/" + os.path.basename(f)
+    return None, None
+
+
+# ====================================================================================================================== BSW
+class BswBench:
+    """config 3: bsw::encrypt + bsw::decrypt, n-leaf access tree, one public key, one secret key with all attributes."""
+    metric = "ABE ops/sec (BSW CP-ABE encrypt+decrypt)"
+    default_group = 2
+    survey_fpmul_per_item = 2.3e6               # SURVEY.md 8d, config 3 restructured work
+    launches_per_submit = {"k_table_mul_g1": 2}
+
+    def __init__(self, r):
+        from rabe_amd import engine as E
+        from rabe_amd import hostprep as hp
+        self.r, self.E, self.hp = r, E, hp
+        args, eng = r.args, r.eng
+        self.B = args.batch or 4096
+        self.n_attr = args.attrs or 100
+        R, le = hp.R_ORDER, hp.fr_le
+        krnd = random.Random(args.seed * 1000003 + 3)
+
+        def kfr():
+            return krnd.randrange(1, R)
+        # ---- setup (bsw/mod.rs:92-114) and keygen (:125-152) through Level E / table kernels (untimed input generation)
+        g1 = eng.g1_mul([G1_GEN], [le(kfr())])[0]
+        g2 = eng.g2_mul([G2_GEN], [le(kfr())])[0]
+        beta, alpha = kfr(), kfr()
+        h = eng.g1_mul([g1], [le(beta)])[0]
+        e_gg_alpha = eng.pairing([g1], [eng.g2_mul([g2], [le(alpha)])[0]])[0]
+        eng.sync()
+        t0 = time.perf_counter()
+        self.pk = E.BswPk(eng, g1, g2, h, e_gg_alpha)
+        eng.sync()
+        self.table_build_ms = 1e3 * (time.perf_counter() - t0)
+        self.attrs = ["b%d" % i for i in range(self.n_attr)]
+        t1, t2 = eng.g1_table(g1), eng.g2_table(g2)
+        rr = kfr()
+        rj = [kfr() for _ in self.attrs]
+        beta_inv = pow(beta, R - 2, R)
+        self.d_sk_d = eng.upload(t2.mul([le((alpha + rr) * beta_inv)])[0])
+        self.d_sk_g1 = eng.upload(b"".join(t1.mul([le(x) for x in rj])))
+        self.d_sk_g2 = eng.upload(b"".join(t2.mul([le(rr + hp.h_fr(a) * x) for a, x in zip(self.attrs, rj)])))
+        self.d_sk_attr_off = eng.upload_u32([0, self.n_attr])
+        t1.destroy()
+        t2.destroy()
+        self.e_tab = eng.gt_table(e_gg_alpha)
+        self.sk_lines = None if args.no_prepared_sk else E.BswSkLines(eng, 1, self.n_attr, self.d_sk_d, self.d_sk_g2)
+        # ---- policies
+        prnd = random.Random(args.seed)
+        self.trees = [self.make_tree(prnd) for _ in range(args.policies)]
+        t0 = time.perf_counter()
+        self.tt = hp.TreeTables(self.trees)
+        self.sel = []
+        for t in self.trees:
+            ok, idx = hp.pruned_leaf_indices(self.attrs, t)
+            assert ok
+            z = hp.leaf_coefficients(t)
+            names = hp.flatten_tree(t)["names"]
+            self.sel.append((idx, [self.attrs.index(names[y]) for y in idx], [z[y] for y in idx]))
+        self.host_prep_ms_per_policy = 1e3 * (time.perf_counter() - t0) / len(self.trees)
+        self.dtt = E.DevTreeTables(eng, self.tt)
+
+    def make_tree(self, prnd):
+        names = list(self.attrs)
+        prnd.shuffle(names)
+        kind = self.r.args.tree
+        if kind == "flat":                          # one n-ary AND: full-size Lagrange coefficients
+            return ("and", [("leaf", x) for x in names])
+        if kind == "nested":                        # balanced binary ANDs
+
+            def nest(ns):
+                if len(ns) == 1:
+                    return ("leaf", ns[0])
+                return ("and", [nest(ns[:len(ns) // 2]), nest(ns[len(ns) // 2:])])
+            return nest(names)
+        # "mixed": AND over two-leaf ORs -- half of the leaves are pruned away
+        return ("and", [("or", [("leaf", names[2 * i]), ("leaf", names[2 * i + 1])]) for i in range(len(names) // 2)])
+
+    def prepare(self, G, lanes):
+        r, eng, E, hp, tt = self.r, self.r.eng, self.E, self.hp, self.tt
+        R, le = hp.R_ORDER, hp.fr_le
+        B, P = self.B, len(self.trees)
+        GB = G * B
+        self.G, self.lanes = G, lanes
+        pol = [i % P for i in range(GB)]
+        sel_start_p, so = [], 0
+        sel_ct, sel_sk, sel_z = [], [], []
+        for idx, ska, z in self.sel:
+            sel_start_p.append(so)
+            sel_ct += idx
+            sel_sk += ska
+            sel_z += z
+            so += len(idx)
+        leaf_off, pair_off, coef_off = [0], [0], [0]
+        for p in pol:
+            leaf_off.append(leaf_off[-1] + tt.n_leaves(p))
+            pair_off.append(pair_off[-1] + 2 * len(self.sel[p][0]) + 1)
+            coef_off.append(coef_off[-1] + tt.n_coef(p))
+        assert all(leaf_off[(j + 1) * B] == (j + 1) * leaf_off[B] for j in range(G)), "batch must be a multiple of the policy count"
+        self.leaves_per_batch, self.pairs_per_batch = leaf_off[B], pair_off[B]
+        self.max_pairs = max(2 * len(s[0]) + 1 for s in self.sel)
+        self.d_leaf_off = eng.upload_u32(leaf_off)
+        self.d_pair_off = eng.upload_u32(pair_off)
+        self.d_item_tree_leaf = eng.upload_u32([tt.first_leaf[p] for p in pol])
+        self.d_item_tree_gate = eng.upload_u32([tt.first_gate[p] for p in pol])
+        self.d_item_coef_off = eng.upload_u32(coef_off[:-1])
+        self.d_sel_start = eng.upload_u32([sel_start_p[p] for p in pol])
+        self.d_sel_ct, self.d_sel_sk = eng.upload_u32(sel_ct), eng.upload_u32(sel_sk)
+        self.d_sel_z = eng.upload(b"".join(le(z) for z in sel_z))
+        self.d_sk_idx = eng.upload_u32([0] * GB)
+        # per-item explicit randomness (bsw::encrypt draw order: secret, msg, gate coefficients)
+        irnd = random.Random(r.args.seed * 7919 + 17 + r.rank)
+        self.d_secret = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        rho = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        self.d_msg = eng.alloc(GB * 384)
+        eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(GB), rho.ptr, self.d_msg.ptr))
+        n_coef = coef_off[-1]
+        # 31 random bytes per coefficient (< 2^248 < r): plenty for a polynomial coefficient of a throughput run
+        raw = irnd.randbytes(31 * n_coef)
+        self.d_coef = eng.upload(b"".join(raw[31 * i:31 * i + 31] + b"\0" for i in range(n_coef)) or bytes(32))
+        total_leaves = leaf_off[-1]
+        self.bufs = [(e_.alloc(GB * 64), e_.alloc(GB * 384), e_.alloc(total_leaves * 64), e_.alloc(total_leaves * 128),
+                      ExtBuf(r.torch, GB * 384, r.dev)) for e_ in lanes]
+        eng.sync()
+
+    def submit(self, lane, g):
+        E, e_ = self.E, self.lanes[lane]
+        c, cp, g1, g2, out = self.bufs[lane]
+        n = g * self.B
+        E.bsw_encrypt_dev(e_, self.pk, n, g * self.leaves_per_batch, self.d_leaf_off, self.d_item_tree_leaf, self.d_item_tree_gate, self.dtt,
+                          self.d_secret, self.d_coef, self.d_item_coef_off, self.d_msg, c, cp, g1, g2)
+        if self.r.args.only_encrypt:
+            return
+        E.bsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.d_pair_off, self.d_sel_start, self.d_sel_ct, self.d_sel_sk,
+                          self.d_sel_z, c, cp, g1, g2, self.d_leaf_off, self.d_sk_d, self.d_sk_g1, self.d_sk_g2, self.d_sk_attr_off,
+                          self.d_sk_idx, self.sk_lines, out)
+
+    def check(self, lane, g):
+        n = g * self.B * 384
+        return self.bufs[lane][4].t[:n].cpu().numpy().tobytes() == self.r.eng.download(self.d_msg)[:n]
+
+    def describe(self):
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        return {"workload": "BSW CP-ABE, %d-leaf %s access tree (%d distinct policies), batch %d encrypt+decrypt per GPU"
+                            % (self.n_attr, self.r.args.tree, len(self.trees), self.B),
+                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "pruned_leaves_avg": round(m, 2),
+                "pairings_per_item": round(2 * m + 1, 1), "prepared_key": self.sk_lines is not None,
+                "table_build_ms_per_public_key": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
+
+    def algorithmic_fpmul_per_item(self):
+        # enc 101 fixed-base G1 (36 kM) + 100 fixed-base G2 (106 kM) + 1.7 kM; dec 200 var-base G1 (560 kM) +
+        # 201 Miller (1.61 MM) + 1 final exponentiation (9 kM); scaled to the pruned leaf count m
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        n = self.n_attr
+        return {"k_miller_multi": (2 * m + 1) * 8000.0, "k_bsw_dec_pairs": 2 * m * 2800.0, "k_final_exp": 9000.0, "k_table_mul_g2": n * 1056.0,
+                "k_table_mul_g1": (n + 1) * 352.0, "k_table_pow_gt_mul": 1700.0, "k_bsw_enc_scalars": 0.0}
+
+    def algorithmic_bytes_per_step(self):
+        B, n = self.B, self.n_attr
+        return B * (32 + 384 + 64 + 384 + 384) + self.leaves_per_batch * (192 * 2 + 32) + self.pairs_per_batch * 4
+
+    def cpu_baseline(self):
+        from oracle import cport
+        if not cport.available():
+            return {"error": "oracle/c not built"}
+        n = self.r.args.cpu_sample or 12
+        dt = cport.bsw_encdec(self.n_attr, n, tree=self.r.args.tree, seed=self.r.args.seed)
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+                "sample": "%d BSW encrypt+decrypt at %d leaves (%s tree) in %.1f s; the reference's operation order (bsw/mod.rs:217-318: binary "
+                          "double-and-add for every G*Fr, two multiplications for (g2*h(name))*q, one full pairing per e(.,.), Gt::pow per leaf) "
+                          "over the C primitives of oracle/c/rabe_ref.c, single thread like the reference" % (n, self.n_attr, self.r.args.tree, dt)}
+
+    def close(self):
+        if self.sk_lines:
+            self.sk_lines.destroy()
+        self.pk.destroy()

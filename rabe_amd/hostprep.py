@@ -186,14 +186,16 @@ def flatten_tree(tree):
 
 
 def lagrange_at_zero(k):
-    """recover_coefficients over the points 1..k (secretsharing/mod.rs:60-72)"""
+    """recover_coefficients over the points 1..k (secretsharing/mod.rs:60-72): L_i = prod_{j != i} (0 - j) / (i - j).
+    Numerator and denominator are accumulated separately, one inversion per coefficient (same field element)."""
     out = []
     for i in range(1, k + 1):
-        res = 1
+        num, den = 1, 1
         for j in range(1, k + 1):
             if i != j:
-                res = res * ((0 - j) * pow(i - j, R_ORDER - 2, R_ORDER)) % R_ORDER
-        out.append(res % R_ORDER)
+                num = num * (0 - j) % R_ORDER
+                den = den * (i - j) % R_ORDER
+        out.append(num * pow(den, R_ORDER - 2, R_ORDER) % R_ORDER)
     return out
 
 
