@@ -291,6 +291,72 @@ int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
                                const uint32_t* dev_sk_attr_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items]*/,
                                const rhip_bsw_sk_lines* sk_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
 
+/* ---- Level B: LSW KP-ABE (src/schemes/lsw/mod.rs) ----------------------------------------------------------------
+ * Positive leaves only: the reference's negative-attribute keygen branch (:137-146) stays in the host layer and its
+ * decrypt has no negative branch at all (a TODO, :265-278). */
+typedef struct rhip_lsw_pk rhip_lsw_pk;       /* window tables of g1, g2 (KpAbePublicKey, lsw/mod.rs:44-51) */
+int32_t rhip_lsw_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, rhip_lsw_pk** out);
+void rhip_lsw_pk_destroy(rhip_lsw_pk* pk);
+/* Group arithmetic of n_items calls of lsw::keygen (lsw/mod.rs:121-170): shares q_y of alpha1 over the item's policy
+ * (flattened trees as for bsw; draws = the gate coefficients), then per leaf the explicit `random` r_y (:136):
+ *   d1[row] = g1 * (alpha2 * q_y + h(y) * r_y)   ( = g1*(alpha2 q_y) + (g1*h(y))*r_y, :149-154 ),   d2[row] = g2 * r_y
+ * dev_alpha = (alpha1, alpha2) of the master key. */
+int32_t rhip_lsw_keygen_batch(rhip_ctx* ctx, const rhip_lsw_pk* pk, size_t n_items, size_t total_leaves,
+                              const uint32_t* dev_item_leaf_off /*[n_items+1]*/, const uint32_t* dev_item_tree_leaf, const uint32_t* dev_item_tree_gate,
+                              const uint32_t* dev_path_off, const uint32_t* dev_path_gate, const uint32_t* dev_path_x, const uint32_t* dev_gate_k,
+                              const uint32_t* dev_gate_coef_off, const rhip_fr* dev_leaf_hash, const rhip_fr* dev_alpha /*[2]*/,
+                              const rhip_fr* dev_coef, const uint32_t* dev_item_coef_off /*[n_items]*/, const rhip_fr* dev_rand /*[total_leaves]*/,
+                              rhip_g1* dev_d1 /*[total_leaves]*/, rhip_g2* dev_d2 /*[total_leaves]*/);
+/* Group arithmetic of n_items calls of lsw::decrypt (lsw/mod.rs:228-290).  Selection entry e: the key's leaf row
+ * (sel_sk_leaf, relative to the key's first row), the ciphertext's attribute row (sel_ct_attr, relative) and the leaf's
+ * coefficient c.  Item i: entries sel_start[i] .. + m_i - 1, pairs [pair_off[i], pair_off[i+1]) with m_i + 1 of them; its
+ * key is sk_idx[i] (NULL: i) with leaf rows [sk_leaf_off[k], ..), its ciphertext ct_idx[i] (NULL: i) with attribute rows
+ * [ct_attr_off[c], ..).  n_sel = total number of selection entries.
+ *   out[i] = e1 * FE( ML( sum_e -c_e D1_e, e2 ) * prod_e ML( c_e E1_e, D2_e ) )               
+ * (the factors that share e2 collapse into one pairing of a multi-scalar sum with shared doublings).
+ * ct_e2_lines (optional): prepared lines of dev_ct_e2 (rhip_g2_lines_prepare over the same array). */
+int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel,
+                               const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                               const uint32_t* dev_sel_sk_leaf, const uint32_t* dev_sel_ct_attr, const rhip_fr* dev_sel_coeff,
+                               const rhip_gt* dev_ct_e1 /*[n_items]: item i's e1*/, const rhip_g2* dev_ct_e2 /*[n_ct]*/,
+                               const rhip_g1* dev_ct_e1j /*[ct attribute rows]: ej.1*/, const uint32_t* dev_ct_attr_off /*[n_ct+1]*/,
+                               const uint32_t* dev_ct_idx /*[n_items] or NULL*/, const rhip_g1* dev_sk_d1, const rhip_g2* dev_sk_d2,
+                               const uint32_t* dev_sk_leaf_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
+                               const rhip_g2_lines* ct_e2_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
+
+/* ---- Level B: AW11 multi-authority CP-ABE (src/schemes/aw11/mod.rs) -----------------------------------------------
+ * rhip_aw11_pk: gk (g1, g2), the constant e(g1, g2) and, for each of the n_attrs attributes of the authorities in play,
+ * (egg_alpha_x, g2 * y_x) (Aw11PublicKey.attr, :56-61) as window tables.  leaf_attr[leaf] (per policy leaf, beside the
+ * flattened tree tables) = the attribute's index in those arrays. */
+typedef struct rhip_aw11_pk rhip_aw11_pk;
+int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, size_t n_attrs,
+                            const rhip_gt* host_egg_alpha /*[n_attrs]*/, const rhip_g2* host_g2_y /*[n_attrs]*/, rhip_aw11_pk** out);
+void rhip_aw11_pk_destroy(rhip_aw11_pk* pk);
+/* Group arithmetic of n_items calls of aw11::encrypt (aw11/mod.rs:241-289).  Explicit randomness per item, in the
+ * reference's draw order: s (:257), the gate coefficients of the s-shares then of the 0-shares (item_n_coef[i] each,
+ * consecutive in dev_coef from item_coef_off[i]; :259-260), the Gt `msg` (:262), and one r_x per row (dev_rand, :267).
+ *   c_0 = msg * E^s ;  per row: c1 = E^lambda_x * egg_alpha_x^r_x,  c2 = g2 * r_x,  c3 = (g2*y_x) * r_x + g2 * omega_x */
+int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk, size_t n_items, size_t total_rows,
+                                const uint32_t* dev_item_row_off /*[n_items+1]*/, const uint32_t* dev_item_tree_leaf, const uint32_t* dev_item_tree_gate,
+                                const uint32_t* dev_item_n_coef /*[n_items]*/, const uint32_t* dev_path_off, const uint32_t* dev_path_gate,
+                                const uint32_t* dev_path_x, const uint32_t* dev_gate_k, const uint32_t* dev_gate_coef_off,
+                                const uint32_t* dev_leaf_attr, const rhip_fr* dev_s /*[n_items]*/, const rhip_fr* dev_coef,
+                                const uint32_t* dev_item_coef_off /*[n_items]*/, const rhip_fr* dev_rand /*[total_rows]*/,
+                                const rhip_gt* dev_msg /*[n_items]*/, rhip_gt* dev_c0 /*[n_items]*/, rhip_gt* dev_c1 /*[total_rows]*/,
+                                rhip_g2* dev_c2 /*[total_rows]*/, rhip_g2* dev_c3 /*[total_rows]*/);
+/* Group arithmetic of n_items calls of aw11::decrypt (aw11/mod.rs:298-366).  Selection entry e: ciphertext row (sel_ct_row,
+ * relative to the item's first row), key attribute row (sel_sk_attr, relative to the key's first row), coefficient c.
+ * dev_sk_hash[k] = g1 * h(gid_k) (the reference hashes the gid inside decrypt, :318).
+ *   out[i] = c_0 * prod_e C1_e^(-c_e) * FE( ML( -H(gid), sum_e c_e C3_e ) * prod_e ML( c_e K_e, C2_e ) )   
+ * The G2 sum and the Gt product run with shared doublings / squarings over the NAFs of the coefficients. */
+int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel,
+                                const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                                const uint32_t* dev_sel_ct_row, const uint32_t* dev_sel_sk_attr, const rhip_fr* dev_sel_coeff,
+                                const rhip_gt* dev_ct_c0 /*[n_items]*/, const rhip_gt* dev_ct_c1, const rhip_g2* dev_ct_c2, const rhip_g2* dev_ct_c3,
+                                const uint32_t* dev_ct_row_off /*[n_items+1]*/, const rhip_g1* dev_sk_hash /*[n_sk]*/, const rhip_g1* dev_sk_k,
+                                const uint32_t* dev_sk_attr_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
+                                rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- measurement helper: integer-multiply issue-rate microbenchmark (the roofline denominator) --
  * Runs `iters` dependent-free v_mad_u64_u32 per lane on every CU and returns elapsed milliseconds
  * and the number of multiply-adds executed. */

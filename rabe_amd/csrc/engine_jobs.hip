@@ -427,3 +427,532 @@ extern "C" int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
           (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref);
   return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
 }
+
+// ------------------------------------------------------------------------------------------------ shared-doubling sums
+// NAF masks of a batch's selection coefficients, once per entry: masks[e] = pos[8] | neg[8] of the SHORTER of c and r - c,
+// with the sign folded in (negating a scalar swaps its masks), so sum_j c_j P_j needs 254 doublings for the whole sum.
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_naf_masks(size_t n, const rhip_fr* k, uint32_t* masks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t kk[8], pos[8], neg_[8];
+  ld_scalar(kk, k + i);
+  const bool flip = fr_shorten(kk);
+  naf_masks(kk, pos, neg_);
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    masks[16 * i + w] = flip ? neg_[w] : pos[w];
+    masks[16 * i + 8 + w] = flip ? pos[w] : neg_[w];
+  }
+}
+struct G2JM { uint32_t l[48]; };
+__device__ __forceinline__ void st_jac_q(G1JM* p, const G1Jac& a) { uint4* q = (uint4*)p; st_fp_q(q, a.x); st_fp_q(q + 2, a.y); st_fp_q(q + 4, a.z); }
+__device__ __forceinline__ G1Jac ld_jac_q(const G1JM* p) { const uint4* q = (const uint4*)p; return G1Jac{ld_fp_q(q), ld_fp_q(q + 2), ld_fp_q(q + 4)}; }
+__device__ __forceinline__ void st_jac_q(G2JM* p, const G2Jac& a) {
+  uint4* q = (uint4*)p;
+  st_fp_q(q, a.x.c0); st_fp_q(q + 2, a.x.c1); st_fp_q(q + 4, a.y.c0); st_fp_q(q + 6, a.y.c1); st_fp_q(q + 8, a.z.c0); st_fp_q(q + 10, a.z.c1);
+}
+__device__ __forceinline__ G2Jac ld_jac_q(const G2JM* p) {
+  const uint4* q = (const uint4*)p;
+  return G2Jac{Fp2{ld_fp_q(q), ld_fp_q(q + 2)}, Fp2{ld_fp_q(q + 4), ld_fp_q(q + 6)}, Fp2{ld_fp_q(q + 8), ld_fp_q(q + 10)}};
+}
+__device__ __forceinline__ G1Aff ld_aff_q(const G1M* p) { return ld_g1_q(p); }
+__device__ __forceinline__ G2Aff ld_aff_q(const G2M* p) { return ld_g2_q(p); }
+// terms of one lane: bases pts[0 .. cnt) (Montgomery), masks of entries e0 .. e0 + cnt - 1; `flip` negates every scalar
+template <class F, class AFFM>
+struct DevTerms {
+  const AFFM* pts;
+  const uint32_t* masks;      // masks + 16 e0
+  int cnt;
+  bool flip;
+  __device__ __forceinline__ int count() const { return cnt; }
+  __device__ __forceinline__ Aff<F> base(int j) const { return ld_aff_q(pts + j); }
+  __device__ __forceinline__ uint32_t pos_word(int j, int w) const { return masks[16 * j + (flip ? 8 : 0) + w]; }
+  __device__ __forceinline__ uint32_t neg_word(int j, int w) const { return masks[16 * j + (flip ? 0 : 8) + w]; }
+};
+// lane t = chunk * n_items + item: the partial sum over terms [term_off[item] + c C, ...) of the item, Jacobian
+template <class F, class AFFM, class JACM>
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_msm_partial(size_t n_items, uint32_t L, uint32_t C, const uint32_t* term_off, const uint32_t* sel_start,
+                                                                 const AFFM* pts, const uint32_t* masks, int flip, JACM* part) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items * L) return;
+  const size_t c = t / n_items, item = t % n_items;
+  const uint32_t lo = term_off[item], hi = term_off[item + 1];
+  const uint64_t first = (uint64_t)lo + (uint64_t)c * C;
+  int cnt = 0;
+  if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
+  const DevTerms<F, AFFM> terms{pts + first, masks + 16 * ((size_t)sel_start[item] + c * C), cnt, flip != 0};
+  st_jac_q(part + item * L + c, jac_msm_naf<F>(terms));
+}
+// lane = item: sum of its L partial sums -> the G1 argument of the item's last pair (affine Montgomery; one inversion per block)
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_msm_finish_g1(size_t n_items, uint32_t L, const G1JM* part, const uint32_t* pair_off, G1M* P, uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n_items;
+  if (!active) i = n_items - 1;
+  G1Jac acc = ld_jac_q(part + i * L);
+  for (uint32_t c = 1; c < L; c++) acc = jac_add(acc, ld_jac_q(part + i * L + c));
+  const bool inf = !active || jac_is_inf(acc);
+  const Fp zinv = block_batch_inverse_n<RB_PAIRS_BLOCK>(lds, inf ? one<FpParams>() : acc.z);
+  if (!active) return;
+  const size_t last = (size_t)pair_off[i + 1] - 1;
+  if (inf) qref[last] = RHIP_Q_SKIP;
+  else st_g1_q(P + last, jac_to_aff_with_zinv(acc, zinv));
+}
+// the same for a G2 sum -> the G2 argument of the item's last pair (a walking pair)
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_msm_finish_g2(size_t n_items, uint32_t L, const G2JM* part, const uint32_t* pair_off, G2M* Q, uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * 128];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n_items;
+  if (!active) i = n_items - 1;
+  G2Jac acc = ld_jac_q(part + i * L);
+  for (uint32_t c = 1; c < L; c++) acc = jac_add(acc, ld_jac_q(part + i * L + c));
+  const bool inf = !active || jac_is_inf(acc);
+  const Fp norm = inf ? one<FpParams>() : add(sqr(acc.z.c0), sqr(acc.z.c1));
+  const Fp ninv = block_batch_inverse_n<128>(lds, norm);
+  if (!active) return;
+  const size_t last = (size_t)pair_off[i + 1] - 1;
+  if (inf) { qref[last] = RHIP_Q_SKIP; return; }
+  const Fp2 zinv{mul(acc.z.c0, ninv), neg(mul(acc.z.c1, ninv))};
+  st_g2_q(Q + last, jac_to_aff_with_zinv(acc, zinv));
+}
+static void choose_msm_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_terms, uint32_t* L, uint32_t* C) {
+  if (max_terms < 1) max_terms = 1;
+  const size_t simds = (size_t)ctx->n_cu * 4;
+  size_t c = 32;                                        // the lane's own 254 doublings are then ~6 % of its work (G1)
+  while (c > 4 && n_items * ((max_terms + c - 1) / c) < simds * 64) c -= 4;
+  const size_t l = (max_terms + c - 1) / c;
+  *C = (uint32_t)((max_terms + l - 1) / l);
+  *L = (uint32_t)l;
+}
+
+// ------------------------------------------------------------------------------------------------ LSW KP-ABE
+struct rhip_lsw_pk {
+  rhip_ctx* ctx;
+  rhip_g1_table* g1;
+  rhip_g2_table* g2;
+};
+extern "C" void rhip_lsw_pk_destroy(rhip_lsw_pk* pk) {
+  if (!pk) return;
+  rhip_g1_table_destroy(pk->g1);
+  rhip_g2_table_destroy(pk->g2);
+  delete pk;
+}
+extern "C" int32_t rhip_lsw_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const rhip_g2* g2, rhip_lsw_pk** out) {
+  if (!ctx || !g1 || !g2 || !out) return RHIP_ERR_ARG;
+  *out = nullptr;
+  rhip_lsw_pk* pk = new rhip_lsw_pk{ctx, nullptr, nullptr};
+  int32_t rc = rhip_g1_table_create(ctx, g1, &pk->g1);
+  if (!rc) rc = rhip_g1_table_add_w16(ctx, pk->g1);
+  if (!rc) rc = rhip_g2_table_create(ctx, g2, &pk->g2);
+  if (!rc) rc = rhip_g2_table_add_w16(ctx, pk->g2);
+  if (rc) { rhip_lsw_pk_destroy(pk); return rc; }
+  *out = pk;
+  return RHIP_OK;
+}
+// keygen, positive leaves (lsw/mod.rs:147-160): D1 = g1 * (alpha2 q_y + h(y) r_y), D2 = g2 * r_y, q_y the leaf's share of alpha1
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_lsw_keygen_scalars(size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                                                         const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, TreeTables tt,
+                                                                         const rhip_fr* leaf_hash, const rhip_fr* alpha /*[2]*/, const rhip_fr* coef,
+                                                                         const uint32_t* item_coef_off, const rhip_fr* rand, rhip_fr* k1) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_leaves) return;
+  const size_t item = owner_of(item_leaf_off, n_items, t);
+  const uint32_t leaf = item_tree_leaf[item] + (uint32_t)(t - item_leaf_off[item]);
+  const Fr q = share_of_leaf(tt, leaf, item_tree_gate[item], coef + item_coef_off[item], load_fr(alpha[0].l));
+  store_fr(k1[t].l, add(mul(load_fr(alpha[1].l), q), mul(load_fr(leaf_hash[leaf].l), load_fr(rand[t].l))));
+}
+extern "C" int32_t rhip_lsw_keygen_batch(rhip_ctx* ctx, const rhip_lsw_pk* pk, size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                         const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, const uint32_t* path_off,
+                                         const uint32_t* path_gate, const uint32_t* path_x, const uint32_t* gate_k, const uint32_t* gate_coef_off,
+                                         const rhip_fr* leaf_hash, const rhip_fr* alpha, const rhip_fr* coef, const uint32_t* item_coef_off,
+                                         const rhip_fr* rand, rhip_g1* d1, rhip_g2* d2) {
+  NEED(ctx);
+  if (!pk) return RHIP_ERR_ARG;
+  if (!n_items || !total_leaves) return RHIP_OK;
+  void* w = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 4, total_leaves * sizeof(rhip_fr), &w);
+  if (rc) return rc;
+  const TreeTables tt{path_off, path_gate, path_x, gate_k, gate_coef_off};
+  KLAUNCH(ctx, "k_lsw_keygen_scalars", k_lsw_keygen_scalars, dim3(blocks_for(total_leaves, 256)), dim3(256), 0, ctx->stream, n_items, total_leaves,
+          item_leaf_off, item_tree_leaf, item_tree_gate, tt, leaf_hash, alpha, coef, item_coef_off, rand, (rhip_fr*)w);
+  rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, (const rhip_fr*)w, d1);
+  if (rc) return rc;
+  return rhip_g2_table_mul(ctx, pk->g2, total_leaves, rand, d2);
+}
+// decrypt (lsw/mod.rs:228-290 restated in SURVEY.md Appendix B.4): item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 1:
+//   s < m : P = c_e * E1[ct attr],                  Q = D2[key leaf]          (e = sel_start[i] + s)
+//   m     : P = sum_e (-c_e) * D1[key leaf]  (MSM),  Q = e2
+// This kernel does the scaled pairs and gathers the MSM's bases (D1, Montgomery) at terms[pair index - item].
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+                                                                    const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
+                                                                    const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
+                                                                    const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2,
+                                                                    const uint32_t* sk_leaf_off, const uint32_t* sk_idx, const uint8_t* e2_line_inf,
+                                                                    G1M* P, G2M* Q, uint32_t* qref, G1M* terms) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < total_pairs;
+  if (!active) t = total_pairs - 1;
+  const size_t item = owner_of(pair_off, n_items, t);
+  const uint32_t j = (uint32_t)(t - pair_off[item]);
+  const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
+  const uint32_t ct = ct_idx ? ct_idx[item] : (uint32_t)item;
+  const uint32_t sk = sk_idx ? sk_idx[item] : (uint32_t)item;
+  const bool last = (j == m);
+  G1Aff base = aff_inf<Fp>();
+  uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t leaf = 0;
+  if (!last) {
+    const uint32_t e = sel_start[item] + j;
+    leaf = sk_leaf_off[sk] + sel_sk_leaf[e];
+    base = load_g1(ct_e1j[ct_attr_off[ct] + sel_ct_attr[e]].l);
+    ld_scalar(k, sel_coeff + e);
+  }
+  bool p_inf;
+  scale_and_store(lds, active && !last, base, k, false, P + t, &p_inf);
+  if (!active) return;
+  if (last) {
+    if (e2_line_inf) {                                   // prepared lines of the ciphertexts' e2: block = ciphertext index
+      qref[t] = e2_line_inf[ct] ? RHIP_Q_SKIP : ct;
+    } else {
+      const G2Aff q = load_g2(ct_e2[ct].l);
+      if (!aff_is_inf(q)) st_g2_q(Q + t, q);
+      qref[t] = aff_is_inf(q) ? RHIP_Q_SKIP : RHIP_Q_WALK;
+    }
+    return;
+  }
+  st_g1_q(terms + (t - item), load_g1(sk_d1[leaf].l));
+  const G2Aff q = load_g2(sk_d2[leaf].l);
+  const bool skip = p_inf || aff_is_inf(q);
+  if (!skip) st_g2_q(Q + t, q);
+  qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+}
+// term offsets of the MSM: item i has m_i = pair_off[i+1] - pair_off[i] - 1 terms starting at pair_off[i] - i
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_term_off(size_t n_items, const uint32_t* pair_off, uint32_t* term_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_items) term_off[i] = pair_off[i] - (uint32_t)i;
+}
+extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                          const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
+                                          const rhip_gt* ct_e1, const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
+                                          const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2, const uint32_t* sk_leaf_off,
+                                          const uint32_t* sk_idx, const rhip_g2_lines* ct_e2_lines, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (!total_pairs || !pair_off || !n_sel) return RHIP_ERR_ARG;
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
+  if (rc) return rc;
+  const size_t total_terms = total_pairs - n_items;
+  void *w_terms = nullptr, *w_masks = nullptr, *w_part = nullptr, *w_off = nullptr;
+  rc = rhip_ensure_work(ctx, 4, (total_terms ? total_terms : 1) * sizeof(G1M), &w_terms);
+  if (!rc) rc = rhip_ensure_work(ctx, 5, n_sel * 16 * sizeof(uint32_t), &w_masks);
+  uint32_t L, C;
+  choose_msm_chunks(ctx, n_items, max_pairs - 1, &L, &C);
+  if (!rc) rc = rhip_ensure_work(ctx, 6, n_items * L * sizeof(G1JM), &w_part);
+  if (!rc) rc = rhip_ensure_work(ctx, 7, (n_items + 1) * sizeof(uint32_t), &w_off);
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
+  KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
+  KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
+          pair_off, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
+          (const uint8_t*)(ct_e2_lines ? ct_e2_lines->q_inf : nullptr), pl.P, pl.Q, pl.qref, (G1M*)w_terms);
+  KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
+          (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
+  KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
+          (const G1JM*)w_part, pair_off, pl.P, pl.qref);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e1, out);
+}
+
+// ------------------------------------------------------------------------------------------------ AW11 multi-authority CP-ABE
+// Public side of aw11::encrypt: gk (g1, g2), E = e(g1, g2) (the constant the reference recomputes per row, aw11/mod.rs:263,274)
+// and, for every attribute of every authority in play, (egg_alpha_x, g2*y_x) (Aw11PublicKey, :56-61): fixed bases, so tables.
+struct rhip_aw11_pk {
+  rhip_ctx* ctx;
+  rhip_g2_table* g2;
+  rhip_gt_table* E;
+  size_t n_attrs;
+  GtM* attr_gt;       // [n_attrs][32][255]
+  G2M* attr_g2;       // [n_attrs][32][255]
+};
+extern "C" void rhip_aw11_pk_destroy(rhip_aw11_pk* pk) {
+  if (!pk) return;
+  rhip_g2_table_destroy(pk->g2);
+  rhip_gt_table_destroy(pk->E);
+  if (pk->attr_gt) (void)hipFree(pk->attr_gt);
+  if (pk->attr_g2) (void)hipFree(pk->attr_g2);
+  delete pk;
+}
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_attr_tables_gt(size_t n_attrs, const rhip_gt* base, GtM* tbl) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_attrs * TBL_WINDOWS * TBL_DIGITS) return;
+  const size_t a = t / (TBL_WINDOWS * TBL_DIGITS), e = t % (TBL_WINDOWS * TBL_DIGITS);
+  const int w = (int)(e / TBL_DIGITS);
+  const uint32_t d = (uint32_t)(e % TBL_DIGITS) + 1;
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = (i == (w >> 2)) ? (d << (8 * (w & 3))) : 0u;
+  st_gt_m(tbl + t, gt_pow_window(load_gt(base[a].l), k));
+}
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_attr_tables_g2(size_t n_attrs, const rhip_g2* base, G2M* tbl) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_attrs * TBL_WINDOWS * TBL_DIGITS) return;
+  const size_t a = t / (TBL_WINDOWS * TBL_DIGITS), e = t % (TBL_WINDOWS * TBL_DIGITS);
+  const int w = (int)(e / TBL_DIGITS);
+  const uint32_t d = (uint32_t)(e % TBL_DIGITS) + 1;
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = (i == (w >> 2)) ? (d << (8 * (w & 3))) : 0u;
+  st_g2_m(tbl + t, jac_to_aff(jac_mul_naf(load_g2(base[a].l), k)));
+}
+extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const rhip_g2* g2, size_t n_attrs, const rhip_gt* host_egg_alpha,
+                                       const rhip_g2* host_g2_y, rhip_aw11_pk** out) {
+  if (!ctx || !g1 || !g2 || !n_attrs || !host_egg_alpha || !host_g2_y || !out) return RHIP_ERR_ARG;
+  *out = nullptr;
+  rhip_aw11_pk* pk = new rhip_aw11_pk{ctx, nullptr, nullptr, n_attrs, nullptr, nullptr};
+  rhip_gt e;
+  int32_t rc = rhip_host_pairing(ctx, g1, g2, &e);
+  if (!rc) rc = rhip_g2_table_create(ctx, g2, &pk->g2);
+  if (!rc) rc = rhip_g2_table_add_w16(ctx, pk->g2);
+  if (!rc) rc = rhip_gt_table_create(ctx, &e, &pk->E);
+  if (!rc) rc = rhip_gt_table_add_w16(ctx, pk->E);
+  if (rc) { rhip_aw11_pk_destroy(pk); return rc; }
+  const size_t per = (size_t)TBL_WINDOWS * TBL_DIGITS;
+  rhip_gt* dgt = nullptr;
+  rhip_g2* dg2 = nullptr;
+  hipError_t he = hipMalloc((void**)&pk->attr_gt, n_attrs * per * sizeof(GtM));
+  if (he == hipSuccess) he = hipMalloc((void**)&pk->attr_g2, n_attrs * per * sizeof(G2M));
+  if (he == hipSuccess) he = hipMalloc((void**)&dgt, n_attrs * sizeof(rhip_gt));
+  if (he == hipSuccess) he = hipMalloc((void**)&dg2, n_attrs * sizeof(rhip_g2));
+  if (he == hipSuccess) he = hipMemcpyAsync(dgt, host_egg_alpha, n_attrs * sizeof(rhip_gt), hipMemcpyHostToDevice, ctx->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(dg2, host_g2_y, n_attrs * sizeof(rhip_g2), hipMemcpyHostToDevice, ctx->stream);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(k_attr_tables_gt, dim3(blocks_for(n_attrs * per, 64)), dim3(64), 0, ctx->stream, n_attrs, (const rhip_gt*)dgt, pk->attr_gt);
+    hipLaunchKernelGGL(k_attr_tables_g2, dim3(blocks_for(n_attrs * per, 128)), dim3(128), 0, ctx->stream, n_attrs, (const rhip_g2*)dg2, pk->attr_g2);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+  if (dgt) (void)hipFree(dgt);
+  if (dg2) (void)hipFree(dg2);
+  if (he != hipSuccess) { rhip_aw11_pk_destroy(pk); return fail(ctx, he, "rhip_aw11_pk_create"); }
+  *out = pk;
+  return RHIP_OK;
+}
+// one lane per (item, leaf row): lambda_x = share of s, omega_x = share of 0 (second coefficient set follows the first in
+// the item's draw list, aw11/mod.rs:259-260)
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_aw11_enc_scalars(size_t n_items, size_t total_rows, const uint32_t* item_row_off,
+                                                                       const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate,
+                                                                       const uint32_t* item_n_coef, TreeTables tt, const rhip_fr* s, const rhip_fr* coef,
+                                                                       const uint32_t* item_coef_off, rhip_fr* lam, rhip_fr* omg) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_rows) return;
+  const size_t item = owner_of(item_row_off, n_items, t);
+  const uint32_t leaf = item_tree_leaf[item] + (uint32_t)(t - item_row_off[item]);
+  const rhip_fr* c0 = coef + item_coef_off[item];
+  store_fr(lam[t].l, share_of_leaf(tt, leaf, item_tree_gate[item], c0, load_fr(s[item].l)));
+  store_fr(omg[t].l, share_of_leaf(tt, leaf, item_tree_gate[item], c0 + item_n_coef[item], zero<FrParams>()));
+}
+// C1[row] = E^lambda * egg_alpha_x^r   (:272-274)
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
+                                                                 const uint32_t* leaf_attr, const GtM* e_tbl, int e_w16, const GtM* attr_tbl,
+                                                                 const rhip_fr* lam, const rhip_fr* rand, rhip_gt* c1) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_rows) return;
+  const size_t item = owner_of(item_row_off, n_items, t);
+  const uint32_t a = leaf_attr[item_tree_leaf[item] + (uint32_t)(t - item_row_off[item])];
+  uint32_t kl[8], kr[8];
+  ld_scalar(kl, lam + t);
+  ld_scalar(kr, rand + t);
+  const Fp12 x = e_w16 ? table_pow_gt_w16(e_tbl, kl) : table_pow_gt(e_tbl, kl);
+  const Fp12 y = table_pow_gt(attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
+  store_gt(c1[t].l, fp12_mul(x, y));
+}
+// C3[row] = (g2*y_x) * r + g2 * omega   (:275-277): two fixed-base sums on one accumulator
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
+                                                                  const uint32_t* leaf_attr, const G2M* g2_tbl8, const G2M* attr_tbl, const rhip_fr* omg,
+                                                                  const rhip_fr* rand, rhip_g2* c3) {
+  __shared__ uint32_t lds[2 * 8 * 128];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < total_rows;
+  if (!active) t = total_rows - 1;
+  const size_t item = owner_of(item_row_off, n_items, t);
+  const uint32_t a = leaf_attr[item_tree_leaf[item] + (uint32_t)(t - item_row_off[item])];
+  uint32_t kr[8], kw[8];
+  ld_scalar(kr, rand + t);
+  ld_scalar(kw, omg + t);
+  const G2M* ta = attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS;
+  G2Jac acc = jac_inf<Fp2>();
+#pragma unroll 1
+  for (int w = 0; w < 2 * TBL_WINDOWS; w++) {
+    const int ww = w & (TBL_WINDOWS - 1);
+    const uint32_t d = scalar_byte(w < TBL_WINDOWS ? kr : kw, ww);
+    if (d) acc = jac_add_aff(acc, ld_g2_m((w < TBL_WINDOWS ? ta : g2_tbl8) + ww * TBL_DIGITS + (d - 1)));
+  }
+  store_g2_block128(lds, active, c3 + t, acc);
+}
+extern "C" int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk, size_t n_items, size_t total_rows, const uint32_t* item_row_off,
+                                           const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, const uint32_t* item_n_coef,
+                                           const uint32_t* path_off, const uint32_t* path_gate, const uint32_t* path_x, const uint32_t* gate_k,
+                                           const uint32_t* gate_coef_off, const uint32_t* leaf_attr, const rhip_fr* s, const rhip_fr* coef,
+                                           const uint32_t* item_coef_off, const rhip_fr* rand, const rhip_gt* msg, rhip_gt* c0, rhip_gt* c1, rhip_g2* c2,
+                                           rhip_g2* c3) {
+  NEED(ctx);
+  if (!pk) return RHIP_ERR_ARG;
+  if (!n_items) return RHIP_OK;
+  const rhip_gt_table* et = pk->E;
+  KLAUNCH(ctx, "k_table_pow_gt_mul", k_table_pow_gt_mul, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream,
+          (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0, n_items, s, msg, c0);
+  if (!total_rows) return RHIP_OK;
+  void* w = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 4, total_rows * 2 * sizeof(rhip_fr), &w);
+  if (rc) return rc;
+  rhip_fr* lam = (rhip_fr*)w;
+  rhip_fr* omg = lam + total_rows;
+  const TreeTables tt{path_off, path_gate, path_x, gate_k, gate_coef_off};
+  KLAUNCH(ctx, "k_aw11_enc_scalars", k_aw11_enc_scalars, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, n_items, total_rows, item_row_off,
+          item_tree_leaf, item_tree_gate, item_n_coef, tt, s, coef, item_coef_off, lam, omg);
+  KLAUNCH(ctx, "k_aw11_enc_c1", k_aw11_enc_c1, dim3(blocks_for(total_rows, 64)), dim3(64), 0, ctx->stream, total_rows, item_row_off, n_items,
+          item_tree_leaf, leaf_attr, (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0, (const GtM*)pk->attr_gt, (const rhip_fr*)lam,
+          rand, c1);
+  rc = rhip_g2_table_mul(ctx, pk->g2, total_rows, rand, c2);
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_aw11_enc_c3", k_aw11_enc_c3, dim3(blocks_for(total_rows, 128)), dim3(128), 0, ctx->stream, total_rows, item_row_off, n_items,
+          item_tree_leaf, leaf_attr, (const G2M*)pk->g2->dev, (const G2M*)pk->attr_g2, (const rhip_fr*)omg, rand, c3);
+  return RHIP_OK;
+}
+// decrypt (aw11/mod.rs:298-366 restated in SURVEY.md Appendix B.5): item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 1:
+//   s < m : P = c_e * K[key attr],   Q = C2[ct row]
+//   m     : P = -H(gid),             Q = sum_e c_e * C3[ct row]   (G2 MSM)
+// and the leading factor c_0 * prod_e C1[ct row]^(-c_e)  (a Gt multi-exponentiation with shared squarings).
+// This kernel does the scaled pairs and gathers the MSM's bases (C3) and the multi-exponentiation's bases (C1), Montgomery.
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+                                                                     const uint32_t* sel_ct_row, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
+                                                                     const rhip_g2* ct_c2, const uint32_t* ct_row_off, const rhip_g1* sk_hash,
+                                                                     const rhip_g1* sk_k, const uint32_t* sk_attr_off, const uint32_t* sk_idx, G1M* P,
+                                                                     G2M* Q, uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < total_pairs;
+  if (!active) t = total_pairs - 1;
+  const size_t item = owner_of(pair_off, n_items, t);
+  const uint32_t j = (uint32_t)(t - pair_off[item]);
+  const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
+  const uint32_t sk = sk_idx ? sk_idx[item] : (uint32_t)item;
+  const bool last = (j == m);
+  G1Aff base;
+  uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t row = 0;
+  if (last) {
+    base = load_g1(sk_hash[sk].l);
+  } else {
+    const uint32_t e = sel_start[item] + j;
+    row = ct_row_off[item] + sel_ct_row[e];
+    base = load_g1(sk_k[sk_attr_off[sk] + sel_sk_attr[e]].l);
+    ld_scalar(k, sel_coeff + e);
+  }
+  bool p_inf;
+  scale_and_store(lds, active, base, k, last, P + t, &p_inf);
+  if (!active) return;
+  if (last) { qref[t] = p_inf ? RHIP_Q_SKIP : RHIP_Q_WALK; return; }      // Q comes from k_msm_finish_g2 (which may turn the pair into a skip)
+  const G2Aff q = load_g2(ct_c2[row].l);
+  const bool skip = p_inf || aff_is_inf(q);
+  if (!skip) st_g2_q(Q + t, q);
+  qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+}
+// lane per term: C3 and C1 of the selected ciphertext row in Montgomery form (term index = pair index - item)
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_gather_terms(size_t n_items, size_t total_terms, const uint32_t* term_off, const uint32_t* sel_start,
+                                                                       const uint32_t* sel_ct_row, const uint32_t* ct_row_off, const rhip_gt* ct_c1,
+                                                                       const rhip_g2* ct_c3, G2M* t_c3, GtM* t_c1) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_terms) return;
+  const size_t item = owner_of(term_off, n_items, t);
+  const uint32_t e = sel_start[item] + (uint32_t)(t - term_off[item]);
+  const uint32_t row = ct_row_off[item] + sel_ct_row[e];
+  st_g2_q(t_c3 + t, load_g2(ct_c3[row].l));
+  st_gt_m(t_c1 + t, load_gt(ct_c1[row].l));
+}
+// lane t = chunk * n_items + item: prod over the chunk's terms of base^(-c) with the squarings shared (Straus over the NAF
+// masks; an inverse in Gt is a conjugation)
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_multiexp_partial(size_t n_items, uint32_t L, uint32_t C, const uint32_t* term_off,
+                                                                         const uint32_t* sel_start, const GtM* bases, const uint32_t* masks, int flip,
+                                                                         GtM* part) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items * L) return;
+  const size_t c = t / n_items, item = t % n_items;
+  const uint32_t lo = term_off[item], hi = term_off[item + 1];
+  const uint64_t first = (uint64_t)lo + (uint64_t)c * C;
+  int cnt = 0;
+  if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
+  const GtM* b = bases + first;
+  const uint32_t* mk = masks + 16 * ((size_t)sel_start[item] + c * C);
+  Fp12 acc = fp12_one();
+  bool started = false;
+  for (int w = 7; w >= 0; w--) {
+    for (int bit = 31; bit >= 0; bit--) {
+      if (started) acc = fp12_cyclotomic_sqr(acc);
+      for (int j = 0; j < cnt; j++) {
+        const uint32_t pw = mk[16 * j + (flip ? 8 : 0) + w], nw = mk[16 * j + (flip ? 0 : 8) + w];
+        const uint32_t pb = (pw >> bit) & 1u, nb = (nw >> bit) & 1u;
+        if (pb | nb) {
+          Fp12 x = ld_gt_m(b + j);
+          if (nb) x = fp12_conj(x);
+          acc = started ? fp12_mul(acc, x) : x;
+          started = true;
+        }
+      }
+    }
+  }
+  st_gt_m(part + item * L + c, acc);
+}
+// lead[i] = c_0[i] * prod_c part[i][c], canonical (the mul_in of the final-exponentiation kernel)
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_lead(size_t n_items, uint32_t L, const rhip_gt* c0, const GtM* part, rhip_gt* lead) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  Fp12 acc = load_gt(c0[i].l);
+  for (uint32_t c = 0; c < L; c++) acc = fp12_mul_fn(acc, ld_gt_m(part + i * L + c));
+  store_gt(lead[i].l, acc);
+}
+extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                           const uint32_t* sel_start, const uint32_t* sel_ct_row, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
+                                           const rhip_gt* ct_c0, const rhip_gt* ct_c1, const rhip_g2* ct_c2, const rhip_g2* ct_c3,
+                                           const uint32_t* ct_row_off, const rhip_g1* sk_hash, const rhip_g1* sk_k, const uint32_t* sk_attr_off,
+                                           const uint32_t* sk_idx, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (!total_pairs || !pair_off || !n_sel) return RHIP_ERR_ARG;
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
+  if (rc) return rc;
+  const size_t total_terms = total_pairs - n_items;
+  uint32_t L, C;
+  choose_msm_chunks(ctx, n_items, max_pairs - 1, &L, &C);
+  // arena 4: [C3 terms (G2M)][C1 terms (GtM)][lead (rhip_gt per item)];  5: masks;  6: [G2 partials][Gt partials];  7: term offsets
+  void *w4 = nullptr, *w_masks = nullptr, *w6 = nullptr, *w_off = nullptr;
+  const size_t nt = total_terms ? total_terms : 1;
+  rc = rhip_ensure_work(ctx, 4, nt * (sizeof(G2M) + sizeof(GtM)) + n_items * sizeof(rhip_gt), &w4);
+  if (!rc) rc = rhip_ensure_work(ctx, 5, n_sel * 16 * sizeof(uint32_t), &w_masks);
+  if (!rc) rc = rhip_ensure_work(ctx, 6, n_items * L * (sizeof(G2JM) + sizeof(GtM)), &w6);
+  if (!rc) rc = rhip_ensure_work(ctx, 7, (n_items + 1) * sizeof(uint32_t), &w_off);
+  if (rc) return rc;
+  G2M* t_c3 = (G2M*)w4;
+  GtM* t_c1 = (GtM*)(t_c3 + nt);
+  rhip_gt* lead = (rhip_gt*)(t_c1 + nt);
+  G2JM* p_g2 = (G2JM*)w6;
+  GtM* p_gt = (GtM*)(p_g2 + n_items * L);
+  KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
+  KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
+  KLAUNCH(ctx, "k_aw11_dec_pairs", k_aw11_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, sel_start, sel_ct_row, sel_sk_attr, sel_coeff, ct_c2, ct_row_off, sk_hash, sk_k, sk_attr_off, sk_idx, pl.P, pl.Q,
+          pl.qref);
+  if (total_terms)
+    KLAUNCH(ctx, "k_aw11_gather_terms", k_aw11_gather_terms, dim3(blocks_for(total_terms, 64)), dim3(64), 0, ctx->stream, n_items, total_terms,
+            (const uint32_t*)w_off, sel_start, sel_ct_row, ct_row_off, ct_c1, ct_c3, t_c3, t_c1);
+  KLAUNCH(ctx, "k_msm_partial_g2", (k_msm_partial<Fp2, G2M, G2JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
+          (const uint32_t*)w_off, sel_start, (const G2M*)t_c3, (const uint32_t*)w_masks, 0, p_g2);
+  KLAUNCH(ctx, "k_msm_finish_g2", k_msm_finish_g2, dim3(blocks_for(n_items, 128)), dim3(128), 0, ctx->stream, n_items, L, (const G2JM*)p_g2, pair_off,
+          pl.Q, pl.qref);
+  KLAUNCH(ctx, "k_gt_multiexp_partial", k_gt_multiexp_partial, dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
+          (const uint32_t*)w_off, sel_start, (const GtM*)t_c1, (const uint32_t*)w_masks, 1, p_gt);
+  KLAUNCH(ctx, "k_gt_lead", k_gt_lead, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, L, ct_c0, (const GtM*)p_gt, lead);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, (const LineM*)nullptr, (const rhip_gt*)lead, out);
+}

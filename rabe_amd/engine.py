@@ -415,3 +415,59 @@ def bsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, d_pair_off, d_sel_star
                                               _p(d_sel_ct_leaf), _p(d_sel_sk_attr), _p(d_sel_coeff), _p(d_ct_c), _p(d_ct_cp), _p(d_ct_cy_g1),
                                               _p(d_ct_cy_g2), _p(d_ct_leaf_off), _p(d_sk_d), _p(d_sk_dj_g1), _p(d_sk_dj_g2),
                                               _p(d_sk_attr_off), _p(d_sk_idx), _p(sk_lines), _p(d_out)))
+
+
+class LswPk:
+    def __init__(self, eng, g1, g2):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_lsw_pk_create(eng.ctx, bytes(g1), bytes(g2), ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_lsw_pk_destroy(self.h)
+            self.h = None
+
+
+def lsw_keygen_dev(eng, pk, n_items, total_leaves, d_item_leaf_off, d_item_tree_leaf, d_item_tree_gate, dtt, d_alpha, d_coef, d_item_coef_off,
+                   d_rand, d_d1, d_d2):
+    eng._check(eng.lib.rhip_lsw_keygen_batch(eng.ctx, pk.h, _sz(n_items), _sz(total_leaves), _p(d_item_leaf_off), _p(d_item_tree_leaf),
+                                             _p(d_item_tree_gate), _p(dtt.path_off), _p(dtt.path_gate), _p(dtt.path_x), _p(dtt.gate_k),
+                                             _p(dtt.gate_coef_off), _p(dtt.leaf_hash), _p(d_alpha), _p(d_coef), _p(d_item_coef_off), _p(d_rand),
+                                             _p(d_d1), _p(d_d2)))
+
+
+def lsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_sel_start, d_sel_sk_leaf, d_sel_ct_attr, d_sel_coeff, d_ct_e1,
+                    d_ct_e2, d_ct_e1j, d_ct_attr_off, d_ct_idx, d_sk_d1, d_sk_d2, d_sk_leaf_off, d_sk_idx, e2_lines, d_out):
+    eng._check(eng.lib.rhip_lsw_decrypt_batch(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _sz(n_sel), _p(d_pair_off), _p(d_sel_start),
+                                              _p(d_sel_sk_leaf), _p(d_sel_ct_attr), _p(d_sel_coeff), _p(d_ct_e1), _p(d_ct_e2), _p(d_ct_e1j),
+                                              _p(d_ct_attr_off), _p(d_ct_idx), _p(d_sk_d1), _p(d_sk_d2), _p(d_sk_leaf_off), _p(d_sk_idx),
+                                              _p(e2_lines), _p(d_out)))
+
+
+class Aw11Pk:
+    def __init__(self, eng, g1, g2, egg_alpha, g2_y):
+        self.eng = eng
+        self.h = ctypes.c_void_p()
+        eng._check(eng.lib.rhip_aw11_pk_create(eng.ctx, bytes(g1), bytes(g2), _sz(len(egg_alpha)), b"".join(egg_alpha), b"".join(g2_y),
+                                               ctypes.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            self.eng.lib.rhip_aw11_pk_destroy(self.h)
+            self.h = None
+
+
+def aw11_encrypt_dev(eng, pk, n_items, total_rows, d_item_row_off, d_item_tree_leaf, d_item_tree_gate, d_item_n_coef, dtt, d_leaf_attr, d_s,
+                     d_coef, d_item_coef_off, d_rand, d_msg, d_c0, d_c1, d_c2, d_c3):
+    eng._check(eng.lib.rhip_aw11_encrypt_batch(eng.ctx, pk.h, _sz(n_items), _sz(total_rows), _p(d_item_row_off), _p(d_item_tree_leaf),
+                                               _p(d_item_tree_gate), _p(d_item_n_coef), _p(dtt.path_off), _p(dtt.path_gate), _p(dtt.path_x),
+                                               _p(dtt.gate_k), _p(dtt.gate_coef_off), _p(d_leaf_attr), _p(d_s), _p(d_coef), _p(d_item_coef_off),
+                                               _p(d_rand), _p(d_msg), _p(d_c0), _p(d_c1), _p(d_c2), _p(d_c3)))
+
+
+def aw11_decrypt_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_sel_start, d_sel_ct_row, d_sel_sk_attr, d_sel_coeff, d_ct_c0,
+                     d_ct_c1, d_ct_c2, d_ct_c3, d_ct_row_off, d_sk_hash, d_sk_k, d_sk_attr_off, d_sk_idx, d_out):
+    eng._check(eng.lib.rhip_aw11_decrypt_batch(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _sz(n_sel), _p(d_pair_off), _p(d_sel_start),
+                                               _p(d_sel_ct_row), _p(d_sel_sk_attr), _p(d_sel_coeff), _p(d_ct_c0), _p(d_ct_c1), _p(d_ct_c2),
+                                               _p(d_ct_c3), _p(d_ct_row_off), _p(d_sk_hash), _p(d_sk_k), _p(d_sk_attr_off), _p(d_sk_idx), _p(d_out)))
