@@ -16,7 +16,7 @@ from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_sum
 
 
 def run(args, world, rank, local_rank):
-    cls = {3: BswBench}.get(args.config)
+    cls = {3: BswBench, 4: LswBench, 5: Aw11Bench}.get(args.config)
     if cls is None:
         raise SystemExit("bench.py --config %d: the device-resident path of this scheme is not built yet" % args.config)
     return SchemeRunner(cls, args, world, rank, local_rank).run()
@@ -107,11 +107,14 @@ class SchemeRunner:
             macs = alg.get(dom, 0) * MAC_PER_FPMUL * G * B
             achieved = macs / (per_kernel[dom] * 1e-3) / 1e12 if per_kernel[dom] > 0 else 0.0
             traffic, tsrc = pmc_traffic(dom, args.config)
+            impl = b.impl_fpmul_per_item().get(dom)
             result["roofline"] = {
                 "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom, "kernel_ms": round(per_kernel[dom], 4),
                 "items_per_launch": G * B, "steps_per_launch": G, "kernel_ms_per_step": round(per_kernel[dom] / G, 4),
                 "achieved": round(achieved, 4), "peak": round(peak, 3), "unit": "TMAC32/s", "frac": round(achieved / peak, 4) if peak else None,
                 "work": "SURVEY 8d algorithmic Fp-muls per item carried by this kernel (%.3g) x 136 MAC32 x items = %.3e MAC32 per launch" % (alg.get(dom, 0), macs),
+                "achieved_impl_count": round(impl * MAC_PER_FPMUL * G * B / (per_kernel[dom] * 1e-3) / 1e12, 4) if impl and per_kernel[dom] > 0 else None,
+                "achieved_impl_count_note": "the same with this engine's own instrumented multiplication count (tests/count_muls.py) instead of SURVEY 8d's",
                 "whole_step_frac": round(b.survey_fpmul_per_item * MAC_PER_FPMUL * B / (elapsed / args.steps) / 1e12 / peak, 4) if peak else None,
                 "whole_step_work": "SURVEY 8d: %.3g M Fp-mul per op" % (b.survey_fpmul_per_item / 1e6),
                 "traffic": traffic, "traffic_source": tsrc,
@@ -214,18 +217,7 @@ class BswBench:
     def make_tree(self, prnd):
         names = list(self.attrs)
         prnd.shuffle(names)
-        kind = self.r.args.tree
-        if kind == "flat":                          # one n-ary AND: full-size Lagrange coefficients
-            return ("and", [("leaf", x) for x in names])
-        if kind == "nested":                        # balanced binary ANDs
-
-            def nest(ns):
-                if len(ns) == 1:
-                    return ("leaf", ns[0])
-                return ("and", [nest(ns[:len(ns) // 2]), nest(ns[len(ns) // 2:])])
-            return nest(names)
-        # "mixed": AND over two-leaf ORs -- half of the leaves are pruned away
-        return ("and", [("or", [("leaf", names[2 * i]), ("leaf", names[2 * i + 1])]) for i in range(len(names) // 2)])
+        return make_tree(self.r.args.tree, names)
 
     def prepare(self, G, lanes):
         r, eng, E, hp, tt = self.r, self.r.eng, self.E, self.hp, self.tt
@@ -306,6 +298,11 @@ class BswBench:
         return {"k_miller_multi": (2 * m + 1) * 8000.0, "k_bsw_dec_pairs": 2 * m * 2800.0, "k_final_exp": 9000.0, "k_table_mul_g2": n * 1056.0,
                 "k_table_mul_g1": (n + 1) * 352.0, "k_table_pow_gt_mul": 1700.0, "k_bsw_enc_scalars": 0.0}
 
+    def impl_fpmul_per_item(self):
+        # tests/count_muls.py: miller_loop_multi 4.9 kM per pair with half of the pairs replaying prepared lines, 6.24 kM all walking
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        return {"k_miller_multi": (2 * m + 1) * (4900.0 if self.sk_lines else 6240.0), "k_bsw_dec_pairs": 2 * m * 2750.0, "k_final_exp": 7553.0 + 15 * 54}
+
     def algorithmic_bytes_per_step(self):
         B, n = self.B, self.n_attr
         return B * (32 + 384 + 64 + 384 + 384) + self.leaves_per_batch * (192 * 2 + 32) + self.pairs_per_batch * 4
@@ -324,4 +321,347 @@ class BswBench:
     def close(self):
         if self.sk_lines:
             self.sk_lines.destroy()
+        self.pk.destroy()
+
+
+# ====================================================================================================================== shared helpers
+def make_tree(kind, names, binary_and_only=False):
+    """flat: one n-ary AND (binary-AND schemes: right-nested instead); nested: balanced binary ANDs; mixed: ANDs over two-leaf ORs"""
+    def nest(nodes):
+        if len(nodes) == 1:
+            return nodes[0]
+        return ("and", [nest(nodes[:len(nodes) // 2]), nest(nodes[len(nodes) // 2:])])
+    leaves = [("leaf", x) for x in names]
+    if kind == "mixed":
+        ors = [("or", [leaves[2 * i], leaves[2 * i + 1]]) for i in range(len(leaves) // 2)]
+        return nest(ors) if binary_and_only else ("and", ors)
+    if kind == "flat" and not binary_and_only:
+        return ("and", leaves)
+    return nest(leaves)
+
+
+def rand_fr_bytes(irnd, n):
+    """n canonical Fr values of 248 random bits each (< r): bulk randomness for throughput runs"""
+    raw = irnd.randbytes(31 * n)
+    return b"".join(raw[31 * i:31 * i + 31] + b"\0" for i in range(n)) or bytes(32)
+
+
+# ====================================================================================================================== LSW
+class LswBench:
+    """config 4: lsw::keygen + lsw::decrypt of a pre-made ciphertext, n positive leaves, a fresh key per item."""
+    metric = "ABE ops/sec (LSW KP-ABE keygen+decrypt)"
+    default_group = 2
+    survey_fpmul_per_item = 3.0e6               # SURVEY.md 8d, config 4 restructured work
+    launches_per_submit = {}
+
+    def __init__(self, r):
+        from rabe_amd import engine as E
+        from rabe_amd import hostprep as hp
+        self.r, self.E, self.hp = r, E, hp
+        args, eng = r.args, r.eng
+        self.B = args.batch or 2048
+        self.n_attr = args.attrs or 200
+        R, le = hp.R_ORDER, hp.fr_le
+        krnd = random.Random(args.seed * 1000003 + 4)
+
+        def kfr():
+            return krnd.randrange(1, R)
+        g1 = eng.g1_mul([G1_GEN], [le(kfr())])[0]
+        g2 = eng.g2_mul([G2_GEN], [le(kfr())])[0]
+        self.alpha1, self.alpha2 = kfr(), kfr()
+        e_gg_alpha = eng.gt_pow(eng.pairing([g1], [g2]), [le(self.alpha1 * self.alpha2)])[0]
+        eng.sync()
+        t0 = time.perf_counter()
+        self.pk = E.LswPk(eng, g1, g2)
+        eng.sync()
+        self.table_build_ms = 1e3 * (time.perf_counter() - t0)
+        self.attrs = ["c%d" % i for i in range(self.n_attr)]
+        # the pre-made ciphertext (lsw::encrypt, lsw/mod.rs:180-219): E1_y = (g1*h(a))*s, e2 = g2*s, e1 = e_gg_alpha^s * msg
+        s = kfr()
+        t1 = eng.g1_table(g1)
+        self.d_ct_e1j = eng.upload(b"".join(t1.mul([le(hp.h_fr(a) * s) for a in self.attrs])))
+        t1.destroy()
+        self.d_ct_e2 = eng.upload(eng.g2_mul([g2], [le(s)])[0])
+        self.msg = eng.gt_pow([e_gg_alpha], [le(kfr())])[0]
+        self.e1 = eng.gt_mul([eng.gt_pow([e_gg_alpha], [le(s)])[0]], [self.msg])[0]
+        self.d_ct_attr_off = eng.upload_u32([0, self.n_attr])
+        self.e2_lines = None if args.no_prepared_sk else E.G2Lines(eng, 1, self.d_ct_e2)
+        self.d_alpha = eng.upload(le(self.alpha1) + le(self.alpha2))
+        prnd = random.Random(args.seed)
+        self.trees = []
+        for _ in range(args.policies):
+            names = list(self.attrs)
+            prnd.shuffle(names)
+            self.trees.append(make_tree(args.tree, names))
+        t0 = time.perf_counter()
+        self.tt = hp.TreeTables(self.trees)
+        self.sel = []
+        for t in self.trees:
+            ok, idx = hp.pruned_leaf_indices(self.attrs, t)
+            assert ok
+            z = hp.leaf_coefficients(t)
+            names = hp.flatten_tree(t)["names"]
+            self.sel.append((idx, [self.attrs.index(names[y]) for y in idx], [z[y] for y in idx]))
+        self.host_prep_ms_per_policy = 1e3 * (time.perf_counter() - t0) / len(self.trees)
+        self.dtt = E.DevTreeTables(eng, self.tt)
+
+    def prepare(self, G, lanes):
+        r, eng, hp, tt = self.r, self.r.eng, self.hp, self.tt
+        le = hp.fr_le
+        B, P = self.B, len(self.trees)
+        GB = G * B
+        self.G, self.lanes = G, lanes
+        pol = [i % P for i in range(GB)]
+        sel_start_p, so, sel_sk, sel_ct, sel_z = [], 0, [], [], []
+        for idx, cta, z in self.sel:
+            sel_start_p.append(so)
+            sel_sk += idx
+            sel_ct += cta
+            sel_z += z
+            so += len(idx)
+        self.n_sel = so
+        leaf_off, pair_off, coef_off = [0], [0], [0]
+        for p in pol:
+            leaf_off.append(leaf_off[-1] + tt.n_leaves(p))
+            pair_off.append(pair_off[-1] + len(self.sel[p][0]) + 1)
+            coef_off.append(coef_off[-1] + tt.n_coef(p))
+        assert all(leaf_off[(j + 1) * B] == (j + 1) * leaf_off[B] for j in range(G)), "batch must be a multiple of the policy count"
+        self.leaves_per_batch, self.pairs_per_batch = leaf_off[B], pair_off[B]
+        self.max_pairs = max(len(s[0]) + 1 for s in self.sel)
+        self.d_leaf_off = eng.upload_u32(leaf_off)
+        self.d_pair_off = eng.upload_u32(pair_off)
+        self.d_item_tree_leaf = eng.upload_u32([tt.first_leaf[p] for p in pol])
+        self.d_item_tree_gate = eng.upload_u32([tt.first_gate[p] for p in pol])
+        self.d_item_coef_off = eng.upload_u32(coef_off[:-1])
+        self.d_sel_start = eng.upload_u32([sel_start_p[p] for p in pol])
+        self.d_sel_sk, self.d_sel_ct = eng.upload_u32(sel_sk), eng.upload_u32(sel_ct)
+        self.d_sel_z = eng.upload(b"".join(le(z) for z in sel_z))
+        self.d_ct_idx = eng.upload_u32([0] * GB)
+        self.d_ct_e1 = eng.upload(self.e1 * GB)
+        irnd = random.Random(r.args.seed * 7919 + 19 + r.rank)
+        self.d_coef = eng.upload(rand_fr_bytes(irnd, coef_off[-1]))
+        self.d_rand = eng.upload(rand_fr_bytes(irnd, leaf_off[-1]))
+        total = leaf_off[-1]
+        self.bufs = [(e_.alloc(total * 64), e_.alloc(total * 128), ExtBuf(r.torch, GB * 384, r.dev)) for e_ in lanes]
+        eng.sync()
+
+    def submit(self, lane, g):
+        E, e_ = self.E, self.lanes[lane]
+        d1, d2, out = self.bufs[lane]
+        n = g * self.B
+        E.lsw_keygen_dev(e_, self.pk, n, g * self.leaves_per_batch, self.d_leaf_off, self.d_item_tree_leaf, self.d_item_tree_gate, self.dtt,
+                         self.d_alpha, self.d_coef, self.d_item_coef_off, self.d_rand, d1, d2)
+        if self.r.args.only_encrypt:
+            return
+        E.lsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_sk, self.d_sel_ct,
+                          self.d_sel_z, self.d_ct_e1, self.d_ct_e2, self.d_ct_e1j, self.d_ct_attr_off, self.d_ct_idx, d1, d2, self.d_leaf_off, None,
+                          self.e2_lines, out)
+
+    def check(self, lane, g):
+        n = g * self.B
+        return self.bufs[lane][2].t[:n * 384].cpu().numpy().tobytes() == self.msg * n
+
+    def describe(self):
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        return {"workload": "LSW KP-ABE, keygen under a %d-leaf %s policy (%d distinct) + decrypt of a pre-made %d-attribute ciphertext, batch %d per GPU"
+                            % (self.n_attr, self.r.args.tree, len(self.trees), self.n_attr, self.B),
+                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "pruned_leaves_avg": round(m, 2),
+                "pairings_per_item": round(m + 1, 1), "reference_pairings_per_item": round(2 * m, 1), "prepared_ciphertext_e2": self.e2_lines is not None,
+                "table_build_ms_per_public_key": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
+
+    def algorithmic_fpmul_per_item(self):
+        # SURVEY.md 8d config 4: keygen 200 fixed-base G1 + 200 fixed-base G2; dec 400 var-base G1 (1.12 MM: 200 scaled E1, 200 in the
+        # sum of D1) + 201 Miller (1.6 MM) + 1 final exponentiation
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        n = self.n_attr
+        return {"k_miller_multi": (m + 1) * 8000.0, "k_lsw_dec_pairs": m * 2800.0, "k_msm_partial_g1": m * 2800.0, "k_final_exp": 9000.0,
+                "k_table_mul_g2": n * 1056.0, "k_table_mul_g1": n * 352.0}
+
+    def impl_fpmul_per_item(self):
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        return {"k_miller_multi": (m + 1) * 6240.0, "k_lsw_dec_pairs": m * 2750.0, "k_msm_partial_g1": m * 1080.0}
+
+    def algorithmic_bytes_per_step(self):
+        return self.leaves_per_batch * (192 + 32 + 32) + self.B * (384 + 384) + self.pairs_per_batch * 4
+
+    def cpu_baseline(self):
+        from oracle import cport
+        if not cport.available():
+            return {"error": "oracle/c not built"}
+        n = self.r.args.cpu_sample or 6
+        dt = cport.lsw_keygen_dec(self.n_attr, n, tree=self.r.args.tree, seed=self.r.args.seed)
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+                "sample": "%d LSW keygen+decrypt at %d leaves (%s tree) in %.1f s; the reference's operation order (lsw/mod.rs:121-170,228-290: "
+                          "three G1 and one G2 binary double-and-add multiplications per leaf in keygen, two full pairings and a Gt::pow per leaf "
+                          "in decrypt) over the C primitives of oracle/c/rabe_ref.c, single thread like the reference"
+                          % (n, self.n_attr, self.r.args.tree, dt)}
+
+    def close(self):
+        if self.e2_lines:
+            self.e2_lines.destroy()
+        self.pk.destroy()
+
+
+# ====================================================================================================================== AW11
+class Aw11Bench:
+    """config 5: aw11::encrypt + aw11::decrypt, 10 authorities x 20 attributes, a user key with all attributes."""
+    metric = "ABE ops/sec (AW11 multi-authority CP-ABE encrypt+decrypt)"
+    default_group = 4
+    survey_fpmul_per_item = 9.5e6               # SURVEY.md 8d, config 5 restructured work
+    launches_per_submit = {}
+
+    def __init__(self, r):
+        from rabe_amd import engine as E
+        from rabe_amd import hostprep as hp
+        self.r, self.E, self.hp = r, E, hp
+        args, eng = r.args, r.eng
+        self.B = args.batch or 1024
+        self.n_attr = args.attrs or 200
+        self.n_auth = 10
+        R, le = hp.R_ORDER, hp.fr_le
+        krnd = random.Random(args.seed * 1000003 + 5)
+
+        def kfr():
+            return krnd.randrange(1, R)
+        g1 = eng.g1_mul([G1_GEN], [le(kfr())])[0]
+        g2 = eng.g2_mul([G2_GEN], [le(kfr())])[0]
+        egg = eng.pairing([g1], [g2])[0]
+        per = self.n_attr // self.n_auth
+        self.attrs = ["AUTH%dX%d" % (i // per, i % per) for i in range(self.n_attr)]          # upper-case, no '_' (aw11/mod.rs:137)
+        alpha = [kfr() for _ in self.attrs]
+        y = [kfr() for _ in self.attrs]
+        te, t2, t1 = eng.gt_table(egg), eng.g2_table(g2), eng.g1_table(g1)
+        egg_alpha = te.mul([le(a) for a in alpha])
+        g2_y = t2.mul([le(v) for v in y])
+        eng.sync()
+        t0 = time.perf_counter()
+        self.pk = E.Aw11Pk(eng, g1, g2, egg_alpha, g2_y)
+        eng.sync()
+        self.table_build_ms = 1e3 * (time.perf_counter() - t0)
+        # the user's key (aw11::keygen, :165-231): K_x = g1*alpha_x + (g1*h(gid))*y_x = g1 * (alpha_x + h(gid) y_x)
+        hg = hp.h_fr("alice")
+        self.d_sk_k = eng.upload(b"".join(t1.mul([le(a + hg * v) for a, v in zip(alpha, y)])))
+        self.d_sk_hash = eng.upload(t1.mul([le(hg)])[0])
+        self.d_sk_attr_off = eng.upload_u32([0, self.n_attr])
+        t1.destroy()
+        t2.destroy()
+        self.e_tab = te
+        prnd = random.Random(args.seed)
+        self.trees = []
+        for _ in range(args.policies):
+            names = list(self.attrs)
+            prnd.shuffle(names)
+            self.trees.append(make_tree("nested" if args.tree == "flat" else args.tree, names, binary_and_only=True))
+        t0 = time.perf_counter()
+        self.tt = hp.TreeTables(self.trees)
+        self.sel = []
+        for t in self.trees:
+            ok, idx = hp.pruned_leaf_indices(self.attrs, t)
+            assert ok
+            z = hp.leaf_coefficients(t)
+            names = hp.flatten_tree(t)["names"]
+            self.sel.append((idx, [self.attrs.index(names[y_]) for y_ in idx], [z[y_] for y_ in idx]))
+        self.host_prep_ms_per_policy = 1e3 * (time.perf_counter() - t0) / len(self.trees)
+        self.dtt = E.DevTreeTables(eng, self.tt)
+        self.d_leaf_attr = eng.upload_u32([self.attrs.index(nm) for f in self.tt.flat for nm in f["names"]])
+
+    def prepare(self, G, lanes):
+        r, eng, E, hp, tt = self.r, self.r.eng, self.E, self.hp, self.tt
+        R, le = hp.R_ORDER, hp.fr_le
+        B, P = self.B, len(self.trees)
+        GB = G * B
+        self.G, self.lanes = G, lanes
+        pol = [i % P for i in range(GB)]
+        sel_start_p, so, sel_ct, sel_sk, sel_z = [], 0, [], [], []
+        for idx, ska, z in self.sel:
+            sel_start_p.append(so)
+            sel_ct += idx
+            sel_sk += ska
+            sel_z += z
+            so += len(idx)
+        self.n_sel = so
+        row_off, pair_off, coef_off = [0], [0], [0]
+        for p in pol:
+            row_off.append(row_off[-1] + tt.n_leaves(p))
+            pair_off.append(pair_off[-1] + len(self.sel[p][0]) + 1)
+            coef_off.append(coef_off[-1] + 2 * tt.n_coef(p))
+        assert all(row_off[(j + 1) * B] == (j + 1) * row_off[B] for j in range(G)), "batch must be a multiple of the policy count"
+        self.rows_per_batch, self.pairs_per_batch = row_off[B], pair_off[B]
+        self.max_pairs = max(len(s[0]) + 1 for s in self.sel)
+        self.d_row_off = eng.upload_u32(row_off)
+        self.d_pair_off = eng.upload_u32(pair_off)
+        self.d_item_tree_leaf = eng.upload_u32([tt.first_leaf[p] for p in pol])
+        self.d_item_tree_gate = eng.upload_u32([tt.first_gate[p] for p in pol])
+        self.d_item_n_coef = eng.upload_u32([tt.n_coef(p) for p in pol])
+        self.d_item_coef_off = eng.upload_u32(coef_off[:-1])
+        self.d_sel_start = eng.upload_u32([sel_start_p[p] for p in pol])
+        self.d_sel_ct, self.d_sel_sk = eng.upload_u32(sel_ct), eng.upload_u32(sel_sk)
+        self.d_sel_z = eng.upload(b"".join(le(z) for z in sel_z))
+        self.d_sk_idx = eng.upload_u32([0] * GB)
+        irnd = random.Random(r.args.seed * 7919 + 23 + r.rank)
+        self.d_s = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        rho = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        self.d_msg = eng.alloc(GB * 384)
+        eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(GB), rho.ptr, self.d_msg.ptr))
+        self.d_coef = eng.upload(rand_fr_bytes(irnd, coef_off[-1]))
+        self.d_rand = eng.upload(rand_fr_bytes(irnd, row_off[-1]))
+        total = row_off[-1]
+        self.bufs = [(e_.alloc(GB * 384), e_.alloc(total * 384), e_.alloc(total * 128), e_.alloc(total * 128), ExtBuf(r.torch, GB * 384, r.dev))
+                     for e_ in lanes]
+        eng.sync()
+
+    def submit(self, lane, g):
+        E, e_ = self.E, self.lanes[lane]
+        c0, c1, c2, c3, out = self.bufs[lane]
+        n = g * self.B
+        E.aw11_encrypt_dev(e_, self.pk, n, g * self.rows_per_batch, self.d_row_off, self.d_item_tree_leaf, self.d_item_tree_gate, self.d_item_n_coef,
+                           self.dtt, self.d_leaf_attr, self.d_s, self.d_coef, self.d_item_coef_off, self.d_rand, self.d_msg, c0, c1, c2, c3)
+        if self.r.args.only_encrypt:
+            return
+        E.aw11_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_ct, self.d_sel_sk,
+                           self.d_sel_z, c0, c1, c2, c3, self.d_row_off, self.d_sk_hash, self.d_sk_k, self.d_sk_attr_off, self.d_sk_idx, out)
+
+    def check(self, lane, g):
+        n = g * self.B * 384
+        return self.bufs[lane][4].t[:n].cpu().numpy().tobytes() == self.r.eng.download(self.d_msg)[:n]
+
+    def describe(self):
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        tree = "nested" if self.r.args.tree == "flat" else self.r.args.tree
+        return {"workload": "AW11 multi-authority CP-ABE, %d authorities x %d attributes, %s binary-AND policy over all %d (%d distinct), batch %d "
+                            "encrypt+decrypt per GPU" % (self.n_auth, self.n_attr // self.n_auth, tree, self.n_attr, len(self.trees), self.B),
+                "attrs": self.n_attr, "authorities": self.n_auth, "policies": len(self.trees), "tree": tree, "pruned_leaves_avg": round(m, 2),
+                "pairings_per_item": round(m + 1, 1), "reference_pairings_per_item": round(2 * m + m + 1, 1),
+                "table_build_ms_per_public_key_set": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
+
+    def algorithmic_fpmul_per_item(self):
+        # SURVEY.md 8d config 5: enc 201 fixed-base Gt pow (0.34 MM) + 200 var-base Gt pow (1.6 MM) + 400 fixed-base + 200 var-base G2 (2.1 MM);
+        # dec 200 var-base G2 (1.7 MM) + 200 var-base G1 (0.56 MM) + 201 Miller (1.6 MM) + 200 var-base Gt pow (1.6 MM) + 1 final exponentiation
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        n = self.n_attr
+        return {"k_miller_multi": (m + 1) * 8000.0, "k_aw11_dec_pairs": m * 2800.0, "k_msm_partial_g2": m * 8400.0, "k_gt_multiexp_partial": m * 8000.0,
+                "k_final_exp": 9000.0, "k_aw11_enc_c1": n * (1700.0 + 8000.0), "k_aw11_enc_c3": n * (1056.0 + 8400.0), "k_table_mul_g2": n * 1056.0,
+                "k_table_pow_gt_mul": 1700.0}
+
+    def impl_fpmul_per_item(self):
+        m = sum(len(s[0]) for s in self.sel) / len(self.sel)
+        return {"k_miller_multi": (m + 1) * 6240.0}
+
+    def algorithmic_bytes_per_step(self):
+        return self.rows_per_batch * (384 + 256 + 32) * 2 + self.B * (32 + 384 * 3) + self.pairs_per_batch * 4
+
+    def cpu_baseline(self):
+        from oracle import cport
+        if not cport.available():
+            return {"error": "oracle/c not built"}
+        n = self.r.args.cpu_sample or 4
+        tree = "nested" if self.r.args.tree == "flat" else self.r.args.tree
+        dt = cport.aw11_encdec(self.n_attr, n, tree=tree, seed=self.r.args.seed)
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+                "sample": "%d AW11 encrypt+decrypt at %d attributes (%s tree) in %.1f s; the reference's operation order (aw11/mod.rs:241-289,298-366: "
+                          "a pairing e(g1,g2) and two Gt::pow per row in encrypt, two full pairings and a Gt::pow per row in decrypt, binary "
+                          "double-and-add everywhere) over the C primitives of oracle/c/rabe_ref.c, single thread like the reference"
+                          % (n, self.n_attr, tree, dt)}
+
+    def close(self):
         self.pk.destroy()

@@ -173,15 +173,26 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_item
   const Fp12 f = miller_loop_multi(acc);
   st_gt_m(mill + item * L + c, f);
 }
-// chunking of a batch: C pairs per lane (even, so that lines are merged two by two), L lanes per item
+// chunking of a batch: C pairs per lane (even, so that lines are merged two by two), L lanes per item.  The kernel runs one
+// wave per SIMD, so a launch of W waves takes ceil(W / #SIMDs) rounds of one lane's time; a lane's time is the shared
+// squarings (65 x 36 Fp multiplications) plus ~5.5 k per pair (tests/count_muls.py).  Pick the C that minimises rounds x
+// lane time: e.g. 4096 items x 201 pairs -> C = 14, L = 15: 960 waves, one round (C = 12 would need a second round for 64 waves).
 static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs, uint32_t* L, uint32_t* C) {
   if (max_pairs < 1) max_pairs = 1;
   const size_t simds = (size_t)ctx->n_cu * 4;
-  size_t c = 16;                                        // the shared squaring is then ~5 % of a lane's work
-  // small batches: more, shorter lanes until the chip is covered once (one wave per SIMD)
-  while (c > 2 && n_items * ((max_pairs + c - 1) / c) < simds * 64) c -= 2;
-  size_t l = (max_pairs + c - 1) / c;
-  c = (max_pairs + l - 1) / l;
+  double best = 0;
+  size_t best_c = 2;
+  for (size_t c = 2; c <= 64; c += 2) {
+    const size_t l = (max_pairs + c - 1) / c;
+    const size_t c_eff = (max_pairs + l - 1) / l;
+    const size_t waves = (n_items * l + 63) / 64;
+    const size_t rounds = (waves + simds - 1) / simds;
+    const double cost = (double)rounds * (2340.0 + 5500.0 * (double)c_eff);
+    if (best == 0 || cost < best) { best = cost; best_c = c; }
+    if (l == 1) break;
+  }
+  size_t l = (max_pairs + best_c - 1) / best_c;
+  size_t c = (max_pairs + l - 1) / l;
   if (c & 1) c++;
   l = (max_pairs + c - 1) / c;
   *L = (uint32_t)l;
@@ -515,12 +526,23 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_msm_finish_g2(size_t n_it
   const Fp2 zinv{mul(acc.z.c0, ninv), neg(mul(acc.z.c1, ninv))};
   st_g2_q(Q + last, jac_to_aff_with_zinv(acc, zinv));
 }
+// chunking of the shared-doubling sums: a lane pays its own 254 doublings / squarings (~1.8 k in G1, ~4 k in G2, ~4.6 k in Gt)
+// plus ~1 k (G1) .. 4.6 k (Gt) per term; same rounds x lane-time model as choose_chunks with a 2 : 1 doubling-to-term ratio
 static void choose_msm_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_terms, uint32_t* L, uint32_t* C) {
   if (max_terms < 1) max_terms = 1;
   const size_t simds = (size_t)ctx->n_cu * 4;
-  size_t c = 32;                                        // the lane's own 254 doublings are then ~6 % of its work (G1)
-  while (c > 4 && n_items * ((max_terms + c - 1) / c) < simds * 64) c -= 4;
-  const size_t l = (max_terms + c - 1) / c;
+  double best = 0;
+  size_t best_c = 1;
+  for (size_t c = 1; c <= 256; c++) {
+    const size_t l = (max_terms + c - 1) / c;
+    const size_t c_eff = (max_terms + l - 1) / l;
+    const size_t waves = (n_items * l + 63) / 64;
+    const size_t rounds = (waves + simds - 1) / simds;
+    const double cost = (double)rounds * (2.0 + (double)c_eff);
+    if (best == 0 || cost < best) { best = cost; best_c = c; }
+    if (l == 1) break;
+  }
+  const size_t l = (max_terms + best_c - 1) / best_c;
   *C = (uint32_t)((max_terms + l - 1) / l);
   *L = (uint32_t)l;
 }

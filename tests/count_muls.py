@@ -58,3 +58,36 @@ res["g1_mul_binary(254-bit) + to_affine incl. io"] = count("hs_g1_mul", P, le(rn
 res["g2_mul_binary(254-bit) + to_affine incl. io"] = count("hs_g2_mul", Q, le(rnd.randrange(bn.R)), out=128)
 res["gt_pow_binary(254-bit) incl. io"] = count("hs_gt_pow", f, le(rnd.randrange(bn.R)))
 print(json.dumps(res, indent=1))
+
+# ---- the job kernels' code paths (engine_jobs.hip): counts per lane; conversions of the harness (loads / stores / line preparation)
+# are subtracted so that the figures are what a device lane executes
+def count_multi(kinds):
+    n = len(kinds)
+    ps = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, rnd.randrange(1, bn.R))) for _ in range(n))
+    qs = b"".join(bn.g2_to_le(bn.g2_mul(bn.G2_GEN, rnd.randrange(1, bn.R))) for _ in range(n))
+    o = (ctypes.c_uint32 * 96)()
+    HS.hs_mul_counter_reset()
+    HS.hs_pairing_multi(n, (ctypes.c_int * n)(*kinds), b2c(ps), b2c(qs), o)
+    total = HS.hs_mul_counter_reset()
+    prep = res["g2_prepare_lines (88 line triples) incl. io"] - 4 - 6            # one preparation without its loads (4) / stores (6)
+    return total - n * (2 + 4) - sum(1 for k in kinds if k == 1) * prep - res["final_exponentiation incl. 12 loads 12 stores"] + 12
+
+
+jobs = {}
+jobs["miller_loop_multi, 14 pairs: 7 prepared + 7 walking (a bsw chunk with a prepared key)"] = count_multi([1, 0] * 7)
+jobs["miller_loop_multi, 14 walking pairs (bsw / lsw / aw11 chunk, nothing prepared)"] = count_multi([0] * 14)
+jobs["miller_loop_multi, 2 walking pairs"] = count_multi([0, 0])
+jobs["miller_loop_multi, 1 walking pair"] = count_multi([0])
+jobs["miller_loop_multi, 1 prepared pair"] = count_multi([1])
+k_full = rnd.randrange(bn.R)
+jobs["jac_mul_naf G1 (254-bit) + to_affine incl. io"] = count("hs_g1_mul_naf", P, le(k_full), out=64)
+jobs["jac_mul_naf G2 (254-bit) + to_affine incl. io"] = count("hs_g2_mul_naf", Q, le(k_full), out=128)
+jobs["jac_mul_naf G1 (k = 2) + to_affine incl. io"] = count("hs_g1_mul_naf", P, le(2), out=64)
+n = 16
+pts = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, rnd.randrange(1, bn.R))) for _ in range(n))
+ks = b"".join(le(rnd.randrange(bn.R)) for _ in range(n))
+o = (ctypes.c_uint32 * 16)()
+HS.hs_mul_counter_reset()
+HS.hs_g1_msm(n, b2c(pts), b2c(ks), o)
+jobs["jac_msm_naf G1, 16 terms (254-bit) + to_affine incl. io"] = HS.hs_mul_counter_reset()
+print(json.dumps(jobs, indent=1))
