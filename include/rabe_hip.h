@@ -87,7 +87,8 @@ int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other);
  *   Gt: * inverse pow                ac17/mod.rs:357-360,418; bsw/mod.rs:234,291-294,308
  *   pairing(G1,G2)                   ac17/mod.rs:148,415-416; bsw/mod.rs:108,292-293,308
  */
-enum { RHIP_FR_ADD = 0, RHIP_FR_SUB = 1, RHIP_FR_MUL = 2, RHIP_FR_NEG = 3, RHIP_FR_INV = 4 };
+/* RHIP_FR_POW: out = a^b with b read as an integer (`Fr::pow(Fr)`, src/utils/secretsharing/mod.rs:218) */
+enum { RHIP_FR_ADD = 0, RHIP_FR_SUB = 1, RHIP_FR_MUL = 2, RHIP_FR_NEG = 3, RHIP_FR_INV = 4, RHIP_FR_POW = 5 };
 int32_t rhip_fr_op(rhip_ctx* ctx, int32_t op, size_t n, const rhip_fr* dev_a, const rhip_fr* dev_b, rhip_fr* dev_out);
 /* `Fr::from_slice` of n 32-byte BIG-endian digests: integer mod r */
 int32_t rhip_fr_from_be32_reduce(rhip_ctx* ctx, size_t n, const uint8_t* dev_digests, rhip_fr* dev_out);
@@ -119,7 +120,11 @@ int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* dev_
  * operator-overloading replacement of the `rabe_bn` crate binds (`impl Mul<Fr> for G1`, `pairing(p, q)`, ...; see
  * INTEGRATION.md section 2 and integration/rabe-bn-shim/): whole-program parity runs of unmodified rabe, not throughput. */
 int32_t rhip_host_fr_op(rhip_ctx* ctx, int32_t op, const rhip_fr* a, const rhip_fr* b /* NULL for NEG / INV */, rhip_fr* out);
+int32_t rhip_host_fr_pow(rhip_ctx* ctx, const rhip_fr* a, const rhip_fr* e, rhip_fr* out);
 int32_t rhip_host_fr_from_be32_reduce(rhip_ctx* ctx, const uint8_t digest[32], rhip_fr* out);
+/* curve membership of a decoded point (what makes `FieldError::NotMember`, src/error.rs:66): *ok = 1 on the curve or infinity */
+int32_t rhip_host_g1_on_curve(rhip_ctx* ctx, const rhip_g1* p, int32_t* ok);
+int32_t rhip_host_g2_on_curve(rhip_ctx* ctx, const rhip_g2* p, int32_t* ok);
 int32_t rhip_host_g1_add(rhip_ctx* ctx, const rhip_g1* a, const rhip_g1* b, rhip_g1* out);
 int32_t rhip_host_g1_neg(rhip_ctx* ctx, const rhip_g1* a, rhip_g1* out);
 int32_t rhip_host_g1_mul(rhip_ctx* ctx, const rhip_g1* p, const rhip_fr* k, rhip_g1* out);

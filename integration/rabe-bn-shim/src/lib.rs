@@ -1,12 +1,24 @@
-//! `rabe_bn` surface used by rabe (`use rabe_bn::{Group, Gt, G1, G2, Fr, pairing}`: src/schemes/ac17/mod.rs:42,
-//! bsw/mod.rs:23, lsw/mod.rs:23, aw11/mod.rs:27, utils/hash/mod.rs:1, utils/secretsharing/mod.rs:1), implemented over the
-//! host-value Level E functions of the HIP engine (`rhip_host_*`, include/rabe_hip.h).  Every value is the engine's wire
-//! record: canonical little-endian, affine, infinity = zeros -- so `==` is byte equality and `normalize` is the identity.
+//! `rabe_bn` surface used by rabe, implemented over the host-value Level E functions of the HIP engine (`rhip_host_*`,
+//! include/rabe_hip.h).  Audited against every `use rabe_bn::` site of rabe 0.4.2:
 //!
-//! One launch per operator: this crate exists to run unmodified rabe against the engine for whole-program parity, not for
-//! throughput (the batch path of INTEGRATION.md section 1 is the fast one).
+//! | rabe call site                                                        | what it needs                                    |
+//! |-----------------------------------------------------------------------|--------------------------------------------------|
+//! | `src/schemes/{ac17,bsw,lsw,aw11,ghw11}/mod.rs` (`Group, Gt, G1, G2, Fr, pairing`) | `+ - neg`, `* Fr`, `G::zero/one`, `Gt::one`, `Gt::pow`, `Gt::inverse`, `Gt * Gt`, `Fr::inverse() -> Option`, `pairing`, `rng.gen::<Fr / G1 / G2 / Gt>()`, `Copy + Clone + PartialEq + Debug` (the key / ciphertext structs derive them, ac17/mod.rs:59) |
+//! | `src/schemes/*` struct derives behind `serde` / `borsh` (ac17/mod.rs:60-61, Cargo.toml:19-20 forwards the features) | `Serialize + Deserialize`, `BorshSerialize + BorshDeserialize` for `Fr, G1, G2, Gt` |
+//! | `src/utils/hash/mod.rs:16,27`                                         | `Fr::from_slice(&[u8]) -> Result<Fr, FieldError>` |
+//! | `src/utils/secretsharing/mod.rs:25-28,66,133,218`                     | `Fr::one/zero`, `+ - *`, `inverse`, `rng.gen()`, `Fr::pow(Fr)` |
+//! | `src/utils/tools/mod.rs:12`                                           | `Fr::from_str(&str) -> Option<Fr>`               |
+//! | `src/utils/aes/mod.rs:10,29,47`                                       | `Into<Vec<u8>> for Gt`                           |
+//! | `src/error.rs:10,60-69`                                               | `enum FieldError { InvalidSliceLength, InvalidU512Encoding, NotMember }` |
+//! | `src/utils/policy/dnf.rs:2` (out-of-scope schemes)                    | `Group, Gt, G1, G2` as above                      |
 //!
-//! Conventions that cannot be checked without the real crate's source are isolated and marked `ASSUMPTION`.
+//! Every value is the engine's wire record: canonical little-endian, affine, infinity = zeros -- so `==` is byte equality
+//! and `normalize` is the identity.  One launch per operator: this crate exists to run unmodified rabe against the engine
+//! for whole-program parity, not for throughput (the batch path of INTEGRATION.md section 1 is the fast one).
+//!
+//! NOT COMPILED in this repository (no Rust toolchain in the build container).  Conventions that cannot be checked without
+//! the real crate's source are isolated and marked `ASSUMPTION`: byte layouts of the serde / borsh
+//! forms, `Into<Vec<u8>> for Gt`, how random group elements are sampled.
 use std::ops::{Add, Mul, Neg, Sub};
 use std::os::raw::c_char;
 use std::sync::Once;
@@ -22,13 +34,16 @@ extern "C" {
     fn rhip_ctx_create(device: i32, out: *mut *mut RhipCtx) -> i32;
     fn rhip_last_error(ctx: *mut RhipCtx) -> *const c_char;
     fn rhip_host_fr_op(ctx: *mut RhipCtx, op: i32, a: *const Fr, b: *const Fr, out: *mut Fr) -> i32;
+    fn rhip_host_fr_pow(ctx: *mut RhipCtx, a: *const Fr, e: *const Fr, out: *mut Fr) -> i32;
     fn rhip_host_fr_from_be32_reduce(ctx: *mut RhipCtx, digest: *const u8, out: *mut Fr) -> i32;
     fn rhip_host_g1_add(ctx: *mut RhipCtx, a: *const G1, b: *const G1, out: *mut G1) -> i32;
     fn rhip_host_g1_neg(ctx: *mut RhipCtx, a: *const G1, out: *mut G1) -> i32;
     fn rhip_host_g1_mul(ctx: *mut RhipCtx, p: *const G1, k: *const Fr, out: *mut G1) -> i32;
+    fn rhip_host_g1_on_curve(ctx: *mut RhipCtx, p: *const G1, ok: *mut i32) -> i32;
     fn rhip_host_g2_add(ctx: *mut RhipCtx, a: *const G2, b: *const G2, out: *mut G2) -> i32;
     fn rhip_host_g2_neg(ctx: *mut RhipCtx, a: *const G2, out: *mut G2) -> i32;
     fn rhip_host_g2_mul(ctx: *mut RhipCtx, p: *const G2, k: *const Fr, out: *mut G2) -> i32;
+    fn rhip_host_g2_on_curve(ctx: *mut RhipCtx, p: *const G2, ok: *mut i32) -> i32;
     fn rhip_host_gt_mul(ctx: *mut RhipCtx, a: *const Gt, b: *const Gt, out: *mut Gt) -> i32;
     fn rhip_host_gt_inv(ctx: *mut RhipCtx, a: *const Gt, out: *mut Gt) -> i32;
     fn rhip_host_gt_pow(ctx: *mut RhipCtx, a: *const Gt, k: *const Fr, out: *mut Gt) -> i32;
@@ -57,6 +72,14 @@ fn ok(rc: i32) {
     }
 }
 
+/// `rabe_bn::FieldError` exactly as `impl From<FieldError> for RabeError` matches it (src/error.rs:60-69).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum FieldError {
+    InvalidSliceLength,
+    InvalidU512Encoding,
+    NotMember,
+}
+
 /// `rabe_bn::Group` as rabe uses it: `zero`, `one`, `random`, `is_zero`, `normalize`.
 pub trait Group: Sized + Copy + PartialEq + Add<Output = Self> + Sub<Output = Self> + Neg<Output = Self> + Mul<Fr, Output = Self> {
     fn zero() -> Self;
@@ -67,7 +90,14 @@ pub trait Group: Sized + Copy + PartialEq + Add<Output = Self> + Sub<Output = Se
 }
 
 // ------------------------------------------------------------------------------------------------ Fr
-#[derive(Debug)] pub struct FieldError;
+// r, little-endian limbs (for the canonical-range check of decoded scalars)
+const R_MOD: [u32; 8] = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72];
+fn below_r(l: &[u32; 8]) -> bool {
+    for i in (0..8).rev() {
+        if l[i] != R_MOD[i] { return l[i] < R_MOD[i]; }
+    }
+    false
+}
 impl Fr {
     pub fn zero() -> Fr { Fr([0; 8]) }
     pub fn one() -> Fr { let mut l = [0u32; 8]; l[0] = 1; Fr(l) }
@@ -81,15 +111,16 @@ impl Fr {
     }
     /// ASSUMPTION: 32 big-endian bytes, reduced mod r (`sha3_hash`, src/utils/hash/mod.rs:16,27, feeds digests here).
     pub fn from_slice(b: &[u8]) -> Result<Fr, FieldError> {
-        if b.len() != 32 { return Err(FieldError); }
+        if b.len() != 32 { return Err(FieldError::InvalidSliceLength); }
         let mut o = Fr::zero();
         ok(unsafe { rhip_host_fr_from_be32_reduce(ctx(), b.as_ptr(), &mut o) });
         Ok(o)
     }
-    /// decimal string (`Fr::from_str`, src/utils/secretsharing/mod.rs)
+    /// decimal string (`usize_to_fr`, src/utils/tools/mod.rs:11-13)
     pub fn from_str(s: &str) -> Option<Fr> {
         let ten = Fr([10, 0, 0, 0, 0, 0, 0, 0]);
         let mut acc = Fr::zero();
+        if s.is_empty() { return None; }
         for c in s.bytes() {
             if !c.is_ascii_digit() { return None; }
             acc = acc * ten + Fr([(c - b'0') as u32, 0, 0, 0, 0, 0, 0, 0]);
@@ -101,6 +132,12 @@ impl Fr {
         let mut o = Fr::zero();
         ok(unsafe { rhip_host_fr_op(ctx(), FR_INV, self, std::ptr::null(), &mut o) });
         Some(o)
+    }
+    /// `x.pow(usize_to_fr(j))` in `polynomial` (src/utils/secretsharing/mod.rs:218): self^exp, exp read as an integer
+    pub fn pow(&self, exp: Fr) -> Fr {
+        let mut o = Fr::zero();
+        ok(unsafe { rhip_host_fr_pow(ctx(), self, &exp, &mut o) });
+        o
     }
     pub fn is_zero(&self) -> bool { *self == Fr::zero() }
 }
@@ -155,3 +192,127 @@ impl rand::distributions::Distribution<G2> for rand::distributions::Standard { f
 
 /// optimal-ate pairing with the libff / zcash-bn final-exponentiation chain
 pub fn pairing(p: G1, q: G2) -> Gt { let mut o = Gt::one(); ok(unsafe { rhip_host_pairing(ctx(), &p, &q, &mut o) }); o }
+
+// ------------------------------------------------------------------------------------------------ byte forms (serde / borsh)
+// ASSUMPTION: the byte layout.  rabe-bn's own encodings are unknown here; this crate encodes every
+// element as its canonical wire record (little-endian limbs, the layouts of include/rabe_hip.h), so rabe built against it
+// round-trips its own files; interoperability with files written by the real rabe-bn is the open item of DESIGN.md 7.
+// Decoding validates what rabe-bn's decoding validates: scalars are < r, points are on the curve (FieldError::NotMember).
+trait Wire: Sized {
+    const BYTES: usize;
+    fn to_wire(&self, out: &mut [u8]);
+    fn from_wire(b: &[u8]) -> Result<Self, FieldError>;
+}
+fn words_to_bytes(w: &[u32], out: &mut [u8]) { for (i, x) in w.iter().enumerate() { out[4 * i..4 * i + 4].copy_from_slice(&x.to_le_bytes()); } }
+fn bytes_to_words<const N: usize>(b: &[u8]) -> Result<[u32; N], FieldError> {
+    if b.len() != 4 * N { return Err(FieldError::InvalidSliceLength); }
+    let mut w = [0u32; N];
+    for i in 0..N { w[i] = u32::from_le_bytes([b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]]); }
+    Ok(w)
+}
+impl Wire for Fr {
+    const BYTES: usize = 32;
+    fn to_wire(&self, out: &mut [u8]) { words_to_bytes(&self.0, out) }
+    fn from_wire(b: &[u8]) -> Result<Fr, FieldError> {
+        let w = bytes_to_words::<8>(b)?;
+        if !below_r(&w) { return Err(FieldError::NotMember); }
+        Ok(Fr(w))
+    }
+}
+impl Wire for G1 {
+    const BYTES: usize = 64;
+    fn to_wire(&self, out: &mut [u8]) { words_to_bytes(&self.0, out) }
+    fn from_wire(b: &[u8]) -> Result<G1, FieldError> {
+        let p = G1(bytes_to_words::<16>(b)?);
+        let mut on = 0i32;
+        ok(unsafe { rhip_host_g1_on_curve(ctx(), &p, &mut on) });
+        if on == 1 { Ok(p) } else { Err(FieldError::NotMember) }
+    }
+}
+impl Wire for G2 {
+    const BYTES: usize = 128;
+    fn to_wire(&self, out: &mut [u8]) { words_to_bytes(&self.0, out) }
+    fn from_wire(b: &[u8]) -> Result<G2, FieldError> {
+        let p = G2(bytes_to_words::<32>(b)?);
+        let mut on = 0i32;
+        ok(unsafe { rhip_host_g2_on_curve(ctx(), &p, &mut on) });
+        // r-torsion: the twist has cofactor > 1, so an on-curve point may still be outside G2
+        if on == 1 && (p * (Fr::zero() - Fr::one()) + p).is_zero() { Ok(p) } else { Err(FieldError::NotMember) }
+    }
+}
+impl Wire for Gt {
+    const BYTES: usize = 384;
+    fn to_wire(&self, out: &mut [u8]) { words_to_bytes(&self.0, out) }
+    fn from_wire(b: &[u8]) -> Result<Gt, FieldError> {
+        let g = Gt(bytes_to_words::<96>(b)?);
+        // membership in the order-r subgroup: g^(r-1) * g == 1 (also rejects non-unitary values the engine's Gt::pow assumes away)
+        if g.pow(Fr::zero() - Fr::one()) * g == Gt::one() { Ok(g) } else { Err(FieldError::NotMember) }
+    }
+}
+
+#[cfg(feature = "serde")]
+mod serde_impl {
+    use super::*;
+    use serde::de::{Error, SeqAccess, Visitor};
+    use serde::ser::SerializeTuple;
+    use serde::{Deserialize, Deserializer, Serialize, Serializer};
+    use std::marker::PhantomData;
+    // a fixed-length tuple of bytes: the same data in binary and self-describing formats (JSON: an array of numbers)
+    struct WireVisitor<T>(PhantomData<T>);
+    impl<'de, T: Wire> Visitor<'de> for WireVisitor<T> {
+        type Value = T;
+        fn expecting(&self, f: &mut std::fmt::Formatter) -> std::fmt::Result { write!(f, "{} bytes", T::BYTES) }
+        fn visit_seq<A: SeqAccess<'de>>(self, mut seq: A) -> Result<T, A::Error> {
+            let mut b = vec![0u8; T::BYTES];
+            for (i, slot) in b.iter_mut().enumerate() {
+                *slot = seq.next_element()?.ok_or_else(|| A::Error::invalid_length(i, &self))?;
+            }
+            T::from_wire(&b).map_err(|e| A::Error::custom(format!("{:?}", e)))
+        }
+    }
+    macro_rules! serde_wire { ($t:ident) => {
+        impl Serialize for $t {
+            fn serialize<S: Serializer>(&self, s: S) -> Result<S::Ok, S::Error> {
+                let mut b = vec![0u8; <$t as Wire>::BYTES];
+                self.to_wire(&mut b);
+                let mut t = s.serialize_tuple(b.len())?;
+                for x in &b { t.serialize_element(x)?; }
+                t.end()
+            }
+        }
+        impl<'de> Deserialize<'de> for $t {
+            fn deserialize<D: Deserializer<'de>>(d: D) -> Result<$t, D::Error> { d.deserialize_tuple(<$t as Wire>::BYTES, WireVisitor::<$t>(PhantomData)) }
+        }
+    } }
+    serde_wire!(Fr);
+    serde_wire!(G1);
+    serde_wire!(G2);
+    serde_wire!(Gt);
+}
+
+#[cfg(feature = "borsh")]
+mod borsh_impl {
+    use super::*;
+    use borsh::io::{Error, ErrorKind, Read, Result, Write};
+    use borsh::{BorshDeserialize, BorshSerialize};
+    macro_rules! borsh_wire { ($t:ident) => {
+        impl BorshSerialize for $t {
+            fn serialize<W: Write>(&self, w: &mut W) -> Result<()> {
+                let mut b = vec![0u8; <$t as Wire>::BYTES];
+                self.to_wire(&mut b);
+                w.write_all(&b)
+            }
+        }
+        impl BorshDeserialize for $t {
+            fn deserialize_reader<R: Read>(r: &mut R) -> Result<$t> {
+                let mut b = vec![0u8; <$t as Wire>::BYTES];
+                r.read_exact(&mut b)?;
+                <$t as Wire>::from_wire(&b).map_err(|e| Error::new(ErrorKind::InvalidData, format!("{:?}", e)))
+            }
+        }
+    } }
+    borsh_wire!(Fr);
+    borsh_wire!(G1);
+    borsh_wire!(G2);
+    borsh_wire!(Gt);
+}

@@ -401,6 +401,10 @@ void rref_g1_mul(const uint8_t* p, const uint8_t* k, uint8_t* out) { rabe_ref_in
 void rref_g2_mul(const uint8_t* p, const uint8_t* k, uint8_t* out) { rabe_ref_init(); g2j a, r; u64 kk[4]; g2_load(&a, p); memcpy(kk, k, 32); g2_mul(&r, &a, kk); g2_store(out, &r); }
 void rref_pairing(const uint8_t* p, const uint8_t* q, uint8_t* out) { rabe_ref_init(); g1j a; g2j b; fe12 r; g1_load(&a, p); g2_load(&b, q); pairing(&r, &a, &b); gt_store(out, &r); }
 void rref_gt_pow(const uint8_t* a, const uint8_t* k, uint8_t* out) { rabe_ref_init(); fe12 x, r; u64 kk[4]; gt_load(&x, a); memcpy(kk, k, 32); f12_pow(&r, &x, kk); gt_store(out, &r); }
+void rref_g1_add(const uint8_t* p, const uint8_t* q, uint8_t* out) { rabe_ref_init(); g1j a, b, r; g1_load(&a, p); g1_load(&b, q); g1_add(&r, &a, &b); g1_store(out, &r); }
+void rref_g2_add(const uint8_t* p, const uint8_t* q, uint8_t* out) { rabe_ref_init(); g2j a, b, r; g2_load(&a, p); g2_load(&b, q); g2_add(&r, &a, &b); g2_store(out, &r); }
+void rref_gt_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { rabe_ref_init(); fe12 x, y, r; gt_load(&x, a); gt_load(&y, b); f12_mul(&r, &x, &y); gt_store(out, &r); }
+void rref_gt_inv(const uint8_t* a, uint8_t* out) { rabe_ref_init(); fe12 x, r; gt_load(&x, a); f12_inv(&r, &x); gt_store(out, &r); }
 void rref_sha3_256(const uint8_t* in, size_t len, uint8_t* out) { sha3_256(out, in, len); }
 void rref_hash_fr(const char* label, size_t len, uint8_t* out) { rabe_ref_init(); uint8_t d[32]; u64 k[4]; sha3_256(d, (const uint8_t*)label, len); fr_from_be32_reduce(k, d); memcpy(out, k, 32); }
 

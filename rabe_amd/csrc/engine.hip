@@ -242,7 +242,18 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_fr_op(int op, size_t n, c
   Fr r;
   if (op == RHIP_FR_NEG) r = neg(x);
   else if (op == RHIP_FR_INV) r = inv(x);
-  else {
+  else if (op == RHIP_FR_POW) {            // `Fr::pow(Fr)` (src/utils/secretsharing/mod.rs:218): x^e, e = b[i] as an integer
+    uint32_t e[8];
+    ld_scalar(e, b + i);
+    r = one<FrParams>();
+    for (int w = 7; w >= 0; w--) {
+      const uint32_t word = word_sel8(e, w);
+      for (int bit = 31; bit >= 0; bit--) {
+        r = sqr(r);
+        if ((word >> bit) & 1u) r = mul(r, x);
+      }
+    }
+  } else {
     Fr y = load_fr(b[i].l);
     r = (op == RHIP_FR_ADD) ? add(x, y) : (op == RHIP_FR_SUB) ? sub(x, y) : mul(x, y);
   }
@@ -936,7 +947,7 @@ extern "C" int32_t rhip_calibrate_mad(rhip_ctx* ctx, int32_t variant, uint32_t i
 
 extern "C" int32_t rhip_fr_op(rhip_ctx* ctx, int32_t op, size_t n, const rhip_fr* a, const rhip_fr* b, rhip_fr* out) {
   NEED(ctx);
-  if (op < 0 || op > RHIP_FR_INV) return RHIP_ERR_ARG;
+  if (op < 0 || op > RHIP_FR_POW) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
   KLAUNCH(ctx, "k_fr_op", k_fr_op, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, op, n, a, b, out);
   return RHIP_OK;
@@ -1094,6 +1105,27 @@ extern "C" int32_t rhip_host_fr_op(rhip_ctx* ctx, int32_t op, const rhip_fr* a, 
   if (b) HOSTOP_TRY(hb.put(32, b, 32));
   HOSTOP_TRY(rhip_fr_op(ctx, op, 1, (const rhip_fr*)hb.d, (const rhip_fr*)(hb.d + 32), (rhip_fr*)(hb.d + 64)));
   return hb.get(out, 64, 32);
+}
+extern "C" int32_t rhip_host_fr_pow(rhip_ctx* ctx, const rhip_fr* a, const rhip_fr* e, rhip_fr* out) {
+  return rhip_host_fr_op(ctx, RHIP_FR_POW, a, e, out);
+}
+extern "C" int32_t rhip_host_g1_on_curve(rhip_ctx* ctx, const rhip_g1* p, int32_t* ok) {
+  HOSTOP_BEGIN(128)
+  HOSTOP_TRY(hb.put(0, p, 64));
+  HOSTOP_TRY(rhip_g1_on_curve(ctx, 1, (const rhip_g1*)hb.d, (uint32_t*)(hb.d + 64)));
+  uint32_t v = 0;
+  HOSTOP_TRY(hb.get(&v, 64, 4));
+  *ok = (int32_t)v;
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_host_g2_on_curve(rhip_ctx* ctx, const rhip_g2* p, int32_t* ok) {
+  HOSTOP_BEGIN(256)
+  HOSTOP_TRY(hb.put(0, p, 128));
+  HOSTOP_TRY(rhip_g2_on_curve(ctx, 1, (const rhip_g2*)hb.d, (uint32_t*)(hb.d + 128)));
+  uint32_t v = 0;
+  HOSTOP_TRY(hb.get(&v, 128, 4));
+  *ok = (int32_t)v;
+  return RHIP_OK;
 }
 extern "C" int32_t rhip_host_fr_from_be32_reduce(rhip_ctx* ctx, const uint8_t digest[32], rhip_fr* out) {
   HOSTOP_BEGIN(64)

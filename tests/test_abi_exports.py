@@ -30,7 +30,11 @@ def test_header_declares_the_expected_surface():
                  "rhip_ac17_cp_keygen_batch", "rhip_g1_table_mul", "rhip_gt_pow", "rhip_ac17_sk_prepare",
                  "rhip_ac17_cp_decrypt_batch_prepared", "rhip_g1_table_add_wide", "rabe_ac17_cp_encrypt_batch", "rabe_bsw_encrypt_batch",
                  "rabe_bsw_decrypt_batch", "rabe_lsw_keygen_batch", "rabe_lsw_decrypt_batch", "rabe_aw11_encrypt_batch",
-                 "rabe_aw11_decrypt_batch"]:
+                 "rabe_aw11_decrypt_batch",
+                 # device-level Level B of the other three schemes and what the rabe-bn replacement crate binds
+                 "rhip_bsw_pk_create", "rhip_bsw_encrypt_batch", "rhip_bsw_sk_prepare", "rhip_bsw_decrypt_batch", "rhip_lsw_pk_create",
+                 "rhip_lsw_keygen_batch", "rhip_lsw_decrypt_batch", "rhip_aw11_pk_create", "rhip_aw11_encrypt_batch", "rhip_aw11_decrypt_batch",
+                 "rhip_g2_lines_prepare", "rhip_host_fr_pow", "rhip_host_g1_on_curve", "rhip_host_g2_on_curve"]:
         assert must in syms
 
 
@@ -49,3 +53,17 @@ def test_no_cpu_fallback_without_device(lib):
     from rabe_amd import Engine, EngineError
     with pytest.raises(EngineError):
         Engine(0)
+
+
+def test_rabe_bn_shim_binds_only_exported_symbols(lib):
+    """integration/rabe-bn-shim/src/lib.rs (not compiled here: no Rust) must only name functions the library exports, and
+    must offer what rabe's call sites use (src/error.rs:60-69, src/utils/secretsharing/mod.rs:218, the serde / borsh derives)."""
+    src = open(os.path.join(ROOT, "integration", "rabe-bn-shim", "src", "lib.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    for sym in re.findall(r"fn (rhip_[a-z0-9_]+)\(", block):
+        assert hasattr(lib, sym), sym
+    for needle in ["enum FieldError", "InvalidSliceLength", "InvalidU512Encoding", "NotMember", "pub fn pow(&self, exp: Fr) -> Fr",
+                   "impl Serialize for", "impl BorshSerialize for", "impl BorshDeserialize for", "impl From<Gt> for Vec<u8>",
+                   "pub fn from_str(s: &str) -> Option<Fr>", "pub fn inverse(&self) -> Option<Fr>"]:
+        assert needle in src, needle

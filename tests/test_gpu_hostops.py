@@ -52,3 +52,23 @@ def test_host_value_operators(eng):
     assert call(eng, "rhip_host_gt_mul", e1, e2, out=384) == bn.gt_to_le(bn.gt_pow(e, (a * b + b) % bn.R))
     assert call(eng, "rhip_host_gt_inv", e2, out=384) == bn.gt_to_le(bn.gt_pow(e, (-b) % bn.R))
     assert call(eng, "rhip_host_gt_pow", e2, le(a), out=384) == e1
+
+
+def test_fr_pow_and_membership(eng):
+    """`Fr::pow(Fr)` (src/utils/secretsharing/mod.rs:218) and the curve-membership test behind `FieldError::NotMember`"""
+    le = bn.fr_to_le
+    for a, e in [(3, 0), (3, 1), (5, 77), (RND.randrange(bn.R), RND.randrange(bn.R)), (0, 5), (bn.R - 1, bn.R - 1), (RND.randrange(bn.R), 99)]:
+        assert call(eng, "rhip_host_fr_pow", le(a), le(e), out=32) == le(pow(a, e, bn.R)), (a, e)
+    ok = ctypes.c_int32(7)
+    p = bn.g1_to_le(bn.g1_mul(bn.G1_GEN, 12345))
+    eng._check(eng.lib.rhip_host_g1_on_curve(eng.ctx, ctypes.c_char_p(p), ctypes.byref(ok)))
+    assert ok.value == 1
+    bad = p[:32] + (int.from_bytes(p[32:], "little") ^ 1).to_bytes(32, "little")
+    eng._check(eng.lib.rhip_host_g1_on_curve(eng.ctx, ctypes.c_char_p(bad), ctypes.byref(ok)))
+    assert ok.value == 0
+    q = bn.g2_to_le(bn.g2_mul(bn.G2_GEN, 54321))
+    eng._check(eng.lib.rhip_host_g2_on_curve(eng.ctx, ctypes.c_char_p(q), ctypes.byref(ok)))
+    assert ok.value == 1
+    badq = q[:96] + (int.from_bytes(q[96:], "little") ^ 1).to_bytes(32, "little")
+    eng._check(eng.lib.rhip_host_g2_on_curve(eng.ctx, ctypes.c_char_p(badq), ctypes.byref(ok)))
+    assert ok.value == 0

@@ -53,3 +53,26 @@ def test_ac17_golden_vectors():
                                         b"".join(hb(p) for _, v in c["sk"]["k"] for p in v),
                                         b"".join(hb(x) for x in c["sk"]["k_p"]), ct_sel, sk_sel)
         assert out == hb(c["decrypted"])
+
+
+def test_c_port_scheme_loops_match_python_oracle():
+    """The reference-order bsw / lsw / aw11 loops over the C primitives (the CPU baselines of bench.py --config 3/4/5)
+    produce the Python oracle's bytes on the same tape and decrypt to the message."""
+    from oracle import schemes as sch
+    from oracle.tape import ListRng, SeededRng
+    rng = SeededRng(77)
+    pk, msk = sch.bsw_setup(rng)
+    policy = '{"name": "and", "children": [{"name": "A"}, {"name": "or", "children": [{"name": "B"}, {"name": "C"}]}, {"name": "D"}]}'
+    sk = sch.bsw_keygen(pk, msk, ["A", "C", "D"], rng)
+    msg = bn.gt_pow(pk["e_gg_alpha"], 4242)
+    tape = [rng.fr() for _ in range(8)]
+    ct = sch.bsw_encrypt(pk, policy, pol.JSON, ListRng(tape), msg)
+    pkb = {"g1": bn.g1_to_le(pk["g1"]), "g2": bn.g2_to_le(pk["g2"]), "h": bn.g1_to_le(pk["h"]), "e_gg_alpha": bn.gt_to_le(pk["e_gg_alpha"])}
+    ctb = cport.bsw_encrypt_raw(pkb, policy, ListRng(tape), bn.gt_to_le(msg))
+    assert ctb["c"] == bn.g1_to_le(ct["c"]) and ctb["c_p"] == bn.gt_to_le(ct["c_p"])
+    assert [(n, a, b) for n, a, b in ctb["c_y"]] == [(y["string"], bn.g1_to_le(y["g1"]), bn.g2_to_le(y["g2"])) for y in ct["c_y"]]
+    skb = {"d": bn.g2_to_le(sk["d"]), "d_j": [(d["string"], bn.g1_to_le(d["g1"]), bn.g2_to_le(d["g2"])) for d in sk["d_j"]]}
+    assert cport.bsw_decrypt_raw(skb, ctb) == bn.gt_to_le(msg) == bn.gt_to_le(sch.bsw_decrypt(sk, ct))
+    # lsw / aw11: the workload drivers assert decrypt(...) == msg on every item
+    assert cport.lsw_keygen_dec(4, 1, tree="flat", seed=3) > 0
+    assert cport.aw11_encdec(10, 1, tree="mixed", seed=3) > 0
