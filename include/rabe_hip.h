@@ -102,6 +102,10 @@ int32_t rhip_g2_mul(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, const rhip_fr
 /* per-element curve membership: dev_ok[i] = 1 if on the curve (or infinity) */
 int32_t rhip_g1_on_curve(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, uint32_t* dev_ok);
 int32_t rhip_g2_on_curve(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
+/* membership in the groups proper (what decoding an untrusted element has to establish; G1 has cofactor 1, so on-curve suffices
+ * there): G2 = the r-torsion of the twist (on the curve and r * P = O), Gt = the order-r subgroup of Fq12* */
+int32_t rhip_g2_in_subgroup(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
+int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
 
 int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_gt* dev_b, rhip_gt* dev_out);
 /* out[i] = product of a[off[i] .. off[i+1]) (1 for an empty segment): the Gt accumulation loops of aw11::decrypt :320-352 */

@@ -43,6 +43,10 @@ void rabe_obj_free(int32_t kind, void* obj);
 /* canonical byte form of a key / ciphertext (layout: rabe_amd/csrc/host/host_abi.cpp); free with rabe_bytes_free */
 int32_t rabe_obj_serialize(int32_t kind, const void* obj, uint8_t** out, size_t* len);
 int32_t rabe_obj_deserialize(int32_t kind, const uint8_t* data, size_t len, void** obj);
+/* rabe_obj_deserialize checks structure and ranges (lengths of the fixed-size AC17 vectors, scalars < r, coordinates < p);
+ * the _checked form additionally establishes group membership of every element on the GPU (G1 on the curve, G2 in the r-torsion
+ * of the twist, Gt in the order-r subgroup): use it for keys / ciphertexts that arrive from outside */
+int32_t rabe_obj_deserialize_checked(rabe_host* h, int32_t kind, const uint8_t* data, size_t len, void** obj);
 void rabe_bytes_free(void* p);
 
 /* ---- ac17 (src/schemes/ac17/mod.rs:141-430) */
@@ -143,6 +147,11 @@ int32_t rabe_fr_reduce512(const uint8_t in_le64[64], uint8_t out_fast[32], uint8
 /* KDF + AES-256-GCM of src/utils/aes/mod.rs with an explicit nonce; out = nonce || ct || tag */
 int32_t rabe_encrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, const uint8_t nonce[12], uint8_t** out, size_t* out_len);
 int32_t rabe_decrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
+/* the raw primitives under the two functions above (sha3 0.10.8 / aes-gcm 0.10.3 in the reference, Cargo.toml:28,36), exported
+ * so that public known-answer vectors can pin them; out of rabe_aes256_gcm_encrypt = ciphertext || tag(16) */
+int32_t rabe_sha3_256(const uint8_t* data, size_t len, uint8_t out[32]);
+int32_t rabe_aes256_gcm_encrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
+int32_t rabe_aes256_gcm_decrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,21 @@ class SchemeRunner:
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             ok = bool(f.item())
         B = b.B
+        gather = None
+        if world > 1:
+            # the trivial gather: every rank's first-slot result records (B x 384 B) in ONE all_gather_into_tensor on device (RCCL);
+            # rank 0 recomputes the unsharded batch's messages from the global randomness stream and compares in global order
+            mine = b.out_tensor(0)[:B * 384]
+            src = mine if dist.get_backend() == "nccl" else mine.cpu()
+            allrec = torch.empty(world * B * 384, dtype=torch.uint8, device=src.device)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            dist.all_gather_into_tensor(allrec, src)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg0
+            if rank == 0:
+                gather = {"collective": "all_gather_into_tensor", "backend": dist.get_backend(), "bytes_per_rank": B * 384, "ms": round(1e3 * tg, 3),
+                          "matches_unsharded_order": allrec.cpu().numpy().tobytes() == b.expected_first_slot_all_ranks()}
         value = world * B * args.steps / elapsed
         result = {
             "metric": b.metric, "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -91,6 +106,8 @@ class SchemeRunner:
                            hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default"),
                            parallelism="batch-sharded x%d (no data-path collective)" % world, device=self.dev_name),
         }
+        if gather is not None:
+            result["gather"] = gather
         if rank == 0:
             eng.timing(True)
             eng.timing_read()
@@ -254,7 +271,8 @@ class BswBench:
         # per-item explicit randomness (bsw::encrypt draw order: secret, msg, gate coefficients)
         irnd = random.Random(r.args.seed * 7919 + 17 + r.rank)
         self.d_secret = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
-        rho = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        self.rho_all, rho_grp = global_rho(r, B, G, R)
+        rho = eng.upload(b"".join(le(x) for x in rho_grp))
         self.d_msg = eng.alloc(GB * 384)
         eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(GB), rho.ptr, self.d_msg.ptr))
         n_coef = coef_off[-1]
@@ -281,6 +299,16 @@ class BswBench:
     def check(self, lane, g):
         n = g * self.B * 384
         return self.bufs[lane][4].t[:n].cpu().numpy().tobytes() == self.r.eng.download(self.d_msg)[:n]
+
+    def out_tensor(self, lane):
+        return self.bufs[lane][4].t
+
+    def expected_first_slot_all_ranks(self):
+        eng, E = self.r.eng, self.E
+        n = len(self.rho_all)
+        d = eng.alloc(n * 384)
+        eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(n), eng.upload(b"".join(self.hp.fr_le(x) for x in self.rho_all)).ptr, d.ptr))
+        return eng.download(d)
 
     def describe(self):
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
@@ -338,6 +366,17 @@ def make_tree(kind, names, binary_and_only=False):
     if kind == "flat" and not binary_and_only:
         return ("and", leaves)
     return nest(leaves)
+
+
+def global_rho(r, B, G, R):
+    """Message exponents of the GLOBAL batch (world x B items per step, one stream for all ranks): (all of them, this rank's
+    group array): slot j of a group re-uses the step's exponents shifted by j."""
+    from rabe_amd import shard
+    grnd = random.Random(r.args.seed * 7919 + 29)
+    rho_all = [grnd.randrange(1, R) for _ in range(r.world * B)]
+    lo, hi = shard.shard_range(r.world * B, r.rank, r.world)
+    loc = rho_all[lo:hi]
+    return rho_all, [((loc[i % B] + i // B) % R) or 1 for i in range(G * B)]
 
 
 def rand_fr_bytes(irnd, n):
@@ -460,6 +499,12 @@ class LswBench:
     def check(self, lane, g):
         n = g * self.B
         return self.bufs[lane][2].t[:n * 384].cpu().numpy().tobytes() == self.msg * n
+
+    def out_tensor(self, lane):
+        return self.bufs[lane][2].t
+
+    def expected_first_slot_all_ranks(self):
+        return self.msg * (self.r.world * self.B)           # every item decrypts the one pre-made ciphertext
 
     def describe(self):
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
@@ -600,7 +645,8 @@ class Aw11Bench:
         self.d_sk_idx = eng.upload_u32([0] * GB)
         irnd = random.Random(r.args.seed * 7919 + 23 + r.rank)
         self.d_s = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
-        rho = eng.upload(b"".join(le(irnd.randrange(1, R)) for _ in range(GB)))
+        self.rho_all, rho_grp = global_rho(r, B, G, R)
+        rho = eng.upload(b"".join(le(x) for x in rho_grp))
         self.d_msg = eng.alloc(GB * 384)
         eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(GB), rho.ptr, self.d_msg.ptr))
         self.d_coef = eng.upload(rand_fr_bytes(irnd, coef_off[-1]))
@@ -624,6 +670,16 @@ class Aw11Bench:
     def check(self, lane, g):
         n = g * self.B * 384
         return self.bufs[lane][4].t[:n].cpu().numpy().tobytes() == self.r.eng.download(self.d_msg)[:n]
+
+    def out_tensor(self, lane):
+        return self.bufs[lane][4].t
+
+    def expected_first_slot_all_ranks(self):
+        eng, E = self.r.eng, self.E
+        n = len(self.rho_all)
+        d = eng.alloc(n * 384)
+        eng._check(eng.lib.rhip_gt_table_pow(eng.ctx, self.e_tab.h, E._sz(n), eng.upload(b"".join(self.hp.fr_le(x) for x in self.rho_all)).ptr, d.ptr))
+        return eng.download(d)
 
     def describe(self):
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)

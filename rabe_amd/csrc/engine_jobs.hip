@@ -978,3 +978,48 @@ extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t
   KLAUNCH(ctx, "k_gt_lead", k_gt_lead, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, L, ct_c0, (const GtM*)p_gt, lead);
   return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, (const LineM*)nullptr, (const rhip_gt*)lead, out);
 }
+
+// ------------------------------------------------------------------------------------------------ membership of decoded elements
+// What a decoder has to establish before an untrusted key / ciphertext reaches the pairing kernels (rabe-bn's decoding
+// raises FieldError::NotMember, src/error.rs:66): G1 has cofactor 1 (on-curve is enough: rhip_g1_on_curve); the twist has
+// a large cofactor, so G2 needs r * P = O; a Gt value has to lie in the order-r subgroup -- the engine's Gt powers use
+// cyclotomic squarings and conjugation-as-inverse, which are only right there.
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_in_subgroup(size_t n, const rhip_g2* p, uint32_t* ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G2Aff P = load_g2(p[i].l);
+  uint32_t r[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) r[w] = FrParams::mod(w);
+  ok[i] = (aff_on_curve(P) && jac_is_inf(jac_mul_naf(P, r))) ? 1u : 0u;          // infinity is a member
+}
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_is_member(size_t n, const rhip_gt* a, uint32_t* ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fp12 f = load_gt(a[i].l);
+  // cyclotomic subgroup: f^(p^4 - p^2 + 1) = 1  <=>  f^(p^4) * f = f^(p^2)
+  const Fp12 f2 = fp12_frob_fn(f, 2);
+  const Fp12 f4 = fp12_frob_fn(f2, 2);
+  bool good = fp12_eq(fp12_mul_fn(f4, f), f2);
+  if (good) {
+    // order divides r: f^(r-1) * f = 1 (cyclotomic squarings are valid now)
+    uint32_t k[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) k[w] = FrParams::mod(w);
+    k[0] -= 1u;                                       // r is odd
+    good = fp12_eq(fp12_mul_fn(gt_pow_window(f, k), f), fp12_one());
+  }
+  ok[i] = good ? 1u : 0u;
+}
+extern "C" int32_t rhip_g2_in_subgroup(rhip_ctx* ctx, size_t n, const rhip_g2* p, uint32_t* ok) {
+  NEED(ctx);
+  if (!n) return RHIP_OK;
+  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok);
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok) {
+  NEED(ctx);
+  if (!n) return RHIP_OK;
+  KLAUNCH(ctx, "k_gt_is_member", k_gt_is_member, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, ok);
+  return RHIP_OK;
+}

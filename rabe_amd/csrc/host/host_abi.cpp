@@ -47,24 +47,58 @@ struct W {
   void vfr(const std::vector<Fr>& v) { u32((uint32_t)v.size()); for (auto& e : v) fr(e); }
   void pol(const PolicyRef& p) { str(p.first); u8((uint8_t)p.second); }
 };
+// r and p, little-endian 32-bit limbs: canonical-range checks of decoded scalars / coordinates
+static const uint32_t R_MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static const uint32_t P_MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static bool below(const uint8_t* le32, const uint32_t m[8]) {
+  for (int i = 7; i >= 0; i--) {
+    uint32_t w;
+    memcpy(&w, le32 + 4 * i, 4);
+    if (w != m[i]) return w < m[i];
+  }
+  return false;
+}
 struct R {
   const uint8_t* p;
   size_t n, o = 0;
+  // every group element decoded so far (offsets into p), for the membership checks of rabe_obj_deserialize_checked
+  std::vector<size_t> g1s, g2s, gts;
   R(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
   void need(size_t k) { if (o + k > n) throw RabeError("deserialize: truncated input"); }
   uint8_t u8() { need(1); return p[o++]; }
   uint32_t u32() { need(4); uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)p[o + i] << (8 * i); o += 4; return v; }
   std::string str() { uint32_t l = u32(); need(l); std::string s((const char*)p + o, l); o += l; return s; }
   Bytes bytes() { uint32_t l = u32(); need(l); Bytes b(p + o, p + o + l); o += l; return b; }
-  Fr fr() { need(32); Fr f; memcpy(f.l, p + o, 32); o += 32; return f; }
-  template <size_t N> std::array<uint8_t, N> el() { need(N); std::array<uint8_t, N> e; memcpy(e.data(), p + o, N); o += N; return e; }
-  template <size_t N> std::vector<std::array<uint8_t, N>> vec() { uint32_t c = u32(); std::vector<std::array<uint8_t, N>> v; for (uint32_t i = 0; i < c; i++) v.push_back(el<N>()); return v; }
+  Fr fr() {
+    need(32);
+    if (!below(p + o, R_MOD)) throw RabeError("deserialize: scalar not below r (FieldError::NotMember)");
+    Fr f; memcpy(f.l, p + o, 32); o += 32; return f;
+  }
+  template <size_t N> std::array<uint8_t, N> el() {
+    need(N);
+    for (size_t c = 0; c < N; c += 32)
+      if (!below(p + o + c, P_MOD)) throw RabeError("deserialize: coordinate not below p (FieldError::NotMember)");
+    (N == 64 ? g1s : N == 128 ? g2s : gts).push_back(o);
+    std::array<uint8_t, N> e; memcpy(e.data(), p + o, N); o += N; return e;
+  }
+  template <size_t N> std::vector<std::array<uint8_t, N>> vec() { uint32_t c = u32(); need((size_t)c * N); std::vector<std::array<uint8_t, N>> v; for (uint32_t i = 0; i < c; i++) v.push_back(el<N>()); return v; }
+  // fixed-size vectors of the AC17 structs (ASSUMPTION_SIZE = 2: ac17/mod.rs:138): anything else is malformed
+  template <size_t N> std::vector<std::array<uint8_t, N>> vec_of(size_t want, const char* what) {
+    auto v = vec<N>();
+    if (v.size() != want) throw RabeError(std::string("deserialize: ") + what + " has " + std::to_string(v.size()) + " elements, expected " + std::to_string(want));
+    return v;
+  }
+  std::vector<Fr> vfr_of(size_t want, const char* what) {
+    auto v = vfr();
+    if (v.size() != want) throw RabeError(std::string("deserialize: ") + what + " has " + std::to_string(v.size()) + " elements, expected " + std::to_string(want));
+    return v;
+  }
   std::vector<Fr> vfr() { uint32_t c = u32(); std::vector<Fr> v; for (uint32_t i = 0; i < c; i++) v.push_back(fr()); return v; }
   PolicyRef pol() { std::string s = str(); uint8_t l = u8(); return {s, l ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy}; }
 };
 typedef std::vector<std::pair<std::string, std::vector<G1>>> NamedG1Vec;
 static void w_named(W& w, const NamedG1Vec& v) { w.u32((uint32_t)v.size()); for (auto& e : v) { w.str(e.first); w.vec(e.second); } }
-static NamedG1Vec r_named(R& r) { uint32_t c = r.u32(); NamedG1Vec v; for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); v.push_back({s, r.vec<64>()}); } return v; }
+static NamedG1Vec r_named(R& r) { uint32_t c = r.u32(); NamedG1Vec v; for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); v.push_back({s, r.vec_of<64>(3, "an AC17 row")}); } return v; }
 
 static void ser(W& w, int32_t kind, const void* o) {
   switch (kind) {
@@ -111,56 +145,61 @@ static void ser(W& w, int32_t kind, const void* o) {
     default: throw RabeError("serialize: unknown object kind");
   }
 }
+// objects are built in a unique_ptr and released on success: a truncated / malformed input leaks nothing
+#define NEW_OBJ(T) std::unique_ptr<T> up(new T()); T* x = up.get()
 static void* deser(R& r, int32_t kind) {
   switch (kind) {
-    case RABE_AC17_PK: { auto* x = new ac17::Ac17PublicKey(); x->g = r.el<64>(); x->h_a = r.vec<128>(); x->e_gh_ka = r.vec<384>(); return x; }
-    case RABE_AC17_MSK: { auto* x = new ac17::Ac17MasterKey(); x->g = r.el<64>(); x->h = r.el<128>(); x->g_k = r.vec<64>(); x->a = r.vfr(); x->b = r.vfr(); return x; }
-    case RABE_AC17_CP_SK: { auto* x = new ac17::Ac17CpSecretKey(); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
-                            x->sk.k_0 = r.vec<128>(); x->sk.k = r_named(r); x->sk.k_p = r.vec<64>(); return x; }
-    case RABE_AC17_CP_CT: { auto* x = new ac17::Ac17CpCiphertext(); x->policy = r.pol(); x->ct.c_0 = r.vec<128>(); x->ct.c = r_named(r);
-                            x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return x; }
-    case RABE_AC17_KP_SK: { auto* x = new ac17::Ac17KpSecretKey(); x->policy = r.pol(); x->sk.k_0 = r.vec<128>(); x->sk.k = r_named(r); x->sk.k_p = r.vec<64>(); return x; }
-    case RABE_AC17_KP_CT: { auto* x = new ac17::Ac17KpCiphertext(); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
-                            x->ct.c_0 = r.vec<128>(); x->ct.c = r_named(r); x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return x; }
-    case RABE_BSW_PK: { auto* x = new bsw::CpAbePublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->h = r.el<64>(); x->f = r.el<128>(); x->e_gg_alpha = r.el<384>(); return x; }
-    case RABE_BSW_MSK: { auto* x = new bsw::CpAbeMasterKey(); x->beta = r.fr(); x->g2_alpha = r.el<128>(); return x; }
-    case RABE_BSW_SK: { auto* x = new bsw::CpAbeSecretKey(); x->d = r.el<128>(); uint32_t c = r.u32();
-                        for (uint32_t i = 0; i < c; i++) { bsw::CpAbeAttribute a; a.string = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->d_j.push_back(a); } return x; }
-    case RABE_BSW_CT: { auto* x = new bsw::CpAbeCiphertext(); x->policy = r.pol(); x->c = r.el<64>(); x->c_p = r.el<384>(); uint32_t c = r.u32();
+    case RABE_AC17_PK: { NEW_OBJ(ac17::Ac17PublicKey); x->g = r.el<64>(); x->h_a = r.vec_of<128>(3, "h_a"); x->e_gh_ka = r.vec_of<384>(2, "e_gh_ka"); return up.release(); }
+    case RABE_AC17_MSK: { NEW_OBJ(ac17::Ac17MasterKey); x->g = r.el<64>(); x->h = r.el<128>(); x->g_k = r.vec_of<64>(3, "g_k"); x->a = r.vfr_of(2, "a");
+                          x->b = r.vfr_of(2, "b"); return up.release(); }
+    case RABE_AC17_CP_SK: { NEW_OBJ(ac17::Ac17CpSecretKey); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
+                            x->sk.k_0 = r.vec_of<128>(3, "k_0"); x->sk.k = r_named(r); x->sk.k_p = r.vec_of<64>(3, "k_p"); return up.release(); }
+    case RABE_AC17_CP_CT: { NEW_OBJ(ac17::Ac17CpCiphertext); x->policy = r.pol(); x->ct.c_0 = r.vec_of<128>(3, "c_0"); x->ct.c = r_named(r);
+                            x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return up.release(); }
+    case RABE_AC17_KP_SK: { NEW_OBJ(ac17::Ac17KpSecretKey); x->policy = r.pol(); x->sk.k_0 = r.vec_of<128>(3, "k_0"); x->sk.k = r_named(r);
+                            x->sk.k_p = r.vec<64>(); if (!x->sk.k_p.empty() && x->sk.k_p.size() != 3) throw RabeError("deserialize: k_p is neither empty nor 3 elements");
+                            return up.release(); }
+    case RABE_AC17_KP_CT: { NEW_OBJ(ac17::Ac17KpCiphertext); uint32_t c = r.u32(); for (uint32_t i = 0; i < c; i++) x->attr.push_back(r.str());
+                            x->ct.c_0 = r.vec_of<128>(3, "c_0"); x->ct.c = r_named(r); x->ct.c_p = r.el<384>(); x->ct.ct = r.bytes(); return up.release(); }
+    case RABE_BSW_PK: { NEW_OBJ(bsw::CpAbePublicKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->h = r.el<64>(); x->f = r.el<128>(); x->e_gg_alpha = r.el<384>(); return up.release(); }
+    case RABE_BSW_MSK: { NEW_OBJ(bsw::CpAbeMasterKey); x->beta = r.fr(); x->g2_alpha = r.el<128>(); return up.release(); }
+    case RABE_BSW_SK: { NEW_OBJ(bsw::CpAbeSecretKey); x->d = r.el<128>(); uint32_t c = r.u32();
+                        for (uint32_t i = 0; i < c; i++) { bsw::CpAbeAttribute a; a.string = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->d_j.push_back(a); } return up.release(); }
+    case RABE_BSW_CT: { NEW_OBJ(bsw::CpAbeCiphertext); x->policy = r.pol(); x->c = r.el<64>(); x->c_p = r.el<384>(); uint32_t c = r.u32();
                         for (uint32_t i = 0; i < c; i++) { bsw::CpAbeAttribute a; a.string = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->c_y.push_back(a); }
-                        x->data = r.bytes(); return x; }
-    case RABE_LSW_PK: { auto* x = new lsw::KpAbePublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_b = r.el<64>(); x->g1_b2 = r.el<64>(); x->h_b = r.el<64>();
-                        x->e_gg_alpha = r.el<384>(); return x; }
-    case RABE_LSW_MSK: { auto* x = new lsw::KpAbeMasterKey(); x->alpha1 = r.fr(); x->alpha2 = r.fr(); x->b = r.fr(); x->h_g1 = r.el<64>(); x->h_g2 = r.el<128>(); return x; }
-    case RABE_LSW_SK: { auto* x = new lsw::KpAbeSecretKey(); x->policy = r.pol(); uint32_t c = r.u32();
+                        x->data = r.bytes(); return up.release(); }
+    case RABE_LSW_PK: { NEW_OBJ(lsw::KpAbePublicKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_b = r.el<64>(); x->g1_b2 = r.el<64>(); x->h_b = r.el<64>();
+                        x->e_gg_alpha = r.el<384>(); return up.release(); }
+    case RABE_LSW_MSK: { NEW_OBJ(lsw::KpAbeMasterKey); x->alpha1 = r.fr(); x->alpha2 = r.fr(); x->b = r.fr(); x->h_g1 = r.el<64>(); x->h_g2 = r.el<128>(); return up.release(); }
+    case RABE_LSW_SK: { NEW_OBJ(lsw::KpAbeSecretKey); x->policy = r.pol(); uint32_t c = r.u32();
                         for (uint32_t i = 0; i < c; i++) { lsw::KpAbeKeyRow d; d.name = r.str(); d.d1 = r.el<64>(); d.d2 = r.el<128>(); d.d3 = r.el<64>(); d.d4 = r.el<64>(); d.d5 = r.el<64>(); x->dj.push_back(d); }
-                        return x; }
-    case RABE_LSW_CT: { auto* x = new lsw::KpAbeCiphertext(); x->e1 = r.el<384>(); x->e2 = r.el<128>(); uint32_t c = r.u32();
+                        return up.release(); }
+    case RABE_LSW_CT: { NEW_OBJ(lsw::KpAbeCiphertext); x->e1 = r.el<384>(); x->e2 = r.el<128>(); uint32_t c = r.u32();
                         for (uint32_t i = 0; i < c; i++) { lsw::KpAbeCtRow e; e.name = r.str(); e.e1 = r.el<64>(); e.e2 = r.el<64>(); e.e3 = r.el<64>(); x->ej.push_back(e); }
-                        x->ct = r.bytes(); return x; }
-    case RABE_AW11_GK: { auto* x = new aw11::Aw11GlobalKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); return x; }
-    case RABE_AW11_PK: { auto* x = new aw11::Aw11PublicKey(); uint32_t c = r.u32();
-                         for (uint32_t i = 0; i < c; i++) { aw11::Aw11PkAttr a; a.name = r.str(); a.egg_alpha = r.el<384>(); a.g2_y = r.el<128>(); x->attr.push_back(a); } return x; }
-    case RABE_AW11_MSK: { auto* x = new aw11::Aw11MasterKey(); uint32_t c = r.u32();
-                          for (uint32_t i = 0; i < c; i++) { aw11::Aw11MkAttr a; a.name = r.str(); a.alpha = r.fr(); a.y = r.fr(); x->attr.push_back(a); } return x; }
-    case RABE_AW11_SK: { auto* x = new aw11::Aw11SecretKey(); x->gid = r.str(); uint32_t c = r.u32();
-                         for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); x->attr.push_back({s, r.el<64>()}); } return x; }
-    case RABE_AW11_CT: { auto* x = new aw11::Aw11Ciphertext(); x->policy = r.pol(); x->c_0 = r.el<384>(); uint32_t c = r.u32();
+                        x->ct = r.bytes(); return up.release(); }
+    case RABE_AW11_GK: { NEW_OBJ(aw11::Aw11GlobalKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); return up.release(); }
+    case RABE_AW11_PK: { NEW_OBJ(aw11::Aw11PublicKey); uint32_t c = r.u32();
+                         for (uint32_t i = 0; i < c; i++) { aw11::Aw11PkAttr a; a.name = r.str(); a.egg_alpha = r.el<384>(); a.g2_y = r.el<128>(); x->attr.push_back(a); } return up.release(); }
+    case RABE_AW11_MSK: { NEW_OBJ(aw11::Aw11MasterKey); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { aw11::Aw11MkAttr a; a.name = r.str(); a.alpha = r.fr(); a.y = r.fr(); x->attr.push_back(a); } return up.release(); }
+    case RABE_AW11_SK: { NEW_OBJ(aw11::Aw11SecretKey); x->gid = r.str(); uint32_t c = r.u32();
+                         for (uint32_t i = 0; i < c; i++) { std::string s = r.str(); x->attr.push_back({s, r.el<64>()}); } return up.release(); }
+    case RABE_AW11_CT: { NEW_OBJ(aw11::Aw11Ciphertext); x->policy = r.pol(); x->c_0 = r.el<384>(); uint32_t c = r.u32();
                          for (uint32_t i = 0; i < c; i++) { aw11::Aw11CtRow t; t.name = r.str(); t.c1 = r.el<384>(); t.c2 = r.el<128>(); t.c3 = r.el<128>(); x->c.push_back(t); }
-                         x->ct = r.bytes(); return x; }
-    case RABE_GHW11_PK: { auto* x = new ghw11::Ghw11PublicKey(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_a = r.el<64>(); x->g2_a = r.el<128>();
-                          x->e_gg_alpha = r.el<384>(); return x; }
-    case RABE_GHW11_MSK: { auto* x = new ghw11::Ghw11MasterKey(); x->g2_alpha = r.el<128>(); auto* pk = (ghw11::Ghw11PublicKey*)deser(r, RABE_GHW11_PK);
-                           x->pk = *pk; delete pk; return x; }
-    case RABE_GHW11_SK: { auto* x = new ghw11::Ghw11SecretKey(); x->k = r.el<128>(); x->l = r.el<128>(); uint32_t c = r.u32();
-                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key.push_back(a); } return x; }
-    case RABE_GHW11_TK: { auto* x = new ghw11::Ghw11TransformKey(); x->k_z = r.el<128>(); x->l_z = r.el<128>(); uint32_t c = r.u32();
-                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key_z.push_back(a); } return x; }
-    case RABE_GHW11_RK: { auto* x = new ghw11::Ghw11RetrieveKey(); x->z = r.fr(); return x; }
-    case RABE_GHW11_CT: { auto* x = new ghw11::Ghw11Ciphertext(); x->policy = r.pol(); x->c = r.el<384>(); x->c1 = r.el<64>(); uint32_t c = r.u32();
+                         x->ct = r.bytes(); return up.release(); }
+    case RABE_GHW11_PK: { NEW_OBJ(ghw11::Ghw11PublicKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->g1_a = r.el<64>(); x->g2_a = r.el<128>();
+                          x->e_gg_alpha = r.el<384>(); return up.release(); }
+    case RABE_GHW11_MSK: { NEW_OBJ(ghw11::Ghw11MasterKey); x->g2_alpha = r.el<128>(); auto* pk = (ghw11::Ghw11PublicKey*)deser(r, RABE_GHW11_PK);
+                           x->pk = *pk; delete pk; return up.release(); }
+    case RABE_GHW11_SK: { NEW_OBJ(ghw11::Ghw11SecretKey); x->k = r.el<128>(); x->l = r.el<128>(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key.push_back(a); } return up.release(); }
+    case RABE_GHW11_TK: { NEW_OBJ(ghw11::Ghw11TransformKey); x->k_z = r.el<128>(); x->l_z = r.el<128>(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11Attribute a; a.string = r.str(); a.k_x = r.el<128>(); x->attr_key_z.push_back(a); } return up.release(); }
+    case RABE_GHW11_RK: { NEW_OBJ(ghw11::Ghw11RetrieveKey); x->z = r.fr(); return up.release(); }
+    case RABE_GHW11_CT: { NEW_OBJ(ghw11::Ghw11Ciphertext); x->policy = r.pol(); x->c = r.el<384>(); x->c1 = r.el<64>(); uint32_t c = r.u32();
                           for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11CtRow t; t.name = r.str(); t.c = r.el<64>(); t.d = r.el<64>(); x->ci_di.push_back(t); }
-                          x->data = r.bytes(); return x; }
-    case RABE_GHW11_TCT: { auto* x = new ghw11::Ghw11TransformCiphertext(); x->c = r.el<384>(); x->t = r.el<384>(); return x; }
+                          x->data = r.bytes(); return up.release(); }
+    case RABE_GHW11_TCT: { NEW_OBJ(ghw11::Ghw11TransformCiphertext); x->c = r.el<384>(); x->t = r.el<384>(); return up.release(); }
     default: throw RabeError("deserialize: unknown object kind");
   }
 }
@@ -272,6 +311,41 @@ int32_t rabe_obj_deserialize(int32_t kind, const uint8_t* data, size_t len, void
   *obj = deser(r, kind);
   return 0;
   GUARD_END((rabe_host*)nullptr)
+}
+// The same, plus group membership of every decoded element on the GPU (one batched launch per group): G1 on the curve, G2
+// on the twist AND in its r-torsion, Gt in the order-r subgroup -- what rabe-bn's decoding establishes (FieldError::NotMember).
+// Use it for anything that arrives from outside; the unchecked form is for objects this process serialised itself.
+int32_t rabe_obj_deserialize_checked(rabe_host* h, int32_t kind, const uint8_t* data, size_t len, void** obj) {
+  GUARD_BEGIN
+  if (!h) throw RabeError("rabe_obj_deserialize_checked: no host");
+  R r(data, len);
+  void* o = deser(r, kind);
+  try {
+    Engine& e = h->eng;
+    auto run = [&](const std::vector<size_t>& offs, size_t sz, int which, const char* what) {
+      if (offs.empty()) return;
+      std::vector<uint8_t> flat(offs.size() * sz);
+      for (size_t i = 0; i < offs.size(); i++) memcpy(flat.data() + i * sz, data + offs[i], sz);
+      DBuf din(&e, flat.data(), flat.size()), dok(&e, offs.size() * 4);
+      int32_t rc = which == 1 ? rhip_g1_on_curve(e.ctx(), offs.size(), din.as<rhip_g1>(), dok.as<uint32_t>())
+                 : which == 2 ? rhip_g2_in_subgroup(e.ctx(), offs.size(), din.as<rhip_g2>(), dok.as<uint32_t>())
+                              : rhip_gt_is_member(e.ctx(), offs.size(), din.as<rhip_gt>(), dok.as<uint32_t>());
+      e.check(rc, what);
+      std::vector<uint32_t> ok(offs.size());
+      dok.download(ok.data(), ok.size() * 4);
+      for (size_t i = 0; i < ok.size(); i++)
+        if (!ok[i]) throw RabeError(std::string("deserialize: ") + what + " element " + std::to_string(i) + " is not a group member (FieldError::NotMember)");
+    };
+    run(r.g1s, 64, 1, "G1");
+    run(r.g2s, 128, 2, "G2");
+    run(r.gts, 384, 3, "Gt");
+  } catch (...) {
+    rabe_obj_free(kind, o);
+    throw;
+  }
+  *obj = o;
+  return 0;
+  GUARD_END(h)
 }
 
 // ---------------------------------------------------------------- ac17
@@ -731,6 +805,26 @@ int32_t rabe_decrypt_symmetric(const uint8_t gt[384], const uint8_t* data, size_
   GUARD_BEGIN
   Bytes pt;
   if (!decrypt_symmetric(gt, data, len, &pt)) { set_err(nullptr, "decryption error: aead::Error"); return -1; }
+  return give_bytes(pt, out, out_len);
+  GUARD_END((rabe_host*)nullptr)
+}
+// raw primitives behind the KEM/DEM step, exported so that public known-answer vectors can pin them (FIPS-202, the GCM
+// specification's 256-bit-key test cases): tests/test_host_policy.py
+int32_t rabe_sha3_256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  GUARD_BEGIN
+  sha3_256(data, len, out);
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_aes256_gcm_encrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) {
+  GUARD_BEGIN
+  return give_bytes(aes256_gcm_encrypt(key, nonce, data, len), out, out_len);       // ciphertext || tag
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_aes256_gcm_decrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) {
+  GUARD_BEGIN
+  Bytes pt;
+  if (!aes256_gcm_decrypt(key, nonce, data, len, &pt)) { set_err(nullptr, "decryption error: aead::Error"); return -1; }
   return give_bytes(pt, out, out_len);
   GUARD_END((rabe_host*)nullptr)
 }

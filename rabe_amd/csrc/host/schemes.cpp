@@ -11,6 +11,7 @@
 #include <thread>
 #include <unordered_map>
 
+#include <errno.h>
 #include <stdio.h>
 #include <sys/random.h>
 
@@ -25,6 +26,7 @@ void OsRng::fill(uint8_t* out, size_t n) {
       size_t off = 0;
       while (off < sizeof(pool)) {
         ssize_t r = getrandom(pool + off, sizeof(pool) - off, 0);
+        if (r < 0 && errno == EINTR) continue;            // a signal during the read: try again
         if (r <= 0) throw RabeError("getrandom failed");
         off += (size_t)r;
       }
@@ -44,6 +46,7 @@ Engine::Engine(int device) {
   if (rc != RHIP_OK) throw RabeError(std::string("no usable HIP device: ") + rhip_last_error(nullptr));
 }
 rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka) {
+  if (h_a.size() != 3 || e_gh_ka.size() != 2) throw RabeError("malformed Ac17PublicKey: h_a must have 3 and e_gh_ka 2 elements");
   auto fha = flatten(h_a), fe = flatten(e_gh_ka);
   std::string key((const char*)g.data(), g.size());
   key.append((const char*)fha.data(), fha.size());
@@ -498,6 +501,7 @@ std::pair<Ac17PublicKey, Ac17MasterKey> setup(Engine& eng, Rng& rng) {      // :
 
 Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& attributes) {   // :191-264
   if (attributes.empty()) throw RabeError("empty attributes!");
+  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
   const size_t n = attributes.size();
   // draw order: r0, r1, sigma per attribute (loop order), sigma'
   std::vector<Fr> r{rng.next_fr(), rng.next_fr()};
@@ -655,13 +659,22 @@ static std::vector<Gt> decrypt_items(Engine& eng, const std::vector<DecItem>& it
   PolicyMemo memo;
   parallel_for(n, [&](size_t i) {
     const DecItem& it = items[i];
-    const PolicyNode& tree = memo.get(it.policy->first, it.policy->second).tree;
-    if (!traverse_policy(*it.attrs, tree)) { (*errors)[i] = it.err_traverse; return; }
-    PrunedList lst;
-    if (!calc_pruned(*it.attrs, tree, &lst)) { (*errors)[i] = it.err_pruned; return; }
-    for (const auto& cur : lst) {
-      for (size_t r = 0; r < it.ct->c.size(); r++) if (it.ct->c[r].first == cur.first) plans[i].ct_sel.push_back((uint32_t)r);
-      for (size_t r = 0; r < it.sk->k.size(); r++) if (it.sk->k[r].first == cur.first) plans[i].sk_sel.push_back((uint32_t)r);
+    try {
+      // fixed-size vectors (ASSUMPTION_SIZE + 1 = 3): the kernels index [item * 3 + j]; a malformed object fails its own item only
+      if (it.ct->c_0.size() != 3 || it.sk->k_0.size() != 3 || !(it.sk->k_p.empty() || it.sk->k_p.size() == 3))
+        throw RabeError("malformed AC17 object: c_0 / k_0 / k_p must have 3 elements");
+      for (const auto& row : it.ct->c) if (row.second.size() != 3) throw RabeError("malformed AC17 ciphertext: a row does not have 3 elements");
+      for (const auto& row : it.sk->k) if (row.second.size() != 3) throw RabeError("malformed AC17 key: a row does not have 3 elements");
+      const PolicyNode& tree = memo.get(it.policy->first, it.policy->second).tree;       // a policy that does not parse fails its item
+      if (!traverse_policy(*it.attrs, tree)) { (*errors)[i] = it.err_traverse; return; }
+      PrunedList lst;
+      if (!calc_pruned(*it.attrs, tree, &lst)) { (*errors)[i] = it.err_pruned; return; }
+      for (const auto& cur : lst) {
+        for (size_t r = 0; r < it.ct->c.size(); r++) if (it.ct->c[r].first == cur.first) plans[i].ct_sel.push_back((uint32_t)r);
+        for (size_t r = 0; r < it.sk->k.size(); r++) if (it.sk->k[r].first == cur.first) plans[i].sk_sel.push_back((uint32_t)r);
+      }
+    } catch (const RabeError& ex) {
+      (*errors)[i] = ex.what();            // like plan_jobs of the other schemes: one bad item does not abort the batch
     }
   });
   for (size_t i = 0; i < n; i++) {
@@ -749,6 +762,7 @@ Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext&
 
 // ---------------------------------------------------------------------------------------------- KP-ABE
 Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang) {   // :439-547
+  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
   PolicyNode tree = parse_or_error(policy, lang);
   AbePolicy msp = calculate_msp(tree);
   const size_t cols = msp.m[0].size(), rows = msp.m.size();

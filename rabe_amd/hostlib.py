@@ -66,9 +66,13 @@ class Obj:
         return _take_bytes(p, n)
 
     @classmethod
-    def deserialize(cls, kind, data):
+    def deserialize(cls, kind, data, host=None):
+        """host given: the checked form (group membership of every element established on the GPU)"""
         p = ctypes.c_void_p()
-        _check(_lib().rabe_obj_deserialize(KINDS[kind], data, ctypes.c_size_t(len(data)), ctypes.byref(p)))
+        if host is not None:
+            _check(_lib().rabe_obj_deserialize_checked(host.h, KINDS[kind], data, ctypes.c_size_t(len(data)), ctypes.byref(p)), host.h)
+        else:
+            _check(_lib().rabe_obj_deserialize(KINDS[kind], data, ctypes.c_size_t(len(data)), ctypes.byref(p)))
         return cls(kind, p)
 
     def __del__(self):
