@@ -61,6 +61,19 @@ int32_t rabe_ac17_cp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const
 /* n independent cp_decrypt calls; status[i] = 0 ok / -1 error; plaintexts[i] malloc'd (rabe_bytes_free) */
 int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                    uint8_t** plaintexts, size_t* lens);
+/* The same two batches with packed input and output -- no per-item objects on either side of the boundary, every buffer
+ * caller-allocated (and reusable across calls).  Ciphertexts are ONE blob of canonical records (the byte form rabe_obj_serialize
+ * gives an Ac17CpCiphertext) delimited by an offset array of n_items + 1 entries; plaintexts likewise.
+ *   encrypt: item i uses policies[item_policy[i]] (distinct policy texts are parsed once, and cached across calls).  ct_off is
+ *            always filled; return 1 (nothing done, no randomness drawn) when ct_cap < ct_off[n_items], the size the records need.
+ *   decrypt: status[i] = 0 / -1 per item (a key that does not satisfy a policy, a malformed record or an authentication failure
+ *            fails that item only; its plaintext is empty).  pt_cap >= ct_off[n_items] - ct_off[0] always suffices; return 1 when
+ *            it is smaller. */
+int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                    const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
+                                    uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
+int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, const uint64_t* ct_off /*[n_items+1]*/,
+                                    int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off /*[n_items+1]*/);
 
 /* KP-ABE variant (src/schemes/ac17/mod.rs:439-675) */
 int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, int32_t language, void** sk);

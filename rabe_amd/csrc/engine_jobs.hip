@@ -114,8 +114,8 @@ struct DevMultiAcc {
   const uint32_t* qref;
   const LineM* lines;
   int cnt;
-  uint4* ws;          // + lane; running point of pair j: quads [12 j, 12 j + 12) at stride `stride`
-  size_t stride;
+  uint4* ws;          // this lane's column of its wave's block; running point of pair j: quads [12 j, 12 j + 12) at stride `stride`
+  size_t stride;      // 64: a wave's running points are one contiguous block (C x 12 KB), quad-major inside it
   __device__ __forceinline__ int count() const { return cnt; }
   __device__ __forceinline__ int kind(int j) const {
     const uint32_t v = qref[j];
@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_item
   const uint64_t first = (uint64_t)lo + (uint64_t)c * C;
   int cnt = 0;
   if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
-  const DevMultiAcc acc{P + first, Q + first, qref + first, lines, cnt, ws + t, ws_stride};
+  // workspace: [wave][pair slot][quad][lane of the wave] -- one coalesced 1 KB access per quad, and everything a wave touches
+  // during its whole run sits in one contiguous C x 12 KB block (page locality)
+  const DevMultiAcc acc{P + first, Q + first, qref + first, lines, cnt, ws + (t >> 6) * ((size_t)C * 12 * 64) + (t & 63), ws_stride};
   const Fp12 f = miller_loop_multi(acc);
   st_gt_m(mill + item * L + c, f);
 }
@@ -212,7 +214,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, 64)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, (const G1M*)pl.P,
-          (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, lanes_pad, mill);
+          (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill);
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
 }
 

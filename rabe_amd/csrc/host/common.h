@@ -51,12 +51,15 @@ inline G2 g2_generator() {
 // lsw/mod.rs:129,188; aw11/mod.rs:131,249; aes/mod.rs:11).
 struct Rng : host::FrSource {
   virtual void fill(uint8_t* out, size_t n) = 0;
+  // true when draws carry no order (OS randomness): a batch may then draw on several threads, each from its own source
+  virtual bool unordered() const { return false; }
 };
 struct OsRng : Rng {
   // getrandom(2) in 4 KB refills: a batch draws hundreds of thousands of Fr values, one system call each would dominate it
   uint8_t pool[4096];
   size_t pool_pos = sizeof(pool);
   void fill(uint8_t* out, size_t n) override;
+  bool unordered() const override { return true; }
   Fr next_fr() override {
     uint8_t b[64];
     fill(b, 64);
@@ -132,6 +135,10 @@ class Engine {
   // device tables of AC17 public keys (g, h_a[3], e_gh_ka[2]; ~1.3 GB each with the 16-bit windows), built on first use
   rhip_ac17_pk* ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka);
   size_t fixed_base_min = 4096;   // G1 / G2 elements sharing one base in one call; Gt uses twice that
+  // grow-only pinned host staging buffers (slot 0..3) for the packed batch entry points: PCIe copies at full rate
+  uint8_t* pinned(int slot, size_t bytes);
+  // window table of the Gt generator e(G1::one(), G2::one()) (random Gt messages of a batch in one launch, on device)
+  rhip_gt_table* gt_generator_table();
 
  private:
   rhip_ctx* ctx_ = nullptr;
@@ -141,6 +148,9 @@ class Engine {
   std::map<std::string, rhip_g2_table*> t2_;
   std::map<std::string, rhip_gt_table*> tt_;
   std::map<std::string, rhip_ac17_pk*> pk17_;
+  void* pin_[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pin_bytes_[4] = {0, 0, 0, 0};
+  rhip_gt_table* e_gen_tbl_ = nullptr;
   void destroy_table(rhip_g1_table* t);
   void destroy_table(rhip_g2_table* t);
   void destroy_table(rhip_gt_table* t);

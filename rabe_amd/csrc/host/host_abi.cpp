@@ -391,6 +391,23 @@ int32_t rabe_ac17_cp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                    const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap,
+                                    uint64_t* ct_off) {
+  GUARD_BEGIN
+  return ac17::cp_encrypt_packed(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, strs(policies, n_policies), lang_of(language), n_items, item_policy,
+                                 pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, const uint64_t* ct_off, int32_t* status,
+                                    uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!ac17::cp_decrypt_packed(h->eng, *(const ac17::Ac17CpSecretKey*)sk, n_items, ct_blob, ct_off, status, pt_buf, pt_cap, pt_off, &errors)) return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
 int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                    uint8_t** plaintexts, size_t* lens) {
   GUARD_BEGIN

@@ -1,7 +1,7 @@
 """rabe::schemes::ac17 (src/schemes/ac17/mod.rs:141-430) over the host layer."""
 import ctypes
 
-from ..hostlib import JSON_POLICY, Obj, _strs, batch_decrypt, batch_items
+from ..hostlib import JSON_POLICY, Obj, _check as _hl_check, _strs, batch_decrypt, batch_items
 
 
 def setup(host):
@@ -96,3 +96,55 @@ def kp_encrypt_batch(host, pk, attribute_sets, datas):
 
 def kp_decrypt_batch(host, sks, cts):
     return batch_decrypt(host, "rabe_ac17_kp_decrypt_batch", (), sks, cts)
+
+
+def hostlib_check(rc, host):
+    _hl_check(rc, host.h)
+
+
+# ---- packed batches: one blob + offsets on both sides (rabe_ac17_cp_{encrypt,decrypt}_packed), caller-allocated numpy buffers
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as_u8(b):
+    import numpy as np
+    return b if isinstance(b, np.ndarray) else np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def cp_encrypt_packed(host, pk, policies, item_policy, pt_blob, pt_off, language=JSON_POLICY, out=None):
+    """policies: distinct policy texts; item_policy[i] indexes them; plaintext i = pt_blob[pt_off[i]:pt_off[i+1]].
+    out: an optional numpy uint8 buffer to write into (re-used across calls); allocated when missing or too small.
+    Returns (ct_blob: numpy uint8 view of exactly the records, ct_off: numpy uint64 [n+1])."""
+    import numpy as np
+    n = len(item_policy)
+    arr, npol = _strs(policies)
+    ip = np.ascontiguousarray(item_policy, dtype=np.uint32)
+    po = np.ascontiguousarray(pt_off, dtype=np.uint64)
+    pt = _as_u8(pt_blob)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_ac17_cp_encrypt_packed(host.h, pk.ptr, arr, npol, language, ctypes.c_size_t(n), _np_ptr(ip), _np_ptr(pt), _np_ptr(po),
+                                                  _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(co))
+        if rc != 1:
+            break
+        buf = np.empty(int(co[n]), dtype=np.uint8)
+    hostlib_check(rc, host)
+    return buf[:int(co[n])], co
+
+
+def cp_decrypt_packed(host, sk, ct_blob, ct_off, out=None):
+    """Returns (pt_blob: numpy uint8 view, pt_off: numpy uint64 [n+1], status: numpy int32 [n]); status[i] != 0: item i did not decrypt."""
+    import numpy as np
+    n = len(ct_off) - 1
+    ct = _as_u8(ct_blob)
+    co = np.ascontiguousarray(ct_off, dtype=np.uint64)
+    po = np.zeros(n + 1, dtype=np.uint64)
+    status = np.zeros(max(n, 1), dtype=np.int32)
+    need = int(co[n] - co[0])
+    buf = out if out is not None and out.size >= need else np.empty(max(need, 1), dtype=np.uint8)
+    rc = host.lib.rabe_ac17_cp_decrypt_packed(host.h, sk.ptr, ctypes.c_size_t(n), _np_ptr(ct), _np_ptr(co), _np_ptr(status), _np_ptr(buf),
+                                              ctypes.c_size_t(buf.size), _np_ptr(po))
+    hostlib_check(rc, host)
+    return buf[:int(po[n])], po, status[:n]

@@ -1,0 +1,65 @@
+"""Packed AC17 batches (rabe_ac17_cp_{encrypt,decrypt}_packed): the records are byte-identical to serialising the objects the
+per-object batch API returns on the same tape; decrypting them returns the plaintexts; a key that does not satisfy one policy,
+a truncated record and a tampered record fail their own item only."""
+import numpy as np
+import pytest
+
+from rabe_amd import hostlib as hl
+from rabe_amd.schemes import ac17
+
+pytestmark = pytest.mark.gpu
+POLS = ['"A" and "B"', '"A" or ("B" and "C")', '"C" and ("A" or "D")']
+
+
+@pytest.fixture(scope="module")
+def host():
+    h = hl.Host(0)
+    yield h
+    h.close()
+
+
+def test_packed_records_equal_object_serialisation_on_the_same_tape(host):
+    pk, msk = ac17.setup(host)
+    n = 9
+    item_pol = [i % 3 for i in range(n)]
+    pts = [b"plaintext-%d" % i * (i + 1) for i in range(n)]
+    tape = [1000003 * (i + 7) + 11 for i in range(4 * n)]                    # s0, s1, msg exponent, nonce per item
+    host.set_tape(tape)
+    objs = ac17.cp_encrypt_batch(host, pk, [POLS[p] for p in item_pol], pts, hl.HUMAN_POLICY)
+    host.set_tape(tape)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+    blob, ct_off = ac17.cp_encrypt_packed(host, pk, POLS, item_pol, b"".join(pts), off, hl.HUMAN_POLICY)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes(), i
+    sk = ac17.cp_keygen(host, msk, ["A", "B", "C"])
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, blob, ct_off)
+    assert not status.any() and out.tobytes() == b"".join(pts) and (out_off == off).all()
+    # the packed records are ordinary ciphertexts: the object API decrypts them too
+    for i in (0, 4):
+        assert ac17.cp_decrypt(host, sk, hl.Obj.deserialize("ac17_cp_ct", blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes())) == pts[i]
+
+
+def test_packed_decrypt_fails_items_individually(host):
+    pk, msk = ac17.setup(host)
+    n = 6
+    item_pol = [i % 3 for i in range(n)]
+    pts = [b"item %d" % i for i in range(n)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+    blob, ct_off = ac17.cp_encrypt_packed(host, pk, POLS, item_pol, b"".join(pts), off, hl.HUMAN_POLICY)
+    sk_ab = ac17.cp_keygen(host, msk, ["A", "B"])                          # does not satisfy policy 2 ("C" and ...)
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk_ab, blob, ct_off)
+    assert list(status) == [0, 0, -1, 0, 0, -1]
+    assert [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(n)] == [pts[0], pts[1], b"", pts[3], pts[4], b""]
+    # tamper with item 1's sealed bytes, truncate item 3's record (by lying about its extent)
+    blob = blob.tobytes()
+    bad = bytearray(blob)
+    bad[int(ct_off[2]) - 3] ^= 0x40
+    off2 = ct_off.copy()
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk_ab, bytes(bad), off2)
+    assert list(status) == [0, -1, -1, 0, 0, -1]
+    cut = blob[:int(ct_off[3])] + blob[int(ct_off[3]):int(ct_off[4]) - 40] + blob[int(ct_off[4]):]
+    off3 = ct_off.copy()
+    off3[4:] -= 40
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk_ab, cut, off3)
+    assert list(status) == [0, 0, -1, -1, 0, -1]
