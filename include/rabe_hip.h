@@ -120,6 +120,17 @@ int32_t rhip_pairing(rhip_ctx* ctx, size_t n, const rhip_g1* dev_p, const rhip_g
 int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uint32_t* dev_off, size_t n_pairs,
                              const rhip_g1* dev_p, const rhip_g2* dev_q, rhip_gt* dev_out);
 
+/* The general form the decrypts of bsw / lsw / aw11 / ghw11 reduce to (coefficient-folded products of pairings):
+ *   out[i] = lead[i] * FE( prod_{j in [pair_off[i], pair_off[i+1])} ML(scal[j] * base[j], q[j])  *  ML( sum_{t in [sum_off[i], sum_off[i+1])} s_scal[t] * s_base[t], s_q[i] ) )
+ * in one launch set: the G1 arguments are scaled over the NAF of their coefficients (the shorter of c and r - c), the sum runs with
+ * shared doublings, all pairs of an item share a few Fq12 accumulators, one final exponentiation per item.  dev_scal NULL: all 1;
+ * dev_sum_off NULL: no summed pair (dev_s_* ignored); dev_lead NULL: no leading factor.  max_pairs / max_terms: the largest per-item
+ * counts (they size the launch). */
+int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t n_pairs, const uint32_t* dev_pair_off /*[n_items+1]*/,
+                          const rhip_g1* dev_base, const rhip_fr* dev_scal, const rhip_g2* dev_q, size_t max_terms, size_t n_terms,
+                          const uint32_t* dev_sum_off /*[n_items+1] or NULL*/, const rhip_g1* dev_s_base, const rhip_fr* dev_s_scal,
+                          const rhip_g2* dev_s_q /*[n_items]*/, const rhip_gt* dev_lead /*[n_items] or NULL*/, rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- Level E, host-value forms: ONE element per call, host pointers (upload, launch, download).  These are what an
  * operator-overloading replacement of the `rabe_bn` crate binds (`impl Mul<Fr> for G1`, `pairing(p, q)`, ...; see
  * INTEGRATION.md section 2 and integration/rabe-bn-shim/): whole-program parity runs of unmodified rabe, not throughput. */

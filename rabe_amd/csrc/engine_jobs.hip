@@ -1025,3 +1025,84 @@ extern "C" int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* a, 
   KLAUNCH(ctx, "k_gt_is_member", k_gt_is_member, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, ok);
   return RHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ generic pairing jobs
+// The shape every decrypt of the host layer plans to (rabe_amd/csrc/host/schemes.cpp: PairingJob), device-resident:
+//   out[i] = lead[i] * FE( prod_{j in pairs(i)} ML(scal_j * base_j, q_j)  *  ML( sum_{t in terms(i)} s_scal_t * s_base_t, s_q[i] ) )
+// One launch set for the whole batch: NAF scaling of the G1 arguments, the shared-doubling sum, all pairs of an item on a few
+// accumulators, one final exponentiation per item.  sum_off == NULL: no summed pair.  lead == NULL: no leading factor.
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_jobs_pairs(size_t n_items, size_t total, const uint32_t* cpair_off, const uint32_t* pair_off,
+                                                                 const rhip_g1* base, const rhip_fr* scal, const rhip_g2* q, const rhip_g2* s_q,
+                                                                 G1M* P, G2M* Q, uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < total;
+  if (!active) t = total - 1;
+  const size_t item = owner_of(cpair_off, n_items, t);
+  const uint32_t j = (uint32_t)(t - cpair_off[item]);
+  const uint32_t np = pair_off[item + 1] - pair_off[item];
+  const bool is_sum = (j >= np);
+  G1Aff b = aff_inf<Fp>();
+  uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  const rhip_g2* qs = s_q + item;
+  if (!is_sum) {
+    const size_t src = (size_t)pair_off[item] + j;
+    b = load_g1(base[src].l);
+    if (scal) ld_scalar(k, scal + src);
+    qs = q + src;
+  }
+  bool p_inf;
+  scale_and_store(lds, active && !is_sum, b, k, false, P + t, &p_inf);
+  if (!active) return;
+  const G2Aff qq = load_g2(qs->l);
+  const bool skip = (!is_sum && p_inf) || aff_is_inf(qq);          // the sum pair's P comes from k_msm_finish_g1 (which may skip it)
+  if (!skip) st_g2_q(Q + t, qq);
+  qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+}
+// combined pair offsets: item i owns pair_off[i+1] - pair_off[i] plain pairs plus (with_sum) one summed pair
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_cpair_off(size_t n_items, const uint32_t* pair_off, int with_sum, uint32_t* cpair_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_items) cpair_off[i] = pair_off[i] + (with_sum ? (uint32_t)i : 0u);
+}
+// Montgomery copies of the sum's bases
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_to_mont(size_t n, const rhip_g1* in, G1M* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st_g1_q(out + i, load_g1(in[i].l));
+}
+extern "C" int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t n_pairs, const uint32_t* pair_off, const rhip_g1* base,
+                                     const rhip_fr* scal, const rhip_g2* q, size_t max_terms, size_t n_terms, const uint32_t* sum_off,
+                                     const rhip_g1* s_base, const rhip_fr* s_scal, const rhip_g2* s_q, const rhip_gt* lead, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (!pair_off) return RHIP_ERR_ARG;
+  const bool with_sum = sum_off != nullptr;
+  const size_t total = n_pairs + (with_sum ? n_items : 0);
+  if (!total) return RHIP_ERR_ARG;
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, total, &pl);
+  if (rc) return rc;
+  void *w_terms = nullptr, *w_masks = nullptr, *w_part = nullptr, *w_off = nullptr;
+  uint32_t L = 1, C = 1;
+  if (with_sum) choose_msm_chunks(ctx, n_items, max_terms ? max_terms : 1, &L, &C);
+  rc = rhip_ensure_work(ctx, 7, (n_items + 1) * sizeof(uint32_t), &w_off);
+  if (!rc && with_sum) rc = rhip_ensure_work(ctx, 4, (n_terms ? n_terms : 1) * sizeof(G1M), &w_terms);
+  if (!rc && with_sum) rc = rhip_ensure_work(ctx, 5, (n_terms ? n_terms : 1) * 16 * sizeof(uint32_t), &w_masks);
+  if (!rc && with_sum) rc = rhip_ensure_work(ctx, 6, n_items * L * sizeof(G1JM), &w_part);
+  if (rc) return rc;
+  uint32_t* cpo = (uint32_t*)w_off;
+  KLAUNCH(ctx, "k_cpair_off", k_cpair_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, with_sum ? 1 : 0, cpo);
+  KLAUNCH(ctx, "k_jobs_pairs", k_jobs_pairs, dim3(blocks_for(total, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total,
+          (const uint32_t*)cpo, pair_off, base, scal, q, s_q, pl.P, pl.Q, pl.qref);
+  if (with_sum) {
+    if (n_terms) {
+      KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_terms, 256)), dim3(256), 0, ctx->stream, n_terms, s_scal, (uint32_t*)w_masks);
+      KLAUNCH(ctx, "k_g1_to_mont", k_g1_to_mont, dim3(blocks_for(n_terms, 256)), dim3(256), 0, ctx->stream, n_terms, s_base, (G1M*)w_terms);
+    }
+    // every item's terms start at sum_off[i] in the term arrays AND in the mask array (one mask per term)
+    KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
+            sum_off, sum_off, (const G1M*)w_terms, (const uint32_t*)w_masks, 0, (G1JM*)w_part);
+    KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
+            (const G1JM*)w_part, (const uint32_t*)cpo, pl.P, pl.qref);
+  }
+  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), pl, (const LineM*)nullptr, lead, out);
+}

@@ -334,84 +334,59 @@ struct PairingJob {
   bool failed = false;
   std::string error;
 };
-// sum of each group's points: pairwise additions, one rhip_g1_add launch per tree level for all groups together
-static std::vector<G1> g1_group_sums(Engine& e, std::vector<std::vector<G1>> groups) {
-  for (;;) {
-    std::vector<G1> a, b;
-    for (auto& g : groups)
-      for (size_t i = 0; i + 1 < g.size(); i += 2) { a.push_back(g[i]); b.push_back(g[i + 1]); }
-    if (a.empty()) break;
-    std::vector<G1> s = g1_add(e, a, b);
-    size_t pos = 0;
-    for (auto& g : groups) {
-      std::vector<G1> next;
-      for (size_t i = 0; i + 1 < g.size(); i += 2) next.push_back(s[pos++]);
-      if (g.size() & 1) next.push_back(g.back());
-      g.swap(next);
-    }
-  }
-  std::vector<G1> out;
-  for (auto& g : groups) { G1 z{}; out.push_back(g.empty() ? z : g[0]); }
-  return out;
-}
 static std::vector<Gt> run_pairing_jobs(Engine& e, const std::vector<PairingJob>& jobs) {
   StageTimer tm("run_pairing_jobs");
   std::vector<size_t> live;
   for (size_t i = 0; i < jobs.size(); i++) if (!jobs[i].failed) live.push_back(i);
   std::vector<Gt> out(jobs.size());
   if (live.empty()) return out;
-  std::vector<G1> base;
-  std::vector<Fr> scal;
   std::vector<Gt> gb;
   std::vector<Fr> gk;
-  bool any_sum = false;
+  bool any_sum = false, any_pair = false;
   for (size_t i : live) {
     const PairingJob& j = jobs[i];
-    base.insert(base.end(), j.base.begin(), j.base.end());
-    scal.insert(scal.end(), j.scal.begin(), j.scal.end());
-    base.insert(base.end(), j.sbase.begin(), j.sbase.end());
-    scal.insert(scal.end(), j.sscal.begin(), j.sscal.end());
     gb.insert(gb.end(), j.gbase.begin(), j.gbase.end());
     gk.insert(gk.end(), j.gexp.begin(), j.gexp.end());
     any_sum = any_sum || !j.sbase.empty();
+    any_pair = any_pair || !j.base.empty() || !j.sbase.empty();
   }
   Gt gt_one{};
   gt_one[0] = 1;
   std::vector<Gt> acc(live.size());
   for (size_t t = 0; t < live.size(); t++) acc[t] = jobs[live[t]].lead_one ? gt_one : jobs[live[t]].lead;
-  if (!base.empty()) {
+  if (any_pair) {
     tm.lap("concat");
-    std::vector<G1> scaled = e.g1_mul(base, scal);
-    tm.lap("g1_mul");
-    // per item: its plain pairs, then (if any) the pair with the summed G1 argument
-    std::vector<G1> p;
-    std::vector<G2> q;
-    std::vector<uint32_t> off{0};
-    std::vector<std::vector<G1>> groups;
-    size_t pos = 0;
+    // the whole batch in ONE device call (rhip_pairing_jobs): NAF scaling of the G1 arguments, the summed argument with shared
+    // doublings, every item's pairs on a few Fq12 accumulators, one final exponentiation per item, times the leading factor
+    std::vector<uint8_t> fb, fs, fq, fsb, fss, fsq;
+    std::vector<uint32_t> pair_off{0}, sum_off{0};
+    size_t max_pairs = 0, max_terms = 0;
     for (size_t i : live) {
       const PairingJob& j = jobs[i];
-      pos += j.base.size();
-      groups.push_back(std::vector<G1>(scaled.begin() + pos, scaled.begin() + pos + j.sbase.size()));
-      pos += j.sbase.size();
+      for (const auto& x : j.base) fb.insert(fb.end(), x.begin(), x.end());
+      for (const auto& x : j.scal) fs.insert(fs.end(), (const uint8_t*)x.l, (const uint8_t*)x.l + 32);
+      for (const auto& x : j.q) fq.insert(fq.end(), x.begin(), x.end());
+      for (const auto& x : j.sbase) fsb.insert(fsb.end(), x.begin(), x.end());
+      for (const auto& x : j.sscal) fss.insert(fss.end(), (const uint8_t*)x.l, (const uint8_t*)x.l + 32);
+      G2 sq{};
+      if (!j.sbase.empty()) sq = j.sq;
+      fsq.insert(fsq.end(), sq.begin(), sq.end());
+      pair_off.push_back(pair_off.back() + (uint32_t)j.base.size());
+      sum_off.push_back(sum_off.back() + (uint32_t)j.sbase.size());
+      max_pairs = std::max(max_pairs, j.base.size());
+      max_terms = std::max(max_terms, j.sbase.size());
     }
-    std::vector<G1> sums = any_sum ? g1_group_sums(e, groups) : std::vector<G1>();
-    pos = 0;
-    for (size_t t = 0; t < live.size(); t++) {
-      const PairingJob& j = jobs[live[t]];
-      p.insert(p.end(), scaled.begin() + pos, scaled.begin() + pos + j.base.size());
-      q.insert(q.end(), j.q.begin(), j.q.end());
-      pos += j.base.size() + j.sbase.size();
-      if (!j.sbase.empty()) { p.push_back(sums[t]); q.push_back(j.sq); }
-      off.push_back((uint32_t)p.size());
-    }
-    tm.lap("sums + pair lists");
-    auto fp = flatten(p); auto fq = flatten(q);
-    DBuf dp(&e, fp.data(), fp.size()), dq(&e, fq.data(), fq.size()), doff(&e, off.data(), off.size() * 4), dout(&e, live.size() * 384);
-    e.check(rhip_pairing_product(e.ctx(), live.size(), doff.as<uint32_t>(), p.size(), dp.as<rhip_g1>(), dq.as<rhip_g2>(), dout.as<rhip_gt>()),
-            "rhip_pairing_product");
-    acc = e.gt_mul(acc, fetch<384>(dout, live.size()));
-    tm.lap("pairing product + gt_mul");
+    auto flead = flatten(acc);
+    const size_t m = live.size(), np = pair_off.back(), nt = sum_off.back();
+    DBuf dbase(&e, fb.data(), fb.size()), dscal(&e, fs.data(), fs.size()), dq(&e, fq.data(), fq.size()), dpo(&e, pair_off.data(), pair_off.size() * 4),
+        dsb(&e, fsb.data(), fsb.size()), dss(&e, fss.data(), fss.size()), dsq(&e, fsq.data(), fsq.size()), dso(&e, sum_off.data(), sum_off.size() * 4),
+        dlead(&e, flead.data(), flead.size()), dout(&e, m * 384);
+    tm.lap("flatten + upload");
+    e.check(rhip_pairing_jobs(e.ctx(), m, max_pairs, np, dpo.as<uint32_t>(), dbase.as<rhip_g1>(), dscal.as<rhip_fr>(), dq.as<rhip_g2>(), max_terms, nt,
+                              any_sum ? dso.as<uint32_t>() : (const uint32_t*)nullptr, dsb.as<rhip_g1>(), dss.as<rhip_fr>(), dsq.as<rhip_g2>(),
+                              dlead.as<rhip_gt>(), dout.as<rhip_gt>()), "rhip_pairing_jobs");
+    acc = fetch<384>(dout, m);
+    tm.lap("pairing jobs");
   }
   if (!gb.empty()) {
     std::vector<Gt> pw = e.gt_pow(gb, gk);
