@@ -54,6 +54,8 @@ SURVEY_MIXED_ADD_FPMUL = 11
 IMPL_MILLER_FPMUL = 8983            # tests/count_muls.py: miller_loop (NAF chain) with Jacobian P
 IMPL_MILLER2_FPMUL = 12170          # tests/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
 IMPL_FINAL_EXP_FPMUL = 7553         # tests/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
+IMPL_MILLER_MULTI6_FPMUL = 30711    # tests/count_muls.py: miller_loop_multi, an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
+IMPL_MILLER_MULTI6_WALK_FPMUL = 38754   # the same with nothing prepared
 
 
 def parse_args():
@@ -461,13 +463,17 @@ def main():
         m_avg = sel_per_batch / B
         NB = G * B
         rows_g = G * rows_per_batch
-        lanes = {"k_ac17_dec_miller": NB * 6, "k_ac17_dec_miller2": NB * 3, "k_final_exp": NB, "k_ac17_dec_miller_c3": NB * 6, "k_final_exp_c3": NB,
-                 "k_ac17_enc_rows": rows_g, "k_ac17_enc_c0": NB * 3, "k_ac17_enc_cp": NB}
+        # lanes of a launch and the algorithmic Fp-muls per lane (SURVEY 8d constants); the shared-accumulator decrypt path
+        # (k_ac17_dec_pairs + k_miller_multi) carries all six Miller loops of an item in one k_miller_multi unit
+        lanes = {"k_ac17_dec_miller": NB * 6, "k_ac17_dec_miller2": NB * 3, "k_miller_multi": NB, "k_ac17_dec_pairs": NB * 6, "k_final_exp": NB,
+                 "k_ac17_dec_miller_c3": NB * 6, "k_final_exp_c3": NB, "k_ac17_enc_rows": rows_g, "k_ac17_enc_c0": NB * 3, "k_ac17_enc_cp": NB}
         alg = {"k_ac17_dec_miller": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL,
                "k_ac17_dec_miller2": 2 * (SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL),
+               "k_miller_multi": 6 * SURVEY_MILLER_FPMUL, "k_ac17_dec_pairs": (m_avg + 0.5) * SURVEY_MIXED_ADD_FPMUL,
                "k_ac17_dec_miller_c3": SURVEY_MILLER_FPMUL + m_avg * SURVEY_MIXED_ADD_FPMUL, "k_final_exp_c3": 9000 + 6 * 54,
                "k_final_exp": 9000 + 6 * 54, "k_ac17_enc_rows": 3 * 352, "k_ac17_enc_c0": 1056, "k_ac17_enc_cp": 2 * 1700 + 54}
         impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_ac17_dec_miller2": IMPL_MILLER2_FPMUL + 2 * m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
+                "k_miller_multi": IMPL_MILLER_MULTI6_FPMUL if sk_lines is not None else IMPL_MILLER_MULTI6_WALK_FPMUL,
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0

@@ -1043,7 +1043,7 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
           (uint32_t*)ctx->fe_ws, lanes);
   return RHIP_OK;
 }
-static bool use_c3(const rhip_ctx* ctx, size_t n_pairs) {
+bool rhip_use_c3(const rhip_ctx* ctx, size_t n_pairs) {
   if (ctx->pairing_mode == 1) return false;
   if (ctx->pairing_mode == 3) return true;
   return n_pairs * 3 <= (size_t)ctx->n_cu * 4 * 63 / 4;      // at most a quarter of the SIMDs busy with one lane each
@@ -1060,7 +1060,7 @@ extern "C" int32_t rhip_pairing_product(rhip_ctx* ctx, size_t n_items, const uin
   int32_t rc = ensure_scratch(ctx, (n_pairs ? n_pairs : 1) * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
-  if (use_c3(ctx, n_pairs)) {
+  if (rhip_use_c3(ctx, n_pairs)) {
     if (n_pairs)
       KLAUNCH(ctx, "k_miller_c3", k_miller_c3, dim3(blocks_for(n_pairs, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_pairs, p, q, mill);
     KLAUNCH(ctx, "k_final_exp_c3", k_final_exp_c3, dim3(blocks_for(n_items, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_items, off, 1u,
@@ -1388,7 +1388,7 @@ extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table*
           (const G2M*)(h_table->dev16 ? h_table->dev16 : h_table->dev), b, n_items, r, k0, h_table->dev16 ? 1 : 0);
   return RHIP_OK;
 }
-extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+int32_t rhip_ac17_cp_decrypt_batch_lanes6(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
                                               const uint32_t* ct_row_off, const rhip_gt* ct_cp, const rhip_g2* sk_k0, const rhip_g1* sk_k,
                                               const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx,
                                               const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
@@ -1398,7 +1398,7 @@ extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, con
   int32_t rc = ensure_scratch(ctx, n_items * 6 * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
-  if (use_c3(ctx, n_items * 6)) {
+  if (rhip_use_c3(ctx, n_items * 6)) {
     KLAUNCH(ctx, "k_ac17_dec_miller_c3", k_ac17_dec_miller_c3, dim3(blocks_for(n_items * 6, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream,
             n_items, ct_c0, ct_c, ct_row_off, sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel, sk_sel_off, mill);
     KLAUNCH(ctx, "k_final_exp_c3", k_final_exp_c3, dim3(blocks_for(n_items, C3_TRIPLES_PER_WAVE)), dim3(64), 0, ctx->stream, n_items,
@@ -1459,7 +1459,7 @@ extern "C" void rhip_ac17_sk_lines_destroy(rhip_ac17_sk_lines* p) {
   (void)hipFree(p->q_inf);
   delete p;
 }
-extern "C" int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+int32_t rhip_ac17_cp_decrypt_batch_prepared_lanes3(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
                                                        const uint32_t* ct_row_off, const rhip_gt* ct_cp, const rhip_ac17_sk_lines* sk_lines,
                                                        const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp,
                                                        const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,

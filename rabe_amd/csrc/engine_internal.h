@@ -58,6 +58,7 @@ int32_t rhip_fail(rhip_ctx* ctx, hipError_t e, const char* what);
 int32_t rhip_ensure_scratch(rhip_ctx* ctx, size_t bytes);
 int32_t rhip_ensure_fe_ws(rhip_ctx* ctx, size_t bytes);
 int32_t rhip_ensure_work(rhip_ctx* ctx, int slot, size_t bytes, void** out);
+bool rhip_use_c3(const rhip_ctx* ctx, size_t n_pairs);
 #define ktime_begin rhip_ktime_begin
 #define ktime_end rhip_ktime_end
 #define fail rhip_fail
@@ -519,3 +520,16 @@ struct DevLineLoad {
     return LineCoeffs{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
   }
 };
+
+// the pairwise AC17 decrypt paths of engine.hip (one lane per pairing / per pairing couple), behind the public entry points
+// of engine_jobs.hip
+struct rhip_ac17_sk_lines;
+int32_t rhip_ac17_cp_decrypt_batch_lanes6(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
+                                          const rhip_gt* ct_cp, const rhip_g2* sk_k0, const rhip_g1* sk_k, const uint32_t* sk_row_off,
+                                          const rhip_g1* sk_kp, const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,
+                                          const uint32_t* sk_sel, const uint32_t* sk_sel_off, rhip_gt* out);
+int32_t rhip_ac17_cp_decrypt_batch_prepared_lanes3(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+                                                   const uint32_t* ct_row_off, const rhip_gt* ct_cp, const rhip_ac17_sk_lines* sk_lines,
+                                                   const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx,
+                                                   const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
+                                                   const uint32_t* sk_sel_off, rhip_gt* out);

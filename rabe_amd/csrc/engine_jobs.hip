@@ -159,14 +159,15 @@ struct DevMultiAcc {
 // lane t = chunk * n_items + item: a wave holds 64 items at the same chunk position, so that batches of equally shaped
 // items run without divergence and read the same prepared lines.  Chunk c of an item = its pairs
 // [pair_off[item] + c C, min(pair_off[item] + (c+1) C, pair_off[item+1])).  Output: mill[item * L + c].
-__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, const G1M* P,
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                   const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
                                                                   GtM* mill) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * L) return;
   const size_t c = t / n_items, item = t % n_items;
-  const uint32_t lo = pair_off[item], hi = pair_off[item + 1];
-  const uint64_t first = (uint64_t)lo + (uint64_t)c * C;
+  // pair_off == NULL: every item owns exactly `uniform` pairs
+  const uint64_t lo = pair_off ? pair_off[item] : (uint64_t)item * uniform, hi = pair_off ? pair_off[item + 1] : (uint64_t)(item + 1) * uniform;
+  const uint64_t first = lo + (uint64_t)c * C;
   int cnt = 0;
   if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
   // workspace: [wave][pair slot][quad][lane of the wave] -- one coalesced 1 KB access per quad, and everything a wave touches
@@ -202,7 +203,7 @@ static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs,
 }
 // Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
 static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, const PairLists& pl, const LineM* lines,
-                              const rhip_gt* mul_in, rhip_gt* out) {
+                              const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
   uint32_t L, C;
   choose_chunks(ctx, n_items, max_pairs, &L, &C);
   const size_t lanes = n_items * L;
@@ -213,7 +214,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   rc = ensure_scratch(ctx, lanes * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
-  KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, 64)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, (const G1M*)pl.P,
+  KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, 64)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
           (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill);
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
 }
@@ -1105,4 +1106,98 @@ extern "C" int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_p
             (const G1JM*)w_part, (const uint32_t*)cpo, pl.P, pl.qref);
   }
   return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), pl, (const LineM*)nullptr, lead, out);
+}
+
+
+// ------------------------------------------------------------------------------------------------ AC17 decrypt on shared accumulators
+// ac17::cp_decrypt (src/schemes/ac17/mod.rs:385-430) as a pair list: item i owns six pairs, couple j < 3 =
+//   6i + 2j     : P =  sum_{x in ct_sel} C[x][j],                Q = k_0[j]   (the key: prepared lines when the key was prepared)
+//   6i + 2j + 1 : P = -(k_p[j] + sum_{x in sk_sel} K[x][j]),     Q = c_0[j]
+// so that ALL six pairings of an item can run on one Fq12 accumulator (one squaring per doubling step instead of three with a lane
+// per couple, six with a lane per pairing) whenever the launch is large enough to fill the chip that way; small launches are
+// chunked into couples by the same rounds x lane-time model as every other pair list.
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_ac17_dec_pairs(size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
+                                                                     const rhip_g2* sk_k0, const uint8_t* sk_qinf, int prepared, const rhip_g1* sk_k,
+                                                                     const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx,
+                                                                     const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
+                                                                     const uint32_t* sk_sel_off, G1M* P, G2M* Q, uint32_t* qref) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = n_items * 6;
+  const bool active = t < total;
+  if (!active) t = total - 1;
+  const size_t item = t / 6;
+  const int j = (int)((t % 6) >> 1), side = (int)(t & 1);
+  const uint32_t sk = sk_idx[item];
+  G1Jac acc = jac_inf<Fp>();
+  if (side == 0) {
+    const uint32_t base = ct_row_off[item];
+    for (uint32_t x = ct_sel_off[item]; x < ct_sel_off[item + 1]; x++)
+      acc = jac_madd_fast(acc, load_g1(ct_c[(size_t)(base + ct_sel[x]) * 3 + j].l));
+  } else {
+    const uint32_t base = sk_row_off[sk];
+    acc = aff_to_jac(load_g1(sk_kp[(size_t)sk * 3 + j].l));
+    for (uint32_t x = sk_sel_off[item]; x < sk_sel_off[item + 1]; x++)
+      acc = jac_madd_fast(acc, load_g1(sk_k[(size_t)(base + sk_sel[x]) * 3 + j].l));
+    acc = jac_neg(acc);
+  }
+  const bool p_inf = !active || jac_is_inf(acc);
+  const Fp zinv = block_batch_inverse_n<RB_PAIRS_BLOCK>(lds, p_inf ? one<FpParams>() : acc.z);
+  if (!active) return;
+  if (!p_inf) st_g1_q(P + t, jac_to_aff_with_zinv(acc, zinv));
+  if (side == 0 && prepared) {
+    const uint32_t line = sk * 3 + (uint32_t)j;
+    qref[t] = (p_inf || sk_qinf[line]) ? RHIP_Q_SKIP : line;
+    return;
+  }
+  const G2Aff q = load_g2((side == 0 ? sk_k0 + (size_t)sk * 3 + j : ct_c0 + item * 3 + j)->l);
+  const bool skip = p_inf || aff_is_inf(q);
+  if (!skip) st_g2_q(Q + t, q);
+  qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+}
+static int32_t ac17_decrypt_shared(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
+                                   const rhip_gt* ct_cp, const rhip_g2* sk_k0, const rhip_ac17_sk_lines* sk_lines, const rhip_g1* sk_k,
+                                   const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx, const uint32_t* ct_sel,
+                                   const uint32_t* ct_sel_off, const uint32_t* sk_sel, const uint32_t* sk_sel_off, rhip_gt* out) {
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, n_items * 6, &pl);
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_ac17_dec_pairs", k_ac17_dec_pairs, dim3(blocks_for(n_items * 6, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, ct_c0, ct_c,
+          ct_row_off, sk_k0, (const uint8_t*)(sk_lines ? sk_lines->q_inf : nullptr), sk_lines ? 1 : 0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off,
+          sk_sel, sk_sel_off, pl.P, pl.Q, pl.qref);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, ct_cp, out);
+}
+// which AC17 decrypt path a launch takes: 0 = shared accumulators (this file), 1 = one lane per pairing / couple (engine.hip).
+// RABE_AC17_DEC_PATH overrides for A/B runs.  Small launches keep the pairwise kernels (their three-lane form is latency-optimised).
+static int ac17_dec_path(const rhip_ctx* ctx, size_t n_items) {
+  static const int forced = getenv("RABE_AC17_DEC_PATH") ? atoi(getenv("RABE_AC17_DEC_PATH")) : -1;
+  if (forced >= 0) return forced;
+  return rhip_use_c3(ctx, n_items * 6) ? 1 : 0;
+}
+extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,
+                                              const rhip_gt* ct_cp, const rhip_g2* sk_k0, const rhip_g1* sk_k, const uint32_t* sk_row_off,
+                                              const rhip_g1* sk_kp, const uint32_t* sk_idx, const uint32_t* ct_sel, const uint32_t* ct_sel_off,
+                                              const uint32_t* sk_sel, const uint32_t* sk_sel_off, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (ac17_dec_path(ctx, n_items) == 1)
+    return rhip_ac17_cp_decrypt_batch_lanes6(ctx, n_items, ct_c0, ct_c, ct_row_off, ct_cp, sk_k0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel,
+                                             sk_sel_off, out);
+  return ac17_decrypt_shared(ctx, n_items, ct_c0, ct_c, ct_row_off, ct_cp, sk_k0, nullptr, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel,
+                             sk_sel_off, out);
+}
+extern "C" int32_t rhip_ac17_cp_decrypt_batch_prepared(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c,
+                                                       const uint32_t* ct_row_off, const rhip_gt* ct_cp, const rhip_ac17_sk_lines* sk_lines,
+                                                       const rhip_g1* sk_k, const uint32_t* sk_row_off, const rhip_g1* sk_kp, const uint32_t* sk_idx,
+                                                       const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
+                                                       const uint32_t* sk_sel_off, rhip_gt* out) {
+  NEED(ctx);
+  if (!sk_lines) return RHIP_ERR_ARG;
+  if (!n_items) return RHIP_OK;
+  static const int forced = getenv("RABE_AC17_DEC_PATH") ? atoi(getenv("RABE_AC17_DEC_PATH")) : -1;
+  if (forced == 1)
+    return rhip_ac17_cp_decrypt_batch_prepared_lanes3(ctx, n_items, ct_c0, ct_c, ct_row_off, ct_cp, sk_lines, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel,
+                                                      ct_sel_off, sk_sel, sk_sel_off, out);
+  return ac17_decrypt_shared(ctx, n_items, ct_c0, ct_c, ct_row_off, ct_cp, nullptr, sk_lines, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off, sk_sel,
+                             sk_sel_off, out);
 }
