@@ -162,42 +162,117 @@ RB_HD Mont<M> dbl(const Mont<M>& a) {
 // Montgomery multiplication, CIOS over 32-bit limbs.  136 limb products (64 a*b, 64 m*p, 8 m).
 // Inputs < mod, output < mod.  Because mod < 2^254 the running value never exceeds 2*mod, so the
 // ninth accumulator word stays zero and only one conditional subtraction is needed at the end.
+// Which limb products of the device form below can issue WITHOUT a carry capture (see the comment there): compile-time data
+// of the modulus, kept outside the device-only block so that tests/hostsim can hand the very table the kernels use to the
+// exact-integer bound check in tests/test_mac_plan.py.
+template <class M>
+struct ColumnPlan {
+  // safe[k] bit i: the reduction product m_i * mod(k - i) of column k issues without a carry capture.
+  // last_safe bit k (k < 8): so does m_k * mod(0), the product that closes column k (it needs every other product of the
+  // column to be in the safe set).  `top2` tells how much of the budget the top-limb products of the a*b part take.
+  uint16_t safe[16];
+  uint16_t last_safe;
+  constexpr ColumnPlan(bool with_ab, uint32_t top_a, uint32_t top_b) : safe{}, last_safe(0) {
+    constexpr uint64_t LIMIT = 0xFFFFFF00ull;     // sum of the bounding limbs, in units of 2^32; 2^8 units of slack cover the
+                                                  // incoming < 2^37 and the one plain 32-bit addend of redc2
+    for (int k = 0; k < 16; k++) {
+      uint64_t used = 0;
+      if (with_ab && k >= 7 && k <= 14) used = (k == 14) ? (uint64_t)top_a : (uint64_t)top_a + top_b;   // a7 b(k-7) [+ a(k-7) b7]
+      const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k - 1 : 7;        // i range of the m_i * mod(k-i) products, m_k * mod(0) excluded
+      bool taken[8] = {false, false, false, false, false, false, false, false};
+      int n_taken = 0;
+      for (;;) {
+        int best = -1;
+        for (int i = lo; i <= hi; i++)
+          if (!taken[i] && (best < 0 || M::mod(k - i) < M::mod(k - best))) best = i;
+        if (best < 0 || used + M::mod(k - best) > LIMIT) break;
+        used += M::mod(k - best);
+        taken[best] = true;
+        n_taken++;
+        safe[k] = (uint16_t)(safe[k] | (1u << best));
+      }
+      // the closing product is safe only when nothing in the column banks a carry before it
+      const int n_mp = hi - lo + 1;
+      const int n_ab_unsafe = !with_ab ? 0 : (k < 7 ? k + 1 : (k == 14 ? 0 : (15 - k) - 2));
+      if (k < 8 && n_taken == n_mp && n_ab_unsafe == 0 && used + M::mod(0) <= LIMIT) last_safe = (uint16_t)(last_safe | (1u << k));
+    }
+  }
+};
+// plan of a bare reduction (redc2) / of a full product of two operands < mod (top limb <= mod(7)) / of one < mod with an
+// arbitrary 256-bit second operand (to_mont_reduce256: only a's top limb is bounded, and only a7 * b(k-7) is taken as safe)
+template <class M> RB_HD constexpr bool plan_redc_safe(int k, int i) { constexpr ColumnPlan<M> t(false, 0, 0); return (t.safe[k] >> i) & 1; }
+template <class M> RB_HD constexpr bool plan_redc_last_safe(int k) { constexpr ColumnPlan<M> t(false, 0, 0); return (t.last_safe >> k) & 1; }
+template <class M> RB_HD constexpr bool plan_mul_safe(int k, int i) { constexpr ColumnPlan<M> t(true, M::mod(7) + 1, M::mod(7) + 1); return (t.safe[k] >> i) & 1; }
+template <class M> RB_HD constexpr bool plan_mul_last_safe(int k) { constexpr ColumnPlan<M> t(true, M::mod(7) + 1, M::mod(7) + 1); return (t.last_safe >> k) & 1; }
+// a_i * b_(k-i) is a top-limb product of column k
+RB_HD constexpr bool ab_top(int k, int i) { return k >= 7 && (i == 7 || k - i == 7); }
+
 #if defined(__HIP_DEVICE_COMPILE__)
-// gfx950 form: product scanning (FIPS).  Each limb product is ONE `v_mad_u64_u32` into a 64-bit column
-// accumulator plus ONE `v_addc_co_u32` that banks the carry-out in a third word -- 2 instructions per
-// 32x32 MAC, no zero-extension moves, no 64-bit adds (the portable CIOS below compiles to ~4 per MAC).
-// 128 MACs + 8 v_mul_lo_u32 (the m_k) + 16 column shifts + the final conditional subtraction.
+// gfx950 form: product scanning (FIPS).  A limb product is ONE `v_mad_u64_u32` into a 64-bit column accumulator; a
+// product that can carry out of the 64 bits is followed by ONE `v_addc_co_u32` that banks the carry in a third word.
+// Which products can NOT carry is known when the code is written, and those issue the mad alone:
+//   * a column starts from the previous column's high word + its banked carries: < 2^37;
+//   * reduction products m_i * p_j are bounded by p_j * 2^32, so a set of them whose p_j sum to < 2^32 - 2^8 cannot carry
+//     (ColumnPlan picks, per column, the largest such set in ascending p_j -- pure compile-time data of the modulus);
+//   * a product with a TOP limb of an operand < 2p is < 2^31 * 2^32, so the (at most two) top-limb products of a column
+//     cannot carry either (the callers' operands are reduced field elements, or sums of two of them in fp2_mul_lazy_raw).
+// Every other product is carry-banked; the first banking addc of a column also DEFINES the carry word (0 + 0 + carry), so no
+// register is zeroed per column.  ~20 % fewer instructions per multiplication than mad + addc for every product.
+// one chain: mad alone / mad + addc into an existing carry word / mad + addc defining the carry word
+#define RB_MAD(acc_, x_, y_) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc_) : "v"(x_), "v"(y_) : "vcc")
+#define RB_MAD_S(acc_, x_, y_) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc_) : "v"(x_), "s"(y_) : "vcc")
 #define RB_MAC(acc_, ovf_, x_, y_) \
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc_), "+v"(ovf_) : "v"(x_), "v"(y_) : "vcc")
 #define RB_MAC_S(acc_, ovf_, x_, y_) \
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc_), "+v"(ovf_) : "v"(x_), "s"(y_) : "vcc")
-template <class M, class A, class B>
+#define RB_MACF(acc_, ovf_, x_, y_) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc" : "+v"(acc_), "=&v"(ovf_) : "v"(x_), "v"(y_) : "vcc")
+#define RB_MACF_S(acc_, ovf_, x_, y_) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc" : "+v"(acc_), "=&v"(ovf_) : "v"(x_), "s"(y_) : "vcc")
+// carry-banked product, defining the carry word when it is the column's first
+#define RB_BANK(have_, acc_, ovf_, x_, y_) do { if (have_) { RB_MAC(acc_, ovf_, x_, y_); } else { RB_MACF(acc_, ovf_, x_, y_); have_ = true; } } while (0)
+#define RB_BANK_S(have_, acc_, ovf_, x_, y_) do { if (have_) { RB_MAC_S(acc_, ovf_, x_, y_); } else { RB_MACF_S(acc_, ovf_, x_, y_); have_ = true; } } while (0)
+// next column: drop the finished word, the banked carries become the high word
+#define RB_SHIFT(have_, acc_, ovf_) do { acc_ = (acc_ >> 32) | ((have_) ? ((uint64_t)(ovf_) << 32) : 0ull); } while (0)
+
+// B_REDUCED: b < mod as well (false: b is any 256-bit integer, to_mont_reduce256)
+template <class M, bool B_REDUCED = true, class A, class B>
 RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
   uint32_t m[8];
   uint32_t t[8];
   uint64_t acc = 0;
-  uint32_t ovf = 0;
+  uint32_t ovf;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 16; k++) {
+    bool have = false;
+    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
+    // products that cannot carry first
 #pragma unroll
-    for (int i = 0; i <= k; i++) { const uint32_t x = a[i], y = b[k - i]; RB_MAC(acc, ovf, x, y); }
-#pragma unroll
-    for (int i = 0; i < k; i++) { const uint32_t x = m[i], y = M::mod(k - i); RB_MAC_S(acc, ovf, x, y); }
-    m[k] = (uint32_t)acc * M::INV;
-    { const uint32_t x = m[k], y = M::mod(0); RB_MAC_S(acc, ovf, x, y); }
-    acc = (acc >> 32) | ((uint64_t)ovf << 32);
-    ovf = 0;
-  }
-#pragma unroll
-  for (int k = 8; k < 16; k++) {
-#pragma unroll
-    for (int i = k - 7; i < 8; i++) {
-      { const uint32_t x = a[i], y = b[k - i]; RB_MAC(acc, ovf, x, y); }
-      { const uint32_t x = m[i], y = M::mod(k - i); RB_MAC_S(acc, ovf, x, y); }
+    for (int i = lo; i <= hi; i++) {
+      const bool top = B_REDUCED ? ab_top(k, i) : (i == 7);
+      if (top) { const uint32_t x = a[i], y = b[k - i]; RB_MAD(acc, x, y); }
     }
-    t[k - 8] = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)ovf << 32);
-    ovf = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && plan_mul_safe<M>(k, i)) { const uint32_t x = m[i], y = M::mod(k - i); RB_MAD_S(acc, x, y); }
+    // the carry-banked rest
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      const bool top = B_REDUCED ? ab_top(k, i) : (i == 7);
+      if (!top) { const uint32_t x = a[i], y = b[k - i]; RB_BANK(have, acc, ovf, x, y); }
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && !plan_mul_safe<M>(k, i)) { const uint32_t x = m[i], y = M::mod(k - i); RB_BANK_S(have, acc, ovf, x, y); }
+    if (k < 8) {
+      m[k] = (uint32_t)acc * M::INV;
+      const uint32_t x = m[k], y = M::mod(0);
+      if (!have && plan_mul_last_safe<M>(k)) RB_MAD_S(acc, x, y);
+      else RB_BANK_S(have, acc, ovf, x, y);
+    } else {
+      t[k - 8] = (uint32_t)acc;
+    }
+    RB_SHIFT(have, acc, ovf);
   }
   // value < 2*mod < 2^255: nothing left in acc
 #pragma unroll
@@ -208,7 +283,14 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
 // dependency chain (mad -> addc -> mad ...); a kernel that runs one wave per SIMD (the Miller loop and the
 // final exponentiation keep ~500 registers of state) cannot hide that latency with other waves, so the Fp2
 // routines interleave their independent Fp products instead: each step issues N mads then N addcs on N
-// accumulators, with the carries in N different SGPR pairs.
+// accumulators, with the carries in N different SGPR pairs (tools/ubench_mac.hip: 11.4 cycles per product at N = 3
+// against 23 at N = 1, one wave per SIMD).
+#define RB_MAD2(A0, X0, Y0, A1, X1, Y1)                                                               \
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"                          \
+      : "+v"(A0), "+v"(A1), "=&s"(c0_) : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1))
+#define RB_MAD2_S(A0, X0, A1, X1, Y)                                                                  \
+  asm("v_mad_u64_u32 %0, %2, %3, %5, %0\n\tv_mad_u64_u32 %1, %2, %4, %5, %1"                          \
+      : "+v"(A0), "+v"(A1), "=&s"(c0_) : "v"(X0), "v"(X1), "s"(Y))
 #define RB_MAC2(A0, O0, X0, Y0, A1, O1, X1, Y1)                                                       \
   asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %2, %5, %8, %9, %2\n\t"                      \
       "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
@@ -219,6 +301,22 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
       "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "=&s"(c0_), "=&s"(c1_)                                \
       : "v"(X0), "v"(X1), "s"(Y))
+#define RB_MAC2F(A0, O0, X0, Y0, A1, O1, X1, Y1)                                                      \
+  asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %2, %5, %8, %9, %2\n\t"                      \
+      "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
+      : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "=&s"(c0_), "=&s"(c1_)                              \
+      : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1))
+#define RB_MAC2F_S(A0, O0, X0, A1, O1, X1, Y)                                                         \
+  asm("v_mad_u64_u32 %0, %4, %6, %8, %0\n\tv_mad_u64_u32 %2, %5, %7, %8, %2\n\t"                      \
+      "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
+      : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "=&s"(c0_), "=&s"(c1_)                              \
+      : "v"(X0), "v"(X1), "s"(Y))
+#define RB_MAD3(A0, X0, Y0, A1, X1, Y1, A2, X2, Y2)                                                   \
+  asm("v_mad_u64_u32 %0, %3, %4, %5, %0\n\tv_mad_u64_u32 %1, %3, %6, %7, %1\n\tv_mad_u64_u32 %2, %3, %8, %9, %2" \
+      : "+v"(A0), "+v"(A1), "+v"(A2), "=&s"(c0_) : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "v"(X2), "v"(Y2))
+#define RB_MAD3_S(A0, X0, A1, X1, A2, X2, Y)                                                          \
+  asm("v_mad_u64_u32 %0, %3, %4, %7, %0\n\tv_mad_u64_u32 %1, %3, %5, %7, %1\n\tv_mad_u64_u32 %2, %3, %6, %7, %2" \
+      : "+v"(A0), "+v"(A1), "+v"(A2), "=&s"(c0_) : "v"(X0), "v"(X1), "v"(X2), "s"(Y))
 #define RB_MAC3(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2)                                       \
   asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\tv_mad_u64_u32 %2, %7, %11, %12, %2\n\t"                   \
       "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"                                                        \
@@ -233,31 +331,63 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
       "v_addc_co_u32_e64 %5, %8, 0, %5, %8"                                                           \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "+v"(A2), "+v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
       : "v"(X0), "v"(X1), "v"(X2), "s"(Y))
+#define RB_MAC3F(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2)                                      \
+  asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\tv_mad_u64_u32 %2, %7, %11, %12, %2\n\t"                   \
+      "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"                                                        \
+      "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
+      "v_addc_co_u32_e64 %5, %8, 0, 0, %8"                                                            \
+      : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "+v"(A2), "=&v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
+      : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "v"(X2), "v"(Y2))
+#define RB_MAC3F_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y)                                             \
+  asm("v_mad_u64_u32 %0, %6, %9, %12, %0\n\tv_mad_u64_u32 %2, %7, %10, %12, %2\n\t"                   \
+      "v_mad_u64_u32 %4, %8, %11, %12, %4\n\t"                                                        \
+      "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
+      "v_addc_co_u32_e64 %5, %8, 0, 0, %8"                                                            \
+      : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "+v"(A2), "=&v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
+      : "v"(X0), "v"(X1), "v"(X2), "s"(Y))
+#define RB_BANK2(have_, A0, O0, X0, Y0, A1, O1, X1, Y1) \
+  do { if (have_) { RB_MAC2(A0, O0, X0, Y0, A1, O1, X1, Y1); } else { RB_MAC2F(A0, O0, X0, Y0, A1, O1, X1, Y1); have_ = true; } } while (0)
+#define RB_BANK2_S(have_, A0, O0, X0, A1, O1, X1, Y) \
+  do { if (have_) { RB_MAC2_S(A0, O0, X0, A1, O1, X1, Y); } else { RB_MAC2F_S(A0, O0, X0, A1, O1, X1, Y); have_ = true; } } while (0)
+#define RB_BANK3(have_, A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2) \
+  do { if (have_) { RB_MAC3(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2); } else { RB_MAC3F(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2); have_ = true; } } while (0)
+#define RB_BANK3_S(have_, A0, O0, X0, A1, O1, X1, A2, O2, X2, Y) \
+  do { if (have_) { RB_MAC3_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y); } else { RB_MAC3F_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y); have_ = true; } } while (0)
 
+// operands < mod (every caller passes reduced field elements)
 template <class M, class A>
 RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
   uint32_t m0[8], m1[8];
   uint64_t acc0 = 0, acc1 = 0, c0_, c1_;
-  uint32_t ovf0 = 0, ovf1 = 0;
+  uint32_t ovf0, ovf1;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
+    bool have = false;
+    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
 #pragma unroll
-    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) {
-      { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i]; RB_MAC2(acc0, ovf0, x0, y0, acc1, ovf1, x1, y1); }
-      if (i < k || k >= 8) {
-        if (!(k < 8 && i == k)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y); }
-      }
-    }
+    for (int i = lo; i <= hi; i++)
+      if (ab_top(k, i)) { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i]; RB_MAD2(acc0, x0, y0, acc1, x1, y1); }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && plan_mul_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_MAD2_S(acc0, x0, acc1, x1, y); }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!ab_top(k, i)) { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i]; RB_BANK2(have, acc0, ovf0, x0, y0, acc1, ovf1, x1, y1); }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && !plan_mul_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y); }
     if (k < 8) {
       m0[k] = (uint32_t)acc0 * M::INV;
       m1[k] = (uint32_t)acc1 * M::INV;
-      { const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0); RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y); }
+      const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0);
+      if (!have && plan_mul_last_safe<M>(k)) RB_MAD2_S(acc0, x0, acc1, x1, y);
+      else RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y);
     } else {
       r0[k - 8] = (uint32_t)acc0;
       r1[k - 8] = (uint32_t)acc1;
     }
-    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
-    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
+    RB_SHIFT(have, acc0, ovf0);
+    RB_SHIFT(have, acc1, ovf1);
   }
   cond_sub_mod<M>(r0, 0);
   cond_sub_mod<M>(r1, 0);
@@ -267,31 +397,50 @@ RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, 
                          const A& b2) {
   uint32_t m0[8], m1[8], m2[8];
   uint64_t acc0 = 0, acc1 = 0, acc2 = 0, c0_, c1_, c2_;
-  uint32_t ovf0 = 0, ovf1 = 0, ovf2 = 0;
+  uint32_t ovf0, ovf1, ovf2;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
+    bool have = false;
+    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
 #pragma unroll
-    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) {
-      { const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
-        RB_MAC3(acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2); }
-      if (!(k < 8 && i == k)) {
-        const uint32_t x0 = m0[i], x1 = m1[i], x2 = m2[i], y = M::mod(k - i);
-        RB_MAC3_S(acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y);
+    for (int i = lo; i <= hi; i++)
+      if (ab_top(k, i)) {
+        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
+        RB_MAD3(acc0, x0, y0, acc1, x1, y1, acc2, x2, y2);
       }
-    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && plan_mul_safe<M>(k, i)) {
+        const uint32_t x0 = m0[i], x1 = m1[i], x2 = m2[i], y = M::mod(k - i);
+        RB_MAD3_S(acc0, x0, acc1, x1, acc2, x2, y);
+      }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!ab_top(k, i)) {
+        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
+        RB_BANK3(have, acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2);
+      }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!(k < 8 && i == k) && !plan_mul_safe<M>(k, i)) {
+        const uint32_t x0 = m0[i], x1 = m1[i], x2 = m2[i], y = M::mod(k - i);
+        RB_BANK3_S(have, acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y);
+      }
     if (k < 8) {
       m0[k] = (uint32_t)acc0 * M::INV;
       m1[k] = (uint32_t)acc1 * M::INV;
       m2[k] = (uint32_t)acc2 * M::INV;
-      { const uint32_t x0 = m0[k], x1 = m1[k], x2 = m2[k], y = M::mod(0); RB_MAC3_S(acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y); }
+      const uint32_t x0 = m0[k], x1 = m1[k], x2 = m2[k], y = M::mod(0);
+      if (!have && plan_mul_last_safe<M>(k)) RB_MAD3_S(acc0, x0, acc1, x1, acc2, x2, y);
+      else RB_BANK3_S(have, acc0, ovf0, x0, acc1, ovf1, x1, acc2, ovf2, x2, y);
     } else {
       r0[k - 8] = (uint32_t)acc0;
       r1[k - 8] = (uint32_t)acc1;
       r2[k - 8] = (uint32_t)acc2;
     }
-    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
-    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
-    acc2 = (acc2 >> 32) | ((uint64_t)ovf2 << 32); ovf2 = 0;
+    RB_SHIFT(have, acc0, ovf0);
+    RB_SHIFT(have, acc1, ovf1);
+    RB_SHIFT(have, acc2, ovf2);
   }
   cond_sub_mod<M>(r0, 0);
   cond_sub_mod<M>(r1, 0);
@@ -302,22 +451,32 @@ RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, 
 //   W0 = a0 b0 - a1 b1 + p^2   in (0, 2p^2)        W1 = (a0+a1)(b0+b1) - a0 b0 - a1 b1 = a0 b1 + a1 b0  in [0, 2p^2)
 //   c0 = W0 / 2^256 mod p,  c1 = W1 / 2^256 mod p   (REDC output < 1.38 p: one conditional subtraction each)
 // 192 + 128 MACs instead of 3 x 128 + ... = 384 for three full Montgomery products.
+// Operands: a0, b0, a1, b1 < p and a2, b2 < 2p (top limbs < 2^31: the two top-limb products of a column sum to < 2^63.6).
 template <class A>
 RB_HD void wide_mul3(uint32_t* T0, uint32_t* T1, uint32_t* T2, const A& a0, const A& b0, const A& a1, const A& b1, const uint32_t* a2,
                      const uint32_t* b2) {
   uint64_t acc0 = 0, acc1 = 0, acc2 = 0, c0_, c1_, c2_;
-  uint32_t ovf0 = 0, ovf1 = 0, ovf2 = 0;
+  uint32_t ovf0, ovf1, ovf2;
 #pragma unroll
   for (int k = 0; k < 15; k++) {
+    bool have = false;
+    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
 #pragma unroll
-    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k : 7); i++) {
-      const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
-      RB_MAC3(acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2);
-    }
+    for (int i = lo; i <= hi; i++)
+      if (ab_top(k, i)) {
+        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
+        RB_MAD3(acc0, x0, y0, acc1, x1, y1, acc2, x2, y2);
+      }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!ab_top(k, i)) {
+        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
+        RB_BANK3(have, acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2);
+      }
     T0[k] = (uint32_t)acc0; T1[k] = (uint32_t)acc1; T2[k] = (uint32_t)acc2;
-    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
-    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
-    acc2 = (acc2 >> 32) | ((uint64_t)ovf2 << 32); ovf2 = 0;
+    RB_SHIFT(have, acc0, ovf0);
+    RB_SHIFT(have, acc1, ovf1);
+    RB_SHIFT(have, acc2, ovf2);
   }
   T0[15] = (uint32_t)acc0; T1[15] = (uint32_t)acc1; T2[15] = (uint32_t)acc2;
 }
@@ -326,26 +485,31 @@ template <class M>
 RB_HD void redc2(uint32_t* r0, uint32_t* r1, const uint32_t* W0, const uint32_t* W1) {
   uint32_t m0[8], m1[8];
   uint64_t acc0 = 0, acc1 = 0, c0_, c1_;
-  uint32_t ovf0 = 0, ovf1 = 0;
+  uint32_t ovf0, ovf1;
   const uint32_t one_ = 1u;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    { const uint32_t x0 = W0[k], x1 = W1[k]; RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, one_); }
+    bool have = false;
+    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k - 1 : 7;
+    { const uint32_t x0 = W0[k], x1 = W1[k]; RB_MAD2_S(acc0, x0, acc1, x1, one_); }       // + W[k]: < 2^37 + 2^32, no carry
 #pragma unroll
-    for (int i = (k < 8 ? 0 : k - 7); i <= (k < 8 ? k - 1 : 7); i++) {
-      const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i);
-      RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y);
-    }
+    for (int i = lo; i <= hi; i++)
+      if (plan_redc_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_MAD2_S(acc0, x0, acc1, x1, y); }
+#pragma unroll
+    for (int i = lo; i <= hi; i++)
+      if (!plan_redc_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y); }
     if (k < 8) {
       m0[k] = (uint32_t)acc0 * M::INV;
       m1[k] = (uint32_t)acc1 * M::INV;
-      { const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0); RB_MAC2_S(acc0, ovf0, x0, acc1, ovf1, x1, y); }
+      const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0);
+      if (!have && plan_redc_last_safe<M>(k)) RB_MAD2_S(acc0, x0, acc1, x1, y);
+      else RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y);
     } else {
       r0[k - 8] = (uint32_t)acc0;
       r1[k - 8] = (uint32_t)acc1;
     }
-    acc0 = (acc0 >> 32) | ((uint64_t)ovf0 << 32); ovf0 = 0;
-    acc1 = (acc1 >> 32) | ((uint64_t)ovf1 << 32); ovf1 = 0;
+    RB_SHIFT(have, acc0, ovf0);
+    RB_SHIFT(have, acc1, ovf1);
   }
   cond_sub_mod<M>(r0, 0);
   cond_sub_mod<M>(r1, 0);
@@ -378,6 +542,25 @@ RB_HD void fp2_mul_lazy_raw(uint32_t* c0, uint32_t* c1, const A& a0, const A& a1
     for (int i = 0; i < 16; i++) W1[i] = subb32(W1[i], T1[i], br); }
   redc2<FpParams>(c0, c1, W0, W1);
 }
+#undef RB_MAD
+#undef RB_MAD_S
+#undef RB_MACF
+#undef RB_MACF_S
+#undef RB_BANK
+#undef RB_BANK_S
+#undef RB_SHIFT
+#undef RB_MAD2
+#undef RB_MAD2_S
+#undef RB_MAC2F
+#undef RB_MAC2F_S
+#undef RB_MAD3
+#undef RB_MAD3_S
+#undef RB_MAC3F
+#undef RB_MAC3F_S
+#undef RB_BANK2
+#undef RB_BANK2_S
+#undef RB_BANK3
+#undef RB_BANK3_S
 #undef RB_MAC2
 #undef RB_MAC2_S
 #undef RB_MAC3
@@ -386,7 +569,7 @@ RB_HD void fp2_mul_lazy_raw(uint32_t* c0, uint32_t* c1, const A& a0, const A& a1
 #undef RB_MAC_S
 #else
 // host: the interleaved forms are just independent multiplications
-template <class M, class A, class B> RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b);
+template <class M, bool B_REDUCED = true, class A, class B> RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b);
 template <class M, class A>
 RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
   mont_mul_raw<M>(r0, a0, b0);
@@ -400,7 +583,7 @@ RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, 
   mont_mul_raw<M>(r2, a2, b2);
 }
 // portable form (host build of the same headers: tests/hostsim)
-template <class M, class A, class B>
+template <class M, bool B_REDUCED, class A, class B>
 RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
   uint32_t t[9];
 #pragma unroll
@@ -490,7 +673,15 @@ RB_HD Mont<M> to_mont(const uint32_t x[8]) {
   Mont<M> rm;
 #pragma unroll
   for (int i = 0; i < 8; i++) { rm.v[i] = r2[i]; }
-  return mul(xm, rm);
+  // x as the second operand, declared unbounded: exact for ANY 256-bit x (a caller's value is canonical, but a wrong one must
+  // not meet an arithmetic precondition)
+  RB_COUNT_ONE_MUL();
+  uint32_t t[8];
+  mont_mul_raw<M, false>(t, rm.v, xm.v);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
 }
 template <class M>
 RB_HD void from_mont(uint32_t out[8], const Mont<M>& a) {
@@ -515,7 +706,14 @@ RB_HD Mont<M> to_mont_reduce256(const uint32_t x[8]) {
   Mont<M> rm;
 #pragma unroll
   for (int i = 0; i < 8; i++) { rm.v[i] = r2[i]; }
-  return mul(rm, xm);   // x plays `b`: rows use b[i] freely, the a-operand (R2) is < mod
+  // x plays `b`: any 256-bit value there keeps the running sum below 2*mod; the a-operand (R2) is < mod
+  RB_COUNT_ONE_MUL();
+  uint32_t t[8];
+  mont_mul_raw<M, false>(t, rm.v, xm.v);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
 }
 
 // a^(mod-2): Fermat inversion, left-to-right binary over the constant exponent (the instruction

@@ -299,6 +299,73 @@ RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b)
   return f;
 }
 
+// ---- Fq12 operations on an accumulator that lives outside the register file.
+// A lane of the pairing kernels owns the whole 512-entry register file and still an Fq12 operation with its operands,
+// three Fq6 temporaries and the Fq2-level callee's 166 registers does not fit; what the register allocator evicts goes to
+// scratch, i.e. to HBM, with one wave per SIMD and nothing to hide the reload behind.  These forms keep f = c0 + c1 w in
+// a home the caller provides (LDS on the device), fetch each half where it is consumed, and park the one Fq6 value that has
+// to survive the other two products in a second slot -- the same formulas as fp12_sqr / fp12_mul_by_line /
+// fp12_mul_by_two_lines (tower.h), hence the same canonical values.
+// FA provides  Fp6 ld_f6(int half) const, void st_f6(int half, const Fp6&) const, Fp6 ld_x() const, void st_x(const Fp6&) const,
+//              void fence() const   (keeps the compiler from carrying a fetched half across it instead of fetching again)
+template <class FA> RB_HD void facc_set_one(FA a) { a.st_f6(0, fp6_one()); a.st_f6(1, fp6_zero()); }
+template <class FA> RB_HD Fp12 facc_get(FA a) { return Fp12{a.ld_f6(0), a.ld_f6(1)}; }
+template <class FA> RB_HD void facc_finish(FA a, const Fp6& t1, const Fp6& t2) {     // r.c0 = t0 + v t1 ; r.c1 = t2 - t0 - t1, t0 parked
+  const Fp6 t0 = a.ld_x();
+  a.st_f6(0, fp6_add(t0, fp6_mul_v(t1)));
+  a.st_f6(1, fp6_sub(fp6_sub(t2, t0), t1));
+}
+template <class FA> RB_HD void facc_sqr(FA a) {
+  { const Fp6 ab = fp6_mul(a.ld_f6(0), a.ld_f6(1)); a.st_x(ab); }
+  a.fence();
+  Fp6 t;
+  { const Fp6 c0 = a.ld_f6(0), c1 = a.ld_f6(1); t = fp6_mul(fp6_add(c0, c1), fp6_add(c0, fp6_mul_v(c1))); }
+  a.fence();
+  const Fp6 ab = a.ld_x();
+  a.st_f6(0, fp6_sub(fp6_sub(t, ab), fp6_mul_v(ab)));
+  a.st_f6(1, fp6_dbl(ab));
+}
+template <class FA> RB_HD void facc_mul_by_line(FA a, const Fp2& l0, const Fp2& l1, const Fp2& l3) {
+  { const Fp6 t0 = fp6_mul_fp2(a.ld_f6(0), l0); a.st_x(t0); }
+  a.fence();
+  const Fp6 t1 = fp6_mul_by_01(a.ld_f6(1), l1, l3);
+  a.fence();
+  const Fp6 t2 = fp6_mul_by_01(fp6_add(a.ld_f6(0), a.ld_f6(1)), fp2_add(l0, l1), l3);
+  a.fence();
+  facc_finish(a, t1, t2);
+}
+template <class FA> RB_HD void facc_mul_by_two_lines(FA a, const Fp2& a0, const Fp2& a1, const Fp2& a3, const Fp2& b0, const Fp2& b1, const Fp2& b3) {
+  const Fp2 m00 = fp2_mul(a0, b0);
+  const Fp2 m11 = fp2_mul(a1, b1);
+  const Fp2 m33 = fp2_mul(a3, b3);
+  const Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a1), fp2_add(b0, b1)), m00), m11);
+  const Fp2 x03 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a3), fp2_add(b0, b3)), m00), m33);
+  const Fp2 x13 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a1, a3), fp2_add(b1, b3)), m11), m33);
+  const Fp6 p0{fp2_add(m00, fp2_mul_xi(m33)), m11, x13};
+  { const Fp6 t0 = fp6_mul(a.ld_f6(0), p0); a.st_x(t0); }
+  a.fence();
+  const Fp6 t1 = fp6_mul_by_01(a.ld_f6(1), x01, x03);
+  a.fence();
+  const Fp6 t2 = fp6_mul(fp6_add(a.ld_f6(0), a.ld_f6(1)), Fp6{fp2_add(p0.a0, x01), fp2_add(p0.a1, x03), p0.a2});
+  a.fence();
+  facc_finish(a, t1, t2);
+}
+template <class FA> RB_HD void facc_ell(FA a, const LineCoeffs& l, const MillerP& p) {
+  const Fp2 l0 = fp2_mul_fp(l.cy, p.py);
+  const Fp2 l1 = fp2_mul_fp(l.cx, p.px);
+  const Fp2 l3 = p.scaled ? fp2_mul_fp(l.c0, p.pz3) : l.c0;
+  facc_mul_by_line(a, l0, l1, l3);
+}
+template <class FA> RB_HD void facc_ell2(FA a, const LineCoeffs& la, const MillerP& pa, const LineCoeffs& lb, const MillerP& pb) {
+  const Fp2 a0 = fp2_mul_fp(la.cy, pa.py);
+  const Fp2 a1 = fp2_mul_fp(la.cx, pa.px);
+  const Fp2 a3 = pa.scaled ? fp2_mul_fp(la.c0, pa.pz3) : la.c0;
+  const Fp2 b0 = fp2_mul_fp(lb.cy, pb.py);
+  const Fp2 b1 = fp2_mul_fp(lb.cx, pb.px);
+  const Fp2 b3 = pb.scaled ? fp2_mul_fp(lb.c0, pb.pz3) : lb.c0;
+  facc_mul_by_two_lines(a, a0, a1, a3, b0, b1, b3);
+}
+
 // ---- any number of pairings on one accumulator: f = prod_j miller(P_j, Q_j) (up to Fq6 factors the final
 // exponentiation removes).  The Fq12 squaring of a doubling step is paid once for all of the lane's pairs, and the
 // lines of two neighbouring pairs are multiplied together first (ell2).  A pair either walks its own G2 point
@@ -313,6 +380,7 @@ RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b)
 //   G2Aff q(int j) const                      MP_WALK: the G2 argument
 //   LineCoeffs line(int j, int n) const       MP_LINES: prepared triple n (order of g2_prepare_lines)
 //   G2Hom ld_t(int j) const / void st_t(int j, const G2Hom&) const      MP_WALK: the running point
+//   the FA interface above (ld_f6 / st_f6 / ld_x / st_x / fence)         the accumulator's home (LDS on the device)
 enum { MP_WALK = 0, MP_LINES = 1, MP_SKIP = 2 };
 enum { MS_DBL = 0, MS_ADD_POS, MS_ADD_NEG, MS_FROB1, MS_FROB2 };
 template <class ACC>
@@ -336,7 +404,7 @@ RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, LineCoeffs& l) {
 template <class ACC>
 RB_FN Fp12 miller_loop_multi(ACC acc) {
   const int n = acc.count();
-  Fp12 f = fp12_one();
+  facc_set_one(acc);
   for (int j = 0; j < n; j++) {
     if (acc.kind(j) == MP_WALK) {
       const G2Aff q = acc.q(j);
@@ -353,7 +421,7 @@ RB_FN Fp12 miller_loop_multi(ACC acc) {
       const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
       const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
       if (!add_pending) {
-        f = fp12_sqr(f);
+        facc_sqr(acc);
         mode = MS_DBL;
         if (pos | ngt) add_pending = true; else i--;
       } else {
@@ -369,12 +437,12 @@ RB_FN Fp12 miller_loop_multi(ACC acc) {
       LineCoeffs la, lb;
       const bool ha = miller_multi_line(acc, j, mode, ln, la);
       const bool hb = (j + 1 < n) && miller_multi_line(acc, j + 1, mode, ln, lb);
-      if (ha && hb) f = ell2(f, la, acc.p(j), lb, acc.p(j + 1));
-      else if (ha) f = ell(f, la, acc.p(j));
-      else if (hb) f = ell(f, lb, acc.p(j + 1));
+      if (ha && hb) facc_ell2(acc, la, acc.p(j), lb, acc.p(j + 1));
+      else if (ha) facc_ell(acc, la, acc.p(j));
+      else if (hb) facc_ell(acc, lb, acc.p(j + 1));
     }
   }
-  return f;
+  return facc_get(acc);
 }
 
 // f^u for f in the cyclotomic subgroup (u = 4965661367192848881, 63 bits).

@@ -108,6 +108,10 @@ __device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Af
 }
 
 // ------------------------------------------------------------------------------------------------ the multi-pairing kernel
+// The Fq12 accumulator of a lane lives in LDS between operations ([quad][lane of the wave]: conflict-free 16-byte accesses):
+// the kernel runs one wave per SIMD (blocks of one wave), so a wave owns a quarter of the CU's 160 KB, and 96 registers less
+// are live across the line computations -- what the register allocator cannot keep goes to HBM-backed scratch otherwise.
+__shared__ uint4 rb_multi_f[36 * 64];
 struct DevMultiAcc {
   const G1M* P;
   const G2M* Q;
@@ -117,6 +121,33 @@ struct DevMultiAcc {
   uint4* ws;          // this lane's column of its wave's block; running point of pair j: quads [12 j, 12 j + 12) at stride `stride`
   size_t stride;      // 64: a wave's running points are one contiguous block (C x 12 KB), quad-major inside it
   __device__ __forceinline__ int count() const { return cnt; }
+  // half h of the accumulator: quads [12 h, 12 h + 12); the parked Fq6: quads [24, 36)
+  __device__ __forceinline__ Fp6 ld_q12(int q0) const {
+    const uint4* p = rb_multi_f + q0 * 64 + threadIdx.x;
+    Fp6 f;
+    Fp* e = &f.a0.c0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const uint4 a = p[(2 * i) * 64], b = p[(2 * i + 1) * 64];
+      e[i].v[0] = a.x; e[i].v[1] = a.y; e[i].v[2] = a.z; e[i].v[3] = a.w;
+      e[i].v[4] = b.x; e[i].v[5] = b.y; e[i].v[6] = b.z; e[i].v[7] = b.w;
+    }
+    return f;
+  }
+  __device__ __forceinline__ void st_q12(int q0, const Fp6& f) const {
+    uint4* p = rb_multi_f + q0 * 64 + threadIdx.x;
+    const Fp* e = &f.a0.c0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      p[(2 * i) * 64] = make_uint4(e[i].v[0], e[i].v[1], e[i].v[2], e[i].v[3]);
+      p[(2 * i + 1) * 64] = make_uint4(e[i].v[4], e[i].v[5], e[i].v[6], e[i].v[7]);
+    }
+  }
+  __device__ __forceinline__ Fp6 ld_f6(int h) const { return ld_q12(12 * h); }
+  __device__ __forceinline__ void st_f6(int h, const Fp6& v) const { st_q12(12 * h, v); }
+  __device__ __forceinline__ Fp6 ld_x() const { return ld_q12(24); }
+  __device__ __forceinline__ void st_x(const Fp6& v) const { st_q12(24, v); }
+  __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
   __device__ __forceinline__ int kind(int j) const {
     const uint32_t v = qref[j];
     return v == RHIP_Q_WALK ? MP_WALK : v == RHIP_Q_SKIP ? MP_SKIP : MP_LINES;

@@ -150,6 +150,18 @@ void hs_pairing_pair_parked(const uint32_t* pa, const uint32_t* qa, const uint32
 void hs_g1_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_naf(load_g1(p), k))); }
 void hs_g2_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g2(out, jac_to_aff(jac_mul_naf(load_g2(p), k))); }
 }
+// the carry-capture plan the device multiplication uses (bn254/fp.h: ColumnPlan): field 0 = Fp, 1 = Fr; kind 0 = a bare
+// reduction (redc2), 1 = a full product of two reduced operands.  out: safe[16], then last_safe.
+extern "C" void hs_column_plan(int field, int kind, uint16_t* out) {
+  auto emit = [&](auto plan) { for (int k = 0; k < 16; k++) out[k] = plan.safe[k]; out[16] = plan.last_safe; };
+  if (field == 0) {
+    if (kind == 0) emit(ColumnPlan<FpParams>(false, 0, 0));
+    else emit(ColumnPlan<FpParams>(true, FpParams::mod(7) + 1, FpParams::mod(7) + 1));
+  } else {
+    if (kind == 0) emit(ColumnPlan<FrParams>(false, 0, 0));
+    else emit(ColumnPlan<FrParams>(true, FrParams::mod(7) + 1, FrParams::mod(7) + 1));
+  }
+}
 // host accessors of the multi-pairing loop / the shared-doubling MSM (the device ones live in engine_jobs.hip)
 struct HostMultiAcc {
   int n;
@@ -158,7 +170,13 @@ struct HostMultiAcc {
   const G2Aff* Q;
   const LineCoeffs* lines;     // [n][RB_MILLER_LINES]
   G2Hom* T;
+  Fp6* F;                      // [3]: the accumulator's two halves + the parked value
   int count() const { return n; }
+  Fp6 ld_f6(int h) const { return F[h]; }
+  void st_f6(int h, const Fp6& v) const { F[h] = v; }
+  Fp6 ld_x() const { return F[2]; }
+  void st_x(const Fp6& v) const { F[2] = v; }
+  void fence() const {}
   int kind(int j) const { return kinds[j]; }
   MillerP p(int j) const { return miller_p_from_aff(P[j]); }
   G2Aff q(int j) const { return Q[j]; }
@@ -192,7 +210,8 @@ void hs_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint32_t
     if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
     if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
   }
-  store_gt(out, final_exponentiation(miller_loop_multi(HostMultiAcc{n, kk, P, Q, lines, T})));
+  Fp6 F[3];
+  store_gt(out, final_exponentiation(miller_loop_multi(HostMultiAcc{n, kk, P, Q, lines, T, F})));
   delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
 }
 void hs_g1_msm(int n, const uint32_t* p, const uint32_t* k, uint32_t* out) {

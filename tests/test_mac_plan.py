@@ -1,0 +1,119 @@
+"""Exact-integer check of the carry-capture plan of the device field multiplication (rabe_amd/csrc/bn254/fp.h).
+
+The gfx950 multiplication accumulates each column of limb products in a 64-bit register pair and banks a carry-out only for
+the products the plan marks as able to overflow.  This test takes the plan from the very header the kernels are compiled from
+(through tests/hostsim) and recomputes, with Python integers and worst-case limbs, the largest value the accumulator can hold
+before every product that issues WITHOUT a carry capture: it must stay below 2^64.  No GPU needed; the adversarial-limb
+comparison on the device is tests/test_gpu_field_edge.py."""
+import ctypes
+
+import pytest
+
+from oracle import bn254 as bn
+from tests.hostsim import build as hs_build
+
+try:
+    HS = hs_build.load()
+except Exception:  # pragma: no cover
+    HS = None
+
+pytestmark = pytest.mark.skipif(HS is None, reason="hostsim library could not be built")
+
+W = (1 << 32) - 1          # largest limb
+FULL = (1 << 64) - 1
+
+
+def limbs(x):
+    return [(x >> (32 * i)) & W for i in range(8)]
+
+
+def plan(field, kind):
+    out = (ctypes.c_uint16 * 17)()
+    HS.hs_column_plan(field, kind, out)
+    return list(out[:16]), out[16]
+
+
+def top_products(k):
+    """indices i of the a_i * b_(k-i) products that involve a top limb (a_7 or b_7)"""
+    lo, hi = (0, k) if k < 8 else (k - 7, 7)
+    return [i for i in range(lo, hi + 1) if k >= 7 and (i == 7 or k - i == 7)]
+
+
+@pytest.mark.parametrize("field,mod", [(0, bn.P), (1, bn.R)])
+def test_reduction_plan_never_overflows(field, mod):
+    """redc2: column k = incoming + W[k] + sum m_i * p_(k-i) (+ m_k * p_0 for k < 8)."""
+    p = limbs(mod)
+    safe, last = plan(field, 0)
+    incoming = 0
+    n_uncaptured = 0
+    for k in range(16):
+        lo, hi = (0, k - 1) if k < 8 else (k - 7, 7)
+        acc = incoming + W                                   # + W[k], issued without capture
+        assert acc <= FULL
+        banked = 0
+        for i in range(lo, hi + 1):
+            if (safe[k] >> i) & 1:
+                acc += W * p[k - i]
+                assert acc <= FULL, (k, i)
+                n_uncaptured += 1
+        for i in range(lo, hi + 1):
+            if not (safe[k] >> i) & 1:
+                acc += W * p[k - i]; banked += 1
+        if k < 8:
+            if (last >> k) & 1:
+                assert banked == 0, "the closing product may skip the capture only in a column without banked products"
+                acc += W * p[0]
+                assert acc <= FULL, k
+                n_uncaptured += 1
+            else:
+                acc += W * p[0]
+        incoming = acc >> 32                                  # high word + banked carries of the true (unbounded) sum
+        assert incoming < 1 << 37
+    assert n_uncaptured >= 16                                 # the plan actually saves something
+
+
+@pytest.mark.parametrize("field,mod,scale", [(0, bn.P, 1), (1, bn.R, 1), (0, bn.P, 2)])
+def test_product_plan_never_overflows(field, mod, scale):
+    """mont_mul{,2,3}_raw: operands < scale * mod (scale 2: the a0 + a1 sums of the lazy Fq2 product use the same top-limb rule
+    in wide_mul3, which has no reduction products: checked with an empty reduction plan)."""
+    p = limbs(mod)
+    top = ((scale * mod - 1) >> 224)                          # largest top limb of an operand
+    safe, last = plan(field, 1) if scale == 1 else ([0] * 16, 0)
+    incoming = 0
+    for k in range(16 if scale == 1 else 15):
+        lo, hi = (0, k) if k < 8 else (k - 7, 7)
+        tops = top_products(k)
+        acc = incoming
+        for i in tops:                                        # top-limb products first, uncaptured
+            acc += (top * top) if (i == 7 and k - i == 7) else top * W
+            assert acc <= FULL, (k, i)
+        banked = 0
+        if scale == 1:
+            for i in range(lo, hi + 1):
+                if not (k < 8 and i == k) and (safe[k] >> i) & 1:
+                    acc += W * p[k - i]
+                    assert acc <= FULL, (k, i)
+        for i in range(lo, hi + 1):
+            if i not in tops:
+                acc += W * W; banked += 1
+        if scale == 1:
+            for i in range(lo, hi + 1):
+                if not (k < 8 and i == k) and not (safe[k] >> i) & 1:
+                    acc += W * p[k - i]; banked += 1
+            if k < 8:
+                if (last >> k) & 1:
+                    assert banked == 0
+                    acc += W * p[0]
+                    assert acc <= FULL, k
+                else:
+                    acc += W * p[0]
+        incoming = acc >> 32
+        assert incoming < 1 << 37
+
+
+def test_unbounded_second_operand_rule():
+    """to_mont / to_mont_reduce256 (B_REDUCED = false): only a_7 * b_(k-7) skips the capture; b is any 256-bit value."""
+    for mod in (bn.P, bn.R):
+        top = (mod - 1) >> 224
+        incoming = (1 << 37) - 1
+        assert incoming + top * W <= FULL
