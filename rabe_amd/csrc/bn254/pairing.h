@@ -307,6 +307,7 @@ RB_FN Fp12 miller_loop_pair_parked(PARK pk, bool skip_a, LOAD load, bool skip_b)
 // to survive the other two products in a second slot -- the same formulas as fp12_sqr / fp12_mul_by_line /
 // fp12_mul_by_two_lines (tower.h), hence the same canonical values.
 // FA provides  Fp6 ld_f6(int half) const, void st_f6(int half, const Fp6&) const, Fp6 ld_x() const, void st_x(const Fp6&) const,
+//              Fp2 ld_f2(int i) const, void st_f2(int i, const Fp2&) const   (coefficient i of c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2),
 //              void fence() const   (keeps the compiler from carrying a fetched half across it instead of fetching again)
 template <class FA> RB_HD void facc_set_one(FA a) { a.st_f6(0, fp6_one()); a.st_f6(1, fp6_zero()); }
 template <class FA> RB_HD Fp12 facc_get(FA a) { return Fp12{a.ld_f6(0), a.ld_f6(1)}; }
@@ -364,6 +365,43 @@ template <class FA> RB_HD void facc_ell2(FA a, const LineCoeffs& la, const Mille
   const Fp2 b1 = fp2_mul_fp(lb.cx, pb.px);
   const Fp2 b3 = pb.scaled ? fp2_mul_fp(lb.c0, pb.pz3) : lb.c0;
   facc_mul_by_two_lines(a, a0, a1, a3, b0, b1, b3);
+}
+
+// f *= y for a general y; Y provides  Fp6 half(int h) const  (fetched where it is consumed: a table entry or a workspace slot)
+template <class FA, class Y> RB_HD void facc_mul(FA a, Y y) {
+  { const Fp6 t0 = fp6_mul(a.ld_f6(0), y.half(0)); a.st_x(t0); }
+  a.fence();
+  const Fp6 t1 = fp6_mul(a.ld_f6(1), y.half(1));
+  a.fence();
+  const Fp6 t2 = fp6_mul(fp6_add(a.ld_f6(0), a.ld_f6(1)), fp6_add(y.half(0), y.half(1)));
+  a.fence();
+  facc_finish(a, t1, t2);
+  a.fence();
+}
+template <class FA, class Y> RB_HD void facc_set(FA a, Y y) { a.st_f6(0, y.half(0)); a.st_f6(1, y.half(1)); a.fence(); }
+// Granger-Scott squaring in place (fp12_cyclotomic_sqr, tower.h): the pair (c0.a0, c1.a1) is self-contained, the other two
+// pairs feed each other's slots and are squared together.
+template <class FA> RB_HD void facc_cyclotomic_sqr(FA a) {
+  {
+    const Fp2 z0 = a.ld_f2(0), z1 = a.ld_f2(4);
+    Fp2 t0, t1;
+    fp4_sqr(t0, t1, z0, z1);
+    a.st_f2(0, fp2_add(fp2_dbl(fp2_sub(t0, z0)), t0));
+    a.st_f2(4, fp2_add(fp2_dbl(fp2_add(t1, z1)), t1));
+  }
+  a.fence();
+  {
+    const Fp2 z4 = a.ld_f2(1), z3 = a.ld_f2(2), z2 = a.ld_f2(3), z5 = a.ld_f2(5);
+    Fp2 t2, t3, t4, t5;
+    fp4_sqr(t2, t3, z2, z3);
+    fp4_sqr(t4, t5, z4, z5);
+    const Fp2 x5 = fp2_mul_xi(t5);
+    a.st_f2(3, fp2_add(fp2_dbl(fp2_add(x5, z2)), x5));
+    a.st_f2(2, fp2_add(fp2_dbl(fp2_sub(t4, z3)), t4));
+    a.st_f2(1, fp2_add(fp2_dbl(fp2_sub(t2, z4)), t2));
+    a.st_f2(5, fp2_add(fp2_dbl(fp2_add(t3, z5)), t3));
+  }
+  a.fence();
 }
 
 // ---- any number of pairings on one accumulator: f = prod_j miller(P_j, Q_j) (up to Fq6 factors the final
@@ -484,11 +522,23 @@ RB_FN Fp12 final_exponentiation(const Fp12& f_in) {
 // [slot][word][lane]); each operation loads its operands, works in registers and stores its result.
 // WS provides  Fp12 ld(int slot) const  and  void st(int slot, const Fp12&) const.
 enum { FE_F = 0, FE_B, FE_D, FE_E, FE_K, FE_L, FE_T0, FE_T1, FE_SLOTS };
+// WS provides  Fp12 ld(int slot) const, void st(int slot, const Fp12&) const, Fp6 ld6(int slot, int half) const,
+//              void st6(int slot, int half, const Fp6&) const, and  home()  -- an FA (above) for the value being worked on.
+template <class WS> struct WsOperand {
+  WS ws; int slot; bool conj;
+  RB_HD Fp6 half(int h) const { const Fp6 v = ws.ld6(slot, h); return (conj && h == 1) ? fp6_neg(v) : v; }
+};
+template <class WS> RB_HD void wsx_to_home(WS ws, int a, bool conj) { facc_set(ws.home(), WsOperand<WS>{ws, a, conj}); }
+template <class WS> RB_HD void wsx_from_home(WS ws, int dst) {
+  auto h = ws.home();
+  ws.st6(dst, 0, h.ld_f6(0));
+  ws.st6(dst, 1, h.ld_f6(1));
+  h.fence();
+}
 template <class WS> RB_FN void wsx_mul(WS ws, int dst, int a, bool conj_a, int b, bool conj_b) {
-  Fp12 x = ws.ld(a), y = ws.ld(b);
-  if (conj_a) x = fp12_conj(x);
-  if (conj_b) y = fp12_conj(y);
-  ws.st(dst, fp12_mul(x, y));
+  wsx_to_home(ws, a, conj_a);
+  facc_mul(ws.home(), WsOperand<WS>{ws, b, conj_b});
+  wsx_from_home(ws, dst);
 }
 template <class WS> RB_FN void wsx_csqr(WS ws, int dst, int a, bool conj_a) {
   Fp12 x = ws.ld(a);
@@ -496,9 +546,16 @@ template <class WS> RB_FN void wsx_csqr(WS ws, int dst, int a, bool conj_a) {
   ws.st(dst, fp12_cyclotomic_sqr(x));
 }
 template <class WS> RB_FN void wsx_frob_mul(WS ws, int dst, int a, int k, int b) {   // dst = a^(p^k) * b
-  Fp12 x = ws.ld(a);
-  x = (k == 1) ? fp12_frob1(x) : (k == 2) ? fp12_frob2(x) : fp12_frob3(x);
-  ws.st(dst, fp12_mul(x, ws.ld(b)));
+  {
+    Fp12 x = ws.ld(a);
+    x = (k == 1) ? fp12_frob1(x) : (k == 2) ? fp12_frob2(x) : fp12_frob3(x);
+    auto h = ws.home();
+    h.st_f6(0, x.c0);
+    h.st_f6(1, x.c1);
+    h.fence();
+  }
+  facc_mul(ws.home(), WsOperand<WS>{ws, b, false});
+  wsx_from_home(ws, dst);
 }
 template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) {      // fp12_inv with the Fq12 operand / result kept out of stack frames
   const Fp12 x = ws.ld(a);
@@ -506,18 +563,19 @@ template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) {      // fp12_inv
   const Fp6 ti = fp6_inv(t);
   ws.st(dst, Fp12{fp6_mul(x.c0, ti), fp6_neg(fp6_mul(x.c1, ti))});
 }
-// dst = a^(2^n) * (b >= 0 ? b (conjugated if conj_b) : 1): a run of cyclotomic squarings and the multiplication that
-// ends it stay in registers
+// dst = a^(2^n) * (b >= 0 ? b (conjugated if conj_b) : 1): the run of cyclotomic squarings stays in registers (a squaring
+// needs few temporaries), the multiplication that ends it works on the home copy
 template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b, bool conj_b) {
   Fp12 x = ws.ld(a);
 #pragma unroll 1
   for (int i = 0; i < n; i++) x = fp12_cyclotomic_sqr(x);
-  if (b >= 0) {
-    Fp12 y = ws.ld(b);
-    if (conj_b) y = fp12_conj(y);
-    x = fp12_mul(x, y);
-  }
-  ws.st(dst, x);
+  if (b < 0) { ws.st(dst, x); return; }
+  auto h = ws.home();
+  h.st_f6(0, x.c0);
+  h.st_f6(1, x.c1);
+  h.fence();
+  facc_mul(h, WsOperand<WS>{ws, b, conj_b});
+  wsx_from_home(ws, dst);
 }
 // dst = src^u over the width-3 NAF of u (digits +-1, +-3; an inverse in the cyclotomic subgroup is a conjugation):
 // 62 squarings + 17 multiplications + f^3, instead of 62 + 27 for the binary chain.  dst, src, cube distinct slots.

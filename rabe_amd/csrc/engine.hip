@@ -557,7 +557,9 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_pow_gt(const GtM* tb
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  store_gt(out[i].l, table_pow_gt(tbl, kk));
+  bool started = false;
+  home_table_pow_gt(started, tbl, kk);
+  store_gt(out[i].l, home_result(started));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,8 +649,12 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_ac17_enc_cp(const GtM* e0,
   uint32_t k0[8], k1[8];
   ld_scalar(k0, s + 2 * i);
   ld_scalar(k1, s + 2 * i + 1);
-  Fp12 r = w16 ? fp12_mul(table_pow_gt_w16(e0, k0), table_pow_gt_w16(e1, k1)) : fp12_mul(table_pow_gt(e0, k0), table_pow_gt(e1, k1));
-  store_gt(cp[i].l, fp12_mul(r, load_gt(msg[i].l)));
+  // msg * e0^s0 * e1^s1 as ONE running product on the lane's home value
+  home_put(load_gt(msg[i].l));
+  bool started = true;
+  if (w16) { home_table_pow_gt_w16(started, e0, k0); home_table_pow_gt_w16(started, e1, k1); }
+  else { home_table_pow_gt(started, e0, k0); home_table_pow_gt(started, e1, k1); }
+  store_gt(cp[i].l, home_result(true));
 }
 
 // keygen: one lane per (item, y <= n_attrs); y == n_attrs is the k_p row.

@@ -126,35 +126,69 @@ __device__ __forceinline__ void ld_scalar(uint32_t k[8], const rhip_fr* p) {
 
 // out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical.
 // The exponentiation's Fq12 values live in the context's workspace (final_exponentiation_ws, bn254/pairing.h).
+// The home of the Fq12 value a lane is working on (bn254/pairing.h: the FA interface).  The Fq12 kernels run one wave per
+// SIMD -- blocks of ONE wave, 512 registers -- so a wave owns a quarter of the CU's 160 KB of LDS: 576 bytes per lane hold the
+// value's two halves and one parked Fq6, laid out [quad][lane of the wave] (conflict-free 16-byte accesses).  What would
+// otherwise be evicted to scratch (HBM) between the Fq6-level steps is fetched from here instead.  Only kernels launched with
+// 64-thread blocks may use it.
+static __shared__ uint4 rb_facc_lds[36 * 64];
+struct LdsHome {
+  __device__ __forceinline__ Fp ld_fp(int q0) const {
+    const uint4* p = rb_facc_lds + q0 * 64 + threadIdx.x;
+    const uint4 a = p[0], b = p[64];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+  }
+  __device__ __forceinline__ void st_fp(int q0, const Fp& a) const {
+    uint4* p = rb_facc_lds + q0 * 64 + threadIdx.x;
+    p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    p[64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+  }
+  // coefficient i (an Fq2) of the value: quads [4 i, 4 i + 4); the parked Fq6: quads [24, 36)
+  __device__ __forceinline__ Fp2 ld_q4(int q0) const { return Fp2{ld_fp(q0), ld_fp(q0 + 2)}; }
+  __device__ __forceinline__ void st_q4(int q0, const Fp2& a) const { st_fp(q0, a.c0); st_fp(q0 + 2, a.c1); }
+  __device__ __forceinline__ Fp6 ld_q12(int q0) const { return Fp6{ld_q4(q0), ld_q4(q0 + 4), ld_q4(q0 + 8)}; }
+  __device__ __forceinline__ void st_q12(int q0, const Fp6& a) const { st_q4(q0, a.a0); st_q4(q0 + 4, a.a1); st_q4(q0 + 8, a.a2); }
+  __device__ __forceinline__ Fp2 ld_f2(int i) const { return ld_q4(4 * i); }
+  __device__ __forceinline__ void st_f2(int i, const Fp2& v) const { st_q4(4 * i, v); }
+  __device__ __forceinline__ Fp6 ld_f6(int h) const { return ld_q12(12 * h); }
+  __device__ __forceinline__ void st_f6(int h, const Fp6& v) const { st_q12(12 * h, v); }
+  __device__ __forceinline__ Fp6 ld_x() const { return ld_q12(24); }
+  __device__ __forceinline__ void st_x(const Fp6& v) const { st_q12(24, v); }
+  __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
+};
 struct DevWs {
   uint4* base;         // + lane; [slot][quad of words][lane]: one 16-byte access per lane, contiguous over the wave
   size_t stride;       // lanes (padded to 64)
-  __device__ __forceinline__ Fp12 ld(int slot) const {
-    const uint4* p = base + (size_t)slot * 24 * stride;
-    Fp12 r;
-    Fp2* c[6] = {&r.c0.a0, &r.c0.a1, &r.c0.a2, &r.c1.a0, &r.c1.a1, &r.c1.a2};
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const uint4 q0 = p[(size_t)(4 * j) * stride], q1 = p[(size_t)(4 * j + 1) * stride];
-      const uint4 q2 = p[(size_t)(4 * j + 2) * stride], q3 = p[(size_t)(4 * j + 3) * stride];
-      c[j]->c0.v[0] = q0.x; c[j]->c0.v[1] = q0.y; c[j]->c0.v[2] = q0.z; c[j]->c0.v[3] = q0.w;
-      c[j]->c0.v[4] = q1.x; c[j]->c0.v[5] = q1.y; c[j]->c0.v[6] = q1.z; c[j]->c0.v[7] = q1.w;
-      c[j]->c1.v[0] = q2.x; c[j]->c1.v[1] = q2.y; c[j]->c1.v[2] = q2.z; c[j]->c1.v[3] = q2.w;
-      c[j]->c1.v[4] = q3.x; c[j]->c1.v[5] = q3.y; c[j]->c1.v[6] = q3.z; c[j]->c1.v[7] = q3.w;
-    }
-    return r;
+  __device__ __forceinline__ Fp2 ld2(const uint4* p) const {
+    const uint4 q0 = p[0], q1 = p[stride], q2 = p[2 * stride], q3 = p[3 * stride];
+    Fp2 c;
+    c.c0.v[0] = q0.x; c.c0.v[1] = q0.y; c.c0.v[2] = q0.z; c.c0.v[3] = q0.w;
+    c.c0.v[4] = q1.x; c.c0.v[5] = q1.y; c.c0.v[6] = q1.z; c.c0.v[7] = q1.w;
+    c.c1.v[0] = q2.x; c.c1.v[1] = q2.y; c.c1.v[2] = q2.z; c.c1.v[3] = q2.w;
+    c.c1.v[4] = q3.x; c.c1.v[5] = q3.y; c.c1.v[6] = q3.z; c.c1.v[7] = q3.w;
+    return c;
   }
-  __device__ __forceinline__ void st(int slot, const Fp12& a) const {
-    uint4* p = base + (size_t)slot * 24 * stride;
-    const Fp2* c[6] = {&a.c0.a0, &a.c0.a1, &a.c0.a2, &a.c1.a0, &a.c1.a1, &a.c1.a2};
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      p[(size_t)(4 * j) * stride] = make_uint4(c[j]->c0.v[0], c[j]->c0.v[1], c[j]->c0.v[2], c[j]->c0.v[3]);
-      p[(size_t)(4 * j + 1) * stride] = make_uint4(c[j]->c0.v[4], c[j]->c0.v[5], c[j]->c0.v[6], c[j]->c0.v[7]);
-      p[(size_t)(4 * j + 2) * stride] = make_uint4(c[j]->c1.v[0], c[j]->c1.v[1], c[j]->c1.v[2], c[j]->c1.v[3]);
-      p[(size_t)(4 * j + 3) * stride] = make_uint4(c[j]->c1.v[4], c[j]->c1.v[5], c[j]->c1.v[6], c[j]->c1.v[7]);
-    }
+  __device__ __forceinline__ void st2(uint4* p, const Fp2& c) const {
+    p[0] = make_uint4(c.c0.v[0], c.c0.v[1], c.c0.v[2], c.c0.v[3]);
+    p[stride] = make_uint4(c.c0.v[4], c.c0.v[5], c.c0.v[6], c.c0.v[7]);
+    p[2 * stride] = make_uint4(c.c1.v[0], c.c1.v[1], c.c1.v[2], c.c1.v[3]);
+    p[3 * stride] = make_uint4(c.c1.v[4], c.c1.v[5], c.c1.v[6], c.c1.v[7]);
   }
+  // half h of slot: quads [12 h, 12 h + 12)
+  __device__ __forceinline__ Fp6 ld6(int slot, int h) const {
+    const uint4* p = base + ((size_t)slot * 24 + 12 * h) * stride;
+    return Fp6{ld2(p), ld2(p + 4 * stride), ld2(p + 8 * stride)};
+  }
+  __device__ __forceinline__ void st6(int slot, int h, const Fp6& a) const {
+    uint4* p = base + ((size_t)slot * 24 + 12 * h) * stride;
+    st2(p, a.a0); st2(p + 4 * stride, a.a1); st2(p + 8 * stride, a.a2);
+  }
+  __device__ __forceinline__ Fp12 ld(int slot) const { return Fp12{ld6(slot, 0), ld6(slot, 1)}; }
+  __device__ __forceinline__ void st(int slot, const Fp12& a) const { st6(slot, 0, a.c0); st6(slot, 1, a.c1); }
+  __device__ __forceinline__ LdsHome home() const { return LdsHome{}; }
 };
 struct GtM;
 int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
@@ -179,9 +213,21 @@ __host__ __device__ inline size_t wide_offset(int w, int i) { return (size_t)i <
 struct rhip_g2_table { rhip_ctx* ctx; G2M* dev; G2M* dev16; };   // dev16: optional 16-bit windows (134 MB)
 struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optional 16-bit windows (402 MB)
 
-static __device__ __noinline__ Fp12 table_pow_gt_w16(const GtM* tbl, const uint32_t k[8]) {
-  Fp12 acc = fp12_one();
-  bool first = true;
+// ---- fixed-base Gt powers on the lane's home value (LdsHome above): home *= entry for every non-zero window digit.
+// `started` false: the first entry is copied instead of multiplied (and stays false when the scalar is 0).
+struct GtMOperand {
+  const GtM* e;
+  __device__ __forceinline__ Fp6 half(int h) const {
+    const uint32_t* p = e->l + 48 * h;
+    return Fp6{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
+  }
+};
+__device__ __forceinline__ void home_mul_entry(const GtM* e) { facc_mul(LdsHome{}, GtMOperand{e}); }
+__device__ __forceinline__ void home_take(bool& started, const GtM* e) {
+  if (started) home_mul_entry(e);
+  else { facc_set(LdsHome{}, GtMOperand{e}); started = true; }
+}
+static __device__ __noinline__ void home_table_pow_gt_w16(bool& started, const GtM* tbl, const uint32_t k[8]) {
 #pragma unroll 1
   for (int w = 0; w < TBL16_WINDOWS; w++) {
     uint32_t word;
@@ -196,13 +242,8 @@ static __device__ __noinline__ Fp12 table_pow_gt_w16(const GtM* tbl, const uint3
       default: word = k[7]; break;
     }
     const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
-    if (d) {
-      Fp12 e = ld_gt_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1));
-      acc = first ? e : fp12_mul(acc, e);
-      first = false;
-    }
+    if (d) home_take(started, tbl + (size_t)w * TBL16_DIGITS + (d - 1));
   }
-  return acc;
 }
 __device__ __forceinline__ uint32_t scalar_byte(const uint32_t k[8], int w) {
   uint32_t word;
@@ -329,18 +370,20 @@ static __device__ __noinline__ G2Jac table_mul_g2_w16(const G2M* tbl, const uint
   }
   return acc;
 }
-static __device__ __noinline__ Fp12 table_pow_gt(const GtM* tbl, const uint32_t k[8]) {
-  Fp12 acc = fp12_one();
-  bool first = true;
+static __device__ __noinline__ void home_table_pow_gt(bool& started, const GtM* tbl, const uint32_t k[8]) {
+#pragma unroll 1
   for (int w = 0; w < TBL_WINDOWS; w++) {
-    uint32_t d = scalar_byte(k, w);
-    if (d) {
-      Fp12 e = ld_gt_m(tbl + w * TBL_DIGITS + (d - 1));
-      acc = first ? e : fp12_mul(acc, e);
-      first = false;
-    }
+    const uint32_t d = scalar_byte(k, w);
+    if (d) home_take(started, tbl + w * TBL_DIGITS + (d - 1));
   }
-  return acc;
+}
+// the value forms (64-thread blocks only: they go through the home)
+__device__ __forceinline__ Fp12 home_result(bool started) { return started ? facc_get(LdsHome{}) : fp12_one(); }
+__device__ __forceinline__ void home_put(const Fp12& v) {
+  const LdsHome h{};
+  h.st_f6(0, v.c0);
+  h.st_f6(1, v.c1);
+  h.fence();
 }
 // ---- batched inversion across a 256-thread block (Montgomery's trick over LDS + one wave-level scan).
 // Every thread of the block contributes one non-zero Fp value and gets its inverse back; the block pays ONE

@@ -108,11 +108,8 @@ __device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Af
 }
 
 // ------------------------------------------------------------------------------------------------ the multi-pairing kernel
-// The Fq12 accumulator of a lane lives in LDS between operations ([quad][lane of the wave]: conflict-free 16-byte accesses):
-// the kernel runs one wave per SIMD (blocks of one wave), so a wave owns a quarter of the CU's 160 KB, and 96 registers less
-// are live across the line computations -- what the register allocator cannot keep goes to HBM-backed scratch otherwise.
-__shared__ uint4 rb_multi_f[36 * 64];
-struct DevMultiAcc {
+// The Fq12 accumulator of a lane lives in LDS (LdsHome, engine_internal.h) -- nothing of the loop goes to scratch.
+struct DevMultiAcc : LdsHome {
   const G1M* P;
   const G2M* Q;
   const uint32_t* qref;
@@ -121,33 +118,6 @@ struct DevMultiAcc {
   uint4* ws;          // this lane's column of its wave's block; running point of pair j: quads [12 j, 12 j + 12) at stride `stride`
   size_t stride;      // 64: a wave's running points are one contiguous block (C x 12 KB), quad-major inside it
   __device__ __forceinline__ int count() const { return cnt; }
-  // half h of the accumulator: quads [12 h, 12 h + 12); the parked Fq6: quads [24, 36)
-  __device__ __forceinline__ Fp6 ld_q12(int q0) const {
-    const uint4* p = rb_multi_f + q0 * 64 + threadIdx.x;
-    Fp6 f;
-    Fp* e = &f.a0.c0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const uint4 a = p[(2 * i) * 64], b = p[(2 * i + 1) * 64];
-      e[i].v[0] = a.x; e[i].v[1] = a.y; e[i].v[2] = a.z; e[i].v[3] = a.w;
-      e[i].v[4] = b.x; e[i].v[5] = b.y; e[i].v[6] = b.z; e[i].v[7] = b.w;
-    }
-    return f;
-  }
-  __device__ __forceinline__ void st_q12(int q0, const Fp6& f) const {
-    uint4* p = rb_multi_f + q0 * 64 + threadIdx.x;
-    const Fp* e = &f.a0.c0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      p[(2 * i) * 64] = make_uint4(e[i].v[0], e[i].v[1], e[i].v[2], e[i].v[3]);
-      p[(2 * i + 1) * 64] = make_uint4(e[i].v[4], e[i].v[5], e[i].v[6], e[i].v[7]);
-    }
-  }
-  __device__ __forceinline__ Fp6 ld_f6(int h) const { return ld_q12(12 * h); }
-  __device__ __forceinline__ void st_f6(int h, const Fp6& v) const { st_q12(12 * h, v); }
-  __device__ __forceinline__ Fp6 ld_x() const { return ld_q12(24); }
-  __device__ __forceinline__ void st_x(const Fp6& v) const { st_q12(24, v); }
-  __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
   __device__ __forceinline__ int kind(int j) const {
     const uint32_t v = qref[j];
     return v == RHIP_Q_WALK ? MP_WALK : v == RHIP_Q_SKIP ? MP_SKIP : MP_LINES;
@@ -203,7 +173,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_item
   if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
   // workspace: [wave][pair slot][quad][lane of the wave] -- one coalesced 1 KB access per quad, and everything a wave touches
   // during its whole run sits in one contiguous C x 12 KB block (page locality)
-  const DevMultiAcc acc{P + first, Q + first, qref + first, lines, cnt, ws + (t >> 6) * ((size_t)C * 12 * 64) + (t & 63), ws_stride};
+  const DevMultiAcc acc{{}, P + first, Q + first, qref + first, lines, cnt, ws + (t >> 6) * ((size_t)C * 12 * 64) + (t & 63), ws_stride};
   const Fp12 f = miller_loop_multi(acc);
   st_gt_m(mill + item * L + c, f);
 }
@@ -332,8 +302,10 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_table_pow_gt_mul(const GtM
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  const Fp12 p = w16 ? table_pow_gt_w16(tbl, kk) : table_pow_gt(tbl, kk);
-  store_gt(out[i].l, fp12_mul(p, load_gt(m[i].l)));
+  home_put(load_gt(m[i].l));
+  bool started = true;
+  if (w16) home_table_pow_gt_w16(started, tbl, kk); else home_table_pow_gt(started, tbl, kk);
+  store_gt(out[i].l, home_result(true));
 }
 extern "C" int32_t rhip_bsw_encrypt_batch(rhip_ctx* ctx, const rhip_bsw_pk* pk, size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
                                           const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, const uint32_t* path_off,
@@ -819,9 +791,10 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_r
   uint32_t kl[8], kr[8];
   ld_scalar(kl, lam + t);
   ld_scalar(kr, rand + t);
-  const Fp12 x = e_w16 ? table_pow_gt_w16(e_tbl, kl) : table_pow_gt(e_tbl, kl);
-  const Fp12 y = table_pow_gt(attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
-  store_gt(c1[t].l, fp12_mul(x, y));
+  bool started = false;       // E^lambda * egg_alpha_x^r as ONE running product on the lane's home value
+  if (e_w16) home_table_pow_gt_w16(started, e_tbl, kl); else home_table_pow_gt(started, e_tbl, kl);
+  home_table_pow_gt(started, attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
+  store_gt(c1[t].l, home_result(started));
 }
 // C3[row] = (g2*y_x) * r + g2 * omega   (:275-277): two fixed-base sums on one accumulator
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,

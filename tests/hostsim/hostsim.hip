@@ -93,15 +93,31 @@ void hs_pairing_prepared(const uint32_t* p, const uint32_t* q, uint32_t* out) {
   g2_prepare_lines(Q, lines);
   store_gt(out, final_exponentiation(miller_loop_prepared(miller_p_from_aff(P), aff_is_inf(P), aff_is_inf(Q), HostLineLoad{lines})));
 }
+// the accumulator's home (LDS on the device): two halves + the parked Fq6
+struct HostHome {
+  Fp6* F;
+  Fp6 ld_f6(int h) const { return F[h]; }
+  void st_f6(int h, const Fp6& v) const { F[h] = v; }
+  Fp6 ld_x() const { return F[2]; }
+  void st_x(const Fp6& v) const { F[2] = v; }
+  Fp2 ld_f2(int i) const { return (&F[i / 3].a0)[i % 3]; }
+  void st_f2(int i, const Fp2& v) const { (&F[i / 3].a0)[i % 3] = v; }
+  void fence() const {}
+};
 struct HostWs {
   Fp12* slots;
+  Fp6* F;
   Fp12 ld(int i) const { return slots[i]; }
   void st(int i, const Fp12& v) const { slots[i] = v; }
+  Fp6 ld6(int i, int h) const { return h ? slots[i].c1 : slots[i].c0; }
+  void st6(int i, int h, const Fp6& v) const { (h ? slots[i].c1 : slots[i].c0) = v; }
+  HostHome home() const { return HostHome{F}; }
 };
 void hs_final_exp_ws(const uint32_t* f, uint32_t* out) {
   Fp12 slots[FE_SLOTS];
   slots[FE_T0] = load_gt(f);
-  final_exponentiation_ws(HostWs{slots});
+  Fp6 F[3];
+  final_exponentiation_ws(HostWs{slots, F});
   store_gt(out, slots[FE_T1]);
 }
 void hs_g2_prepare(const uint32_t* q, uint32_t* out /* first line, 48 words */) {
@@ -176,6 +192,8 @@ struct HostMultiAcc {
   void st_f6(int h, const Fp6& v) const { F[h] = v; }
   Fp6 ld_x() const { return F[2]; }
   void st_x(const Fp6& v) const { F[2] = v; }
+  Fp2 ld_f2(int i) const { return (&F[i / 3].a0)[i % 3]; }
+  void st_f2(int i, const Fp2& v) const { (&F[i / 3].a0)[i % 3] = v; }
   void fence() const {}
   int kind(int j) const { return kinds[j]; }
   MillerP p(int j) const { return miller_p_from_aff(P[j]); }
