@@ -24,7 +24,10 @@ enum {   /* object kinds for rabe_obj_free / rabe_obj_serialize / rabe_obj_deser
   RABE_BSW_PK = 10, RABE_BSW_MSK = 11, RABE_BSW_SK = 12, RABE_BSW_CT = 13,
   RABE_LSW_PK = 20, RABE_LSW_MSK = 21, RABE_LSW_SK = 22, RABE_LSW_CT = 23,
   RABE_AW11_GK = 30, RABE_AW11_PK = 31, RABE_AW11_MSK = 32, RABE_AW11_SK = 33, RABE_AW11_CT = 34,
-  RABE_GHW11_PK = 40, RABE_GHW11_MSK = 41, RABE_GHW11_SK = 42, RABE_GHW11_TK = 43, RABE_GHW11_RK = 44, RABE_GHW11_CT = 45, RABE_GHW11_TCT = 46
+  RABE_GHW11_PK = 40, RABE_GHW11_MSK = 41, RABE_GHW11_SK = 42, RABE_GHW11_TK = 43, RABE_GHW11_RK = 44, RABE_GHW11_CT = 45, RABE_GHW11_TCT = 46,
+  /* bdabe / mke08: public key, master key, secret AUTHORITY key, user key (with its attribute keys), public attribute key, ciphertext */
+  RABE_BDABE_PK = 50, RABE_BDABE_MSK = 51, RABE_BDABE_SKA = 52, RABE_BDABE_UK = 53, RABE_BDABE_PKA = 54, RABE_BDABE_CT = 55,
+  RABE_MKE08_PK = 60, RABE_MKE08_MSK = 61, RABE_MKE08_SKA = 62, RABE_MKE08_UK = 63, RABE_MKE08_PKA = 64, RABE_MKE08_CT = 65
 };
 enum { RABE_JSON_POLICY = 0, RABE_HUMAN_POLICY = 1 };   /* PolicyLanguage, src/utils/policy/pest/mod.rs:18-23 */
 
@@ -138,6 +141,36 @@ int32_t rabe_ghw11_transform_batch(rabe_host* h, size_t n, const void* const* ct
 /* `data` of the reference's decrypt_out is the ciphertext's data field: pass the ciphertext object */
 int32_t rabe_ghw11_decrypt_out(rabe_host* h, const void* tct, const void* rk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_ghw11_decrypt_out_gt(rabe_host* h, const void* tct, const void* rk, uint8_t out_gt[384]);
+
+/* ---- bdabe (src/schemes/bdabe/mod.rs:149-399) and mke08 (src/schemes/mke08/mod.rs:130-380): DNF policies, attributes named
+ * "authority::attribute".  `request_attribute_sk` / `request_authority_sk` APPEND the new secret attribute key to the user key
+ * (the reference returns it and its callers push it onto `sk.sk_a`: bdabe/mod.rs:21, mke08 tests).  decrypt: every item's
+ * pairing factors on one accumulator, one final exponentiation (rhip_pairing_jobs). */
+int32_t rabe_bdabe_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_bdabe_authgen(rabe_host* h, const void* pk, const void* msk, const char* name, void** ska);
+int32_t rabe_bdabe_keygen(rabe_host* h, const void* pk, const void* ska, const char* name, void** uk);
+int32_t rabe_bdabe_request_attribute_pk(rabe_host* h, const void* pk, const void* ska, const char* attribute, void** pka);
+int32_t rabe_bdabe_request_attribute_sk(rabe_host* h, void* uk, const void* ska, const char* attribute);
+int32_t rabe_bdabe_encrypt(rabe_host* h, const void* pk, const void* const* attr_pks, size_t n_pks, const char* policy, int32_t language,
+                           const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_bdabe_decrypt(rabe_host* h, const void* uk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_bdabe_decrypt_gt(rabe_host* h, const void* uk, const void* ct, uint8_t out_gt[384]);
+int32_t rabe_bdabe_decrypt_batch(rabe_host* h, size_t n, const void* const* uks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                                 size_t* lens);
+int32_t rabe_mke08_setup(rabe_host* h, void** pk, void** msk);
+int32_t rabe_mke08_keygen(rabe_host* h, const void* pk, const void* msk, const char* name, void** uk);
+int32_t rabe_mke08_authgen(rabe_host* h, const char* name, void** ska);
+int32_t rabe_mke08_request_authority_pk(rabe_host* h, const void* pk, const char* attribute, const void* ska, void** pka);
+int32_t rabe_mke08_request_authority_sk(rabe_host* h, void* uk, const char* attribute, const void* ska);
+int32_t rabe_mke08_encrypt(rabe_host* h, const void* pk, const void* const* attr_pks, size_t n_pks, const char* policy, int32_t language,
+                           const uint8_t* plaintext, size_t len, void** ct);
+int32_t rabe_mke08_decrypt(rabe_host* h, const void* uk, const void* ct, uint8_t** plaintext, size_t* len);
+int32_t rabe_mke08_decrypt_gt(rabe_host* h, const void* uk, const void* ct, uint8_t out_gt[384]);
+int32_t rabe_mke08_decrypt_batch(rabe_host* h, size_t n, const void* const* uks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                                 size_t* lens);
+/* dnf.rs:203-243 and :186-201 on attribute names only: result 1 / 0; the terms as JSON [[attr, ..], ..] (keys = one name per public attribute key) */
+int32_t rabe_policy_in_dnf(const char* policy, int32_t language, int32_t* result);
+int32_t rabe_policy_dnf_terms(const char* policy, int32_t language, const char* const* key_attrs, size_t n, char** out);
 
 /* ---- host-only policy utilities (no GPU needed): results as small JSON texts, free with rabe_bytes_free.
  *   rabe_policy_parse      -> serialize_policy(parse(policy, language), out_language)       pest/mod.rs:40-114

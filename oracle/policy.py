@@ -439,3 +439,72 @@ def calc_pruned(attr, node):
         if found:
             return True, lst
     return False, []
+
+
+# ----------------------------------------------------------------------------- DNF policies (bdabe, mke08)
+
+def policy_in_dnf(node, conjunction=False):
+    """src/utils/policy/dnf.rs:203-243.  An OR below an AND is the only thing it rejects (an AND below an AND passes here and
+    fails in `json_to_dnf`)."""
+    kind = node[0]
+    if kind == "leaf":
+        return True
+    if kind == "and":
+        ret = True
+        for child in node[1]:
+            ret &= policy_in_dnf(child, True)
+        return ret
+    if conjunction:            # Array under Or while inside a conjunction (:225-227)
+        return False
+    ret = True
+    for child in node[1]:
+        ret &= policy_in_dnf(child, conjunction)
+    return ret
+
+
+def _dnf(terms, pks, node, i, parent, ops):
+    """src/utils/policy/dnf.rs:106-183.  `terms` = list of [attrs, gt1, gt2, g1, g2]; `pks` = public attribute keys as
+    (attr, g1, g2, gt1, gt2); `ops` = (gt_mul, g1_add, g2_add).  Child k of an OR is sent to term index 2k (`i + i` with the
+    loop's shadowing `i`, :162-164) while a missing index APPENDS (:133-141) -- both restated as they are."""
+    gt_mul, g1_add, g2_add = ops
+    kind = node[0]
+    if kind == "leaf":
+        for pak in pks:
+            if pak[0] == node[1]:
+                if len(terms) > i:
+                    t = terms[i]
+                    t[0].append(pak[0])
+                    t[1] = gt_mul(t[1], pak[3])
+                    t[2] = gt_mul(t[2], pak[4])
+                    t[3] = g1_add(t[3], pak[1])
+                    t[4] = g2_add(t[4], pak[2])
+                else:
+                    terms.append([[pak[0]], pak[3], pak[4], pak[1], pak[2]])
+        return True
+    # Object((kind, Array(children)))
+    if parent is None:
+        arr_parent = kind
+    elif parent == "or":
+        if kind != "and":
+            return False
+        arr_parent = "and"
+    else:                       # an inner node under an AND: only Leaf objects pass there and the parser makes none (:172-177)
+        return False
+    ret = True
+    if arr_parent == "and":
+        for child in node[1]:
+            ret = ret and _dnf(terms, pks, child, i, "and", ops)
+    else:
+        for idx, child in enumerate(node[1]):
+            ret = ret and _dnf(terms, pks, child, idx + idx, "or", ops)
+    return ret
+
+
+def json_to_dnf(node, pks, ops):
+    """src/utils/policy/dnf.rs:186-201: the terms, stably sorted by their number of attributes; PolicyPanic where the
+    callers' `.unwrap()` meets the Err."""
+    terms = []
+    if not _dnf(terms, pks, node, 0, None, ops):
+        raise PolicyPanic("Error in json_to_dnf: could not parse policy as DNF")
+    terms.sort(key=lambda t: len(t[0]))
+    return terms

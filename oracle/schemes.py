@@ -600,3 +600,186 @@ def ghw11_transform(ct, tk):
 def ghw11_decrypt_out(pct, rk):
     """ghw11/mod.rs:298-305: the client's part, one Gt power.  Returns the Gt handed to decrypt_symmetric."""
     return bn.gt_mul(pct["c"], bn.gt_inv(bn.gt_pow(pct["t"], rk["z"])))
+
+
+# ============================================================================= BDABE and MKE08 (DNF policies)
+
+_DNF_OPS = (bn.gt_mul, bn.g1_add, bn.g2_add)
+
+
+def _from_authority(attr, authority):
+    """bdabe/mod.rs:457-467 = mke08/mod.rs: exactly one "::" and the part before it equals the authority's name."""
+    if attr.count("::") != 1:          # match_indices("::") counts non-overlapping matches, as str.count does
+        return False
+    return attr[:attr.index("::")] == authority
+
+
+def _attr_exponent(attribute, authority_name, secret):
+    return sha3_hash_fr(attribute) * sha3_hash_fr(authority_name) * secret % bn.R
+
+
+def _is_satisfiable(conjunction, sk_a):
+    return all(any(k[0] == a for k in sk_a) for a in conjunction)
+
+
+def _calc_satisfiable(conjunction, sk_a):
+    """bdabe/mod.rs:424-447 = mke08/mod.rs: sums of the attribute keys; the start value (G1::one(), G2::one()) survives only
+    when the first attribute is missing, which `is_satisfiable` excludes."""
+    ret = (bn.G1_GEN, bn.G2_GEN)
+    for i, a in enumerate(conjunction):
+        found = next((k for k in sk_a if k[0] == a), None)
+        if found is None:
+            continue
+        ret = (found[1], found[2]) if i == 0 else (bn.g1_add(ret[0], found[1]), bn.g2_add(ret[1], found[2]))
+    return ret
+
+
+def bdabe_setup(rng):
+    """bdabe/mod.rs:149-163."""
+    g1, g2, p1, p2 = rng.g1(), rng.g2(), rng.g1(), rng.g2()
+    y = rng.fr()
+    return {"g1": g1, "g2": g2, "p1": p1, "p2": p2, "e_gg_y": bn.gt_pow(bn.pairing(g1, g2), y)}, {"y": y}
+
+
+def bdabe_authgen(pk, msk, name, rng):
+    """bdabe/mod.rs:174-189."""
+    alpha = rng.fr()
+    beta = (msk["y"] - alpha) % bn.R
+    a1 = bn.g1_mul(pk["g1"], alpha)
+    a2 = bn.g2_mul(pk["g2"], beta)
+    a3 = rng.fr()
+    return {"name": name, "a1": a1, "a2": a2, "a3": a3}
+
+
+def bdabe_keygen(pk, ska, name, rng):
+    """bdabe/mod.rs:202-224."""
+    r_u = rng.fr()
+    return {"sk": {"u1": bn.g1_add(ska["a1"], bn.g1_mul(pk["p1"], r_u)), "u2": bn.g2_add(ska["a2"], bn.g2_mul(pk["p2"], r_u))},
+            "pk": {"u": name, "u1": bn.g1_mul(pk["g1"], r_u), "u2": bn.g2_mul(pk["g2"], r_u)},
+            "sk_a": []}
+
+
+def bdabe_request_attribute_pk(pk, ska, attribute):
+    """bdabe/mod.rs:234-265; ValueError = the RabeError."""
+    if not _from_authority(attribute, ska["name"]):
+        raise ValueError("attribute %s is not from_authority() or !is_eligible()" % attribute)
+    exp = _attr_exponent(attribute, ska["name"], ska["a3"])
+    return {"attr": attribute, "a1": bn.g1_mul(pk["g1"], exp), "a2": bn.g2_mul(pk["g2"], exp), "a3": bn.gt_pow(pk["e_gg_y"], exp)}
+
+
+def bdabe_request_attribute_sk(pk_u, ska, attribute):
+    """bdabe/mod.rs:275-305 (is_eligible is constant true, :470-475)."""
+    if not _from_authority(attribute, ska["name"]):
+        raise ValueError("attribute %s is not from_authority() or !is_eligible()" % attribute)
+    exp = _attr_exponent(attribute, ska["name"], ska["a3"])
+    return {"attr": attribute, "au1": bn.g1_mul(pk_u["u1"], exp), "au2": bn.g2_mul(pk_u["u2"], exp)}
+
+
+def bdabe_encrypt(pk, attr_pks, policy, language, rng):
+    """bdabe/mod.rs:317-358.  Draws: the two arguments of `pairing(rng.gen(), rng.gen())` (G1 first), then r_j per term.
+    Returns (ct, msg)."""
+    tree = pol.parse(policy, language)
+    if not pol.policy_in_dnf(tree):
+        raise ValueError("Error in bdabe/encrypt: Policy not in DNF.")
+    pks = [(k["attr"], k["a1"], k["a2"], k["a3"], bn.GT_ONE) for k in attr_pks]
+    terms = pol.json_to_dnf(tree, pks, _DNF_OPS)
+    a, b = rng.g1(), rng.g2()
+    msg = bn.pairing(a, b)
+    j = []
+    for t in terms:
+        r_j = rng.fr()
+        j.append({"attr": list(t[0]), "e1": bn.gt_mul(bn.gt_pow(t[1], r_j), msg), "e2": bn.g1_mul(pk["p1"], r_j),
+                  "e3": bn.g2_mul(pk["p2"], r_j), "e4": bn.g1_mul(t[3], r_j), "e5": bn.g2_mul(t[4], r_j)})
+    return {"policy": (policy, language), "j": j}, msg
+
+
+def bdabe_decrypt(sk, ct):
+    """bdabe/mod.rs:367-399: the first satisfiable conjunction; Gt::one() when none is (the AES layer then fails)."""
+    str_attr = [k["attr"] for k in sk["sk_a"]]
+    tree = pol.parse(ct["policy"][0], ct["policy"][1])
+    if not pol.traverse_policy(str_attr, tree):
+        raise ValueError("Error in bdabe/decrypt: attributes in sk do not match policy in ct.")
+    sk_a = [(k["attr"], k["au1"], k["au2"]) for k in sk["sk_a"]]
+    msg = bn.GT_ONE
+    for ct_j in ct["j"]:
+        if _is_satisfiable(ct_j["attr"], sk_a):
+            s1, s2 = _calc_satisfiable(ct_j["attr"], sk_a)
+            msg = bn.gt_mul(bn.gt_mul(bn.gt_mul(ct_j["e1"], bn.pairing(ct_j["e2"], s2)), bn.pairing(s1, ct_j["e3"])),
+                            bn.gt_inv(bn.gt_mul(bn.pairing(ct_j["e4"], sk["sk"]["u2"]), bn.pairing(sk["sk"]["u1"], ct_j["e5"]))))
+            break
+    return msg
+
+
+def mke08_setup(rng):
+    """mke08/mod.rs:130-149."""
+    g1, g2, p1, p2 = rng.g1(), rng.g2(), rng.g1(), rng.g2()
+    y1, y2 = rng.fr(), rng.fr()
+    e = bn.pairing(g1, g2)
+    return ({"g1": g1, "g2": g2, "p1": p1, "p2": p2, "e_gg_y1": bn.gt_pow(e, y1), "e_gg_y2": bn.gt_pow(e, y2)},
+            {"g1": bn.g1_mul(g1, y1), "g2": bn.g2_mul(g2, y2)})
+
+
+def mke08_keygen(pk, msk, name, rng):
+    """mke08/mod.rs:159-181."""
+    mk_u = rng.fr()
+    return {"sk": {"g1": bn.g1_add(msk["g1"], bn.g1_mul(pk["p1"], mk_u)), "g2": bn.g2_add(msk["g2"], bn.g2_mul(pk["p2"], mk_u))},
+            "pk": {"name": name, "g1": bn.g1_mul(pk["g1"], mk_u), "g2": bn.g2_mul(pk["g2"], mk_u)},
+            "sk_a": []}
+
+
+def mke08_authgen(name, rng):
+    """mke08/mod.rs:189-197."""
+    return {"name": name, "r": rng.fr()}
+
+
+def mke08_request_authority_pk(pk, attribute, ska):
+    """mke08/mod.rs:207-238."""
+    if not _from_authority(attribute, ska["name"]):
+        raise ValueError("attribute %s is not from_authority() or !is_eligible()" % attribute)
+    exp = _attr_exponent(attribute, ska["name"], ska["r"])
+    return {"attr": attribute, "g1": bn.g1_mul(pk["g1"], exp), "g2": bn.g2_mul(pk["g2"], exp),
+            "gt1": bn.gt_pow(pk["e_gg_y1"], exp), "gt2": bn.gt_pow(pk["e_gg_y2"], exp)}
+
+
+def mke08_request_authority_sk(pk_u, attr, ska):
+    """mke08/mod.rs:248-278."""
+    if not _from_authority(attr, ska["name"]):
+        raise ValueError("attribute %s is not from_authority() or !is_eligible()" % attr)
+    exp = _attr_exponent(attr, ska["name"], ska["r"])
+    return {"attr": attr, "g1": bn.g1_mul(pk_u["g1"], exp), "g2": bn.g2_mul(pk_u["g2"], exp)}
+
+
+def mke08_encrypt(pk, attr_pks, policy, language, rng):
+    """mke08/mod.rs:290-334.  Draws: G1, G2 of msg1, the exponent of msg2, r_j per term.  Returns (ct, msg = msg1 * msg2)."""
+    tree = pol.parse(policy, language)
+    if not pol.policy_in_dnf(tree):
+        raise ValueError("Error in mke08/encrypt: policy is not in dnf")
+    pks = [(k["attr"], k["g1"], k["g2"], k["gt1"], k["gt2"]) for k in attr_pks]
+    terms = pol.json_to_dnf(tree, pks, _DNF_OPS)
+    a, b = rng.g1(), rng.g2()
+    msg1 = bn.pairing(a, b)
+    msg2 = bn.gt_pow(msg1, rng.fr())
+    msg = bn.gt_mul(msg1, msg2)
+    e = []
+    for t in terms:
+        r_j = rng.fr()
+        e.append({"str": list(t[0]), "j1": bn.gt_mul(bn.gt_pow(t[1], r_j), msg1), "j2": bn.gt_mul(bn.gt_pow(t[2], r_j), msg2),
+                  "j3": bn.g1_mul(pk["p1"], r_j), "j4": bn.g2_mul(pk["p2"], r_j), "j5": bn.g1_mul(t[3], r_j), "j6": bn.g2_mul(t[4], r_j)})
+    return {"policy": (policy, language), "e": e}, msg
+
+
+def mke08_decrypt(sk, ct):
+    """mke08/mod.rs:343-380."""
+    attr_str = [k["attr"] for k in sk["sk_a"]]
+    tree = pol.parse(ct["policy"][0], ct["policy"][1])
+    if not pol.traverse_policy(attr_str, tree):
+        raise ValueError("Error in mke08/decrypt: attributes in sk do not match policy in ct.")
+    sk_a = [(k["attr"], k["g1"], k["g2"]) for k in sk["sk_a"]]
+    msg = bn.GT_ONE
+    for e_j in ct["e"]:
+        if _is_satisfiable(e_j["str"], sk_a):
+            s1, s2 = _calc_satisfiable(e_j["str"], sk_a)
+            msg = bn.gt_mul(bn.gt_mul(bn.gt_mul(bn.gt_mul(e_j["j1"], e_j["j2"]), bn.pairing(e_j["j3"], s2)), bn.pairing(s1, e_j["j4"])),
+                            bn.gt_inv(bn.gt_mul(bn.pairing(e_j["j5"], sk["sk"]["g2"]), bn.pairing(sk["sk"]["g1"], e_j["j6"]))))
+            break
+    return msg

@@ -61,3 +61,9 @@ class ListRng:
         return v % bn.R
 
     fr_nonzero = fr
+
+    def g1(self):
+        return bn.g1_mul(bn.G1_GEN, self.fr())
+
+    def g2(self):
+        return bn.g2_mul(bn.G2_GEN, self.fr())

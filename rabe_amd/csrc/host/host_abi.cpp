@@ -142,6 +142,24 @@ static void ser(W& w, int32_t kind, const void* o) {
     case RABE_GHW11_CT: { auto& x = *(const ghw11::Ghw11Ciphertext*)o; w.pol(x.policy); w.el(x.c); w.el(x.c1); w.u32((uint32_t)x.ci_di.size());
                           for (auto& r : x.ci_di) { w.str(r.name); w.el(r.c); w.el(r.d); } w.bytes(x.data); break; }
     case RABE_GHW11_TCT: { auto& x = *(const ghw11::Ghw11TransformCiphertext*)o; w.el(x.c); w.el(x.t); break; }
+    case RABE_BDABE_PK: { auto& x = *(const bdabe::BdabePublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.p1); w.el(x.p2); w.el(x.e_gg_y); break; }
+    case RABE_BDABE_MSK: { auto& x = *(const bdabe::BdabeMasterKey*)o; w.fr(x.y); break; }
+    case RABE_BDABE_SKA: { auto& x = *(const bdabe::BdabeSecretAuthorityKey*)o; w.str(x.name); w.el(x.a1); w.el(x.a2); w.fr(x.a3); break; }
+    case RABE_BDABE_UK: { auto& x = *(const bdabe::BdabeUserKey*)o; w.el(x.sk.u1); w.el(x.sk.u2); w.str(x.pk.u); w.el(x.pk.u1); w.el(x.pk.u2);
+                          w.u32((uint32_t)x.sk_a.size()); for (auto& a : x.sk_a) { w.str(a.attr); w.el(a.au1); w.el(a.au2); } break; }
+    case RABE_BDABE_PKA: { auto& x = *(const bdabe::BdabePublicAttributeKey*)o; w.str(x.attr); w.el(x.a1); w.el(x.a2); w.el(x.a3); break; }
+    case RABE_BDABE_CT: { auto& x = *(const bdabe::BdabeCiphertext*)o; w.pol(x.policy); w.u32((uint32_t)x.j.size());
+                          for (auto& t : x.j) { w.u32((uint32_t)t.attr.size()); for (auto& a : t.attr) w.str(a); w.el(t.e1); w.el(t.e2); w.el(t.e3); w.el(t.e4); w.el(t.e5); }
+                          w.bytes(x.ct); break; }
+    case RABE_MKE08_PK: { auto& x = *(const mke08::Mke08PublicKey*)o; w.el(x.g1); w.el(x.g2); w.el(x.p1); w.el(x.p2); w.el(x.e_gg_y1); w.el(x.e_gg_y2); break; }
+    case RABE_MKE08_MSK: { auto& x = *(const mke08::Mke08MasterKey*)o; w.el(x.g1); w.el(x.g2); break; }
+    case RABE_MKE08_SKA: { auto& x = *(const mke08::Mke08SecretAuthorityKey*)o; w.str(x.name); w.fr(x.r); break; }
+    case RABE_MKE08_UK: { auto& x = *(const mke08::Mke08UserKey*)o; w.el(x.sk.g1); w.el(x.sk.g2); w.str(x.pk.name); w.el(x.pk.g1); w.el(x.pk.g2);
+                          w.u32((uint32_t)x.sk_a.size()); for (auto& a : x.sk_a) { w.str(a.attr); w.el(a.g1); w.el(a.g2); } break; }
+    case RABE_MKE08_PKA: { auto& x = *(const mke08::Mke08PublicAttributeKey*)o; w.str(x.attr); w.el(x.g1); w.el(x.g2); w.el(x.gt1); w.el(x.gt2); break; }
+    case RABE_MKE08_CT: { auto& x = *(const mke08::Mke08Ciphertext*)o; w.pol(x.policy); w.u32((uint32_t)x.e.size());
+                          for (auto& t : x.e) { w.u32((uint32_t)t.str.size()); for (auto& a : t.str) w.str(a); w.el(t.j1); w.el(t.j2); w.el(t.j3); w.el(t.j4); w.el(t.j5); w.el(t.j6); }
+                          w.bytes(x.ct); break; }
     default: throw RabeError("serialize: unknown object kind");
   }
 }
@@ -200,6 +218,32 @@ static void* deser(R& r, int32_t kind) {
                           for (uint32_t i = 0; i < c; i++) { ghw11::Ghw11CtRow t; t.name = r.str(); t.c = r.el<64>(); t.d = r.el<64>(); x->ci_di.push_back(t); }
                           x->data = r.bytes(); return up.release(); }
     case RABE_GHW11_TCT: { NEW_OBJ(ghw11::Ghw11TransformCiphertext); x->c = r.el<384>(); x->t = r.el<384>(); return up.release(); }
+    case RABE_BDABE_PK: { NEW_OBJ(bdabe::BdabePublicKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->p1 = r.el<64>(); x->p2 = r.el<128>(); x->e_gg_y = r.el<384>(); return up.release(); }
+    case RABE_BDABE_MSK: { NEW_OBJ(bdabe::BdabeMasterKey); x->y = r.fr(); return up.release(); }
+    case RABE_BDABE_SKA: { NEW_OBJ(bdabe::BdabeSecretAuthorityKey); x->name = r.str(); x->a1 = r.el<64>(); x->a2 = r.el<128>(); x->a3 = r.fr(); return up.release(); }
+    case RABE_BDABE_UK: { NEW_OBJ(bdabe::BdabeUserKey); x->sk.u1 = r.el<64>(); x->sk.u2 = r.el<128>(); x->pk.u = r.str(); x->pk.u1 = r.el<64>(); x->pk.u2 = r.el<128>();
+                          uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { bdabe::BdabeSecretAttributeKey a; a.attr = r.str(); a.au1 = r.el<64>(); a.au2 = r.el<128>(); x->sk_a.push_back(a); }
+                          return up.release(); }
+    case RABE_BDABE_PKA: { NEW_OBJ(bdabe::BdabePublicAttributeKey); x->attr = r.str(); x->a1 = r.el<64>(); x->a2 = r.el<128>(); x->a3 = r.el<384>(); return up.release(); }
+    case RABE_BDABE_CT: { NEW_OBJ(bdabe::BdabeCiphertext); x->policy = r.pol(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { bdabe::BdabeCiphertextTuple t; uint32_t na = r.u32(); for (uint32_t k = 0; k < na; k++) t.attr.push_back(r.str());
+                            t.e1 = r.el<384>(); t.e2 = r.el<64>(); t.e3 = r.el<128>(); t.e4 = r.el<64>(); t.e5 = r.el<128>(); x->j.push_back(t); }
+                          x->ct = r.bytes(); return up.release(); }
+    case RABE_MKE08_PK: { NEW_OBJ(mke08::Mke08PublicKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->p1 = r.el<64>(); x->p2 = r.el<128>(); x->e_gg_y1 = r.el<384>();
+                          x->e_gg_y2 = r.el<384>(); return up.release(); }
+    case RABE_MKE08_MSK: { NEW_OBJ(mke08::Mke08MasterKey); x->g1 = r.el<64>(); x->g2 = r.el<128>(); return up.release(); }
+    case RABE_MKE08_SKA: { NEW_OBJ(mke08::Mke08SecretAuthorityKey); x->name = r.str(); x->r = r.fr(); return up.release(); }
+    case RABE_MKE08_UK: { NEW_OBJ(mke08::Mke08UserKey); x->sk.g1 = r.el<64>(); x->sk.g2 = r.el<128>(); x->pk.name = r.str(); x->pk.g1 = r.el<64>(); x->pk.g2 = r.el<128>();
+                          uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { mke08::Mke08SecretAttributeKey a; a.attr = r.str(); a.g1 = r.el<64>(); a.g2 = r.el<128>(); x->sk_a.push_back(a); }
+                          return up.release(); }
+    case RABE_MKE08_PKA: { NEW_OBJ(mke08::Mke08PublicAttributeKey); x->attr = r.str(); x->g1 = r.el<64>(); x->g2 = r.el<128>(); x->gt1 = r.el<384>(); x->gt2 = r.el<384>();
+                           return up.release(); }
+    case RABE_MKE08_CT: { NEW_OBJ(mke08::Mke08Ciphertext); x->policy = r.pol(); uint32_t c = r.u32();
+                          for (uint32_t i = 0; i < c; i++) { mke08::Mke08CTConjunction t; uint32_t na = r.u32(); for (uint32_t k = 0; k < na; k++) t.str.push_back(r.str());
+                            t.j1 = r.el<384>(); t.j2 = r.el<384>(); t.j3 = r.el<64>(); t.j4 = r.el<128>(); t.j5 = r.el<64>(); t.j6 = r.el<128>(); x->e.push_back(t); }
+                          x->ct = r.bytes(); return up.release(); }
     default: throw RabeError("deserialize: unknown object kind");
   }
 }
@@ -288,6 +332,18 @@ void rabe_obj_free(int32_t kind, void* o) {
     case RABE_AW11_MSK: delete (aw11::Aw11MasterKey*)o; break;
     case RABE_AW11_SK: delete (aw11::Aw11SecretKey*)o; break;
     case RABE_AW11_CT: delete (aw11::Aw11Ciphertext*)o; break;
+    case RABE_BDABE_PK: delete (bdabe::BdabePublicKey*)o; break;
+    case RABE_BDABE_MSK: delete (bdabe::BdabeMasterKey*)o; break;
+    case RABE_BDABE_SKA: delete (bdabe::BdabeSecretAuthorityKey*)o; break;
+    case RABE_BDABE_UK: delete (bdabe::BdabeUserKey*)o; break;
+    case RABE_BDABE_PKA: delete (bdabe::BdabePublicAttributeKey*)o; break;
+    case RABE_BDABE_CT: delete (bdabe::BdabeCiphertext*)o; break;
+    case RABE_MKE08_PK: delete (mke08::Mke08PublicKey*)o; break;
+    case RABE_MKE08_MSK: delete (mke08::Mke08MasterKey*)o; break;
+    case RABE_MKE08_SKA: delete (mke08::Mke08SecretAuthorityKey*)o; break;
+    case RABE_MKE08_UK: delete (mke08::Mke08UserKey*)o; break;
+    case RABE_MKE08_PKA: delete (mke08::Mke08PublicAttributeKey*)o; break;
+    case RABE_MKE08_CT: delete (mke08::Mke08Ciphertext*)o; break;
     case RABE_GHW11_PK: delete (ghw11::Ghw11PublicKey*)o; break;
     case RABE_GHW11_MSK: delete (ghw11::Ghw11MasterKey*)o; break;
     case RABE_GHW11_SK: delete (ghw11::Ghw11SecretKey*)o; break;
@@ -660,6 +716,136 @@ int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const vo
   GUARD_END(h)
 }
 
+// ---------------------------------------------------------------- bdabe / mke08
+int32_t rabe_bdabe_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = bdabe::setup(h->eng, h->rng());
+  *pk = new bdabe::BdabePublicKey(r.first);
+  *msk = new bdabe::BdabeMasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_authgen(rabe_host* h, const void* pk, const void* msk, const char* name, void** ska) {
+  GUARD_BEGIN
+  *ska = new bdabe::BdabeSecretAuthorityKey(bdabe::authgen(h->eng, h->rng(), *(const bdabe::BdabePublicKey*)pk, *(const bdabe::BdabeMasterKey*)msk, name));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_keygen(rabe_host* h, const void* pk, const void* ska, const char* name, void** uk) {
+  GUARD_BEGIN
+  *uk = new bdabe::BdabeUserKey(bdabe::keygen(h->eng, h->rng(), *(const bdabe::BdabePublicKey*)pk, *(const bdabe::BdabeSecretAuthorityKey*)ska, name));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_request_attribute_pk(rabe_host* h, const void* pk, const void* ska, const char* attribute, void** pka) {
+  GUARD_BEGIN
+  *pka = new bdabe::BdabePublicAttributeKey(bdabe::request_attribute_pk(h->eng, *(const bdabe::BdabePublicKey*)pk, *(const bdabe::BdabeSecretAuthorityKey*)ska, attribute));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_request_attribute_sk(rabe_host* h, void* uk, const void* ska, const char* attribute) {
+  GUARD_BEGIN
+  auto* k = (bdabe::BdabeUserKey*)uk;
+  k->sk_a.push_back(bdabe::request_attribute_sk(h->eng, k->pk, *(const bdabe::BdabeSecretAuthorityKey*)ska, attribute));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_encrypt(rabe_host* h, const void* pk, const void* const* attr_pks, size_t n_pks, const char* policy, int32_t language,
+                           const uint8_t* plaintext, size_t len, void** ct) {
+  GUARD_BEGIN
+  std::vector<const bdabe::BdabePublicAttributeKey*> v;
+  for (size_t i = 0; i < n_pks; i++) v.push_back((const bdabe::BdabePublicAttributeKey*)attr_pks[i]);
+  *ct = new bdabe::BdabeCiphertext(bdabe::encrypt(h->eng, h->rng(), *(const bdabe::BdabePublicKey*)pk, v, policy, lang_of(language), Bytes(plaintext, plaintext + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_decrypt(rabe_host* h, const void* uk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(bdabe::decrypt(h->eng, *(const bdabe::BdabeUserKey*)uk, *(const bdabe::BdabeCiphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_decrypt_gt(rabe_host* h, const void* uk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = bdabe::decrypt_gt(h->eng, *(const bdabe::BdabeUserKey*)uk, *(const bdabe::BdabeCiphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_decrypt_batch(rabe_host* h, size_t n, const void* const* uks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                                 size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const bdabe::BdabeUserKey*> s;
+  std::vector<const bdabe::BdabeCiphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const bdabe::BdabeUserKey*)uks[i]); c.push_back((const bdabe::BdabeCiphertext*)cts[i]); }
+  give_results(h, bdabe::decrypt_batch(h->eng, s, c), status, plaintexts, lens);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_setup(rabe_host* h, void** pk, void** msk) {
+  GUARD_BEGIN
+  auto r = mke08::setup(h->eng, h->rng());
+  *pk = new mke08::Mke08PublicKey(r.first);
+  *msk = new mke08::Mke08MasterKey(r.second);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_keygen(rabe_host* h, const void* pk, const void* msk, const char* name, void** uk) {
+  GUARD_BEGIN
+  *uk = new mke08::Mke08UserKey(mke08::keygen(h->eng, h->rng(), *(const mke08::Mke08PublicKey*)pk, *(const mke08::Mke08MasterKey*)msk, name));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_authgen(rabe_host* h, const char* name, void** ska) {
+  GUARD_BEGIN
+  *ska = new mke08::Mke08SecretAuthorityKey(mke08::authgen(h->rng(), name));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_request_authority_pk(rabe_host* h, const void* pk, const char* attribute, const void* ska, void** pka) {
+  GUARD_BEGIN
+  *pka = new mke08::Mke08PublicAttributeKey(mke08::request_authority_pk(h->eng, *(const mke08::Mke08PublicKey*)pk, attribute, *(const mke08::Mke08SecretAuthorityKey*)ska));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_request_authority_sk(rabe_host* h, void* uk, const char* attribute, const void* ska) {
+  GUARD_BEGIN
+  auto* k = (mke08::Mke08UserKey*)uk;
+  k->sk_a.push_back(mke08::request_authority_sk(h->eng, k->pk, attribute, *(const mke08::Mke08SecretAuthorityKey*)ska));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_encrypt(rabe_host* h, const void* pk, const void* const* attr_pks, size_t n_pks, const char* policy, int32_t language,
+                           const uint8_t* plaintext, size_t len, void** ct) {
+  GUARD_BEGIN
+  std::vector<const mke08::Mke08PublicAttributeKey*> v;
+  for (size_t i = 0; i < n_pks; i++) v.push_back((const mke08::Mke08PublicAttributeKey*)attr_pks[i]);
+  *ct = new mke08::Mke08Ciphertext(mke08::encrypt(h->eng, h->rng(), *(const mke08::Mke08PublicKey*)pk, v, policy, lang_of(language), Bytes(plaintext, plaintext + len)));
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_decrypt(rabe_host* h, const void* uk, const void* ct, uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give_bytes(mke08::decrypt(h->eng, *(const mke08::Mke08UserKey*)uk, *(const mke08::Mke08Ciphertext*)ct), out, len);
+  GUARD_END(h)
+}
+int32_t rabe_mke08_decrypt_gt(rabe_host* h, const void* uk, const void* ct, uint8_t out_gt[384]) {
+  GUARD_BEGIN
+  Gt g = mke08::decrypt_gt(h->eng, *(const mke08::Mke08UserKey*)uk, *(const mke08::Mke08Ciphertext*)ct);
+  memcpy(out_gt, g.data(), 384);
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_mke08_decrypt_batch(rabe_host* h, size_t n, const void* const* uks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
+                                 size_t* lens) {
+  GUARD_BEGIN
+  std::vector<const mke08::Mke08UserKey*> s;
+  std::vector<const mke08::Mke08Ciphertext*> c;
+  for (size_t i = 0; i < n; i++) { s.push_back((const mke08::Mke08UserKey*)uks[i]); c.push_back((const mke08::Mke08Ciphertext*)cts[i]); }
+  give_results(h, mke08::decrypt_batch(h->eng, s, c), status, plaintexts, lens);
+  return 0;
+  GUARD_END(h)
+}
+
 // ---------------------------------------------------------------- ghw11
 int32_t rabe_ghw11_setup(rabe_host* h, void** pk, void** msk) {
   GUARD_BEGIN
@@ -789,6 +975,25 @@ int32_t rabe_policy_traverse(const char* policy, int32_t language, const char* c
   GUARD_BEGIN
   *result = traverse_policy(strs(attributes, n), parse_policy(policy, lang_of(language))) ? 1 : 0;
   return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_in_dnf(const char* policy, int32_t language, int32_t* result) {
+  GUARD_BEGIN
+  *result = policy_in_dnf(parse_policy(policy, lang_of(language))) ? 1 : 0;
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_policy_dnf_terms(const char* policy, int32_t language, const char* const* key_attrs, size_t n, char** out) {
+  GUARD_BEGIN
+  std::vector<DnfTerm> terms;
+  if (!json_to_dnf(parse_policy(policy, lang_of(language)), strs(key_attrs, n), &terms)) throw RabeError("Error in json_to_dnf: could not parse policy as DNF");
+  std::string s = "[";
+  for (size_t t = 0; t < terms.size(); t++) {
+    s += std::string(t ? ", " : "") + "[";
+    for (size_t i = 0; i < terms[t].attrs.size(); i++) s += std::string(i ? ", " : "") + jstr(terms[t].attrs[i]);
+    s += "]";
+  }
+  return give_text(s + "]", out);
   GUARD_END((rabe_host*)nullptr)
 }
 static std::string named_json(const NamedFr& v) {

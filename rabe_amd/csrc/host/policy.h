@@ -442,4 +442,56 @@ inline bool calc_pruned(const std::vector<std::string>& attr, const PolicyNode& 
   return false;
 }
 
+
+// ---------------------------------------------------------------------------------------------- DNF policies (bdabe, mke08)
+// src/utils/policy/dnf.rs:203-243: rejects an OR below an AND only (an AND below an AND passes here and fails in dnf_terms)
+inline bool policy_in_dnf(const PolicyNode& n, bool conjunction = false) {
+  if (n.type == PolicyType::Leaf) return true;
+  if (n.type == PolicyType::And) {
+    bool ret = true;
+    for (const auto& ch : n.children) ret &= policy_in_dnf(ch, true);
+    return ret;
+  }
+  if (conjunction) return false;
+  bool ret = true;
+  for (const auto& ch : n.children) ret &= policy_in_dnf(ch, conjunction);
+  return ret;
+}
+// One conjunction of the DNF: its attribute names and, in order, the indices of the public attribute keys whose elements were
+// multiplied / added into it (a name that matches several keys takes all of them, one that matches none is dropped: dnf.rs:117-143).
+struct DnfTerm {
+  std::vector<std::string> attrs;
+  std::vector<size_t> keys;
+};
+// dnf.rs:106-183.  Child k of an OR is sent to term index 2k (`i + i` with the loop's shadowing `i`, :162-164) while a missing
+// index APPENDS (:133-141) -- both restated as they are.  parent: 0 = none, 1 = and, 2 = or.
+inline bool dnf_walk(std::vector<DnfTerm>* terms, const std::vector<std::string>& pk_attrs, const PolicyNode& n, size_t i, int parent) {
+  if (n.type == PolicyType::Leaf) {
+    for (size_t k = 0; k < pk_attrs.size(); k++) {
+      if (pk_attrs[k] != n.name) continue;
+      if (terms->size() > i) { (*terms)[i].attrs.push_back(pk_attrs[k]); (*terms)[i].keys.push_back(k); }
+      else terms->push_back(DnfTerm{{pk_attrs[k]}, {k}});
+    }
+    return true;
+  }
+  int arr_parent;
+  if (parent == 0) arr_parent = (n.type == PolicyType::And) ? 1 : 2;
+  else if (parent == 2) { if (n.type != PolicyType::And) return false; arr_parent = 1; }
+  else return false;                 // an inner node below an AND (:172-177)
+  bool ret = true;
+  if (arr_parent == 1) {
+    for (const auto& ch : n.children) ret = ret && dnf_walk(terms, pk_attrs, ch, i, 1);
+  } else {
+    for (size_t k = 0; k < n.children.size(); k++) ret = ret && dnf_walk(terms, pk_attrs, n.children[k], k + k, 2);
+  }
+  return ret;
+}
+// dnf.rs:186-201: the terms, stably sorted by their number of attributes; false = the Err the callers `.unwrap()`
+inline bool json_to_dnf(const PolicyNode& n, const std::vector<std::string>& pk_attrs, std::vector<DnfTerm>* terms) {
+  terms->clear();
+  if (!dnf_walk(terms, pk_attrs, n, 0, 0)) return false;
+  std::stable_sort(terms->begin(), terms->end(), [](const DnfTerm& a, const DnfTerm& b) { return a.attrs.size() < b.attrs.size(); });
+  return true;
+}
+
 }}  // namespace rabe::host

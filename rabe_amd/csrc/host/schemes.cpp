@@ -1898,5 +1898,290 @@ Bytes decrypt_out(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11R
 }
 }  // namespace ghw11
 
+// ================================================================================================ BDABE / MKE08 (DNF policies)
+// What the two schemes share (bdabe/mod.rs:401-475 = mke08/mod.rs:382-470): the authority test on "auth::attribute" names, the
+// attribute exponent h(attribute) * h(authority) * secret, the conjunction sums of dnf.rs, and the shape of decrypt:
+//   msg = lead * e(c_a, sum S2) * e(sum S1, c_b) / (e(c_c, u2) * e(u1, c_d))
+// which is ONE pairing job: m pairs (c_a, S2_i), one pair with the summed G1 argument (sum S1_i, c_b), two pairs with exponent -1.
+namespace dnfabe {
+static bool from_authority(const std::string& attr, const std::string& authority) {
+  size_t count = 0, first = std::string::npos;
+  for (size_t pos = attr.find("::"); pos != std::string::npos; pos = attr.find("::", pos + 2)) { if (!count) first = pos; count++; }   // match_indices: non-overlapping
+  return count == 1 && attr.substr(0, first) == authority;
+}
+static Fr attr_exponent(const std::string& attribute, const std::string& authority, const Fr& secret) {
+  return fr_mul(fr_mul(sha3_hash_fr(attribute), sha3_hash_fr(authority)), secret);
+}
+struct AttrKey { const std::string* attr; const G1* g1; const G2* g2; };
+static bool is_satisfiable(const std::vector<std::string>& conjunction, const std::vector<AttrKey>& sk) {
+  for (const auto& a : conjunction) {
+    bool found = false;
+    for (const auto& k : sk) if (*k.attr == a) { found = true; break; }
+    if (!found) return false;
+  }
+  return true;
+}
+// the first satisfiable conjunction of a ciphertext -> the pairing job of decrypt; `lead` is set by the caller
+static void plan_term(const std::vector<std::string>& conjunction, const std::vector<AttrKey>& sk, const G1& c_a, const G2& c_b, const G1& c_c,
+                      const G2& c_d, const G1& u1, const G2& u2, PairingJob* job) {
+  const Fr one = fr_one(), minus_one = fr_neg(fr_one());
+  for (const auto& a : conjunction) {
+    for (const auto& k : sk) {
+      if (*k.attr != a) continue;
+      job->base.push_back(c_a); job->scal.push_back(one); job->q.push_back(*k.g2);      // e(c_a, sum S2) factor by factor
+      job->sbase.push_back(*k.g1); job->sscal.push_back(one);                            // sum S1
+      break;                                                                             // find(): the first match
+    }
+  }
+  job->sq = c_b;
+  job->base.push_back(c_c); job->scal.push_back(minus_one); job->q.push_back(u2);
+  job->base.push_back(u1); job->scal.push_back(minus_one); job->q.push_back(c_d);
+}
+// sums / products of the public attribute keys of every DNF term, round by round (one batched launch per round and group)
+template <class T, class ADD>
+static std::vector<T> fold_terms(const std::vector<DnfTerm>& terms, const std::vector<T>& elems, ADD add) {
+  std::vector<T> acc;
+  size_t longest = 0;
+  for (const auto& t : terms) { acc.push_back(elems[t.keys[0]]); longest = std::max(longest, t.keys.size()); }
+  for (size_t r = 1; r < longest; r++) {
+    std::vector<T> a, b;
+    std::vector<size_t> who;
+    for (size_t t = 0; t < terms.size(); t++) if (terms[t].keys.size() > r) { a.push_back(acc[t]); b.push_back(elems[terms[t].keys[r]]); who.push_back(t); }
+    std::vector<T> sum = add(a, b);
+    for (size_t i = 0; i < who.size(); i++) acc[who[i]] = sum[i];
+  }
+  return acc;
+}
+}  // namespace dnfabe
+
+namespace bdabe {
+using namespace dnfabe;
+std::pair<BdabePublicKey, BdabeMasterKey> setup(Engine& eng, Rng& rng) {          // :149-163
+  G1 g1 = eng.random_g1(rng);
+  G2 g2 = eng.random_g2(rng);
+  G1 p1 = eng.random_g1(rng);
+  G2 p2 = eng.random_g2(rng);
+  Fr y = rng.next_fr();
+  Gt e = eng.gt_pow({eng.pairing({g1}, {g2})[0]}, {y})[0];
+  return {BdabePublicKey{g1, g2, p1, p2, e}, BdabeMasterKey{y}};
+}
+BdabeSecretAuthorityKey authgen(Engine& eng, Rng& rng, const BdabePublicKey& pk, const BdabeMasterKey& msk, const std::string& name) {   // :174-189
+  Fr alpha = rng.next_fr();
+  Fr beta = fr_sub(msk.y, alpha);
+  G1 a1 = eng.g1_mul({pk.g1}, {alpha})[0];
+  G2 a2 = eng.g2_mul({pk.g2}, {beta})[0];
+  Fr a3 = rng.next_fr();
+  return BdabeSecretAuthorityKey{name, a1, a2, a3};
+}
+BdabeUserKey keygen(Engine& eng, Rng& rng, const BdabePublicKey& pk, const BdabeSecretAuthorityKey& ska, const std::string& name) {   // :202-224
+  Fr r_u = rng.next_fr();
+  std::vector<G1> a = eng.g1_mul({pk.p1, pk.g1}, {r_u, r_u});
+  std::vector<G2> b = eng.g2_mul({pk.p2, pk.g2}, {r_u, r_u});
+  BdabeUserKey k;
+  k.sk = {g1_add(eng, {ska.a1}, {a[0]})[0], g2_add(eng, {ska.a2}, {b[0]})[0]};
+  k.pk = {name, a[1], b[1]};
+  return k;
+}
+BdabePublicAttributeKey request_attribute_pk(Engine& eng, const BdabePublicKey& pk, const BdabeSecretAuthorityKey& ska, const std::string& attribute) {   // :234-265
+  if (!from_authority(attribute, ska.name)) throw RabeError("attribute " + attribute + " is not from_authority() or !is_eligible()");
+  Fr exp = attr_exponent(attribute, ska.name, ska.a3);
+  return BdabePublicAttributeKey{attribute, eng.g1_mul({pk.g1}, {exp})[0], eng.g2_mul({pk.g2}, {exp})[0], eng.gt_pow({pk.e_gg_y}, {exp})[0]};
+}
+BdabeSecretAttributeKey request_attribute_sk(Engine& eng, const BdabePublicUserKey& pk_u, const BdabeSecretAuthorityKey& ska, const std::string& attribute) {   // :275-305
+  if (!from_authority(attribute, ska.name)) throw RabeError("attribute " + attribute + " is not from_authority() or !is_eligible()");
+  Fr exp = attr_exponent(attribute, ska.name, ska.a3);
+  return BdabeSecretAttributeKey{attribute, eng.g1_mul({pk_u.u1}, {exp})[0], eng.g2_mul({pk_u.u2}, {exp})[0]};
+}
+BdabeCiphertext encrypt(Engine& eng, Rng& rng, const BdabePublicKey& pk, const std::vector<const BdabePublicAttributeKey*>& attr_pks,
+                        const std::string& policy, PolicyLanguage language, const Bytes& plaintext) {        // :317-358
+  PolicyNode tree = parse_or_error(policy, language);
+  if (!policy_in_dnf(tree)) throw RabeError("Error in bdabe/encrypt: Policy not in DNF.");
+  std::vector<std::string> names;
+  std::vector<G1> k1;
+  std::vector<G2> k2;
+  std::vector<Gt> kt;
+  for (const auto* k : attr_pks) { names.push_back(k->attr); k1.push_back(k->a1); k2.push_back(k->a2); kt.push_back(k->a3); }
+  std::vector<DnfTerm> terms;
+  if (!json_to_dnf(tree, names, &terms)) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: Error in json_to_dnf: could not parse policy as DNF");
+  // _msg = pairing(rng.gen(), rng.gen()) = e(G1::one(), G2::one())^(a b)
+  Fr a = rng.next_fr(), b = rng.next_fr();
+  Gt msg = eng.gt_pow({eng.gt_generator()}, {fr_mul(a, b)})[0];
+  BdabeCiphertext ct;
+  ct.policy = {policy, language};
+  if (!terms.empty()) {
+    std::vector<Gt> t_gt = fold_terms(terms, kt, [&](const std::vector<Gt>& x, const std::vector<Gt>& y) { return eng.gt_mul(x, y); });
+    std::vector<G1> t_g1 = fold_terms(terms, k1, [&](const std::vector<G1>& x, const std::vector<G1>& y) { return g1_add(eng, x, y); });
+    std::vector<G2> t_g2 = fold_terms(terms, k2, [&](const std::vector<G2>& x, const std::vector<G2>& y) { return g2_add(eng, x, y); });
+    std::vector<Fr> r;
+    for (size_t t = 0; t < terms.size(); t++) r.push_back(rng.next_fr());
+    const size_t m = terms.size();
+    std::vector<G1> b1(m, pk.p1);
+    std::vector<G2> b2(m, pk.p2);
+    std::vector<Fr> rr = r;
+    b1.insert(b1.end(), t_g1.begin(), t_g1.end());
+    b2.insert(b2.end(), t_g2.begin(), t_g2.end());
+    rr.insert(rr.end(), r.begin(), r.end());
+    std::vector<G1> o1 = eng.g1_mul(b1, rr);
+    std::vector<G2> o2 = eng.g2_mul(b2, rr);
+    std::vector<Gt> e1 = eng.gt_mul(eng.gt_pow(t_gt, r), std::vector<Gt>(m, msg));
+    for (size_t t = 0; t < m; t++) ct.j.push_back({terms[t].attrs, e1[t], o1[t], o2[t], o1[m + t], o2[m + t]});
+  }
+  ct.ct = seal(rng, msg, plaintext);
+  return ct;
+}
+static void plan_decrypt(const BdabeUserKey& sk, const BdabeCiphertext& ct, PairingJob* job) {      // :367-399
+  std::vector<std::string> str_attr;
+  std::vector<AttrKey> keys;
+  for (const auto& k : sk.sk_a) { str_attr.push_back(k.attr); keys.push_back({&k.attr, &k.au1, &k.au2}); }
+  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  if (!traverse_policy(str_attr, tree)) throw RabeError("Error in bdabe/decrypt: attributes in sk do not match policy in ct.");
+  job->lead_one = true;                       // no satisfiable conjunction: msg stays Gt::one() and the AES layer fails
+  for (const auto& cj : ct.j) {
+    if (!is_satisfiable(cj.attr, keys)) continue;
+    job->lead_one = false;
+    job->lead = cj.e1;
+    plan_term(cj.attr, keys, cj.e2, cj.e3, cj.e4, cj.e5, sk.sk.u1, sk.sk.u2, job);
+    break;
+  }
+}
+Gt decrypt_gt(Engine& eng, const BdabeUserKey& sk, const BdabeCiphertext& ct) {
+  std::vector<PairingJob> jobs(1);
+  plan_decrypt(sk, ct, &jobs[0]);
+  return run_pairing_jobs(eng, jobs)[0];
+}
+Bytes decrypt(Engine& eng, const BdabeUserKey& sk, const BdabeCiphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const BdabeUserKey*>& sks, const std::vector<const BdabeCiphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
+  std::vector<PairingJob> jobs = plan_jobs(cts.size(), [&](size_t i, PairingJob* j) { plan_decrypt(*sks[i], *cts[i], j); });
+  std::vector<const Bytes*> sealed;
+  for (const auto* c : cts) sealed.push_back(&c->ct);
+  return open_jobs(eng, jobs, sealed);
+}
+}  // namespace bdabe
+
+namespace mke08 {
+using namespace dnfabe;
+std::pair<Mke08PublicKey, Mke08MasterKey> setup(Engine& eng, Rng& rng) {          // :130-149
+  G1 g1 = eng.random_g1(rng);
+  G2 g2 = eng.random_g2(rng);
+  G1 p1 = eng.random_g1(rng);
+  G2 p2 = eng.random_g2(rng);
+  Fr y1 = rng.next_fr(), y2 = rng.next_fr();
+  Gt e = eng.pairing({g1}, {g2})[0];
+  std::vector<Gt> ey = eng.gt_pow({e, e}, {y1, y2});
+  return {Mke08PublicKey{g1, g2, p1, p2, ey[0], ey[1]}, Mke08MasterKey{eng.g1_mul({g1}, {y1})[0], eng.g2_mul({g2}, {y2})[0]}};
+}
+Mke08UserKey keygen(Engine& eng, Rng& rng, const Mke08PublicKey& pk, const Mke08MasterKey& msk, const std::string& name) {   // :159-181
+  Fr mk_u = rng.next_fr();
+  std::vector<G1> a = eng.g1_mul({pk.p1, pk.g1}, {mk_u, mk_u});
+  std::vector<G2> b = eng.g2_mul({pk.p2, pk.g2}, {mk_u, mk_u});
+  Mke08UserKey k;
+  k.sk = {g1_add(eng, {msk.g1}, {a[0]})[0], g2_add(eng, {msk.g2}, {b[0]})[0]};
+  k.pk = {name, a[1], b[1]};
+  return k;
+}
+Mke08SecretAuthorityKey authgen(Rng& rng, const std::string& name) { return Mke08SecretAuthorityKey{name, rng.next_fr()}; }   // :189-197
+Mke08PublicAttributeKey request_authority_pk(Engine& eng, const Mke08PublicKey& pk, const std::string& attribute, const Mke08SecretAuthorityKey& ska) {   // :207-238
+  if (!from_authority(attribute, ska.name)) throw RabeError("attribute " + attribute + " is not from_authority() or !is_eligible()");
+  Fr exp = attr_exponent(attribute, ska.name, ska.r);
+  std::vector<Gt> g = eng.gt_pow({pk.e_gg_y1, pk.e_gg_y2}, {exp, exp});
+  return Mke08PublicAttributeKey{attribute, eng.g1_mul({pk.g1}, {exp})[0], eng.g2_mul({pk.g2}, {exp})[0], g[0], g[1]};
+}
+Mke08SecretAttributeKey request_authority_sk(Engine& eng, const Mke08PublicUserKey& pk_u, const std::string& attr, const Mke08SecretAuthorityKey& ska) {   // :248-278
+  if (!from_authority(attr, ska.name)) throw RabeError("attribute " + attr + " is not from_authority() or !is_eligible()");
+  Fr exp = attr_exponent(attr, ska.name, ska.r);
+  return Mke08SecretAttributeKey{attr, eng.g1_mul({pk_u.g1}, {exp})[0], eng.g2_mul({pk_u.g2}, {exp})[0]};
+}
+Mke08Ciphertext encrypt(Engine& eng, Rng& rng, const Mke08PublicKey& pk, const std::vector<const Mke08PublicAttributeKey*>& attr_pks,
+                        const std::string& policy, PolicyLanguage language, const Bytes& plaintext) {        // :290-334
+  PolicyNode tree = parse_or_error(policy, language);
+  if (!policy_in_dnf(tree)) throw RabeError("Error in mke08/encrypt: policy is not in dnf");
+  std::vector<std::string> names;
+  std::vector<G1> k1;
+  std::vector<G2> k2;
+  std::vector<Gt> kt1, kt2;
+  for (const auto* k : attr_pks) { names.push_back(k->attr); k1.push_back(k->g1); k2.push_back(k->g2); kt1.push_back(k->gt1); kt2.push_back(k->gt2); }
+  std::vector<DnfTerm> terms;
+  if (!json_to_dnf(tree, names, &terms)) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: Error in json_to_dnf: could not parse policy as DNF");
+  // msg1 = pairing(rng.gen(), rng.gen()); msg2 = msg1.pow(rng.gen()); msg = msg1 * msg2
+  Fr a = rng.next_fr(), b = rng.next_fr(), c = rng.next_fr();
+  Fr ab = fr_mul(a, b);
+  std::vector<Gt> ms = eng.gt_pow({eng.gt_generator(), eng.gt_generator(), eng.gt_generator()}, {ab, fr_mul(ab, c), fr_mul(ab, fr_add(fr_one(), c))});
+  const Gt msg1 = ms[0], msg2 = ms[1], msg = ms[2];
+  Mke08Ciphertext ct;
+  ct.policy = {policy, language};
+  if (!terms.empty()) {
+    auto gmul = [&](const std::vector<Gt>& x, const std::vector<Gt>& y) { return eng.gt_mul(x, y); };
+    std::vector<Gt> t1 = fold_terms(terms, kt1, gmul), t2 = fold_terms(terms, kt2, gmul);
+    std::vector<G1> t_g1 = fold_terms(terms, k1, [&](const std::vector<G1>& x, const std::vector<G1>& y) { return g1_add(eng, x, y); });
+    std::vector<G2> t_g2 = fold_terms(terms, k2, [&](const std::vector<G2>& x, const std::vector<G2>& y) { return g2_add(eng, x, y); });
+    std::vector<Fr> r;
+    for (size_t t = 0; t < terms.size(); t++) r.push_back(rng.next_fr());
+    const size_t m = terms.size();
+    std::vector<G1> b1(m, pk.p1);
+    std::vector<G2> b2(m, pk.p2);
+    std::vector<Fr> rr = r;
+    b1.insert(b1.end(), t_g1.begin(), t_g1.end());
+    b2.insert(b2.end(), t_g2.begin(), t_g2.end());
+    rr.insert(rr.end(), r.begin(), r.end());
+    std::vector<G1> o1 = eng.g1_mul(b1, rr);
+    std::vector<G2> o2 = eng.g2_mul(b2, rr);
+    std::vector<Gt> tt = t1, mm(m, msg1);
+    tt.insert(tt.end(), t2.begin(), t2.end());
+    mm.insert(mm.end(), m, msg2);
+    std::vector<Gt> j = eng.gt_mul(eng.gt_pow(tt, rr), mm);
+    for (size_t t = 0; t < m; t++) ct.e.push_back({terms[t].attrs, j[t], j[m + t], o1[t], o2[t], o1[m + t], o2[m + t]});
+  }
+  ct.ct = seal(rng, msg, plaintext);
+  return ct;
+}
+// leads (j1 * j2) are multiplied in one launch for the whole batch before the pairing jobs run
+static bool plan_decrypt(const Mke08UserKey& sk, const Mke08Ciphertext& ct, PairingJob* job, Gt* j1, Gt* j2) {      // :343-380
+  std::vector<std::string> str_attr;
+  std::vector<AttrKey> keys;
+  for (const auto& k : sk.sk_a) { str_attr.push_back(k.attr); keys.push_back({&k.attr, &k.g1, &k.g2}); }
+  PolicyNode tree = parse_or_error(ct.policy.first, ct.policy.second);
+  if (!traverse_policy(str_attr, tree)) throw RabeError("Error in mke08/decrypt: attributes in sk do not match policy in ct.");
+  job->lead_one = true;
+  for (const auto& ej : ct.e) {
+    if (!is_satisfiable(ej.str, keys)) continue;
+    job->lead_one = false;
+    *j1 = ej.j1;
+    *j2 = ej.j2;
+    plan_term(ej.str, keys, ej.j3, ej.j4, ej.j5, ej.j6, sk.sk.g1, sk.sk.g2, job);
+    return true;
+  }
+  return false;
+}
+static std::vector<PairingJob> plan_batch(Engine& eng, const std::vector<const Mke08UserKey*>& sks, const std::vector<const Mke08Ciphertext*>& cts) {
+  const size_t n = cts.size();
+  std::vector<Gt> j1(n), j2(n);
+  std::vector<char> has(n, 0);
+  std::vector<PairingJob> jobs = plan_jobs(n, [&](size_t i, PairingJob* j) { has[i] = plan_decrypt(*sks[i], *cts[i], j, &j1[i], &j2[i]) ? 1 : 0; });
+  std::vector<Gt> a, b;
+  std::vector<size_t> who;
+  for (size_t i = 0; i < n; i++) if (has[i] && !jobs[i].failed) { a.push_back(j1[i]); b.push_back(j2[i]); who.push_back(i); }
+  if (!who.empty()) {
+    std::vector<Gt> lead = eng.gt_mul(a, b);
+    for (size_t t = 0; t < who.size(); t++) jobs[who[t]].lead = lead[t];
+  }
+  return jobs;
+}
+Gt decrypt_gt(Engine& eng, const Mke08UserKey& sk, const Mke08Ciphertext& ct) {
+  std::vector<PairingJob> jobs(1);
+  Gt j1, j2;
+  if (plan_decrypt(sk, ct, &jobs[0], &j1, &j2)) jobs[0].lead = eng.gt_mul({j1}, {j2})[0];
+  return run_pairing_jobs(eng, jobs)[0];
+}
+Bytes decrypt(Engine& eng, const Mke08UserKey& sk, const Mke08Ciphertext& ct) { return open_or_error(decrypt_gt(eng, sk, ct), ct.ct); }
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const Mke08UserKey*>& sks, const std::vector<const Mke08Ciphertext*>& cts) {
+  if (sks.size() != cts.size()) throw RabeError("decrypt_batch: sks and cts differ in length");
+  std::vector<PairingJob> jobs = plan_batch(eng, sks, cts);
+  std::vector<const Bytes*> sealed;
+  for (const auto* c : cts) sealed.push_back(&c->ct);
+  return open_jobs(eng, jobs, sealed);
+}
+}  // namespace mke08
+
 }  // namespace schemes
 }  // namespace rabe

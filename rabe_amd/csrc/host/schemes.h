@@ -5,6 +5,7 @@
 //   bsw   src/schemes/bsw/mod.rs:39-318    setup / keygen / encrypt / decrypt
 //   lsw   src/schemes/lsw/mod.rs:40-290    setup / keygen / encrypt / decrypt
 //   aw11  src/schemes/aw11/mod.rs:46-390   setup / authgen / keygen / encrypt / decrypt
+//   bdabe src/schemes/bdabe/mod.rs:49-475, mke08 src/schemes/mke08/mod.rs:20-470   the DNF-policy schemes
 // Struct fields mirror the reference structs one for one.  Every function takes the Engine (GPU context) and,
 // where the reference draws from thread_rng(), an Rng, as its first arguments; the rest is the reference signature.
 #pragma once
@@ -150,5 +151,54 @@ std::vector<Ghw11TransformCiphertext> transform_batch(Engine& eng, const std::ve
 Gt decrypt_out_gt(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk);
 Bytes decrypt_out(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk, const Bytes& data);
 }  // namespace ghw11
+
+namespace bdabe {       // src/schemes/bdabe/mod.rs (DNF policies, multi-authority)
+struct BdabePublicKey { G1 g1; G2 g2; G1 p1; G2 p2; Gt e_gg_y; };                          // :49-55
+struct BdabeMasterKey { Fr y; };                                                            // :61-63
+struct BdabeSecretUserKey { G1 u1; G2 u2; };                                                // :89-92
+struct BdabePublicUserKey { std::string u; G1 u1; G2 u2; };                                 // :79-83
+struct BdabeSecretAttributeKey { std::string attr; G1 au1; G2 au2; };                       // :98-102
+struct BdabeUserKey { BdabeSecretUserKey sk; BdabePublicUserKey pk; std::vector<BdabeSecretAttributeKey> sk_a; };   // :69-73
+struct BdabePublicAttributeKey { std::string attr; G1 a1; G2 a2; Gt a3; };                  // :108-113
+struct BdabeSecretAuthorityKey { std::string name; G1 a1; G2 a2; Fr a3; };                  // :119-124
+struct BdabeCiphertextTuple { std::vector<std::string> attr; Gt e1; G1 e2; G2 e3; G1 e4; G2 e5; };   // :130-137
+struct BdabeCiphertext { PolicyRef policy; std::vector<BdabeCiphertextTuple> j; Bytes ct; };          // :143-147
+
+std::pair<BdabePublicKey, BdabeMasterKey> setup(Engine& eng, Rng& rng);
+BdabeSecretAuthorityKey authgen(Engine& eng, Rng& rng, const BdabePublicKey& pk, const BdabeMasterKey& msk, const std::string& name);
+BdabeUserKey keygen(Engine& eng, Rng& rng, const BdabePublicKey& pk, const BdabeSecretAuthorityKey& ska, const std::string& name);
+BdabePublicAttributeKey request_attribute_pk(Engine& eng, const BdabePublicKey& pk, const BdabeSecretAuthorityKey& ska, const std::string& attribute);
+BdabeSecretAttributeKey request_attribute_sk(Engine& eng, const BdabePublicUserKey& pk_u, const BdabeSecretAuthorityKey& ska, const std::string& attribute);
+BdabeCiphertext encrypt(Engine& eng, Rng& rng, const BdabePublicKey& pk, const std::vector<const BdabePublicAttributeKey*>& attr_pks,
+                        const std::string& policy, PolicyLanguage language, const Bytes& plaintext);
+Bytes decrypt(Engine& eng, const BdabeUserKey& sk, const BdabeCiphertext& ct);
+Gt decrypt_gt(Engine& eng, const BdabeUserKey& sk, const BdabeCiphertext& ct);
+// n independent decrypts: every item's four pairing factors on one accumulator, one launch set for the batch
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const BdabeUserKey*>& sks, const std::vector<const BdabeCiphertext*>& cts);
+}  // namespace bdabe
+
+namespace mke08 {       // src/schemes/mke08/mod.rs (DNF policies, multi-authority)
+struct Mke08PublicKey { G1 g1; G2 g2; G1 p1; G2 p2; Gt e_gg_y1; Gt e_gg_y2; };              // :20-27
+struct Mke08MasterKey { G1 g1; G2 g2; };                                                    // :32-35
+struct Mke08SecretUserKey { G1 g1; G2 g2; };                                                // :58-61
+struct Mke08PublicUserKey { std::string name; G1 g1; G2 g2; };                              // :49-53
+struct Mke08SecretAttributeKey { std::string attr; G1 g1; G2 g2; };                         // :85-89
+struct Mke08UserKey { Mke08SecretUserKey sk; Mke08PublicUserKey pk; std::vector<Mke08SecretAttributeKey> sk_a; };   // :40-44
+struct Mke08SecretAuthorityKey { std::string name; Fr r; };                                 // :66-69
+struct Mke08PublicAttributeKey { std::string attr; G1 g1; G2 g2; Gt gt1; Gt gt2; };         // :74-80
+struct Mke08CTConjunction { std::vector<std::string> str; Gt j1; Gt j2; G1 j3; G2 j4; G1 j5; G2 j6; };   // :103-111
+struct Mke08Ciphertext { PolicyRef policy; std::vector<Mke08CTConjunction> e; Bytes ct; };               // :94-98
+
+std::pair<Mke08PublicKey, Mke08MasterKey> setup(Engine& eng, Rng& rng);
+Mke08UserKey keygen(Engine& eng, Rng& rng, const Mke08PublicKey& pk, const Mke08MasterKey& msk, const std::string& name);
+Mke08SecretAuthorityKey authgen(Rng& rng, const std::string& name);
+Mke08PublicAttributeKey request_authority_pk(Engine& eng, const Mke08PublicKey& pk, const std::string& attribute, const Mke08SecretAuthorityKey& ska);
+Mke08SecretAttributeKey request_authority_sk(Engine& eng, const Mke08PublicUserKey& pk_u, const std::string& attr, const Mke08SecretAuthorityKey& ska);
+Mke08Ciphertext encrypt(Engine& eng, Rng& rng, const Mke08PublicKey& pk, const std::vector<const Mke08PublicAttributeKey*>& attr_pks,
+                        const std::string& policy, PolicyLanguage language, const Bytes& plaintext);
+Bytes decrypt(Engine& eng, const Mke08UserKey& sk, const Mke08Ciphertext& ct);
+Gt decrypt_gt(Engine& eng, const Mke08UserKey& sk, const Mke08Ciphertext& ct);
+std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const Mke08UserKey*>& sks, const std::vector<const Mke08Ciphertext*>& cts);
+}  // namespace mke08
 
 }}  // namespace rabe::schemes

@@ -10,7 +10,9 @@ KINDS = {"ac17_pk": 1, "ac17_msk": 2, "ac17_cp_sk": 3, "ac17_cp_ct": 4, "ac17_kp
          "bsw_pk": 10, "bsw_msk": 11, "bsw_sk": 12, "bsw_ct": 13,
          "lsw_pk": 20, "lsw_msk": 21, "lsw_sk": 22, "lsw_ct": 23,
          "aw11_gk": 30, "aw11_pk": 31, "aw11_msk": 32, "aw11_sk": 33, "aw11_ct": 34,
-         "ghw11_pk": 40, "ghw11_msk": 41, "ghw11_sk": 42, "ghw11_tk": 43, "ghw11_rk": 44, "ghw11_ct": 45, "ghw11_tct": 46}
+         "ghw11_pk": 40, "ghw11_msk": 41, "ghw11_sk": 42, "ghw11_tk": 43, "ghw11_rk": 44, "ghw11_ct": 45, "ghw11_tct": 46,
+         "bdabe_pk": 50, "bdabe_msk": 51, "bdabe_ska": 52, "bdabe_uk": 53, "bdabe_pka": 54, "bdabe_ct": 55,
+         "mke08_pk": 60, "mke08_msk": 61, "mke08_ska": 62, "mke08_uk": 63, "mke08_pka": 64, "mke08_ct": 65}
 
 
 class RabeError(Exception):
@@ -185,6 +187,20 @@ def policy_traverse(policy, attributes, language=JSON_POLICY):
     return bool(r.value)
 
 
+def policy_in_dnf(policy, language=JSON_POLICY):
+    r = ctypes.c_int32()
+    _check(_lib().rabe_policy_in_dnf(policy.encode(), language, ctypes.byref(r)))
+    return bool(r.value)
+
+
+def policy_dnf_terms(policy, key_attrs, language=JSON_POLICY):
+    """the conjunctions `json_to_dnf` builds for public attribute keys with these names (dnf.rs:186-201); RabeError = its Err"""
+    arr, n = _strs(key_attrs)
+    p = ctypes.c_void_p()
+    _check(_lib().rabe_policy_dnf_terms(policy.encode(), language, arr, n, ctypes.byref(p)))
+    return json.loads(_take_text(p))
+
+
 def policy_shares(policy, secret, tape, language=JSON_POLICY):
     p = ctypes.c_void_p()
     data = b"".join(int(v).to_bytes(32, "little") for v in tape)
@@ -293,6 +309,34 @@ def parse_obj(kind, data):
         o = {"policy": r.pol(), "c": r.raw(384), "c1": r.raw(64), "ci_di": [(r.s(), r.raw(64), r.raw(64)) for _ in range(r.u32())], "data": r.raw(r.u32())}
     elif kind == "ghw11_tct":
         o = {"c": r.raw(384), "t": r.raw(384)}
+    elif kind == "bdabe_pk":
+        o = {"g1": r.raw(64), "g2": r.raw(128), "p1": r.raw(64), "p2": r.raw(128), "e_gg_y": r.raw(384)}
+    elif kind == "bdabe_msk":
+        o = {"y": r.raw(32)}
+    elif kind == "bdabe_ska":
+        o = {"name": r.s(), "a1": r.raw(64), "a2": r.raw(128), "a3": r.raw(32)}
+    elif kind == "bdabe_uk":
+        o = {"sk": {"u1": r.raw(64), "u2": r.raw(128)}, "pk": {"u": r.s(), "u1": r.raw(64), "u2": r.raw(128)},
+             "sk_a": [(r.s(), r.raw(64), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "bdabe_pka":
+        o = {"attr": r.s(), "a1": r.raw(64), "a2": r.raw(128), "a3": r.raw(384)}
+    elif kind == "bdabe_ct":
+        o = {"policy": r.pol(), "j": [([r.s() for _ in range(r.u32())], r.raw(384), r.raw(64), r.raw(128), r.raw(64), r.raw(128)) for _ in range(r.u32())],
+             "ct": r.raw(r.u32())}
+    elif kind == "mke08_pk":
+        o = {"g1": r.raw(64), "g2": r.raw(128), "p1": r.raw(64), "p2": r.raw(128), "e_gg_y1": r.raw(384), "e_gg_y2": r.raw(384)}
+    elif kind == "mke08_msk":
+        o = {"g1": r.raw(64), "g2": r.raw(128)}
+    elif kind == "mke08_ska":
+        o = {"name": r.s(), "r": r.raw(32)}
+    elif kind == "mke08_uk":
+        o = {"sk": {"g1": r.raw(64), "g2": r.raw(128)}, "pk": {"name": r.s(), "g1": r.raw(64), "g2": r.raw(128)},
+             "sk_a": [(r.s(), r.raw(64), r.raw(128)) for _ in range(r.u32())]}
+    elif kind == "mke08_pka":
+        o = {"attr": r.s(), "g1": r.raw(64), "g2": r.raw(128), "gt1": r.raw(384), "gt2": r.raw(384)}
+    elif kind == "mke08_ct":
+        o = {"policy": r.pol(), "e": [([r.s() for _ in range(r.u32())], r.raw(384), r.raw(384), r.raw(64), r.raw(128), r.raw(64), r.raw(128))
+                                      for _ in range(r.u32())], "ct": r.raw(r.u32())}
     else:
         raise ValueError(kind)
     r.done()

@@ -5,7 +5,8 @@ The reference cannot run here (Rust, and its arithmetic crate rabe-bn is not ven
 known-answer vectors for group values, so these vectors pin the ORACLE: inputs (keys,
 policy strings, explicit-randomness tapes) and every output element in the canonical wire format of
 include/rabe_hip.h, hex-encoded.  The policy strings and attribute sets are the ones the reference's own
-tests use (ac17/mod.rs:756-809, bsw/mod.rs:344-602, lsw/mod.rs:300-374, aw11/mod.rs:400-561).
+tests use (ac17/mod.rs:756-809, bsw/mod.rs:344-602, lsw/mod.rs:300-374, aw11/mod.rs:400-561, bdabe/mod.rs:477-663,
+mke08/mod.rs:472-619).
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import json
@@ -271,11 +272,102 @@ def ghw11_cases():
     return doc
 
 
+def _dnf_world(setup, seed):
+    rng = SeededRng(seed)
+    return rng, setup(rng)
+
+
+def bdabe_cases():
+    """bdabe/mod.rs:477-663: `and`, `or`, `or_and` -- including or_and's shadowed `_att2_pk` (the ciphertext only carries the
+    conjunction whose public attribute key was passed, :600-626) -- with every element of every key and ciphertext."""
+    rng = SeededRng(30)
+    ts = [rng.fr_nonzero() for _ in range(5)]
+    pk, msk = sch.bdabe_setup(ListRng(ts))
+    doc = {"setup_tape": [fr(x) for x in ts],
+           "pk": {"g1": g1(pk["g1"]), "g2": g2(pk["g2"]), "p1": g1(pk["p1"]), "p2": g2(pk["p2"]), "e_gg_y": gt(pk["e_gg_y"])},
+           "msk": {"y": fr(msk["y"])}, "authorities": [], "cases": []}
+    auths = {}
+    for name in ("aa1", "aa2", "aa3"):
+        ta = [rng.fr(), rng.fr()]
+        a = sch.bdabe_authgen(pk, msk, name, ListRng(ta))
+        auths[name] = a
+        doc["authorities"].append({"name": name, "tape": [fr(x) for x in ta], "a1": g1(a["a1"]), "a2": g2(a["a2"]), "a3": fr(a["a3"])})
+    cases = [("and", "aa1", ["aa1::A", "aa2::B"], ["aa1::A", "aa2::B"],
+              r'''{"name": "and", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}'''),
+             ("or", "aa2", ["aa1::C", "aa2::B"], ["aa1::C", "aa2::B"],
+              r'''{"name": "or", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}'''),
+             ("or_and", "aa2", ["aa1::A", "aa2::B", "aa3::C"], ["aa1::A", "aa3::C"],
+              r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "aa3::C"}, {"name": "aa2::B"}]}, {"name": "aa1::X"}]}''')]
+    for label, key_auth, sk_attrs, pk_attrs, policy in cases:
+        tk = [rng.fr()]
+        sk = sch.bdabe_keygen(pk, auths[key_auth], "u1", ListRng(tk))
+        for a in sk_attrs:
+            sk["sk_a"].append(sch.bdabe_request_attribute_sk(sk["pk"], auths[a.split("::")[0]], a))
+        pkas = [sch.bdabe_request_attribute_pk(pk, auths[a.split("::")[0]], a) for a in pk_attrs]
+        rec = RecRng(rng.fr() % (1 << 62))
+        ct, msg = sch.bdabe_encrypt(pk, pkas, policy, pol.JSON, rec)
+        dec = sch.bdabe_decrypt(sk, ct)
+        assert dec == msg
+        doc["cases"].append({
+            "label": label, "policy": policy, "language": pol.JSON, "key_authority": key_auth, "keygen_tape": [fr(x) for x in tk],
+            "sk_attrs": sk_attrs, "pk_attrs": pk_attrs, "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+            "uk": {"sk": {"u1": g1(sk["sk"]["u1"]), "u2": g2(sk["sk"]["u2"])}, "pk": {"u1": g1(sk["pk"]["u1"]), "u2": g2(sk["pk"]["u2"])},
+                   "sk_a": [[k["attr"], g1(k["au1"]), g2(k["au2"])] for k in sk["sk_a"]]},
+            "pkas": [[k["attr"], g1(k["a1"]), g2(k["a2"]), gt(k["a3"])] for k in pkas],
+            "ct": [[t["attr"], gt(t["e1"]), g1(t["e2"]), g2(t["e3"]), g1(t["e4"]), g2(t["e5"])] for t in ct["j"]],
+            "decrypted": gt(dec)})
+    return doc
+
+
+def mke08_cases():
+    """mke08/mod.rs:472-619: `and`, `or`, `or_and`."""
+    rng = SeededRng(31)
+    ts = [rng.fr_nonzero() for _ in range(6)]
+    pk, msk = sch.mke08_setup(ListRng(ts))
+    doc = {"setup_tape": [fr(x) for x in ts],
+           "pk": {"g1": g1(pk["g1"]), "g2": g2(pk["g2"]), "p1": g1(pk["p1"]), "p2": g2(pk["p2"]), "e_gg_y1": gt(pk["e_gg_y1"]), "e_gg_y2": gt(pk["e_gg_y2"])},
+           "msk": {"g1": g1(msk["g1"]), "g2": g2(msk["g2"])}, "authorities": [], "cases": []}
+    auths = {}
+    for name in ("auth1", "auth2", "auth3"):
+        ta = [rng.fr()]
+        auths[name] = sch.mke08_authgen(name, ListRng(ta))
+        doc["authorities"].append({"name": name, "tape": [fr(x) for x in ta]})
+    cases = [("and", ["auth1::A", "auth2::B"], ["auth1::A", "auth2::B"],
+              r'''{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}'''),
+             ("or", ["auth1::C", "auth2::B"], ["auth1::C", "auth2::B"],
+              r'''{"name": "or", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}'''),
+             ("or_and", ["auth1::A", "auth2::B", "auth2::X"], ["auth1::A", "auth2::B", "auth2::X"],
+              r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}, {"name": "auth2::X"}]}'''),
+             # three conjunctions, the middle child of the OR lands on term index 2 (dnf.rs:162-164): terms [[C], [A], [A, B], [C]] after the sort
+             ("three_terms", ["auth1::A", "auth3::C"], ["auth1::A", "auth2::B", "auth3::C"],
+              r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}, {"name": "auth3::C"}, {"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth3::C"}]}]}''')]
+    for label, sk_attrs, pk_attrs, policy in cases:
+        tk = [rng.fr()]
+        sk = sch.mke08_keygen(pk, msk, "user1", ListRng(tk))
+        for a in sk_attrs:
+            sk["sk_a"].append(sch.mke08_request_authority_sk(sk["pk"], a, auths[a.split("::")[0]]))
+        pkas = [sch.mke08_request_authority_pk(pk, a, auths[a.split("::")[0]]) for a in pk_attrs]
+        rec = RecRng(rng.fr() % (1 << 62))
+        ct, msg = sch.mke08_encrypt(pk, pkas, policy, pol.JSON, rec)
+        dec = sch.mke08_decrypt(sk, ct)
+        assert dec == msg
+        doc["cases"].append({
+            "label": label, "policy": policy, "language": pol.JSON, "keygen_tape": [fr(x) for x in tk],
+            "sk_attrs": sk_attrs, "pk_attrs": pk_attrs, "encrypt_tape": [fr(x) for x in rec.log], "msg": gt(msg),
+            "uk": {"sk": {"g1": g1(sk["sk"]["g1"]), "g2": g2(sk["sk"]["g2"])}, "pk": {"g1": g1(sk["pk"]["g1"]), "g2": g2(sk["pk"]["g2"])},
+                   "sk_a": [[k["attr"], g1(k["g1"]), g2(k["g2"])] for k in sk["sk_a"]]},
+            "pkas": [[k["attr"], g1(k["g1"]), g2(k["g2"]), gt(k["gt1"]), gt(k["gt2"])] for k in pkas],
+            "ct": [[t["str"], gt(t["j1"]), gt(t["j2"]), g1(t["j3"]), g2(t["j4"]), g1(t["j5"]), g2(t["j6"])] for t in ct["e"]],
+            "decrypted": gt(dec)})
+    return doc
+
+
 def main():
     import sys as _sys
     only = set(_sys.argv[1:])
     for name, fn in (("bn254_primitives", primitives), ("ac17", ac17_cases), ("bsw", bsw_cases), ("lsw", lsw_cases), ("aw11", aw11_cases),
-                     ("ac17_kp", ac17_kp_cases), ("bsw_delegate", bsw_delegate_cases), ("ghw11", ghw11_cases)):
+                     ("ac17_kp", ac17_kp_cases), ("bsw_delegate", bsw_delegate_cases), ("ghw11", ghw11_cases), ("bdabe", bdabe_cases),
+                     ("mke08", mke08_cases)):
         if only and name not in only:
             continue
         doc = fn()

@@ -7,7 +7,7 @@ import os
 import pytest
 
 from rabe_amd import hostlib as hl
-from rabe_amd.schemes import ac17, aw11, bsw, lsw
+from rabe_amd.schemes import ac17, aw11, bdabe, bsw, lsw, mke08
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -342,3 +342,139 @@ def test_ac17_reference_quirks_against_the_oracle(host):
         else:
             with pytest.raises(hl.RabeError):
                 ac17.cp_decrypt(host, sk, ct)          # "decryption error: aead::Error", as in the reference
+
+
+# ------------------------------------------------------------------------------------------------ the DNF schemes
+def test_bdabe_reference_cases(host):
+    # bdabe/mod.rs:477-663: and, or, or_and, not
+    pk, msk = bdabe.setup(host)
+    a1, a2, a3 = (bdabe.authgen(host, pk, msk, n) for n in ("aa1", "aa2", "aa3"))
+    sk = bdabe.keygen(host, pk, a1, "u1")
+    p1 = bdabe.request_attribute_pk(host, pk, a1, "aa1::A")
+    p2 = bdabe.request_attribute_pk(host, pk, a2, "aa2::B")
+    p3 = bdabe.request_attribute_pk(host, pk, a3, "aa3::C")
+    bdabe.request_attribute_sk(host, sk, a1, "aa1::A")
+    bdabe.request_attribute_sk(host, sk, a2, "aa2::B")
+    ct_and = bdabe.encrypt(host, pk, [p1, p2], r'''{"name": "and", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}''', hl.JSON_POLICY, PLAINTEXT)
+    assert bdabe.decrypt(host, sk, ct_and) == PLAINTEXT
+    ct_or = bdabe.encrypt(host, pk, [p1, p2], r'''{"name": "or", "children": [{"name": "aa1::C"}, {"name": "aa2::B"}]}''', hl.JSON_POLICY, PLAINTEXT)
+    assert bdabe.decrypt(host, sk, ct_or) == PLAINTEXT
+    ct_human = bdabe.encrypt(host, pk, [p1], '"aa1::A" or "aa1::B"', hl.HUMAN_POLICY, PLAINTEXT)       # the doc example, :13-27
+    assert bdabe.decrypt(host, sk, ct_human) == PLAINTEXT
+    # or_and: a key with C and B, the policy's X unknown; the shadowed pk list leaves only [aa3::C] in the ciphertext
+    sk3 = bdabe.keygen(host, pk, a2, "u1")
+    for a, n in ((a1, "aa1::A"), (a2, "aa2::B"), (a3, "aa3::C")):
+        bdabe.request_attribute_sk(host, sk3, a, n)
+    pol3 = r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "aa3::C"}, {"name": "aa2::B"}]}, {"name": "aa1::X"}]}'''
+    ct3 = bdabe.encrypt(host, pk, [p1, p3], pol3, hl.JSON_POLICY, PLAINTEXT)
+    assert [t[0] for t in hl.parse_obj("bdabe_ct", ct3.serialize())["j"]] == [["aa3::C"]]
+    assert bdabe.decrypt(host, sk3, ct3) == PLAINTEXT
+    # not: no attribute of the key in the policy
+    ct_not = bdabe.encrypt(host, pk, [p1, p2], r'''{"name": "or", "children": [{"name": "aa1::B"}, {"name": "aa2::A"}]}''', hl.JSON_POLICY, PLAINTEXT)
+    with pytest.raises(hl.RabeError):
+        bdabe.decrypt(host, sk, ct_not)
+    with pytest.raises(hl.RabeError):
+        bdabe.request_attribute_pk(host, pk, a1, "aa2::B")                    # not from that authority
+    with pytest.raises(hl.RabeError):
+        bdabe.encrypt(host, pk, [p1, p2], r'''{"name": "and", "children": [{"name": "or", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}, {"name": "aa1::A"}]}''',
+                      hl.JSON_POLICY, PLAINTEXT)                              # not in DNF
+    # the batch form: per-item failures, the rest decrypt
+    got = bdabe.decrypt_batch(host, [sk, sk, sk3, sk], [ct_and, ct_not, ct3, ct_or])
+    assert got == [PLAINTEXT, None, PLAINTEXT, PLAINTEXT]
+    # a key that passes traverse_policy (it holds one OR branch) but satisfies no conjunction carried by the ciphertext: AES fails
+    sk_x = bdabe.keygen(host, pk, a1, "u2")
+    bdabe.request_attribute_sk(host, sk_x, a1, "aa1::X")
+    with pytest.raises(hl.RabeError):
+        bdabe.decrypt(host, sk_x, ct3)
+    # serialize / deserialize round trip of every new object kind
+    for o in (pk, msk, a1, sk3, p1, ct3):
+        assert hl.Obj.deserialize(o.kind, o.serialize(), host).serialize() == o.serialize()
+
+
+def test_mke08_reference_cases(host):
+    # mke08/mod.rs:472-619: and, or, or_and
+    pk, msk = mke08.setup(host)
+    sk = mke08.keygen(host, pk, msk, "user1")
+    a1, a2 = mke08.authgen(host, "auth1"), mke08.authgen(host, "auth2")
+    names = ["auth1::A", "auth2::B", "auth2::X"]
+    auth = {"auth1": a1, "auth2": a2}
+    pks = [mke08.request_authority_pk(host, pk, n, auth[n.split("::")[0]]) for n in names]
+    for n in names:
+        mke08.request_authority_sk(host, sk, n, auth[n.split("::")[0]])
+    pol_and = r'''{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}'''
+    pol_or = r'''{"name": "or", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}'''
+    pol_or_and = r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}, {"name": "auth2::X"}]}'''
+    cts = [mke08.encrypt(host, pk, pks[:2], pol_and, hl.JSON_POLICY, PLAINTEXT), mke08.encrypt(host, pk, pks[:2], pol_or, hl.JSON_POLICY, PLAINTEXT),
+           mke08.encrypt(host, pk, pks, pol_or_and, hl.JSON_POLICY, PLAINTEXT)]
+    for ct in cts:
+        assert mke08.decrypt(host, sk, ct) == PLAINTEXT
+    sk_other = mke08.keygen(host, pk, msk, "user2")
+    mke08.request_authority_sk(host, sk_other, "auth1::A", a1)
+    assert mke08.decrypt_batch(host, [sk, sk_other, sk_other, sk], [cts[0], cts[0], cts[1], cts[2]]) == [PLAINTEXT, None, PLAINTEXT, PLAINTEXT]
+    with pytest.raises(hl.RabeError):
+        mke08.request_authority_pk(host, pk, "auth2::B", a1)
+    for o in (pk, msk, a1, sk, pks[0], cts[2]):
+        assert hl.Obj.deserialize(o.kind, o.serialize(), host).serialize() == o.serialize()
+
+
+def test_bdabe_matches_golden(host):
+    doc = load("bdabe")
+    host.set_tape([fri(x) for x in doc["setup_tape"]])
+    pk, msk = bdabe.setup(host)
+    g = hl.parse_obj("bdabe_pk", pk.serialize())
+    assert g == {k: hb(v) for k, v in doc["pk"].items()} and hl.parse_obj("bdabe_msk", msk.serialize())["y"] == hb(doc["msk"]["y"])
+    auths = {}
+    for a in doc["authorities"]:
+        host.set_tape([fri(x) for x in a["tape"]])
+        ska = bdabe.authgen(host, pk, msk, a["name"])
+        assert hl.parse_obj("bdabe_ska", ska.serialize()) == {"name": a["name"], "a1": hb(a["a1"]), "a2": hb(a["a2"]), "a3": hb(a["a3"])}
+        auths[a["name"]] = ska
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        uk = bdabe.keygen(host, pk, auths[c["key_authority"]], "u1")
+        host.clear_tape()
+        for a in c["sk_attrs"]:
+            bdabe.request_attribute_sk(host, uk, auths[a.split("::")[0]], a)
+        g = hl.parse_obj("bdabe_uk", uk.serialize())
+        assert g["sk"] == {k: hb(v) for k, v in c["uk"]["sk"].items()}
+        assert (g["pk"]["u1"], g["pk"]["u2"]) == (hb(c["uk"]["pk"]["u1"]), hb(c["uk"]["pk"]["u2"]))
+        assert g["sk_a"] == [(n, hb(x), hb(y)) for n, x, y in c["uk"]["sk_a"]]
+        pkas = [bdabe.request_attribute_pk(host, pk, auths[a.split("::")[0]], a) for a in c["pk_attrs"]]
+        for o, w in zip(pkas, c["pkas"]):
+            assert hl.parse_obj("bdabe_pka", o.serialize()) == {"attr": w[0], "a1": hb(w[1]), "a2": hb(w[2]), "a3": hb(w[3])}
+        host.set_tape([fri(x) for x in c["encrypt_tape"]] + [17])                     # msg's G1, G2; r_j per term; nonce
+        ct = bdabe.encrypt(host, pk, pkas, c["policy"], LANG[c["language"]], PLAINTEXT)
+        host.clear_tape()
+        assert hl.parse_obj("bdabe_ct", ct.serialize())["j"] == [(t[0], hb(t[1]), hb(t[2]), hb(t[3]), hb(t[4]), hb(t[5])) for t in c["ct"]]
+        assert bdabe.decrypt_gt(host, uk, ct) == hb(c["decrypted"]) == hb(c["msg"])
+        assert bdabe.decrypt(host, uk, ct) == PLAINTEXT
+
+
+def test_mke08_matches_golden(host):
+    doc = load("mke08")
+    host.set_tape([fri(x) for x in doc["setup_tape"]])
+    pk, msk = mke08.setup(host)
+    assert hl.parse_obj("mke08_pk", pk.serialize()) == {k: hb(v) for k, v in doc["pk"].items()}
+    assert hl.parse_obj("mke08_msk", msk.serialize()) == {k: hb(v) for k, v in doc["msk"].items()}
+    auths = {}
+    for a in doc["authorities"]:
+        host.set_tape([fri(x) for x in a["tape"]])
+        auths[a["name"]] = mke08.authgen(host, a["name"])
+    for c in doc["cases"]:
+        host.set_tape([fri(x) for x in c["keygen_tape"]])
+        uk = mke08.keygen(host, pk, msk, "user1")
+        host.clear_tape()
+        for a in c["sk_attrs"]:
+            mke08.request_authority_sk(host, uk, a, auths[a.split("::")[0]])
+        g = hl.parse_obj("mke08_uk", uk.serialize())
+        assert g["sk"] == {k: hb(v) for k, v in c["uk"]["sk"].items()}
+        assert g["sk_a"] == [(n, hb(x), hb(y)) for n, x, y in c["uk"]["sk_a"]]
+        pkas = [mke08.request_authority_pk(host, pk, a, auths[a.split("::")[0]]) for a in c["pk_attrs"]]
+        for o, w in zip(pkas, c["pkas"]):
+            assert hl.parse_obj("mke08_pka", o.serialize()) == {"attr": w[0], "g1": hb(w[1]), "g2": hb(w[2]), "gt1": hb(w[3]), "gt2": hb(w[4])}
+        host.set_tape([fri(x) for x in c["encrypt_tape"]] + [19])                     # msg1's G1, G2; msg2's exponent; r_j per term; nonce
+        ct = mke08.encrypt(host, pk, pkas, c["policy"], LANG[c["language"]], PLAINTEXT)
+        host.clear_tape()
+        assert hl.parse_obj("mke08_ct", ct.serialize())["e"] == [(t[0], hb(t[1]), hb(t[2]), hb(t[3]), hb(t[4]), hb(t[5]), hb(t[6])) for t in c["ct"]]
+        assert mke08.decrypt_gt(host, uk, ct) == hb(c["decrypted"]) == hb(c["msg"])
+        assert mke08.decrypt(host, uk, ct) == PLAINTEXT

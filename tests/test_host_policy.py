@@ -141,3 +141,36 @@ def test_hash_to_fr_and_wide_reduction():
         a, b = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
         lib.rabe_fr_reduce512(x.to_bytes(64, "little"), a, b)
         assert int.from_bytes(a.raw, "little") == int.from_bytes(b.raw, "little") == x % bn.R
+
+
+def test_dnf_kat_and_fuzz():
+    """dnf.rs:245-307 through the C ABI, then random AND/OR trees against the oracle's restatement"""
+    from tests.test_oracle_policy import DNF_IN, DNF_OUT, DNF_TERMS
+    for policy, want in zip(DNF_IN, DNF_TERMS):
+        assert hl.policy_in_dnf(policy)
+        assert hl.policy_dnf_terms(policy, list("ABCD")) == want
+    for policy in DNF_OUT:
+        assert not hl.policy_in_dnf(policy)
+    with pytest.raises(hl.RabeError):
+        hl.policy_dnf_terms(r'''{"name": "and", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}''', list("ABC"))
+    rnd = random.Random(99)
+    ops = (lambda a, b: a + b,) * 3
+
+    def tree(depth):
+        if depth == 0 or rnd.random() < 0.3:
+            return '{"name": "%s"}' % rnd.choice("ABCDE")
+        kids = ", ".join(tree(depth - 1) for _ in range(rnd.randint(2, 4)))
+        return '{"name": "%s", "children": [%s]}' % (rnd.choice(["and", "or"]), kids)
+
+    for _ in range(300):
+        policy = tree(3)
+        keys = [rnd.choice("ABCDEF") for _ in range(rnd.randint(1, 6))]
+        t = opol.parse(policy, opol.JSON)
+        assert hl.policy_in_dnf(policy) == opol.policy_in_dnf(t)
+        try:
+            want = [x[0] for x in opol.json_to_dnf(t, [(k, 1, 1, 1, 1) for k in keys], ops)]
+        except opol.PolicyPanic:
+            with pytest.raises(hl.RabeError):
+                hl.policy_dnf_terms(policy, keys)
+            continue
+        assert hl.policy_dnf_terms(policy, keys) == want

@@ -112,3 +112,35 @@ def test_msp_rows_sum_to_unit_over_pruned_set():
             row = m[pi.index(n)]
             tot = [a + b for a, b in zip(tot, row)]
         assert tot == [1] + [0] * (c - 1)
+
+
+# dnf.rs:245-307 (test_dnf_from): which policies are in DNF, and how many conjunctions `json_to_dnf` builds (3 / 1 / 5 -- the
+# "2 x child index" placement of dnf.rs:162-164 included)
+DNF_IN = [r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children":  [{"name": "A"}, {"name": "C"}]}]}''',
+          r'''{"name": "and", "children": [{"name": "C"}, {"name": "D"}]}''',
+          r'''{"name": "or", "children": [{"name": "C"}, {"name": "and",  "children": [{"name": "A"}, {"name": "C"}]}, {"name" :"and",  "children": [{"name": "A"}, {"name": "D"}]}]}''']
+DNF_OUT = [r'''{"name": "or", "children":  [{"name": "and",  "children": [{"name": "or",  "children": [{"name": "C"}, {"name": "D"}]}, {"name": "B"}]}, {"name": "and",  "children": [{"name": "C"}, {"name": "D"}]}]}''',
+           r'''{"name": "and", "children": [{"name": "or",  "children": [{"name": "A"}, {"name": "B"}]}, {"name": "and",  "children": [{"name": "C"}, {"name": "D"}]}]}''']
+DNF_TERMS = [[["A"], ["C"], ["A", "B"]], [["C", "D"]], [["C"], ["A"], ["C"], ["A"], ["D"]]]
+
+
+def test_dnf_kat():
+    ops = (lambda a, b: a + b, lambda a, b: a + b, lambda a, b: a + b)       # the term structure does not depend on the groups
+    pks = [(n, 1, 1, 1, 1) for n in "ABCD"]
+    for policy, want in zip(DNF_IN, DNF_TERMS):
+        tree = pol.parse(policy, pol.JSON)
+        assert pol.policy_in_dnf(tree)
+        terms = pol.json_to_dnf(tree, pks, ops)
+        assert [t[0] for t in terms] == want
+        assert all(t[3] == len(t[0]) for t in terms)                         # every attribute added its key once
+    for policy in DNF_OUT:
+        assert not pol.policy_in_dnf(pol.parse(policy, pol.JSON))
+    # an AND below an AND passes policy_in_dnf and fails in json_to_dnf (encrypt's `.unwrap()` panics there)
+    nested = r'''{"name": "and", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}'''
+    tree = pol.parse(nested, pol.JSON)
+    assert pol.policy_in_dnf(tree)
+    with pytest.raises(pol.PolicyPanic):
+        pol.json_to_dnf(tree, pks, ops)
+    # a name that matches no key is dropped, one that matches two keys takes both
+    tree = pol.parse(r'''{"name": "and", "children": [{"name": "A"}, {"name": "Z"}]}''', pol.JSON)
+    assert [t[0] for t in pol.json_to_dnf(tree, pks + [("A", 1, 1, 1, 1)], ops)] == [["A", "A"]]

@@ -92,3 +92,39 @@ def test_ac17_kp_and_delegate():
     bct = sch.bsw_encrypt(bpk, r'''{"name": "and", "children":  [{"name": "A"}, {"name": "B"}]}''', pol.JSON, rng, msg)
     assert sch.bsw_decrypt(dsk, bct) == msg
     assert sch.bsw_delegate(bpk, bsk, ["A", "Z"], rng) is None
+
+
+def test_bdabe_reference_cases():
+    # bdabe/mod.rs:477-663: and / or / not (or_and with its shadowed key is in the golden vectors)
+    rng = SeededRng(16)
+    pk, msk = sch.bdabe_setup(rng)
+    a1, a2 = sch.bdabe_authgen(pk, msk, "aa1", rng), sch.bdabe_authgen(pk, msk, "aa2", rng)
+    sk = sch.bdabe_keygen(pk, a1, "u1", rng)
+    p1, p2 = sch.bdabe_request_attribute_pk(pk, a1, "aa1::A"), sch.bdabe_request_attribute_pk(pk, a2, "aa2::B")
+    sk["sk_a"].append(sch.bdabe_request_attribute_sk(sk["pk"], a1, "aa1::A"))
+    sk["sk_a"].append(sch.bdabe_request_attribute_sk(sk["pk"], a2, "aa2::B"))
+    ct, msg = sch.bdabe_encrypt(pk, [p1, p2], r'''{"name": "and", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}''', pol.JSON, rng)
+    assert [t["attr"] for t in ct["j"]] == [["aa1::A", "aa2::B"]] and sch.bdabe_decrypt(sk, ct) == msg
+    ct, msg = sch.bdabe_encrypt(pk, [p1, p2], r'''{"name": "or", "children": [{"name": "aa1::B"}, {"name": "aa2::A"}]}''', pol.JSON, rng)
+    with pytest.raises(ValueError):                       # `not`: no attribute of the key appears in the policy
+        sch.bdabe_decrypt(sk, ct)
+    with pytest.raises(ValueError):                       # an attribute of another authority
+        sch.bdabe_request_attribute_pk(pk, a1, "aa2::B")
+    with pytest.raises(ValueError):
+        sch.bdabe_encrypt(pk, [p1, p2], r'''{"name": "and", "children": [{"name": "or", "children": [{"name": "aa1::A"}, {"name": "aa2::B"}]}, {"name": "aa1::A"}]}''', pol.JSON, rng)
+
+
+def test_mke08_reference_cases():
+    # mke08/mod.rs:472-619: and / or_and
+    rng = SeededRng(17)
+    pk, msk = sch.mke08_setup(rng)
+    sk = sch.mke08_keygen(pk, msk, "user1", rng)
+    a1, a2 = sch.mke08_authgen("auth1", rng), sch.mke08_authgen("auth2", rng)
+    names = ["auth1::A", "auth2::B", "auth2::X"]
+    pks = [sch.mke08_request_authority_pk(pk, n, a1 if n.startswith("auth1") else a2) for n in names]
+    for n in names[:2]:
+        sk["sk_a"].append(sch.mke08_request_authority_sk(sk["pk"], n, a1 if n.startswith("auth1") else a2))
+    policy = r'''{"name": "or", "children": [{"name": "and", "children": [{"name": "auth1::A"}, {"name": "auth2::B"}]}, {"name": "auth2::X"}]}'''
+    ct, msg = sch.mke08_encrypt(pk, pks, policy, pol.JSON, rng)
+    assert [t["str"] for t in ct["e"]] == [["auth2::X"], ["auth1::A", "auth2::B"]]
+    assert sch.mke08_decrypt(sk, ct) == msg
