@@ -597,7 +597,7 @@ def pmc_traffic(kernel):
     cannot run inside the bench).  None when no summary names the kernel."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")) if "_cfg" not in os.path.basename(f))   # config 2's sets
     for f in reversed(files):
         tot, seen = 0.0, 0
         for line in open(f):
@@ -615,7 +615,7 @@ def pmc_valu_issue(kernel):
     instructions per wave issue slot (SQ_WAVE_CYCLES counts 4-cycle slots)."""
     import glob
     import re
-    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")))):
+    for f in reversed(sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.txt")) if "_cfg" not in os.path.basename(f))):
         vals, cur = {}, None
         for line in open(f):
             if not line.startswith(" "):

@@ -354,9 +354,9 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
 #define RB_BANK3_S(have_, A0, O0, X0, A1, O1, X1, A2, O2, X2, Y) \
   do { if (have_) { RB_MAC3_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y); } else { RB_MAC3F_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y); have_ = true; } } while (0)
 
-// operands < mod (every caller passes reduced field elements)
+// operands < mod (every caller passes reduced field elements); the Fp instance is the generated mont_mul2_fp below
 template <class M, class A>
-RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
+RB_HD void mont_mul2_generic(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
   uint32_t m0[8], m1[8];
   uint64_t acc0 = 0, acc1 = 0, c0_, c1_;
   uint32_t ovf0, ovf1;
@@ -451,68 +451,19 @@ RB_HD void mont_mul3_raw(uint32_t* r0, uint32_t* r1, uint32_t* r2, const A& a0, 
 //   W0 = a0 b0 - a1 b1 + p^2   in (0, 2p^2)        W1 = (a0+a1)(b0+b1) - a0 b0 - a1 b1 = a0 b1 + a1 b0  in [0, 2p^2)
 //   c0 = W0 / 2^256 mod p,  c1 = W1 / 2^256 mod p   (REDC output < 1.38 p: one conditional subtraction each)
 // 192 + 128 MACs instead of 3 x 128 + ... = 384 for three full Montgomery products.
-// Operands: a0, b0, a1, b1 < p and a2, b2 < 2p (top limbs < 2^31: the two top-limb products of a column sum to < 2^63.6).
-template <class A>
-RB_HD void wide_mul3(uint32_t* T0, uint32_t* T1, uint32_t* T2, const A& a0, const A& b0, const A& a1, const A& b1, const uint32_t* a2,
-                     const uint32_t* b2) {
-  uint64_t acc0 = 0, acc1 = 0, acc2 = 0, c0_, c1_, c2_;
-  uint32_t ovf0, ovf1, ovf2;
-#pragma unroll
-  for (int k = 0; k < 15; k++) {
-    bool have = false;
-    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k : 7;
-#pragma unroll
-    for (int i = lo; i <= hi; i++)
-      if (ab_top(k, i)) {
-        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
-        RB_MAD3(acc0, x0, y0, acc1, x1, y1, acc2, x2, y2);
-      }
-#pragma unroll
-    for (int i = lo; i <= hi; i++)
-      if (!ab_top(k, i)) {
-        const uint32_t x0 = a0[i], y0 = b0[k - i], x1 = a1[i], y1 = b1[k - i], x2 = a2[i], y2 = b2[k - i];
-        RB_BANK3(have, acc0, ovf0, x0, y0, acc1, ovf1, x1, y1, acc2, ovf2, x2, y2);
-      }
-    T0[k] = (uint32_t)acc0; T1[k] = (uint32_t)acc1; T2[k] = (uint32_t)acc2;
-    RB_SHIFT(have, acc0, ovf0);
-    RB_SHIFT(have, acc1, ovf1);
-    RB_SHIFT(have, acc2, ovf2);
-  }
-  T0[15] = (uint32_t)acc0; T1[15] = (uint32_t)acc1; T2[15] = (uint32_t)acc2;
-}
-// two Montgomery reductions of 512-bit values (< 2^256 * p) in lockstep; results < p
-template <class M>
-RB_HD void redc2(uint32_t* r0, uint32_t* r1, const uint32_t* W0, const uint32_t* W1) {
-  uint32_t m0[8], m1[8];
-  uint64_t acc0 = 0, acc1 = 0, c0_, c1_;
-  uint32_t ovf0, ovf1;
-  const uint32_t one_ = 1u;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    bool have = false;
-    const int lo = k < 8 ? 0 : k - 7, hi = k < 8 ? k - 1 : 7;
-    { const uint32_t x0 = W0[k], x1 = W1[k]; RB_MAD2_S(acc0, x0, acc1, x1, one_); }       // + W[k]: < 2^37 + 2^32, no carry
-#pragma unroll
-    for (int i = lo; i <= hi; i++)
-      if (plan_redc_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_MAD2_S(acc0, x0, acc1, x1, y); }
-#pragma unroll
-    for (int i = lo; i <= hi; i++)
-      if (!plan_redc_safe<M>(k, i)) { const uint32_t x0 = m0[i], x1 = m1[i], y = M::mod(k - i); RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y); }
-    if (k < 8) {
-      m0[k] = (uint32_t)acc0 * M::INV;
-      m1[k] = (uint32_t)acc1 * M::INV;
-      const uint32_t x0 = m0[k], x1 = m1[k], y = M::mod(0);
-      if (!have && plan_redc_last_safe<M>(k)) RB_MAD2_S(acc0, x0, acc1, x1, y);
-      else RB_BANK2_S(have, acc0, ovf0, x0, acc1, ovf1, x1, y);
-    } else {
-      r0[k - 8] = (uint32_t)acc0;
-      r1[k - 8] = (uint32_t)acc1;
-    }
-    RB_SHIFT(have, acc0, ovf0);
-    RB_SHIFT(have, acc1, ovf1);
-  }
-  cond_sub_mod<M>(r0, 0);
-  cond_sub_mod<M>(r1, 0);
+// wide_mul3 (operands a0, b0, a1, b1 < p and a2, b2 < 2p: top limbs < 2^31, so the two top-limb products of a column sum to
+// < 2^63.6), redc2_fp and mont_mul2_fp come from tools/gen_fp_asm.py: the same plan as the loops above, laid out as straight-line
+// code with as many products per asm statement as its 30 operands allow (hipcc pads every statement boundary with a wait state).
+#include "fp_gfx950_gen.h"      // inside namespace rabe::bn254, device-only
+template <class M> struct IsFp { static constexpr bool value = false; };
+template <> struct IsFp<FpParams> { static constexpr bool value = true; };
+template <class M, class A>
+RB_HD void mont_mul2_raw(uint32_t* r0, uint32_t* r1, const A& a0, const A& b0, const A& a1, const A& b1) {
+#ifndef RB_NO_GEN_MUL2
+  if constexpr (IsFp<M>::value) mont_mul2_fp(r0, r1, a0, b0, a1, b1);
+  else
+#endif
+    mont_mul2_generic<M>(r0, r1, a0, b0, a1, b1);
 }
 // (a0 + a1 u)(b0 + b1 u) over Fp with lazy reduction; all operands / results fully reduced Montgomery values
 template <class A>
@@ -540,7 +491,7 @@ RB_HD void fp2_mul_lazy_raw(uint32_t* c0, uint32_t* c1, const A& a0, const A& a1
   { uint32_t br = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) W1[i] = subb32(W1[i], T1[i], br); }
-  redc2<FpParams>(c0, c1, W0, W1);
+  redc2_fp(c0, c1, W0, W1);
 }
 #undef RB_MAD
 #undef RB_MAD_S

@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_table_mul_g1(const G1M* tb
   if (!active) return;
   store_g1(out[i].l, inf ? aff_inf<Fp>() : jac_to_aff_with_zinv(r, zinv));
 }
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out, int w16) {
+__global__ void __launch_bounds__(128, RB_G2_WAVES) k_table_mul_g2(const G2M* tbl, size_t n, const rhip_fr* k, rhip_g2* out, int w16) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_enc_rows(co
   store3_g1_block(sh, active, c + t * 3, pt[0], pt[1], pt[2]);
 }
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
+__global__ void __launch_bounds__(128, RB_G2_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
                                                      const rhip_fr* s, rhip_g2* c0, int w16) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_keygen_rows
   store3_g1_block(sh, active, dst, pt[0], pt[1], pt[2]);
 }
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0,
+__global__ void __launch_bounds__(128, RB_G2_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0,
                                                                       int w16) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

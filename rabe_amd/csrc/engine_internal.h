@@ -27,6 +27,11 @@ using namespace rabe::bn254;
 #ifndef RB_MIN_WAVES
 #define RB_MIN_WAVES 1
 #endif
+// the fixed-base / summing G2 kernels sit at the edge of 256 registers: two waves per SIMD hide their table gathers and the
+// single-wave issue gaps (k_aw11_enc_c3: 15.4 ms with 256 registers, 21.5 ms with 260)
+#ifndef RB_G2_WAVES
+#define RB_G2_WAVES 2
+#endif
 // ------------------------------------------------------------------------------------------------
 // context
 struct rhip_ctx {

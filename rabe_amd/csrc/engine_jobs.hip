@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_msm_finish_g1(size_t n_it
   else st_g1_q(P + last, jac_to_aff_with_zinv(acc, zinv));
 }
 // the same for a G2 sum -> the G2 argument of the item's last pair (a walking pair)
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_msm_finish_g2(size_t n_items, uint32_t L, const G2JM* part, const uint32_t* pair_off, G2M* Q, uint32_t* qref) {
+__global__ void __launch_bounds__(128, RB_G2_WAVES) k_msm_finish_g2(size_t n_items, uint32_t L, const G2JM* part, const uint32_t* pair_off, G2M* Q, uint32_t* qref) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n_items;
@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_r
   store_gt(c1[t].l, home_result(started));
 }
 // C3[row] = (g2*y_x) * r + g2 * omega   (:275-277): two fixed-base sums on one accumulator
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
+__global__ void __launch_bounds__(128, RB_G2_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
                                                                   const uint32_t* leaf_attr, const G2M* g2_tbl8, const G2M* attr_tbl, const rhip_fr* omg,
                                                                   const rhip_fr* rand, rhip_g2* c3) {
   __shared__ uint32_t lds[2 * 8 * 128];

@@ -117,3 +117,41 @@ def test_unbounded_second_operand_rule():
         top = (mod - 1) >> 224
         incoming = (1 << 37) - 1
         assert incoming + top * W <= FULL
+
+
+def test_generated_header_is_current(tmp_path, monkeypatch):
+    """rabe_amd/csrc/bn254/fp_gfx950_gen.h is what tools/gen_fp_asm.py writes today (its static_asserts tie it to ColumnPlan)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_fp_asm", os.path.join(root, "tools", "gen_fp_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(root, "rabe_amd", "csrc", "bn254", "fp_gfx950_gen.h")).read()
+    real_open = open
+    written = {}
+
+    class Capture:
+        def __init__(self, path):
+            self.path = path
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+        def write(self, text):
+            written[self.path] = written.get(self.path, "") + text
+
+    def fake_open(path, mode="r", *a, **k):
+        if "w" in mode:
+            return Capture(path)
+        return real_open(path, mode, *a, **k)
+
+    monkeypatch.setattr(gen, "open", fake_open, raising=False)
+    gen.main()
+    assert list(written.values()) == [committed]
+    # and the generator's plan is the header's plan (the compile-time static_asserts say the same)
+    mod = gen.fp_mod()
+    safe, last = plan(0, 0)
+    assert gen.column_plan(mod, False, 0, 0) == (safe, last)
+    safe, last = plan(0, 1)
+    assert gen.column_plan(mod, True, mod[7] + 1, mod[7] + 1) == (safe, last)
