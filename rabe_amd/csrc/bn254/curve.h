@@ -249,9 +249,30 @@ RB_HD uint32_t word_sel8(const uint32_t a[8], int w) {
   }
 }
 template <class F> RB_HD Jac<F> jac_madd_fast(const Jac<F>& p, const Aff<F>& q) { return jac_add_aff(p, q); }
+// G1 form of dbl-2009-l: the seven products as three interleaved pairs + one (same formulas as jac_dbl, hence the same values);
+// the variable-base kernels run two waves per SIMD, where a lone product chain leaves issue slots empty (tools/ubench_mac.hip)
+RB_HD Jac<Fp> g1_dbl_inl(const Jac<Fp>& p) {
+  Fp A, B;
+  mul2_inl(A, B, p.x, p.x, p.y, p.y);
+  Fp C, YZ;
+  mul2_inl(C, YZ, B, B, p.y, p.z);
+  const Fp xb = add(p.x, B);
+  const Fp E = add(dbl(A), A);
+  Fp T, Fq;
+  mul2_inl(T, Fq, xb, xb, E, E);
+  const Fp D = dbl(sub(sub(T, A), C));
+  Jac<Fp> r;
+  r.x = sub(Fq, dbl(D));
+  r.z = dbl(YZ);                                  // Y = 0 cannot happen on an odd-order group; Z = 0 stays 0
+  const Fp C8 = dbl(dbl(dbl(C)));
+  r.y = sub(mul_inl(E, sub(D, r.x)), C8);
+  return r;
+}
+template <class F> RB_HD Jac<F> jac_dbl_fast(const Jac<F>& p) { return jac_dbl(p); }
+template <> RB_HD Jac<Fp> jac_dbl_fast<Fp>(const Jac<Fp>& p) { return g1_dbl_inl(p); }
 template <> RB_HD Jac<Fp> jac_madd_fast<Fp>(const Jac<Fp>& p, const Aff<Fp>& q) { return g1_madd_inl(p, q); }
 template <class F>
-RB_FN Jac<F> jac_mul_naf(const Aff<F>& base, const uint32_t k[8]) {
+RB_FN Jac<F> jac_mul_naf_plain(const Aff<F>& base, const uint32_t k[8]) {
   uint32_t pos[8], neg[8];
   naf_masks(k, pos, neg);
   Jac<F> acc = jac_inf<F>();
@@ -261,7 +282,7 @@ RB_FN Jac<F> jac_mul_naf(const Aff<F>& base, const uint32_t k[8]) {
     const uint32_t pw = word_sel8(pos, w), nw = word_sel8(neg, w);
     if (!started && !(pw | nw)) continue;
     for (int b = 31; b >= 0; b--) {
-      if (started) acc = jac_dbl(acc);
+      if (started) acc = jac_dbl_fast(acc);
       const uint32_t pb = (pw >> b) & 1u, nb = (nw >> b) & 1u;
       if (pb | nb) {
         Aff<F> q = base;
@@ -274,6 +295,124 @@ RB_FN Jac<F> jac_mul_naf(const Aff<F>& base, const uint32_t k[8]) {
   return acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// GLV on G1: the curve y^2 = x^3 + 3 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y) (beta, lambda: cube roots of
+// unity mod p, mod r).  k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^130, so k P = k1 P + k2 phi(P) runs as a two-term sum with
+// shared doublings: ~128 doublings + ~85 mixed additions instead of 254 + ~85.  The decomposition rounds with the precomputed
+// g_i = floor(2^256 |b_i| / r) (constants.h); whatever the rounding, k1 + k2 lambda = k (mod r) holds exactly, so the result is the
+// same group element as `G * Fr` -- only the size of k1, k2 depends on it.  Small scalars come out as k1 = k, k2 = 0.
+template <int NA, int NB>
+RB_HD void limbs_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {      // out[NA + NB] = a[NA] * b[NB]
+#pragma unroll
+  for (int i = 0; i < NA + NB; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    out[i + NB] = (uint32_t)carry;
+  }
+}
+// |x| and the sign of a 256-bit two's-complement value
+RB_HD bool limbs_abs8(uint32_t x[8]) {
+  const bool neg_ = (x[7] >> 31) != 0;
+  if (neg_) {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = subb32(0u, x[i], borrow);
+  }
+  return neg_;
+}
+RB_HD void glv_decompose(const uint32_t k[8], uint32_t k1[8], bool& neg1, uint32_t k2[8], bool& neg2) {
+  constexpr uint32_t A1[2] = RB_GLV_A1, NB1[4] = RB_GLV_NEG_B1, A2[4] = RB_GLV_A2, B2[2] = RB_GLV_B2, G1C[3] = RB_GLV_G1, G2C[5] = RB_GLV_G2;
+  uint32_t a1[2], nb1[4], a2[4], b2[2], g1[3], g2[5];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { a1[i] = A1[i]; b2[i] = B2[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { nb1[i] = NB1[i]; a2[i] = A2[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) g1[i] = G1C[i];
+#pragma unroll
+  for (int i = 0; i < 5; i++) g2[i] = G2C[i];
+  uint32_t kk[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) kk[i] = k[i];
+  uint32_t p1[11], p2[13];
+  limbs_mul<8, 3>(kk, g1, p1);
+  limbs_mul<8, 5>(kk, g2, p2);
+  uint32_t c1[3], c2[5];                     // c_i = floor(k g_i / 2^256)
+#pragma unroll
+  for (int i = 0; i < 3; i++) c1[i] = p1[8 + i];
+#pragma unroll
+  for (int i = 0; i < 5; i++) c2[i] = p2[8 + i];
+  uint32_t t1[5], t2[9], u1[7], u2[7];
+  limbs_mul<3, 2>(c1, a1, t1);               // c1 a1
+  limbs_mul<5, 4>(c2, a2, t2);               // c2 a2   (< 2^256)
+  limbs_mul<3, 4>(c1, nb1, u1);              // c1 |b1|
+  limbs_mul<5, 2>(c2, b2, u2);               // c2 b2
+  // k1 = k - c1 a1 - c2 a2, k2 = c1 |b1| - c2 b2: small signed values, exact in 256-bit two's complement
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k1[i] = subb32(kk[i], i < 5 ? t1[i] : 0u, borrow);
+  borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k1[i] = subb32(k1[i], t2[i], borrow);
+  borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k2[i] = subb32(i < 7 ? u1[i] : 0u, i < 7 ? u2[i] : 0u, borrow);
+  neg1 = limbs_abs8(k1);
+  neg2 = limbs_abs8(k2);
+}
+RB_FN Jac<Fp> jac_mul_glv_g1(const Aff<Fp>& base, const uint32_t k[8]) {
+  Jac<Fp> acc = jac_inf<Fp>();
+  if (aff_is_inf(base)) return acc;
+  uint32_t k1[8], k2[8];
+  bool neg1, neg2;
+  glv_decompose(k, k1, neg1, k2, neg2);
+  uint32_t p1[8], n1[8], p2[8], n2[8];
+  naf_masks(k1, p1, n1);
+  naf_masks(k2, p2, n2);
+  constexpr uint32_t BETA[8] = RB_GLV_BETA;
+  Fp beta;
+#pragma unroll
+  for (int i = 0; i < 8; i++) beta.v[i] = BETA[i];
+  Aff<Fp> b1 = base, b2{mul(base.x, beta), base.y};
+  if (neg1) b1.y = neg(b1.y);
+  if (neg2) b2.y = neg(b2.y);
+  bool started = false;
+  for (int w = 4; w >= 0; w--) {             // |k1|, |k2| < 2^130: NAF digits up to bit 130
+    const uint32_t pw1 = word_sel8(p1, w), nw1 = word_sel8(n1, w), pw2 = word_sel8(p2, w), nw2 = word_sel8(n2, w);
+    if (!started && !(pw1 | nw1 | pw2 | nw2)) continue;
+    for (int b = 31; b >= 0; b--) {
+      if (started) acc = g1_dbl_inl(acc);
+      const uint32_t d1p = (pw1 >> b) & 1u, d1n = (nw1 >> b) & 1u, d2p = (pw2 >> b) & 1u, d2n = (nw2 >> b) & 1u;
+      if (d1p | d1n) {
+        Aff<Fp> q = b1;
+        if (d1n) q.y = neg(q.y);
+        acc = g1_madd_inl(acc, q);           // handles acc = infinity and the doubling / cancelling cases
+        started = true;
+      }
+      if (d2p | d2n) {
+        Aff<Fp> q = b2;
+        if (d2n) q.y = neg(q.y);
+        acc = g1_madd_inl(acc, q);
+        started = true;
+      }
+    }
+  }
+  return acc;
+}
+// Which one where (measured): the decrypt kernels scale by Lagrange coefficients, which for the gates the benchmarks use are
+// signed binomials (<= 97 bits at 100 leaves, <= 196 at 200) -- the plain chain skips their leading zeros and GLV, whose halves are
+// ~127 bits whatever the size of k, gains nothing there (k_bsw_dec_pairs 27.7 ms either way, k_lsw_dec_pairs 27.5 vs 26.9 ms).
+// GLV serves `rhip_g1_mul` (uniform 254-bit scalars: 1.8 k instead of 3.2 k Fp multiplications for the binary chain).
+template <class F> RB_HD Jac<F> jac_mul_naf(const Aff<F>& base, const uint32_t k[8]) { return jac_mul_naf_plain(base, k); }
+
 // Multi-scalar multiplication  sum_j k_j * P_j  with the doublings shared (Straus over the NAFs of the k_j):
 // 254 doublings for the whole sum + ~85 mixed additions per term, instead of a full multiplication per term.
 // TERMS provides  int count() const;  Aff<F> base(int j) const;  uint32_t pos_word(int j, int w) / neg_word(int j, int w) const
@@ -285,7 +424,7 @@ RB_FN Jac<F> jac_msm_naf(TERMS terms) {
   bool started = false;
   for (int w = 7; w >= 0; w--) {
     for (int b = 31; b >= 0; b--) {
-      if (started) acc = jac_dbl(acc);
+      if (started) acc = jac_dbl_fast(acc);
       for (int j = 0; j < n; j++) {
         const uint32_t pw = terms.pos_word(j, w), nw = terms.neg_word(j, w);
         const uint32_t pb = (pw >> b) & 1u, nb = (nw >> b) & 1u;

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_g1_mul(size_t n, const rhi
   if (i >= n) return;
   uint32_t kk[8];
   ld_scalar(kk, k + i);
-  store_g1(out[i].l, jac_to_aff(jac_mul_binary(load_g1(p[i].l), kk)));
+  store_g1(out[i].l, jac_to_aff(jac_mul_glv_g1(load_g1(p[i].l), kk)));      // any 256-bit k (curve.h)
 }
 __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_on_curve(size_t n, const rhip_g1* p, uint32_t* ok) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -164,8 +164,17 @@ void hs_pairing_pair_parked(const uint32_t* pa, const uint32_t* qa, const uint32
 }
 
 void hs_g1_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_naf(load_g1(p), k))); }
+void hs_g1_mul_glv(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_glv_g1(load_g1(p), k))); }
 void hs_g2_mul_naf(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g2(out, jac_to_aff(jac_mul_naf(load_g2(p), k))); }
 }
+// GLV decomposition (bn254/curve.h): out = |k1| (8 words), |k2| (8 words), sign of k1, sign of k2
+extern "C" void hs_glv_decompose(const uint32_t* k, uint32_t* out) {
+  bool n1, n2;
+  glv_decompose(k, out, n1, out + 8, n2);
+  out[16] = n1 ? 1u : 0u;
+  out[17] = n2 ? 1u : 0u;
+}
+extern "C" void hs_g1_mul_naf_plain(const uint32_t* p, const uint32_t* k, uint32_t* out) { store_g1(out, jac_to_aff(jac_mul_naf_plain(load_g1(p), k))); }
 // the carry-capture plan the device multiplication uses (bn254/fp.h: ColumnPlan): field 0 = Fp, 1 = Fr; kind 0 = a bare
 // reduction (redc2), 1 = a full product of two reduced operands.  out: safe[16], then last_safe.
 extern "C" void hs_column_plan(int field, int kind, uint16_t* out) {

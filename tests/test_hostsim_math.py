@@ -235,6 +235,34 @@ def test_naf_scalar_multiplication_equals_oracle():
     assert call("hs_g1_mul_naf", bytes(64), le(5), out=64) == bytes(64)
 
 
+def test_glv_decomposition_and_multiplication():
+    """curve.h: glv_decompose / jac_mul_glv_g1 -- k = k1 + k2 lambda (mod r) with short k1, k2, and the same point as the plain chain"""
+    import re
+    text = open("rabe_amd/csrc/bn254/constants.h").read()
+    lam = sum(int(x.rstrip("u"), 16) << (32 * i) for i, x in enumerate(re.search(r"RB_GLV_LAMBDA \{([^}]*)\}", text).group(1).replace(" ", "").split(",")))
+    beta_m = sum(int(x.rstrip("u"), 16) << (32 * i) for i, x in enumerate(re.search(r"RB_GLV_BETA \{([^}]*)\}", text).group(1).replace(" ", "").split(",")))
+    beta = beta_m * pow(1 << 256, -1, bn.P) % bn.P
+    assert pow(lam, 3, bn.R) == 1 and lam != 1 and pow(beta, 3, bn.P) == 1 and beta != 1
+    p = bn.g1_mul(bn.G1_GEN, RND.randrange(1, bn.R))
+    assert (beta * p[0] % bn.P, p[1]) == bn.g1_mul(p, lam)                    # phi = [lambda]
+    ks = [0, 1, 2, 3, lam, lam - 1, lam + 1, bn.R - 1, bn.R - 2, bn.R, bn.R + 5, (1 << 256) - 1, 1 << 255, (1 << 254) - 1, (bn.R - 1) // 2,
+          int("a" * 63, 16), int("5" * 64, 16), (1 << 128) - 1, 1 << 128, (1 << 127) + 12345] + [RND.randrange(bn.R) for _ in range(60)]
+    for k in ks:
+        o = buf(72)
+        HS.hs_glv_decompose(b2c(le(k)), o)
+        w = list(o)
+        k1 = sum(x << (32 * i) for i, x in enumerate(w[:8])) * (-1 if w[16] else 1)
+        k2 = sum(x << (32 * i) for i, x in enumerate(w[8:16])) * (-1 if w[17] else 1)
+        assert (k1 + k2 * lam - k) % bn.R == 0, hex(k)
+        assert abs(k1) < 1 << 130 and abs(k2) < 1 << 130, (hex(k), k1.bit_length(), k2.bit_length())
+        if k < 1 << 60:
+            assert (k1, k2) == (k, 0)
+        want = bn.g1_to_le(bn.g1_mul(p, k % bn.R))
+        assert call("hs_g1_mul_glv", bn.g1_to_le(p), le(k), out=64) == want, hex(k)
+    for k in [x for x in ks[:20] if x < bn.R]:            # the plain chain takes canonical scalars only (3k must fit 256 bits)
+        assert call("hs_g1_mul_naf_plain", bn.g1_to_le(p), le(k), out=64) == bn.g1_to_le(bn.g1_mul(p, k % bn.R)), hex(k)
+
+
 def test_shared_doubling_msm_equals_sum_of_products():
     """jac_msm_naf (curve.h): Straus over the NAFs -- lsw's sum of c_y * D1_y, aw11's sum of c_x * C3_x"""
     n = 7
