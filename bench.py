@@ -74,8 +74,7 @@ def parse_args():
     ap.add_argument("--group", type=int, default=16, help="steps submitted as ONE launch set (their batches are contiguous in HBM)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="groups in flight on separate HIP streams; 0 = the config's default (configs 2-4: 1 -- every launch fills the chip and "
-                         "two groups' kernels only disturb each other, config 2: 1.13 M vs 1.02 M ops/s; 2 for config 5, whose launches are smaller, and whenever "
-                         "--steps leaves a partial last group)")
+                         "two groups' kernels only disturb each other, config 2: 1.13 M vs 1.02 M ops/s; config 5: 2, its launches are smaller)")
     ap.add_argument("--min-time", type=float, default=1.0,
                     help="the K-step timed region is repeated until this many seconds have been timed; every region times exactly --steps steps")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for experiments (0 = leave the HIP default)")
@@ -93,9 +92,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="items for the CPU baseline (0 = auto)")
     args = ap.parse_args()
     if args.inflight <= 0:
-        # full groups fill the chip on their own; a partial last group (--steps not a multiple of --group, e.g. the driver's 20)
-        # leaves SIMDs idle in its Miller / final-exponentiation rounds, which a second stream's kernels can use (974 k vs 934 k ops/s)
-        args.inflight = 2 if (args.config == 5 or args.steps % max(1, args.group)) else 1
+        args.inflight = 2 if args.config == 5 else 1
     return args
 
 
@@ -224,6 +221,9 @@ def main():
     # ---------------------------------------------------------------- the groups: up to G steps' batches contiguous in HBM
     B = args.batch
     sizes = split_steps(args.steps, max(1, min(args.group, args.steps)))
+    if os.environ.get("RABE_BENCH_SPLIT"):           # experiments: explicit group sizes, e.g. 16,4
+        sizes = [int(x) for x in os.environ["RABE_BENCH_SPLIT"].split(",")]
+        assert sum(sizes) == args.steps
     G = max(sizes)
     GB = G * B
     item_pol = [i % args.policies for i in range(GB)]
