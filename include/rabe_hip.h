@@ -347,7 +347,9 @@ int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
 /* ---- Level B: AW11 multi-authority CP-ABE (src/schemes/aw11/mod.rs) -----------------------------------------------
  * rhip_aw11_pk: gk (g1, g2), the constant e(g1, g2) and, for each of the n_attrs attributes of the authorities in play,
  * (egg_alpha_x, g2 * y_x) (Aw11PublicKey.attr, :56-61) as window tables.  leaf_attr[leaf] (per policy leaf, beside the
- * flattened tree tables) = the attribute's index in those arrays. */
+ * flattened tree tables) = the attribute's index in those arrays.  The per-attribute tables are 8-bit windows (4.2 MB per
+ * attribute) and, when the device has the room plus 48 GB to spare, 16-bit windows as well (536 MB per attribute, 107 GB for
+ * 200: half the table entries per power; environment RABE_AW11_ATTR_W16=0 / =1 forces the choice).  Results do not depend on it. */
 typedef struct rhip_aw11_pk rhip_aw11_pk;
 int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, size_t n_attrs,
                             const rhip_gt* host_egg_alpha /*[n_attrs]*/, const rhip_g2* host_g2_y /*[n_attrs]*/, rhip_aw11_pk** out);

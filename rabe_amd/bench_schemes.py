@@ -688,7 +688,10 @@ class Aw11Bench:
                             "encrypt+decrypt per GPU" % (self.n_auth, self.n_attr // self.n_auth, tree, self.n_attr, len(self.trees), self.B),
                 "attrs": self.n_attr, "authorities": self.n_auth, "policies": len(self.trees), "tree": tree, "pruned_leaves_avg": round(m, 2),
                 "pairings_per_item": round(m + 1, 1), "reference_pairings_per_item": round(2 * m + m + 1, 1),
-                "table_build_ms_per_public_key_set": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
+                "table_build_ms_per_public_key_set": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3),
+                "attribute_tables": "16-bit windows for the %d per-attribute bases (%.0f GB; RABE_AW11_ATTR_W16=0: 8-bit, 0.8 GB) when the device has the "
+                                    "room -- 16 instead of 32 table entries per power" % (2 * self.n_attr, self.n_attr * 16 * 65535 * 512 / 1e9)
+                if os.environ.get("RABE_AW11_ATTR_W16", "1") != "0" else "8-bit windows for the per-attribute bases (RABE_AW11_ATTR_W16=0)"}
 
     def algorithmic_fpmul_per_item(self):
         # enc 201 fixed-base Gt pow (0.34 MM) + 200 var-base Gt pow (1.6 MM) + 400 fixed-base + 200 var-base G2 (2.1 MM);

@@ -1298,6 +1298,17 @@ extern "C" int32_t rhip_gt_table_add_w16(rhip_ctx* ctx, rhip_gt_table* t) {
   t->dev16 = d16;
   return RHIP_OK;
 }
+// 16-bit-window tables from 8-bit ones at caller-provided addresses (engine_jobs.hip: AW11's per-attribute tables)
+int32_t rhip_build_w16_gt(rhip_ctx* ctx, const GtM* t8, GtM* t16) {
+  const size_t n = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  KLAUNCH(ctx, "k_table_build_gt_w16", k_table_build_gt_w16, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, t8, t16);
+  return RHIP_OK;
+}
+int32_t rhip_build_w16_g2(rhip_ctx* ctx, const G2M* t8, G2M* t16) {
+  const size_t n = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  KLAUNCH(ctx, "k_table_build_g2_w16", k_table_build_g2_w16, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, t8, t16);
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_g1_table_mul(rhip_ctx* ctx, const rhip_g1_table* t, size_t n, const rhip_fr* k, rhip_g1* out) {
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;

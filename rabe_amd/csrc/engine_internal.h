@@ -196,6 +196,9 @@ struct DevWs {
   __device__ __forceinline__ LdsHome home() const { return LdsHome{}; }
 };
 struct GtM;
+int32_t rhip_build_w16_gt(rhip_ctx* ctx, const GtM* t8, GtM* t16);
+struct G2M;
+int32_t rhip_build_w16_g2(rhip_ctx* ctx, const G2M* t8, G2M* t16);
 int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
                               rhip_gt* out);
 #define launch_final_exp rhip_launch_final_exp

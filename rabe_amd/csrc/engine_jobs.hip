@@ -702,6 +702,10 @@ struct rhip_aw11_pk {
   size_t n_attrs;
   GtM* attr_gt;       // [n_attrs][32][255]
   G2M* attr_g2;       // [n_attrs][32][255]
+  // 16-bit windows of the same bases, [n_attrs][16][65535] (402 + 134 MB per attribute: 107 GB for 200 attributes -- memory traded
+  // for work on a 288 GB part: 16 instead of 32 table entries per power).  Built when the device has the room (rhip_aw11_pk_create).
+  GtM* attr_gt16;
+  G2M* attr_g216;
 };
 extern "C" void rhip_aw11_pk_destroy(rhip_aw11_pk* pk) {
   if (!pk) return;
@@ -709,6 +713,8 @@ extern "C" void rhip_aw11_pk_destroy(rhip_aw11_pk* pk) {
   rhip_gt_table_destroy(pk->E);
   if (pk->attr_gt) (void)hipFree(pk->attr_gt);
   if (pk->attr_g2) (void)hipFree(pk->attr_g2);
+  if (pk->attr_gt16) (void)hipFree(pk->attr_gt16);
+  if (pk->attr_g216) (void)hipFree(pk->attr_g216);
   delete pk;
 }
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_attr_tables_gt(size_t n_attrs, const rhip_gt* base, GtM* tbl) {
@@ -737,7 +743,7 @@ extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const r
                                        const rhip_g2* host_g2_y, rhip_aw11_pk** out) {
   if (!ctx || !g1 || !g2 || !n_attrs || !host_egg_alpha || !host_g2_y || !out) return RHIP_ERR_ARG;
   *out = nullptr;
-  rhip_aw11_pk* pk = new rhip_aw11_pk{ctx, nullptr, nullptr, n_attrs, nullptr, nullptr};
+  rhip_aw11_pk* pk = new rhip_aw11_pk{ctx, nullptr, nullptr, n_attrs, nullptr, nullptr, nullptr, nullptr};
   rhip_gt e;
   int32_t rc = rhip_host_pairing(ctx, g1, g2, &e);
   if (!rc) rc = rhip_g2_table_create(ctx, g2, &pk->g2);
@@ -763,6 +769,31 @@ extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const r
   if (dgt) (void)hipFree(dgt);
   if (dg2) (void)hipFree(dg2);
   if (he != hipSuccess) { rhip_aw11_pk_destroy(pk); return fail(ctx, he, "rhip_aw11_pk_create"); }
+  // 16-bit windows per attribute when the device has the room for them and 48 GB to spare (RABE_AW11_ATTR_W16=0 / =1 forces the choice)
+  const size_t per16 = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
+  const size_t need = n_attrs * per16 * (sizeof(GtM) + sizeof(G2M));
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const char* env = getenv("RABE_AW11_ATTR_W16");
+  const bool want = env ? (env[0] == '1') : (free_b > need + ((size_t)48 << 30));
+  if (want) {
+    he = hipMalloc((void**)&pk->attr_gt16, n_attrs * per16 * sizeof(GtM));
+    if (he == hipSuccess) he = hipMalloc((void**)&pk->attr_g216, n_attrs * per16 * sizeof(G2M));
+    if (he == hipSuccess) {
+      for (size_t a = 0; a < n_attrs && !rc; a++) {
+        rc = rhip_build_w16_gt(ctx, pk->attr_gt + a * per, pk->attr_gt16 + a * per16);
+        if (!rc) rc = rhip_build_w16_g2(ctx, pk->attr_g2 + a * per, pk->attr_g216 + a * per16);
+      }
+      if (!rc) he = hipStreamSynchronize(ctx->stream);
+    }
+    if (he != hipSuccess || rc) {                    // no room after all: the 8-bit tables serve
+      (void)hipGetLastError();
+      if (pk->attr_gt16) (void)hipFree(pk->attr_gt16);
+      if (pk->attr_g216) (void)hipFree(pk->attr_g216);
+      pk->attr_gt16 = nullptr;
+      pk->attr_g216 = nullptr;
+    }
+  }
   *out = pk;
   return RHIP_OK;
 }
@@ -783,7 +814,7 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_aw11_enc_scalars(size_t n
 // C1[row] = E^lambda * egg_alpha_x^r   (:272-274)
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
                                                                  const uint32_t* leaf_attr, const GtM* e_tbl, int e_w16, const GtM* attr_tbl,
-                                                                 const rhip_fr* lam, const rhip_fr* rand, rhip_gt* c1) {
+                                                                 int attr_w16, const rhip_fr* lam, const rhip_fr* rand, rhip_gt* c1) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_rows) return;
   const size_t item = owner_of(item_row_off, n_items, t);
@@ -793,13 +824,14 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_r
   ld_scalar(kr, rand + t);
   bool started = false;       // E^lambda * egg_alpha_x^r as ONE running product on the lane's home value
   if (e_w16) home_table_pow_gt_w16(started, e_tbl, kl); else home_table_pow_gt(started, e_tbl, kl);
-  home_table_pow_gt(started, attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
+  if (attr_w16) home_table_pow_gt_w16(started, attr_tbl + (size_t)a * TBL16_WINDOWS * TBL16_DIGITS, kr);
+  else home_table_pow_gt(started, attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
   store_gt(c1[t].l, home_result(started));
 }
 // C3[row] = (g2*y_x) * r + g2 * omega   (:275-277): two fixed-base sums on one accumulator
 __global__ void __launch_bounds__(128, RB_G2_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
-                                                                  const uint32_t* leaf_attr, const G2M* g2_tbl8, const G2M* attr_tbl, const rhip_fr* omg,
-                                                                  const rhip_fr* rand, rhip_g2* c3) {
+                                                                  const uint32_t* leaf_attr, const G2M* g2_tbl, const G2M* attr_tbl, int w16,
+                                                                  const rhip_fr* omg, const rhip_fr* rand, rhip_g2* c3) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = t < total_rows;
@@ -809,13 +841,24 @@ __global__ void __launch_bounds__(128, RB_G2_WAVES) k_aw11_enc_c3(size_t total_r
   uint32_t kr[8], kw[8];
   ld_scalar(kr, rand + t);
   ld_scalar(kw, omg + t);
-  const G2M* ta = attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS;
   G2Jac acc = jac_inf<Fp2>();
+  if (w16) {             // both tables with 16-bit windows: 2 x 16 entries
+    const G2M* ta = attr_tbl + (size_t)a * TBL16_WINDOWS * TBL16_DIGITS;
 #pragma unroll 1
-  for (int w = 0; w < 2 * TBL_WINDOWS; w++) {
-    const int ww = w & (TBL_WINDOWS - 1);
-    const uint32_t d = scalar_byte(w < TBL_WINDOWS ? kr : kw, ww);
-    if (d) acc = jac_add_aff(acc, ld_g2_m((w < TBL_WINDOWS ? ta : g2_tbl8) + ww * TBL_DIGITS + (d - 1)));
+    for (int w = 0; w < 2 * TBL16_WINDOWS; w++) {
+      const int ww = w & (TBL16_WINDOWS - 1);
+      const uint32_t word = word_sel8(w < TBL16_WINDOWS ? kr : kw, ww >> 1);
+      const uint32_t d = (ww & 1) ? (word >> 16) : (word & 0xffffu);
+      if (d) acc = jac_add_aff(acc, ld_g2_m((w < TBL16_WINDOWS ? ta : g2_tbl) + (size_t)ww * TBL16_DIGITS + (d - 1)));
+    }
+  } else {
+    const G2M* ta = attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS;
+#pragma unroll 1
+    for (int w = 0; w < 2 * TBL_WINDOWS; w++) {
+      const int ww = w & (TBL_WINDOWS - 1);
+      const uint32_t d = scalar_byte(w < TBL_WINDOWS ? kr : kw, ww);
+      if (d) acc = jac_add_aff(acc, ld_g2_m((w < TBL_WINDOWS ? ta : g2_tbl) + ww * TBL_DIGITS + (d - 1)));
+    }
   }
   store_g2_block128(lds, active, c3 + t, acc);
 }
@@ -841,12 +884,13 @@ extern "C" int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk
   KLAUNCH(ctx, "k_aw11_enc_scalars", k_aw11_enc_scalars, dim3(blocks_for(total_rows, 256)), dim3(256), 0, ctx->stream, n_items, total_rows, item_row_off,
           item_tree_leaf, item_tree_gate, item_n_coef, tt, s, coef, item_coef_off, lam, omg);
   KLAUNCH(ctx, "k_aw11_enc_c1", k_aw11_enc_c1, dim3(blocks_for(total_rows, 64)), dim3(64), 0, ctx->stream, total_rows, item_row_off, n_items,
-          item_tree_leaf, leaf_attr, (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0, (const GtM*)pk->attr_gt, (const rhip_fr*)lam,
-          rand, c1);
+          item_tree_leaf, leaf_attr, (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0,
+          (const GtM*)(pk->attr_gt16 ? pk->attr_gt16 : pk->attr_gt), pk->attr_gt16 ? 1 : 0, (const rhip_fr*)lam, rand, c1);
   rc = rhip_g2_table_mul(ctx, pk->g2, total_rows, rand, c2);
   if (rc) return rc;
   KLAUNCH(ctx, "k_aw11_enc_c3", k_aw11_enc_c3, dim3(blocks_for(total_rows, 128)), dim3(128), 0, ctx->stream, total_rows, item_row_off, n_items,
-          item_tree_leaf, leaf_attr, (const G2M*)pk->g2->dev, (const G2M*)pk->attr_g2, (const rhip_fr*)omg, rand, c3);
+          item_tree_leaf, leaf_attr, (const G2M*)(pk->attr_g216 && pk->g2->dev16 ? pk->g2->dev16 : pk->g2->dev),
+          (const G2M*)(pk->attr_g216 && pk->g2->dev16 ? pk->attr_g216 : pk->attr_g2), (pk->attr_g216 && pk->g2->dev16) ? 1 : 0, (const rhip_fr*)omg, rand, c3);
   return RHIP_OK;
 }
 // decrypt (aw11/mod.rs:298-366 restated in SURVEY.md Appendix B.5): item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 1:
