@@ -137,11 +137,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    n_dev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl (= RCCL) on the GPUs; RABE_DIST_BACKEND=gloo lets several ranks share one GPU for a functional check
-        dist.init_process_group(backend=os.environ.get("RABE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+        # nccl (= RCCL) with one rank per GPU.  With fewer GPUs than local ranks (a launcher started more ranks than the box has
+        # devices: a functional check) the ranks share devices and rendezvous over gloo -- RCCL refuses two ranks on one device.
+        shared = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > n_dev
+        dist.init_process_group(backend=os.environ.get("RABE_DIST_BACKEND", "gloo" if shared else "nccl"), rank=rank, world_size=world)
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     if args.config != 2:
         from rabe_amd import bench_schemes
