@@ -565,7 +565,7 @@ template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) {      // fp12_inv
 }
 // dst = a^(2^n) * (b >= 0 ? b (conjugated if conj_b) : 1): the run of cyclotomic squarings stays in registers (a squaring
 // needs few temporaries), the multiplication that ends it works on the home copy
-template <class WS> RB_FN void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b, bool conj_b) {
+template <class WS> RB_MID void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b, bool conj_b) {
   Fp12 x = ws.ld(a);
 #pragma unroll 1
   for (int i = 0; i < n; i++) x = fp12_cyclotomic_sqr(x);
