@@ -93,3 +93,14 @@ def test_gt_mul_inv_on_extreme_limbs(eng):
         except Exception:
             continue                                                       # not invertible
         assert g == bn.gt_to_le(want_inv)
+
+
+def test_g1_mul_glv_on_extreme_scalars(eng):
+    """`rhip_g1_mul` runs the GLV chain (curve.h: jac_mul_glv_g1): any 256-bit scalar, also >= r, gives k mod r times the point"""
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    p = bn.g1_mul(bn.G1_GEN, RND.randrange(1, bn.R))
+    ks = [0, 1, 2, lam, lam + 1, lam - 1, bn.R - 1, bn.R, bn.R + 5, (1 << 256) - 1, 1 << 255, (1 << 254) - 1, (1 << 128) - 1, 1 << 128, 1 << 127,
+          int("a" * 64, 16), int("5" * 64, 16)] + [RND.randrange(1 << 256) for _ in range(40)]
+    got = eng.g1_mul([bn.g1_to_le(p)] * len(ks), [le(k) for k in ks])
+    assert got == [bn.g1_to_le(bn.g1_mul(p, k % bn.R)) for k in ks]
+    assert eng.g1_mul([bytes(64)], [le(7)]) == [bytes(64)]
