@@ -38,8 +38,9 @@ const char* rabe_host_last_error(rabe_host* h);          /* h may be NULL: error
  * draw order, instead of the OS generator.  n = 0 switches back to OS randomness. */
 int32_t rabe_host_set_tape(rabe_host* h, const uint8_t* fr_le32, size_t n);
 
-/* G*Fr / Gt^Fr calls in which at least n elements share one base are served from a cached fixed-base window table
- * (default 4096; Gt: twice that); the results do not depend on it.  Tests set 1 / SIZE_MAX to force either path. */
+/* G*Fr / Gt^Fr elements that share one base are served from a cached fixed-base window table once n of them have been seen,
+ * in one call or accumulated over calls (default 1024); the results do not depend on it.  Tests set 1 / SIZE_MAX to force
+ * either path. */
 int32_t rabe_host_set_fixed_base_min(rabe_host* h, size_t n);
 
 void rabe_obj_free(int32_t kind, void* obj);

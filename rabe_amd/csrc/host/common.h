@@ -134,7 +134,8 @@ class Engine {
   // 8 160 variable-base multiplications, so it pays for itself from a few thousand elements per base on (Gt: more).
   // device tables of AC17 public keys (g, h_a[3], e_gh_ka[2]; ~1.3 GB each with the 16-bit windows), built on first use
   rhip_ac17_pk* ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka);
-  size_t fixed_base_min = 4096;   // G1 / G2 elements sharing one base in one call; Gt uses twice that
+  size_t fixed_base_min = 1024;   // elements sharing one base, in one call or accumulated over calls, before it gets a window table
+  std::map<std::string, size_t> seen_[3];   // uses so far of the heavier bases (G1, G2, Gt)
   // grow-only pinned host staging buffers (slot 0..3) for the packed batch entry points: PCIe copies at full rate
   uint8_t* pinned(int slot, size_t bytes);
   // window table of the Gt generator e(G1::one(), G2::one()) (random Gt messages of a batch in one launch, on device)

@@ -141,18 +141,38 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
   std::unordered_map<Key, uint32_t, KeyHash, KeyEq> count;
   count.reserve(n);
   for (size_t i = 0; i < n; i++) count[Key{p[i].data()}]++;
-  // bases that repeat often enough, or already have a table, leave the generic path
-  const size_t need = (N == 384 && fixed_base_min > 1) ? 2 * fixed_base_min : fixed_base_min;
+  // bases that repeat often enough -- in this call or over the calls so far (a server meets the same public-key elements again
+  // and again) -- or already have a table, leave the generic path
+  const size_t need = fixed_base_min;
   std::unordered_map<Key, size_t, KeyHash, KeyEq> slot;       // base -> index into `lists`
   std::vector<std::vector<size_t>> lists;
-  for (auto& g : count)
-    if (g.second >= need) { slot[g.first] = lists.size(); lists.emplace_back(); }
+  std::map<std::string, size_t>& seen = seen_[N == 64 ? 0 : N == 128 ? 1 : 2];
+  if (seen.size() > 65536) seen.clear();
+  for (auto& g : count) {
+    size_t total = g.second;
+    if (g.second >= 16 && need > 1 && need != (size_t)-1) {   // only bases with some weight are remembered
+      size_t& acc = seen[std::string((const char*)g.first.b, N)];
+      acc += g.second;
+      total = acc;
+    }
+    if (total >= need) { slot[g.first] = lists.size(); lists.emplace_back(); }
+  }
+  // every table group is a launch of its own: a call with hundreds of medium-sized groups (aw11: 2 x 200 attribute bases, 1024 uses
+  // each) is better served by ONE generic launch -- then only groups that are big in this very call keep their table
+  if (slot.size() > 16 && need > 1) {
+    std::unordered_map<Key, size_t, KeyHash, KeyEq> keep;
+    lists.clear();
+    for (auto& g : count)
+      if (slot.count(g.first) && g.second >= 4096) { keep[g.first] = lists.size(); lists.emplace_back(); }
+    slot.swap(keep);
+  }
   std::vector<std::string> cached_keys;                        // keeps the Key pointers below alive
   cached_keys.reserve(cache.size());
   for (auto& c : cache) cached_keys.push_back(c.first);
   for (auto& ck : cached_keys) {
     Key k2{(const uint8_t*)ck.data()};
-    if (count.count(k2) && !slot.count(k2)) { slot[k2] = lists.size(); lists.emplace_back(); }
+    auto it = count.find(k2);
+    if (it != count.end() && !slot.count(k2) && (slot.size() < 16 || it->second >= 4096)) { slot[k2] = lists.size(); lists.emplace_back(); }
   }
   // pass 2: distribute
   std::vector<size_t> rest;
@@ -174,7 +194,7 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
     const std::string key((const char*)p[idx[0]].data(), N);
     const bool cached = cache.count(key) != 0;
     if (!cached) {
-      if (cache.size() >= 64) {                       // bounded: drop everything rather than track recency
+      if (cache.size() >= 1024) {                     // bounded: drop everything rather than track recency
         for (auto& c : cache) this->destroy_table(c.second);
         cache.clear();
       }
@@ -1341,6 +1361,7 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
                 std::vector<Fr> k2; };
   std::vector<Item> items(n);
   PolicyMemo memo;
+  StageTimer tm("bsw::encrypt_batch");
   for (size_t i = 0; i < n; i++) {              // sequential: the generator is consumed in encrypt's order
     Item& it = items[i];
     it.secret = rng.next_fr();
@@ -1351,12 +1372,14 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
     rng.fill(it.nonce.data(), 12);
     cts[i].policy = {policies[i], language};
   }
+  tm.lap("draws (sequential)");
   parallel_for(n, [&](size_t i) {               // parallel: shares and label hashes
     Item& it = items[i];
     VecFrSource src(it.draws.data(), it.draws.size());
     gen_shares_policy(it.secret, *it.tree, src, &it.shares);
     for (const auto& sh : it.shares) it.k2.push_back(fr_mul(sha3_hash_fr(remove_index(sh.first)), sh.second));
   });
+  tm.lap("shares (parallel)");
   std::vector<G1> b1; std::vector<Fr> k1;
   std::vector<G2> b2; std::vector<Fr> k2;
   std::vector<Gt> bt; std::vector<Fr> kt;
@@ -1373,12 +1396,17 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
     }
   }
   if (!n) return cts;
+  tm.lap("concat");
   std::vector<G1> r1 = eng.g1_mul(b1, k1);
+  tm.lap("g1_mul");
   std::vector<G2> r2 = b2.empty() ? std::vector<G2>() : eng.g2_mul(b2, k2);
+  tm.lap("g2_mul");
   std::vector<Gt> rt = eng.gt_pow(bt, kt);
+  tm.lap("gt_pow");
   std::vector<Gt> ea, msg;
   for (size_t i = 0; i < n; i++) { ea.push_back(rt[2 * i]); msg.push_back(rt[2 * i + 1]); }
   std::vector<Gt> cp = eng.gt_mul(ea, msg);
+  tm.lap("gt_mul");
   for (size_t i = 0; i < n; i++) {
     cts[i].c = r1[items[i].o1];
     cts[i].c_p = cp[i];
@@ -1386,6 +1414,7 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
       cts[i].c_y.push_back({items[i].shares[y].first, r1[items[i].o1 + 1 + y], r2[items[i].o2 + y]});
     cts[i].data = encrypt_symmetric(msg[i].data(), plaintexts[i].data(), plaintexts[i].size(), items[i].nonce.data());
   }
+  tm.lap("assemble");
   return cts;
 }
 }  // namespace bsw
