@@ -19,7 +19,6 @@ ap.add_argument("--rounds", type=int, default=2, help="timed repetitions per con
 args = ap.parse_args()
 B = args.batch
 PT = b"dance like no one's watching, encrypt like everyone is!"
-ap2 = None
 host = hl.Host(0)
 if os.environ.get("RABE_FIXED_BASE_MIN"):
     host.set_fixed_base_min(int(os.environ["RABE_FIXED_BASE_MIN"]))
