@@ -10,7 +10,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rabe_amd import hostlib as hl  # noqa: E402
-from rabe_amd.schemes import aw11, bsw, ghw11, lsw  # noqa: E402
+from rabe_amd.schemes import aw11, bdabe, bsw, ghw11, lsw, mke08  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
@@ -105,4 +105,40 @@ if args.only in ("", "ghw11"):
     t1 = time.perf_counter()
     assert ghw11.decrypt_out(host, tcts[-1], rk, items[-1]) == PT
     report("8f-1: GHW11 transform (outsourced decryption), 50-attribute AND policy (52 pairings/item)", B, t1 - t0, {"transform_s": round(t1 - t0, 3)})
+
+if args.only in ("", "dnf"):
+    # 8f-4: the DNF schemes' decrypt (m + 3 pairings per item on one accumulator): a 3-conjunction policy, the key satisfies the last one
+    pol_dnf = ('{"name": "or", "children": [{"name": "and", "children": [{"name": "%s::A"}, {"name": "%s::Z"}]}, '
+               '{"name": "and", "children": [{"name": "%s::B"}, {"name": "%s::C"}, {"name": "%s::D"}]}]}')
+    pk, msk = bdabe.setup(host)
+    au = bdabe.authgen(host, pk, msk, "aa1")
+    uk = bdabe.keygen(host, pk, au, "u1")
+    names = ["aa1::" + x for x in "ABCDZ"]
+    pkas = [bdabe.request_attribute_pk(host, pk, au, n) for n in names]
+    for n in names[1:4]:
+        bdabe.request_attribute_sk(host, uk, au, n)
+    n_ct = min(B, 32)
+    cts = [bdabe.encrypt(host, pk, pkas, pol_dnf % (("aa1",) * 5), hl.JSON_POLICY, PT) for _ in range(n_ct)]
+    items = [cts[i % n_ct] for i in range(B)]
+    bdabe.decrypt_batch(host, [uk] * 2, items[:2])
+    t0 = time.perf_counter()
+    pts = bdabe.decrypt_batch(host, [uk] * B, items)
+    t1 = time.perf_counter()
+    assert pts == [PT] * B
+    report("8f-4: BDABE decrypt, 3-attribute conjunction (6 pairings/item)", B, t1 - t0, {"decrypt_s": round(t1 - t0, 3)})
+    pk, msk = mke08.setup(host)
+    uk = mke08.keygen(host, pk, msk, "user1")
+    au = mke08.authgen(host, "auth1")
+    names = ["auth1::" + x for x in "ABCDZ"]
+    pkas = [mke08.request_authority_pk(host, pk, n, au) for n in names]
+    for n in names[1:4]:
+        mke08.request_authority_sk(host, uk, n, au)
+    cts = [mke08.encrypt(host, pk, pkas, pol_dnf % (("auth1",) * 5), hl.JSON_POLICY, PT) for _ in range(n_ct)]
+    items = [cts[i % n_ct] for i in range(B)]
+    mke08.decrypt_batch(host, [uk] * 2, items[:2])
+    t0 = time.perf_counter()
+    pts = mke08.decrypt_batch(host, [uk] * B, items)
+    t1 = time.perf_counter()
+    assert pts == [PT] * B
+    report("8f-4: MKE08 decrypt, 3-attribute conjunction (6 pairings/item)", B, t1 - t0, {"decrypt_s": round(t1 - t0, 3)})
 host.close()
