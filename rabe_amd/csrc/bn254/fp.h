@@ -93,6 +93,99 @@ RB_HD Mont<M> one() {
   return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 carry chains.  hipcc pads every carry-dependent v_addc / v_subb with two wait states (LLVM's gfx940+ rule "VALU
+// writes SGPR/VCC -> VALU reads it"); with one wave per SIMD each pad costs ~6 cycles, which doubles the time of an add / sub
+// chain (tools/ubench_addc.hip: 113 vs 55 cycles per 9-instruction chain) -- ~15 % of a pairing kernel.  The hardware interlocks
+// the dependency itself: a chain without the pads runs at 6.1 cycles per instruction against ~4 for independent ones, and its
+// results are identical on 7.5e11 dependent instructions (same tool; the multiply-accumulate chains above have relied on the
+// same interlock since round 1).  So the 8-limb chains are written here as single asm statements.
+#define RB_CH8(first_, next_, lit_) \
+  first_ " %0, vcc, " lit_ "%8, %0\n\t" next_ " %1, vcc, " lit_ "%9, %1, vcc\n\t" next_ " %2, vcc, " lit_ "%10, %2, vcc\n\t" \
+  next_ " %3, vcc, " lit_ "%11, %3, vcc\n\t" next_ " %4, vcc, " lit_ "%12, %4, vcc\n\t" next_ " %5, vcc, " lit_ "%13, %5, vcc\n\t" \
+  next_ " %6, vcc, " lit_ "%14, %6, vcc\n\t" next_ " %7, vcc, " lit_ "%15, %7, vcc"
+// t += b  (8 limbs, carry out dropped: the callers' sums stay below 2^256)
+RB_HD void limbs_add8(uint32_t* t, const uint32_t* b) {
+  asm(RB_CH8("v_add_co_u32", "v_addc_co_u32", "")
+      : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+}
+// t <- t - mod if t >= mod, for t < 2*mod < 2^255 (so t itself never carries out of 256 bits)
+template <class M>
+RB_HD void cond_sub_mod(uint32_t* t, uint32_t /*hi: always 0*/) {
+  uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+  asm("v_subrev_co_u32 %8, vcc, %16, %0\n\tv_subbrev_co_u32 %9, vcc, %17, %1, vcc\n\tv_subbrev_co_u32 %10, vcc, %18, %2, vcc\n\t"
+      "v_subbrev_co_u32 %11, vcc, %19, %3, vcc\n\tv_subbrev_co_u32 %12, vcc, %20, %4, vcc\n\tv_subbrev_co_u32 %13, vcc, %21, %5, vcc\n\t"
+      "v_subbrev_co_u32 %14, vcc, %22, %6, vcc\n\tv_subbrev_co_u32 %15, vcc, %23, %7, vcc\n\t"
+      // borrow: t < mod, keep t
+      "v_cndmask_b32 %0, %8, %0, vcc\n\tv_cndmask_b32 %1, %9, %1, vcc\n\tv_cndmask_b32 %2, %10, %2, vcc\n\tv_cndmask_b32 %3, %11, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %12, %4, vcc\n\tv_cndmask_b32 %5, %13, %5, vcc\n\tv_cndmask_b32 %6, %14, %6, vcc\n\tv_cndmask_b32 %7, %15, %7, vcc"
+      : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "=&v"(d0), "=&v"(d1), "=&v"(d2),
+        "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+      // a carry-consuming VOP2 cannot also read a literal (one constant-bus operand on gfx9): limbs 1..7 sit in VGPRs
+      : "i"(M::mod(0)), "v"(M::mod(1)), "v"(M::mod(2)), "v"(M::mod(3)), "v"(M::mod(4)), "v"(M::mod(5)), "v"(M::mod(6)), "v"(M::mod(7))
+      : "vcc");
+}
+// a + b mod m: both < m < 2^254, so the sum needs no ninth limb
+template <class M>
+RB_HD Mont<M> add(const Mont<M>& a, const Mont<M>& b) {
+  uint32_t t[8], u[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { t[i] = a.v[i]; u[i] = b.v[i]; }
+  limbs_add8(t, u);
+  cond_sub_mod<M>(t, 0);
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+template <class M>
+RB_HD Mont<M> sub(const Mont<M>& a, const Mont<M>& b) {
+  uint32_t t0 = a.v[0], t1 = a.v[1], t2 = a.v[2], t3 = a.v[3], t4 = a.v[4], t5 = a.v[5], t6 = a.v[6], t7 = a.v[7], m;
+  // t = a - b; m = -(borrow)
+  asm("v_sub_co_u32 %0, vcc, %0, %9\n\tv_subb_co_u32 %1, vcc, %1, %10, vcc\n\tv_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\tv_subb_co_u32 %4, vcc, %4, %13, vcc\n\tv_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\tv_subb_co_u32 %7, vcc, %7, %16, vcc\n\tv_subb_co_u32_e64 %8, vcc, 0, 0, vcc"
+      : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "=&v"(m)
+      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]) : "vcc");
+  // add the modulus back when the subtraction wrapped: r = t + (mod & m)
+  uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+  asm("v_and_b32 %0, %17, %16\n\tv_and_b32 %1, %18, %16\n\tv_and_b32 %2, %19, %16\n\tv_and_b32 %3, %20, %16\n\t"
+      "v_and_b32 %4, %21, %16\n\tv_and_b32 %5, %22, %16\n\tv_and_b32 %6, %23, %16\n\tv_and_b32 %7, %24, %16\n\t"
+      "v_add_co_u32 %0, vcc, %0, %8\n\tv_addc_co_u32 %1, vcc, %1, %9, vcc\n\tv_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\tv_addc_co_u32 %4, vcc, %4, %12, vcc\n\tv_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\tv_addc_co_u32 %7, vcc, %7, %15, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "v"(m), "i"(M::mod(0)), "i"(M::mod(1)), "i"(M::mod(2)),
+        "i"(M::mod(3)), "i"(M::mod(4)), "i"(M::mod(5)), "i"(M::mod(6)), "i"(M::mod(7))
+      : "vcc");
+  Mont<M> r;
+  r.v[0] = r0; r.v[1] = r1; r.v[2] = r2; r.v[3] = r3; r.v[4] = r4; r.v[5] = r5; r.v[6] = r6; r.v[7] = r7;
+  return r;
+}
+template <class M>
+RB_HD Mont<M> neg(const Mont<M>& a) {
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) nz |= a.v[i];
+  const uint32_t m = nz ? 0xFFFFFFFFu : 0u;
+  // (mod & m) - a
+  uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+  asm("v_and_b32 %0, %17, %16\n\tv_and_b32 %1, %18, %16\n\tv_and_b32 %2, %19, %16\n\tv_and_b32 %3, %20, %16\n\t"
+      "v_and_b32 %4, %21, %16\n\tv_and_b32 %5, %22, %16\n\tv_and_b32 %6, %23, %16\n\tv_and_b32 %7, %24, %16\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %8\n\tv_subb_co_u32 %1, vcc, %1, %9, vcc\n\tv_subb_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %3, %11, vcc\n\tv_subb_co_u32 %4, vcc, %4, %12, vcc\n\tv_subb_co_u32 %5, vcc, %5, %13, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %6, %14, vcc\n\tv_subb_co_u32 %7, vcc, %7, %15, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(m), "i"(M::mod(0)),
+        "i"(M::mod(1)), "i"(M::mod(2)), "i"(M::mod(3)), "i"(M::mod(4)), "i"(M::mod(5)), "i"(M::mod(6)), "i"(M::mod(7))
+      : "vcc");
+  Mont<M> r;
+  r.v[0] = r0; r.v[1] = r1; r.v[2] = r2; r.v[3] = r3; r.v[4] = r4; r.v[5] = r5; r.v[6] = r6; r.v[7] = r7;
+  return r;
+}
+#undef RB_CH8
+#else
 // t <- t - mod if t >= mod, for t < 2*mod < 2^255 (so t itself never carries out of 256 bits)
 template <class M>
 RB_HD void cond_sub_mod(uint32_t* t, uint32_t hi) {
@@ -144,6 +237,7 @@ RB_HD Mont<M> neg(const Mont<M>& a) {
   for (int i = 0; i < 8; i++) r.v[i] = subb32(M::mod(i) & mask, a.v[i], borrow);
   return r;
 }
+#endif
 // 2a mod m: shift left by one, then one conditional subtraction
 template <class M>
 RB_HD Mont<M> dbl(const Mont<M>& a) {

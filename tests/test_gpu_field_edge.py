@@ -104,3 +104,18 @@ def test_g1_mul_glv_on_extreme_scalars(eng):
     got = eng.g1_mul([bn.g1_to_le(p)] * len(ks), [le(k) for k in ks])
     assert got == [bn.g1_to_le(bn.g1_mul(p, k % bn.R)) for k in ks]
     assert eng.g1_mul([bytes(64)], [le(7)]) == [bytes(64)]
+
+
+def test_fr_add_sub_neg_on_extreme_limbs(eng):
+    """the carry chains of add / sub / neg (fp.h: asm statements without the compiler's wait states) on saturated limb patterns"""
+    ms = mont_patterns(bn.R, 150)
+    xs = [canon(m, RINV_R, bn.R) for m in ms] + [0, 1, bn.R - 1, bn.R - 2, (bn.R - 1) // 2, (bn.R + 1) // 2]
+    a = [x for x in xs for _ in range(3)]
+    b = [RND.choice(xs) for _ in a]
+    for i in range(len(xs)):
+        b[3 * i] = xs[i]                                                   # a + a, a - a
+        b[3 * i + 1] = (bn.R - xs[i]) % bn.R                               # a + (-a) = 0
+    A, B = [le(x) for x in a], [le(x) for x in b]
+    assert eng.fr_op(0, A, B) == [le((x + y) % bn.R) for x, y in zip(a, b)]
+    assert eng.fr_op(1, A, B) == [le((x - y) % bn.R) for x, y in zip(a, b)]
+    assert eng.fr_op(3, A) == [le((-x) % bn.R) for x in a]
