@@ -342,7 +342,7 @@ template <class FA> RB_HD void facc_mul_by_two_lines(FA a, const Fp2& a0, const 
   const Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a1), fp2_add(b0, b1)), m00), m11);
   const Fp2 x03 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a3), fp2_add(b0, b3)), m00), m33);
   const Fp2 x13 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a1, a3), fp2_add(b1, b3)), m11), m33);
-  const Fp6 p0{fp2_add(m00, fp2_mul_xi(m33)), m11, x13};
+  const Fp6 p0{fp2_add_mul_xi(m00, m33), m11, x13};
   { const Fp6 t0 = fp6_mul(a.ld_f6(0), p0); a.st_x(t0); }
   a.fence();
   const Fp6 t1 = fp6_mul_by_01(a.ld_f6(1), x01, x03);

@@ -63,6 +63,80 @@ RB_FN Fp2 fp2_mul_fp_regs(Fp a0, Fp a1, Fp k) {
 }
 RB_HD Fp2 fp2_mul_fp(const Fp2& a, const Fp& k) { return fp2_mul_fp_regs(a.c0, a.c1, k); }
 // (c0 + c1 u)(9 + u) = (9 c0 - c1) + (c0 + 9 c1) u
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RB_NO_LIN9)
+// x + 9 y -+ z mod p in ONE reduction (x optional): the value is built as a 9-limb integer below 12 p, its quotient by p is
+// estimated from the top 26 bits (constants.h: RB_FP_LIN_RECIP -- floor(v / p) or one less, checked exhaustively by
+// tools/gen_constants.py), q p is subtracted and one conditional subtraction finishes.  ~95 instructions instead of the ~190 of
+// three doublings, two additions / subtractions and their five reductions.  Carry chains as in fp.h (no compiler wait states).
+template <bool MINUS, bool HAS_X>
+RB_HD Fp fp_lin9(const Fp& x, const Fp& y, const Fp& z) {
+  uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8;
+  // s = y << 3
+  s0 = y.v[0] << 3;
+  s1 = (y.v[1] << 3) | (y.v[0] >> 29); s2 = (y.v[2] << 3) | (y.v[1] >> 29); s3 = (y.v[3] << 3) | (y.v[2] >> 29);
+  s4 = (y.v[4] << 3) | (y.v[3] >> 29); s5 = (y.v[5] << 3) | (y.v[4] >> 29); s6 = (y.v[6] << 3) | (y.v[5] >> 29);
+  s7 = (y.v[7] << 3) | (y.v[6] >> 29); s8 = y.v[7] >> 29;
+#define RB_ADD9(B)                                                                                                        \
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\tv_addc_co_u32 %1, vcc, %1, %10, vcc\n\tv_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"       \
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\tv_addc_co_u32 %4, vcc, %4, %13, vcc\n\tv_addc_co_u32 %5, vcc, %5, %14, vcc\n\t" \
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\tv_addc_co_u32 %8, vcc, 0, %8, vcc"        \
+      : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8)                        \
+      : "v"(B.v[0]), "v"(B.v[1]), "v"(B.v[2]), "v"(B.v[3]), "v"(B.v[4]), "v"(B.v[5]), "v"(B.v[6]), "v"(B.v[7]) : "vcc")
+  RB_ADD9(y);                       // 9 y
+  if (HAS_X) RB_ADD9(x);
+  if (!MINUS) {
+    RB_ADD9(z);                     // < 11 p
+  } else {
+    // s -= z; negative (> -p): add p back
+    uint32_t m;
+    asm("v_sub_co_u32 %0, vcc, %0, %10\n\tv_subb_co_u32 %1, vcc, %1, %11, vcc\n\tv_subb_co_u32 %2, vcc, %2, %12, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, %13, vcc\n\tv_subb_co_u32 %4, vcc, %4, %14, vcc\n\tv_subb_co_u32 %5, vcc, %5, %15, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, %16, vcc\n\tv_subb_co_u32 %7, vcc, %7, %17, vcc\n\tv_subbrev_co_u32 %8, vcc, 0, %8, vcc\n\t"
+        "v_subb_co_u32_e64 %9, vcc, 0, 0, vcc"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8), "=&v"(m)
+        : "v"(z.v[0]), "v"(z.v[1]), "v"(z.v[2]), "v"(z.v[3]), "v"(z.v[4]), "v"(z.v[5]), "v"(z.v[6]), "v"(z.v[7]) : "vcc");
+    uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
+    asm("v_and_b32 %9, %18, %17\n\tv_and_b32 %10, %19, %17\n\tv_and_b32 %11, %20, %17\n\tv_and_b32 %12, %21, %17\n\t"
+        "v_and_b32 %13, %22, %17\n\tv_and_b32 %14, %23, %17\n\tv_and_b32 %15, %24, %17\n\tv_and_b32 %16, %25, %17\n\t"
+        "v_add_co_u32 %0, vcc, %0, %9\n\tv_addc_co_u32 %1, vcc, %1, %10, vcc\n\tv_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\tv_addc_co_u32 %4, vcc, %4, %13, vcc\n\tv_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\tv_addc_co_u32 %8, vcc, 0, %8, vcc"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8), "=&v"(p0), "=&v"(p1), "=&v"(p2),
+          "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+        : "v"(m), "i"(FpParams::mod(0)), "i"(FpParams::mod(1)), "i"(FpParams::mod(2)), "i"(FpParams::mod(3)), "i"(FpParams::mod(4)),
+          "i"(FpParams::mod(5)), "i"(FpParams::mod(6)), "i"(FpParams::mod(7))
+        : "vcc");
+  }
+#undef RB_ADD9
+  // q = floor(s / p) or one less, from the top 26 bits (s < 12 p < 2^258)
+  const uint32_t top = (s8 << 24) | (s7 >> 8);
+  const uint32_t q = __umulhi(top << 6, (uint32_t)RB_FP_LIN_RECIP << 6) >> 24;
+  // s -= q p   (q <= 11: the product's limbs come out of one 64-bit multiply-add chain)
+  uint32_t w[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    acc = (uint64_t)q * FpParams::mod(i) + (acc >> 32);
+    w[i] = (uint32_t)acc;
+  }
+  w[8] = (uint32_t)(acc >> 32);
+  asm("v_sub_co_u32 %0, vcc, %0, %9\n\tv_subb_co_u32 %1, vcc, %1, %10, vcc\n\tv_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\tv_subb_co_u32 %4, vcc, %4, %13, vcc\n\tv_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\tv_subb_co_u32 %7, vcc, %7, %16, vcc\n\tv_subb_co_u32 %8, vcc, %8, %17, vcc"
+      : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7), "+v"(s8)
+      : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]) : "vcc");
+  // now s < 2 p (s8 == 0): one conditional subtraction
+  uint32_t t[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+  cond_sub_mod<FpParams>(t, 0);
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+RB_HD Fp2 fp2_mul_xi(const Fp2& a) { return Fp2{fp_lin9<true, false>(a.c0, a.c0, a.c1), fp_lin9<false, false>(a.c1, a.c1, a.c0)}; }
+// x + xi a
+RB_HD Fp2 fp2_add_mul_xi(const Fp2& x, const Fp2& a) { return Fp2{fp_lin9<true, true>(x.c0, a.c0, a.c1), fp_lin9<false, true>(x.c1, a.c1, a.c0)}; }
+#else
 RB_HD Fp2 fp2_mul_xi(const Fp2& a) {
   Fp t0 = dbl(dbl(dbl(a.c0)));   // 8 c0
   Fp t1 = dbl(dbl(dbl(a.c1)));   // 8 c1
@@ -71,6 +145,8 @@ RB_HD Fp2 fp2_mul_xi(const Fp2& a) {
   r.c1 = add(add(t1, a.c1), a.c0);
   return r;
 }
+RB_HD Fp2 fp2_add_mul_xi(const Fp2& x, const Fp2& a) { return fp2_add(x, fp2_mul_xi(a)); }
+#endif
 RB_FN Fp2 fp2_inv(const Fp2& a) {
   Fp n = add(sqr(a.c0), sqr(a.c1));
   Fp ni = inv(n);
@@ -100,8 +176,8 @@ RB_MID Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   Fp2 t1 = fp2_mul(fp2_add(a.a0, a.a1), fp2_add(b.a0, b.a1));
   Fp2 t2 = fp2_mul(fp2_add(a.a0, a.a2), fp2_add(b.a0, b.a2));
   Fp6 r;
-  r.a0 = fp2_add(v0, fp2_mul_xi(fp2_sub(fp2_sub(t0, v1), v2)));
-  r.a1 = fp2_add(fp2_sub(fp2_sub(t1, v0), v1), fp2_mul_xi(v2));
+  r.a0 = fp2_add_mul_xi(v0, fp2_sub(fp2_sub(t0, v1), v2));
+  r.a1 = fp2_add_mul_xi(fp2_sub(fp2_sub(t1, v0), v1), v2);
   r.a2 = fp2_add(fp2_sub(fp2_sub(t2, v0), v2), v1);
   return r;
 }
@@ -113,7 +189,7 @@ RB_MID Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 t1 = fp2_mul(fp2_add(a.a0, a.a1), fp2_add(b0, b1));       // a0b0 + a0b1 + a1b0 + a1b1
   Fp2 t2 = fp2_mul(a.a2, b0);
   Fp6 r;
-  r.a0 = fp2_add(v0, fp2_mul_xi(fp2_sub(t0, v1)));              // a0b0 + xi a2b1
+  r.a0 = fp2_add_mul_xi(v0, fp2_sub(t0, v1));                   // a0b0 + xi a2b1
   r.a1 = fp2_sub(fp2_sub(t1, v0), v1);                          // a0b1 + a1b0
   r.a2 = fp2_add(t2, v1);                                       // a2b0 + a1b1
   return r;
@@ -129,8 +205,8 @@ RB_MID Fp6 fp6_sqr(const Fp6& a) {
   Fp2 s3 = fp2_dbl(bc);
   Fp2 s4 = fp2_sqr(a.a2);
   Fp6 r;
-  r.a0 = fp2_add(s0, fp2_mul_xi(s3));
-  r.a1 = fp2_add(s1, fp2_mul_xi(s4));
+  r.a0 = fp2_add_mul_xi(s0, s3);
+  r.a1 = fp2_add_mul_xi(s1, s4);
   r.a2 = fp2_sub(fp2_sub(fp2_add(fp2_add(s1, s2), s3), s0), s4);
   return r;
 }
@@ -197,7 +273,7 @@ RB_MID Fp12 fp12_mul_by_two_lines(const Fp12& f, const Fp2& a0, const Fp2& a1, c
   Fp2 x01 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a1), fp2_add(b0, b1)), m00), m11);
   Fp2 x03 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a0, a3), fp2_add(b0, b3)), m00), m33);
   Fp2 x13 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a1, a3), fp2_add(b1, b3)), m11), m33);
-  Fp6 p0{fp2_add(m00, fp2_mul_xi(m33)), m11, x13};
+  Fp6 p0{fp2_add_mul_xi(m00, m33), m11, x13};
   Fp6 t0 = fp6_mul(f.c0, p0);
   Fp6 t1 = fp6_mul_by_01(f.c1, x01, x03);
   Fp6 t2 = fp6_mul(fp6_add(f.c0, f.c1), Fp6{fp2_add(p0.a0, x01), fp2_add(p0.a1, x03), p0.a2});
@@ -300,7 +376,7 @@ RB_MID Fp12 fp12_frob3(const Fp12& a) {
 RB_HD void fp4_sqr(Fp2& r0, Fp2& r1, const Fp2& a, const Fp2& b) {
   Fp2 t0 = fp2_sqr(a);
   Fp2 t1 = fp2_sqr(b);
-  r0 = fp2_add(fp2_mul_xi(t1), t0);                       // a^2 + xi b^2
+  r0 = fp2_add_mul_xi(t0, t1);                            // a^2 + xi b^2
   r1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1);  // 2ab
 }
 RB_MID Fp12 fp12_cyclotomic_sqr(const Fp12& f) {

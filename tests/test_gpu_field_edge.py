@@ -119,3 +119,24 @@ def test_fr_add_sub_neg_on_extreme_limbs(eng):
     assert eng.fr_op(0, A, B) == [le((x + y) % bn.R) for x, y in zip(a, b)]
     assert eng.fr_op(1, A, B) == [le((x - y) % bn.R) for x, y in zip(a, b)]
     assert eng.fr_op(3, A) == [le((-x) % bn.R) for x in a]
+
+
+def test_mul_by_xi_on_extreme_values(eng):
+    """fp2_mul_xi / fp2_add_mul_xi (tower.h: x + 9 y -+ z reduced through a quotient estimate): an Fq12 product whose only non-zero
+    coefficients are a.c0.a2 = Y and b.c0.a1 = 1 is xi * Y in c0.a0; with b.c0.a1 = 1 and a.c0.a0 = X, b.c0.a0 = 1 the same slot
+    carries X + ... paths of the Karatsuba form -- all compared with the oracle's Fq12 product, on values at the edges of [0, p)."""
+    edge = [0, 1, 2, bn.P - 1, bn.P - 2, (bn.P - 1) // 9, (bn.P - 1) // 9 + 1, (2 * bn.P) // 9, (bn.P + 8) // 9, bn.P // 2, bn.P // 2 + 1,
+            (1 << 253), (1 << 224) - 1] + [canon(m, RINV_P, bn.P) for m in mont_patterns(bn.P, 30)[:40]]
+    A, B, want = [], [], []
+    for i in range(300):
+        y = (RND.choice(edge), RND.choice(edge))
+        x = (RND.choice(edge), RND.choice(edge))
+        z = (RND.choice(edge), RND.choice(edge))
+        # a = x + y v^2 + z v (c0 only), b = 1 + v: the product's c0.a0 = x + xi y, c0.a1 = x + z, c0.a2 = z + y -- and squared terms below
+        a = ((x, z, y), bn.FP6_ZERO)
+        b = ((bn.FP2_ONE, bn.FP2_ONE, bn.FP2_ZERO), bn.FP6_ZERO)
+        A.append(bn.gt_to_le(a)); B.append(bn.gt_to_le(b)); want.append(bn.gt_to_le(bn.fp12_mul(a, b)))
+        # a full element times itself: every fused slot of fp6_mul / fp12_mul sees extreme operands
+        f = bn.fp12_from_coeffs([RND.choice(edge) for _ in range(12)])
+        A.append(bn.gt_to_le(f)); B.append(bn.gt_to_le(f)); want.append(bn.gt_to_le(bn.fp12_mul(f, f)))
+    assert eng.gt_mul(A, B) == want
