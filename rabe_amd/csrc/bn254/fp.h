@@ -777,7 +777,7 @@ RB_HD uint32_t inv_exp_word(int k) {
   }
 }
 template <class M>
-RB_HD_NOINLINE Mont<M> inv(Mont<M> a) {
+RB_HD_NOINLINE Mont<M> inv_fermat(Mont<M> a) {
   Mont<M> acc = a;   // top bit (bit 253) of mod-2 is set
   for (int i = 252; i >= 0; i--) {
     acc = sqr(acc);
@@ -785,6 +785,85 @@ RB_HD_NOINLINE Mont<M> inv(Mont<M> a) {
     if (bit) acc = mul(acc, a);
   }
   return acc;
+}
+// The inversion the kernels use: Kaliski's almost-inverse (binary extended Euclid on the 256-bit integers: shifts,
+// additions and subtractions only, 254..508 steps of ~35 instructions) followed by the power-of-two correction as two
+// Montgomery multiplications -- ~14 k instructions instead of the ~125 k of the exponentiation above.  The inverse of a
+// field element is unique, so the result is the same canonical value; inv(0) = 0.  The step sequence depends on the
+// data: where a block's ONE inversion is computed by a wave on a wave-uniform value (block_batch_inverse_*) there is no
+// divergence; per-lane calls (final exponentiation) diverge over at most four short branches.
+RB_HD void inv_shr1(uint32_t x[8]) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+  x[7] >>= 1;
+}
+RB_HD void inv_shl1(uint32_t x[8]) {
+#pragma unroll
+  for (int i = 7; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 31);
+  x[0] <<= 1;
+}
+template <class M>
+RB_HD_NOINLINE Mont<M> inv(Mont<M> a) {
+  uint32_t u[8], v[8], r[8], s[8];
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { u[i] = M::mod(i); v[i] = a.v[i]; r[i] = 0; s[i] = (i == 0) ? 1u : 0u; any |= a.v[i]; }
+  if (!any) return a;
+  // u = mod, v = x, r = 0, s = 1: on exit (v = 0, u = 1)  mod - r = x^-1 2^k  with r < 2 mod, s <= 2 mod (255 bits)
+  int k = 0;
+  for (;;) {
+    any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= v[i];
+    if (!any) break;
+    k++;
+    if (!(u[0] & 1u)) { inv_shr1(u); inv_shl1(s); continue; }
+    if (!(v[0] & 1u)) { inv_shr1(v); inv_shl1(r); continue; }
+    uint32_t d[8], borrow = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { d[i] = subb32(u[i], v[i], borrow); nz |= d[i]; }
+    if (!borrow && nz) {                       // u > v: u = (u - v) / 2, r += s, s *= 2
+#pragma unroll
+      for (int i = 0; i < 8; i++) u[i] = d[i];
+      inv_shr1(u);
+      uint32_t c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) r[i] = addc32(r[i], s[i], c);
+      inv_shl1(s);
+    } else {                                   // v >= u: v = (v - u) / 2, s += r, r *= 2
+      borrow = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = subb32(v[i], u[i], borrow);
+      inv_shr1(v);
+      uint32_t c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = addc32(s[i], r[i], c);
+      inv_shl1(r);
+    }
+  }
+  // y = mod - (r mod mod)
+  uint32_t t[8], borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = subb32(r[i], M::mod(i), borrow);
+  if (!borrow) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = t[i];
+  }
+  Mont<M> y, r2;
+  borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { y.v[i] = subb32(M::mod(i), r[i], borrow); r2.v[i] = M::r2(i); }
+  // x = a R, y = x^-1 2^k; wanted a^-1 R = y 2^(512 - k): mul(mul(y, R^2), 2^c) = y 2^c for c <= 253 (2^253 < mod)
+  int e = 512 - k;                             // 4 .. 258
+  while (e > 0) {
+    const int c = e < 253 ? e : 253;
+    Mont<M> oh;
+#pragma unroll
+    for (int i = 0; i < 8; i++) oh.v[i] = ((c >> 5) == i) ? (1u << (c & 31)) : 0u;
+    y = mul(mul(y, r2), oh);
+    e -= c;
+  }
+  return y;
 }
 
 }}  // namespace rabe::bn254

@@ -65,14 +65,25 @@ def test_fp_ops():
     for a in [1, 2, bn.P - 1] + [rand_fp() for _ in range(5)]:
         assert call("hs_fp_inv", le(a)) == le(pow(a, bn.P - 2, bn.P))
     assert call("hs_fp_inv", le(0)) == le(0)
+    # the inversion is a binary extended Euclid on the Montgomery residue x = a R: residues that are tiny, powers of two,
+    # all-ones patterns and p - small drive its shortest / longest step sequences
+    rinv = pow(1 << 256, -1, bn.P)
+    residues = [1, 2, 3, 4, 1 << 31, 1 << 32, 1 << 128, 1 << 253, (1 << 253) - 1, (1 << 253) + 1, bn.P - 1, bn.P - 2, (bn.P + 1) // 2,
+                (bn.P - 1) // 2, 0x55555555 * ((1 << 248) // 0xFFFFFFFF)] + [RND.randrange(1, bn.P) for _ in range(150)]
+    for x in residues:
+        a = x * rinv % bn.P
+        assert call("hs_fp_inv", le(a)) == le(pow(a, bn.P - 2, bn.P))
 
 
 def test_fr_ops():
     for _ in range(20):
         a, b = RND.randrange(bn.R), RND.randrange(bn.R)
         assert call("hs_fr_mul", le(a), le(b)) == le(a * b % bn.R)
-    a = RND.randrange(1, bn.R)
-    assert call("hs_fr_inv", le(a)) == le(pow(a, bn.R - 2, bn.R))
+    rinv = pow(1 << 256, -1, bn.R)
+    for x in [1, 2, 3, 1 << 253, bn.R - 1, (bn.R + 1) // 2] + [RND.randrange(1, bn.R) for _ in range(60)]:
+        a = x * rinv % bn.R
+        assert call("hs_fr_inv", le(a)) == le(pow(a, bn.R - 2, bn.R))
+    assert call("hs_fr_inv", le(0)) == le(0)
     # Fr::from_slice on an arbitrary 256-bit digest (reduction mod r)
     for x in [(1 << 256) - 1, bn.R, bn.R + 5, RND.getrandbits(256), 0]:
         assert call("hs_fr_reduce256", le(x)) == le(x % bn.R)

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) k_mac(uint32_t iters, uint32_t seed, uint
   uint32_t x = seed + threadIdx.x * 2654435761u, y = seed ^ (blockIdx.x * 40503u + 77u);
   uint64_t a0 = x, a1 = y, a2 = x ^ y, a3 = x + y, a4 = x * 3u, a5 = y * 5u;
   uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0;
-  uint64_t c0, c1, c2, c3, c4, c5;
+  uint64_t c0 = 0, c1 = 0, c2, c3, c4, c5;
   uint32_t p0 = x, p1 = y, p2 = x, p3 = y;
   for (uint32_t it = 0; it < iters; it++) {
 #pragma unroll
@@ -58,6 +58,27 @@ __global__ void __launch_bounds__(256) k_mac(uint32_t iters, uint32_t seed, uint
                        "+v"(a5), "+v"(o5), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4),
                        [c5] "=&s"(c5)
                      : [x] "v"(x), [y] "v"(y));
+      if (K == 8)   // the same six MACs, addcs interleaved between the mads (each addc two instructions behind its mad)
+        asm volatile("v_mad_u64_u32 %0, %[c0], %[x], %[y], %0\n\tv_mad_u64_u32 %2, %[c1], %[x], %[y], %2\n\t"
+                     "v_addc_co_u32_e64 %1, %[c0], 0, %1, %[c0]\n\tv_mad_u64_u32 %4, %[c2], %[x], %[y], %4\n\t"
+                     "v_addc_co_u32_e64 %3, %[c1], 0, %3, %[c1]\n\tv_mad_u64_u32 %6, %[c3], %[x], %[y], %6\n\t"
+                     "v_addc_co_u32_e64 %5, %[c2], 0, %5, %[c2]\n\tv_mad_u64_u32 %8, %[c4], %[x], %[y], %8\n\t"
+                     "v_addc_co_u32_e64 %7, %[c3], 0, %7, %[c3]\n\tv_mad_u64_u32 %10, %[c5], %[x], %[y], %10\n\t"
+                     "v_addc_co_u32_e64 %9, %[c4], 0, %9, %[c4]\n\tv_addc_co_u32_e64 %11, %[c5], 0, %11, %[c5]"
+                     : "+v"(a0), "+v"(o0), "+v"(a1), "+v"(o1), "+v"(a2), "+v"(o2), "+v"(a3), "+v"(o3), "+v"(a4), "+v"(o4),
+                       "+v"(a5), "+v"(o5), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4),
+                       [c5] "=&s"(c5)
+                     : [x] "v"(x), [y] "v"(y));
+      if (K == 9)   // mads only (no carry capture): the multiplier's own rate for one wave
+        asm volatile("v_mad_u64_u32 %0, %[c0], %[x], %[y], %0\n\tv_mad_u64_u32 %1, %[c0], %[x], %[y], %1\n\t"
+                     "v_mad_u64_u32 %2, %[c0], %[x], %[y], %2\n\tv_mad_u64_u32 %3, %[c0], %[x], %[y], %3\n\t"
+                     "v_mad_u64_u32 %4, %[c0], %[x], %[y], %4\n\tv_mad_u64_u32 %5, %[c0], %[x], %[y], %5"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), [c0] "=&s"(c0) : [x] "v"(x), [y] "v"(y));
+      if (K == 10)  // addcs only
+        asm volatile("v_addc_co_u32_e64 %0, %[c0], 0, %0, %[c0]\n\tv_addc_co_u32_e64 %1, %[c1], 0, %1, %[c1]\n\t"
+                     "v_addc_co_u32_e64 %2, %[c0], 0, %2, %[c0]\n\tv_addc_co_u32_e64 %3, %[c1], 0, %3, %[c1]\n\t"
+                     "v_addc_co_u32_e64 %4, %[c0], 0, %4, %[c0]\n\tv_addc_co_u32_e64 %5, %[c1], 0, %5, %[c1]"
+                     : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), [c0] "+s"(c0), [c1] "+s"(c1));
       // PAD independent filler instructions per step (what the glue code looks like)
       if (PAD == 1) asm volatile("v_mov_b32 %0, %1" : "=v"(p0) : "v"(p1));
       if (PAD == 2) asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %1, a0" : "=v"(p2) : "v"(p3) : "a0");
@@ -82,7 +103,7 @@ static void run(const char* what, int blocks, uint32_t* sink) {
   CHECK(hipEventSynchronize(e1));
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
-  const double macs_per_wave = (double)iters * 32 * K;
+  const double macs_per_wave = (double)iters * 32 * (K >= 8 ? 6 : K);
   const double waves_per_simd = blocks * 4.0 / 1024.0;
   const double cyc = ms * 1e-3 * 2.4e9 / (macs_per_wave * (waves_per_simd < 1 ? 1 : waves_per_simd));
   printf("%-34s K=%d pad=%d blocks=%5d  %.3f ms  %.2f cycles/MAC/SIMD  (%.1f T MAC/s)\n", what, K, PAD, blocks, ms, cyc,
@@ -99,6 +120,9 @@ int main() {
     run<3, 0>("3 mads, 3 addcs", blocks, sink);
     run<4, 0>("4 mads, 4 addcs", blocks, sink);
     run<6, 0>("6 mads, 6 addcs", blocks, sink);
+    run<8, 0>("6 mads / 6 addcs alternating", blocks, sink);
+    run<9, 0>("6 mads, no addc", blocks, sink);
+    run<10, 0>("6 addcs, no mad", blocks, sink);
   }
   for (int blocks : {256, 1024}) {
     run<3, 1>("3+3 + v_mov", blocks, sink);
