@@ -161,8 +161,8 @@ def test_cp_encrypt_rows_with_wide_signed_windows(w_bits):
     half = 1 << (w_bits - 1)
     edge = [sum(half << (w_bits * i) for i in range(254 // w_bits)) % bn.R,             # every digit exactly 2^(w-1)
             sum((half + 1) << (w_bits * i) for i in range(254 // w_bits)) % bn.R,       # every digit just above: all negative with carries
-            bn.R - 1, 1, (1 << 253) + 12345]
-    items = [(rng.fr(), rng.fr()) for _ in range(3)] + [(edge[i], edge[(i + 1) % len(edge)]) for i in range(len(edge))]
+            bn.R - 1, 1, (1 << 253) + 12345, 0, 1 << (w_bits * 3), (1 << (w_bits * 9)) + (1 << w_bits)]    # zero digits too
+    items = [(rng.fr(), rng.fr()) for _ in range(3)] + [(edge[i], edge[(i + 1) % len(edge)]) for i in range(len(edge))] + [(0, 0)]
     msgs = [bn.gt_pow(e_gen, rng.fr_nonzero()) for _ in items]
     pi, c0, c, cp, _ = gpu_encrypt(eng, E, dpk, policy, lang, items, msgs)
     dpk.set_g_window(w_bits)
