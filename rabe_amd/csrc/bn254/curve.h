@@ -106,7 +106,14 @@ RB_MID Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
 // G1 form of madd-2007-bl for the fixed-base table kernels: the 11 field products are expanded in place (no call,
 // so nothing has to sit in callee-saved registers around them) and issued as 1 + 5 interleaved pairs of
 // independent products.  Same formulas and special cases as jac_add_aff, hence the same values.
-RB_FN Jac<Fp> g1_dbl_fn(const Jac<Fp>& p) { return jac_dbl(p); }
+// The doubling case of the mixed addition (never taken with honest inputs) as a function that passes and returns FIELD elements
+// in registers, one coordinate per call: a call that takes the accumulator by reference, or returns a point through a memory
+// slot, pins the caller's accumulator to the stack -- a store and a reload of the whole point in every loop iteration of the
+// fixed-base and NAF kernels (19 GB of scratch write-back per launch of the row kernel).
+RB_FN Fp g1_dbl_coord(Fp x, Fp y, Fp z, int which) {
+  const Jac<Fp> d = jac_dbl(Jac<Fp>{x, y, z});
+  return which == 0 ? d.x : which == 1 ? d.y : d.z;
+}
 RB_HD Jac<Fp> g1_madd_inl(const Jac<Fp>& p, const Aff<Fp>& q) {
   if (aff_is_inf(q)) return p;
   if (jac_is_inf(p)) return Jac<Fp>{q.x, q.y, fone<Fp>()};
@@ -118,7 +125,7 @@ RB_HD Jac<Fp> g1_madd_inl(const Jac<Fp>& p, const Aff<Fp>& q) {
   mul2_inl(S2, HH, T, Z1Z1, H, H);
   Fp rr = sub(S2, p.y);
   if (is_zero(H)) {
-    if (is_zero(rr)) return g1_dbl_fn(p);
+    if (is_zero(rr)) return Jac<Fp>{g1_dbl_coord(p.x, p.y, p.z, 0), g1_dbl_coord(p.x, p.y, p.z, 1), g1_dbl_coord(p.x, p.y, p.z, 2)};
     return jac_inf<Fp>();
   }
   rr = dbl(rr);

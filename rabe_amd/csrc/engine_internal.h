@@ -276,32 +276,26 @@ static __device__ __noinline__ G1Jac table_mul_g1(const G1M* tbl, const uint32_t
   }
   return acc;
 }
-// 16-bit digits: 16 mixed additions; the next entry is fetched while the current addition runs
+// 16-bit digits: 16 mixed additions.  The entry is fetched where it is used: holding the next entry across the addition (a
+// software prefetch) costs 16 of the 128 registers these kernels run with and came out slower than the gather latency it hid
+// (four waves per SIMD cover it): row kernel 13.0 -> 12.1 ms.
 static __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[8]) {
   G1Jac acc = jac_inf<Fp>();
-  uint32_t d = k[0] & 0xffffu;
-  G1Aff e = ld_g1_m(tbl + (d ? d - 1 : 0));
 #pragma unroll 1
   for (int w = 0; w < TBL16_WINDOWS; w++) {
-    const uint32_t dcur = d;
-    const G1Aff ecur = e;
-    if (w + 1 < TBL16_WINDOWS) {
-      const int wn = w + 1;
-      uint32_t word;
-      switch (wn >> 1) {
-        case 0: word = k[0]; break;
-        case 1: word = k[1]; break;
-        case 2: word = k[2]; break;
-        case 3: word = k[3]; break;
-        case 4: word = k[4]; break;
-        case 5: word = k[5]; break;
-        case 6: word = k[6]; break;
-        default: word = k[7]; break;
-      }
-      d = (wn & 1) ? (word >> 16) : (word & 0xffffu);
-      e = ld_g1_m(tbl + (size_t)wn * TBL16_DIGITS + (d ? d - 1 : 0));
+    uint32_t word;
+    switch (w >> 1) {
+      case 0: word = k[0]; break;
+      case 1: word = k[1]; break;
+      case 2: word = k[2]; break;
+      case 3: word = k[3]; break;
+      case 4: word = k[4]; break;
+      case 5: word = k[5]; break;
+      case 6: word = k[6]; break;
+      default: word = k[7]; break;
     }
-    if (dcur) acc = g1_madd_inl(acc, ecur);
+    const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+    if (d) acc = g1_madd_inl(acc, ld_g1_m(tbl + (size_t)w * TBL16_DIGITS + (d - 1)));
   }
   return acc;
 }
@@ -326,26 +320,16 @@ static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uin
   const int n = wide_windows(w);
   const uint32_t half = 1u << (w - 1);
   G1Jac acc = jac_inf<Fp>();
-  uint32_t raw = scalar_bits(k, 0, w);
-  uint32_t carry = raw > half ? 1u : 0u;
-  uint32_t mag = carry ? (1u << w) - raw : raw;
-  bool neg_ = carry != 0;
-  G1Aff e = ld_g1_m(tbl + (mag ? mag - 1 : 0));
+  uint32_t carry = 0;
 #pragma unroll 1
   for (int i = 0; i < n; i++) {
-    const uint32_t mcur = mag;
-    const bool ncur = neg_;
-    G1Aff ecur = e;
-    if (i + 1 < n) {
-      raw = scalar_bits(k, w * (i + 1), w) + carry;
-      carry = raw > half ? 1u : 0u;
-      mag = carry ? (1u << w) - raw : raw;
-      neg_ = carry != 0;
-      e = ld_g1_m(tbl + wide_offset(w, i + 1) + (mag ? mag - 1 : 0));
-    }
-    if (mcur) {
-      if (ncur) ecur.y = neg(ecur.y);
-      acc = g1_madd_inl(acc, ecur);
+    const uint32_t raw = scalar_bits(k, w * i, w) + carry;
+    carry = raw > half ? 1u : 0u;
+    const uint32_t mag = carry ? (1u << w) - raw : raw;
+    if (mag) {
+      G1Aff e = ld_g1_m(tbl + wide_offset(w, i) + (mag - 1));        // fetched where it is used (see table_mul_g1_w16)
+      if (carry) e.y = neg(e.y);
+      acc = g1_madd_inl(acc, e);
     }
   }
   return acc;
