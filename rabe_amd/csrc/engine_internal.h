@@ -458,11 +458,12 @@ static __device__ __noinline__ Fp block_batch_inverse_256(uint32_t (*sh)[256], c
   return r;
 }
 
-// Block size of the G1 row kernels = the group that shares one field inversion.  The inversion (361 multiplications,
-// executed by wave 0 while the block's other waves wait at the barrier) is a fixed cost per block: 28 % of the block's
-// issue slots at 256 threads (4 waves x ~340 multiplications of useful work each), 15 % at 512, 8 % at 1024.
+// Block size of the G1 row kernels = the group that shares one field inversion (computed by wave 0 while the block's other
+// waves wait at the barrier).  With the Fermat inversion (361 multiplications) that fixed cost asked for 512-thread blocks; the
+// binary-Euclid inversion (~45 multiplication-equivalents, fp.h) makes it cheap, and smaller blocks overlap their barrier phases
+// better: 256 threads 11.8 ms, 512 threads 12.2 ms per 16-step launch of k_ac17_enc_rows.
 #ifndef RB_ROWS_BLOCK
-#define RB_ROWS_BLOCK 512
+#define RB_ROWS_BLOCK 256
 #endif
 // Generalisation of block_batch_inverse_256 to NT = 64 E threads: lane j of wave 0 owns elements j, j + 64, ...,
 // j + 64 (E - 1) (conflict-free), keeps their running products in a second LDS array, joins the 64-lane scan, and
