@@ -121,6 +121,17 @@ def test_fr_add_sub_neg_on_extreme_limbs(eng):
     assert eng.fr_op(3, A) == [le((-x) % bn.R) for x in a]
 
 
+def test_fr_inv_on_extreme_residues(eng):
+    """the field inversion (fp.h: inv -- Kaliski's almost-inverse, a binary extended Euclid on the Montgomery residue, then the
+    power-of-two correction) on residues that drive its shortest / longest step sequences: tiny values, powers of two, r - small,
+    saturated limbs.  Every lane has its own step sequence here (divergent); the block inversion of the kernels runs it uniformly."""
+    ms = [m for m in mont_patterns(bn.R, 200) if m] + [2, 3, 4, 1 << 31, 1 << 32, 1 << 128, 1 << 253, (1 << 253) - 1, (1 << 253) + 1,
+                                                        (bn.R - 1) // 2, (bn.R + 1) // 2, bn.R - 3]
+    xs = [canon(m, RINV_R, bn.R) for m in ms]
+    assert eng.fr_op(4, [le(x) for x in xs]) == [le(pow(x, bn.R - 2, bn.R)) for x in xs]
+    assert eng.fr_op(4, [le(0)]) == [le(0)]
+
+
 def test_mul_by_xi_on_extreme_values(eng):
     """fp2_mul_xi / fp2_add_mul_xi (tower.h: x + 9 y -+ z reduced through a quotient estimate): an Fq12 product whose only non-zero
     coefficients are a.c0.a2 = Y and b.c0.a1 = 1 is xi * Y in c0.a0; with b.c0.a1 = 1 and a.c0.a0 = X, b.c0.a0 = 1 the same slot
