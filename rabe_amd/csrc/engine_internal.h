@@ -379,8 +379,8 @@ __device__ __forceinline__ void home_put(const Fp12& v) {
 }
 // ---- batched inversion across a 256-thread block (Montgomery's trick over LDS + one wave-level scan).
 // Every thread of the block contributes one non-zero Fp value and gets its inverse back; the block pays ONE
-// field inversion (361 multiplications, executed by wave 0 while the other waves wait at the barrier and free
-// their issue slots for other resident blocks) instead of one per thread.
+// field inversion (fp.h: inv -- a binary extended Euclid, ~45 multiplication-equivalents, computed on a wave-uniform value by
+// wave 0 while the other waves wait at the barrier and free their issue slots for other resident blocks) instead of one per thread.
 __device__ __forceinline__ Fp shfl_up_fp(const Fp& x, int d) {
   Fp r;
 #pragma unroll
