@@ -471,7 +471,7 @@ def main():
         dom = max(per_kernel, key=lambda kk: per_kernel[kk])
         dom_ms = per_kernel[dom]
         # peak: dependent-free v_mad_u64_u32 issue rate measured live on this chip
-        ms_c, ops_c = eng.calibrate(0, 20000)
+        ms_c, ops_c = min((eng.calibrate(0, 20000) for _ in range(2)), key=lambda r_: r_[0])          # best of two: the first may see clocks ramping
         peak_tmac = ops_c / (ms_c * 1e-3) / 1e12
         m_avg = sel_per_batch / B
         NB = G * B

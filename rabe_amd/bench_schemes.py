@@ -118,7 +118,7 @@ class SchemeRunner:
             eng.timing(False)
             per_kernel = {k: ms / cnt * b.launches_per_submit.get(k, 1) for k, (ms, cnt) in tim.items()}
             dom = max(per_kernel, key=lambda k: per_kernel[k])
-            ms_c, ops_c = eng.calibrate(0, 20000)
+            ms_c, ops_c = min((eng.calibrate(0, 20000) for _ in range(2)), key=lambda r_: r_[0])          # best of two: the first may see clocks ramping
             peak = ops_c / (ms_c * 1e-3) / 1e12
             alg = b.algorithmic_fpmul_per_item()          # {kernel: SURVEY 8d Fp-mul per item carried by that kernel}
             macs = alg.get(dom, 0) * MAC_PER_FPMUL * G * B
