@@ -96,7 +96,9 @@ static int32_t alloc_pair_lists(rhip_ctx* ctx, size_t total_pairs, PairLists* pl
 }
 
 // k * base (or k * -base), affine Montgomery, one field inversion per 256-thread block.  All threads must call this.
+#ifndef RB_PAIRS_BLOCK
 #define RB_PAIRS_BLOCK 256
+#endif
 __device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Aff base, uint32_t k[8], bool negate, G1M* out, bool* is_inf) {
   if (fr_shorten(k)) negate = !negate;
   if (negate) base.y = neg(base.y);
