@@ -109,6 +109,31 @@ __device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Af
   if (active && !inf) st_g1_q(out, jac_to_aff_with_zinv(r, zinv));
 }
 
+// lane -> pair of the gather kernels.  ppi != 0 (every item of the batch owns ppi pairs, pair_off[i] = i ppi): a WAVE holds pair j of
+// 64 consecutive items.  Items that share a policy share the scalar of their j-th pair, so the NAF chains of a wave run without
+// divergence -- lanes with different scalars execute the union of their additions, ~1.7x the work (k_bsw_dec_pairs 22.6 -> see
+// DESIGN.md section 8).  ppi == 0 (ragged batch): lane = pair.
+__device__ __forceinline__ void pair_lane(size_t v, size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, size_t* t, size_t* item,
+                                          bool* active) {
+  if (ppi) {
+    const size_t per_tile = (size_t)64 * ppi;
+    const size_t tile = v / per_tile, r = v % per_tile;
+    size_t it = tile * 64 + (r & 63);
+    *active = it < n_items;
+    if (!*active) it = n_items - 1;
+    *item = it;
+    *t = it * ppi + (r >> 6);
+  } else {
+    *active = v < total_pairs;
+    *t = *active ? v : total_pairs - 1;
+    *item = owner_of(pair_off, n_items, *t);
+  }
+}
+static inline uint32_t uniform_ppi(size_t n_items, size_t max_pairs, size_t total_pairs) {
+  return (max_pairs && total_pairs == n_items * max_pairs) ? (uint32_t)max_pairs : 0u;
+}
+static inline size_t pair_lanes(size_t n_items, size_t total_pairs, uint32_t ppi) { return ppi ? (n_items + 63) / 64 * 64 * (size_t)ppi : total_pairs; }
+
 // ------------------------------------------------------------------------------------------------ the multi-pairing kernel
 // The Fq12 accumulator of a lane lives in LDS (LdsHome, engine_internal.h) -- nothing of the loop goes to scratch.
 struct DevMultiAcc : LdsHome {
@@ -345,7 +370,7 @@ extern "C" int32_t rhip_bsw_encrypt_batch(rhip_ctx* ctx, const rhip_bsw_pk* pk, 
 //   2s+1 : P = -z_e * Dj.g1,  Q = Cy.g2
 //   2m   : P = -c,            Q = d
 // (msg = c_p * FE(prod), bsw/mod.rs:282-308 restated in SURVEY.md Appendix B.4)
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
                                                                     const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
                                                                     const rhip_g1* ct_c, const rhip_g1* ct_cy_g1, const rhip_g2* ct_cy_g2,
                                                                     const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
@@ -353,10 +378,9 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_it
                                                                     uint32_t lines_d_base, int prepared, const uint8_t* line_inf, G1M* P, G2M* Q,
                                                                     uint32_t* qref) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = t < total_pairs;
-  if (!active) t = total_pairs - 1;
-  const size_t item = owner_of(pair_off, n_items, t);
+  size_t t, item;
+  bool active;
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = (pair_off[item + 1] - pair_off[item] - 1) >> 1;
   const uint32_t sk = sk_idx[item];
@@ -440,8 +464,9 @@ extern "C" int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
   PairLists pl;
   int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
   if (rc) return rc;
-  KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
-          total_pairs, pair_off, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
+  const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
+  KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, ppi, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
           sk_attr_off, sk_idx, (uint32_t)(sk_lines ? sk_lines->total_attrs : 0), sk_lines ? 1 : 0,
           (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref);
   return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
@@ -613,17 +638,16 @@ extern "C" int32_t rhip_lsw_keygen_batch(rhip_ctx* ctx, const rhip_lsw_pk* pk, s
 //   s < m : P = c_e * E1[ct attr],                  Q = D2[key leaf]          (e = sel_start[i] + s)
 //   m     : P = sum_e (-c_e) * D1[key leaf]  (MSM),  Q = e2
 // This kernel does the scaled pairs and gathers the MSM's bases (D1, Montgomery) at terms[pair index - item].
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
                                                                     const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
                                                                     const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
                                                                     const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2,
                                                                     const uint32_t* sk_leaf_off, const uint32_t* sk_idx, const uint8_t* e2_line_inf,
                                                                     G1M* P, G2M* Q, uint32_t* qref, G1M* terms) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = t < total_pairs;
-  if (!active) t = total_pairs - 1;
-  const size_t item = owner_of(pair_off, n_items, t);
+  size_t t, item;
+  bool active;
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
   const uint32_t ct = ct_idx ? ct_idx[item] : (uint32_t)item;
@@ -684,8 +708,9 @@ extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
   if (rc) return rc;
   KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
   KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
-  KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
-          pair_off, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
+  const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
+  KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
+          pair_off, ppi, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
           (const uint8_t*)(ct_e2_lines ? ct_e2_lines->q_inf : nullptr), pl.P, pl.Q, pl.qref, (G1M*)w_terms);
   KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
@@ -900,16 +925,15 @@ extern "C" int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk
 //   m     : P = -H(gid),             Q = sum_e c_e * C3[ct row]   (G2 MSM)
 // and the leading factor c_0 * prod_e C1[ct row]^(-c_e)  (a Gt multi-exponentiation with shared squarings).
 // This kernel does the scaled pairs and gathers the MSM's bases (C3) and the multi-exponentiation's bases (C1), Montgomery.
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
                                                                      const uint32_t* sel_ct_row, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
                                                                      const rhip_g2* ct_c2, const uint32_t* ct_row_off, const rhip_g1* sk_hash,
                                                                      const rhip_g1* sk_k, const uint32_t* sk_attr_off, const uint32_t* sk_idx, G1M* P,
                                                                      G2M* Q, uint32_t* qref) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = t < total_pairs;
-  if (!active) t = total_pairs - 1;
-  const size_t item = owner_of(pair_off, n_items, t);
+  size_t t, item;
+  bool active;
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
   const uint32_t sk = sk_idx ? sk_idx[item] : (uint32_t)item;
@@ -1016,8 +1040,9 @@ extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t
   GtM* p_gt = (GtM*)(p_g2 + n_items * L);
   KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
   KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
-  KLAUNCH(ctx, "k_aw11_dec_pairs", k_aw11_dec_pairs, dim3(blocks_for(total_pairs, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
-          total_pairs, pair_off, sel_start, sel_ct_row, sel_sk_attr, sel_coeff, ct_c2, ct_row_off, sk_hash, sk_k, sk_attr_off, sk_idx, pl.P, pl.Q,
+  const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
+  KLAUNCH(ctx, "k_aw11_dec_pairs", k_aw11_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, ppi, sel_start, sel_ct_row, sel_sk_attr, sel_coeff, ct_c2, ct_row_off, sk_hash, sk_k, sk_attr_off, sk_idx, pl.P, pl.Q,
           pl.qref);
   if (total_terms)
     KLAUNCH(ctx, "k_aw11_gather_terms", k_aw11_gather_terms, dim3(blocks_for(total_terms, 64)), dim3(64), 0, ctx->stream, n_items, total_terms,
@@ -1172,10 +1197,14 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_ac17_dec_pairs(size_t n_i
                                                                      const uint32_t* ct_sel, const uint32_t* ct_sel_off, const uint32_t* sk_sel,
                                                                      const uint32_t* sk_sel_off, G1M* P, G2M* Q, uint32_t* qref) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // a WAVE holds one side of 64 couples (the two sides run different loops: interleaved in a wave they would execute one after the
+  // other): launch lane v -> couple u = 64 (v / 128) + v % 64, side = (v / 64) & 1, pair t = 2 u + side = 6 item + 2 j + side
+  static_assert(RB_PAIRS_BLOCK % 128 == 0, "a block holds whole (side 0, side 1) wave pairs");
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = n_items * 6;
+  size_t t = 2 * ((v >> 7) * 64 + (v & 63)) + ((v >> 6) & 1);
   const bool active = t < total;
-  if (!active) t = total - 1;
+  if (!active) t = total - 2 + (t & 1);
   const size_t item = t / 6;
   const int j = (int)((t % 6) >> 1), side = (int)(t & 1);
   const uint32_t sk = sk_idx[item];
@@ -1212,7 +1241,8 @@ static int32_t ac17_decrypt_shared(rhip_ctx* ctx, size_t n_items, const rhip_g2*
   PairLists pl;
   int32_t rc = alloc_pair_lists(ctx, n_items * 6, &pl);
   if (rc) return rc;
-  KLAUNCH(ctx, "k_ac17_dec_pairs", k_ac17_dec_pairs, dim3(blocks_for(n_items * 6, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, ct_c0, ct_c,
+  // lanes: 128 per 64 couples (see the kernel), i.e. the couple count rounded up to whole waves, times two
+  KLAUNCH(ctx, "k_ac17_dec_pairs", k_ac17_dec_pairs, dim3(blocks_for((n_items * 3 + 63) / 64 * 128, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, ct_c0, ct_c,
           ct_row_off, sk_k0, (const uint8_t*)(sk_lines ? sk_lines->q_inf : nullptr), sk_lines ? 1 : 0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off,
           sk_sel, sk_sel_off, pl.P, pl.Q, pl.qref);
   return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, ct_cp, out);
