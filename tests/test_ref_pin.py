@@ -1,0 +1,439 @@
+"""Pin the oracle (and, on a GPU, the HIP engine) to REAL rabe: tests/golden/ref_primitives.json and ref_schemes.json are
+written by integration/ref-harness (cargo run --bin dump_vectors) on a machine with a Rust toolchain.  While they are
+absent -- this container has no Rust and no registry -- the reference-dependent tests SKIP and parity stays "unpinned"
+(DESIGN.md section 2); the self-tests below run always and prove that the loader (tests/refpin.py) finds the layout of
+files written in layouts a real crate might use, and names the convention that is off when the numbers differ.
+
+Conventions checked, each isolated in one function of the oracle and of the engine:
+  (i)   Fr::from_slice(digest) = big-endian integer mod r          oracle/bn254.py: fr_from_be32_reduce; fp.h: to_mont_reduce256
+  (ii)  tower / curve / generators                                  oracle/bn254.py: G1_GEN, G2_GEN, XI
+  (iii) final exponent = 2u(6u^2+3u+1) (p^12-1)/r (libff chain)     oracle/bn254.py: FINAL_EXP; pairing.h: final_exponentiation
+  (v)   Into<Vec<u8>> for Gt (AES key input)                        aes_gcm.h: gt_kdf_bytes
+  (vi)  serde / borsh layouts                                       reported by the loader (the answer to SURVEY 8f-2)
+"""
+import hashlib
+import json
+import os
+
+import pytest
+
+from oracle import bn254 as bn
+from oracle import policy as pol
+from oracle import schemes as sch
+from oracle.tape import SeededRng
+from tests import refpin as rp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PRIM = os.path.join(GOLD, "ref_primitives.json")
+SCHEMES = os.path.join(GOLD, "ref_schemes.json")
+
+
+# ------------------------------------------------------------------------------------------------ the checker
+def learn_sources(prim):
+    """layouts of Fr / G1 / G2 / Gt in the borsh and the serde encodings, from anchors whose values need no convention:
+    small scalars, k * generator.  Returns ({source name: Source}, report)."""
+    by_k = lambda rows: {r["k"]: r["out"] for r in rows}
+    frs, g1s, g2s = by_k(prim["fr_from_str"]), by_k(prim["g1_mul"]), by_k(prim["g2_mul"])
+    big = "12345678901234567890123456789012345678901234567890123456789012345678"
+    srcs, report = {}, {}
+    for name in ("borsh", "serde"):
+        s = rp.Source(name)
+        ok = s.learn("fr", [(frs[k], int(k) % bn.R) for k in ("1", "4294967296", big)])
+        ok = s.learn("g1", [(g1s[k], bn.g1_mul(bn.G1_GEN, int(k))) for k in ("1", "2", big)]) and ok
+        ok = s.learn("g2", [(g2s[k], bn.g2_mul(bn.G2_GEN, int(k))) for k in ("1", "2", big)]) and ok
+        report[name] = {k: repr(v) for k, v in s.layout.items()}
+        if ok:
+            srcs[name] = s
+    assert srcs, ("convention (ii)/(vi): neither the borsh nor the serde form of Fr / G1 / G2 decodes k * generator under any layout "
+                  "of tests/refpin.py -- generators or curve differ, or the encoding is outside the search space: %r" % report)
+    return srcs, report
+
+
+def learn_gt(src, prim):
+    """Gt layout + which final exponent the reference's pairing uses (convention (iii))"""
+    e11 = next(r for r in prim["pairing"] if r["a"] == "1" and r["b"] == "1")["out"]
+    f = bn.miller_loop(bn.G1_GEN, bn.G2_GEN)
+    hyps = [("libff chain 2u(6u^2+3u+1) x exact (oracle FINAL_EXP)", bn.pairing(bn.G1_GEN, bn.G2_GEN)),
+            ("exact (p^12-1)/r (oracle pairing_exact)", bn.pairing_exact(bn.G1_GEN, bn.G2_GEN))]
+    for name, want in hyps:
+        if src.learn("gt", [(e11, want)]):
+            return name
+    del f
+    raise AssertionError("convention (iii)/(ii): pairing(G1::one(), G2::one()) of the reference matches neither final exponent under "
+                         "any Gt layout -- tower (xi, coefficient order) or Miller-loop normalisation differ")
+
+
+def check_primitives(prim):
+    srcs, report = learn_sources(prim)
+    src = srcs.get("borsh") or srcs["serde"]
+    which = learn_gt(src, prim)
+    report["final_exponent"] = which
+    assert which.startswith("libff"), "convention (iii): the reference's final exponent is the %s; flip oracle/bn254.py FINAL_EXP and pairing.h" % which
+    for s in srcs.values():
+        if "gt" not in s.layout:
+            learn_gt(s, prim)
+        report[s.name]["gt"] = repr(s.layout["gt"])
+    # --- everything else through the layout found
+    for r in prim["fr_from_str"]:
+        assert src.decode("fr", r["out"]) == int(r["k"]) % bn.R, "Fr::from_str(%s)" % r["k"]
+    for r in prim["g1_mul"]:
+        assert src.decode("g1", r["out"]) == bn.g1_mul(bn.G1_GEN, int(r["k"])), "G1::one() * %s" % r["k"]
+    for r in prim["g2_mul"]:
+        assert src.decode("g2", r["out"]) == bn.g2_mul(bn.G2_GEN, int(r["k"])), "G2::one() * %s" % r["k"]
+    e11 = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    for r in prim["gt_pow"]:
+        assert rp.same("gt", src.decode("gt", r["out"]), bn.gt_pow(e11, int(r["k"]))), "Gt::pow(%s)" % r["k"]
+    for r in prim["fr_from_digest"]:
+        d = hashlib.sha3_256(r["label"].encode()).digest()
+        assert d.hex() == r["digest_be"], "SHA3-256 of %r" % r["label"]
+        want = bn.fr_from_be32_reduce(d)
+        got = src.decode("fr", r["out"])
+        if got != want:
+            alt = {"little-endian integer mod r": int.from_bytes(d, "little") % bn.R}
+            hit = [k for k, v in alt.items() if v == got]
+            raise AssertionError("convention (i): Fr::from_slice(SHA3(%r)) = %d, oracle %d%s" % (r["label"], got, want, "; it is the " + hit[0] if hit else ""))
+        assert src.decode("g1", r["g1"]) == bn.g1_mul(bn.G1_GEN, want), "G1::one() * Fr::from_slice(SHA3(%r))" % r["label"]
+    a = int(prim["fr_ops"]["a"])
+    assert src.decode("fr", prim["fr_ops"]["inverse"]) == bn.fr_inv(a)
+    assert src.decode("fr", prim["fr_ops"]["pow_3"]) == pow(a, 3, bn.R)
+    assert src.decode("fr", prim["fr_ops"]["neg"]) == (-a) % bn.R
+    assert src.decode("fr", prim["fr_ops"]["a_times_65537"]) == a * 65537 % bn.R
+    for r in prim["pairing"]:
+        p, q = src.decode("g1", r["p"]), src.decode("g2", r["q"])
+        assert p == bn.g1_mul(bn.G1_GEN, int(r["a"])) and q == bn.g2_mul(bn.G2_GEN, int(r["b"]))
+        e = bn.pairing(p, q)
+        assert rp.same("gt", src.decode("gt", r["out"]), e), "pairing(%s G1, %s G2)" % (r["a"], r["b"])
+    go = prim["group_ops"]
+    assert src.decode("g1", go["g1_zero"]) is None and src.decode("g2", go["g2_zero"]) is None
+    assert rp.same("gt", src.decode("gt", go["gt_one"]), bn.GT_ONE)
+    assert src.decode("g1", go["g1_2_plus_3"]) == bn.g1_mul(bn.G1_GEN, 5)
+    assert src.decode("g1", go["g1_neg_2"]) == bn.g1_neg(bn.g1_mul(bn.G1_GEN, 2))
+    assert rp.same("gt", src.decode("gt", go["gt_inverse_e11"]), bn.gt_inv(e11))
+    assert rp.same("gt", src.decode("gt", go["gt_mul"]), bn.gt_pow(e11, 4))
+    # --- convention (v): bytes(Gt) that feed the KDF
+    report["into_vec_u8"] = learn_gt_bytes(prim)
+    return srcs, report
+
+
+def gt_bytes_candidates(g):
+    tower = [int.from_bytes(bn.gt_to_le(g)[32 * i:32 * i + 32], "little") for i in range(12)]
+    for form in rp.BYTE_FORMS:
+        for mont in (False, True):
+            fe = rp.FeLayout(form, mont, bn.P)
+            for name, order in rp.gt_orders():
+                yield "%r, order %s" % (fe, name), b"".join(fe.enc(tower[t]) for t in order)
+
+
+def learn_gt_bytes(prim):
+    found = None
+    for r in prim["pairing"]:
+        g = bn.pairing(bn.g1_mul(bn.G1_GEN, int(r["a"])), bn.g2_mul(bn.G2_GEN, int(r["b"])))
+        want = bytes.fromhex(r["into_vec_u8"])
+        hits = [n for n, b in gt_bytes_candidates(g) if b == want]
+        assert hits, "convention (v): Into<Vec<u8>> for Gt (%d bytes) is none of the candidate layouts" % len(want)
+        found = hits[0] if found is None else found
+        assert found in hits
+    assert found == "be, order declared", ("convention (v): Into<Vec<u8>> for Gt is `%s`; aes_gcm.h gt_kdf_bytes assumes 12 x 32-byte big-endian in "
+                                           "tower order -- flip it there and in the oracle's KDF" % found)
+    return found
+
+
+def kdf_key(g, layout_name):
+    return hashlib.sha3_256(next(b for n, b in gt_bytes_candidates(g) if n == layout_name)).digest()
+
+
+def aes_open(key, blob):
+    from tests.test_host_kats import aes256_gcm
+    nonce, body, tag = blob[:12], blob[12:-16], blob[-16:]
+    ks_ct, _ = aes256_gcm(key, nonce, bytes(len(body)))          # keystream = encryption of zeros
+    pt = bytes(a ^ b for a, b in zip(body, ks_ct))
+    ct2, tag2 = aes256_gcm(key, nonce, pt)
+    return pt if (ct2 == body and tag2 == tag) else None
+
+
+# ---- rabe's serde structs -> the oracle's dicts (field names: src/schemes/*/mod.rs struct definitions)
+def lang(v):
+    return pol.JSON if v == "JsonPolicy" else pol.HUMAN
+
+
+class SchemeReader:
+    def __init__(self, src):
+        self.s = src
+
+    def el(self, kind, v):
+        return self.s.decode(kind, {"serde": v, "borsh": ""})
+
+    def ac17_sk(self, j):
+        return {"k_0": [self.el("g2", x) for x in j["k_0"]], "k": [(n, [self.el("g1", p) for p in vec]) for n, vec in j["k"]],
+                "k_p": [self.el("g1", x) for x in j["k_p"]]}
+
+    def ac17_ct(self, j):
+        return {"c_0": [self.el("g2", x) for x in j["c_0"]], "c": [(n, [self.el("g1", p) for p in vec]) for n, vec in j["c"]],
+                "c_p": self.el("gt", j["c_p"])}
+
+    def bsw_attr(self, j):
+        return {"string": j["string"], "g1": self.el("g1", j["g1"]), "g2": self.el("g2", j["g2"])}
+
+
+def check_schemes(sch_j, srcs, gt_bytes_layout):
+    src = srcs.get("serde")
+    assert src is not None, "the serde form was not readable; scheme transcripts are serde JSON"
+    rd = SchemeReader(src)
+    plaintext = bytes.fromhex(sch_j["plaintext_hex"])
+    done = []
+    # ---- AC17: algebraic relations of the key material + CP and KP decryption
+    a = sch_j["ac17"]
+    msk = {"g": rd.el("g1", a["msk"]["g"]), "h": rd.el("g2", a["msk"]["h"]), "g_k": [rd.el("g1", x) for x in a["msk"]["g_k"]],
+           "a": [rd.el("fr", x) for x in a["msk"]["a"]], "b": [rd.el("fr", x) for x in a["msk"]["b"]]}
+    pk = {"g": rd.el("g1", a["pk"]["g"]), "h_a": [rd.el("g2", x) for x in a["pk"]["h_a"]], "e_gh_ka": [rd.el("gt", x) for x in a["pk"]["e_gh_ka"]]}
+    assert pk["g"] == msk["g"] and pk["h_a"][2] == msk["h"]
+    for i in range(2):
+        assert pk["h_a"][i] == bn.g2_mul(msk["h"], msk["a"][i])
+        # e(g,h)^(k_i a_i + k_2) = e(g_k[i], h)^(a_i) e(g_k[2], h): the pairing on points the reference drew at random
+        want = bn.gt_mul(bn.gt_pow(bn.pairing(msk["g_k"][i], msk["h"]), msk["a"][i]), bn.pairing(msk["g_k"][2], msk["h"]))
+        assert rp.same("gt", pk["e_gh_ka"][i], want), "ac17 e_gh_ka[%d] != pairing relation (conventions (ii)/(iii))" % i
+    sk = {"attr": a["cp_sk"]["attr"], "sk": rd.ac17_sk(a["cp_sk"]["sk"])}
+    ct = {"policy": (a["cp_ct"]["policy"][0], lang(a["cp_ct"]["policy"][1])), "ct": rd.ac17_ct(a["cp_ct"]["ct"])}
+    g = sch.ac17_cp_decrypt(sk, ct)
+    assert aes_open(kdf_key(g, gt_bytes_layout), bytes(a["cp_ct"]["ct"]["ct"])) == plaintext, "ac17 cp_decrypt: plaintext differs"
+    ksk = {"policy": (a["kp_sk"]["policy"][0], lang(a["kp_sk"]["policy"][1])), "sk": rd.ac17_sk(a["kp_sk"]["sk"])}
+    kct = {"attr": a["kp_ct"]["attr"], "ct": rd.ac17_ct(a["kp_ct"]["ct"])}
+    g = sch.ac17_kp_decrypt(ksk, kct)
+    assert aes_open(kdf_key(g, gt_bytes_layout), bytes(a["kp_ct"]["ct"]["ct"])) == plaintext, "ac17 kp_decrypt: plaintext differs"
+    done.append("ac17")
+    # ---- BSW
+    b = sch_j["bsw"]
+    sk = {"d": rd.el("g2", b["sk"]["d"]), "d_j": [rd.bsw_attr(x) for x in b["sk"]["d_j"]]}
+    ct = {"policy": (b["ct"]["policy"][0], lang(b["ct"]["policy"][1])), "c": rd.el("g1", b["ct"]["c"]), "c_p": rd.el("gt", b["ct"]["c_p"]),
+          "c_y": [rd.bsw_attr(x) for x in b["ct"]["c_y"]]}
+    g = sch.bsw_decrypt(sk, ct)
+    assert aes_open(kdf_key(g, gt_bytes_layout), bytes(b["ct"]["data"])) == plaintext, "bsw decrypt: plaintext differs"
+    # label hashing: Cy.g2 / Cy.g1 relation needs the shares; D_j: e(g1 r_j, H(j)) pairs -- checked through decryption above
+    done.append("bsw")
+    # ---- LSW
+    l = sch_j["lsw"]
+    opt = lambda kind, v: None if v is None else rd.el(kind, v)
+    sk = {"policy": (l["sk"]["policy"][0], lang(l["sk"]["policy"][1])),
+          "dj": [(t[0], opt("g1", t[1]), opt("g2", t[2]), opt("g1", t[3]), opt("g1", t[4]), opt("g1", t[5])) for t in l["sk"]["dj"]]}
+    ct = {"e1": rd.el("gt", l["ct"]["e1"]), "e2": rd.el("g2", l["ct"]["e2"]),
+          "ej": [(t[0], rd.el("g1", t[1]), rd.el("g1", t[2]), rd.el("g1", t[3])) for t in l["ct"]["ej"]]}
+    g = sch.lsw_decrypt(sk, ct)
+    assert aes_open(kdf_key(g, gt_bytes_layout), bytes(l["ct"]["ct"])) == plaintext, "lsw decrypt: plaintext differs"
+    done.append("lsw")
+    # ---- AW11
+    w = sch_j["aw11"]
+    gk = {"g1": rd.el("g1", w["gk"]["g1"]), "g2": rd.el("g2", w["gk"]["g2"])}
+    egg = bn.pairing(gk["g1"], gk["g2"])
+    for pkj, mskj in zip(w["pks"], w["msks"]):
+        for (n, e, y2), (n2, alpha, y) in zip(pkj["attr"], mskj["attr"]):
+            assert n == n2
+            assert rp.same("gt", rd.el("gt", e), bn.gt_pow(egg, rd.el("fr", alpha))), "aw11 egg_alpha of %s" % n
+            assert rd.el("g2", y2) == bn.g2_mul(gk["g2"], rd.el("fr", y))
+    sk = {"gid": w["sk"]["gid"], "attr": [(n, rd.el("g1", p)) for n, p in w["sk"]["attr"]]}
+    # K_x = g1 * alpha_x + H(gid) * y_x pins hash-to-G1 of the gid on the reference's own values
+    hgid = sch.sha3_hash_g1(gk["g1"], sk["gid"])
+    msk_by = {t[0].upper(): t for m in w["msks"] for t in m["attr"]}
+    for n, p in sk["attr"]:
+        t = msk_by[n]
+        assert p == bn.g1_add(bn.g1_mul(gk["g1"], rd.el("fr", t[1])), bn.g1_mul(hgid, rd.el("fr", t[2]))), "aw11 key component %s (convention (i))" % n
+    ct = {"policy": (w["ct"]["policy"][0], lang(w["ct"]["policy"][1])), "c_0": rd.el("gt", w["ct"]["c_0"]),
+          "c": [(t[0], rd.el("gt", t[1]), rd.el("g2", t[2]), rd.el("g2", t[3])) for t in w["ct"]["c"]]}
+    g = sch.aw11_decrypt(gk, sk, ct)
+    assert aes_open(kdf_key(g, gt_bytes_layout), bytes(w["ct"]["ct"])) == plaintext, "aw11 decrypt: plaintext differs"
+    done.append("aw11")
+    return done
+
+
+# ------------------------------------------------------------------------------------------------ reference-dependent tests
+needs_ref = pytest.mark.skipif(not os.path.exists(PRIM), reason="tests/golden/ref_primitives.json absent: run integration/ref-harness "
+                               "(cargo run --release --bin dump_vectors -- tests/golden) on a machine with Rust; parity stays unpinned until then")
+
+
+@needs_ref
+def test_ref_primitives_pin_the_oracle():
+    srcs, report = check_primitives(rp.load(PRIM))
+    print(json.dumps(report, indent=1))
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(SCHEMES), reason="tests/golden/ref_schemes.json absent")
+def test_ref_scheme_transcripts_decrypt_with_the_oracle():
+    prim = rp.load(PRIM)
+    srcs, report = check_primitives(prim)
+    assert check_schemes(rp.load(SCHEMES), srcs, report["into_vec_u8"]) == ["ac17", "bsw", "lsw", "aw11"]
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_ref_primitives_pin_the_hip_engine():
+    """the same vectors through the C ABI: k * generator, pairings and Gt powers as the HIP kernels compute them"""
+    from rabe_amd import Engine
+    prim = rp.load(PRIM)
+    srcs, _ = check_primitives(prim)
+    src = srcs.get("borsh") or srcs["serde"]
+    eng = Engine(0)
+    le = lambda k: (int(k) % bn.R).to_bytes(32, "little")
+    ks = [r["k"] for r in prim["g1_mul"]]
+    g1 = eng.g1_mul([bn.g1_to_le(bn.G1_GEN)] * len(ks), [le(k) for k in ks])
+    g2 = eng.g2_mul([bn.g2_to_le(bn.G2_GEN)] * len(ks), [le(k) for k in ks])
+    for k, a, b, ra, rb in zip(ks, g1, g2, prim["g1_mul"], prim["g2_mul"]):
+        assert a == bn.g1_to_le(src.decode("g1", ra["out"])), "HIP G1::one() * %s" % k
+        assert b == bn.g2_to_le(src.decode("g2", rb["out"])), "HIP G2::one() * %s" % k
+    ps = [bn.g1_to_le(src.decode("g1", r["p"])) for r in prim["pairing"]]
+    qs = [bn.g2_to_le(src.decode("g2", r["q"])) for r in prim["pairing"]]
+    for r, e in zip(prim["pairing"], eng.pairing(ps, qs)):
+        assert e == bn.gt_to_le(src.decode("gt", r["out"])), "HIP pairing(%s, %s)" % (r["a"], r["b"])
+    e11 = bn.gt_to_le(bn.pairing(bn.G1_GEN, bn.G2_GEN))
+    for r, e in zip(prim["gt_pow"], eng.gt_pow([e11] * len(ks), [le(r["k"]) for r in prim["gt_pow"]])):
+        assert e == bn.gt_to_le(src.decode("gt", r["out"])), "HIP Gt::pow(%s)" % r["k"]
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ self-tests (always run)
+SCALARS = ["1", "2", "3", "65537", "4294967296", "340282366920938463463374607431768211456", str(bn.R - 1),
+           "12345678901234567890123456789012345678901234567890123456789012345678"]
+LABELS = ["A00", "B10", "01", "", "a1"]
+
+
+def synth_primitives(fe_r, fe_p, g_shape, g2_order, gt_order, serde_limb, prefix, pairing_fn=bn.pairing, from_digest=bn.fr_from_be32_reduce,
+                     gt_bytes=None):
+    """a ref_primitives.json as a crate with the given layout would write it, computed by the oracle"""
+    z = 0x1234567 if g_shape != "affine" else 1
+    e = {"fr": lambda v: rp.encode_element("fr", v, fe_r, serde_limb=serde_limb, prefix=prefix),
+         "g1": lambda v: rp.encode_element("g1", v, fe_p, g_shape, z=z, serde_limb=serde_limb, prefix=prefix),
+         "g2": lambda v: rp.encode_element("g2", v, fe_p, g_shape, order=g2_order, z=z, serde_limb=serde_limb, prefix=prefix),
+         "gt": lambda v: rp.encode_element("gt", v, fe_p, order=gt_order, serde_limb=serde_limb, prefix=prefix)}
+    e11 = pairing_fn(bn.G1_GEN, bn.G2_GEN)
+    prim = {"fr_from_str": [], "g1_mul": [], "g2_mul": [], "gt_pow": [], "fr_from_digest": [], "pairing": []}
+    for s in SCALARS:
+        k = int(s)
+        prim["fr_from_str"].append({"k": s, "out": e["fr"](k)})
+        prim["g1_mul"].append({"k": s, "out": e["g1"](bn.g1_mul(bn.G1_GEN, k))})
+        prim["g2_mul"].append({"k": s, "out": e["g2"](bn.g2_mul(bn.G2_GEN, k))})
+        prim["gt_pow"].append({"k": s, "out": e["gt"](bn.gt_pow(e11, k))})
+    for l in LABELS:
+        d = hashlib.sha3_256(l.encode()).digest()
+        f = from_digest(d)
+        prim["fr_from_digest"].append({"label": l, "digest_be": d.hex(), "out": e["fr"](f), "g1": e["g1"](bn.g1_mul(bn.G1_GEN, f))})
+    a = int(SCALARS[7])
+    prim["fr_ops"] = {"a": SCALARS[7], "inverse": e["fr"](bn.fr_inv(a)), "pow_3": e["fr"](pow(a, 3, bn.R)), "neg": e["fr"]((-a) % bn.R),
+                      "a_times_65537": e["fr"](a * 65537 % bn.R)}
+    gt_bytes = gt_bytes or (lambda g: b"".join(bn.gt_to_le(g)[32 * i:32 * i + 32][::-1] for i in range(12)))
+    for x, y in (("1", "1"), ("2", "3")):
+        p, q = bn.g1_mul(bn.G1_GEN, int(x)), bn.g2_mul(bn.G2_GEN, int(y))
+        g = pairing_fn(p, q)
+        prim["pairing"].append({"a": x, "b": y, "p": e["g1"](p), "q": e["g2"](q), "out": e["gt"](g), "into_vec_u8": gt_bytes(g).hex()})
+    # the affine encoding of infinity is (0, 0); a Jacobian crate writes z = 0
+    inf1 = rp.encode_element("g1", None, fe_p, "affine", serde_limb=serde_limb, prefix=prefix) if g_shape == "affine" else \
+        {"serde": list(bytes(96)), "borsh": bytes(96).hex(), "debug": ""}
+    inf2 = {"serde": list(bytes(128 if g_shape == "affine" else 192)), "borsh": bytes(128 if g_shape == "affine" else 192).hex(), "debug": ""}
+    prim["group_ops"] = {"g1_zero": inf1, "g2_zero": inf2, "gt_one": e["gt"](bn.GT_ONE), "g1_2_plus_3": e["g1"](bn.g1_mul(bn.G1_GEN, 5)),
+                         "g1_neg_2": e["g1"](bn.g1_neg(bn.g1_mul(bn.G1_GEN, 2))), "gt_inverse_e11": e["gt"](bn.gt_inv(e11)),
+                         "gt_mul": e["gt"](bn.gt_pow(e11, 4))}
+    return prim, e
+
+
+LAYOUT_A = dict(fe_r=rp.FeLayout("le", False, bn.R), fe_p=rp.FeLayout("le", False, bn.P), g_shape="affine", g2_order=[0, 1],
+                gt_order=list(range(12)), serde_limb=None, prefix=False)
+# what zcash-bn-style code would plausibly write: Montgomery limbs, Jacobian points, u128 limbs in serde, c1 before c0
+LAYOUT_B = dict(fe_r=rp.FeLayout("limb16_msf", True, bn.R), fe_p=rp.FeLayout("limb16_msf", True, bn.P), g_shape="jacobian", g2_order=[1, 0],
+                gt_order=rp.gt_orders()[7][1], serde_limb=16, prefix=True)
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_A, LAYOUT_B], ids=["canonical-affine", "montgomery-jacobian"])
+def test_selftest_loader_finds_the_layout(layout):
+    prim, _ = synth_primitives(**layout)
+    srcs, report = check_primitives(json.loads(json.dumps(prim)))
+    assert set(srcs) == {"borsh", "serde"}
+    assert report["final_exponent"].startswith("libff")
+    assert ("montgomery" in report["borsh"]["g1"]) == layout["fe_p"].mont
+    assert ("jacobian" in report["borsh"]["g1"]) == (layout["g_shape"] == "jacobian")
+
+
+def test_selftest_names_the_final_exponent():
+    prim, _ = synth_primitives(pairing_fn=bn.pairing_exact, **LAYOUT_A)
+    with pytest.raises(AssertionError, match=r"convention \(iii\)"):
+        check_primitives(prim)
+
+
+def test_selftest_names_the_digest_reduction():
+    prim, _ = synth_primitives(from_digest=lambda d: int.from_bytes(d, "little") % bn.R, **LAYOUT_A)
+    with pytest.raises(AssertionError, match=r"convention \(i\).*little-endian"):
+        check_primitives(prim)
+
+
+def test_selftest_names_the_gt_byte_form():
+    prim, _ = synth_primitives(gt_bytes=lambda g: bn.gt_to_le(g), **LAYOUT_A)
+    with pytest.raises(AssertionError, match=r"convention \(v\).*`le"):
+        check_primitives(prim)
+
+
+def test_selftest_scheme_transcripts():
+    """ref_schemes.json as rabe's serde derives would write it (layout B), produced by the oracle's own encrypt / keygen, must
+    decrypt through the loader: exercises every struct reader and the KDF + AES-GCM step"""
+    from tests.test_host_kats import aes256_gcm
+    prim, e = synth_primitives(**LAYOUT_B)
+    srcs, report = check_primitives(json.loads(json.dumps(prim)))
+    S = lambda kind, v: e[kind](v)["serde"]
+    rng = SeededRng(77)
+    plaintext = b"dance like no one's watching, encrypt like everyone is!"
+    nonce = bytes(range(12))
+
+    def seal(g):
+        ct, tag = aes256_gcm(kdf_key(g, report["into_vec_u8"]), nonce, plaintext)
+        return list(nonce + ct + tag)
+    J = lambda l: "JsonPolicy" if l == pol.JSON else "HumanPolicy"
+    out = {"plaintext_hex": plaintext.hex()}
+    # AC17
+    pk, msk = sch.ac17_setup(rng)
+    policy = '{"name": "and", "children": [{"name": "A"}, {"name": "or", "children": [{"name": "B"}, {"name": "C"}]}]}'
+    e_base = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    msg = bn.gt_pow(e_base, rng.fr_nonzero())
+    ct = sch.ac17_cp_encrypt(pk, policy, pol.JSON, rng, msg)
+    sk = sch.ac17_cp_keygen(msk, ["A", "B"], rng)
+    ksk = sch.ac17_kp_keygen(msk, policy, pol.JSON, rng)
+    msg2 = bn.gt_pow(e_base, rng.fr_nonzero())
+    kct = sch.ac17_kp_encrypt(pk, ["A", "B"], rng, msg2)
+    skj = lambda s: {"k_0": [S("g2", x) for x in s["k_0"]], "k": [[n, [S("g1", p) for p in v]] for n, v in s["k"]], "k_p": [S("g1", x) for x in s["k_p"]]}
+    ctj = lambda c, m: {"c_0": [S("g2", x) for x in c["c_0"]], "c": [[n, [S("g1", p) for p in v]] for n, v in c["c"]], "c_p": S("gt", c["c_p"]), "ct": seal(m)}
+    out["ac17"] = {"pk": {"g": S("g1", pk["g"]), "h_a": [S("g2", x) for x in pk["h_a"]], "e_gh_ka": [S("gt", x) for x in pk["e_gh_ka"]]},
+                   "msk": {"g": S("g1", msk["g"]), "h": S("g2", msk["h"]), "g_k": [S("g1", x) for x in msk["g_k"]],
+                           "a": [S("fr", x) for x in msk["a"]], "b": [S("fr", x) for x in msk["b"]]},
+                   "cp_sk": {"attr": ["A", "B"], "sk": skj(sk["sk"])}, "cp_ct": {"policy": [policy, "JsonPolicy"], "ct": ctj(ct["ct"], msg)},
+                   "kp_sk": {"policy": [policy, "JsonPolicy"], "sk": skj(ksk["sk"])}, "kp_ct": {"attr": ["A", "B"], "ct": ctj(kct["ct"], msg2)}}
+    # BSW
+    pk, msk = sch.bsw_setup(rng)
+    policy = '{"name": "and", "children": [{"name": "A"}, {"name": "B"}, {"name": "or", "children": [{"name": "C"}, {"name": "D"}]}]}'
+    msg = bn.gt_pow(e_base, rng.fr_nonzero())
+    ct = sch.bsw_encrypt(pk, policy, pol.JSON, rng, msg)
+    sk = sch.bsw_keygen(pk, msk, ["A", "B", "D"], rng)
+    at = lambda x: {"string": x["string"], "g1": S("g1", x["g1"]), "g2": S("g2", x["g2"])}
+    out["bsw"] = {"sk": {"d": S("g2", sk["d"]), "d_j": [at(x) for x in sk["d_j"]]},
+                  "ct": {"policy": [policy, J(ct["policy"][1])], "c": S("g1", ct["c"]), "c_p": S("gt", ct["c_p"]), "c_y": [at(x) for x in ct["c_y"]],
+                         "data": seal(msg)}}
+    # LSW
+    pk, msk = sch.lsw_setup(rng)
+    policy = '{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}'
+    sk = sch.lsw_keygen(pk, msk, policy, pol.JSON, rng)
+    msg = bn.gt_pow(e_base, rng.fr_nonzero())
+    ct = sch.lsw_encrypt(pk, ["B", "C"], rng, msg)
+    o = lambda kind, v: None if v is None else S(kind, v)
+    out["lsw"] = {"sk": {"policy": [policy, "JsonPolicy"], "dj": [[t[0], o("g1", t[1]), o("g2", t[2]), o("g1", t[3]), o("g1", t[4]), o("g1", t[5])] for t in sk["dj"]]},
+                  "ct": {"e1": S("gt", ct["e1"]), "e2": S("g2", ct["e2"]), "ej": [[t[0], S("g1", t[1]), S("g1", t[2]), S("g1", t[3])] for t in ct["ej"]],
+                         "ct": seal(msg)}}
+    # AW11
+    gk = sch.aw11_setup(rng)
+    pk1, msk1 = sch.aw11_authgen(gk, ["A", "B"], rng)
+    pk2, msk2 = sch.aw11_authgen(gk, ["C", "D"], rng)
+    policy = '{"name": "and", "children": [{"name": "A"}, {"name": "or", "children": [{"name": "C"}, {"name": "B"}]}]}'
+    sk = sch.aw11_keygen(gk, msk1, "bob", ["A"])
+    sk["attr"] += sch.aw11_keygen(gk, msk2, "bob", ["C"])["attr"]
+    msg = bn.gt_pow(e_base, rng.fr_nonzero())
+    ct = sch.aw11_encrypt(gk, [pk1, pk2], policy, pol.JSON, rng, msg)
+    out["aw11"] = {"gk": {"g1": S("g1", gk["g1"]), "g2": S("g2", gk["g2"])},
+                   "pks": [{"attr": [[n, S("gt", g), S("g2", y)] for n, g, y in p["attr"]]} for p in (pk1, pk2)],
+                   "msks": [{"attr": [[n, S("fr", a), S("fr", y)] for n, a, y in m["attr"]]} for m in (msk1, msk2)],
+                   "sk": {"gid": "bob", "attr": [[n, S("g1", p)] for n, p in sk["attr"]]},
+                   "ct": {"policy": [policy, "JsonPolicy"], "c_0": S("gt", ct["c_0"]), "c": [[t[0], S("gt", t[1]), S("g2", t[2]), S("g2", t[3])] for t in ct["c"]],
+                          "ct": seal(msg)}}
+    assert check_schemes(json.loads(json.dumps(out)), srcs, report["into_vec_u8"]) == ["ac17", "bsw", "lsw", "aw11"]
