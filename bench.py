@@ -80,8 +80,13 @@ def parse_args():
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for experiments (0 = leave the HIP default)")
     ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
-    ap.add_argument("--g-window", type=int, default=26,
-                    help="window width (bits) of the fixed-base table of g: 16 (67 MB), or 17..27 signed digits (24: 5.4 GB, 26: 19 GB)")
+    ap.add_argument("--g-window", type=int, default=20,
+                    help="window width (bits) of the fixed-base table of g: 16 (67 MB, unsigned digits), or 17..27 signed digits "
+                         "(20: 0.4 GB -- the default, a third of what the key's other tables take; 24: 5.4 GB; 26: 19 GB, reported as value_wide_tables)")
+    ap.add_argument("--wide-window", type=int, default=26, help="g-window of the informational value_wide_tables leg (0 = skip the leg)")
+    ap.add_argument("--no-single-batch", action="store_true", help="skip the informational single-batch legs (--group 1 submissions)")
+    ap.add_argument("--no-configs-leg", action="store_true", help="skip the bounded runs of BASELINE configs 3-5 (N = 1 only)")
+    ap.add_argument("--configs-min-time", type=float, default=0.3, help="timed seconds per config of the configs leg")
     ap.add_argument("--no-host-io-leg", action="store_true",
                     help="skip the informational second timed region in which every step also moves its inputs and outputs over PCIe")
     ap.add_argument("--only-encrypt", action="store_true", help="diagnostic: skip the decrypt half of every step (value is then not the metric)")
@@ -286,12 +291,11 @@ def main():
     sk_lines = None if args.no_prepared_sk else E.Ac17SkLines(eng, 1, dk0)
     eng.sync()
 
-    def submit(g_steps, lane=None):
-        """one launch set over g_steps contiguous batches"""
+    def submit(g_steps, lane=None, on=None):
+        """one launch set over g_steps contiguous batches (on = (engine context, its buffers) of an extra lane)"""
         i = launch_no[0] % S if lane is None else lane
         launch_no[0] += 1
-        e_ = lanes_ctx[i]
-        c0_, c_, cp_, out_ = bufs[i]
+        e_, (c0_, c_, cp_, out_) = on if on is not None else (lanes_ctx[i], bufs[i])
         n = g_steps * B
         E.ac17_encrypt_dev(e_, pk, n, dA, d_item_A_off, d_ct_row_off, g_steps * rows_per_batch, ds, dmsg, c0_, c_, cp_)
         if args.only_encrypt:
@@ -377,6 +381,48 @@ def main():
     }
     if gather is not None:
         result["gather"] = gather
+
+    # ---------------------------------------------------------------- informational: ONE batch of 4096 per launch set (BASELINE config 2
+    # words the workload as "batch of 4096"): its latency alone, and the rate of a stream of single-batch submissions with up to
+    # four of them in flight on separate HIP streams (what a server that receives batches one at a time sees)
+    if world == 1 and not args.no_single_batch and not args.only_encrypt:
+        # four lanes = four HIP streams in all (the main context's included): HIP's default of four hardware queues, one each
+        extra = [(eng, (eng.alloc(B * 3 * 128), eng.alloc(rows_per_batch * 3 * 64), eng.alloc(B * 384), ExtBuf(torch, B * 384, dev)), stream)]
+        for _ in range(3):
+            e2 = Engine(local_rank)
+            st2 = torch.cuda.Stream(device=local_rank)
+            e2.set_stream(st2.cuda_stream)
+            e2.set_pairing_mode(args.pairing_mode)
+            extra.append((e2, (e2.alloc(B * 3 * 128), e2.alloc(rows_per_batch * 3 * 64), e2.alloc(B * 384), ExtBuf(torch, B * 384, dev)), st2))
+        for e2, b2, _ in extra:
+            submit(1, on=(e2, b2))
+            e2.sync()
+        torch.cuda.synchronize()
+        reps = 6
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            submit(1, on=(extra[0][0], extra[0][1]))
+            extra[0][0].sync()
+        lat = (time.perf_counter() - t0) / reps
+        single = {"batch": B, "latency_ms": round(1e3 * lat, 3), "ops_per_s_alone": round(B / lat, 1)}
+        for k_in in (2, 4):
+            n_sub = 8 * k_in
+            t0 = time.perf_counter()
+            for j in range(n_sub):
+                e2, b2, _ = extra[j % k_in]
+                submit(1, on=(e2, b2))
+            for e2, _, _ in extra[:k_in]:
+                e2.sync()
+            dt = time.perf_counter() - t0
+            single["ops_per_s_%d_in_flight" % k_in] = round(n_sub * B / dt, 1)
+        single["roundtrip_bit_exact"] = all(b2[3].t[:B * 384].cpu().numpy().tobytes() == want[:B * 384] for _, b2, _ in extra)
+        single["fraction_of_grouped_rate"] = round(single["ops_per_s_4_in_flight"] / value, 3)
+        single["note"] = ("one step per launch set (--group 1): a lone batch is 64 final-exponentiation waves and 192-384 Miller waves on 1024 SIMDs, and its "
+                          "latency is the serial chain Miller -> final exponentiation of one lane (~14 k dependent Fp multiplications); batches in flight "
+                          "on separate streams overlap each other's chains")
+        result["single_batch"] = single
+        for e2, _, _ in extra[1:]:
+            e2.close()
 
     # ---------------------------------------------------------------- informational: the same steps with host buffers
     # (inputs s, msg uploaded; ciphertext c_0, c, c_p and the decrypted Gt downloaded; pinned memory, copies on a copy
@@ -490,6 +536,8 @@ def main():
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        macs_impl = lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL
+        achieved_impl = macs_impl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # whole step against the same peak: SURVEY 8d's 0.12 M Fp-mul per op (16.4 M MAC32)
         step_macs = 0.12e6 * MAC_PER_FPMUL * B
         # HBM side (reported, not binding): algorithmic bytes of the whole step
@@ -499,11 +547,15 @@ def main():
             "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
             "kernel_ms": round(dom_ms, 4), "items_per_launch": NB, "steps_per_launch": G,
             "kernel_ms_per_step": round(dom_ms / G, 4),
-            "achieved": round(achieved, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
-            "frac": round(achieved / peak_tmac, 4) if peak_tmac else None,
-            "work": "algorithmic Fp-muls/lane (SURVEY 8d) x 136 MAC32 x lanes = %.3e MAC32 per launch" % macs,
-            "achieved_impl_count": round(lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL / (dom_ms * 1e-3) / 1e12, 4)
-            if dom_ms > 0 else None,
+            "achieved": round(achieved_impl, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
+            "frac": round(achieved_impl / peak_tmac, 4) if peak_tmac else None,
+            "work": "Fp multiplications this engine executes per lane (instrumented: tests/count_muls.py) x 136 MAC32 x lanes = %.3e MAC32 per launch"
+                    % macs_impl,
+            "achieved_survey": round(achieved, 4),
+            "frac_survey": round(achieved / peak_tmac, 4) if peak_tmac else None,
+            "work_survey": "SURVEY.md 8d's algorithmic constants (8 k Fp-mul per Miller loop) x 136 MAC32 x lanes = %.3e MAC32 per launch; the engine "
+                           "executes fewer multiplications than that (shared squarings, merged and prepared lines), so frac_survey overstates the "
+                           "utilisation of the multiplier -- `frac` is the honest figure" % macs,
             "whole_step_frac": round(step_macs / (elapsed / args.steps) / 1e12 / peak_tmac, 4) if peak_tmac else None,
             "traffic": traffic, "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
             "traffic_source": traffic_src,
@@ -532,14 +584,73 @@ def main():
                     result["cpu_baseline_multicore"] = mc
             except Exception as ex:
                 result["cpu_baseline_multicore"] = {"error": repr(ex)}
+        # ------------------------------------------------------------ informational: the same steps with the WIDE table of g (memory for work)
+        if world == 1 and args.wide_window > 16 and args.wide_window != args.g_window and not args.only_encrypt:
+            try:
+                eng.sync()
+                t_w = time.perf_counter()
+                pk.set_g_window(args.wide_window)
+                eng.sync()
+                wide_build_ms = 1e3 * (time.perf_counter() - t_w)
+                run_steps()
+                sync_all()
+                reg_w = timed_regions(run_steps, sync_all, min(0.4, args.min_time))
+                el_w = sum(reg_w) / len(reg_w)
+                v_w = B * args.steps / el_w
+                wb = 64 * sum(E.wide_count(args.wide_window, i) for i in range(E.wide_windows(args.wide_window)))
+                result["value_wide_tables"] = {
+                    "value": round(v_w, 2), "unit": "ops/s", "ms_per_step": round(1e3 * el_w / args.steps, 4), "g_window_bits": args.wide_window,
+                    "g_table_bytes": wb, "build_ms_per_public_key": round(wide_build_ms, 1), "break_even_ops": round(wide_build_ms * 1e-3 * v_w),
+                    "speedup_over_value": round(v_w / value, 4),
+                    "note": "same timed region with a %d-bit signed-window table of g (%.1f GB per public key instead of %.2f GB): %d instead of %d mixed "
+                            "additions per fixed-base multiplication; not the headline because it makes the number single-tenant"
+                            % (args.wide_window, wb / 1e9, g_table_bytes / 1e9, E.wide_windows(args.wide_window),
+                               16 if gw <= 16 else E.wide_windows(gw))}
+            except Exception as ex:
+                result["value_wide_tables"] = {"error": repr(ex)}
+        # ------------------------------------------------------------ BASELINE configs 3-5, bounded (their own processes: fresh tables, fresh memory)
+        if world == 1 and not args.no_configs_leg and not args.only_encrypt:
+            pk.destroy()
+            pk = None
+            result["configs"] = configs_leg(args)
         print(json.dumps(result), flush=True)
 
-    pk.destroy()
+    if pk is not None:
+        pk.destroy()
     for e_ in lanes_ctx[1:]:
         e_.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def configs_leg(args):
+    """`python bench.py --config K` for K = 3, 4, 5 as bounded sub-runs (a few steps, --configs-min-time seconds timed each, default --
+    i.e. small -- AW11 attribute tables), so that the driver's one default run carries every BASELINE configuration.  Each
+    entry is that run's own JSON line reduced to the fields a reviewer checks."""
+    out = {}
+    env = dict(os.environ)
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    for cfg, steps in ((3, 4), (4, 4), (5, 8)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--steps", str(steps), "--warmup", str(steps),
+               "--min-time", str(args.configs_min_time), "--no-cpu-baseline", "--seed", str(args.seed)]
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
+            d = json.loads(line)
+            rf = d.get("roofline", {})
+            out[str(cfg)] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                             "batch_per_gpu": d["config"]["batch_per_gpu"], "workload": d["config"]["workload"],
+                             "steps_per_launch_set": d["config"]["steps_per_launch_set"], "roundtrip_bit_exact": d["roundtrip_bit_exact"],
+                             "timed_regions": {"count": d["timed_regions"]["count"], "ms_mean": d["timed_regions"]["ms_mean"]},
+                             "roofline": {"kernel": rf.get("kernel"), "kernel_ms": rf.get("kernel_ms"), "frac": rf.get("frac"),
+                                          "frac_survey": rf.get("frac_survey"), "peak": rf.get("peak"), "kernels_ms": rf.get("kernels_ms")},
+                             "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as ex:
+            out[str(cfg)] = {"error": repr(ex)[:300]}
+    return out
 
 
 def object_api_leg(args, trees):
@@ -570,17 +681,28 @@ def object_api_leg(args, trees):
         ct_buf[:] = 0
         pt_buf = np.zeros(ct_buf.size, dtype=np.uint8)
         best = None
+        best_tr = None
+        ok_packed = True
         for rep in range(4):
             t0 = time.perf_counter()
             ct_blob, ct_off = ac17.cp_encrypt_packed(host, pk, pols, item_pol, pt_np, pt_off, out=ct_buf)
             t1 = time.perf_counter()
-            out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf)
+            out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf)          # checked: membership pass on
             t2 = time.perf_counter()
+            ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any() and (out_off == pt_off).all()
+            out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf, trusted=True)
+            t3 = time.perf_counter()
+            ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any()
             if rep and (best is None or t2 - t0 < best[0]):
                 best = (t2 - t0, t1 - t0, t2 - t1)
-        ok_packed = out_blob.tobytes() == pt_blob and not status.any() and (out_off == pt_off).all()
+            if rep and (best_tr is None or t3 - t2 < best_tr):
+                best_tr = t3 - t2
         packed = {"ops_per_s": round(n / best[0], 1), "encrypt_s": round(best[1], 4), "decrypt_s": round(best[2], 4), "batch": n,
-                  "ciphertext_bytes": int(ct_blob.size), "plaintexts_match": bool(ok_packed)}
+                  "decrypt_trusted_s": round(best_tr, 4), "ops_per_s_trusted": round(n / (best[1] + best_tr), 1),
+                  "ciphertext_bytes": int(ct_blob.size), "plaintexts_match": bool(ok_packed),
+                  "note": "decrypt_s includes the batched group-membership pass over every decoded element (c_0 in G2's r-torsion, rows on the G1 "
+                          "curve, c_p in Gt's order-r subgroup, coordinates < p): the default for external ciphertexts; *_trusted skips it "
+                          "(RABE_PACKED_TRUSTED)"}
         # ---- one object handle per ciphertext (round 1's path), one step's worth
         n = args.batch
         pts = pts[:n]

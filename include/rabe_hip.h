@@ -86,6 +86,10 @@ int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other);
  *   G1/G2: + - neg, * Fr             ac17/mod.rs:219,235-240,300-302,343-348,406-415
  *   Gt: * inverse pow                ac17/mod.rs:357-360,418; bsw/mod.rs:234,291-294,308
  *   pairing(G1,G2)                   ac17/mod.rs:148,415-416; bsw/mod.rs:108,292-293,308
+ * Scalars (rhip_fr operands of * Fr, pow, the MSM / selection coefficients of Level B) are canonical records (< r).  A record
+ * that is not is brought below r where it is loaded, so `k * P` is the group's answer for every 256-bit word; nothing relies on
+ * the caller having checked.  Group elements are NOT validated by the arithmetic entry points: rhip_g1_on_curve /
+ * rhip_g2_in_subgroup / rhip_gt_is_member (which also reject non-canonical coordinates >= p) are the decoding checks.
  */
 /* RHIP_FR_POW: out = a^b with b read as an integer (`Fr::pow(Fr)`, src/utils/secretsharing/mod.rs:218) */
 enum { RHIP_FR_ADD = 0, RHIP_FR_SUB = 1, RHIP_FR_MUL = 2, RHIP_FR_NEG = 3, RHIP_FR_INV = 4, RHIP_FR_POW = 5 };
@@ -140,6 +144,9 @@ int32_t rhip_host_fr_from_be32_reduce(rhip_ctx* ctx, const uint8_t digest[32], r
 /* curve membership of a decoded point (what makes `FieldError::NotMember`, src/error.rs:66): *ok = 1 on the curve or infinity */
 int32_t rhip_host_g1_on_curve(rhip_ctx* ctx, const rhip_g1* p, int32_t* ok);
 int32_t rhip_host_g2_on_curve(rhip_ctx* ctx, const rhip_g2* p, int32_t* ok);
+/* the full decoding checks of one element: canonical coordinates, on the twist and r * P = O / in the order-r subgroup of Fq12 */
+int32_t rhip_host_g2_in_subgroup(rhip_ctx* ctx, const rhip_g2* p, int32_t* ok);
+int32_t rhip_host_gt_is_member(rhip_ctx* ctx, const rhip_gt* a, int32_t* ok);
 int32_t rhip_host_g1_add(rhip_ctx* ctx, const rhip_g1* a, const rhip_g1* b, rhip_g1* out);
 int32_t rhip_host_g1_neg(rhip_ctx* ctx, const rhip_g1* a, rhip_g1* out);
 int32_t rhip_host_g1_mul(rhip_ctx* ctx, const rhip_g1* p, const rhip_fr* k, rhip_g1* out);
@@ -348,8 +355,9 @@ int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
  * rhip_aw11_pk: gk (g1, g2), the constant e(g1, g2) and, for each of the n_attrs attributes of the authorities in play,
  * (egg_alpha_x, g2 * y_x) (Aw11PublicKey.attr, :56-61) as window tables.  leaf_attr[leaf] (per policy leaf, beside the
  * flattened tree tables) = the attribute's index in those arrays.  The per-attribute tables are 8-bit windows (4.2 MB per
- * attribute) and, when the device has the room plus 48 GB to spare, 16-bit windows as well (536 MB per attribute, 107 GB for
- * 200: half the table entries per power; environment RABE_AW11_ATTR_W16=0 / =1 forces the choice).  Results do not depend on it. */
+ * attribute).  16-bit windows as well (536 MB per attribute, 107 GB for 200: half the table entries per power) are OPT-IN through
+ * the environment variable RABE_AW11_ATTR_W16=1, and even then only built while they leave a quarter of the device memory free.
+ * Results do not depend on it. */
 typedef struct rhip_aw11_pk rhip_aw11_pk;
 int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, size_t n_attrs,
                             const rhip_gt* host_egg_alpha /*[n_attrs]*/, const rhip_g2* host_g2_y /*[n_attrs]*/, rhip_aw11_pk** out);

@@ -71,13 +71,20 @@ int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sk
  *   encrypt: item i uses policies[item_policy[i]] (distinct policy texts are parsed once, and cached across calls).  ct_off is
  *            always filled; return 1 (nothing done, no randomness drawn) when ct_cap < ct_off[n_items], the size the records need.
  *   decrypt: status[i] = 0 / -1 per item (a key that does not satisfy a policy, a malformed record or an authentication failure
- *            fails that item only; its plaintext is empty).  pt_cap >= ct_off[n_items] - ct_off[0] always suffices; return 1 when
- *            it is smaller. */
+ *            fails that item only; its plaintext is empty).  pt_cap >= the sum of the sizes of the records whose bounds are valid always suffices (<= ct_len unless records overlap);
+ *            return 1 when it is smaller. */
 int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                     const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
                                     uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
-int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, const uint64_t* ct_off /*[n_items+1]*/,
-                                    int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off /*[n_items+1]*/);
+/* decrypt reads UNTRUSTED bytes: ct_len is the size of ct_blob, and ct_off must be monotone inside it (an item whose bounds are not
+ * fails alone with status -1; nothing outside [0, ct_len) is read).  Unless RABE_PACKED_TRUSTED is set in `flags`, every decoded element
+ * goes through one batched membership pass on the GPU -- coordinates < p, rows on the G1 curve, c_0 in the r-torsion of the twist, c_p in
+ * the order-r subgroup of Fq12 (rabe-bn: FieldError::NotMember) -- and a non-member fails its item only.  Set the flag only for
+ * ciphertexts this process produced itself. */
+#define RABE_PACKED_TRUSTED 1u
+int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
+                                    const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf,
+                                    size_t pt_cap, uint64_t* pt_off /*[n_items+1]*/);
 
 /* KP-ABE variant (src/schemes/ac17/mod.rs:439-675) */
 int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, int32_t language, void** sk);

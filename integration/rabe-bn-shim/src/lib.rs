@@ -44,6 +44,8 @@ extern "C" {
     fn rhip_host_g2_neg(ctx: *mut RhipCtx, a: *const G2, out: *mut G2) -> i32;
     fn rhip_host_g2_mul(ctx: *mut RhipCtx, p: *const G2, k: *const Fr, out: *mut G2) -> i32;
     fn rhip_host_g2_on_curve(ctx: *mut RhipCtx, p: *const G2, ok: *mut i32) -> i32;
+    fn rhip_host_g2_in_subgroup(ctx: *mut RhipCtx, p: *const G2, ok: *mut i32) -> i32;
+    fn rhip_host_gt_is_member(ctx: *mut RhipCtx, a: *const Gt, ok: *mut i32) -> i32;
     fn rhip_host_gt_mul(ctx: *mut RhipCtx, a: *const Gt, b: *const Gt, out: *mut Gt) -> i32;
     fn rhip_host_gt_inv(ctx: *mut RhipCtx, a: *const Gt, out: *mut Gt) -> i32;
     fn rhip_host_gt_pow(ctx: *mut RhipCtx, a: *const Gt, k: *const Fr, out: *mut Gt) -> i32;
@@ -197,7 +199,8 @@ pub fn pairing(p: G1, q: G2) -> Gt { let mut o = Gt::one(); ok(unsafe { rhip_hos
 // ASSUMPTION: the byte layout.  rabe-bn's own encodings are unknown here; this crate encodes every
 // element as its canonical wire record (little-endian limbs, the layouts of include/rabe_hip.h), so rabe built against it
 // round-trips its own files; interoperability with files written by the real rabe-bn is the open item of DESIGN.md 7.
-// Decoding validates what rabe-bn's decoding validates: scalars are < r, points are on the curve (FieldError::NotMember).
+// Decoding validates what rabe-bn's decoding validates: scalars are < r, coordinates < p (one encoding per element, so `==` is byte
+// equality), points on the curve / in the subgroup (FieldError::NotMember).  rhip_host_g1_on_curve rejects coordinates >= p itself.
 trait Wire: Sized {
     const BYTES: usize;
     fn to_wire(&self, out: &mut [u8]);
@@ -235,9 +238,9 @@ impl Wire for G2 {
     fn from_wire(b: &[u8]) -> Result<G2, FieldError> {
         let p = G2(bytes_to_words::<32>(b)?);
         let mut on = 0i32;
-        ok(unsafe { rhip_host_g2_on_curve(ctx(), &p, &mut on) });
-        // r-torsion: the twist has cofactor > 1, so an on-curve point may still be outside G2
-        if on == 1 && (p * (Fr::zero() - Fr::one()) + p).is_zero() { Ok(p) } else { Err(FieldError::NotMember) }
+        // canonical coordinates (< p), on the twist, and in its r-torsion (the twist has cofactor > 1): one engine call
+        ok(unsafe { rhip_host_g2_in_subgroup(ctx(), &p, &mut on) });
+        if on == 1 { Ok(p) } else { Err(FieldError::NotMember) }
     }
 }
 impl Wire for Gt {
@@ -245,8 +248,11 @@ impl Wire for Gt {
     fn to_wire(&self, out: &mut [u8]) { words_to_bytes(&self.0, out) }
     fn from_wire(b: &[u8]) -> Result<Gt, FieldError> {
         let g = Gt(bytes_to_words::<96>(b)?);
-        // membership in the order-r subgroup: g^(r-1) * g == 1 (also rejects non-unitary values the engine's Gt::pow assumes away)
-        if g.pow(Fr::zero() - Fr::one()) * g == Gt::one() { Ok(g) } else { Err(FieldError::NotMember) }
+        // canonical coefficients, cyclotomic (Frobenius test) FIRST, then order r: Gt::pow's cyclotomic squarings are only valid
+        // once the first test has passed, which is why this is the engine's k_gt_is_member and not a pow here
+        let mut on = 0i32;
+        ok(unsafe { rhip_host_gt_is_member(ctx(), &g, &mut on) });
+        if on == 1 { Ok(g) } else { Err(FieldError::NotMember) }
     }
 }
 

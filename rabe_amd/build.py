@@ -24,8 +24,12 @@ def _headers():
     return deps
 
 
-def _obj(src):
-    return os.path.join(OBJ, os.path.basename(src) + ".o")
+LIB_SAFE = os.path.join(HERE, "librabe_hip_safe.so")          # the RB_SAFE_CARRY build of the same sources (fp.h): an A/B reference
+DEVICE_SOURCES = SOURCES[:2]
+
+
+def _obj(src, safe=False):
+    return os.path.join(OBJ, os.path.basename(src) + (".safe.o" if safe else ".o"))
 
 
 def _flags():
@@ -40,8 +44,8 @@ def stale():
     return any(os.path.getmtime(d) > t for d in _headers() + [s for s in SOURCES if os.path.exists(s)])
 
 
-def _compile(src, verbose):
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src)] + _flags()
+def _compile(src, verbose, safe=False):
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src, safe)] + _flags() + (["-DRB_SAFE_CARRY"] if safe else [])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, timeout=3000)
@@ -69,5 +73,43 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_safe(force=False, verbose=False):
+    """librabe_hip_safe.so: the two device translation units compiled with -DRB_SAFE_CARRY (every carry dependency padded with the
+    wait states LLVM's gfx940+ hazard table asks for, compiler-scheduled additive chains), linked with the host objects of the
+    normal build.  tests/test_gpu_carry_interlock.py runs the same vectors through both libraries and requires identical bytes."""
+    build(force=force, verbose=verbose)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    todo = [s for s in DEVICE_SOURCES if force or not os.path.exists(_obj(s, True)) or os.path.getmtime(_obj(s, True)) < max(hdr_t, os.path.getmtime(s))]
+    if not todo and os.path.exists(LIB_SAFE) and os.path.getmtime(LIB_SAFE) >= os.path.getmtime(LIB):
+        return LIB_SAFE
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(todo)) as ex:
+            for f in [ex.submit(_compile, s, verbose, True) for s in todo]:
+                f.result()
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_SAFE] + [_obj(s, s in DEVICE_SOURCES) for s in srcs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, timeout=600)
+    return LIB_SAFE
+
+
+def build_tools(verbose=False):
+    """build/ubench_addc: the carry-chain equality check tests/test_gpu_carry_interlock.py runs on the GPU box"""
+    src = os.path.join(os.path.dirname(HERE), "tools", "ubench_addc.hip")
+    exe = os.path.join(os.path.dirname(HERE), "build", "ubench_addc")
+    if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+        return exe
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", src, "-o", exe]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, timeout=600)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--safe" in sys.argv:
+        print(build_safe(force="--force" in sys.argv, verbose=True))
+        print(build_tools(verbose=True))

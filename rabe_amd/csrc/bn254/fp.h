@@ -93,7 +93,20 @@ RB_HD Mont<M> one() {
   return r;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// RB_SAFE_CARRY (a build switch, `python -m rabe_amd.build --safe`): every carry dependency gets the wait states LLVM's gfx940+
+// hazard table asks for -- the additive chains fall back to compiler-scheduled code (which hipcc pads itself), the multiply-
+// accumulate statements put `s_nop 1` between a carry-writing instruction and its first reader (RB_CPAD), fp_lin9 falls back to
+// the doubling form.  The fast build relies on the hardware interlocking these dependencies (tools/ubench_addc.hip);
+// tests/test_gpu_carry_interlock.py runs the same vectors through both builds and requires identical bytes.
+#if defined(RB_SAFE_CARRY)
+#define RB_CPAD "s_nop 1\n\t"
+#ifndef RB_NO_LIN9
+#define RB_NO_LIN9
+#endif
+#else
+#define RB_CPAD ""
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RB_SAFE_CARRY)
 // ---- gfx950 carry chains.  hipcc pads every carry-dependent v_addc / v_subb with two wait states (LLVM's gfx940+ rule "VALU
 // writes SGPR/VCC -> VALU reads it"); with one wave per SIMD each pad costs ~6 cycles, which doubles the time of an add / sub
 // chain (tools/ubench_addc.hip: 113 vs 55 cycles per 9-instruction chain) -- ~15 % of a pairing kernel.  The hardware interlocks
@@ -387,22 +400,22 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
       : "+v"(A0), "+v"(A1), "=&s"(c0_) : "v"(X0), "v"(X1), "s"(Y))
 #define RB_MAC2(A0, O0, X0, Y0, A1, O1, X1, Y1)                                                       \
   asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %2, %5, %8, %9, %2\n\t"                      \
-      "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "=&s"(c0_), "=&s"(c1_)                                \
       : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1))
 #define RB_MAC2_S(A0, O0, X0, A1, O1, X1, Y)                                                          \
   asm("v_mad_u64_u32 %0, %4, %6, %8, %0\n\tv_mad_u64_u32 %2, %5, %7, %8, %2\n\t"                      \
-      "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\tv_addc_co_u32_e64 %3, %5, 0, %3, %5"                    \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "=&s"(c0_), "=&s"(c1_)                                \
       : "v"(X0), "v"(X1), "s"(Y))
 #define RB_MAC2F(A0, O0, X0, Y0, A1, O1, X1, Y1)                                                      \
   asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %2, %5, %8, %9, %2\n\t"                      \
-      "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
       : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "=&s"(c0_), "=&s"(c1_)                              \
       : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1))
 #define RB_MAC2F_S(A0, O0, X0, A1, O1, X1, Y)                                                         \
   asm("v_mad_u64_u32 %0, %4, %6, %8, %0\n\tv_mad_u64_u32 %2, %5, %7, %8, %2\n\t"                      \
-      "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %4, 0, 0, %4\n\tv_addc_co_u32_e64 %3, %5, 0, 0, %5"                      \
       : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "=&s"(c0_), "=&s"(c1_)                              \
       : "v"(X0), "v"(X1), "s"(Y))
 #define RB_MAD3(A0, X0, Y0, A1, X1, Y1, A2, X2, Y2)                                                   \
@@ -414,28 +427,28 @@ RB_HD void mont_mul_raw(uint32_t* r, const A& a, const B& b) {
 #define RB_MAC3(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2)                                       \
   asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\tv_mad_u64_u32 %2, %7, %11, %12, %2\n\t"                   \
       "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"                                                        \
-      "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
       "v_addc_co_u32_e64 %5, %8, 0, %5, %8"                                                           \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "+v"(A2), "+v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
       : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "v"(X2), "v"(Y2))
 #define RB_MAC3_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y)                                              \
   asm("v_mad_u64_u32 %0, %6, %9, %12, %0\n\tv_mad_u64_u32 %2, %7, %10, %12, %2\n\t"                   \
       "v_mad_u64_u32 %4, %8, %11, %12, %4\n\t"                                                        \
-      "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\tv_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"                \
       "v_addc_co_u32_e64 %5, %8, 0, %5, %8"                                                           \
       : "+v"(A0), "+v"(O0), "+v"(A1), "+v"(O1), "+v"(A2), "+v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
       : "v"(X0), "v"(X1), "v"(X2), "s"(Y))
 #define RB_MAC3F(A0, O0, X0, Y0, A1, O1, X1, Y1, A2, O2, X2, Y2)                                      \
   asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\tv_mad_u64_u32 %2, %7, %11, %12, %2\n\t"                   \
       "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"                                                        \
-      "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
       "v_addc_co_u32_e64 %5, %8, 0, 0, %8"                                                            \
       : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "+v"(A2), "=&v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
       : "v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "v"(X2), "v"(Y2))
 #define RB_MAC3F_S(A0, O0, X0, A1, O1, X1, A2, O2, X2, Y)                                             \
   asm("v_mad_u64_u32 %0, %6, %9, %12, %0\n\tv_mad_u64_u32 %2, %7, %10, %12, %2\n\t"                   \
       "v_mad_u64_u32 %4, %8, %11, %12, %4\n\t"                                                        \
-      "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
+      "" RB_CPAD "v_addc_co_u32_e64 %1, %6, 0, 0, %6\n\tv_addc_co_u32_e64 %3, %7, 0, 0, %7\n\t"                  \
       "v_addc_co_u32_e64 %5, %8, 0, 0, %8"                                                            \
       : "+v"(A0), "=&v"(O0), "+v"(A1), "=&v"(O1), "+v"(A2), "=&v"(O2), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_) \
       : "v"(X0), "v"(X1), "v"(X2), "s"(Y))

@@ -32,6 +32,19 @@ RB_HD void store_fr(uint32_t* p, const Fr& a) {
 #pragma unroll
   for (int i = 0; i < 8; i++) p[i] = t[i];
 }
+// decoding check of the membership entry points: each of the n little-endian 256-bit words at p is a canonical field element
+// (< p).  load_fp itself reduces any 256-bit word (to_mont is exact for every input), so a non-canonical coordinate would
+// otherwise be a second accepted encoding of the same element; rabe-bn's decoding rejects it (FieldError::NotMember).
+RB_HD bool wire_words_canonical(const uint32_t* p, int n) {
+  bool ok = true;
+  for (int e = 0; e < n; e++) {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) (void)subb32(p[8 * e + i], FpParams::mod(i), borrow);
+    ok = ok && (borrow != 0);          // x - p borrows  <=>  x < p
+  }
+  return ok;
+}
 RB_HD Fp2 load_fp2(const uint32_t* p) { return Fp2{load_fp(p), load_fp(p + 8)}; }
 RB_HD void store_fp2(uint32_t* p, const Fp2& a) { store_fp(p, a.c0); store_fp(p + 8, a.c1); }
 RB_HD G1Aff load_g1(const uint32_t* p) { return G1Aff{load_fp(p), load_fp(p + 8)}; }

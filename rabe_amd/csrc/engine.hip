@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, RB_G1_WAVES) k_g1_mul(size_t n, const rhi
 __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_g1_on_curve(size_t n, const rhip_g1* p, uint32_t* ok) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  ok[i] = aff_on_curve(load_g1(p[i].l)) ? 1u : 0u;
+  ok[i] = (wire_words_canonical(p[i].l, 2) && aff_on_curve(load_g1(p[i].l))) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_add(size_t n, const rhip_g2* a, const rhip_g2* b, rhip_g2* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_mul(size_t n, const rh
 __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_on_curve(size_t n, const rhip_g2* p, uint32_t* ok) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  ok[i] = aff_on_curve(load_g2(p[i].l)) ? 1u : 0u;
+  ok[i] = (wire_words_canonical(p[i].l, 4) && aff_on_curve(load_g2(p[i].l))) ? 1u : 0u;
 }
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_mul(size_t n, const rhip_gt* a, const rhip_gt* b, rhip_gt* out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -572,10 +572,19 @@ struct rhip_ac17_pk {
 };
 
 
-// three Jacobian points -> affine canonical with ONE field inversion per BLOCK (Montgomery's trick twice:
-// over the thread's three z's, then over the block's products).  Inactive threads pass active = false.
-__device__ __noinline__ void store3_g1_block(uint32_t* lds, bool active, rhip_g1* out, const G1Jac& a, const G1Jac& b, const G1Jac& c) {
-  // infinity has z = 0: substitute 1 so the product stays invertible, emit zeros for that slot
+// three Jacobian points -> affine canonical with ONE field inversion per BLOCK (Montgomery's trick twice: over the thread's
+// three z's, then over the block's products).  Inactive threads pass active = false.
+// The row kernels' form: the first two points are PARKED, as Jacobian Montgomery values, in the row's own output slots (3 x 64 B
+// of affine output = exactly 2 x 96 B) by the lane that computed them; the third arrives in registers.  Everything is read into
+// registers before the first affine point is stored over the parked data.
+__device__ __noinline__ void store3_g1_block_parked(uint32_t* lds, bool active, rhip_g1* out, Fp cx, Fp cy, Fp cz) {
+  G1Jac a = jac_inf<Fp>(), b = jac_inf<Fp>();
+  const G1Jac c{cx, cy, cz};
+  if (active) {
+    const G1Jac* park = (const G1Jac*)out;
+    a = park[0];
+    b = park[1];
+  }
   const bool ia = !active || jac_is_inf(a), ib = !active || jac_is_inf(b), ic = !active || jac_is_inf(c);
   Fp za = ia ? one<FpParams>() : a.z, zb = ib ? one<FpParams>() : b.z, zc = ic ? one<FpParams>() : c.z;
   Fp ab = mul(za, zb);
@@ -586,10 +595,14 @@ __device__ __noinline__ void store3_g1_block(uint32_t* lds, bool active, rhip_g1
   Fp inv_ab = mul(inv_abc, zc);
   Fp zb_inv = mul(inv_ab, za);
   Fp za_inv = mul(inv_ab, zb);
-  store_g1(out[0].l, ia ? aff_inf<Fp>() : jac_to_aff_with_zinv(a, za_inv));
-  store_g1(out[1].l, ib ? aff_inf<Fp>() : jac_to_aff_with_zinv(b, zb_inv));
-  store_g1(out[2].l, ic ? aff_inf<Fp>() : jac_to_aff_with_zinv(c, zc_inv));
+  const G1Aff ra = ia ? aff_inf<Fp>() : jac_to_aff_with_zinv(a, za_inv);
+  const G1Aff rb = ib ? aff_inf<Fp>() : jac_to_aff_with_zinv(b, zb_inv);
+  const G1Aff rc = ic ? aff_inf<Fp>() : jac_to_aff_with_zinv(c, zc_inv);
+  store_g1(out[0].l, ra);
+  store_g1(out[1].l, rb);
+  store_g1(out[2].l, rc);
 }
+static_assert(sizeof(G1Jac) == 96 && 2 * sizeof(G1Jac) == 3 * sizeof(rhip_g1), "two parked Jacobian points fill a row's three output records");
 
 // one lane per ciphertext row (items may carry different policies):
 //   c[row][l] = g * (s0*A[a][l][0] + s1*A[a][l][1]), l = 0..2, where item = the i with
@@ -609,18 +622,24 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_enc_rows(co
   }
   const size_t item = lo;
   const size_t arow = (size_t)item_A_off[item] + (t - row_off[item]);
-  Fr s0 = load_fr(s[2 * item].l), s1 = load_fr(s[2 * item + 1].l);
-  G1Jac pt[3];
+  // ONE accumulator is live at a time: the table walk is inlined (the accumulator stays in registers), the finished points of
+  // l = 0, 1 are parked in the row's output slots and picked up by the block conversion
+  G1Jac* park = (G1Jac*)(c + t * 3);
+  G1Jac r = jac_inf<Fp>();
 #pragma unroll 1
   for (int l = 0; l < 3; l++) {
-    Fr a0 = load_fr(A[(arow * 3 + l) * 2].l), a1 = load_fr(A[(arow * 3 + l) * 2 + 1].l);
-    Fr k = add(mul(s0, a0), mul(s1, a1));
+    Fr k;
+    {
+      const Fr s0 = load_fr(s[2 * item].l), s1 = load_fr(s[2 * item + 1].l);
+      const Fr a0 = load_fr(A[(arow * 3 + l) * 2].l), a1 = load_fr(A[(arow * 3 + l) * 2 + 1].l);
+      k = add(mul(s0, a0), mul(s1, a1));
+    }
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
-    G1Jac r = (w16 > 16) ? table_mul_g1_wide(g_tbl, kk, w16) : w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
-    if (l == 0) pt[0] = r; else if (l == 1) pt[1] = r; else pt[2] = r;
+    r = (w16 > 16) ? table_mul_g1_wide_inl(g_tbl, kk, w16) : w16 ? table_mul_g1_w16_inl(g_tbl, kk) : table_mul_g1(g_tbl, kk);
+    if (l < 2 && active) park[l] = r;
   }
-  store3_g1_block(sh, active, c + t * 3, pt[0], pt[1], pt[2]);
+  store3_g1_block_parked(sh, active, c + t * 3, r.x, r.y, r.z);
 }
 // one lane per (item, j<3): c_0[item][j] = h_a[j] * (s0 | s1 | s0+s1)
 __global__ void __launch_bounds__(128, RB_G2_WAVES) k_ac17_enc_c0(const G2M* t0, const G2M* t1, const G2M* t2, size_t n_items,
@@ -675,7 +694,9 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_keygen_rows
   Fr br[3] = {mul(load_fr(b[0].l), r0), mul(load_fr(b[1].l), r1), add(r0, r1)};
   Fr sg = load_fr(is_kp ? sigma_p[item].l : sigma[item * n_attrs + y].l);
   const rhip_fr* Hy = is_kp ? H01 : (H + y * 6);
-  G1Jac pt[3];
+  rhip_g1* dst = is_kp ? (kp_out + item * 3) : (k_out + (item * n_attrs + y) * 3);
+  G1Jac* park = (G1Jac*)dst;
+  G1Jac rj = jac_inf<Fp>();
 #pragma unroll 1
   for (int tt = 0; tt < 3; tt++) {
     Fr k;
@@ -692,12 +713,11 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_keygen_rows
     }
     uint32_t kk[8];
     from_mont<FrParams>(kk, k);
-    G1Jac rj = (w16 > 16) ? table_mul_g1_wide(g_tbl, kk, w16) : w16 ? table_mul_g1_w16(g_tbl, kk) : table_mul_g1(g_tbl, kk);
+    rj = (w16 > 16) ? table_mul_g1_wide_inl(g_tbl, kk, w16) : w16 ? table_mul_g1_w16_inl(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (is_kp) rj = jac_add_aff(rj, load_g1(g_k[tt].l));
-    if (tt == 0) pt[0] = rj; else if (tt == 1) pt[1] = rj; else pt[2] = rj;
+    if (tt < 2 && active) park[tt] = rj;
   }
-  rhip_g1* dst = is_kp ? (kp_out + item * 3) : (k_out + (item * n_attrs + y) * 3);
-  store3_g1_block(sh, active, dst, pt[0], pt[1], pt[2]);
+  store3_g1_block_parked(sh, active, dst, rj.x, rj.y, rj.z);
 }
 // k_0[item][j] = h * (b0 r0 | b1 r1 | r0 + r1)
 __global__ void __launch_bounds__(128, RB_G2_WAVES) k_ac17_keygen_k0(const G2M* h_tbl, const rhip_fr* b, size_t n_items, const rhip_fr* r, rhip_g2* k0,
@@ -1138,6 +1158,25 @@ extern "C" int32_t rhip_host_g2_on_curve(rhip_ctx* ctx, const rhip_g2* p, int32_
   HOSTOP_TRY(rhip_g2_on_curve(ctx, 1, (const rhip_g2*)hb.d, (uint32_t*)(hb.d + 128)));
   uint32_t v = 0;
   HOSTOP_TRY(hb.get(&v, 128, 4));
+  *ok = (int32_t)v;
+  return RHIP_OK;
+}
+// full decoding checks of one element (canonical coordinates + membership): what a `rabe_bn` replacement's deserialisers call
+extern "C" int32_t rhip_host_g2_in_subgroup(rhip_ctx* ctx, const rhip_g2* p, int32_t* ok) {
+  HOSTOP_BEGIN(256)
+  HOSTOP_TRY(hb.put(0, p, 128));
+  HOSTOP_TRY(rhip_g2_in_subgroup(ctx, 1, (const rhip_g2*)hb.d, (uint32_t*)(hb.d + 128)));
+  uint32_t v = 0;
+  HOSTOP_TRY(hb.get(&v, 128, 4));
+  *ok = (int32_t)v;
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_host_gt_is_member(rhip_ctx* ctx, const rhip_gt* a, int32_t* ok) {
+  HOSTOP_BEGIN(512)
+  HOSTOP_TRY(hb.put(0, a, 384));
+  HOSTOP_TRY(rhip_gt_is_member(ctx, 1, (const rhip_gt*)hb.d, (uint32_t*)(hb.d + 384)));
+  uint32_t v = 0;
+  HOSTOP_TRY(hb.get(&v, 384, 4));
   *ok = (int32_t)v;
   return RHIP_OK;
 }

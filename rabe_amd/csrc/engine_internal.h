@@ -124,9 +124,22 @@ static __device__ __noinline__ void st_gt_m(GtM* p, const Fp12& a) {
   st_fp2_m(p->l, a.c0.a0);      st_fp2_m(p->l + 16, a.c0.a1); st_fp2_m(p->l + 32, a.c0.a2);
   st_fp2_m(p->l + 48, a.c1.a0); st_fp2_m(p->l + 64, a.c1.a1); st_fp2_m(p->l + 80, a.c1.a2);
 }
+// A scalar record is a canonical Fr (< r); every chain below it (NAF masks compute 3k in 256 bits, window digits, GLV) relies on
+// k < 2^254.  The raw C ABI takes rhip_fr arrays from anywhere, so the load itself brings any 256-bit word below r: at most five
+// conditional subtractions (2^256 / r < 5.3), a no-op on canonical input -- k * P is then the group's answer for every input.
 __device__ __forceinline__ void ld_scalar(uint32_t k[8], const rhip_fr* p) {
 #pragma unroll
   for (int i = 0; i < 8; i++) k[i] = p->l[i];
+  if (k[7] >= FrParams::mod(7)) {          // only words with a top limb >= r's can be >= r: canonical input almost never enters
+    for (int t = 0; t < 5; t++) {
+      uint32_t d[8], borrow = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) d[i] = subb32(k[i], FrParams::mod(i), borrow);
+      if (borrow) break;
+#pragma unroll
+      for (int i = 0; i < 8; i++) k[i] = d[i];
+    }
+  }
 }
 
 // out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical.
@@ -279,7 +292,10 @@ static __device__ __noinline__ G1Jac table_mul_g1(const G1M* tbl, const uint32_t
 // 16-bit digits: 16 mixed additions.  The entry is fetched where it is used: holding the next entry across the addition (a
 // software prefetch) costs 16 of the 128 registers these kernels run with and came out slower than the gather latency it hid
 // (four waves per SIMD cover it): row kernel 13.0 -> 12.1 ms.
-static __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[8]) {
+// The *_inl forms are for kernels whose lane walks several tables in a row (the AC17 row kernels): as out-of-line functions
+// these return their point through a stack slot, and the compiler then keeps the ACCUMULATOR in that slot -- 96 bytes of scratch
+// written per window (profiles/r02k_pmc_traffic.txt: 14 GB of write-back per launch of k_ac17_enc_rows, 22 x its results).
+static __device__ __forceinline__ G1Jac table_mul_g1_w16_inl(const G1M* tbl, const uint32_t k[8]) {
   G1Jac acc = jac_inf<Fp>();
 #pragma unroll 1
   for (int w = 0; w < TBL16_WINDOWS; w++) {
@@ -299,6 +315,7 @@ static __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint
   }
   return acc;
 }
+static __device__ __noinline__ G1Jac table_mul_g1_w16(const G1M* tbl, const uint32_t k[8]) { return table_mul_g1_w16_inl(tbl, k); }
 // signed w-bit digits: ceil(254/w) mixed additions (11 for w = 24, 10 for w = 26); the digit's sign flips y
 __device__ __forceinline__ uint32_t scalar_bits(const uint32_t k[8], int b, int w) {
   const int word = b >> 5, sh = b & 31;
@@ -316,7 +333,7 @@ __device__ __forceinline__ uint32_t scalar_bits(const uint32_t k[8], int b, int 
   const uint64_t v = (((uint64_t)hi << 32) | lo) >> sh;
   return (uint32_t)v & ((1u << w) - 1u);
 }
-static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uint32_t k[8], int w) {
+static __device__ __forceinline__ G1Jac table_mul_g1_wide_inl(const G1M* tbl, const uint32_t k[8], int w) {
   const int n = wide_windows(w);
   const uint32_t half = 1u << (w - 1);
   G1Jac acc = jac_inf<Fp>();
@@ -334,6 +351,7 @@ static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uin
   }
   return acc;
 }
+static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uint32_t k[8], int w) { return table_mul_g1_wide_inl(tbl, k, w); }
 static __device__ __noinline__ G2Jac table_mul_g2(const G2M* tbl, const uint32_t k[8]) {
   G2Jac acc = jac_inf<Fp2>();
   for (int w = 0; w < TBL_WINDOWS; w++) {

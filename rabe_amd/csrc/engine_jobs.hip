@@ -796,13 +796,15 @@ extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const r
   if (dgt) (void)hipFree(dgt);
   if (dg2) (void)hipFree(dg2);
   if (he != hipSuccess) { rhip_aw11_pk_destroy(pk); return fail(ctx, he, "rhip_aw11_pk_create"); }
-  // 16-bit windows per attribute when the device has the room for them and 48 GB to spare (RABE_AW11_ATTR_W16=0 / =1 forces the choice)
+  // 16-bit windows per attribute are OPT-IN (RABE_AW11_ATTR_W16=1): 536 MB per attribute -- 107 GB at 200 attributes -- is not a
+  // side effect a constructor may have on a device other tenants share; without the variable the 8-bit tables (4 MB per
+  // attribute) serve.  Even when asked for, they are only built while they leave a quarter of the device memory free.
   const size_t per16 = (size_t)TBL16_WINDOWS * TBL16_DIGITS;
   const size_t need = n_attrs * per16 * (sizeof(GtM) + sizeof(G2M));
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   const char* env = getenv("RABE_AW11_ATTR_W16");
-  const bool want = env ? (env[0] == '1') : (free_b > need + ((size_t)48 << 30));
+  const bool want = env && env[0] == '1' && free_b > need + total_b / 4;
   if (want) {
     he = hipMalloc((void**)&pk->attr_gt16, n_attrs * per16 * sizeof(GtM));
     if (he == hipSuccess) he = hipMalloc((void**)&pk->attr_g216, n_attrs * per16 * sizeof(G2M));
@@ -1069,7 +1071,7 @@ __global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_in_subgroup(size_t n, 
   uint32_t r[8];
 #pragma unroll
   for (int w = 0; w < 8; w++) r[w] = FrParams::mod(w);
-  ok[i] = (aff_on_curve(P) && jac_is_inf(jac_mul_naf(P, r))) ? 1u : 0u;          // infinity is a member
+  ok[i] = (wire_words_canonical(p[i].l, 4) && aff_on_curve(P) && jac_is_inf(jac_mul_naf(P, r))) ? 1u : 0u;          // infinity is a member
 }
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_is_member(size_t n, const rhip_gt* a, uint32_t* ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1078,7 +1080,7 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_is_member(size_t n, con
   // cyclotomic subgroup: f^(p^4 - p^2 + 1) = 1  <=>  f^(p^4) * f = f^(p^2)
   const Fp12 f2 = fp12_frob_fn(f, 2);
   const Fp12 f4 = fp12_frob_fn(f2, 2);
-  bool good = fp12_eq(fp12_mul_fn(f4, f), f2);
+  bool good = wire_words_canonical(a[i].l, 12) && fp12_eq(fp12_mul_fn(f4, f), f2);
   if (good) {
     // order divides r: f^(r-1) * f = 1 (cyclotomic squarings are valid now)
     uint32_t k[8];

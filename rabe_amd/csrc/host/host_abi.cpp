@@ -455,11 +455,13 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
                                  pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
-int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, const uint64_t* ct_off, int32_t* status,
-                                    uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
+                                    uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN
   std::vector<std::string> errors;
-  if (!ac17::cp_decrypt_packed(h->eng, *(const ac17::Ac17CpSecretKey*)sk, n_items, ct_blob, ct_off, status, pt_buf, pt_cap, pt_off, &errors)) return 1;
+  if (!ac17::cp_decrypt_packed(h->eng, *(const ac17::Ac17CpSecretKey*)sk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status,
+                               pt_buf, pt_cap, pt_off, &errors))
+    return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
   return 0;
   GUARD_END(h)

@@ -904,11 +904,24 @@ bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std
 // status[i]: 0 ok, -1 the key does not satisfy the policy / malformed record / authentication failure (errors[i] says which).
 // pt_buf / pt_cap: caller-allocated; a capacity of ct_off[n] bytes always suffices (a plaintext is 28 bytes shorter than its sealed
 // form).  Returns false, before any work, when pt_cap is smaller than that.
-bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, const uint64_t* ct_off, int32_t* status,
-                       uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+//
+// The records come from outside: the offsets are validated against ct_len before anything is read (monotone, inside the blob -- an
+// item whose own bounds are bad fails alone), and unless `trusted` is set every decoded element goes through one batched membership
+// pass on the GPU (coordinates < p, rows on the G1 curve, c_0 in the r-torsion of the twist, c_p in the order-r subgroup of Fq12:
+// what rabe-bn's decoding establishes, FieldError::NotMember) -- the Gt arithmetic downstream (cyclotomic squarings, conjugate as
+// inverse) is only valid inside the subgroup.  `trusted` is for ciphertexts this process produced itself.
+bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                       int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
   StageTimer tm("ac17::cp_decrypt_packed");
   errors->assign(n, "");
-  if (!pt_buf || pt_cap < ct_off[n] - ct_off[0]) return false;
+  if (!ct_off || (n && !ct_blob)) throw RabeError("cp_decrypt_packed: null input");
+  // bounds first: everything below trusts [ct_off[i], ct_off[i+1]) to lie inside the blob
+  uint64_t span = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (ct_off[i] > ct_off[i + 1] || ct_off[i + 1] > ct_len) (*errors)[i] = "deserialize: record offsets are not monotone inside the blob";
+    else span += ct_off[i + 1] - ct_off[i];
+  }
+  if (!pt_buf || pt_cap < span) return false;
   if (sk.sk.k_0.size() != 3 || sk.sk.k_p.size() != 3) throw RabeError("malformed Ac17CpSecretKey");
   for (const auto& row : sk.sk.k) if (row.second.size() != 3) throw RabeError("malformed Ac17CpSecretKey: a row does not have 3 elements");
   // per distinct policy text (items of a batch repeat a few): the tree, the verdict for this key, the key-side selection and --
@@ -953,6 +966,7 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
                 std::vector<uint32_t> own_sel; };
   std::vector<View> v(n);
   parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
     try {
       const uint8_t* p = ct_blob + ct_off[i];
       const uint8_t* end = ct_blob + ct_off[i + 1];
@@ -1046,6 +1060,25 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     eng.check(rhip_upload_async(cx, d1.ptr(), h_x, m * 384), "upload");
     eng.check(rhip_upload_async(cx, d4.ptr(), h_x + m * 384, m * 384), "upload");
     eng.check(rhip_upload_async(cx, d2.ptr(), h_c, total_rows * 192), "upload");
+    if (!trusted) {
+      // one launch per group over the staged records; a non-member fails its item only (the batch still runs: the kernels terminate
+      // on any input, the item's result is discarded below)
+      DBuf ok(&eng, (3 * m + 3 * total_rows + m) * 4);
+      eng.check(rhip_g2_in_subgroup(cx, 3 * m, d1.as<rhip_g2>(), ok.as<uint32_t>()), "rhip_g2_in_subgroup");
+      eng.check(rhip_g1_on_curve(cx, 3 * total_rows, d2.as<rhip_g1>(), ok.as<uint32_t>() + 3 * m), "rhip_g1_on_curve");
+      eng.check(rhip_gt_is_member(cx, m, d4.as<rhip_gt>(), ok.as<uint32_t>() + 3 * m + 3 * total_rows), "rhip_gt_is_member");
+      std::vector<uint32_t> h_ok(3 * m + 3 * total_rows + m);
+      ok.download(h_ok.data(), h_ok.size() * 4);
+      for (size_t j = 0; j < m; j++) {
+        const char* bad = nullptr;
+        for (int t = 0; t < 3 && !bad; t++) if (!h_ok[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
+        for (size_t r = 3 * (size_t)ct_row_off[j]; r < 3 * (size_t)ct_row_off[j + 1] && !bad; r++)
+          if (!h_ok[3 * m + r]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
+        if (!bad && !h_ok[3 * m + 3 * total_rows + j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
+        if (bad) (*errors)[live[j]] = bad;
+      }
+      tm.lap("membership");
+    }
     rhip_ac17_sk_lines* lines = nullptr;
     eng.check(rhip_ac17_sk_prepare(cx, 1, d5.as<rhip_g2>(), &lines), "rhip_ac17_sk_prepare");
     int32_t rc = rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), lines,

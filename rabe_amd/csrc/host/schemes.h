@@ -40,8 +40,8 @@ typedef schemes::DecryptResult DecryptResult;
 // packed forms: n ciphertexts = one blob of canonical records + offsets (schemes.cpp: "packed batches")
 bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                        const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
-bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, const uint64_t* ct_off, int32_t* status,
-                       uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
+bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                       int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const Ac17CpSecretKey*>& sks,
                                             const std::vector<const Ac17CpCiphertext*>& cts);
 // the Gt value handed to decrypt_symmetric (parity hook for tests; not part of the reference API)

@@ -134,17 +134,25 @@ def cp_encrypt_packed(host, pk, policies, item_policy, pt_blob, pt_off, language
     return buf[:int(co[n])], co
 
 
-def cp_decrypt_packed(host, sk, ct_blob, ct_off, out=None):
-    """Returns (pt_blob: numpy uint8 view, pt_off: numpy uint64 [n+1], status: numpy int32 [n]); status[i] != 0: item i did not decrypt."""
+PACKED_TRUSTED = 1
+
+
+def cp_decrypt_packed(host, sk, ct_blob, ct_off, out=None, trusted=False):
+    """Returns (pt_blob: numpy uint8 view, pt_off: numpy uint64 [n+1], status: numpy int32 [n]); status[i] != 0: item i did not decrypt.
+    trusted=True skips the batched group-membership pass over the decoded elements (only for ciphertexts this process produced)."""
     import numpy as np
     n = len(ct_off) - 1
     ct = _as_u8(ct_blob)
     co = np.ascontiguousarray(ct_off, dtype=np.uint64)
     po = np.zeros(n + 1, dtype=np.uint64)
     status = np.zeros(max(n, 1), dtype=np.int32)
-    need = int(co[n] - co[0])
+    # capacity: the sum of the well-formed records' sizes (what the library checks; overlapping records can exceed the blob's size)
+    lo, hi = co[:-1], co[1:]
+    okm = (lo <= hi) & (hi <= ct.size)
+    need = int((hi[okm] - lo[okm]).sum()) if n else 0
     buf = out if out is not None and out.size >= need else np.empty(max(need, 1), dtype=np.uint8)
-    rc = host.lib.rabe_ac17_cp_decrypt_packed(host.h, sk.ptr, ctypes.c_size_t(n), _np_ptr(ct), _np_ptr(co), _np_ptr(status), _np_ptr(buf),
+    rc = host.lib.rabe_ac17_cp_decrypt_packed(host.h, sk.ptr, ctypes.c_size_t(n), _np_ptr(ct), ctypes.c_size_t(ct.size), _np_ptr(co),
+                                              ctypes.c_uint32(PACKED_TRUSTED if trusted else 0), _np_ptr(status), _np_ptr(buf),
                                               ctypes.c_size_t(buf.size), _np_ptr(po))
     hostlib_check(rc, host)
     return buf[:int(po[n])], po, status[:n]

@@ -118,3 +118,34 @@ def test_fixed_base_tables(eng):
     tt = eng.gt_table(bn.gt_to_le(e_gen))
     assert tt.mul(K[:7]) == [bn.gt_to_le(bn.gt_pow(e_gen, k)) for k in sc[:7]]
     t1.destroy(); t2.destroy(); tt.destroy()
+
+
+def test_non_canonical_scalars_are_reduced_not_trusted(eng):
+    """the raw C ABI accepts any rhip_fr word; the chains below (3k in 256 bits for the NAF, windows, GLV) need k < r,
+    so the load reduces -- k + r, k + 5r and 2^256 - 1 give the group's answer for k mod r."""
+    base = bn.g1_mul(bn.G1_GEN, 987654321)
+    q2 = bn.g2_mul(bn.G2_GEN, 123456789)
+    ks = [5, bn.R - 1, 1 << 253]
+    raw = [k + bn.R for k in ks] + [7 + 5 * bn.R, (1 << 256) - 1, bn.R]
+    assert all(x < 1 << 256 for x in raw)
+    got = eng.g1_mul([bn.g1_to_le(base)] * len(raw), [le(x) for x in raw])
+    assert got == [bn.g1_to_le(bn.g1_mul(base, x % bn.R)) for x in raw]
+    got = eng.g2_mul([bn.g2_to_le(q2)] * len(raw), [le(x) for x in raw])
+    assert got == [bn.g2_to_le(bn.g2_mul(q2, x % bn.R)) for x in raw]
+    e = bn.pairing(base, q2)
+    got = eng.gt_pow([bn.gt_to_le(e)] * 3, [le(x) for x in raw[:3]])
+    assert got == [bn.gt_to_le(bn.gt_pow(e, x % bn.R)) for x in raw[:3]]
+
+
+def test_membership_checks_reject_non_canonical_coordinates(eng):
+    p = bn.g1_mul(bn.G1_GEN, 31337)
+    good = bn.g1_to_le(p)
+    x, y = p
+    assert x + bn.P < 1 << 256
+    alias = (x + bn.P).to_bytes(32, "little") + y.to_bytes(32, "little")          # the same residue, a second encoding
+    d = eng.upload(good + alias)
+    out = eng.alloc(8)
+    from rabe_amd.engine import _sz
+    eng._check(eng.lib.rhip_g1_on_curve(eng.ctx, _sz(2), d.ptr, out.ptr))
+    import struct
+    assert struct.unpack("<2I", eng.download(out)) == (1, 0)

@@ -168,3 +168,120 @@ def test_config3_bsw_hundred_leaves_against_reference_order(eng, shape):
         assert eng.download(d_out) == want
     lines.destroy()
     dpk.destroy()
+
+
+def _offsets(counts):
+    out = [0]
+    for c in counts:
+        out.append(out[-1] + c)
+    return out
+
+
+def test_config4_lsw_two_hundred_leaves_against_reference_order(eng):
+    """BASELINE config 4 at its full size, one item: lsw::keygen under a flat 200-leaf AND (199 coefficient draws, 200 share
+    randoms) and lsw::decrypt of a 200-attribute ciphertext, device against the reference-order C port byte for byte."""
+    from rabe_amd import engine as E
+    from oracle.tape import ListRng
+    rnd = random.Random(4)
+    rng = cport._Rnd(44)
+    names = ["c%d" % i for i in range(200)]
+    g1, g2 = cport._g1m(bn.g1_to_le(bn.G1_GEN), rng.fr()), cport._g2m(bn.g2_to_le(bn.G2_GEN), rng.fr())
+    msk = {"alpha1": rng.fr(), "alpha2": rng.fr()}
+    pk = {"g1": g1, "g2": g2, "e_gg_alpha": cport._gtp(cport._pair(g1, g2), msk["alpha1"] * msk["alpha2"] % bn.R)}
+    secret = rng.fr()
+    msg = cport._gtp(pk["e_gg_alpha"], rng.fr())
+    ct = {"e1": cport._gtm(cport._gtp(pk["e_gg_alpha"], secret), msg), "e2": cport._g2m(g2, secret),
+          "ej": [(a, cport._g1m(cport._g1m(g1, cport.hash_fr(a)), secret)) for a in names]}
+    tree = ("and", [("leaf", x) for x in names])
+    policy = hp.to_json(tree)
+    tt = hp.TreeTables([tree])
+    assert tt.n_leaves(0) == 200 and tt.n_coef(0) == 199
+    coefs = [rnd.randrange(bn.R) for _ in range(199)]
+    rands = [rnd.randrange(1, bn.R) for _ in range(200)]
+    sk = cport.lsw_keygen_raw(pk, msk, policy, ListRng(coefs + rands))                     # reference order
+    want = cport.lsw_decrypt_raw(sk, ct)
+    assert want == msg
+    dpk = E.LswPk(eng, g1, g2)
+    dtt = E.DevTreeTables(eng, tt)
+    d_d1, d_d2 = eng.alloc(200 * 64), eng.alloc(200 * 128)
+    d_leaf_off = eng.upload_u32([0, 200])
+    E.lsw_keygen_dev(eng, dpk, 1, 200, d_leaf_off, eng.upload_u32([tt.first_leaf[0]]), eng.upload_u32([tt.first_gate[0]]), dtt,
+                     eng.upload(le(msk["alpha1"]) + le(msk["alpha2"])), eng.upload(b"".join(le(x) for x in coefs)), eng.upload_u32([0]),
+                     eng.upload(b"".join(le(x) for x in rands)), d_d1, d_d2)
+    # leaf order of the flattened tree = DFS order = the reference's share order
+    leaf_names = tt.flat[0]["names"]
+    assert leaf_names == [row[0] for row in sk["dj"]]
+    assert eng.download(d_d1) == b"".join(row[1] for row in sk["dj"])
+    assert eng.download(d_d2) == b"".join(row[2] for row in sk["dj"])
+    ok, idx = hp.pruned_leaf_indices(names, tree)
+    assert ok and len(idx) == 200
+    z = hp.leaf_coefficients(tree)
+    d_e2 = eng.upload(ct["e2"])
+    lines = E.G2Lines(eng, 1, d_e2)
+    for e2_lines in (None, lines):
+        d_out = eng.alloc(384)
+        E.lsw_decrypt_dev(eng, 1, 201, 201, 200, eng.upload_u32([0, 201]), eng.upload_u32([0]), eng.upload_u32(idx),
+                          eng.upload_u32([names.index(leaf_names[y]) for y in idx]), eng.upload(b"".join(le(z[y]) for y in idx)),
+                          eng.upload(ct["e1"]), d_e2, eng.upload(b"".join(row[1] for row in ct["ej"])), eng.upload_u32([0, 200]),
+                          eng.upload_u32([0]), d_d1, d_d2, d_leaf_off, None, e2_lines, d_out)
+        assert eng.download(d_out) == want, "prepared e2" if e2_lines else "walking e2"
+    lines.destroy()
+    dpk.destroy()
+
+
+def test_config5_aw11_ten_by_twenty_against_reference_order(eng):
+    """BASELINE config 5 at its full size, one item: aw11::encrypt under binary ANDs over all 10 x 20 attributes and
+    aw11::decrypt with a key holding all of them, device against the reference-order C port byte for byte."""
+    from rabe_amd import engine as E
+    from oracle.tape import ListRng
+    rnd = random.Random(5)
+    rng = cport._Rnd(55)
+    gk = {"g1": cport._g1m(bn.g1_to_le(bn.G1_GEN), rng.fr()), "g2": cport._g2m(bn.g2_to_le(bn.G2_GEN), rng.fr())}
+    egg = cport._pair(gk["g1"], gk["g2"])
+    names = ["AUTH%dX%d" % (i // 20, i % 20) for i in range(200)]
+    hg = cport.hash_fr("alice")
+    pk_attr, sk = {}, {"gid": "alice", "attr": []}
+    for nm in names:
+        a, y = rng.fr(), rng.fr()
+        pk_attr[nm] = (cport._gtp(egg, a), cport._g2m(gk["g2"], y))
+        sk["attr"].append((nm, cport._g1m(gk["g1"], (a + hg * y) % bn.R)))
+
+    def nest(nodes):
+        return nodes[0] if len(nodes) == 1 else ("and", [nest(nodes[:len(nodes) // 2]), nest(nodes[len(nodes) // 2:])])
+    tree = nest([("leaf", x) for x in names])
+    policy = hp.to_json(tree)
+    tt = hp.TreeTables([tree])
+    assert tt.n_leaves(0) == 200
+    nc = tt.n_coef(0)
+    s = rnd.randrange(1, bn.R)
+    coefs = [rnd.randrange(bn.R) for _ in range(2 * nc)]
+    rands = [rnd.randrange(1, bn.R) for _ in range(200)]
+    msg = cport._gtp(egg, rnd.randrange(1, bn.R))
+    ct = cport.aw11_encrypt_raw(gk, pk_attr, policy, ListRng([s] + coefs + rands), msg)       # reference order
+    want = cport.aw11_decrypt_raw(gk, sk, ct)
+    assert want == msg
+    dpk = E.Aw11Pk(eng, gk["g1"], gk["g2"], [pk_attr[nm][0] for nm in names], [pk_attr[nm][1] for nm in names])
+    dtt = E.DevTreeTables(eng, tt)
+    leaf_names = tt.flat[0]["names"]
+    d_leaf_attr = eng.upload_u32([names.index(nm) for nm in leaf_names])
+    d_c0, d_c1, d_c2, d_c3 = eng.alloc(384), eng.alloc(200 * 384), eng.alloc(200 * 128), eng.alloc(200 * 128)
+    d_row_off = eng.upload_u32([0, 200])
+    E.aw11_encrypt_dev(eng, dpk, 1, 200, d_row_off, eng.upload_u32([tt.first_leaf[0]]), eng.upload_u32([tt.first_gate[0]]), eng.upload_u32([nc]), dtt,
+                       d_leaf_attr, eng.upload(le(s)), eng.upload(b"".join(le(x) for x in coefs)), eng.upload_u32([0]),
+                       eng.upload(b"".join(le(x) for x in rands)), eng.upload(msg), d_c0, d_c1, d_c2, d_c3)
+    assert len(ct["c"]) == 200
+    assert eng.download(d_c0) == ct["c_0"]
+    assert eng.download(d_c1) == b"".join(r[1] for r in ct["c"])
+    assert eng.download(d_c2) == b"".join(r[2] for r in ct["c"])
+    assert eng.download(d_c3) == b"".join(r[3] for r in ct["c"])
+    key_attrs = [a[0] for a in sk["attr"]]
+    ok, idx = hp.pruned_leaf_indices(key_attrs, tree)
+    assert ok and len(idx) == 200
+    z = hp.leaf_coefficients(tree)
+    d_out = eng.alloc(384)
+    E.aw11_decrypt_dev(eng, 1, 201, 201, 200, eng.upload_u32([0, 201]), eng.upload_u32([0]), eng.upload_u32(idx),
+                       eng.upload_u32([key_attrs.index(leaf_names[y]) for y in idx]), eng.upload(b"".join(le(z[y]) for y in idx)),
+                       d_c0, d_c1, d_c2, d_c3, d_row_off, eng.upload(cport._g1m(gk["g1"], hg)), eng.upload(b"".join(a[1] for a in sk["attr"])),
+                       eng.upload_u32([0, 200]), eng.upload_u32([0]), d_out)
+    assert eng.download(d_out) == want
+    dpk.destroy()

@@ -63,3 +63,54 @@ def test_packed_decrypt_fails_items_individually(host):
     off3[4:] -= 40
     out, out_off, status = ac17.cp_decrypt_packed(host, sk_ab, cut, off3)
     assert list(status) == [0, 0, -1, -1, 0, -1]
+
+
+def test_packed_decrypt_validates_offsets_and_membership(host):
+    """the packed decrypt is the entry point for external data -- offsets are checked against the blob length before
+    anything is read, and decoded elements go through the batched membership pass (coordinate < p, curve, subgroup)."""
+    pk, msk = ac17.setup(host)
+    n = 5
+    pts = [b"item %d" % i for i in range(n)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+    blob, ct_off = ac17.cp_encrypt_packed(host, pk, POLS, [0] * n, b"".join(pts), off, hl.HUMAN_POLICY)
+    sk = ac17.cp_keygen(host, msk, ["A", "B", "C"])
+    blob = blob.tobytes()
+    # non-monotone and out-of-range offsets: those items fail, nothing outside the blob is read, the others decrypt
+    o = ct_off.copy()
+    o[2] = o[3] + 5                                                       # item 1 ends after item 2 starts, item 2 has negative extent
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, blob, o)
+    assert status[2] == -1 and status[0] == 0 and status[3] == 0 and status[4] == 0
+    o = ct_off.copy()
+    o[5] = np.uint64(len(blob) + (1 << 40))                               # last record claims to run far past the blob
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, blob, o)
+    assert list(status) == [0, 0, 0, 0, -1]
+    # a row coordinate >= p (x + p: the same residue, a second encoding) and a point off the curve
+    P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    rec0 = int(ct_off[0])
+    pol_len = int.from_bytes(blob[rec0:rec0 + 4], "little")
+    rows_at = rec0 + 4 + pol_len + 1 + 4 + 384 + 4                        # first row record: name length, name, count, 3 x G1
+    nl = int.from_bytes(blob[rows_at:rows_at + 4], "little")
+    x_at = rows_at + 4 + nl + 4
+    x = int.from_bytes(blob[x_at:x_at + 32], "little")
+    bad = bytearray(blob)
+    if x + P < 1 << 256:
+        bad[x_at:x_at + 32] = (x + P).to_bytes(32, "little")
+        out, out_off, status = ac17.cp_decrypt_packed(host, sk, bytes(bad), ct_off)
+        assert list(status) == [-1, 0, 0, 0, 0], "a coordinate >= p must be rejected, not reduced"
+        # the trusted form skips the pass: the reduced coordinate is the same point, the item decrypts
+        out, out_off, status = ac17.cp_decrypt_packed(host, sk, bytes(bad), ct_off, trusted=True)
+        assert not status.any()
+    bad = bytearray(blob)
+    bad[x_at] ^= 1                                                        # off the curve
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, bytes(bad), ct_off)
+    assert list(status) == [-1, 0, 0, 0, 0]
+    # c_p outside the order-r subgroup (an arbitrary Fq12 element): item 3
+    rec3 = int(ct_off[3])
+    end3 = int(ct_off[4])
+    sealed_len = len(pts[3]) + 28
+    cp_at = end3 - sealed_len - 4 - 384
+    bad = bytearray(blob)
+    bad[cp_at:cp_at + 384] = b"".join((7 + i).to_bytes(32, "little") for i in range(12))
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, bytes(bad), ct_off)
+    assert list(status) == [0, 0, 0, -1, 0]
+    assert rec3 < cp_at

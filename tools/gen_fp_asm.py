@@ -117,7 +117,9 @@ class Stmt:
                 for ch in range(n):
                     c = op(carries[ch], "=&s")
                     o = op(ovfs[ch], "")
-                    lines.append("v_addc_co_u32_e64 %s, %s, 0, %s, %s" % (o, c, "0" if defines else o, c))
+                    # RB_CPAD (fp.h): empty in the fast build; "s_nop 1" in the RB_SAFE_CARRY build, between the carry-writing
+                    # multiply-adds of the group and their first reader (the later readers are further from their writers still)
+                    lines.append(("\" RB_CPAD \"" if ch == 0 else "") + "v_addc_co_u32_e64 %s, %s, 0, %s, %s" % (o, c, "0" if defines else o, c))
         outs = ", ".join('"%s"(%s)' % (cst, name) for name, cst in ops[:n_out])
         ins = ", ".join('"%s"(%s)' % (cst, name) for name, cst in ops[n_out:])
         assert len(ops) <= 30, len(ops)

@@ -75,6 +75,7 @@ static void run(int blocks, uint32_t iters, uint32_t* dev, uint32_t* host) {
 
 int main() {
   const int maxb = 2048;
+  size_t bad_total = 0;
   uint32_t* dev;
   CHECK(hipMalloc(&dev, (size_t)maxb * 256 * 4));
   uint32_t* h0 = (uint32_t*)malloc((size_t)maxb * 256 * 4);
@@ -91,6 +92,8 @@ int main() {
     for (size_t i = 0; i < (size_t)blocks * 256; i++) { bad1 += h0[i] != h1[i]; bad2 += h0[i] != h2[i]; bad3 += h0[i] != h3[i]; }
     printf("   lanes whose result differs from the compiler chain: without wait states %zu (vcc) / %zu (SGPR pair), with %zu (of %d; %.2e chained additions each)\n", bad1, bad3, bad2,
            blocks * 256, 20000.0 * 8 * 8);
+    bad_total += bad1 + bad2 + bad3;
   }
-  return 0;
+  // exit status for tests/test_gpu_carry_interlock.py: non-zero when any lane of any unpadded chain differs from the padded one
+  return bad_total ? 3 : 0;
 }

@@ -62,6 +62,18 @@ __global__ void __launch_bounds__(256) k_form(uint32_t iters, uint32_t seed, uin
         asm volatile("v_cndmask_b32_e64 %0, %0, %6, %7\n\tv_cndmask_b32_e64 %1, %1, %6, %7\n\tv_cndmask_b32_e64 %2, %2, %6, %7\n\t"
                      "v_cndmask_b32_e64 %3, %3, %6, %7\n\tv_cndmask_b32_e64 %4, %4, %6, %7\n\tv_cndmask_b32_e64 %5, %5, %6, %7"
                      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5) : "v"(x), "s"(c0));
+      if (F == 11)  // v_fma_f64 (the double-precision-limb alternative to v_mad_u64_u32)
+        asm volatile("v_fma_f64 %0, %6, %7, %0\n\tv_fma_f64 %1, %6, %7, %1\n\tv_fma_f64 %2, %6, %7, %2\n\t"
+                     "v_fma_f64 %3, %6, %7, %3\n\tv_fma_f64 %4, %6, %7, %4\n\tv_fma_f64 %5, %6, %7, %5"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(c0), "v"(c1));
+      if (F == 12)  // v_add_f64
+        asm volatile("v_add_f64 %0, %6, %0\n\tv_add_f64 %1, %6, %1\n\tv_add_f64 %2, %6, %2\n\t"
+                     "v_add_f64 %3, %6, %3\n\tv_add_f64 %4, %6, %4\n\tv_add_f64 %5, %6, %5"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(c0));
+      if (F == 13)  // v_lshl_add_u64 (64-bit integer add in one instruction)
+        asm volatile("v_lshl_add_u64 %0, %6, 0, %0\n\tv_lshl_add_u64 %1, %6, 0, %1\n\tv_lshl_add_u64 %2, %6, 0, %2\n\t"
+                     "v_lshl_add_u64 %3, %6, 0, %3\n\tv_lshl_add_u64 %4, %6, 0, %4\n\tv_lshl_add_u64 %5, %6, 0, %5"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(c0));
     }
   }
   uint64_t s = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5;
@@ -90,7 +102,7 @@ static void run(const char* what, int blocks, uint32_t* sink) {
 int main() {
   uint32_t* sink;
   CHECK(hipMalloc(&sink, 64));
-  for (int blocks : {256, 1024}) {
+  for (int blocks : {256, 512, 1024}) {
     run<0>("v_mad_u64_u32, distinct carry-out pairs", blocks, sink);
     run<1>("v_mad_u64_u32, carry-out to vcc", blocks, sink);
     run<2>("v_mul_hi_u32", blocks, sink);
@@ -102,6 +114,9 @@ int main() {
     run<5>("v_addc_co_u32 e64, carry in+out, distinct pairs", blocks, sink);
     run<10>("v_cndmask_b32 e64, SGPR mask", blocks, sink);
     run<8>("v_mov_b32", blocks, sink);
+    run<11>("v_fma_f64", blocks, sink);
+    run<12>("v_add_f64", blocks, sink);
+    run<13>("v_lshl_add_u64", blocks, sink);
   }
   CHECK(hipFree(sink));
   return 0;
