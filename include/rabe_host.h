@@ -110,6 +110,16 @@ int32_t rabe_bsw_encrypt_batch(rabe_host* h, const void* pk, size_t n, const cha
                                const uint8_t* const* plaintexts, const size_t* lens, void** cts);
 int32_t rabe_bsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                uint8_t** plaintexts, size_t* lens);
+/* The same two batches packed (conventions of rabe_ac17_cp_{encrypt,decrypt}_packed: one blob of canonical CpAbeCiphertext records +
+ * n_items + 1 offsets per side, caller-allocated buffers, per-item status, ct_len / RABE_PACKED_TRUSTED for untrusted input).  These
+ * feed the device-resident path (rhip_bsw_{encrypt,decrypt}_batch): share generation, fixed-base multiplications, the folded
+ * pairing product and one final exponentiation per item all happen on HBM-resident arrays (src/schemes/bsw/mod.rs:217-318). */
+int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
+                                uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
+int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
+                                const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap,
+                                uint64_t* pt_off /*[n_items+1]*/);
 
 /* ---- lsw (src/schemes/lsw/mod.rs:86-290) */
 int32_t rabe_lsw_setup(rabe_host* h, void** pk, void** msk);
@@ -121,6 +131,16 @@ int32_t rabe_lsw_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_
 int32_t rabe_lsw_keygen_batch(rabe_host* h, const void* pk, const void* msk, size_t n, const char* const* policies, int32_t language, void** sks);
 int32_t rabe_lsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                uint8_t** plaintexts, size_t* lens);
+/* Packed forms over the device-resident path (rhip_lsw_{keygen,decrypt}_batch; src/schemes/lsw/mod.rs:121-290): keygen writes n
+ * KpAbeSecretKey records (item i's policy = policies[item_policy[i]]) into one caller-allocated blob; decrypt takes n such records
+ * and ONE ciphertext object (BASELINE config 4) and returns n plaintexts.  Size / status / ct_len / RABE_PACKED_TRUSTED conventions as
+ * rabe_ac17_cp_{encrypt,decrypt}_packed.  Positive attributes only: a policy with "!x" leaves, or a selection that reaches one, is an
+ * error here -- rabe_lsw_keygen / rabe_lsw_decrypt reproduce the reference's negative branches. */
+int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language,
+                               size_t n_items, const uint32_t* item_policy /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
+int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, const uint8_t* sk_blob, size_t sk_len,
+                                const uint64_t* sk_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap,
+                                uint64_t* pt_off /*[n_items+1]*/);
 
 /* ---- aw11 (src/schemes/aw11/mod.rs:100-390) */
 int32_t rabe_aw11_setup(rabe_host* h, void** gk);
@@ -136,6 +156,15 @@ int32_t rabe_aw11_encrypt_batch(rabe_host* h, const void* gk, const void* const*
                                 int32_t language, const uint8_t* const* datas, const size_t* lens, void** cts);
 int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                 uint8_t** plaintexts, size_t* lens);
+/* Packed forms over the device-resident path (rhip_aw11_{encrypt,decrypt}_batch; src/schemes/aw11/mod.rs:241-366), conventions as
+ * rabe_ac17_cp_{encrypt,decrypt}_packed.  Every policy leaf must name an attribute of one of the authority keys (the reference drops
+ * other rows silently, :269-271; rabe_aw11_encrypt reproduces that). */
+int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* const* policies, size_t n_policies,
+                                 int32_t language, size_t n_items, const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob,
+                                 const uint64_t* pt_off /*[n_items+1]*/, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
+int32_t rabe_aw11_decrypt_packed(rabe_host* h, const void* gk, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
+                                 const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap,
+                                 uint64_t* pt_off /*[n_items+1]*/);
 
 /* ---- ghw11, CP-ABE with outsourced decryption (src/schemes/ghw11/mod.rs:92-305): `transform` is the server's part
  * (m + 2 pairings per ciphertext), `decrypt_out` the client's (one Gt power) */

@@ -13,13 +13,22 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
 SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "host", "schemes.cpp"),
-           os.path.join(CSRC, "host", "host_abi.cpp")]
+           os.path.join(CSRC, "host", "host_abi.cpp"), os.path.join(CSRC, "host", "packed.cpp")]
 
 
-def _headers():
+def _headers(src=None):
+    """headers a translation unit can see: the device units (csrc/*.hip) include bn254/, engine_internal.h and rabe_hip.h; the host
+    units (csrc/host/*.cpp) their own directory and both public headers -- a host-header edit does not recompile the kernels"""
     inc = os.path.join(os.path.dirname(HERE), "include")
-    deps = [os.path.join(inc, "rabe_hip.h"), os.path.join(inc, "rabe_host.h")]
+    deps = [os.path.join(inc, "rabe_hip.h")]
+    host_dir = os.path.join(CSRC, "host")
+    is_host = src is None or os.path.dirname(src) == host_dir
+    is_dev = src is None or not is_host
+    if is_host:
+        deps.append(os.path.join(inc, "rabe_host.h"))
     for root, _dirs, files in os.walk(CSRC):
+        if (root == host_dir and not is_host) or (root != host_dir and not is_dev):
+            continue
         deps += [os.path.join(root, f) for f in files if f.endswith(".h")]
     return deps
 
@@ -56,11 +65,11 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(s)]
-    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    hdr_t = {s: max(os.path.getmtime(h) for h in _headers(s)) for s in srcs}
     flags_tag = os.path.join(OBJ, ".flags")
     same_flags = os.path.exists(flags_tag) and open(flags_tag).read() == " ".join(_flags())
     todo = [s for s in srcs if force or not same_flags or not os.path.exists(_obj(s))
-            or os.path.getmtime(_obj(s)) < max(hdr_t, os.path.getmtime(s))]
+            or os.path.getmtime(_obj(s)) < max(hdr_t[s], os.path.getmtime(s))]
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 2))) as ex:
             for f in [ex.submit(_compile, s, verbose) for s in todo]:
@@ -78,8 +87,8 @@ def build_safe(force=False, verbose=False):
     wait states LLVM's gfx940+ hazard table asks for, compiler-scheduled additive chains), linked with the host objects of the
     normal build.  tests/test_gpu_carry_interlock.py runs the same vectors through both libraries and requires identical bytes."""
     build(force=force, verbose=verbose)
-    hdr_t = max(os.path.getmtime(h) for h in _headers())
-    todo = [s for s in DEVICE_SOURCES if force or not os.path.exists(_obj(s, True)) or os.path.getmtime(_obj(s, True)) < max(hdr_t, os.path.getmtime(s))]
+    todo = [s for s in DEVICE_SOURCES if force or not os.path.exists(_obj(s, True))
+            or os.path.getmtime(_obj(s, True)) < max(max(os.path.getmtime(h) for h in _headers(s)), os.path.getmtime(s))]
     if not todo and os.path.exists(LIB_SAFE) and os.path.getmtime(LIB_SAFE) >= os.path.getmtime(LIB):
         return LIB_SAFE
     if todo:

@@ -140,6 +140,9 @@ class Engine {
   uint8_t* pinned(int slot, size_t bytes);
   // window table of the Gt generator e(G1::one(), G2::one()) (random Gt messages of a batch in one launch, on device)
   rhip_gt_table* gt_generator_table();
+  // device-side key handles of the packed entry points (rhip_bsw_pk, rhip_lsw_pk, rhip_aw11_pk), cached by the key's bytes and
+  // destroyed with the engine; at most `cap` entries per kind live at a time
+  void* aux(const std::string& kind, const std::string& key, void* (*make)(Engine&, const void*), const void* arg, void (*destroy)(void*), size_t cap = 4);
 
  private:
   rhip_ctx* ctx_ = nullptr;
@@ -149,6 +152,8 @@ class Engine {
   std::map<std::string, rhip_g2_table*> t2_;
   std::map<std::string, rhip_gt_table*> tt_;
   std::map<std::string, rhip_ac17_pk*> pk17_;
+  struct Aux { void* h; void (*destroy)(void*); };
+  std::map<std::string, std::map<std::string, Aux>> aux_;
   void* pin_[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pin_bytes_[4] = {0, 0, 0, 0};
   rhip_gt_table* e_gen_tbl_ = nullptr;

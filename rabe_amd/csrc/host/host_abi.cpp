@@ -466,6 +466,63 @@ int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
+  GUARD_BEGIN
+  return bsw::encrypt_packed(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, strs(policies, n_policies), lang_of(language), n_items, item_policy, pt_blob,
+                             pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!bsw::decrypt_packed(h->eng, *(const bsw::CpAbeSecretKey*)sk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf,
+                           pt_cap, pt_off, &errors))
+    return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                               const uint32_t* item_policy, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  return lsw::keygen_packed(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, *(const lsw::KpAbeMasterKey*)msk, strs(policies, n_policies), lang_of(language),
+                            n_items, item_policy, sk_buf, sk_cap, sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, uint32_t flags,
+                                int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!lsw::decrypt_packed(h->eng, *(const lsw::KpAbeCiphertext*)ct, n_items, sk_blob, sk_len, sk_off, (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf,
+                           pt_cap, pt_off, &errors))
+    return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* const* policies, size_t n_policies,
+                                 int32_t language, size_t n_items, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off,
+                                 uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
+  GUARD_BEGIN
+  std::vector<const aw11::Aw11PublicKey*> p;
+  for (size_t i = 0; i < n_pks; i++) p.push_back((const aw11::Aw11PublicKey*)pks[i]);
+  return aw11::encrypt_packed(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, p, strs(policies, n_policies), lang_of(language), n_items, item_policy,
+                              pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_aw11_decrypt_packed(rabe_host* h, const void* gk, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
+                                 uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!aw11::decrypt_packed(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, n_items, ct_blob, ct_len, ct_off,
+                            (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf, pt_cap, pt_off, &errors))
+    return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
 int32_t rabe_ac17_cp_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, const void* const* cts, int32_t* status,
                                    uint8_t** plaintexts, size_t* lens) {
   GUARD_BEGIN

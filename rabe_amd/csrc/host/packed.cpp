@@ -1,0 +1,1033 @@
+// Packed batch entry points of bsw / lsw / aw11 (include/rabe_host.h: rabe_{bsw,lsw,aw11}_*_packed): n independent calls of the
+// reference's scheme functions -- bsw::encrypt / decrypt (src/schemes/bsw/mod.rs:217-318), lsw::keygen / decrypt
+// (lsw/mod.rs:121-290), aw11::encrypt / decrypt (aw11/mod.rs:241-366) -- with ONE blob of canonical records + offsets on each side
+// of the boundary, fed to the device-resident Level B paths (rhip_{bsw,lsw,aw11}_*_batch, include/rabe_hip.h) instead of the
+// per-object pairing jobs.  What stays on the host is what the reference does with strings and bytes: policy parsing, flattening
+// the tree into the index tables the share kernels walk, traverse / calc_pruned / calc_coefficients per distinct policy, record
+// assembly, KDF + AES-GCM.  Records are the byte form rabe_obj_serialize gives the corresponding struct (host_abi.cpp), so packed
+// and object APIs interoperate.
+#include "schemes.h"
+
+#include <chrono>
+#include <functional>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace rabe {
+using namespace host;
+PolicyNode parse_or_error(const std::string& policy, PolicyLanguage lang);          // schemes.cpp
+void parallel_for(size_t n, const std::function<void(size_t)>& fn);                // schemes.cpp
+
+namespace schemes {
+namespace {
+
+inline void put_u32(uint8_t* p, uint32_t v) { for (int i = 0; i < 4; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+inline uint32_t get_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+struct Timer {
+  bool on;
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit Timer(const char* w) : on(getenv("RABE_HOST_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* stage) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host-timing] %s: %s %.1f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
+// A policy text as the device-level paths want it (include/rabe_hip.h, "Flattened policy trees"): leaves in DFS order -- the order
+// gen_shares_policy emits shares (src/utils/secretsharing/mod.rs:82-122) -- each with its root-to-leaf path of (gate, 1-based child
+// number); gates in DFS pre-order with their threshold and the offset of their k - 1 coefficient draws (:128-134); per leaf the
+// share's name `name_col` (node_index, :74-76), Fr(SHA3(remove_index(name_col))) (what the schemes hash, e.g. bsw/mod.rs:239) and
+// the reconstruction coefficient (calc_coefficients, :9-57).  Cached across calls by (language, text).
+struct FlatPolicy {
+  PolicyNode tree;
+  std::vector<std::string> leaf_name, leaf_name_col;
+  std::vector<uint32_t> path_off{0}, path_gate, path_x, gate_k, gate_coef_off;
+  uint32_t n_coef = 0;
+  std::vector<Fr> leaf_hash, leaf_coeff;
+  bool has_negative = false;
+  size_t names_bytes = 0;          // sum of name_col lengths (record sizes)
+};
+void flatten_walk(FlatPolicy& f, const PolicyNode& n, std::vector<std::pair<uint32_t, uint32_t>>& path) {
+  if (n.type == PolicyType::Leaf) {
+    f.leaf_name.push_back(n.name);
+    f.leaf_name_col.push_back(node_index(n));
+    for (auto& pe : path) { f.path_gate.push_back(pe.first); f.path_x.push_back(pe.second); }
+    f.path_off.push_back((uint32_t)f.path_gate.size());
+    return;
+  }
+  if (n.children.size() < 2)
+    throw PolicyPanic(n.type == PolicyType::And ? "Error: Invalid policy (AND with just a single child)." : "Error: Invalid policy (OR with just a single child).");
+  const uint32_t g = (uint32_t)f.gate_k.size();
+  const uint32_t k = n.type == PolicyType::And ? (uint32_t)n.children.size() : 1u;
+  f.gate_k.push_back(k);
+  f.gate_coef_off.push_back(f.n_coef);
+  f.n_coef += k - 1;
+  for (size_t i = 0; i < n.children.size(); i++) {
+    path.push_back({g, (uint32_t)i + 1});
+    flatten_walk(f, n.children[i], path);
+    path.pop_back();
+  }
+}
+std::shared_ptr<const FlatPolicy> flat_policy(const std::string& pol, PolicyLanguage language) {
+  static std::mutex mu;
+  static std::map<std::pair<int, std::string>, std::shared_ptr<const FlatPolicy>> cache;
+  const auto key = std::make_pair((int)language, pol);
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  auto f = std::make_shared<FlatPolicy>();
+  f->tree = parse_or_error(pol, language);
+  std::vector<std::pair<uint32_t, uint32_t>> path;
+  flatten_walk(*f, f->tree, path);
+  NamedFr coeff;
+  calc_coefficients(f->tree, fr_one(), &coeff);
+  for (size_t i = 0; i < f->leaf_name_col.size(); i++) {
+    f->leaf_hash.push_back(sha3_hash_fr(remove_index(f->leaf_name_col[i])));
+    f->leaf_coeff.push_back(coeff[i].second);
+    f->has_negative = f->has_negative || is_negative(f->leaf_name[i]);
+    f->names_bytes += f->leaf_name_col[i].size();
+  }
+  std::lock_guard<std::mutex> g(mu);
+  if (cache.size() >= 1024) cache.clear();
+  cache[key] = f;
+  return f;
+}
+
+// uploads that tolerate empty vectors (the device entry points are never handed a null array)
+DBuf up32(Engine& eng, const std::vector<uint32_t>& v) {
+  static const uint32_t zero = 0;
+  return v.empty() ? DBuf(&eng, &zero, 4) : DBuf(&eng, v.data(), v.size() * 4);
+}
+DBuf up_bytes(Engine& eng, const std::vector<uint8_t>& v) {
+  static const uint8_t zero[32] = {0};
+  return v.empty() ? DBuf(&eng, zero, 32) : DBuf(&eng, v.data(), v.size());
+}
+
+// the concatenated tables of a call's distinct policies, on the device
+struct DevTrees {
+  std::vector<uint32_t> first_leaf, first_gate;
+  DBuf path_off, path_gate, path_x, gate_k, gate_coef_off, leaf_hash;
+  DevTrees(Engine& eng, const std::vector<std::shared_ptr<const FlatPolicy>>& pols) {
+    std::vector<uint32_t> po{0}, pg, px, gk, gc;
+    std::vector<Fr> lh;
+    for (const auto& f : pols) {
+      first_leaf.push_back((uint32_t)lh.size());
+      first_gate.push_back((uint32_t)gk.size());
+      const uint32_t base = (uint32_t)pg.size();
+      for (size_t i = 1; i < f->path_off.size(); i++) po.push_back(base + f->path_off[i]);
+      pg.insert(pg.end(), f->path_gate.begin(), f->path_gate.end());
+      px.insert(px.end(), f->path_x.begin(), f->path_x.end());
+      gk.insert(gk.end(), f->gate_k.begin(), f->gate_k.end());
+      gc.insert(gc.end(), f->gate_coef_off.begin(), f->gate_coef_off.end());
+      lh.insert(lh.end(), f->leaf_hash.begin(), f->leaf_hash.end());
+    }
+    path_off = up32(eng, po); path_gate = up32(eng, pg); path_x = up32(eng, px); gate_k = up32(eng, gk); gate_coef_off = up32(eng, gc);
+    leaf_hash = up_bytes(eng, flatten_fr(lh));
+  }
+};
+
+// randomness of a batch in the reference's per-call draw order, item after item; OS randomness has no order, so blocks of items
+// may then draw on their own sources in parallel
+template <class DRAW>
+void draw_items(Rng& rng, size_t n, DRAW draw) {
+  if (rng.unordered() && n >= 1024) {
+    const size_t blocks = (n + 255) / 256;
+    parallel_for(blocks, [&](size_t b) {
+      OsRng local;
+      for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) draw(local, i);
+    });
+  } else {
+    for (size_t i = 0; i < n; i++) draw(rng, i);
+  }
+}
+
+// bounds of the records of an untrusted blob: monotone, inside [0, len); span = total size of the well-formed ones
+uint64_t check_offsets(size_t n, const uint64_t* off, size_t len, std::vector<std::string>* errors) {
+  uint64_t span = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (off[i] > off[i + 1] || off[i + 1] > len) (*errors)[i] = "deserialize: record offsets are not monotone inside the blob";
+    else span += off[i + 1] - off[i];
+  }
+  return span;
+}
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  void need(size_t k) const { if ((size_t)(end - p) < k) throw RabeError("deserialize: truncated input"); }
+  uint32_t u32() { need(4); uint32_t v = get_u32(p); p += 4; return v; }
+  const uint8_t* raw(size_t k) { need(k); const uint8_t* q = p; p += k; return q; }
+  std::pair<const char*, uint32_t> str() { uint32_t l = u32(); return {(const char*)raw(l), l}; }
+};
+inline bool same(const std::pair<const char*, uint32_t>& a, const std::string& b) { return a.second == b.size() && memcmp(a.first, b.data(), b.size()) == 0; }
+
+// the batched decoding checks over staged device arrays (what rabe-bn's decoding establishes, FieldError::NotMember); ok[] per element
+std::vector<uint32_t> member_pass(Engine& eng, int which, const void* dev, size_t count) {
+  std::vector<uint32_t> ok(count, 1);
+  if (!count) return ok;
+  DBuf dok(&eng, count * 4);
+  rhip_ctx* cx = eng.ctx();
+  int32_t rc = which == 1 ? rhip_g1_on_curve(cx, count, (const rhip_g1*)dev, dok.as<uint32_t>())
+             : which == 2 ? rhip_g2_in_subgroup(cx, count, (const rhip_g2*)dev, dok.as<uint32_t>())
+                          : rhip_gt_is_member(cx, count, (const rhip_gt*)dev, dok.as<uint32_t>());
+  eng.check(rc, "membership pass");
+  dok.download(ok.data(), count * 4);
+  return ok;
+}
+
+// AES-GCM open of every live item into the caller's buffer (status / offsets as in ac17::cp_decrypt_packed)
+struct Sealed { const uint8_t* p = nullptr; uint32_t len = 0; };
+void open_all(size_t n, const std::vector<Sealed>& sealed, const std::vector<size_t>& slot, const uint8_t* h_gt, int32_t* status, uint8_t* pt_buf,
+              uint64_t* pt_off, std::vector<std::string>* errors) {
+  pt_off[0] = 0;
+  for (size_t i = 0; i < n; i++) pt_off[i + 1] = pt_off[i] + ((*errors)[i].empty() && sealed[i].len >= 28 ? sealed[i].len - 28 : 0);
+  parallel_for(n, [&](size_t i) {
+    status[i] = -1;
+    if (!(*errors)[i].empty()) return;
+    Bytes pt;
+    if (sealed[i].len >= 28 && decrypt_symmetric(h_gt + 384 * slot[i], sealed[i].p, sealed[i].len, &pt) && pt.size() == sealed[i].len - 28) {
+      memcpy(pt_buf + pt_off[i], pt.data(), pt.size());
+      status[i] = 0;
+    } else {
+      memset(pt_buf + pt_off[i], 0, (size_t)(pt_off[i + 1] - pt_off[i]));
+      (*errors)[i] = "decryption error: aead::Error";
+    }
+  });
+}
+
+}  // namespace
+
+// ================================================================================================================= BSW
+namespace bsw {
+namespace {
+void* make_pk(Engine& eng, const void* arg) {
+  const CpAbePublicKey& pk = *(const CpAbePublicKey*)arg;
+  rhip_bsw_pk* d = nullptr;
+  eng.check(rhip_bsw_pk_create(eng.ctx(), (const rhip_g1*)pk.g1.data(), (const rhip_g2*)pk.g2.data(), (const rhip_g1*)pk.h.data(),
+                               (const rhip_gt*)pk.e_gg_alpha.data(), &d), "rhip_bsw_pk_create");
+  return d;
+}
+void destroy_pk(void* h) { rhip_bsw_pk_destroy((rhip_bsw_pk*)h); }
+}  // namespace
+
+// n calls of bsw::encrypt (bsw/mod.rs:217-251).  Draw order per item: secret (:228), msg (:229), the gate coefficients of
+// gen_shares_policy (secretsharing/mod.rs:128-134), the AES nonce (aes/mod.rs:17).  Record = CpAbeCiphertext:
+//   policy text, language, c, c_p, leaf count, per leaf (name_col, g1 * q_y, (g2 * h(name)) * q_y), sealed plaintext.
+bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
+                    const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("bsw::encrypt_packed");
+  std::vector<std::shared_ptr<const FlatPolicy>> pols;
+  for (const auto& p : policies) pols.push_back(flat_policy(p, language));
+  for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("bsw::encrypt_packed: item_policy out of range");
+  std::vector<size_t> fixed(policies.size());
+  for (size_t p = 0; p < policies.size(); p++)
+    fixed[p] = 4 + policies[p].size() + 1 + 64 + 384 + 4 + pols[p]->leaf_name.size() * (4 + 64 + 128) + pols[p]->names_bytes + 4;
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_policy[i]] + (pt_off[i + 1] - pt_off[i]) + 28;
+  if (!out_buf || out_cap < out_off[n]) return false;
+  std::vector<uint32_t> leaf_off(n + 1, 0), coef_off(n + 1, 0), tree_leaf(n), tree_gate(n);
+  for (size_t i = 0; i < n; i++) {
+    leaf_off[i + 1] = leaf_off[i] + (uint32_t)pols[item_policy[i]]->leaf_name.size();
+    coef_off[i + 1] = coef_off[i] + pols[item_policy[i]]->n_coef;
+  }
+  const size_t total = leaf_off[n], total_coef = coef_off[n];
+  tm.lap("policies");
+  uint8_t* h_in = eng.pinned(0, n * 64 + (total_coef + 1) * 32);          // secret | msg exponent | coefficients
+  uint8_t* h_sec = h_in;
+  uint8_t* h_rho = h_in + n * 32;
+  uint8_t* h_coef = h_in + n * 64;
+  std::vector<std::array<uint8_t, 12>> nonces(n);
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    Fr s = r.next_fr(), rho = r.next_fr();
+    memcpy(h_sec + 32 * i, s.l, 32);
+    memcpy(h_rho + 32 * i, rho.l, 32);
+    for (uint32_t c = coef_off[i]; c < coef_off[i + 1]; c++) { Fr a = r.next_fr(); memcpy(h_coef + 32 * (size_t)c, a.l, 32); }
+    r.fill(nonces[i].data(), 12);
+  });
+  tm.lap("draws");
+  rhip_ctx* cx = eng.ctx();
+  std::string key((const char*)pk.g1.data(), 64);
+  key.append((const char*)pk.g2.data(), 128).append((const char*)pk.h.data(), 64).append((const char*)pk.e_gg_alpha.data(), 384);
+  rhip_bsw_pk* dpk = (rhip_bsw_pk*)eng.aux("bsw_pk", key, make_pk, &pk, destroy_pk);
+  DevTrees dt(eng, pols);
+  for (size_t i = 0; i < n; i++) { tree_leaf[i] = dt.first_leaf[item_policy[i]]; tree_gate[i] = dt.first_gate[item_policy[i]]; }
+  DBuf d_leaf_off(&eng, leaf_off.data(), (n + 1) * 4), d_tl(&eng, tree_leaf.data(), n * 4), d_tg(&eng, tree_gate.data(), n * 4),
+      d_coef_off(&eng, coef_off.data(), n * 4), d_in(&eng, n * 64 + (total_coef + 1) * 32), d_msg(&eng, n * 384), d_c(&eng, n * 64), d_cp(&eng, n * 384),
+      d_g1(&eng, total * 64), d_g2(&eng, total * 128);
+  eng.check(rhip_upload_async(cx, d_in.ptr(), h_in, n * 64 + total_coef * 32), "upload");
+  const rhip_fr* dsec = d_in.as<rhip_fr>();
+  eng.check(rhip_gt_table_pow(cx, eng.gt_generator_table(), n, dsec + n, d_msg.as<rhip_gt>()), "rhip_gt_table_pow");
+  eng.check(rhip_bsw_encrypt_batch(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
+                                   dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
+                                   dt.leaf_hash.as<rhip_fr>(), dsec, dsec + 2 * n, d_coef_off.as<uint32_t>(), d_msg.as<rhip_gt>(), d_c.as<rhip_g1>(),
+                                   d_cp.as<rhip_gt>(), d_g1.as<rhip_g1>(), d_g2.as<rhip_g2>()), "rhip_bsw_encrypt_batch");
+  uint8_t* h_l = eng.pinned(1, total * 192);                // g1 rows | g2 rows
+  uint8_t* h_x = eng.pinned(2, n * (64 + 384 + 384));       // c | c_p | msg
+  eng.check(rhip_download_async(cx, h_l, d_g1.ptr(), total * 64), "download");
+  eng.check(rhip_download_async(cx, h_l + total * 64, d_g2.ptr(), total * 128), "download");
+  eng.check(rhip_download_async(cx, h_x, d_c.ptr(), n * 64), "download");
+  eng.check(rhip_download_async(cx, h_x + n * 64, d_cp.ptr(), n * 384), "download");
+  eng.check(rhip_download_async(cx, h_x + n * 448, d_msg.ptr(), n * 384), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const size_t p_ = item_policy[i];
+    const FlatPolicy& f = *pols[p_];
+    const std::string& pol = policies[p_];
+    uint8_t* w = out_buf + out_off[i];
+    put_u32(w, (uint32_t)pol.size()); w += 4;
+    memcpy(w, pol.data(), pol.size()); w += pol.size();
+    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
+    memcpy(w, h_x + 64 * i, 64); w += 64;
+    memcpy(w, h_x + n * 64 + 384 * i, 384); w += 384;
+    put_u32(w, (uint32_t)f.leaf_name.size()); w += 4;
+    for (size_t y = 0; y < f.leaf_name.size(); y++) {
+      const std::string& nm = f.leaf_name_col[y];
+      put_u32(w, (uint32_t)nm.size()); w += 4;
+      memcpy(w, nm.data(), nm.size()); w += nm.size();
+      memcpy(w, h_l + (size_t)(leaf_off[i] + y) * 64, 64); w += 64;
+      memcpy(w, h_l + total * 64 + (size_t)(leaf_off[i] + y) * 128, 128); w += 128;
+    }
+    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
+    put_u32(w, (uint32_t)(len + 28)); w += 4;
+    Bytes sealed = encrypt_symmetric(h_x + n * 448 + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
+    memcpy(w, sealed.data(), sealed.size());
+  });
+  tm.lap("assembly + AES");
+  return true;
+}
+
+// n calls of bsw::decrypt (bsw/mod.rs:260-318) with one key.  Per distinct policy text: traverse_policy, calc_pruned and the
+// coefficients, turned into the selection entries the device path takes -- entry = (ciphertext leaf row, key attribute row, z):
+// for every pruned (name, name_col) the FIRST ciphertext row named name_col, the FIRST key row named name, and one entry per
+// coefficient named name_col (:283-299 as index lists).  status / errors / buffers as ac17::cp_decrypt_packed.
+bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                    int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  Timer tm("bsw::decrypt_packed");
+  errors->assign(n, "");
+  if (!ct_off || (n && !ct_blob)) throw RabeError("bsw::decrypt_packed: null input");
+  const uint64_t span = check_offsets(n, ct_off, ct_len, errors);
+  if (!pt_buf || pt_cap < span) return false;
+  std::vector<std::string> attr;
+  for (const auto& v : sk.d_j) attr.push_back(v.string);
+  struct Plan {
+    std::shared_ptr<const FlatPolicy> flat; std::string err;
+    struct E { std::string name_col; uint32_t sk_row; Fr z; uint32_t std_ct_row; };
+    std::vector<E> ent;
+  };
+  std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
+  std::mutex plans_mu;
+  auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
+    std::lock_guard<std::mutex> g(plans_mu);
+    auto key = std::make_pair((int)lang, text);
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second;
+    auto pl = std::make_shared<Plan>();
+    try {
+      pl->flat = flat_policy(text, lang);
+      const PolicyNode& tree = pl->flat->tree;
+      if (!traverse_policy(attr, tree)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
+      PrunedList pruned;
+      if (!calc_pruned(attr, tree, &pruned)) throw RabeError("Error in bsw/encrypt: attributes do not match policy.");
+      for (const auto& pr : pruned) {
+        size_t dj = 0;
+        while (dj < sk.d_j.size() && sk.d_j[dj].string != pr.first) dj++;
+        if (dj == sk.d_j.size()) continue;
+        size_t std_row = 0;
+        while (std_row < pl->flat->leaf_name_col.size() && pl->flat->leaf_name_col[std_row] != pr.second) std_row++;
+        for (size_t y = 0; y < pl->flat->leaf_name_col.size(); y++)
+          if (pl->flat->leaf_name_col[y] == pr.second) pl->ent.push_back({pr.second, (uint32_t)dj, pl->flat->leaf_coeff[y], (uint32_t)std_row});
+      }
+    } catch (const RabeError& ex) {
+      pl->err = ex.what();
+      if (pl->err.empty()) pl->err = "policy error";
+    }
+    plans[key] = pl;
+    return pl;
+  };
+  struct View { const uint8_t* c; const uint8_t* cp; uint32_t rows; std::vector<const uint8_t*> g1, g2; std::shared_ptr<Plan> plan;
+                std::vector<uint32_t> ct_row; bool standard; };
+  std::vector<View> v(n);
+  std::vector<Sealed> sealed(n);
+  parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
+    try {
+      Cursor r{ct_blob + ct_off[i], ct_blob + ct_off[i + 1]};
+      auto pol = r.str();
+      const PolicyLanguage lang = *r.raw(1) ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      v[i].c = r.raw(64);
+      v[i].cp = r.raw(384);
+      const uint32_t rows = r.u32();
+      if ((size_t)rows * 196 > (size_t)(r.end - r.p)) throw RabeError("deserialize: truncated input");
+      v[i].rows = rows;
+      v[i].g1.resize(rows);
+      v[i].g2.resize(rows);
+      std::vector<std::pair<const char*, uint32_t>> names(rows);
+      for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].g1[y] = r.raw(64); v[i].g2[y] = r.raw(128); }
+      sealed[i].len = r.u32();
+      sealed[i].p = r.raw(sealed[i].len);
+      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      if (!pl->err.empty()) throw RabeError(pl->err);
+      v[i].plan = pl;
+      const auto& std_names = pl->flat->leaf_name_col;
+      bool standard = rows == std_names.size();
+      for (uint32_t y = 0; y < rows && standard; y++) standard = same(names[y], std_names[y]);
+      v[i].standard = standard;
+      if (!standard) {                              // rows in another order / other names: the name-matching loop itself (:283-287)
+        for (const auto& e : pl->ent) {
+          uint32_t y = 0;
+          while (y < rows && !same(names[y], e.name_col)) y++;
+          v[i].ct_row.push_back(y);               // y == rows: no such row -> the entry is skipped below
+        }
+      }
+    } catch (const RabeError& ex) {
+      (*errors)[i] = ex.what();
+      if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
+    }
+  });
+  tm.lap("parse + plan");
+  std::vector<size_t> live;
+  std::vector<uint32_t> leaf_off{0}, pair_off{0}, sel_start, sel_ct, sel_sk;
+  std::vector<Fr> sel_z;
+  std::map<const Plan*, uint32_t> shared_start;          // standard-layout items of one policy share their selection entries
+  size_t max_pairs = 1;
+  for (size_t i = 0; i < n; i++) {
+    if (!(*errors)[i].empty()) continue;
+    live.push_back(i);
+    leaf_off.push_back(leaf_off.back() + v[i].rows);
+    const Plan& pl = *v[i].plan;
+    uint32_t m = 0;
+    if (v[i].standard) {
+      auto it = shared_start.find(&pl);
+      if (it == shared_start.end()) {
+        it = shared_start.insert({&pl, (uint32_t)sel_ct.size()}).first;
+        for (const auto& e : pl.ent) { sel_ct.push_back(e.std_ct_row); sel_sk.push_back(e.sk_row); sel_z.push_back(e.z); }
+      }
+      sel_start.push_back(it->second);
+      m = (uint32_t)pl.ent.size();
+    } else {
+      sel_start.push_back((uint32_t)sel_ct.size());
+      for (size_t e = 0; e < pl.ent.size(); e++)
+        if (v[i].ct_row[e] < v[i].rows) { sel_ct.push_back(v[i].ct_row[e]); sel_sk.push_back(pl.ent[e].sk_row); sel_z.push_back(pl.ent[e].z); m++; }
+    }
+    pair_off.push_back(pair_off.back() + 2 * m + 1);
+    if ((size_t)2 * m + 1 > max_pairs) max_pairs = 2 * m + 1;
+  }
+  const size_t m_items = live.size();
+  uint8_t* h_out = nullptr;
+  std::vector<size_t> slot(n, (size_t)-1);
+  if (m_items) {
+    const size_t total = leaf_off[m_items];
+    uint8_t* h_l = eng.pinned(1, total * 192 + 4);
+    uint8_t* h_x = eng.pinned(2, m_items * (64 + 384 + 384));
+    parallel_for(m_items, [&](size_t j) {
+      const View& w = v[live[j]];
+      memcpy(h_x + 64 * j, w.c, 64);
+      memcpy(h_x + m_items * 64 + 384 * j, w.cp, 384);
+      for (uint32_t y = 0; y < w.rows; y++) {
+        memcpy(h_l + (size_t)(leaf_off[j] + y) * 64, w.g1[y], 64);
+        memcpy(h_l + total * 64 + (size_t)(leaf_off[j] + y) * 128, w.g2[y], 128);
+      }
+    });
+    tm.lap("pack");
+    rhip_ctx* cx = eng.ctx();
+    std::vector<uint8_t> kg1, kg2;
+    for (const auto& a : sk.d_j) { kg1.insert(kg1.end(), a.g1.begin(), a.g1.end()); kg2.insert(kg2.end(), a.g2.begin(), a.g2.end()); }
+    std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.d_j.size()}, sk_idx(m_items, 0);
+    auto fz = flatten_fr(sel_z);
+    DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off),
+        d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_sk = up32(eng, sel_sk),
+        d_sel_z = up_bytes(eng, fz), d_skd(&eng, sk.d.data(), 128), d_kg1 = up_bytes(eng, kg1), d_kg2 = up_bytes(eng, kg2),
+        d_sk_attr_off = up32(eng, sk_attr_off), d_sk_idx = up32(eng, sk_idx), d_out(&eng, m_items * 384);
+    eng.check(rhip_upload_async(cx, d_c.ptr(), h_x, m_items * 64), "upload");
+    eng.check(rhip_upload_async(cx, d_cp.ptr(), h_x + m_items * 64, m_items * 384), "upload");
+    eng.check(rhip_upload_async(cx, d_g1.ptr(), h_l, total * 64), "upload");
+    eng.check(rhip_upload_async(cx, d_g2.ptr(), h_l + total * 64, total * 128), "upload");
+    if (!trusted) {
+      auto ok_c = member_pass(eng, 1, d_c.ptr(), m_items), ok_g1 = member_pass(eng, 1, d_g1.ptr(), total), ok_g2 = member_pass(eng, 2, d_g2.ptr(), total),
+           ok_cp = member_pass(eng, 3, d_cp.ptr(), m_items);
+      for (size_t j = 0; j < m_items; j++) {
+        const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
+        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1] && !bad; y++)
+          if (!ok_g1[y] || !ok_g2[y]) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
+        if (bad) (*errors)[live[j]] = bad;
+      }
+      tm.lap("membership");
+    }
+    rhip_bsw_sk_lines* lines = nullptr;
+    if (!sk.d_j.empty()) eng.check(rhip_bsw_sk_prepare(cx, 1, sk.d_j.size(), d_skd.as<rhip_g2>(), d_kg2.as<rhip_g2>(), &lines), "rhip_bsw_sk_prepare");
+    int32_t rc = rhip_bsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(), d_sel_ct.as<uint32_t>(),
+                                        d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(), d_g1.as<rhip_g1>(),
+                                        d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(), d_kg2.as<rhip_g2>(),
+                                        d_sk_attr_off.as<uint32_t>(), d_sk_idx.as<uint32_t>(), lines, d_out.as<rhip_gt>());
+    h_out = h_x + m_items * 448;
+    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
+    if (rc == RHIP_OK) rc = rhip_sync(cx);
+    if (lines) rhip_bsw_sk_lines_destroy(lines);
+    eng.check(rc, "rhip_bsw_decrypt_batch");
+    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
+  }
+  tm.lap("device + copies");
+  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
+  tm.lap("AES open");
+  return true;
+}
+}  // namespace bsw
+
+
+// ================================================================================================================= LSW
+namespace lsw {
+namespace {
+void* make_pk(Engine& eng, const void* arg) {
+  const KpAbePublicKey& pk = *(const KpAbePublicKey*)arg;
+  rhip_lsw_pk* d = nullptr;
+  eng.check(rhip_lsw_pk_create(eng.ctx(), (const rhip_g1*)pk.g1.data(), (const rhip_g2*)pk.g2.data(), &d), "rhip_lsw_pk_create");
+  return d;
+}
+void destroy_pk(void* h) { rhip_lsw_pk_destroy((rhip_lsw_pk*)h); }
+}  // namespace
+
+// n calls of lsw::keygen (lsw/mod.rs:121-170).  Draw order per item: the gate coefficients of gen_shares_policy(alpha1), then one
+// `random` per share (:136).  Record = KpAbeSecretKey: policy text, language, leaf count, per leaf (name, d1, d2, d3, d4, d5) with
+// d3..d5 the identity for positive leaves.  Policies with negative attributes ("!x", :137-146) take the object API (rabe_lsw_keygen).
+bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::vector<std::string>& policies,
+                   PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("lsw::keygen_packed");
+  std::vector<std::shared_ptr<const FlatPolicy>> pols;
+  std::vector<std::vector<std::string>> striped(policies.size());
+  std::vector<size_t> fixed(policies.size());
+  for (size_t p = 0; p < policies.size(); p++) {
+    pols.push_back(flat_policy(policies[p], language));
+    if (pols[p]->has_negative) throw RabeError("lsw::keygen_packed: policies with negative attributes take rabe_lsw_keygen / rabe_lsw_keygen_batch");
+    fixed[p] = 4 + policies[p].size() + 1 + 4;
+    for (const auto& nc : pols[p]->leaf_name_col) { striped[p].push_back(remove_index(nc)); fixed[p] += 4 + striped[p].back().size() + 64 + 128 + 3 * 64; }
+  }
+  for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("lsw::keygen_packed: item_policy out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_policy[i]];
+  if (!out_buf || out_cap < out_off[n]) return false;
+  std::vector<uint32_t> leaf_off(n + 1, 0), coef_off(n + 1, 0), tree_leaf(n), tree_gate(n);
+  for (size_t i = 0; i < n; i++) {
+    leaf_off[i + 1] = leaf_off[i] + (uint32_t)pols[item_policy[i]]->leaf_name.size();
+    coef_off[i + 1] = coef_off[i] + pols[item_policy[i]]->n_coef;
+  }
+  const size_t total = leaf_off[n], total_coef = coef_off[n];
+  uint8_t* h_in = eng.pinned(0, 64 + (total_coef + total + 1) * 32);        // alpha1 | alpha2 | coefficients | randoms
+  memcpy(h_in, msk.alpha1.l, 32);
+  memcpy(h_in + 32, msk.alpha2.l, 32);
+  uint8_t* h_coef = h_in + 64;
+  uint8_t* h_rand = h_coef + total_coef * 32;
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    for (uint32_t c = coef_off[i]; c < coef_off[i + 1]; c++) { Fr a = r.next_fr(); memcpy(h_coef + 32 * (size_t)c, a.l, 32); }
+    for (uint32_t y = leaf_off[i]; y < leaf_off[i + 1]; y++) { Fr a = r.next_fr(); memcpy(h_rand + 32 * (size_t)y, a.l, 32); }
+  });
+  tm.lap("policies + draws");
+  rhip_ctx* cx = eng.ctx();
+  std::string key((const char*)pk.g1.data(), 64);
+  key.append((const char*)pk.g2.data(), 128);
+  rhip_lsw_pk* dpk = (rhip_lsw_pk*)eng.aux("lsw_pk", key, make_pk, &pk, destroy_pk);
+  DevTrees dt(eng, pols);
+  for (size_t i = 0; i < n; i++) { tree_leaf[i] = dt.first_leaf[item_policy[i]]; tree_gate[i] = dt.first_gate[item_policy[i]]; }
+  DBuf d_leaf_off = up32(eng, leaf_off), d_tl = up32(eng, tree_leaf), d_tg = up32(eng, tree_gate), d_coef_off = up32(eng, coef_off),
+       d_in(&eng, 64 + (total_coef + total + 1) * 32), d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4);
+  eng.check(rhip_upload_async(cx, d_in.ptr(), h_in, 64 + (total_coef + total) * 32), "upload");
+  const rhip_fr* din = d_in.as<rhip_fr>();
+  eng.check(rhip_lsw_keygen_batch(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
+                                  dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
+                                  dt.leaf_hash.as<rhip_fr>(), din, din + 2, d_coef_off.as<uint32_t>(), din + 2 + total_coef, d_d1.as<rhip_g1>(),
+                                  d_d2.as<rhip_g2>()), "rhip_lsw_keygen_batch");
+  uint8_t* h_l = eng.pinned(1, total * 192 + 4);
+  eng.check(rhip_download_async(cx, h_l, d_d1.ptr(), total * 64), "download");
+  eng.check(rhip_download_async(cx, h_l + total * 64, d_d2.ptr(), total * 128), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const size_t p_ = item_policy[i];
+    const std::string& pol = policies[p_];
+    uint8_t* w = out_buf + out_off[i];
+    put_u32(w, (uint32_t)pol.size()); w += 4;
+    memcpy(w, pol.data(), pol.size()); w += pol.size();
+    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
+    put_u32(w, (uint32_t)striped[p_].size()); w += 4;
+    for (size_t y = 0; y < striped[p_].size(); y++) {
+      const std::string& nm = striped[p_][y];
+      put_u32(w, (uint32_t)nm.size()); w += 4;
+      memcpy(w, nm.data(), nm.size()); w += nm.size();
+      memcpy(w, h_l + (size_t)(leaf_off[i] + y) * 64, 64); w += 64;
+      memcpy(w, h_l + total * 64 + (size_t)(leaf_off[i] + y) * 128, 128); w += 128;
+      memset(w, 0, 192); w += 192;
+    }
+  });
+  tm.lap("assembly");
+  return true;
+}
+
+// n calls of lsw::decrypt (lsw/mod.rs:228-290): n keys (a blob of KpAbeSecretKey records) against ONE ciphertext (BASELINE config 4:
+// a pre-made ciphertext, a fresh key per item).  Per distinct key policy: calc_pruned over the ciphertext's attributes and, for every
+// pruned (name, name_col), the FIRST key row and the FIRST ciphertext row named `name` and the FIRST coefficient named name_col
+// (:249-263).  A pruned negative attribute (the reference's TODO branch, :265-278) fails the item here: the object API reproduces it.
+bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, bool trusted,
+                    int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  Timer tm("lsw::decrypt_packed");
+  errors->assign(n, "");
+  if (!sk_off || (n && !sk_blob)) throw RabeError("lsw::decrypt_packed: null input");
+  (void)check_offsets(n, sk_off, sk_len, errors);
+  const size_t pt_each = ct.ct.size() >= 28 ? ct.ct.size() - 28 : 0;
+  if (!pt_buf || pt_cap < n * pt_each) return false;
+  std::vector<std::string> attr;
+  for (const auto& a : ct.ej) attr.push_back(a.name);
+  struct Plan {
+    std::shared_ptr<const FlatPolicy> flat; std::string err; std::vector<std::string> std_names;
+    struct E { std::string name; uint32_t ct_row; Fr c; uint32_t std_sk_row; };
+    std::vector<E> ent;
+  };
+  std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
+  std::mutex plans_mu;
+  auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
+    std::lock_guard<std::mutex> g(plans_mu);
+    auto key = std::make_pair((int)lang, text);
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second;
+    auto pl = std::make_shared<Plan>();
+    try {
+      pl->flat = flat_policy(text, lang);
+      for (const auto& nc : pl->flat->leaf_name_col) pl->std_names.push_back(remove_index(nc));
+      PrunedList list;
+      if (!calc_pruned(attr, pl->flat->tree, &list)) throw RabeError("Error in lsw/decrypt: attributes do not match policy.");
+      for (const auto& a : list) {
+        if (is_negative(a.first)) throw RabeError("lsw::decrypt_packed: a negative attribute is selected; rabe_lsw_decrypt reproduces the reference's branch");
+        size_t cr = 0, sr = 0, co = 0;
+        while (cr < ct.ej.size() && ct.ej[cr].name != a.first) cr++;
+        while (sr < pl->std_names.size() && pl->std_names[sr] != a.first) sr++;
+        while (co < pl->flat->leaf_name_col.size() && pl->flat->leaf_name_col[co] != a.second) co++;
+        if (cr == ct.ej.size() || co == pl->flat->leaf_name_col.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+        pl->ent.push_back({a.first, (uint32_t)cr, pl->flat->leaf_coeff[co], (uint32_t)sr});
+      }
+    } catch (const RabeError& ex) {
+      pl->err = ex.what();
+      if (pl->err.empty()) pl->err = "policy error";
+    }
+    plans[key] = pl;
+    return pl;
+  };
+  struct View { uint32_t rows; std::vector<const uint8_t*> d1, d2; std::shared_ptr<Plan> plan; std::vector<uint32_t> sk_row; bool standard; };
+  std::vector<View> v(n);
+  parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
+    try {
+      Cursor r{sk_blob + sk_off[i], sk_blob + sk_off[i + 1]};
+      auto pol = r.str();
+      const PolicyLanguage lang = *r.raw(1) ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      const uint32_t rows = r.u32();
+      if ((size_t)rows * 388 > (size_t)(r.end - r.p)) throw RabeError("deserialize: truncated input");
+      v[i].rows = rows;
+      v[i].d1.resize(rows);
+      v[i].d2.resize(rows);
+      std::vector<std::pair<const char*, uint32_t>> names(rows);
+      for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].d1[y] = r.raw(64); v[i].d2[y] = r.raw(128); (void)r.raw(192); }
+      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      if (!pl->err.empty()) throw RabeError(pl->err);
+      v[i].plan = pl;
+      bool standard = rows == pl->std_names.size();
+      for (uint32_t y = 0; y < rows && standard; y++) standard = same(names[y], pl->std_names[y]);
+      v[i].standard = standard;
+      if (!standard) {
+        for (const auto& e : pl->ent) {
+          uint32_t y = 0;
+          while (y < rows && !same(names[y], e.name)) y++;
+          if (y == rows) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+          v[i].sk_row.push_back(y);
+        }
+      } else {
+        for (const auto& e : pl->ent) if (e.std_sk_row >= rows) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+      }
+    } catch (const RabeError& ex) {
+      (*errors)[i] = ex.what();
+      if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
+    }
+  });
+  tm.lap("parse + plan");
+  std::vector<size_t> live;
+  std::vector<uint32_t> leaf_off{0}, pair_off{0}, sel_start, sel_sk, sel_ct;
+  std::vector<Fr> sel_z;
+  std::map<const Plan*, uint32_t> shared_start;
+  size_t max_pairs = 1;
+  for (size_t i = 0; i < n; i++) {
+    if (!(*errors)[i].empty()) continue;
+    live.push_back(i);
+    leaf_off.push_back(leaf_off.back() + v[i].rows);
+    const Plan& pl = *v[i].plan;
+    if (v[i].standard) {
+      auto it = shared_start.find(&pl);
+      if (it == shared_start.end()) {
+        it = shared_start.insert({&pl, (uint32_t)sel_sk.size()}).first;
+        for (const auto& e : pl.ent) { sel_sk.push_back(e.std_sk_row); sel_ct.push_back(e.ct_row); sel_z.push_back(e.c); }
+      }
+      sel_start.push_back(it->second);
+    } else {
+      sel_start.push_back((uint32_t)sel_sk.size());
+      for (size_t e = 0; e < pl.ent.size(); e++) { sel_sk.push_back(v[i].sk_row[e]); sel_ct.push_back(pl.ent[e].ct_row); sel_z.push_back(pl.ent[e].c); }
+    }
+    const uint32_t m = (uint32_t)pl.ent.size();
+    pair_off.push_back(pair_off.back() + m + 1);
+    if ((size_t)m + 1 > max_pairs) max_pairs = m + 1;
+  }
+  const size_t m_items = live.size();
+  uint8_t* h_out = nullptr;
+  std::vector<size_t> slot(n, (size_t)-1);
+  if (m_items) {
+    const size_t total = leaf_off[m_items];
+    uint8_t* h_l = eng.pinned(1, total * 192 + 4);
+    parallel_for(m_items, [&](size_t j) {
+      const View& w = v[live[j]];
+      for (uint32_t y = 0; y < w.rows; y++) {
+        memcpy(h_l + (size_t)(leaf_off[j] + y) * 64, w.d1[y], 64);
+        memcpy(h_l + total * 64 + (size_t)(leaf_off[j] + y) * 128, w.d2[y], 128);
+      }
+    });
+    tm.lap("pack");
+    rhip_ctx* cx = eng.ctx();
+    std::vector<uint8_t> e1j, e1rep(m_items * 384);
+    for (const auto& a : ct.ej) e1j.insert(e1j.end(), a.e1.begin(), a.e1.end());
+    for (size_t j = 0; j < m_items; j++) memcpy(e1rep.data() + 384 * j, ct.e1.data(), 384);
+    std::vector<uint32_t> ct_attr_off{0, (uint32_t)ct.ej.size()}, ct_idx(m_items, 0);
+    DBuf d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off), d_pair_off = up32(eng, pair_off),
+        d_sel_start = up32(eng, sel_start), d_sel_sk = up32(eng, sel_sk), d_sel_ct = up32(eng, sel_ct), d_sel_z = up_bytes(eng, flatten_fr(sel_z)),
+        d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j), d_ct_attr_off = up32(eng, ct_attr_off),
+        d_ct_idx = up32(eng, ct_idx), d_out(&eng, m_items * 384);
+    eng.check(rhip_upload_async(cx, d_d1.ptr(), h_l, total * 64), "upload");
+    eng.check(rhip_upload_async(cx, d_d2.ptr(), h_l + total * 64, total * 128), "upload");
+    if (!trusted) {
+      auto ok1 = member_pass(eng, 1, d_d1.ptr(), total), ok2 = member_pass(eng, 2, d_d2.ptr(), total);
+      for (size_t j = 0; j < m_items; j++)
+        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1]; y++)
+          if (!ok1[y] || !ok2[y]) { (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)"; break; }
+      tm.lap("membership");
+    }
+    rhip_g2_lines* lines = nullptr;
+    eng.check(rhip_g2_lines_prepare(cx, 1, d_e2.as<rhip_g2>(), &lines), "rhip_g2_lines_prepare");
+    int32_t rc = rhip_lsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_sk.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
+                                        d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
+                                        d_e1j.as<rhip_g1>(), d_ct_attr_off.as<uint32_t>(), d_ct_idx.as<uint32_t>(), d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(),
+                                        d_leaf_off.as<uint32_t>(), (const uint32_t*)nullptr, lines, d_out.as<rhip_gt>());
+    h_out = eng.pinned(2, m_items * 384);
+    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
+    if (rc == RHIP_OK) rc = rhip_sync(cx);
+    rhip_g2_lines_destroy(lines);
+    eng.check(rc, "rhip_lsw_decrypt_batch");
+    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
+  }
+  tm.lap("device + copies");
+  std::vector<Sealed> sealed(n);
+  for (size_t i = 0; i < n; i++) { sealed[i].p = ct.ct.data(); sealed[i].len = (uint32_t)ct.ct.size(); }
+  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
+  tm.lap("AES open");
+  return true;
+}
+}  // namespace lsw
+
+// ================================================================================================================= AW11
+namespace aw11 {
+namespace {
+std::string upper(const std::string& s) {
+  std::string o = s;
+  for (auto& c : o) if (c >= 'a' && c <= 'z') c = (char)(c - 'a' + 'A');
+  return o;
+}
+struct PkArg { const Aw11GlobalKey* gk; std::vector<const Aw11PkAttr*> attrs; };
+void* make_pk(Engine& eng, const void* arg) {
+  const PkArg& a = *(const PkArg*)arg;
+  std::vector<uint8_t> egg, g2y;
+  for (const auto* t : a.attrs) { egg.insert(egg.end(), t->egg_alpha.begin(), t->egg_alpha.end()); g2y.insert(g2y.end(), t->g2_y.begin(), t->g2_y.end()); }
+  rhip_aw11_pk* d = nullptr;
+  eng.check(rhip_aw11_pk_create(eng.ctx(), (const rhip_g1*)a.gk->g1.data(), (const rhip_g2*)a.gk->g2.data(), a.attrs.size(), (const rhip_gt*)egg.data(),
+                                (const rhip_g2*)g2y.data(), &d), "rhip_aw11_pk_create");
+  return d;
+}
+void destroy_pk(void* h) { rhip_aw11_pk_destroy((rhip_aw11_pk*)h); }
+}  // namespace
+
+// n calls of aw11::encrypt (aw11/mod.rs:241-289) under the same authority keys.  Draw order per item: s (:257), the gate
+// coefficients of the s-shares then of the 0-shares (:259-260), msg (:262), one r_x per share (:267), the nonce.  Record =
+// Aw11Ciphertext: policy, c_0, row count, per row (NAME_COL upper-cased, c1, c2, c3), sealed data.  A leaf whose attribute no
+// authority key lists is silently dropped by the reference (:269-271); here it is an error (use rabe_aw11_encrypt for that case).
+bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::vector<std::string>& policies,
+                    PolicyLanguage language, size_t n, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf,
+                    size_t out_cap, uint64_t* out_off) {
+  Timer tm("aw11::encrypt_packed");
+  PkArg arg{&gk, {}};
+  std::string key((const char*)gk.g1.data(), 64);
+  key.append((const char*)gk.g2.data(), 128);
+  for (const auto* pk : pks) for (const auto& t : pk->attr) { arg.attrs.push_back(&t); key.append((const char*)t.egg_alpha.data(), 384).append((const char*)t.g2_y.data(), 128); }
+  if (arg.attrs.empty()) throw RabeError("aw11::encrypt_packed: no authority attributes");
+  std::vector<std::shared_ptr<const FlatPolicy>> pols;
+  std::vector<std::vector<std::string>> row_name(policies.size());
+  std::vector<uint32_t> leaf_attr;
+  std::vector<size_t> fixed(policies.size());
+  for (size_t p = 0; p < policies.size(); p++) {
+    pols.push_back(flat_policy(policies[p], language));
+    (void)calculate_msp(pols[p]->tree);                    // built and unused in the reference (:253-255) -- but it must not panic
+    fixed[p] = 4 + policies[p].size() + 1 + 384 + 4 + 4;
+    for (const auto& nc : pols[p]->leaf_name_col) {
+      const std::string up = upper(nc), want = remove_index(up);
+      size_t a = 0;
+      while (a < arg.attrs.size() && arg.attrs[a]->name != want) a++;
+      if (a == arg.attrs.size()) throw RabeError("aw11::encrypt_packed: attribute " + want + " is in no authority key (rabe_aw11_encrypt drops such rows like the reference)");
+      leaf_attr.push_back((uint32_t)a);
+      row_name[p].push_back(up);
+      fixed[p] += 4 + up.size() + 384 + 128 + 128;
+    }
+  }
+  for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("aw11::encrypt_packed: item_policy out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_policy[i]] + (pt_off[i + 1] - pt_off[i]) + 28;
+  if (!out_buf || out_cap < out_off[n]) return false;
+  std::vector<uint32_t> row_off(n + 1, 0), coef_off(n + 1, 0), tree_leaf(n), tree_gate(n), n_coef(n);
+  for (size_t i = 0; i < n; i++) {
+    const FlatPolicy& f = *pols[item_policy[i]];
+    row_off[i + 1] = row_off[i] + (uint32_t)f.leaf_name.size();
+    coef_off[i + 1] = coef_off[i] + 2 * f.n_coef;
+    n_coef[i] = f.n_coef;
+  }
+  const size_t total = row_off[n], total_coef = coef_off[n];
+  uint8_t* h_in = eng.pinned(0, (2 * n + total_coef + total + 1) * 32);      // s | msg exponent | coefficients | r_x
+  uint8_t* h_s = h_in;
+  uint8_t* h_rho = h_in + n * 32;
+  uint8_t* h_coef = h_in + 2 * n * 32;
+  uint8_t* h_rand = h_coef + total_coef * 32;
+  std::vector<std::array<uint8_t, 12>> nonces(n);
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    Fr s = r.next_fr();
+    memcpy(h_s + 32 * i, s.l, 32);
+    for (uint32_t c = coef_off[i]; c < coef_off[i + 1]; c++) { Fr a = r.next_fr(); memcpy(h_coef + 32 * (size_t)c, a.l, 32); }
+    Fr rho = r.next_fr();
+    memcpy(h_rho + 32 * i, rho.l, 32);
+    for (uint32_t y = row_off[i]; y < row_off[i + 1]; y++) { Fr a = r.next_fr(); memcpy(h_rand + 32 * (size_t)y, a.l, 32); }
+    r.fill(nonces[i].data(), 12);
+  });
+  tm.lap("policies + draws");
+  rhip_ctx* cx = eng.ctx();
+  rhip_aw11_pk* dpk = (rhip_aw11_pk*)eng.aux("aw11_pk", key, make_pk, &arg, destroy_pk, 2);
+  DevTrees dt(eng, pols);
+  for (size_t i = 0; i < n; i++) { tree_leaf[i] = dt.first_leaf[item_policy[i]]; tree_gate[i] = dt.first_gate[item_policy[i]]; }
+  DBuf d_row_off = up32(eng, row_off), d_tl = up32(eng, tree_leaf), d_tg = up32(eng, tree_gate), d_nc = up32(eng, n_coef), d_coef_off = up32(eng, coef_off),
+       d_leaf_attr = up32(eng, leaf_attr), d_in(&eng, (2 * n + total_coef + total + 1) * 32), d_msg(&eng, n * 384), d_c0(&eng, n * 384),
+       d_c1(&eng, total * 384 + 4), d_c2(&eng, total * 128 + 4), d_c3(&eng, total * 128 + 4);
+  eng.check(rhip_upload_async(cx, d_in.ptr(), h_in, (2 * n + total_coef + total) * 32), "upload");
+  const rhip_fr* din = d_in.as<rhip_fr>();
+  eng.check(rhip_gt_table_pow(cx, eng.gt_generator_table(), n, din + n, d_msg.as<rhip_gt>()), "rhip_gt_table_pow");
+  eng.check(rhip_aw11_encrypt_batch(cx, dpk, n, total, d_row_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), d_nc.as<uint32_t>(),
+                                    dt.path_off.as<uint32_t>(), dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(),
+                                    dt.gate_coef_off.as<uint32_t>(), d_leaf_attr.as<uint32_t>(), din, din + 2 * n, d_coef_off.as<uint32_t>(),
+                                    din + 2 * n + total_coef, d_msg.as<rhip_gt>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(), d_c2.as<rhip_g2>(),
+                                    d_c3.as<rhip_g2>()), "rhip_aw11_encrypt_batch");
+  uint8_t* h_l = eng.pinned(1, total * 640 + 4);              // c1 rows | c2 rows | c3 rows
+  uint8_t* h_x = eng.pinned(2, n * 768);                      // c_0 | msg
+  eng.check(rhip_download_async(cx, h_l, d_c1.ptr(), total * 384), "download");
+  eng.check(rhip_download_async(cx, h_l + total * 384, d_c2.ptr(), total * 128), "download");
+  eng.check(rhip_download_async(cx, h_l + total * 512, d_c3.ptr(), total * 128), "download");
+  eng.check(rhip_download_async(cx, h_x, d_c0.ptr(), n * 384), "download");
+  eng.check(rhip_download_async(cx, h_x + n * 384, d_msg.ptr(), n * 384), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const size_t p_ = item_policy[i];
+    const std::string& pol = policies[p_];
+    uint8_t* w = out_buf + out_off[i];
+    put_u32(w, (uint32_t)pol.size()); w += 4;
+    memcpy(w, pol.data(), pol.size()); w += pol.size();
+    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
+    memcpy(w, h_x + 384 * i, 384); w += 384;
+    put_u32(w, (uint32_t)row_name[p_].size()); w += 4;
+    for (size_t y = 0; y < row_name[p_].size(); y++) {
+      const std::string& nm = row_name[p_][y];
+      const size_t row = row_off[i] + y;
+      put_u32(w, (uint32_t)nm.size()); w += 4;
+      memcpy(w, nm.data(), nm.size()); w += nm.size();
+      memcpy(w, h_l + row * 384, 384); w += 384;
+      memcpy(w, h_l + total * 384 + row * 128, 128); w += 128;
+      memcpy(w, h_l + total * 512 + row * 128, 128); w += 128;
+    }
+    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
+    put_u32(w, (uint32_t)(len + 28)); w += 4;
+    Bytes sealed = encrypt_symmetric(h_x + n * 384 + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
+    memcpy(w, sealed.data(), sealed.size());
+  });
+  tm.lap("assembly + AES");
+  return true;
+}
+
+// n calls of aw11::decrypt (aw11/mod.rs:298-366) with one key.  Per distinct policy: traverse_policy, calc_pruned, and per pruned
+// (name, name_col) the FIRST key attribute named `name`, the FIRST ciphertext row named name_col (literal spelling, :325-333) and the
+// FIRST coefficient named name_col.
+bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
+                    bool trusted, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  Timer tm("aw11::decrypt_packed");
+  errors->assign(n, "");
+  if (!ct_off || (n && !ct_blob)) throw RabeError("aw11::decrypt_packed: null input");
+  const uint64_t span = check_offsets(n, ct_off, ct_len, errors);
+  if (!pt_buf || pt_cap < span) return false;
+  std::vector<std::string> str_attr;
+  for (const auto& a : sk.attr) str_attr.push_back(a.first);
+  struct Plan {
+    std::shared_ptr<const FlatPolicy> flat; std::string err; std::vector<std::string> std_names;
+    struct E { std::string name_col; uint32_t sk_row; Fr c; uint32_t std_ct_row; };
+    std::vector<E> ent;
+  };
+  std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
+  std::mutex plans_mu;
+  auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
+    std::lock_guard<std::mutex> g(plans_mu);
+    auto key = std::make_pair((int)lang, text);
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second;
+    auto pl = std::make_shared<Plan>();
+    try {
+      pl->flat = flat_policy(text, lang);
+      for (const auto& nc : pl->flat->leaf_name_col) pl->std_names.push_back(upper(nc));
+      if (!traverse_policy(str_attr, pl->flat->tree)) throw RabeError("Error: attributes in sk do not match policy in ct.");
+      PrunedList list;
+      if (!calc_pruned(str_attr, pl->flat->tree, &list)) throw RabeError("Error in aw11/decrypt: attributes in sk do not match policy in ct.");
+      for (const auto& cur : list) {
+        size_t sr = 0, co = 0, cr = 0;
+        while (sr < sk.attr.size() && sk.attr[sr].first != cur.first) sr++;
+        while (co < pl->flat->leaf_name_col.size() && pl->flat->leaf_name_col[co] != cur.second) co++;
+        while (cr < pl->std_names.size() && pl->std_names[cr] != cur.second) cr++;
+        if (sr == sk.attr.size() || co == pl->flat->leaf_name_col.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+        pl->ent.push_back({cur.second, (uint32_t)sr, pl->flat->leaf_coeff[co], (uint32_t)cr});
+      }
+    } catch (const RabeError& ex) {
+      pl->err = ex.what();
+      if (pl->err.empty()) pl->err = "policy error";
+    }
+    plans[key] = pl;
+    return pl;
+  };
+  struct View { const uint8_t* c0; uint32_t rows; std::vector<const uint8_t*> c1, c2, c3; std::shared_ptr<Plan> plan; std::vector<uint32_t> ct_row; bool standard; };
+  std::vector<View> v(n);
+  std::vector<Sealed> sealed(n);
+  parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
+    try {
+      Cursor r{ct_blob + ct_off[i], ct_blob + ct_off[i + 1]};
+      auto pol = r.str();
+      const PolicyLanguage lang = *r.raw(1) ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      v[i].c0 = r.raw(384);
+      const uint32_t rows = r.u32();
+      if ((size_t)rows * 644 > (size_t)(r.end - r.p)) throw RabeError("deserialize: truncated input");
+      v[i].rows = rows;
+      v[i].c1.resize(rows); v[i].c2.resize(rows); v[i].c3.resize(rows);
+      std::vector<std::pair<const char*, uint32_t>> names(rows);
+      for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].c1[y] = r.raw(384); v[i].c2[y] = r.raw(128); v[i].c3[y] = r.raw(128); }
+      sealed[i].len = r.u32();
+      sealed[i].p = r.raw(sealed[i].len);
+      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      if (!pl->err.empty()) throw RabeError(pl->err);
+      v[i].plan = pl;
+      bool standard = rows == pl->std_names.size();
+      for (uint32_t y = 0; y < rows && standard; y++) standard = same(names[y], pl->std_names[y]);
+      v[i].standard = standard;
+      for (size_t e = 0; e < pl->ent.size(); e++) {
+        uint32_t y = standard ? pl->ent[e].std_ct_row : 0;
+        if (!standard) while (y < rows && !same(names[y], pl->ent[e].name_col)) y++;
+        if (y >= rows) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+        if (!standard) v[i].ct_row.push_back(y);
+      }
+    } catch (const RabeError& ex) {
+      (*errors)[i] = ex.what();
+      if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
+    }
+  });
+  tm.lap("parse + plan");
+  std::vector<size_t> live;
+  std::vector<uint32_t> row_off{0}, pair_off{0}, sel_start, sel_ct, sel_sk;
+  std::vector<Fr> sel_z;
+  std::map<const Plan*, uint32_t> shared_start;
+  size_t max_pairs = 1;
+  for (size_t i = 0; i < n; i++) {
+    if (!(*errors)[i].empty()) continue;
+    live.push_back(i);
+    row_off.push_back(row_off.back() + v[i].rows);
+    const Plan& pl = *v[i].plan;
+    if (v[i].standard) {
+      auto it = shared_start.find(&pl);
+      if (it == shared_start.end()) {
+        it = shared_start.insert({&pl, (uint32_t)sel_ct.size()}).first;
+        for (const auto& e : pl.ent) { sel_ct.push_back(e.std_ct_row); sel_sk.push_back(e.sk_row); sel_z.push_back(e.c); }
+      }
+      sel_start.push_back(it->second);
+    } else {
+      sel_start.push_back((uint32_t)sel_ct.size());
+      for (size_t e = 0; e < pl.ent.size(); e++) { sel_ct.push_back(v[i].ct_row[e]); sel_sk.push_back(pl.ent[e].sk_row); sel_z.push_back(pl.ent[e].c); }
+    }
+    const uint32_t m = (uint32_t)pl.ent.size();
+    pair_off.push_back(pair_off.back() + m + 1);
+    if ((size_t)m + 1 > max_pairs) max_pairs = m + 1;
+  }
+  const size_t m_items = live.size();
+  uint8_t* h_out = nullptr;
+  std::vector<size_t> slot(n, (size_t)-1);
+  if (m_items) {
+    const size_t total = row_off[m_items];
+    uint8_t* h_l = eng.pinned(1, total * 640 + 4);
+    uint8_t* h_x = eng.pinned(2, m_items * 768);
+    parallel_for(m_items, [&](size_t j) {
+      const View& w = v[live[j]];
+      memcpy(h_x + 384 * j, w.c0, 384);
+      for (uint32_t y = 0; y < w.rows; y++) {
+        const size_t row = row_off[j] + y;
+        memcpy(h_l + row * 384, w.c1[y], 384);
+        memcpy(h_l + total * 384 + row * 128, w.c2[y], 128);
+        memcpy(h_l + total * 512 + row * 128, w.c3[y], 128);
+      }
+    });
+    tm.lap("pack");
+    rhip_ctx* cx = eng.ctx();
+    G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];            // H(gid) = g1 * h(gid), hashed inside decrypt (:318)
+    std::vector<uint8_t> kk;
+    for (const auto& a : sk.attr) kk.insert(kk.end(), a.second.begin(), a.second.end());
+    std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.attr.size()}, sk_idx(m_items, 0);
+    DBuf d_c0(&eng, m_items * 384), d_c1(&eng, total * 384 + 4), d_c2(&eng, total * 128 + 4), d_c3(&eng, total * 128 + 4), d_row_off = up32(eng, row_off),
+        d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_sk = up32(eng, sel_sk),
+        d_sel_z = up_bytes(eng, flatten_fr(sel_z)), d_hash(&eng, hash.data(), 64), d_kk = up_bytes(eng, kk), d_sk_attr_off = up32(eng, sk_attr_off),
+        d_sk_idx = up32(eng, sk_idx), d_out(&eng, m_items * 384);
+    eng.check(rhip_upload_async(cx, d_c0.ptr(), h_x, m_items * 384), "upload");
+    eng.check(rhip_upload_async(cx, d_c1.ptr(), h_l, total * 384), "upload");
+    eng.check(rhip_upload_async(cx, d_c2.ptr(), h_l + total * 384, total * 128), "upload");
+    eng.check(rhip_upload_async(cx, d_c3.ptr(), h_l + total * 512, total * 128), "upload");
+    if (!trusted) {
+      auto ok0 = member_pass(eng, 3, d_c0.ptr(), m_items), ok1 = member_pass(eng, 3, d_c1.ptr(), total), ok2 = member_pass(eng, 2, d_c2.ptr(), total),
+           ok3 = member_pass(eng, 2, d_c3.ptr(), total);
+      for (size_t j = 0; j < m_items; j++) {
+        bool bad = !ok0[j];
+        for (uint32_t y = row_off[j]; y < row_off[j + 1] && !bad; y++) bad = !ok1[y] || !ok2[y] || !ok3[y];
+        if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
+      }
+      tm.lap("membership");
+    }
+    int32_t rc = rhip_aw11_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
+                                         d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(),
+                                         d_c2.as<rhip_g2>(), d_c3.as<rhip_g2>(), d_row_off.as<uint32_t>(), d_hash.as<rhip_g1>(), d_kk.as<rhip_g1>(),
+                                         d_sk_attr_off.as<uint32_t>(), d_sk_idx.as<uint32_t>(), d_out.as<rhip_gt>());
+    h_out = h_x + m_items * 384;
+    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
+    if (rc == RHIP_OK) rc = rhip_sync(cx);
+    eng.check(rc, "rhip_aw11_decrypt_batch");
+    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
+  }
+  tm.lap("device + copies");
+  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
+  tm.lap("AES open");
+  return true;
+}
+}  // namespace aw11
+
+}  // namespace schemes
+}  // namespace rabe

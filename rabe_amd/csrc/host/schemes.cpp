@@ -82,7 +82,20 @@ rhip_gt_table* Engine::gt_generator_table() {
   }
   return e_gen_tbl_;
 }
+void* Engine::aux(const std::string& kind, const std::string& key, void* (*make)(Engine&, const void*), const void* arg, void (*destroy)(void*), size_t cap) {
+  auto& m = aux_[kind];
+  auto it = m.find(key);
+  if (it != m.end()) return it->second.h;
+  if (m.size() >= cap) {
+    for (auto& c : m) c.second.destroy(c.second.h);
+    m.clear();
+  }
+  void* h = make(*this, arg);
+  m[key] = Aux{h, destroy};
+  return h;
+}
 Engine::~Engine() {
+  for (auto& k : aux_) for (auto& c : k.second) c.second.destroy(c.second.h);
   for (int i = 0; i < 4; i++) if (pin_[i]) rhip_host_free(ctx_, pin_[i]);
   if (e_gen_tbl_) rhip_gt_table_destroy(e_gen_tbl_);
   for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
@@ -305,7 +318,7 @@ static Fr must_inv(const Fr& a) {
   if (!fr_inv(a, &o)) throw std::runtime_error("called `Option::unwrap()` on a `None` value (Fr::inverse of zero)");
   return o;
 }
-static PolicyNode parse_or_error(const std::string& policy, PolicyLanguage lang) {
+PolicyNode parse_or_error(const std::string& policy, PolicyLanguage lang) {
   try {
     return parse_policy(policy, lang);
   } catch (const PolicyError& e) {
@@ -435,7 +448,7 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
 }
 // Host-side planning of a batch (share generation, hashing, pruning: string and Fr work) runs on all cores; the
 // randomness is pulled from the generator beforehand, item after item, so results do not depend on the thread count.
-static void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
   unsigned nt = std::thread::hardware_concurrency();
   if (nt > 64) nt = 64;
   if (n < 16 || nt < 2) { for (size_t i = 0; i < n; i++) fn(i); return; }

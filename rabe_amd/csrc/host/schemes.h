@@ -78,6 +78,12 @@ Gt decrypt_gt(Engine& eng, const CpAbeSecretKey& sk, const CpAbeCiphertext& ct);
 std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies,
                                            PolicyLanguage language, const std::vector<Bytes>& plaintexts);
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const CpAbeSecretKey*>& sks, const std::vector<const CpAbeCiphertext*>& cts);
+// the same two batches with packed input and output (packed.cpp): one blob of canonical records + offsets per side, caller-allocated
+// buffers, the device-resident Level B path (rhip_bsw_{encrypt,decrypt}_batch).  Conventions as ac17::cp_{encrypt,decrypt}_packed.
+bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
+                    const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
+bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                    int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 }  // namespace bsw
 
 namespace lsw {
@@ -98,6 +104,12 @@ Gt decrypt_gt(Engine& eng, const KpAbeSecretKey& sk, const KpAbeCiphertext& ct);
 std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk,
                                          const std::vector<std::string>& policies, PolicyLanguage language);
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const KpAbeSecretKey*>& sks, const std::vector<const KpAbeCiphertext*>& cts);
+// packed forms (packed.cpp) over rhip_lsw_{keygen,decrypt}_batch: n keys as one blob of KpAbeSecretKey records; decrypt takes the n keys
+// and ONE ciphertext (BASELINE config 4).  Positive attributes only -- policies / selections with "!x" take the object API.
+bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::vector<std::string>& policies,
+                   PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
+bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, bool trusted,
+                    int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 }  // namespace lsw
 
 namespace aw11 {
@@ -125,6 +137,12 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
                                           const std::vector<std::string>& policies, PolicyLanguage language, const std::vector<Bytes>& datas);
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, const std::vector<const Aw11SecretKey*>& sks,
                                          const std::vector<const Aw11Ciphertext*>& cts);
+// packed forms (packed.cpp) over rhip_aw11_{encrypt,decrypt}_batch; conventions as ac17::cp_{encrypt,decrypt}_packed
+bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::vector<std::string>& policies,
+                    PolicyLanguage language, size_t n, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf,
+                    size_t out_cap, uint64_t* out_off);
+bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
+                    bool trusted, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 }  // namespace aw11
 
 namespace ghw11 {

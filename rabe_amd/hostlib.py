@@ -341,3 +341,56 @@ def parse_obj(kind, data):
         raise ValueError(kind)
     r.done()
     return o
+
+
+# ---- packed batches (one blob of canonical records + offsets per side, caller-allocated numpy buffers): shared plumbing of
+# rabe_{ac17_cp,bsw,aw11}_encrypt_packed / rabe_lsw_keygen_packed and rabe_*_decrypt_packed
+PACKED_TRUSTED = 1
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as_u8(b):
+    import numpy as np
+    return b if isinstance(b, np.ndarray) else np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def packed_produce(host, fn, head_args, policies, item_policy, language, tail_arrays=(), out=None):
+    """calls `fn(host, *head_args, policies, n_policies, language, n, item_policy, *tail_arrays, out_buf, out_cap, out_off)`, growing
+    the output buffer once when the library reports the size it needs.  Returns (blob view, offsets uint64 [n+1])."""
+    import numpy as np
+    n = len(item_policy)
+    arr, npol = _strs(policies)
+    ip = np.ascontiguousarray(item_policy, dtype=np.uint32)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    tails = [_np_ptr(t) if hasattr(t, "ctypes") else t for t in tail_arrays]
+    for _ in range(2):
+        rc = getattr(host.lib, fn)(host.h, *head_args, arr, npol, language, ctypes.c_size_t(n), _np_ptr(ip), *tails, _np_ptr(buf),
+                                   ctypes.c_size_t(buf.size), _np_ptr(co))
+        if rc != 1:
+            break
+        buf = np.empty(int(co[n]), dtype=np.uint8)
+    _check(rc, host.h)
+    return buf[:int(co[n])], co
+
+
+def packed_decrypt(host, fn, head_args, blob, off, out=None, trusted=False):
+    """calls `fn(host, *head_args, n, blob, len, off, flags, status, pt_buf, pt_cap, pt_off)`.
+    Returns (pt_blob view, pt_off uint64 [n+1], status int32 [n])."""
+    import numpy as np
+    n = len(off) - 1
+    ct = _as_u8(blob)
+    co = np.ascontiguousarray(off, dtype=np.uint64)
+    po = np.zeros(n + 1, dtype=np.uint64)
+    status = np.zeros(max(n, 1), dtype=np.int32)
+    lo, hi = co[:-1], co[1:]
+    okm = (lo <= hi) & (hi <= ct.size)
+    need = int((hi[okm] - lo[okm]).sum()) if n else 0
+    buf = out if out is not None and out.size >= need else np.empty(max(need, 1), dtype=np.uint8)
+    rc = getattr(host.lib, fn)(host.h, *head_args, ctypes.c_size_t(n), _np_ptr(ct), ctypes.c_size_t(ct.size), _np_ptr(co),
+                               ctypes.c_uint32(PACKED_TRUSTED if trusted else 0), _np_ptr(status), _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(po))
+    _check(rc, host.h)
+    return buf[:int(po[n])], po, status[:n]

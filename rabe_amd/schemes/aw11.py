@@ -59,3 +59,17 @@ def encrypt_batch(host, gk, pks, policies, language, datas):
 
 def decrypt_batch(host, gk, sks, cts):
     return batch_decrypt(host, "rabe_aw11_decrypt_batch", (gk.ptr,), sks, cts)
+
+
+# ---- packed batches (rabe_aw11_{encrypt,decrypt}_packed): the device-resident path behind the scheme API
+def encrypt_packed(host, gk, pks, policies, item_policy, pt_blob, pt_off, language=JSON_POLICY, out=None):
+    import numpy as np
+    from ..hostlib import _as_u8, packed_produce
+    arr = (ctypes.c_void_p * max(1, len(pks)))(*[p.ptr for p in pks])
+    return packed_produce(host, "rabe_aw11_encrypt_packed", (gk.ptr, arr, ctypes.c_size_t(len(pks))), policies, item_policy, language,
+                          (_as_u8(pt_blob), np.ascontiguousarray(pt_off, dtype=np.uint64)), out)
+
+
+def decrypt_packed(host, gk, sk, ct_blob, ct_off, out=None, trusted=False):
+    from ..hostlib import packed_decrypt
+    return packed_decrypt(host, "rabe_aw11_decrypt_packed", (gk.ptr, sk.ptr), ct_blob, ct_off, out, trusted)

@@ -54,3 +54,17 @@ def encrypt_batch(host, pk, policies, language, plaintexts):
 
 def decrypt_batch(host, sks, cts):
     return batch_decrypt(host, "rabe_bsw_decrypt_batch", (), sks, cts)
+
+
+# ---- packed batches (rabe_bsw_{encrypt,decrypt}_packed): the device-resident path behind the scheme API
+def encrypt_packed(host, pk, policies, item_policy, pt_blob, pt_off, language=JSON_POLICY, out=None):
+    """policies: distinct texts, item_policy[i] indexes them, plaintext i = pt_blob[pt_off[i]:pt_off[i+1]] -> (ct_blob, ct_off)"""
+    import numpy as np
+    from ..hostlib import _as_u8, packed_produce
+    return packed_produce(host, "rabe_bsw_encrypt_packed", (pk.ptr,), policies, item_policy, language,
+                          (_as_u8(pt_blob), np.ascontiguousarray(pt_off, dtype=np.uint64)), out)
+
+
+def decrypt_packed(host, sk, ct_blob, ct_off, out=None, trusted=False):
+    from ..hostlib import packed_decrypt
+    return packed_decrypt(host, "rabe_bsw_decrypt_packed", (sk.ptr,), ct_blob, ct_off, out, trusted)

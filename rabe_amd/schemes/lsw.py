@@ -42,3 +42,16 @@ def keygen_batch(host, pk, msk, policies, language=JSON_POLICY):
 
 def decrypt_batch(host, sks, cts):
     return batch_decrypt(host, "rabe_lsw_decrypt_batch", (), sks, cts)
+
+
+# ---- packed batches (rabe_lsw_{keygen,decrypt}_packed): the device-resident path behind the scheme API
+def keygen_packed(host, pk, msk, policies, item_policy, language=JSON_POLICY, out=None):
+    """n keys as one blob of KpAbeSecretKey records: item i's policy = policies[item_policy[i]] -> (sk_blob, sk_off)"""
+    from ..hostlib import packed_produce
+    return packed_produce(host, "rabe_lsw_keygen_packed", (pk.ptr, msk.ptr), policies, item_policy, language, (), out)
+
+
+def decrypt_packed(host, ct, sk_blob, sk_off, out=None, trusted=False):
+    """n keys against ONE ciphertext object -> (pt_blob, pt_off, status)"""
+    from ..hostlib import packed_decrypt
+    return packed_decrypt(host, "rabe_lsw_decrypt_packed", (ct.ptr,), sk_blob, sk_off, out, trusted)

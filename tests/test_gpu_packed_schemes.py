@@ -1,0 +1,164 @@
+"""Packed batches of bsw / lsw / aw11 (rabe_{bsw,lsw,aw11}_*_packed): records byte-identical to serialising the objects of the
+per-object API on the same tape, round trips, per-item failures, and interoperability with the object API (the packed entry points
+run the device-resident Level B paths, the object API the general pairing-job path: two routes to the same bytes)."""
+import numpy as np
+import pytest
+
+from rabe_amd import hostlib as hl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    h = hl.Host(0)
+    yield h
+    h.close()
+
+
+def offsets(items):
+    return np.concatenate([[0], np.cumsum([len(p) for p in items])]).astype(np.uint64)
+
+
+BSW_POLS = ['"A" and "B" and "C"', '"A" or ("B" and "D")', '("C" or "D") and ("A" or "E") and "B"']
+
+
+def test_bsw_packed_equals_object_api_and_round_trips(host):
+    from rabe_amd.schemes import bsw
+    pk, msk = bsw.setup(host)
+    n = 9
+    item_pol = [i % 3 for i in range(n)]
+    pts = [b"bsw plaintext %d " % i * (i + 1) for i in range(n)]
+    # same tape through both APIs: secret, msg exponent, gate coefficients, nonce per item
+    tape = [1000003 * (i + 5) + 17 for i in range(40 * n)]
+    host.set_tape(tape)
+    objs = bsw.encrypt_batch(host, pk, [BSW_POLS[p] for p in item_pol], hl.HUMAN_POLICY, pts)
+    host.set_tape(tape)
+    blob, ct_off = bsw.encrypt_packed(host, pk, BSW_POLS, item_pol, b"".join(pts), offsets(pts), hl.HUMAN_POLICY)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes(), i
+    sk = bsw.keygen(host, pk, msk, ["A", "B", "C", "D"])
+    out, out_off, status = bsw.decrypt_packed(host, sk, blob, ct_off)
+    assert not status.any() and out.tobytes() == b"".join(pts) and (out_off == offsets(pts)).all()
+    # the packed records are ordinary ciphertexts: the object API (general pairing-job path) decrypts them too
+    for i in (0, 4, 8):
+        assert bsw.decrypt(host, sk, hl.Obj.deserialize("bsw_ct", blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes())) == pts[i]
+    # and the other way round: object-API ciphertexts in a packed decrypt
+    blob2 = b"".join(o.serialize() for o in objs)
+    out, _, status = bsw.decrypt_packed(host, sk, blob2, offsets([o.serialize() for o in objs]), trusted=True)
+    assert not status.any() and out.tobytes() == b"".join(pts)
+
+
+def test_bsw_packed_items_fail_individually(host):
+    from rabe_amd.schemes import bsw
+    pk, msk = bsw.setup(host)
+    n = 6
+    item_pol = [i % 3 for i in range(n)]
+    pts = [b"item %d" % i for i in range(n)]
+    blob, ct_off = bsw.encrypt_packed(host, pk, BSW_POLS, item_pol, b"".join(pts), offsets(pts), hl.HUMAN_POLICY)
+    sk_ab = bsw.keygen(host, pk, msk, ["A", "B"])                      # satisfies policy 1 only ("A" or ...)
+    out, out_off, status = bsw.decrypt_packed(host, sk_ab, blob, ct_off)
+    assert list(status) == [-1, 0, -1, -1, 0, -1]
+    assert [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(n)] == [b"", pts[1], b"", b"", pts[4], b""]
+    sk = bsw.keygen(host, pk, msk, ["A", "B", "C", "D", "E"])
+    raw = blob.tobytes()
+    bad = bytearray(raw)
+    bad[int(ct_off[2]) - 3] ^= 0x40                                    # item 1's sealed bytes
+    o = ct_off.copy()
+    o[6] = np.uint64(len(raw) + 1000)                                  # item 5 claims bytes past the blob
+    out, out_off, status = bsw.decrypt_packed(host, sk, bytes(bad), o)
+    assert list(status) == [0, -1, 0, 0, 0, -1]
+    # a leaf point off its curve fails the membership pass of that item only
+    rec = int(ct_off[3])
+    pl = int.from_bytes(raw[rec:rec + 4], "little")
+    first_leaf = rec + 4 + pl + 1 + 64 + 384 + 4
+    nl = int.from_bytes(raw[first_leaf:first_leaf + 4], "little")
+    bad = bytearray(raw)
+    bad[first_leaf + 4 + nl] ^= 1
+    out, out_off, status = bsw.decrypt_packed(host, sk, bytes(bad), ct_off)
+    assert list(status) == [0, 0, 0, -1, 0, 0]
+
+
+LSW_POLS = ['{"name": "and", "children": [{"name": "A"}, {"name": "B"}, {"name": "C"}]}',
+            '{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "D"}]}]}',
+            '{"name": "and", "children": [{"name": "or", "children": [{"name": "C"}, {"name": "D"}]}, {"name": "B"}]}']
+
+
+def test_lsw_packed_keygen_equals_object_api_and_decrypts(host):
+    from rabe_amd.schemes import lsw
+    pk, msk = lsw.setup(host)
+    n = 9
+    item_pol = [i % 3 for i in range(n)]
+    pt = b"lsw: one ciphertext, a fresh key per item"
+    ct = lsw.encrypt(host, pk, ["A", "B", "C"], pt)                 # satisfies policies 0 and 1, and 2 (C, B)
+    tape = [1000003 * (i + 9) + 29 for i in range(20 * n)]
+    host.set_tape(tape)
+    objs = lsw.keygen_batch(host, pk, msk, [LSW_POLS[p] for p in item_pol], hl.JSON_POLICY)
+    host.set_tape(tape)
+    blob, sk_off = lsw.keygen_packed(host, pk, msk, LSW_POLS, item_pol, hl.JSON_POLICY)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(sk_off[i]):int(sk_off[i + 1])].tobytes(), i
+    out, out_off, status = lsw.decrypt_packed(host, ct, blob, sk_off)
+    assert not status.any() and out.tobytes() == pt * n
+    # packed keys are ordinary keys: the object API decrypts with them
+    for i in (0, 4, 8):
+        assert lsw.decrypt(host, hl.Obj.deserialize("lsw_sk", blob[int(sk_off[i]):int(sk_off[i + 1])].tobytes()), ct) == pt
+    # a ciphertext that satisfies only some of the key policies: those items fail alone
+    ct2 = lsw.encrypt(host, pk, ["A", "E"], pt)                     # policy 1 only ("A" or ...)
+    out, out_off, status = lsw.decrypt_packed(host, ct2, blob, sk_off, trusted=True)
+    assert list(status) == [-1, 0, -1] * 3
+    # a key component off its curve: the membership pass fails that key only
+    raw = bytearray(blob.tobytes())
+    rec = int(sk_off[4])
+    pl = int.from_bytes(raw[rec:rec + 4], "little")
+    first = rec + 4 + pl + 1 + 4
+    nl = int.from_bytes(raw[first:first + 4], "little")
+    raw[first + 4 + nl] ^= 1
+    out, out_off, status = lsw.decrypt_packed(host, ct, bytes(raw), sk_off)
+    assert list(status) == [0, 0, 0, 0, -1, 0, 0, 0, 0]
+
+
+AW_POLS = ['{"name": "and", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "D"}, {"name": "or", "children": [{"name": "B"}, {"name": "C"}]}]}]}',
+           '{"name": "or", "children": [{"name": "and", "children": [{"name": "E"}, {"name": "A"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "D"}]}]}',
+           '{"name": "and", "children": [{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "D"}]}]}']
+
+
+def test_aw11_packed_equals_object_api_and_round_trips(host):
+    from rabe_amd.schemes import aw11
+    gk = aw11.setup(host)
+    pk1, msk1 = aw11.authgen(host, gk, ["A", "B", "C"])
+    pk2, msk2 = aw11.authgen(host, gk, ["D", "E"])
+    n = 9
+    item_pol = [i % 3 for i in range(n)]
+    pts = [b"aw11 plaintext %d " % i * (i + 1) for i in range(n)]
+    tape = [1000003 * (i + 3) + 41 for i in range(40 * n)]
+    host.set_tape(tape)
+    objs = aw11.encrypt_batch(host, gk, [pk1, pk2], [AW_POLS[p] for p in item_pol], hl.JSON_POLICY, pts)
+    host.set_tape(tape)
+    blob, ct_off = aw11.encrypt_packed(host, gk, [pk1, pk2], AW_POLS, item_pol, b"".join(pts), offsets(pts), hl.JSON_POLICY)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes(), i
+    sk = aw11.keygen(host, gk, msk1, "alice", ["A", "B", "C"])
+    aw11.add_to_attribute(host, gk, msk2, "D", sk)
+    aw11.add_to_attribute(host, gk, msk2, "E", sk)
+    out, out_off, status = aw11.decrypt_packed(host, gk, sk, blob, ct_off)
+    assert not status.any() and out.tobytes() == b"".join(pts) and (out_off == offsets(pts)).all()
+    for i in (1, 5):
+        assert aw11.decrypt(host, gk, sk, hl.Obj.deserialize("aw11_ct", blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes())) == pts[i]
+    # a key that satisfies only policy 1's second branch (C and D)
+    bob = aw11.keygen(host, gk, msk1, "bob", ["C"])
+    aw11.add_to_attribute(host, gk, msk2, "D", bob)
+    out, out_off, status = aw11.decrypt_packed(host, gk, bob, blob, ct_off, trusted=True)
+    assert list(status) == [-1, 0, -1] * 3
+    assert [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in (1, 4, 7)] == [pts[1], pts[4], pts[7]]
+    # tampered c_0 (an arbitrary Fq12 value is outside the order-r subgroup): that item only
+    raw = bytearray(blob.tobytes())
+    rec = int(ct_off[2])
+    pl = int.from_bytes(raw[rec:rec + 4], "little")
+    c0 = rec + 4 + pl + 1
+    raw[c0:c0 + 384] = b"".join((11 + i).to_bytes(32, "little") for i in range(12))
+    out, out_off, status = aw11.decrypt_packed(host, gk, sk, bytes(raw), ct_off)
+    assert list(status) == [0, 0, -1, 0, 0, 0, 0, 0, 0]
