@@ -84,6 +84,9 @@ def parse_args():
                     help="window width (bits) of the fixed-base table of g: 16 (67 MB, unsigned digits), or 17..27 signed digits "
                          "(20: 0.4 GB -- the default, a third of what the key's other tables take; 24: 5.4 GB; 26: 19 GB, reported as value_wide_tables)")
     ap.add_argument("--wide-window", type=int, default=26, help="g-window of the informational value_wide_tables leg (0 = skip the leg)")
+    ap.add_argument("--no-tail-overlap", action="store_true",
+                    help="run a remainder group (--steps not a multiple of --group) after the full groups on the same stream instead of first, "
+                         "with the next group's encrypt kernels beside its final exponentiation")
     ap.add_argument("--no-single-batch", action="store_true", help="skip the informational single-batch legs (--group 1 submissions)")
     ap.add_argument("--no-configs-leg", action="store_true", help="skip the bounded runs of BASELINE configs 3-5 (N = 1 only)")
     ap.add_argument("--configs-min-time", type=float, default=0.3, help="timed seconds per config of the configs leg")
@@ -291,14 +294,17 @@ def main():
     sk_lines = None if args.no_prepared_sk else E.Ac17SkLines(eng, 1, dk0)
     eng.sync()
 
-    def submit(g_steps, lane=None, on=None):
-        """one launch set over g_steps contiguous batches (on = (engine context, its buffers) of an extra lane)"""
+    def submit(g_steps, lane=None, on=None, part=3):
+        """one launch set over g_steps contiguous batches (on = (engine context, its buffers) of an extra lane); part: 1 = the
+        encrypt half, 2 = the decrypt half, 3 = both"""
         i = launch_no[0] % S if lane is None else lane
-        launch_no[0] += 1
+        if part & 1:
+            launch_no[0] += 1
         e_, (c0_, c_, cp_, out_) = on if on is not None else (lanes_ctx[i], bufs[i])
         n = g_steps * B
-        E.ac17_encrypt_dev(e_, pk, n, dA, d_item_A_off, d_ct_row_off, g_steps * rows_per_batch, ds, dmsg, c0_, c_, cp_)
-        if args.only_encrypt:
+        if part & 1:
+            E.ac17_encrypt_dev(e_, pk, n, dA, d_item_A_off, d_ct_row_off, g_steps * rows_per_batch, ds, dmsg, c0_, c_, cp_)
+        if args.only_encrypt or not (part & 2):
             return
         if sk_lines is None:
             E.ac17_decrypt_dev(e_, n, c0_, c_, d_ct_row_off, cp_, dk0, dk, d_sk_row_off, dkp, d_sk_idx,
@@ -307,14 +313,43 @@ def main():
             E.ac17_decrypt_prepared_dev(e_, n, c0_, c_, d_ct_row_off, cp_, sk_lines, dk, d_sk_row_off, dkp, d_sk_idx,
                                         d_ct_sel, d_ct_sel_off, d_sk_sel, d_sk_sel_off, out_)
 
+    # A remainder group (the driver's --steps 20 = 16 + 4) is a launch set whose final exponentiation -- one wave per item, 256
+    # waves for 4 steps -- leaves three quarters of the SIMDs idle for as long as a full group's.  It goes FIRST, on its own
+    # context, and the first full group's encrypt kernels run beside that final exponentiation (rhip_ctx_release_before_final_exp)
+    # instead of behind it; every Miller kernel still has the chip to itself.
+    tail = None
+    if S == 1 and len(sizes) >= 2 and sizes[-1] < sizes[0] and not args.no_tail_overlap and not args.only_encrypt:
+        e2 = Engine(local_rank)
+        # high priority: when the main stream is released, the remainder's final-exponentiation waves (a whole SIMD each) must be
+        # placed before the encrypt kernel's blocks fill every SIMD's register file -- otherwise they wait for that kernel to end
+        st2 = torch.cuda.Stream(device=local_rank, priority=-1)
+        e2.set_stream(st2.cuda_stream)
+        e2.set_pairing_mode(args.pairing_mode)
+        tb = sizes[-1] * B
+        tail = (e2, (e2.alloc(tb * 3 * 128), e2.alloc(sizes[-1] * rows_per_batch * 3 * 64), e2.alloc(tb * 384), ExtBuf(torch, tb * 384, dev)), st2)
+
     def run_steps():
         launch_no[0] = 0
+        if tail is not None:
+            e2, b2, _ = tail
+            e2.wait_for(eng)                                   # the previous region's work on the main stream is done
+            submit(sizes[-1], on=(e2, b2), part=1)
+            e2.release_before_final_exp(eng)                   # the main stream resumes when the tail's Miller loops are done
+            submit(sizes[-1], on=(e2, b2), part=2)
+            submit(sizes[0], lane=0, part=1)                   # beside the tail's final exponentiation
+            eng.wait_for(e2)
+            submit(sizes[0], lane=0, part=2)
+            for g_ in sizes[1:-1]:
+                submit(g_, lane=0)
+            return
         for g_ in sizes:
             submit(g_)
 
     def sync_all():
         for e_ in lanes_ctx:
             e_.sync()
+        if tail is not None:
+            tail[0].sync()
 
     def barrier():
         if world > 1:
@@ -335,7 +370,11 @@ def main():
     used = {}
     for j, g_ in enumerate(sizes):
         used[j % S] = g_                # the LAST group a lane ran is what its buffer holds
+    if tail is not None:
+        used = {0: sizes[-2] if len(sizes) > 1 else sizes[0]}
     ok = all(bufs[i][3].t[:g_ * B * 384].cpu().numpy().tobytes() == want[:g_ * B * 384] for i, g_ in used.items())
+    if tail is not None:
+        ok = ok and tail[1][3].t[:sizes[-1] * B * 384].cpu().numpy().tobytes() == want[:sizes[-1] * B * 384]
     gather = None
     if world > 1:
         f = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -370,6 +409,8 @@ def main():
                    "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": rows_per_batch // B,
                    "pruned_leaves_avg": round(sel_per_batch / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
                    "steps_per_launch_set": sizes, "launch_sets_in_flight": S, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"),
+                   "remainder_group": ("first, on its own stream; the next group's encrypt kernels run beside its final exponentiation"
+                                       if tail is not None else None),
                    "pairing_mode": args.pairing_mode,
                    "parallelism": "batch-sharded x%d (no data-path collective)" % world, "device": dev_name},
         "tables": {"bytes_per_public_key": table_bytes, "g_window_bits": gw, "g_table_bytes": g_table_bytes,

@@ -78,6 +78,11 @@ int32_t rhip_download_async(rhip_ctx* ctx, void* host_pinned, const void* dev, s
  * submitted to `other` so far has finished (event record + stream wait): e.g. a copy context that drains one batch's
  * outputs while the compute context already runs the next kernels */
 int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other);
+/* Pipelining two launch sets on two contexts (streams): `waiter`'s stream is held until ctx's NEXT decrypt (any entry point that runs
+ * the shared-accumulator Miller kernel) has issued its Miller loops; what is left on ctx then is its final exponentiation (one wave per
+ * item), beside which the waiter's encrypt kernels can run.  One-shot.  Typical use: a small launch set on ctx, the next large one on
+ * waiter -- submit ctx first, then enqueue waiter's work; make waiter's decrypt wait for all of ctx with rhip_ctx_wait_for. */
+int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------
  * rabe_bn surface replaced ("rabe_bn API surface actually used"):
@@ -109,7 +114,12 @@ int32_t rhip_g2_on_curve(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t
 /* membership in the groups proper (what decoding an untrusted element has to establish; G1 has cofactor 1, so on-curve suffices
  * there): G2 = the r-torsion of the twist (on the curve and r * P = O), Gt = the order-r subgroup of Fq12* */
 int32_t rhip_g2_in_subgroup(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
+/* the same verdicts by the definition r * Q = O (rhip_g2_in_subgroup uses the BN-specific test [u+1]Q + psi([u]Q) + psi^2([u]Q) =
+ * psi^3([2u]Q): one multiplication by the 63-bit curve parameter instead of the 254-bit order) -- kept for cross-checks */
+int32_t rhip_g2_in_subgroup_by_order(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
 int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
+/* the same verdicts with the order test by the definition f^r = 1 (rhip_gt_is_member uses f^p = f^(6u^2) after the cyclotomic test) */
+int32_t rhip_gt_is_member_by_order(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
 
 int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_gt* dev_b, rhip_gt* dev_out);
 /* out[i] = product of a[off[i] .. off[i+1]) (1 for an empty segment): the Gt accumulation loops of aw11::decrypt :320-352 */

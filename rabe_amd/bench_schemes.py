@@ -173,7 +173,7 @@ def packed_api_leg(args, b):
     from rabe_amd import hostprep as hp
     host = hl.Host(0)
     try:
-        n = b.B
+        n = b.B * b.default_group          # one packed call carries a launch set's worth of items, like the device-level groups
         pols = [hp.to_json(t) for t in b.trees]
         item_pol = np.arange(n, dtype=np.uint32) % len(pols)
         pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]

@@ -750,6 +750,17 @@ RB_HD void from_mont(uint32_t out[8], const Mont<M>& a) {
 #pragma unroll
   for (int i = 0; i < 8; i++) out[i] = r.v[i];
 }
+// inlined form of from_mont for kernels that must not call out of their hot loop (a call parks every live value in callee-saved
+// registers or on the stack: the AC17 row kernels)
+template <class M>
+RB_HD void from_mont_inl(uint32_t out[8], const Mont<M>& a) {
+  Mont<M> o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.v[i] = (i == 0) ? 1u : 0u;
+  Mont<M> r = mul_inl(a, o);
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = r.v[i];
+}
 // Reduce an arbitrary 256-bit integer into Montgomery form: mont_mul(x, R^2) = x*R mod m for any
 // x < 2^256 (the CIOS bound only needs one operand < mod).  This is `Fr::from_slice` on a SHA3
 // digest (src/utils/hash/mod.rs:16) -- SURVEY.md 8c assumption (i).

@@ -111,6 +111,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->fe_ws) (void)hipFree(ctx->fe_ws);
+  if (ctx->fe_started) (void)hipFree(ctx->fe_started);
   for (int i = 0; i < rhip_ctx::N_WORK; i++) if (ctx->work[i]) (void)hipFree(ctx->work[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -221,6 +222,15 @@ extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* de
 }
 
 // work submitted to `ctx` after this call starts only when everything submitted to `other` so far has finished
+// Pipelining of two launch sets on two contexts: `waiter`'s stream is held until THIS context's next multi-pairing launch has
+// issued its Miller kernel -- from there only the final exponentiation of this context is left, one wave per item, which fills
+// the chip only for >= 65 536 items; the waiter's occupancy-flexible kernels (the fixed-base encrypt kernels of the next launch
+// set) then run beside it instead of behind it.  One-shot; without a following pairing launch nothing is held.
+extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter) {
+  if (!ctx || !waiter || ctx == waiter) return RHIP_ERR_ARG;
+  ctx->fe_waiter = waiter;
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other) {
   if (!ctx || !other) return RHIP_ERR_ARG;
   hipEvent_t ev;
@@ -358,12 +368,16 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller(size_t n, const rhi
 }
 // out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical.
 // The exponentiation's Fq12 values live in the context's workspace (final_exponentiation_ws, bn254/pairing.h).
-__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_final_exp(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
-                                                  const rhip_gt* mul_in, rhip_gt* out, uint32_t* ws_base, size_t ws_stride) {
+// Blocks of four waves: a block owns one CU (see rb_facc_lds4) -- 65 536 items are one block per CU, fewer items leave whole CUs free.
+#define RB_FE_BLOCK 256
+__global__ void __launch_bounds__(RB_FE_BLOCK, RB_MIN_WAVES) k_final_exp(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill,
+                                                  const rhip_gt* mul_in, rhip_gt* out, uint32_t* ws_base, size_t ws_stride, uint32_t* started) {
+  // rhip_ctx_release_before_final_exp: every block announces that it is resident (the held stream's first kernel waits for the count)
+  if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const size_t lo = off ? off[i] : i * stride, hi = off ? off[i + 1] : (i + 1) * stride;
-  const DevWs ws{(uint4*)ws_base + i, ws_stride};
+  const DevWsT<LdsHomeT<4>> ws{(uint4*)ws_base + i, ws_stride};
   if (lo == hi) ws.st(FE_T0, fp12_one());
   for (size_t j = lo; j < hi; j++) {
     ws.st(j == lo ? FE_T0 : FE_T1, ld_gt_m(mill + j));
@@ -632,10 +646,12 @@ __global__ void __launch_bounds__(RB_ROWS_BLOCK, RB_G1_WAVES) k_ac17_enc_rows(co
     {
       const Fr s0 = load_fr(s[2 * item].l), s1 = load_fr(s[2 * item + 1].l);
       const Fr a0 = load_fr(A[(arow * 3 + l) * 2].l), a1 = load_fr(A[(arow * 3 + l) * 2 + 1].l);
-      k = add(mul(s0, a0), mul(s1, a1));
+      Fr t0, t1;
+      mul2_inl(t0, t1, s0, a0, s1, a1);          // inlined: no call inside the row loop
+      k = add(t0, t1);
     }
     uint32_t kk[8];
-    from_mont<FrParams>(kk, k);
+    from_mont_inl<FrParams>(kk, k);
     r = (w16 > 16) ? table_mul_g1_wide_inl(g_tbl, kk, w16) : w16 ? table_mul_g1_w16_inl(g_tbl, kk) : table_mul_g1(g_tbl, kk);
     if (l < 2 && active) park[l] = r;
   }
@@ -1068,13 +1084,42 @@ extern "C" int32_t rhip_gt_pow(rhip_ctx* ctx, size_t n, const rhip_gt* a, const 
 // 1.3x faster (Miller 8.4 ms vs 11.1 ms, final exponentiation 8.5 vs 11.6) but cost 2.3x the SIMD time, and at one
 // wave per SIMD (512 registers of replicated state) more than 21 504 pairs need a second round.  So "auto" uses them
 // only for small launches, where latency is all that matters; throughput-sized batches keep one lane per pairing.
+// first kernel on a stream released by rhip_ctx_release_before_final_exp: one wave that waits -- for a bounded number of polls, so
+// that nothing can hang on it -- until `target` final-exponentiation waves of the other context are resident.  Those waves need a
+// whole SIMD each; released without this, the held stream's many small blocks fill every SIMD's register file first and the final
+// exponentiation only starts when they are done (measured: no overlap at all).
+__global__ void __launch_bounds__(64) k_wait_resident(const uint32_t* started, uint32_t target, uint32_t max_polls) {
+  if (threadIdx.x != 0) return;
+  for (uint32_t p = 0; p < max_polls; p++) {
+    if (__atomic_load_n(started, __ATOMIC_RELAXED) >= target) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
 int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
                                 rhip_gt* out) {
   const size_t lanes = (n_items + 63) / 64 * 64;
   int32_t rc = ensure_fe_ws(ctx, lanes * FE_SLOTS * 96 * sizeof(uint32_t));
   if (rc) return rc;
-  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
-          (uint32_t*)ctx->fe_ws, lanes);
+  uint32_t* started = nullptr;
+  const size_t blocks = blocks_for(n_items, RB_FE_BLOCK);
+  if (ctx->fe_waiter) {                     // rhip_ctx_release_before_final_exp: the other context's stream goes on from here
+    rhip_ctx* w = ctx->fe_waiter;
+    ctx->fe_waiter = nullptr;
+    if (!ctx->fe_started) HIP_TRY(ctx, hipMalloc((void**)&ctx->fe_started, 256));
+    started = (uint32_t*)ctx->fe_started;
+    HIP_TRY(ctx, hipMemsetAsync(started, 0, 4, ctx->stream));
+    hipEvent_t ev;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);                  // everything before the final exponentiation is done
+    if (e == hipSuccess) e = hipStreamWaitEvent(w->stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(ctx, e, "rhip_ctx_release_before_final_exp");
+    // ... and the final exponentiation's waves are resident (at most as many as there are SIMDs); ~2 ms of polling at most
+    const uint32_t target = (uint32_t)(blocks < (size_t)ctx->n_cu ? blocks : (size_t)ctx->n_cu);
+    hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
+  }
+  KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks), dim3(RB_FE_BLOCK), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
+          (uint32_t*)ctx->fe_ws, lanes, started);
   return RHIP_OK;
 }
 bool rhip_use_c3(const rhip_ctx* ctx, size_t n_pairs) {

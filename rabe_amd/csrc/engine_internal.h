@@ -52,6 +52,8 @@ struct rhip_ctx {
   size_t work_bytes[N_WORK] = {0, 0, 0, 0, 0, 0, 0, 0};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
   int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
+  void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)
+  rhip_ctx* fe_waiter = nullptr;   // one-shot (rhip_ctx_release_before_final_exp): released after this context's next Miller launch
   bool timing = false;
   struct Pending { std::string name; hipEvent_t e0, e1; };
   std::vector<Pending> pending;
@@ -150,9 +152,18 @@ __device__ __forceinline__ void ld_scalar(uint32_t k[8], const rhip_fr* p) {
 // otherwise be evicted to scratch (HBM) between the Fq6-level steps is fetched from here instead.  Only kernels launched with
 // 64-thread blocks may use it.
 static __shared__ uint4 rb_facc_lds[36 * 64];
-struct LdsHome {
+// the same home for blocks of FOUR waves (k_final_exp): a block then owns a whole CU -- its four SIMDs and 144 KB of the LDS -- so
+// that a launch of few items packs into few CUs and leaves the others to whatever else is running (rhip_ctx_release_before_final_exp:
+// workgroups of the fixed-base kernels need a wave slot on every SIMD of a CU, and one resident final-exponentiation wave per CU
+// would lock them out of the whole chip)
+static __shared__ uint4 rb_facc_lds4[4 * 36 * 64];
+template <int W> __device__ __forceinline__ uint4* rb_facc_base();
+template <> __device__ __forceinline__ uint4* rb_facc_base<1>() { return rb_facc_lds + threadIdx.x; }
+template <> __device__ __forceinline__ uint4* rb_facc_base<4>() { return rb_facc_lds4 + (threadIdx.x >> 6) * (36 * 64) + (threadIdx.x & 63); }
+template <int W>
+struct LdsHomeT {
   __device__ __forceinline__ Fp ld_fp(int q0) const {
-    const uint4* p = rb_facc_lds + q0 * 64 + threadIdx.x;
+    const uint4* p = rb_facc_base<W>() + q0 * 64;
     const uint4 a = p[0], b = p[64];
     Fp r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
@@ -160,7 +171,7 @@ struct LdsHome {
     return r;
   }
   __device__ __forceinline__ void st_fp(int q0, const Fp& a) const {
-    uint4* p = rb_facc_lds + q0 * 64 + threadIdx.x;
+    uint4* p = rb_facc_base<W>() + q0 * 64;
     p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     p[64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
   }
@@ -177,7 +188,9 @@ struct LdsHome {
   __device__ __forceinline__ void st_x(const Fp6& v) const { st_q12(24, v); }
   __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
 };
-struct DevWs {
+typedef LdsHomeT<1> LdsHome;
+template <class HOME>
+struct DevWsT {
   uint4* base;         // + lane; [slot][quad of words][lane]: one 16-byte access per lane, contiguous over the wave
   size_t stride;       // lanes (padded to 64)
   __device__ __forceinline__ Fp2 ld2(const uint4* p) const {
@@ -206,8 +219,9 @@ struct DevWs {
   }
   __device__ __forceinline__ Fp12 ld(int slot) const { return Fp12{ld6(slot, 0), ld6(slot, 1)}; }
   __device__ __forceinline__ void st(int slot, const Fp12& a) const { st6(slot, 0, a.c0); st6(slot, 1, a.c1); }
-  __device__ __forceinline__ LdsHome home() const { return LdsHome{}; }
+  __device__ __forceinline__ HOME home() const { return HOME{}; }
 };
+typedef DevWsT<LdsHome> DevWs;
 struct GtM;
 int32_t rhip_build_w16_gt(rhip_ctx* ctx, const GtM* t8, GtM* t16);
 struct G2M;

@@ -138,11 +138,12 @@ struct DevTrees {
 // may then draw on their own sources in parallel
 template <class DRAW>
 void draw_items(Rng& rng, size_t n, DRAW draw) {
-  if (rng.unordered() && n >= 1024) {
-    const size_t blocks = (n + 255) / 256;
+  if (rng.unordered() && n >= 256) {
+    // an item of these schemes draws hundreds of values (one per gate coefficient and leaf): small blocks, so that every core draws
+    const size_t per = 16, blocks = (n + per - 1) / per;
     parallel_for(blocks, [&](size_t b) {
       OsRng local;
-      for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) draw(local, i);
+      for (size_t i = b * per; i < n && i < (b + 1) * per; i++) draw(local, i);
     });
   } else {
     for (size_t i = 0; i < n; i++) draw(rng, i);

@@ -206,6 +206,10 @@ class Engine:
     def host_free(self, p):
         self._check(self.lib.rhip_host_free(self.ctx, p))
 
+    def release_before_final_exp(self, waiter):
+        """one-shot: `waiter`'s stream is held until this context's next decrypt has issued its Miller loops (rhip_ctx_release_before_final_exp)"""
+        self._check(self.lib.rhip_ctx_release_before_final_exp(self.ctx, waiter.ctx))
+
     def wait_for(self, other):
         """order this context's future work after everything submitted to `other` so far (no host wait)"""
         self._check(self.lib.rhip_ctx_wait_for(self.ctx, other.ctx))

@@ -109,3 +109,72 @@ def test_one_malformed_policy_fails_its_item_only(host):
     broken = hl.Obj.deserialize("ac17_cp_ct", blob[:4] + b"(" * n + blob[4 + n:])
     got = ac17.cp_decrypt_batch(host, [sk] * 3, [cts[0], broken, cts[2]])
     assert got[0] == PT and got[2] == PT and got[1] is None
+
+
+@pytest.mark.gpu
+def test_fast_g2_subgroup_test_agrees_with_the_order_test():
+    """rhip_g2_in_subgroup uses the BN-specific criterion [u+1]Q + psi([u]Q) + psi^2([u]Q) = psi^3([2u]Q); it must give the verdicts
+    of the definition r * Q = O on members, on points of the twist outside G2 (a random twist point almost surely has a component in
+    the cofactor), on members shifted by a cofactor-torsion point, on infinity, on points off the twist and on non-canonical encodings."""
+    import random
+    import struct
+    from rabe_amd import Engine
+    from rabe_amd.engine import _sz
+    rnd = random.Random(99)
+    b2 = bn.fp2_mul((3, 0), bn.fp2_inv(bn.XI))
+    twist = []
+    while len(twist) < 12:
+        x = (rnd.randrange(bn.P), rnd.randrange(bn.P))
+        y = fp2_sqrt(bn.fp2_add(bn.fp2_mul(bn.fp2_mul(x, x), x), b2))
+        if y is not None:
+            twist.append((x, y))
+    members = [bn.g2_mul(bn.G2_GEN, rnd.randrange(1, bn.R)) for _ in range(12)]
+    # r * T lies in the cofactor torsion (T's G2 component is killed): a member plus such a point is on the twist, outside G2
+    cof = [bn.g2_add(bn.ec_mul(bn.FP2, t, bn.R - 1), t) for t in twist[:4]]
+    assert all(c is not None for c in cof)
+    shifted = [bn.g2_add(m, c) for m, c in zip(members, cof)]
+    off = [(m[0], bn.fp2_add(m[1], (1, 0))) for m in members[:3]]
+    pts = members + twist + cof + shifted + off + [None]
+    raw = [bn.g2_to_le(p) for p in pts]
+    x0, x1 = members[0][0]
+    raw.append((x0 + bn.P).to_bytes(32, "little") + bn.g2_to_le(members[0])[32:])          # x.c0 + p: the same point, second encoding
+    want = [1] * 12 + [0] * 12 + [0] * 4 + [0] * 4 + [0] * 3 + [1] + [0]
+    eng = Engine(0)
+    d = eng.upload(b"".join(raw))
+    n = len(raw)
+    for fn in ("rhip_g2_in_subgroup", "rhip_g2_in_subgroup_by_order"):
+        out = eng.alloc(4 * n)
+        eng._check(getattr(eng.lib, fn)(eng.ctx, _sz(n), d.ptr, out.ptr))
+        assert list(struct.unpack("<%dI" % n, eng.download(out))) == want, fn
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_fast_gt_membership_test_agrees_with_the_order_test():
+    """rhip_gt_is_member: cyclotomic test by Frobenius maps, then f^p = f^(6u^2) instead of f^r = 1.  Same verdicts as the definition
+    on members, on elements of the cyclotomic subgroup outside Gt (a random Fq12 value raised to the easy part of the final
+    exponentiation), on arbitrary Fq12 values, on 1 and on non-canonical encodings."""
+    import random
+    import struct
+    from rabe_amd import Engine
+    from rabe_amd.engine import _sz
+    rnd = random.Random(98)
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    members = [bn.gt_pow(e, rnd.randrange(1, bn.R)) for _ in range(6)] + [bn.GT_ONE]
+    rand12 = [bn.fp12_from_coeffs([rnd.randrange(bn.P) for _ in range(12)]) for _ in range(6)]
+    cyc = [bn.fp12_pow(f, bn.FE_EASY) for f in rand12[:4]]                      # order divides p^4 - p^2 + 1, almost surely not r
+    mixed = [bn.fp12_mul(m, c) for m, c in zip(members, cyc)]
+    vals = members + rand12 + cyc + mixed
+    raw = [bn.gt_to_le(v) for v in vals]
+    c0 = int.from_bytes(raw[0][:32], "little")
+    if c0 + bn.P < 1 << 256:
+        raw.append((c0 + bn.P).to_bytes(32, "little") + raw[0][32:])              # a member with a non-canonical first coefficient
+    want = [1] * 7 + [0] * 6 + [0] * 4 + [0] * 4 + [0] * (len(raw) - 21)
+    eng = Engine(0)
+    d = eng.upload(b"".join(raw))
+    n = len(raw)
+    for fn in ("rhip_gt_is_member", "rhip_gt_is_member_by_order"):
+        out = eng.alloc(4 * n)
+        eng._check(getattr(eng.lib, fn)(eng.ctx, _sz(n), d.ptr, out.ptr))
+        assert list(struct.unpack("<%dI" % n, eng.download(out))) == want, fn
+    eng.close()
