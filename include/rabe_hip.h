@@ -329,8 +329,8 @@ int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
                                const rhip_bsw_sk_lines* sk_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
 
 /* ---- Level B: LSW KP-ABE (src/schemes/lsw/mod.rs) ----------------------------------------------------------------
- * Positive leaves only: the reference's negative-attribute keygen branch (:137-146) stays in the host layer and its
- * decrypt has no negative branch at all (a TODO, :265-278). */
+ * rhip_lsw_keygen_batch: positive leaves; rhip_lsw_keygen_batch_signed: positive and negative ("!x", :137-146).  The reference's
+ * decrypt has no negative branch at all (a TODO, :265-278): the host layer reproduces what it does instead. */
 typedef struct rhip_lsw_pk rhip_lsw_pk;       /* window tables of g1, g2 (KpAbePublicKey, lsw/mod.rs:44-51) */
 int32_t rhip_lsw_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, rhip_lsw_pk** out);
 void rhip_lsw_pk_destroy(rhip_lsw_pk* pk);
@@ -344,6 +344,17 @@ int32_t rhip_lsw_keygen_batch(rhip_ctx* ctx, const rhip_lsw_pk* pk, size_t n_ite
                               const uint32_t* dev_gate_coef_off, const rhip_fr* dev_leaf_hash, const rhip_fr* dev_alpha /*[2]*/,
                               const rhip_fr* dev_coef, const uint32_t* dev_item_coef_off /*[n_items]*/, const rhip_fr* dev_rand /*[total_leaves]*/,
                               rhip_g1* dev_d1 /*[total_leaves]*/, rhip_g2* dev_d2 /*[total_leaves]*/);
+/* The same with negative leaves ("!x", lsw/mod.rs:137-146): leaf_neg[leaf] (per policy leaf, beside leaf_hash) != 0 marks them.
+ * A positive row gets (d1, d2) as above and the identity in d3..d5; a negative row gets the identity in d1, d2 and
+ *   d3 = g1 * q_y + g1_b2 * r_y,   d4 = g1_b * (h(y) r_y) + h_g1 * r_y,   d5 = g1 * (-r_y)
+ * with g1_b = g1 * b, g1_b2 = g1 * b^2 (dev_b = the master key's b, host_h_g1 its h_g1; a window table of h_g1 is built per call). */
+int32_t rhip_lsw_keygen_batch_signed(rhip_ctx* ctx, const rhip_lsw_pk* pk, size_t n_items, size_t total_leaves,
+                                     const uint32_t* dev_item_leaf_off /*[n_items+1]*/, const uint32_t* dev_item_tree_leaf, const uint32_t* dev_item_tree_gate,
+                                     const uint32_t* dev_path_off, const uint32_t* dev_path_gate, const uint32_t* dev_path_x, const uint32_t* dev_gate_k,
+                                     const uint32_t* dev_gate_coef_off, const rhip_fr* dev_leaf_hash, const uint32_t* dev_leaf_neg,
+                                     const rhip_fr* dev_alpha /*[2]*/, const rhip_fr* dev_b /*[1]*/, const rhip_g1* host_h_g1, const rhip_fr* dev_coef,
+                                     const uint32_t* dev_item_coef_off /*[n_items]*/, const rhip_fr* dev_rand /*[total_leaves]*/,
+                                     rhip_g1* dev_d1, rhip_g2* dev_d2, rhip_g1* dev_d3, rhip_g1* dev_d4, rhip_g1* dev_d5 /*[total_leaves] each*/);
 /* Group arithmetic of n_items calls of lsw::decrypt (lsw/mod.rs:228-290).  Selection entry e: the key's leaf row
  * (sel_sk_leaf, relative to the key's first row), the ciphertext's attribute row (sel_ct_attr, relative) and the leaf's
  * coefficient c.  Item i: entries sel_start[i] .. + m_i - 1, pairs [pair_off[i], pair_off[i+1]) with m_i + 1 of them; its

@@ -134,8 +134,9 @@ int32_t rabe_lsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, c
 /* Packed forms over the device-resident path (rhip_lsw_{keygen,decrypt}_batch; src/schemes/lsw/mod.rs:121-290): keygen writes n
  * KpAbeSecretKey records (item i's policy = policies[item_policy[i]]) into one caller-allocated blob; decrypt takes n such records
  * and ONE ciphertext object (BASELINE config 4) and returns n plaintexts.  Size / status / ct_len / RABE_PACKED_TRUSTED conventions as
- * rabe_ac17_cp_{encrypt,decrypt}_packed.  Positive attributes only: a policy with "!x" leaves, or a selection that reaches one, is an
- * error here -- rabe_lsw_keygen / rabe_lsw_decrypt reproduce the reference's negative branches. */
+ * rabe_ac17_cp_{encrypt,decrypt}_packed.  keygen handles negative leaves ("!x", lsw/mod.rs:137-146) on the device as well; a decrypt
+ * whose pruned selection reaches a negative attribute fails that item -- the reference's own decrypt has no negative branch (a TODO,
+ * :265-278), and rabe_lsw_decrypt reproduces what it does instead. */
 int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language,
                                size_t n_items, const uint32_t* item_policy /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, const uint8_t* sk_blob, size_t sk_len,

@@ -135,8 +135,11 @@ static inline uint32_t uniform_ppi(size_t n_items, size_t max_pairs, size_t tota
 static inline size_t pair_lanes(size_t n_items, size_t total_pairs, uint32_t ppi) { return ppi ? (n_items + 63) / 64 * 64 * (size_t)ppi : total_pairs; }
 
 // ------------------------------------------------------------------------------------------------ the multi-pairing kernel
-// The Fq12 accumulator of a lane lives in LDS (LdsHome, engine_internal.h) -- nothing of the loop goes to scratch.
-struct DevMultiAcc : LdsHome {
+// The Fq12 accumulator of a lane lives in LDS (LdsHomeT, engine_internal.h) -- nothing of the loop goes to scratch.  Blocks of four
+// waves: a block owns one CU (see rb_facc_lds4), so that a launch smaller than the chip leaves WHOLE CUs to whatever else is running
+// (launch sets in flight on other streams: their 256-thread blocks need a wave slot on every SIMD of a CU).
+#define RB_MILLER_BLOCK 256
+struct DevMultiAcc : LdsHomeT<4> {
   const G1M* P;
   const G2M* Q;
   const uint32_t* qref;
@@ -187,7 +190,7 @@ struct DevMultiAcc : LdsHome {
 // lane t = chunk * n_items + item: a wave holds 64 items at the same chunk position, so that batches of equally shaped
 // items run without divergence and read the same prepared lines.  Chunk c of an item = its pairs
 // [pair_off[item] + c C, min(pair_off[item] + (c+1) C, pair_off[item+1])).  Output: mill[item * L + c].
-__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
+__global__ void __launch_bounds__(RB_MILLER_BLOCK, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                   const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
                                                                   GtM* mill) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,7 +245,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   rc = ensure_scratch(ctx, lanes * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
-  KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, 64)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
+  KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
           (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill);
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
 }
@@ -633,6 +636,71 @@ extern "C" int32_t rhip_lsw_keygen_batch(rhip_ctx* ctx, const rhip_lsw_pk* pk, s
   rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, (const rhip_fr*)w, d1);
   if (rc) return rc;
   return rhip_g2_table_mul(ctx, pk->g2, total_leaves, rand, d2);
+}
+// keygen with negative leaves ("!x", lsw/mod.rs:137-146) beside positive ones: per leaf row six scalars --
+//   positive:  k1 = alpha2 q + h(y) r   (D1 = g1 * k1),   k2 = r  (D2 = g2 * r),   k3 = k4a = k4b = k5 = 0
+//   negative:  k1 = k2 = 0,   k3 = q + b^2 r   (D3 = g1 * q + g1_b2 * r = g1 * k3),   k4a = b h(y) r,  k4b = r
+//              (D4 = g1_b * (h r) + h_g1 * r = g1 * k4a + h_g1 * k4b),   k5 = -r   (D5 = g1 * (-r))
+// a zero scalar gives the identity, which is what the reference's struct holds in the unused slots of a row (None -> G::zero()).
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_lsw_keygen_scalars_signed(size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                                                                const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, TreeTables tt,
+                                                                                const rhip_fr* leaf_hash, const uint32_t* leaf_neg, const rhip_fr* alpha /*[2]*/,
+                                                                                const rhip_fr* b, const rhip_fr* coef, const uint32_t* item_coef_off,
+                                                                                const rhip_fr* rand, rhip_fr* k /* [6][total_leaves] */) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_leaves) return;
+  const size_t item = owner_of(item_leaf_off, n_items, t);
+  const uint32_t leaf = item_tree_leaf[item] + (uint32_t)(t - item_leaf_off[item]);
+  const Fr q = share_of_leaf(tt, leaf, item_tree_gate[item], coef + item_coef_off[item], load_fr(alpha[0].l));
+  const Fr r = load_fr(rand[t].l), h = load_fr(leaf_hash[leaf].l), z = zero<FrParams>();
+  const bool neg_leaf = leaf_neg[leaf] != 0;
+  Fr k1 = z, k2 = z, k3 = z, k4a = z, k4b = z, k5 = z;
+  if (neg_leaf) {
+    const Fr bb = load_fr(b[0].l);
+    k3 = add(q, mul(mul(bb, bb), r));
+    k4a = mul(mul(bb, h), r);
+    k4b = r;
+    k5 = neg(r);
+  } else {
+    k1 = add(mul(load_fr(alpha[1].l), q), mul(h, r));
+    k2 = r;
+  }
+  store_fr(k[t].l, k1);
+  store_fr(k[total_leaves + t].l, k2);
+  store_fr(k[2 * total_leaves + t].l, k3);
+  store_fr(k[3 * total_leaves + t].l, k4a);
+  store_fr(k[4 * total_leaves + t].l, k4b);
+  store_fr(k[5 * total_leaves + t].l, k5);
+}
+extern "C" int32_t rhip_lsw_keygen_batch_signed(rhip_ctx* ctx, const rhip_lsw_pk* pk, size_t n_items, size_t total_leaves, const uint32_t* item_leaf_off,
+                                                const uint32_t* item_tree_leaf, const uint32_t* item_tree_gate, const uint32_t* path_off,
+                                                const uint32_t* path_gate, const uint32_t* path_x, const uint32_t* gate_k, const uint32_t* gate_coef_off,
+                                                const rhip_fr* leaf_hash, const uint32_t* leaf_neg, const rhip_fr* alpha, const rhip_fr* b,
+                                                const rhip_g1* host_h_g1, const rhip_fr* coef, const uint32_t* item_coef_off, const rhip_fr* rand,
+                                                rhip_g1* d1, rhip_g2* d2, rhip_g1* d3, rhip_g1* d4, rhip_g1* d5) {
+  NEED(ctx);
+  if (!pk || !host_h_g1) return RHIP_ERR_ARG;
+  if (!n_items || !total_leaves) return RHIP_OK;
+  void* w = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 4, total_leaves * (6 * sizeof(rhip_fr) + sizeof(rhip_g1)), &w);
+  if (rc) return rc;
+  rhip_fr* k = (rhip_fr*)w;
+  rhip_g1* tmp = (rhip_g1*)(k + 6 * total_leaves);
+  const TreeTables tt{path_off, path_gate, path_x, gate_k, gate_coef_off};
+  KLAUNCH(ctx, "k_lsw_keygen_scalars_signed", k_lsw_keygen_scalars_signed, dim3(blocks_for(total_leaves, 256)), dim3(256), 0, ctx->stream, n_items,
+          total_leaves, item_leaf_off, item_tree_leaf, item_tree_gate, tt, leaf_hash, leaf_neg, alpha, b, coef, item_coef_off, rand, k);
+  rhip_g1_table* th = nullptr;
+  rc = rhip_g1_table_create(ctx, host_h_g1, &th);
+  if (!rc) rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, k, d1);
+  if (!rc) rc = rhip_g2_table_mul(ctx, pk->g2, total_leaves, k + total_leaves, d2);
+  if (!rc) rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, k + 2 * total_leaves, d3);
+  if (!rc) rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, k + 3 * total_leaves, tmp);
+  if (!rc) rc = rhip_g1_table_mul(ctx, th, total_leaves, k + 4 * total_leaves, d4);
+  if (!rc) rc = rhip_g1_add(ctx, total_leaves, tmp, d4, d4);
+  if (!rc) rc = rhip_g1_table_mul(ctx, pk->g1, total_leaves, k + 5 * total_leaves, d5);
+  if (!rc) rc = rhip_sync(ctx);                       // the table of h_g1 lives for this call only
+  rhip_g1_table_destroy(th);
+  return rc;
 }
 // decrypt (lsw/mod.rs:228-290 restated in SURVEY.md Appendix B.4): item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 1:
 //   s < m : P = c_e * E1[ct attr],                  Q = D2[key leaf]          (e = sel_start[i] + s)

@@ -497,16 +497,17 @@ void destroy_pk(void* h) { rhip_lsw_pk_destroy((rhip_lsw_pk*)h); }
 
 // n calls of lsw::keygen (lsw/mod.rs:121-170).  Draw order per item: the gate coefficients of gen_shares_policy(alpha1), then one
 // `random` per share (:136).  Record = KpAbeSecretKey: policy text, language, leaf count, per leaf (name, d1, d2, d3, d4, d5) with
-// d3..d5 the identity for positive leaves.  Policies with negative attributes ("!x", :137-146) take the object API (rabe_lsw_keygen).
+// d3..d5 the identity for positive leaves and d1, d2 the identity for negative ones ("!x", :137-146: rhip_lsw_keygen_batch_signed).
 bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::vector<std::string>& policies,
                    PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("lsw::keygen_packed");
   std::vector<std::shared_ptr<const FlatPolicy>> pols;
   std::vector<std::vector<std::string>> striped(policies.size());
   std::vector<size_t> fixed(policies.size());
+  bool any_negative = false;
   for (size_t p = 0; p < policies.size(); p++) {
     pols.push_back(flat_policy(policies[p], language));
-    if (pols[p]->has_negative) throw RabeError("lsw::keygen_packed: policies with negative attributes take rabe_lsw_keygen / rabe_lsw_keygen_batch");
+    any_negative = any_negative || pols[p]->has_negative;
     fixed[p] = 4 + policies[p].size() + 1 + 4;
     for (const auto& nc : pols[p]->leaf_name_col) { striped[p].push_back(remove_index(nc)); fixed[p] += 4 + striped[p].back().size() + 64 + 128 + 3 * 64; }
   }
@@ -540,11 +541,26 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
        d_in(&eng, 64 + (total_coef + total + 1) * 32), d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4);
   eng.check(rhip_upload_async(cx, d_in.ptr(), h_in, 64 + (total_coef + total) * 32), "upload");
   const rhip_fr* din = d_in.as<rhip_fr>();
-  eng.check(rhip_lsw_keygen_batch(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
-                                  dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
-                                  dt.leaf_hash.as<rhip_fr>(), din, din + 2, d_coef_off.as<uint32_t>(), din + 2 + total_coef, d_d1.as<rhip_g1>(),
-                                  d_d2.as<rhip_g2>()), "rhip_lsw_keygen_batch");
-  uint8_t* h_l = eng.pinned(1, total * 192 + 4);
+  uint8_t* h_l = eng.pinned(1, total * (192 + (any_negative ? 192 : 0)) + 4);       // d1 rows | d2 rows [| d3 | d4 | d5 rows]
+  DBuf d_d345;
+  if (!any_negative) {
+    eng.check(rhip_lsw_keygen_batch(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
+                                    dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
+                                    dt.leaf_hash.as<rhip_fr>(), din, din + 2, d_coef_off.as<uint32_t>(), din + 2 + total_coef, d_d1.as<rhip_g1>(),
+                                    d_d2.as<rhip_g2>()), "rhip_lsw_keygen_batch");
+  } else {                                   // negative leaves (lsw/mod.rs:137-146): d3, d4, d5 from the share, b and the master key's h_g1
+    std::vector<uint32_t> leaf_neg;
+    for (const auto& f : pols) for (const auto& nm : f->leaf_name) leaf_neg.push_back(is_negative(nm) ? 1u : 0u);
+    DBuf d_neg = up32(eng, leaf_neg), d_b(&eng, msk.b.l, 32);
+    d_d345 = DBuf(&eng, total * 192 + 4);
+    rhip_g1* d3 = d_d345.as<rhip_g1>();
+    eng.check(rhip_lsw_keygen_batch_signed(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
+                                           dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
+                                           dt.leaf_hash.as<rhip_fr>(), d_neg.as<uint32_t>(), din, d_b.as<rhip_fr>(), (const rhip_g1*)msk.h_g1.data(),
+                                           din + 2, d_coef_off.as<uint32_t>(), din + 2 + total_coef, d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(), d3,
+                                           d3 + total, d3 + 2 * total), "rhip_lsw_keygen_batch_signed");
+    eng.check(rhip_download_async(cx, h_l + total * 192, d_d345.ptr(), total * 192), "download");
+  }
   eng.check(rhip_download_async(cx, h_l, d_d1.ptr(), total * 64), "download");
   eng.check(rhip_download_async(cx, h_l + total * 64, d_d2.ptr(), total * 128), "download");
   eng.check(rhip_sync(cx), "rhip_sync");
@@ -563,7 +579,11 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
       memcpy(w, nm.data(), nm.size()); w += nm.size();
       memcpy(w, h_l + (size_t)(leaf_off[i] + y) * 64, 64); w += 64;
       memcpy(w, h_l + total * 64 + (size_t)(leaf_off[i] + y) * 128, 128); w += 128;
-      memset(w, 0, 192); w += 192;
+      if (any_negative) {
+        for (int k3 = 0; k3 < 3; k3++) { memcpy(w, h_l + total * 192 + ((size_t)k3 * total + leaf_off[i] + y) * 64, 64); w += 64; }
+      } else {
+        memset(w, 0, 192); w += 192;
+      }
     }
   });
   tm.lap("assembly");

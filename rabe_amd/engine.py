@@ -441,6 +441,15 @@ def lsw_keygen_dev(eng, pk, n_items, total_leaves, d_item_leaf_off, d_item_tree_
                                              _p(d_d1), _p(d_d2)))
 
 
+def lsw_keygen_signed_dev(eng, pk, n_items, total_leaves, d_item_leaf_off, d_item_tree_leaf, d_item_tree_gate, dtt, d_leaf_neg, d_alpha, d_b, h_g1,
+                          d_coef, d_item_coef_off, d_rand, d_d1, d_d2, d_d3, d_d4, d_d5):
+    """rhip_lsw_keygen_batch_signed: policies with negative leaves ("!x"); h_g1 = the master key's h_g1 (64 host bytes)"""
+    eng._check(eng.lib.rhip_lsw_keygen_batch_signed(eng.ctx, pk.h, _sz(n_items), _sz(total_leaves), _p(d_item_leaf_off), _p(d_item_tree_leaf),
+                                                    _p(d_item_tree_gate), _p(dtt.path_off), _p(dtt.path_gate), _p(dtt.path_x), _p(dtt.gate_k),
+                                                    _p(dtt.gate_coef_off), _p(dtt.leaf_hash), _p(d_leaf_neg), _p(d_alpha), _p(d_b), bytes(h_g1),
+                                                    _p(d_coef), _p(d_item_coef_off), _p(d_rand), _p(d_d1), _p(d_d2), _p(d_d3), _p(d_d4), _p(d_d5)))
+
+
 def lsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_sel_start, d_sel_sk_leaf, d_sel_ct_attr, d_sel_coeff, d_ct_e1,
                     d_ct_e2, d_ct_e1j, d_ct_attr_off, d_ct_idx, d_sk_d1, d_sk_d2, d_sk_leaf_off, d_sk_idx, e2_lines, d_out):
     eng._check(eng.lib.rhip_lsw_decrypt_batch(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _sz(n_sel), _p(d_pair_off), _p(d_sel_start),

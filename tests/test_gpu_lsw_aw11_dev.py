@@ -96,6 +96,44 @@ def test_lsw_device_keygen_decrypt_match_oracle(eng):
     dpk.destroy()
 
 
+def test_lsw_device_keygen_with_negative_leaves_matches_oracle(eng):
+    """lsw/mod.rs:137-146: a "!x" leaf gets (d3, d4, d5) from the share, b, b^2 and the master key's h_g1; positive rows of the same
+    key keep (d1, d2).  Device (rhip_lsw_keygen_batch_signed) against the oracle on the same tape, byte for byte."""
+    rng = SeededRng(47)
+    pk, msk = sch.lsw_setup(rng)
+    N1 = ("and", [("leaf", "A"), ("leaf", "!B"), ("or", [("leaf", "!C"), ("leaf", "D")])])
+    N2 = ("or", [("and", [("leaf", "!D"), ("leaf", "E")]), ("leaf", "!A")])
+    trees = [N1, N2, L3]
+    tt = hp.TreeTables(trees)
+    dtt = E.DevTreeTables(eng, tt)
+    dpk = E.LswPk(eng, bn.g1_to_le(pk["g1"]), bn.g2_to_le(pk["g2"]))
+    items = [0, 1, 2, 0, 1]
+    n = len(items)
+    rnd = random.Random(17)
+    coefs = [[rnd.randrange(bn.R) for _ in range(tt.n_coef(p))] for p in items]
+    rands = [[rnd.randrange(1, bn.R) for _ in range(tt.n_leaves(p))] for p in items]
+    leaf_off = offsets([tt.n_leaves(p) for p in items])
+    coef_off = offsets([len(c) for c in coefs])
+    total = leaf_off[-1]
+    d = [eng.alloc(total * 64), eng.alloc(total * 128), eng.alloc(total * 64), eng.alloc(total * 64), eng.alloc(total * 64)]
+    leaf_neg = [1 if nm.startswith("!") else 0 for f in tt.flat for nm in f["names"]]
+    E.lsw_keygen_signed_dev(eng, dpk, n, total, eng.upload_u32(leaf_off), eng.upload_u32([tt.first_leaf[p] for p in items]),
+                            eng.upload_u32([tt.first_gate[p] for p in items]), dtt, eng.upload_u32(leaf_neg),
+                            eng.upload(le(msk["alpha1"]) + le(msk["alpha2"])), eng.upload(le(msk["b"])), bn.g1_to_le(msk["h_g1"]),
+                            eng.upload(b"".join(le(x) for c in coefs for x in c) or bytes(32)), eng.upload_u32(coef_off[:-1]),
+                            eng.upload(b"".join(le(x) for r in rands for x in r)), *d)
+    sks = [sch.lsw_keygen(pk, msk, hp.to_json(trees[p]), pol.JSON, ListRng(coefs[i] + rands[i])) for i, p in enumerate(items)]
+    rows = [row for sk in sks for row in sk["dj"]]
+    assert any(r[1] is None for r in rows) and any(r[3] is None for r in rows)
+    g1 = lambda p: bn.g1_to_le(p)              # None (the struct's unused slot) is the identity: zeros
+    assert eng.download(d[0]) == b"".join(g1(r[1]) for r in rows)
+    assert eng.download(d[1]) == b"".join(bn.g2_to_le(r[2]) for r in rows)
+    assert eng.download(d[2]) == b"".join(g1(r[3]) for r in rows)
+    assert eng.download(d[3]) == b"".join(g1(r[4]) for r in rows)
+    assert eng.download(d[4]) == b"".join(g1(r[5]) for r in rows)
+    dpk.destroy()
+
+
 # ---------------------------------------------------------------------------------------------------------------- AW11
 W1 = ("and", [("leaf", "A"), ("and", [("leaf", "D"), ("or", [("leaf", "B"), ("leaf", "C")])])])
 W2 = ("or", [("and", [("leaf", "E"), ("leaf", "A")]), ("and", [("leaf", "C"), ("leaf", "D")])])

@@ -120,6 +120,21 @@ def test_lsw_packed_keygen_equals_object_api_and_decrypts(host):
     assert list(status) == [0, 0, 0, 0, -1, 0, 0, 0, 0]
 
 
+def test_lsw_packed_keygen_with_negative_attributes_equals_object_api(host):
+    from rabe_amd.schemes import lsw
+    pk, msk = lsw.setup(host)
+    pols = ['{"name": "and", "children": [{"name": "A"}, {"name": "!B"}, {"name": "or", "children": [{"name": "!C"}, {"name": "D"}]}]}', LSW_POLS[0]]
+    item_pol = [0, 1, 0, 0, 1]
+    tape = [1000003 * (i + 2) + 53 for i in range(60)]
+    host.set_tape(tape)
+    objs = lsw.keygen_batch(host, pk, msk, [pols[p] for p in item_pol], hl.JSON_POLICY)
+    host.set_tape(tape)
+    blob, sk_off = lsw.keygen_packed(host, pk, msk, pols, item_pol, hl.JSON_POLICY)
+    host.clear_tape()
+    for i in range(len(item_pol)):
+        assert objs[i].serialize() == blob[int(sk_off[i]):int(sk_off[i + 1])].tobytes(), i
+
+
 AW_POLS = ['{"name": "and", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "D"}, {"name": "or", "children": [{"name": "B"}, {"name": "C"}]}]}]}',
            '{"name": "or", "children": [{"name": "and", "children": [{"name": "E"}, {"name": "A"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "D"}]}]}',
            '{"name": "and", "children": [{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}, {"name": "and", "children": [{"name": "C"}, {"name": "D"}]}]}']

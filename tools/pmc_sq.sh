@@ -6,7 +6,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
   rm -rf gpurun_out/sq_$i
-  timeout 900 rocprofv3 --pmc $set --kernel-trace -d gpurun_out/sq_$i -o t --output-format csv -- python bench.py --steps 16 --warmup 16 --inflight 1 --min-time 0 --no-cpu-baseline --no-object-api --no-host-io-leg "$@" > /dev/null 2> gpurun_out/sq_$i.err
+  timeout 900 rocprofv3 --pmc $set --kernel-trace -d gpurun_out/sq_$i -o t --output-format csv -- python bench.py --steps 16 --warmup 16 --inflight 1 --min-time 0 --no-cpu-baseline --no-object-api --no-host-io-leg --no-single-batch --no-configs-leg --wide-window 0 "$@" > /dev/null 2> gpurun_out/sq_$i.err
 done
 python - <<'PY'
 import csv, collections, glob

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  timeout 900 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_$c -o t --output-format csv -- python bench.py --steps 16 --warmup 16 --inflight 1 --min-time 0 --no-cpu-baseline --no-object-api --no-host-io-leg "$@" > /dev/null 2> gpurun_out/pmc_$c.err
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_$c -o t --output-format csv -- python bench.py --steps 16 --warmup 16 --inflight 1 --min-time 0 --no-cpu-baseline --no-object-api --no-host-io-leg --no-single-batch --no-configs-leg --wide-window 0 "$@" > /dev/null 2> gpurun_out/pmc_$c.err
 done
 python - <<'PY'
 import csv, collections, glob
