@@ -447,18 +447,20 @@ def main():
         lat = (time.perf_counter() - t0) / reps
         single = {"batch": B, "latency_ms": round(1e3 * lat, 3), "ops_per_s_alone": round(B / lat, 1)}
         for k_in in (2, 4):
-            n_sub = 16 * k_in
-            best_dt = None
-            for _rep in range(3):                      # best of three passes (the first still warms the extra streams' queues)
-                t0 = time.perf_counter()
-                for j in range(n_sub):
+            # the same machinery as the headline: exactly-16-submission regions repeated for >= 0.3 s (what `bench.py --group 1
+            # --inflight 4 --steps 16` measures)
+            def run_k():
+                for j in range(16):
                     e2, b2, _ = extra[j % k_in]
                     submit(1, on=(e2, b2))
+
+            def sync_k():
                 for e2, _, _ in extra[:k_in]:
                     e2.sync()
-                dt = time.perf_counter() - t0
-                best_dt = dt if best_dt is None else min(best_dt, dt)
-            single["ops_per_s_%d_in_flight" % k_in] = round(n_sub * B / best_dt, 1)
+            run_k()
+            sync_k()
+            reg_k = timed_regions(run_k, sync_k, 0.3)
+            single["ops_per_s_%d_in_flight" % k_in] = round(16 * B / (sum(reg_k) / len(reg_k)), 1)
         single["roundtrip_bit_exact"] = all(b2[3].t[:B * 384].cpu().numpy().tobytes() == want[:B * 384] for _, b2, _ in extra)
         single["fraction_of_grouped_rate"] = round(single["ops_per_s_4_in_flight"] / value, 3)
         single["note"] = ("one step per launch set (--group 1): a lone batch is 64 final-exponentiation waves and 192-384 Miller waves on 1024 SIMDs, and its "
