@@ -286,6 +286,14 @@ def main():
         e2.set_pairing_mode(args.pairing_mode)
         lanes_ctx.append(e2)
         streams.append(st2)
+    # spare contexts (streams) for the remainder group and the single-batch legs, created here with the others: four in all
+    pool = [(e_, st_) for e_, st_ in zip(lanes_ctx, streams)]
+    while world == 1 and len(pool) < 4:
+        e2 = Engine(local_rank)
+        st2 = torch.cuda.Stream(device=local_rank)
+        e2.set_stream(st2.cuda_stream)
+        e2.set_pairing_mode(args.pairing_mode)
+        pool.append((e2, st2))
     total_rows = ct_row_off[GB]
     bufs = [(e_.alloc(GB * 3 * 128), e_.alloc(total_rows * 3 * 64), e_.alloc(GB * 384), ExtBuf(torch, GB * 384, dev)) for e_ in lanes_ctx]
     launch_no = [0]
@@ -319,12 +327,14 @@ def main():
     # instead of behind it; every Miller kernel still has the chip to itself.
     tail = None
     if S == 1 and len(sizes) >= 2 and sizes[-1] < sizes[0] and not args.no_tail_overlap and not args.only_encrypt:
-        e2 = Engine(local_rank)
-        # high priority: when the main stream is released, the remainder's final-exponentiation waves (a whole SIMD each) must be
-        # placed before the encrypt kernel's blocks fill every SIMD's register file -- otherwise they wait for that kernel to end
-        st2 = torch.cuda.Stream(device=local_rank, priority=-1)
-        e2.set_stream(st2.cuda_stream)
-        e2.set_pairing_mode(args.pairing_mode)
+        if len(pool) > 1:
+            e2, st2 = pool[1]
+        else:
+            e2 = Engine(local_rank)
+            st2 = torch.cuda.Stream(device=local_rank)      # a plain stream: the release waits until the remainder's final-exponentiation
+            e2.set_stream(st2.cuda_stream)                  # blocks are resident, so no stream priority is needed
+            e2.set_pairing_mode(args.pairing_mode)
+            pool.append((e2, st2))
         tb = sizes[-1] * B
         tail = (e2, (e2.alloc(tb * 3 * 128), e2.alloc(sizes[-1] * rows_per_batch * 3 * 64), e2.alloc(tb * 384), ExtBuf(torch, tb * 384, dev)), st2)
 
@@ -427,14 +437,10 @@ def main():
     # words the workload as "batch of 4096"): its latency alone, and the rate of a stream of single-batch submissions with up to
     # four of them in flight on separate HIP streams (what a server that receives batches one at a time sees)
     if world == 1 and not args.no_single_batch and not args.only_encrypt:
-        # four lanes = four HIP streams in all (the main context's included): HIP's default of four hardware queues, one each
-        extra = [(eng, (eng.alloc(B * 3 * 128), eng.alloc(rows_per_batch * 3 * 64), eng.alloc(B * 384), ExtBuf(torch, B * 384, dev)), stream)]
-        for _ in range(3):
-            e2 = Engine(local_rank)
-            st2 = torch.cuda.Stream(device=local_rank)
-            e2.set_stream(st2.cuda_stream)
-            e2.set_pairing_mode(args.pairing_mode)
-            extra.append((e2, (e2.alloc(B * 3 * 128), e2.alloc(rows_per_batch * 3 * 64), e2.alloc(B * 384), ExtBuf(torch, B * 384, dev)), st2))
+        # four lanes = the four contexts / HIP streams of the pool (the main context's and the remainder group's included): HIP's default
+        # of four hardware queues, one each
+        extra = [(e2, (e2.alloc(B * 3 * 128), e2.alloc(rows_per_batch * 3 * 64), e2.alloc(B * 384), ExtBuf(torch, B * 384, dev)), st2)
+                 for e2, st2 in pool[:4]]
         for e2, b2, _ in extra:
             submit(1, on=(e2, b2))
             e2.sync()
@@ -467,8 +473,6 @@ def main():
                           "latency is the serial chain Miller -> final exponentiation of one lane (~14 k dependent Fp multiplications); batches in flight "
                           "on separate streams overlap each other's chains")
         result["single_batch"] = single
-        for e2, _, _ in extra[1:]:
-            e2.close()
 
     # ---------------------------------------------------------------- informational: the same steps with host buffers
     # (inputs s, msg uploaded; ciphertext c_0, c, c_p and the decrypted Gt downloaded; pinned memory, copies on a copy
@@ -663,6 +667,8 @@ def main():
 
     if pk is not None:
         pk.destroy()
+    for e2, _ in pool[len(lanes_ctx):]:
+        e2.close()
     for e_ in lanes_ctx[1:]:
         e_.close()
     eng.close()

@@ -81,7 +81,9 @@ int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other);
 /* Pipelining two launch sets on two contexts (streams): `waiter`'s stream is held until ctx's NEXT decrypt (any entry point that runs
  * the shared-accumulator Miller kernel) has issued its Miller loops; what is left on ctx then is its final exponentiation (one wave per
  * item), beside which the waiter's encrypt kernels can run.  One-shot.  Typical use: a small launch set on ctx, the next large one on
- * waiter -- submit ctx first, then enqueue waiter's work; make waiter's decrypt wait for all of ctx with rhip_ctx_wait_for. */
+ * waiter -- submit ctx first, then enqueue waiter's work; make waiter's decrypt wait for all of ctx with rhip_ctx_wait_for.  The request
+ * is consumed by ctx's next final-exponentiation launch; waiter = NULL withdraws a pending one (a context must not be destroyed while
+ * it is a pending waiter).  The hold is bounded: the waiter's stream polls for at most a few tens of milliseconds. */
 int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------

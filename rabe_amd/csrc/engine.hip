@@ -227,8 +227,8 @@ extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* de
 // the chip only for >= 65 536 items; the waiter's occupancy-flexible kernels (the fixed-base encrypt kernels of the next launch
 // set) then run beside it instead of behind it.  One-shot; without a following pairing launch nothing is held.
 extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter) {
-  if (!ctx || !waiter || ctx == waiter) return RHIP_ERR_ARG;
-  ctx->fe_waiter = waiter;
+  if (!ctx || ctx == waiter) return RHIP_ERR_ARG;
+  ctx->fe_waiter = waiter;          // NULL withdraws a pending request (e.g. before the waiter's context is destroyed)
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other) {
