@@ -133,3 +133,36 @@ def test_ac17_kp_encrypt_decrypt_batch(host):
     # key 0 ("A" and "B") opens items 0 and 2; key 1 (C or (A and D)) opens items 1, 2 and 4
     assert ac17.kp_decrypt_batch(host, [sks[0]] * 5, batch) == [PTS[0], None, PTS[2], None, None]
     assert ac17.kp_decrypt_batch(host, [sks[1]] * 5, batch) == [None, PTS[1], PTS[2], None, PTS[4]]
+
+
+def test_release_before_final_exp_pipelines_two_contexts_with_identical_results():
+    """rhip_ctx_release_before_final_exp: context B's decrypt releases context A's stream after its Miller kernel; A's work then runs
+    beside B's final exponentiation.  Results must be what the serial order gives, and nothing may hang when the request is unused or
+    withdrawn."""
+    import random
+    from rabe_amd import Engine
+    from oracle import bn254 as bn
+    rnd = random.Random(5)
+    a, b = Engine(0), Engine(0)
+    a.set_pairing_mode(1)                                         # the one-lane kernels (k_miller + k_final_exp), whatever the launch size
+    b.set_pairing_mode(1)
+    n = 700                                                       # a few blocks of the four-wave final exponentiation
+    ks = [rnd.randrange(1, bn.R) for _ in range(8)]
+    P = [bn.g1_to_le(bn.g1_mul(bn.G1_GEN, k)) for k in ks]
+    Q = [bn.g2_to_le(bn.g2_mul(bn.G2_GEN, k + 1)) for k in ks]
+    ps, qs = [P[i % 8] for i in range(n)], [Q[(3 * i) % 8] for i in range(n)]
+    off = list(range(0, n + 1, 7))                                # items of seven pairs: the shared-accumulator kernel + final exponentiation
+    want = a.pairing_product(off, ps, qs)
+    b.release_before_final_exp(a)                                 # A is held until B's Miller loops are done and its blocks resident
+    got_b = b.pairing_product(off, ps, qs)
+    got_a = a.pairing_product(off, ps, qs)
+    assert got_a == want and got_b == want
+    b.release_before_final_exp(a)
+    b._check(b.lib.rhip_ctx_release_before_final_exp(b.ctx, None))          # withdrawn: nothing is held
+    assert a.pairing_product(off, ps, qs) == want
+    acc = bn.GT_ONE
+    for i in range(7):
+        acc = bn.gt_mul(acc, bn.pairing(bn.g1_from_le(ps[i]), bn.g2_from_le(qs[i])))
+    assert want[0] == bn.gt_to_le(acc)
+    a.close()
+    b.close()
