@@ -7,6 +7,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,6 +54,10 @@ struct Rng : host::FrSource {
   virtual void fill(uint8_t* out, size_t n) = 0;
   // true when draws carry no order (OS randomness): a batch may then draw on several threads, each from its own source
   virtual bool unordered() const { return false; }
+  // brackets around the draws of one batch call: the chunks of a pipelined batch (pipeline.cpp) take turns here, so an ordered
+  // source hands out the same values to the same items as in one unchunked call
+  virtual void begin_draws() {}
+  virtual void end_draws() {}
 };
 struct OsRng : Rng {
   // getrandom(2) in 4 KB refills: a batch draws hundreds of thousands of Fr values, one system call each would dominate it
@@ -113,7 +118,28 @@ class Engine {
  public:
   explicit Engine(int device = 0);
   ~Engine();
-  rhip_ctx* ctx() const { return ctx_; }
+  // A LANE is a context (= HIP stream + workspaces) with its own pinned staging buffers and device arena.  Lane 0 is the engine's
+  // own; the pipelined packed entry points (pipeline.cpp) run chunks of a batch on worker threads, one lane each, so that one
+  // chunk's record parsing / AES runs beside another's kernels and a third's PCIe copies.  The calling thread picks its lane with a
+  // LaneScope; everything below (`ctx`, `pinned`, DBuf) then refers to that lane.  Tables and key handles are shared by all lanes.
+  rhip_ctx* ctx() const { return lanes_[cur_lane()]->ctx; }
+  void ensure_lanes(size_t count);                 // call before handing lanes to threads
+  size_t lanes() const { return lanes_.size(); }
+  struct LaneScope {
+    int prev;
+    explicit LaneScope(int lane);
+    ~LaneScope();
+  };
+  // Inside an ArenaScope, DBufs of the current lane are carved from one grow-only device block (no hipMalloc / hipFree -- the
+  // latter synchronises the whole device -- per buffer); the block is recycled when the outermost scope ends (after a stream sync).
+  // A request the block cannot hold falls back to hipMalloc and makes the block grow for the next call.
+  struct ArenaScope {
+    Engine& e;
+    explicit ArenaScope(Engine& eng);
+    ~ArenaScope();
+  };
+  void* arena_take(size_t bytes);                  // nullptr: no scope active or block full
+  bool arena_owns(const void* p) const;
   void check(int32_t rc, const char* what) const;
 
   // Level E conveniences on host values (each a small batched launch)
@@ -145,7 +171,19 @@ class Engine {
   void* aux(const std::string& kind, const std::string& key, void* (*make)(Engine&, const void*), const void* arg, void (*destroy)(void*), size_t cap = 4);
 
  private:
-  rhip_ctx* ctx_ = nullptr;
+  struct Lane {
+    rhip_ctx* ctx = nullptr;
+    void* pin[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pin_bytes[4] = {0, 0, 0, 0};
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0, arena_want = 0;
+    int arena_depth = 0;
+  };
+  std::vector<std::unique_ptr<Lane>> lanes_;
+  int device_ = 0;
+  static int& tl_lane();
+  size_t cur_lane() const { size_t l = (size_t)tl_lane(); return l < lanes_.size() ? l : 0; }
+  mutable std::recursive_mutex mu_;                // tables, key handles, use counters: shared by the lanes
   bool have_e_ = false;
   Gt e_gen_;
   std::map<std::string, rhip_g1_table*> t1_;
@@ -154,8 +192,6 @@ class Engine {
   std::map<std::string, rhip_ac17_pk*> pk17_;
   struct Aux { void* h; void (*destroy)(void*); };
   std::map<std::string, std::map<std::string, Aux>> aux_;
-  void* pin_[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t pin_bytes_[4] = {0, 0, 0, 0};
   rhip_gt_table* e_gen_tbl_ = nullptr;
   void destroy_table(rhip_g1_table* t);
   void destroy_table(rhip_g2_table* t);

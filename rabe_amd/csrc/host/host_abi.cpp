@@ -25,6 +25,11 @@ struct rabe_host {
 };
 static thread_local std::string g_err;
 
+// fewest items per chunk of a pipelined packed call (pipeline.cpp).  AC17 (host stages and copies are two thirds of a call): two chunks
+// from 16 384 items on, +6 % at 20 480 items, +15 % at 131 072.  bsw / lsw / aw11 at 100-200 leaves are GPU-bound (the kernels are 70-80 % of
+// a call) and two concurrent half-size launch sets run slower than one (-6 ... -10 %, tools/exp_r03x.sh): never chunked unless
+// RABE_PACKED_CHUNK asks for it.
+static const size_t CHUNK_AC17 = 8192, CHUNK_BSW = (size_t)1 << 40, CHUNK_LSW = (size_t)1 << 40, CHUNK_AW11 = (size_t)1 << 40;
 #define GUARD_BEGIN try {
 #define GUARD_END(h)                                                         \
   }                                                                          \
@@ -451,16 +456,25 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
                                     const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap,
                                     uint64_t* ct_off) {
   GUARD_BEGIN
-  return ac17::cp_encrypt_packed(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, strs(policies, n_policies), lang_of(language), n_items, item_policy,
-                                 pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  const auto& key = *(const ac17::Ac17PublicKey*)pk;
+  const auto pols = strs(policies, n_policies);
+  const auto lang = lang_of(language);
+  if (!item_policy || !pt_off || !ct_off) throw RabeError("cp_encrypt_packed: null input");
+  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_AC17, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return ac17::cp_encrypt_packed(h->eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
 int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
                                     uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN
   std::vector<std::string> errors;
-  if (!ac17::cp_decrypt_packed(h->eng, *(const ac17::Ac17CpSecretKey*)sk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status,
-                               pt_buf, pt_cap, pt_off, &errors))
+  const auto& key = *(const ac17::Ac17CpSecretKey*)sk;
+  const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
+  if (!pipeline::consume(h->eng, n_items, CHUNK_AC17, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+                                                                           std::vector<std::string>* errs) {
+        return ac17::cp_decrypt_packed(h->eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+      }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
   return 0;
@@ -469,16 +483,25 @@ int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                 const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
   GUARD_BEGIN
-  return bsw::encrypt_packed(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, strs(policies, n_policies), lang_of(language), n_items, item_policy, pt_blob,
-                             pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  const auto& key = *(const bsw::CpAbePublicKey*)pk;
+  const auto pols = strs(policies, n_policies);
+  const auto lang = lang_of(language);
+  if (!item_policy || !pt_off || !ct_off) throw RabeError("bsw::encrypt_packed: null input");
+  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_BSW, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return bsw::encrypt_packed(h->eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
 int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
                                 int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN
   std::vector<std::string> errors;
-  if (!bsw::decrypt_packed(h->eng, *(const bsw::CpAbeSecretKey*)sk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf,
-                           pt_cap, pt_off, &errors))
+  const auto& key = *(const bsw::CpAbeSecretKey*)sk;
+  const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
+  if (!pipeline::consume(h->eng, n_items, CHUNK_BSW, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+                                                                          std::vector<std::string>* errs) {
+        return bsw::decrypt_packed(h->eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+      }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
   return 0;
@@ -487,16 +510,26 @@ int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, co
 int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                const uint32_t* item_policy, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
   GUARD_BEGIN
-  return lsw::keygen_packed(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, *(const lsw::KpAbeMasterKey*)msk, strs(policies, n_policies), lang_of(language),
-                            n_items, item_policy, sk_buf, sk_cap, sk_off) ? 0 : 1;
+  const auto& key = *(const lsw::KpAbePublicKey*)pk;
+  const auto& master = *(const lsw::KpAbeMasterKey*)msk;
+  const auto pols = strs(policies, n_policies);
+  const auto lang = lang_of(language);
+  if (!item_policy || !sk_off) throw RabeError("lsw::keygen_packed: null input");
+  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_LSW, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return lsw::keygen_packed(h->eng, r, key, master, pols, lang, hi - lo, item_policy + lo, out, cap, off);
+  }, sk_buf, sk_cap, sk_off) ? 0 : 1;
   GUARD_END(h)
 }
 int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, uint32_t flags,
                                 int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN
   std::vector<std::string> errors;
-  if (!lsw::decrypt_packed(h->eng, *(const lsw::KpAbeCiphertext*)ct, n_items, sk_blob, sk_len, sk_off, (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf,
-                           pt_cap, pt_off, &errors))
+  const auto& c = *(const lsw::KpAbeCiphertext*)ct;
+  const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
+  if (!pipeline::consume(h->eng, n_items, CHUNK_LSW, sk_off, sk_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+                                                                          std::vector<std::string>* errs) {
+        return lsw::decrypt_packed(h->eng, c, hi - lo, sk_blob, sk_len, sk_off + lo, trusted, st, pt, cap, off, errs);
+      }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
   return 0;
@@ -508,16 +541,26 @@ int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const
   GUARD_BEGIN
   std::vector<const aw11::Aw11PublicKey*> p;
   for (size_t i = 0; i < n_pks; i++) p.push_back((const aw11::Aw11PublicKey*)pks[i]);
-  return aw11::encrypt_packed(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, p, strs(policies, n_policies), lang_of(language), n_items, item_policy,
-                              pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  const auto& g = *(const aw11::Aw11GlobalKey*)gk;
+  const auto pols = strs(policies, n_policies);
+  const auto lang = lang_of(language);
+  if (!item_policy || !pt_off || !ct_off) throw RabeError("aw11::encrypt_packed: null input");
+  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_AW11, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return aw11::encrypt_packed(h->eng, r, g, p, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
 int32_t rabe_aw11_decrypt_packed(rabe_host* h, const void* gk, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
                                  uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN
   std::vector<std::string> errors;
-  if (!aw11::decrypt_packed(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, n_items, ct_blob, ct_len, ct_off,
-                            (flags & RABE_PACKED_TRUSTED) != 0, status, pt_buf, pt_cap, pt_off, &errors))
+  const auto& g = *(const aw11::Aw11GlobalKey*)gk;
+  const auto& key = *(const aw11::Aw11SecretKey*)sk;
+  const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
+  if (!pipeline::consume(h->eng, n_items, CHUNK_AW11, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+                                                                           std::vector<std::string>* errs) {
+        return aw11::decrypt_packed(h->eng, g, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+      }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
   return 0;

@@ -138,6 +138,7 @@ struct DevTrees {
 // may then draw on their own sources in parallel
 template <class DRAW>
 void draw_items(Rng& rng, size_t n, DRAW draw) {
+  struct Turn { Rng& r; explicit Turn(Rng& x) : r(x) { r.begin_draws(); } ~Turn() { r.end_draws(); } } turn(rng);
   if (rng.unordered() && n >= 256) {
     // an item of these schemes draws hundreds of values (one per gate coefficient and leaf): small blocks, so that every core draws
     const size_t per = 16, blocks = (n + per - 1) / per;
@@ -216,6 +217,14 @@ void* make_pk(Engine& eng, const void* arg) {
   return d;
 }
 void destroy_pk(void* h) { rhip_bsw_pk_destroy((rhip_bsw_pk*)h); }
+void* make_sk_lines(Engine& eng, const void* arg) {          // arg: d | d_j[0].g2 | d_j[1].g2 ... (128 B each)
+  const std::string& pts = *(const std::string*)arg;
+  DBuf d(&eng, pts.data(), pts.size());
+  rhip_bsw_sk_lines* lines = nullptr;
+  eng.check(rhip_bsw_sk_prepare(eng.ctx(), 1, pts.size() / 128 - 1, d.as<rhip_g2>(), (const rhip_g2*)(d.as<uint8_t>() + 128), &lines), "rhip_bsw_sk_prepare");
+  return lines;
+}
+void destroy_sk_lines(void* h) { rhip_bsw_sk_lines_destroy((rhip_bsw_sk_lines*)h); }
 }  // namespace
 
 // n calls of bsw::encrypt (bsw/mod.rs:217-251).  Draw order per item: secret (:228), msg (:229), the gate coefficients of
@@ -224,6 +233,7 @@ void destroy_pk(void* h) { rhip_bsw_pk_destroy((rhip_bsw_pk*)h); }
 bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                     const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("bsw::encrypt_packed");
+  Engine::ArenaScope arena(eng);
   std::vector<std::shared_ptr<const FlatPolicy>> pols;
   for (const auto& p : policies) pols.push_back(flat_policy(p, language));
   for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("bsw::encrypt_packed: item_policy out of range");
@@ -312,6 +322,7 @@ bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::
 bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
                     int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
   Timer tm("bsw::decrypt_packed");
+  Engine::ArenaScope arena(eng);
   errors->assign(n, "");
   if (!ct_off || (n && !ct_blob)) throw RabeError("bsw::decrypt_packed: null input");
   const uint64_t span = check_offsets(n, ct_off, ct_len, errors);
@@ -462,8 +473,13 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       }
       tm.lap("membership");
     }
+    // the key's prepared lines (d and every d_j.g2: 17 KB per point) are a function of the key alone: kept across calls
     rhip_bsw_sk_lines* lines = nullptr;
-    if (!sk.d_j.empty()) eng.check(rhip_bsw_sk_prepare(cx, 1, sk.d_j.size(), d_skd.as<rhip_g2>(), d_kg2.as<rhip_g2>(), &lines), "rhip_bsw_sk_prepare");
+    if (!sk.d_j.empty()) {
+      std::string key((const char*)sk.d.data(), 128);
+      for (const auto& a : sk.d_j) key.append((const char*)a.g2.data(), 128);
+      lines = (rhip_bsw_sk_lines*)eng.aux("bsw_sk_lines", key, make_sk_lines, &key, destroy_sk_lines, 4);
+    }
     int32_t rc = rhip_bsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(), d_sel_ct.as<uint32_t>(),
                                         d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(), d_g1.as<rhip_g1>(),
                                         d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(), d_kg2.as<rhip_g2>(),
@@ -471,7 +487,6 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     h_out = h_x + m_items * 448;
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
-    if (lines) rhip_bsw_sk_lines_destroy(lines);
     eng.check(rc, "rhip_bsw_decrypt_batch");
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
@@ -493,6 +508,14 @@ void* make_pk(Engine& eng, const void* arg) {
   return d;
 }
 void destroy_pk(void* h) { rhip_lsw_pk_destroy((rhip_lsw_pk*)h); }
+void* make_e2_lines(Engine& eng, const void* arg) {
+  const std::string& pt = *(const std::string*)arg;
+  DBuf d(&eng, pt.data(), pt.size());
+  rhip_g2_lines* lines = nullptr;
+  eng.check(rhip_g2_lines_prepare(eng.ctx(), 1, d.as<rhip_g2>(), &lines), "rhip_g2_lines_prepare");
+  return lines;
+}
+void destroy_e2_lines(void* h) { rhip_g2_lines_destroy((rhip_g2_lines*)h); }
 }  // namespace
 
 // n calls of lsw::keygen (lsw/mod.rs:121-170).  Draw order per item: the gate coefficients of gen_shares_policy(alpha1), then one
@@ -501,6 +524,7 @@ void destroy_pk(void* h) { rhip_lsw_pk_destroy((rhip_lsw_pk*)h); }
 bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::vector<std::string>& policies,
                    PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("lsw::keygen_packed");
+  Engine::ArenaScope arena(eng);
   std::vector<std::shared_ptr<const FlatPolicy>> pols;
   std::vector<std::vector<std::string>> striped(policies.size());
   std::vector<size_t> fixed(policies.size());
@@ -597,6 +621,7 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
 bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, bool trusted,
                     int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
   Timer tm("lsw::decrypt_packed");
+  Engine::ArenaScope arena(eng);
   errors->assign(n, "");
   if (!sk_off || (n && !sk_blob)) throw RabeError("lsw::decrypt_packed: null input");
   (void)check_offsets(n, sk_off, sk_len, errors);
@@ -732,8 +757,8 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
           if (!ok1[y] || !ok2[y]) { (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)"; break; }
       tm.lap("membership");
     }
-    rhip_g2_lines* lines = nullptr;
-    eng.check(rhip_g2_lines_prepare(cx, 1, d_e2.as<rhip_g2>(), &lines), "rhip_g2_lines_prepare");
+    std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
+    rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
     int32_t rc = rhip_lsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_sk.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                         d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
                                         d_e1j.as<rhip_g1>(), d_ct_attr_off.as<uint32_t>(), d_ct_idx.as<uint32_t>(), d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(),
@@ -741,7 +766,6 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     h_out = eng.pinned(2, m_items * 384);
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
-    rhip_g2_lines_destroy(lines);
     eng.check(rc, "rhip_lsw_decrypt_batch");
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
@@ -783,6 +807,7 @@ bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::v
                     PolicyLanguage language, size_t n, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf,
                     size_t out_cap, uint64_t* out_off) {
   Timer tm("aw11::encrypt_packed");
+  Engine::ArenaScope arena(eng);
   PkArg arg{&gk, {}};
   std::string key((const char*)gk.g1.data(), 64);
   key.append((const char*)gk.g2.data(), 128);
@@ -891,6 +916,7 @@ bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::v
 bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
                     bool trusted, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
   Timer tm("aw11::decrypt_packed");
+  Engine::ArenaScope arena(eng);
   errors->assign(n, "");
   if (!ct_off || (n && !ct_blob)) throw RabeError("aw11::decrypt_packed: null input");
   const uint64_t span = check_offsets(n, ct_off, ct_len, errors);

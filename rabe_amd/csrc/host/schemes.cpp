@@ -42,9 +42,24 @@ void OsRng::fill(uint8_t* out, size_t n) {
   }
 }
 
-Engine::Engine(int device) {
-  int32_t rc = rhip_ctx_create(device, &ctx_);
+int& Engine::tl_lane() {
+  static thread_local int lane = 0;
+  return lane;
+}
+Engine::LaneScope::LaneScope(int lane) : prev(Engine::tl_lane()) { Engine::tl_lane() = lane; }
+Engine::LaneScope::~LaneScope() { Engine::tl_lane() = prev; }
+Engine::Engine(int device) : device_(device) {
+  lanes_.emplace_back(new Lane());
+  int32_t rc = rhip_ctx_create(device, &lanes_[0]->ctx);
   if (rc != RHIP_OK) throw RabeError(std::string("no usable HIP device: ") + rhip_last_error(nullptr));
+}
+void Engine::ensure_lanes(size_t count) {
+  std::lock_guard<std::recursive_mutex> g(mu_);
+  while (lanes_.size() < count) {
+    std::unique_ptr<Lane> l(new Lane());
+    check(rhip_ctx_create(device_, &l->ctx), "rhip_ctx_create (lane)");
+    lanes_.push_back(std::move(l));
+  }
 }
 rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka) {
   if (h_a.size() != 3 || e_gh_ka.size() != 2) throw RabeError("malformed Ac17PublicKey: h_a must have 3 and e_gh_ka 2 elements");
@@ -52,37 +67,79 @@ rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std
   std::string key((const char*)g.data(), g.size());
   key.append((const char*)fha.data(), fha.size());
   key.append((const char*)fe.data(), fe.size());
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   auto it = pk17_.find(key);
   if (it != pk17_.end()) return it->second;
-  if (pk17_.size() >= 4) {                       // bounded: each entry holds ~1.3 GB of tables
+  if (pk17_.size() >= 4) {                       // bounded: each entry holds ~1.7 GB of tables
     for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
     pk17_.clear();
   }
   rhip_ac17_pk* dpk = nullptr;
-  check(rhip_ac17_pk_create(ctx_, (const rhip_g1*)g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk), "rhip_ac17_pk_create");
+  check(rhip_ac17_pk_create(ctx(), (const rhip_g1*)g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk), "rhip_ac17_pk_create");
+  // signed 20-bit windows for g (13 instead of 16 additions per row element, +0.44 GB): the device-level default of bench.py;
+  // RABE_G_WINDOW=16 keeps the plain 16-bit table, larger values trade more memory (include/rabe_hip.h)
+  int w = 20;
+  if (const char* env = getenv("RABE_G_WINDOW")) w = atoi(env);
+  if (w > 16) check(rhip_ac17_pk_set_g_window(ctx(), dpk, w), "rhip_ac17_pk_set_g_window");
   pk17_[key] = dpk;
   return dpk;
 }
 uint8_t* Engine::pinned(int slot, size_t bytes) {
-  if (pin_bytes_[slot] < bytes) {
-    if (pin_[slot]) rhip_host_free(ctx_, pin_[slot]);
-    pin_[slot] = nullptr;
-    pin_bytes_[slot] = 0;
+  Lane& l = *lanes_[cur_lane()];
+  if (l.pin_bytes[slot] < bytes) {
+    if (l.pin[slot]) rhip_host_free(l.ctx, l.pin[slot]);
+    l.pin[slot] = nullptr;
+    l.pin_bytes[slot] = 0;
     const size_t want = bytes + bytes / 4 + 4096;
-    check(rhip_host_alloc(ctx_, want, &pin_[slot]), "rhip_host_alloc");
-    pin_bytes_[slot] = want;
+    check(rhip_host_alloc(l.ctx, want, &l.pin[slot]), "rhip_host_alloc");
+    l.pin_bytes[slot] = want;
   }
-  return (uint8_t*)pin_[slot];
+  return (uint8_t*)l.pin[slot];
+}
+Engine::ArenaScope::ArenaScope(Engine& eng) : e(eng) {
+  Lane& l = *e.lanes_[e.cur_lane()];
+  if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; }
+}
+Engine::ArenaScope::~ArenaScope() {
+  Lane& l = *e.lanes_[e.cur_lane()];
+  if (--l.arena_depth) return;
+  rhip_sync(l.ctx);                               // nothing of this call may still read the block when the next call reuses it
+  if (l.arena_want > l.arena_bytes) {             // grow for the next call
+    if (l.arena) rhip_free(l.ctx, l.arena);
+    l.arena = nullptr;
+    l.arena_bytes = 0;
+    const size_t want = l.arena_want + l.arena_want / 4 + (1u << 20);
+    void* p = nullptr;
+    if (rhip_malloc(l.ctx, want, &p) == RHIP_OK) { l.arena = (uint8_t*)p; l.arena_bytes = want; }
+  }
+}
+void* Engine::arena_take(size_t bytes) {
+  Lane& l = *lanes_[cur_lane()];
+  static const bool off = getenv("RABE_NO_ARENA") != nullptr;          // diagnostics: every buffer its own hipMalloc again
+  if (!l.arena_depth || off) return nullptr;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  l.arena_want += need;
+  if (l.arena_used + need > l.arena_bytes) return nullptr;
+  void* p = l.arena + l.arena_used;
+  l.arena_used += need;
+  return p;
+}
+bool Engine::arena_owns(const void* p) const {
+  for (const auto& l : lanes_)
+    if (l->arena && (const uint8_t*)p >= l->arena && (const uint8_t*)p < l->arena + l->arena_bytes) return true;
+  return false;
 }
 rhip_gt_table* Engine::gt_generator_table() {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   if (!e_gen_tbl_) {
     const Gt& g = gt_generator();
-    check(rhip_gt_table_create(ctx_, (const rhip_gt*)g.data(), &e_gen_tbl_), "rhip_gt_table_create");
-    check(rhip_gt_table_add_w16(ctx_, e_gen_tbl_), "rhip_gt_table_add_w16");
+    check(rhip_gt_table_create(ctx(), (const rhip_gt*)g.data(), &e_gen_tbl_), "rhip_gt_table_create");
+    check(rhip_gt_table_add_w16(ctx(), e_gen_tbl_), "rhip_gt_table_add_w16");
   }
   return e_gen_tbl_;
 }
 void* Engine::aux(const std::string& kind, const std::string& key, void* (*make)(Engine&, const void*), const void* arg, void (*destroy)(void*), size_t cap) {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   auto& m = aux_[kind];
   auto it = m.find(key);
   if (it != m.end()) return it->second.h;
@@ -96,25 +153,32 @@ void* Engine::aux(const std::string& kind, const std::string& key, void* (*make)
 }
 Engine::~Engine() {
   for (auto& k : aux_) for (auto& c : k.second) c.second.destroy(c.second.h);
-  for (int i = 0; i < 4; i++) if (pin_[i]) rhip_host_free(ctx_, pin_[i]);
   if (e_gen_tbl_) rhip_gt_table_destroy(e_gen_tbl_);
   for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
   for (auto& c : t1_) rhip_g1_table_destroy(c.second);
   for (auto& c : t2_) rhip_g2_table_destroy(c.second);
   for (auto& c : tt_) rhip_gt_table_destroy(c.second);
-  rhip_ctx_destroy(ctx_);
+  for (auto& l : lanes_) {
+    for (int i = 0; i < 4; i++) if (l->pin[i]) rhip_host_free(l->ctx, l->pin[i]);
+    if (l->arena) rhip_free(l->ctx, l->arena);
+  }
+  for (size_t i = lanes_.size(); i-- > 0;) rhip_ctx_destroy(lanes_[i]->ctx);
 }
 void Engine::check(int32_t rc, const char* what) const {
-  if (rc != RHIP_OK) throw RabeError(std::string(what) + " failed: " + rhip_last_error(ctx_));
+  if (rc != RHIP_OK) throw RabeError(std::string(what) + " failed: " + rhip_last_error(ctx()));
 }
 
-DBuf::DBuf(Engine* e, size_t bytes) : eng_(e), n_(bytes) { e->check(rhip_malloc(e->ctx(), bytes ? bytes : 4, &p_), "rhip_malloc"); }
+DBuf::DBuf(Engine* e, size_t bytes) : eng_(e), n_(bytes) {
+  p_ = e->arena_take(bytes ? bytes : 4);
+  if (!p_) e->check(rhip_malloc(e->ctx(), bytes ? bytes : 4, &p_), "rhip_malloc");
+}
 DBuf::DBuf(Engine* e, const void* host_data, size_t bytes) : DBuf(e, bytes) {
   if (bytes) e->check(rhip_upload(e->ctx(), p_, host_data, bytes), "rhip_upload");
 }
-DBuf::~DBuf() { if (p_) rhip_free(eng_->ctx(), p_); }
+static void dbuf_release(Engine* e, void* p) { if (p && !e->arena_owns(p)) rhip_free(e->ctx(), p); }
+DBuf::~DBuf() { dbuf_release(eng_, p_); }
 DBuf& DBuf::operator=(DBuf&& o) noexcept {
-  if (this != &o) { if (p_) rhip_free(eng_->ctx(), p_); eng_ = o.eng_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; }
+  if (this != &o) { dbuf_release(eng_, p_); eng_ = o.eng_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; }
   return *this;
 }
 void DBuf::download(void* host, size_t bytes) const { if (bytes) eng_->check(rhip_download(eng_->ctx(), host, p_, bytes), "rhip_download"); }
@@ -212,14 +276,14 @@ std::vector<std::array<uint8_t, N>> Engine::mul_grouped(const std::vector<std::a
         cache.clear();
       }
       TBL* t = nullptr;
-      check(create(ctx_, p[idx[0]].data(), &t), "fixed-base table build");
+      check(create(ctx(), p[idx[0]].data(), &t), "fixed-base table build");
       cache[key] = t;
     }
     std::vector<Fr> kk;
     for (size_t i : idx) kk.push_back(k[i]);
     auto fk = flatten_fr(kk);
     DBuf dk(this, fk.data(), fk.size()), dout(this, idx.size() * N);
-    check(mul(ctx_, cache[key], idx.size(), dk.as<rhip_fr>(), dout.ptr()), "fixed-base table multiplication");
+    check(mul(ctx(), cache[key], idx.size(), dk.as<rhip_fr>(), dout.ptr()), "fixed-base table multiplication");
     auto r = fetch<N>(dout, idx.size());
     for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = r[j];
   }
@@ -240,6 +304,7 @@ void Engine::destroy_table(rhip_g2_table* t) { rhip_g2_table_destroy(t); }
 void Engine::destroy_table(rhip_gt_table* t) { rhip_gt_table_destroy(t); }
 
 std::vector<G1> Engine::g1_mul(const std::vector<G1>& p, const std::vector<Fr>& k) {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   return mul_grouped<64>(p, k, t1_,
       [](rhip_ctx* c, const uint8_t* b, rhip_g1_table** t) { return rhip_g1_table_create(c, (const rhip_g1*)b, t); },
       [](rhip_ctx* c, const rhip_g1_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_g1_table_mul(c, t, n, dk, (rhip_g1*)o); },
@@ -247,11 +312,12 @@ std::vector<G1> Engine::g1_mul(const std::vector<G1>& p, const std::vector<Fr>& 
         size_t n = rp.size();
         auto fp = flatten(rp); auto fk = flatten_fr(rk);
         DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 64);
-        check(rhip_g1_mul(ctx_, n, dp.as<rhip_g1>(), dk.as<rhip_fr>(), out.as<rhip_g1>()), "rhip_g1_mul");
+        check(rhip_g1_mul(ctx(), n, dp.as<rhip_g1>(), dk.as<rhip_fr>(), out.as<rhip_g1>()), "rhip_g1_mul");
         return fetch<64>(out, n);
       });
 }
 std::vector<G2> Engine::g2_mul(const std::vector<G2>& p, const std::vector<Fr>& k) {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   return mul_grouped<128>(p, k, t2_,
       [](rhip_ctx* c, const uint8_t* b, rhip_g2_table** t) { return rhip_g2_table_create(c, (const rhip_g2*)b, t); },
       [](rhip_ctx* c, const rhip_g2_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_g2_table_mul(c, t, n, dk, (rhip_g2*)o); },
@@ -259,11 +325,12 @@ std::vector<G2> Engine::g2_mul(const std::vector<G2>& p, const std::vector<Fr>& 
         size_t n = rp.size();
         auto fp = flatten(rp); auto fk = flatten_fr(rk);
         DBuf dp(this, fp.data(), fp.size()), dk(this, fk.data(), fk.size()), out(this, n * 128);
-        check(rhip_g2_mul(ctx_, n, dp.as<rhip_g2>(), dk.as<rhip_fr>(), out.as<rhip_g2>()), "rhip_g2_mul");
+        check(rhip_g2_mul(ctx(), n, dp.as<rhip_g2>(), dk.as<rhip_fr>(), out.as<rhip_g2>()), "rhip_g2_mul");
         return fetch<128>(out, n);
       });
 }
 std::vector<Gt> Engine::gt_pow(const std::vector<Gt>& a, const std::vector<Fr>& k) {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   return mul_grouped<384>(a, k, tt_,
       [](rhip_ctx* c, const uint8_t* b, rhip_gt_table** t) { return rhip_gt_table_create(c, (const rhip_gt*)b, t); },
       [](rhip_ctx* c, const rhip_gt_table* t, size_t n, const rhip_fr* dk, void* o) { return rhip_gt_table_pow(c, t, n, dk, (rhip_gt*)o); },
@@ -271,7 +338,7 @@ std::vector<Gt> Engine::gt_pow(const std::vector<Gt>& a, const std::vector<Fr>& 
         size_t n = ra.size();
         auto fa = flatten(ra); auto fk = flatten_fr(rk);
         DBuf da(this, fa.data(), fa.size()), dk(this, fk.data(), fk.size()), out(this, n * 384);
-        check(rhip_gt_pow(ctx_, n, da.as<rhip_gt>(), dk.as<rhip_fr>(), out.as<rhip_gt>()), "rhip_gt_pow");
+        check(rhip_gt_pow(ctx(), n, da.as<rhip_gt>(), dk.as<rhip_fr>(), out.as<rhip_gt>()), "rhip_gt_pow");
         return fetch<384>(out, n);
       });
 }
@@ -279,17 +346,18 @@ std::vector<Gt> Engine::gt_mul(const std::vector<Gt>& a, const std::vector<Gt>& 
   size_t n = a.size();
   auto fa = flatten(a); auto fb = flatten(b);
   DBuf da(this, fa.data(), fa.size()), db(this, fb.data(), fb.size()), out(this, n * 384);
-  check(rhip_gt_mul(ctx_, n, da.as<rhip_gt>(), db.as<rhip_gt>(), out.as<rhip_gt>()), "rhip_gt_mul");
+  check(rhip_gt_mul(ctx(), n, da.as<rhip_gt>(), db.as<rhip_gt>(), out.as<rhip_gt>()), "rhip_gt_mul");
   return fetch<384>(out, n);
 }
 std::vector<Gt> Engine::pairing(const std::vector<G1>& p, const std::vector<G2>& q) {
   size_t n = p.size();
   auto fp = flatten(p); auto fq = flatten(q);
   DBuf dp(this, fp.data(), fp.size()), dq(this, fq.data(), fq.size()), out(this, n * 384);
-  check(rhip_pairing(ctx_, n, dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()), "rhip_pairing");
+  check(rhip_pairing(ctx(), n, dp.as<rhip_g1>(), dq.as<rhip_g2>(), out.as<rhip_gt>()), "rhip_pairing");
   return fetch<384>(out, n);
 }
 const Gt& Engine::gt_generator() {
+  std::lock_guard<std::recursive_mutex> lk(mu_);
   if (!have_e_) { e_gen_ = pairing({g1_generator()}, {g2_generator()})[0]; have_e_ = true; }
   return e_gen_;
 }
@@ -823,6 +891,7 @@ static std::shared_ptr<const EncPolicy> enc_policy(const std::string& pol, Polic
 bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                        const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   StageTimer tm("ac17::cp_encrypt_packed");
+  Engine::ArenaScope arena(eng);
   if (pk.h_a.size() != 3 || pk.e_gh_ka.size() != 2) throw RabeError("malformed Ac17PublicKey");
   std::vector<std::shared_ptr<const EncPolicy>> pols;
   std::vector<uint32_t> a_off{0};
@@ -848,14 +917,17 @@ bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std
     memcpy(h_rho + 32 * i, rho.l, 32);
     r.fill(nonces[i].data(), 12);
   };
-  if (rng.unordered() && n >= 1024) {            // OS randomness has no order: blocks of items draw on their own sources
-    const size_t blocks = (n + 255) / 256;
-    parallel_for(blocks, [&](size_t b) {
-      OsRng local;
-      for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) draw_item(local, i);
-    });
-  } else {
-    for (size_t i = 0; i < n; i++) draw_item(rng, i);
+  {
+    struct Turn { Rng& r; explicit Turn(Rng& x) : r(x) { r.begin_draws(); } ~Turn() { r.end_draws(); } } turn(rng);
+    if (rng.unordered() && n >= 1024) {          // OS randomness has no order: blocks of items draw on their own sources
+      const size_t blocks = (n + 255) / 256;
+      parallel_for(blocks, [&](size_t b) {
+        OsRng local;
+        for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) draw_item(local, i);
+      });
+    } else {
+      for (size_t i = 0; i < n; i++) draw_item(rng, i);
+    }
   }
   std::vector<uint32_t> item_a_off(n), row_off(n + 1, 0);
   for (size_t i = 0; i < n; i++) {
@@ -914,6 +986,14 @@ bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std
   return true;
 }
 
+static void* make_ac17_sk_lines(Engine& eng, const void* arg) {
+  const std::string& k0 = *(const std::string*)arg;
+  DBuf d(&eng, k0.data(), k0.size());
+  rhip_ac17_sk_lines* lines = nullptr;
+  eng.check(rhip_ac17_sk_prepare(eng.ctx(), 1, d.as<rhip_g2>(), &lines), "rhip_ac17_sk_prepare");
+  return lines;
+}
+static void destroy_ac17_sk_lines(void* h) { rhip_ac17_sk_lines_destroy((rhip_ac17_sk_lines*)h); }
 // status[i]: 0 ok, -1 the key does not satisfy the policy / malformed record / authentication failure (errors[i] says which).
 // pt_buf / pt_cap: caller-allocated; a capacity of ct_off[n] bytes always suffices (a plaintext is 28 bytes shorter than its sealed
 // form).  Returns false, before any work, when pt_cap is smaller than that.
@@ -926,6 +1006,7 @@ bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std
 bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
                        int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
   StageTimer tm("ac17::cp_decrypt_packed");
+  Engine::ArenaScope arena(eng);
   errors->assign(n, "");
   if (!ct_off || (n && !ct_blob)) throw RabeError("cp_decrypt_packed: null input");
   // bounds first: everything below trusts [ct_off[i], ct_off[i+1]) to lie inside the blob
@@ -1092,15 +1173,15 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
       }
       tm.lap("membership");
     }
-    rhip_ac17_sk_lines* lines = nullptr;
-    eng.check(rhip_ac17_sk_prepare(cx, 1, d5.as<rhip_g2>(), &lines), "rhip_ac17_sk_prepare");
+    // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
+    std::string k0_key((const char*)k0.data(), k0.size());
+    rhip_ac17_sk_lines* lines = (rhip_ac17_sk_lines*)eng.aux("ac17_sk_lines", k0_key, make_ac17_sk_lines, &k0_key, destroy_ac17_sk_lines, 4);
     int32_t rc = rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), lines,
                                                      d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
                                                      d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>());
     h_out = h_x + 2 * m * 384;
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, dout.ptr(), m * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
-    rhip_ac17_sk_lines_destroy(lines);
     eng.check(rc, "rhip_ac17_cp_decrypt_batch_prepared");
   }
   tm.lap("device + copies");

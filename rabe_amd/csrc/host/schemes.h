@@ -220,3 +220,15 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const Mk
 }  // namespace mke08
 
 }}  // namespace rabe::schemes
+
+// pipelined packed batches (pipeline.cpp): the packed entry points above run on chunks of the items, a few chunks at a time, each on its
+// own engine lane; results are those of the unchunked call.  `call(lo, hi, ...)` is the entry point bound to items [lo, hi).
+#include <functional>
+namespace rabe { namespace pipeline {
+typedef std::function<bool(size_t lo, size_t hi, Rng& rng, uint8_t* out, size_t cap, uint64_t* off)> ProduceFn;
+typedef std::function<bool(size_t lo, size_t hi, int32_t* status, uint8_t* pt, size_t cap, uint64_t* pt_off, std::vector<std::string>* errors)> ConsumeFn;
+// min_chunk: fewest items a chunk may hold (RABE_PACKED_CHUNK overrides); RABE_PACKED_LANES: chunks in flight (default 2, 1 = unchunked)
+bool produce(Engine& eng, Rng& rng, size_t n, size_t min_chunk, const ProduceFn& call, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
+bool consume(Engine& eng, size_t n, size_t min_chunk, const uint64_t* in_off, size_t in_len, const ConsumeFn& call, int32_t* status, uint8_t* pt_buf,
+             size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
+}}  // namespace rabe::pipeline

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/variants
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c rabe_amd/csrc/engine.hip -o build/variants/$name.engine.o "$@"
-hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib$name.so build/variants/$name.engine.o build/obj/engine_jobs.hip.o build/obj/schemes.cpp.o build/obj/host_abi.cpp.o build/obj/packed.cpp.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib$name.so build/variants/$name.engine.o build/obj/engine_jobs.hip.o build/obj/schemes.cpp.o build/obj/host_abi.cpp.o build/obj/packed.cpp.o build/obj/pipeline.cpp.o
 echo build/variants/lib$name.so
