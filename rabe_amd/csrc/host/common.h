@@ -138,6 +138,8 @@ class Engine {
     explicit ArenaScope(Engine& eng);
     ~ArenaScope();
   };
+  // the lane's SIDE context (a second stream, created on first use): work that may run beside the main context's kernels
+  rhip_ctx* side_ctx();
   void* arena_take(size_t bytes);                  // nullptr: no scope active or block full
   bool arena_owns(const void* p) const;
   void check(int32_t rc, const char* what) const;
@@ -173,6 +175,7 @@ class Engine {
  private:
   struct Lane {
     rhip_ctx* ctx = nullptr;
+    rhip_ctx* side = nullptr;
     void* pin[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t pin_bytes[4] = {0, 0, 0, 0};
     uint8_t* arena = nullptr;
@@ -199,6 +202,25 @@ class Engine {
   template <size_t N, class TBL, class CREATE, class MUL, class GENERIC>
   std::vector<std::array<uint8_t, N>> mul_grouped(const std::vector<std::array<uint8_t, N>>& p, const std::vector<Fr>& k,
                                                    std::map<std::string, TBL*>& cache, CREATE create, MUL mul, GENERIC generic);
+};
+
+// The batched decoding checks of untrusted records (coordinates < p, curve, subgroup: what rabe-bn's decoding establishes) on the lane's
+// side context, BESIDE the scheme's kernels on the main one: the checks of a batch are small launches (one lane per element, a few
+// hundred waves) that leave most of the GPU idle when they run alone, and the scheme's kernels do not depend on their verdicts -- they
+// terminate on any input, and a failed item's result is discarded.  Construct after the staged uploads were enqueued on the main
+// context (the side context waits for them), `add` the element arrays, launch the scheme's work, then `collect`.
+// RABE_MEMBER_INLINE=1 runs the checks on the main context instead (A/B).
+class MemberChecks {
+ public:
+  explicit MemberChecks(Engine& eng);
+  void add(int which, const void* dev, size_t count);           // which: 1 G1 on curve, 2 G2 in the r-torsion, 3 Gt in the order-r subgroup
+  void collect();                                               // waits for the checks (not for the main context)
+  const std::vector<uint32_t>& ok(size_t k) const { return flags_[k]; }      // verdicts of the k-th add, one per element
+ private:
+  Engine& eng_;
+  rhip_ctx* cx_;
+  std::vector<DBuf> dev_;
+  std::vector<std::vector<uint32_t>> flags_;
 };
 
 template <class T, size_t N>

@@ -170,20 +170,6 @@ struct Cursor {
 };
 inline bool same(const std::pair<const char*, uint32_t>& a, const std::string& b) { return a.second == b.size() && memcmp(a.first, b.data(), b.size()) == 0; }
 
-// the batched decoding checks over staged device arrays (what rabe-bn's decoding establishes, FieldError::NotMember); ok[] per element
-std::vector<uint32_t> member_pass(Engine& eng, int which, const void* dev, size_t count) {
-  std::vector<uint32_t> ok(count, 1);
-  if (!count) return ok;
-  DBuf dok(&eng, count * 4);
-  rhip_ctx* cx = eng.ctx();
-  int32_t rc = which == 1 ? rhip_g1_on_curve(cx, count, (const rhip_g1*)dev, dok.as<uint32_t>())
-             : which == 2 ? rhip_g2_in_subgroup(cx, count, (const rhip_g2*)dev, dok.as<uint32_t>())
-                          : rhip_gt_is_member(cx, count, (const rhip_gt*)dev, dok.as<uint32_t>());
-  eng.check(rc, "membership pass");
-  dok.download(ok.data(), count * 4);
-  return ok;
-}
-
 // AES-GCM open of every live item into the caller's buffer (status / offsets as in ac17::cp_decrypt_packed)
 struct Sealed { const uint8_t* p = nullptr; uint32_t len = 0; };
 void open_all(size_t n, const std::vector<Sealed>& sealed, const std::vector<size_t>& slot, const uint8_t* h_gt, int32_t* status, uint8_t* pt_buf,
@@ -462,16 +448,10 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     eng.check(rhip_upload_async(cx, d_cp.ptr(), h_x + m_items * 64, m_items * 384), "upload");
     eng.check(rhip_upload_async(cx, d_g1.ptr(), h_l, total * 64), "upload");
     eng.check(rhip_upload_async(cx, d_g2.ptr(), h_l + total * 64, total * 128), "upload");
+    std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
     if (!trusted) {
-      auto ok_c = member_pass(eng, 1, d_c.ptr(), m_items), ok_g1 = member_pass(eng, 1, d_g1.ptr(), total), ok_g2 = member_pass(eng, 2, d_g2.ptr(), total),
-           ok_cp = member_pass(eng, 3, d_cp.ptr(), m_items);
-      for (size_t j = 0; j < m_items; j++) {
-        const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
-        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1] && !bad; y++)
-          if (!ok_g1[y] || !ok_g2[y]) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
-        if (bad) (*errors)[live[j]] = bad;
-      }
-      tm.lap("membership");
+      mc.reset(new MemberChecks(eng));
+      mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total); mc->add(2, d_g2.ptr(), total); mc->add(3, d_cp.ptr(), m_items);
     }
     // the key's prepared lines (d and every d_j.g2: 17 KB per point) are a function of the key alone: kept across calls
     rhip_bsw_sk_lines* lines = nullptr;
@@ -488,6 +468,16 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_bsw_decrypt_batch");
+    if (mc) {
+      mc->collect();
+      const auto &ok_c = mc->ok(0), &ok_g1 = mc->ok(1), &ok_g2 = mc->ok(2), &ok_cp = mc->ok(3);
+      for (size_t j = 0; j < m_items; j++) {
+        const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
+        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1] && !bad; y++)
+          if (!ok_g1[y] || !ok_g2[y]) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
+        if (bad) (*errors)[live[j]] = bad;
+      }
+    }
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
   tm.lap("device + copies");
@@ -750,12 +740,10 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
         d_ct_idx = up32(eng, ct_idx), d_out(&eng, m_items * 384);
     eng.check(rhip_upload_async(cx, d_d1.ptr(), h_l, total * 64), "upload");
     eng.check(rhip_upload_async(cx, d_d2.ptr(), h_l + total * 64, total * 128), "upload");
+    std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
-      auto ok1 = member_pass(eng, 1, d_d1.ptr(), total), ok2 = member_pass(eng, 2, d_d2.ptr(), total);
-      for (size_t j = 0; j < m_items; j++)
-        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1]; y++)
-          if (!ok1[y] || !ok2[y]) { (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)"; break; }
-      tm.lap("membership");
+      mc.reset(new MemberChecks(eng));
+      mc->add(1, d_d1.ptr(), total); mc->add(2, d_d2.ptr(), total);
     }
     std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
     rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
@@ -767,6 +755,13 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_lsw_decrypt_batch");
+    if (mc) {
+      mc->collect();
+      const auto &ok1 = mc->ok(0), &ok2 = mc->ok(1);
+      for (size_t j = 0; j < m_items; j++)
+        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1]; y++)
+          if (!ok1[y] || !ok2[y]) { (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)"; break; }
+    }
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
   tm.lap("device + copies");
@@ -1049,15 +1044,10 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     eng.check(rhip_upload_async(cx, d_c1.ptr(), h_l, total * 384), "upload");
     eng.check(rhip_upload_async(cx, d_c2.ptr(), h_l + total * 384, total * 128), "upload");
     eng.check(rhip_upload_async(cx, d_c3.ptr(), h_l + total * 512, total * 128), "upload");
+    std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
-      auto ok0 = member_pass(eng, 3, d_c0.ptr(), m_items), ok1 = member_pass(eng, 3, d_c1.ptr(), total), ok2 = member_pass(eng, 2, d_c2.ptr(), total),
-           ok3 = member_pass(eng, 2, d_c3.ptr(), total);
-      for (size_t j = 0; j < m_items; j++) {
-        bool bad = !ok0[j];
-        for (uint32_t y = row_off[j]; y < row_off[j + 1] && !bad; y++) bad = !ok1[y] || !ok2[y] || !ok3[y];
-        if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
-      }
-      tm.lap("membership");
+      mc.reset(new MemberChecks(eng));
+      mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total); mc->add(2, d_c2.ptr(), total); mc->add(2, d_c3.ptr(), total);
     }
     int32_t rc = rhip_aw11_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                          d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(),
@@ -1067,6 +1057,15 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_aw11_decrypt_batch");
+    if (mc) {
+      mc->collect();
+      const auto &ok0 = mc->ok(0), &ok1 = mc->ok(1), &ok2 = mc->ok(2), &ok3 = mc->ok(3);
+      for (size_t j = 0; j < m_items; j++) {
+        bool bad = !ok0[j];
+        for (uint32_t y = row_off[j]; y < row_off[j + 1] && !bad; y++) bad = !ok1[y] || !ok2[y] || !ok3[y];
+        if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
+      }
+    }
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
   tm.lap("device + copies");

@@ -100,10 +100,34 @@ Engine::ArenaScope::ArenaScope(Engine& eng) : e(eng) {
   Lane& l = *e.lanes_[e.cur_lane()];
   if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; }
 }
+rhip_ctx* Engine::side_ctx() {
+  Lane& l = *lanes_[cur_lane()];
+  if (!l.side) check(rhip_ctx_create(device_, &l.side), "rhip_ctx_create (side)");
+  return l.side;
+}
+MemberChecks::MemberChecks(Engine& eng) : eng_(eng), cx_(getenv("RABE_MEMBER_INLINE") ? eng.ctx() : eng.side_ctx()) {
+  if (cx_ != eng.ctx()) eng.check(rhip_ctx_wait_for(cx_, eng.ctx()), "rhip_ctx_wait_for");
+}
+void MemberChecks::add(int which, const void* dev, size_t count) {
+  flags_.emplace_back(count, 1u);
+  dev_.emplace_back(&eng_, count * 4);
+  if (!count) return;
+  uint32_t* ok = dev_.back().as<uint32_t>();
+  int32_t rc = which == 1 ? rhip_g1_on_curve(cx_, count, (const rhip_g1*)dev, ok)
+             : which == 2 ? rhip_g2_in_subgroup(cx_, count, (const rhip_g2*)dev, ok)
+                          : rhip_gt_is_member(cx_, count, (const rhip_gt*)dev, ok);
+  eng_.check(rc, "membership pass");
+}
+void MemberChecks::collect() {
+  for (size_t k = 0; k < flags_.size(); k++)
+    if (!flags_[k].empty()) eng_.check(rhip_download_async(cx_, flags_[k].data(), dev_[k].ptr(), flags_[k].size() * 4), "download");
+  eng_.check(rhip_sync(cx_), "rhip_sync (membership pass)");
+}
 Engine::ArenaScope::~ArenaScope() {
   Lane& l = *e.lanes_[e.cur_lane()];
   if (--l.arena_depth) return;
   rhip_sync(l.ctx);                               // nothing of this call may still read the block when the next call reuses it
+  if (l.side) rhip_sync(l.side);
   if (l.arena_want > l.arena_bytes) {             // grow for the next call
     if (l.arena) rhip_free(l.ctx, l.arena);
     l.arena = nullptr;
@@ -162,7 +186,10 @@ Engine::~Engine() {
     for (int i = 0; i < 4; i++) if (l->pin[i]) rhip_host_free(l->ctx, l->pin[i]);
     if (l->arena) rhip_free(l->ctx, l->arena);
   }
-  for (size_t i = lanes_.size(); i-- > 0;) rhip_ctx_destroy(lanes_[i]->ctx);
+  for (size_t i = lanes_.size(); i-- > 0;) {
+    if (lanes_[i]->side) rhip_ctx_destroy(lanes_[i]->side);
+    rhip_ctx_destroy(lanes_[i]->ctx);
+  }
 }
 void Engine::check(int32_t rc, const char* what) const {
   if (rc != RHIP_OK) throw RabeError(std::string(what) + " failed: " + rhip_last_error(ctx()));
@@ -1154,24 +1181,14 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     eng.check(rhip_upload_async(cx, d1.ptr(), h_x, m * 384), "upload");
     eng.check(rhip_upload_async(cx, d4.ptr(), h_x + m * 384, m * 384), "upload");
     eng.check(rhip_upload_async(cx, d2.ptr(), h_c, total_rows * 192), "upload");
+    // decoding checks over the staged records, on the side context beside the decrypt kernels; a non-member fails its item only (the
+    // batch still runs: the kernels terminate on any input, the item's result is discarded below)
+    std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
-      // one launch per group over the staged records; a non-member fails its item only (the batch still runs: the kernels terminate
-      // on any input, the item's result is discarded below)
-      DBuf ok(&eng, (3 * m + 3 * total_rows + m) * 4);
-      eng.check(rhip_g2_in_subgroup(cx, 3 * m, d1.as<rhip_g2>(), ok.as<uint32_t>()), "rhip_g2_in_subgroup");
-      eng.check(rhip_g1_on_curve(cx, 3 * total_rows, d2.as<rhip_g1>(), ok.as<uint32_t>() + 3 * m), "rhip_g1_on_curve");
-      eng.check(rhip_gt_is_member(cx, m, d4.as<rhip_gt>(), ok.as<uint32_t>() + 3 * m + 3 * total_rows), "rhip_gt_is_member");
-      std::vector<uint32_t> h_ok(3 * m + 3 * total_rows + m);
-      ok.download(h_ok.data(), h_ok.size() * 4);
-      for (size_t j = 0; j < m; j++) {
-        const char* bad = nullptr;
-        for (int t = 0; t < 3 && !bad; t++) if (!h_ok[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
-        for (size_t r = 3 * (size_t)ct_row_off[j]; r < 3 * (size_t)ct_row_off[j + 1] && !bad; r++)
-          if (!h_ok[3 * m + r]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
-        if (!bad && !h_ok[3 * m + 3 * total_rows + j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
-        if (bad) (*errors)[live[j]] = bad;
-      }
-      tm.lap("membership");
+      mc.reset(new MemberChecks(eng));
+      mc->add(2, d1.ptr(), 3 * m);
+      mc->add(1, d2.ptr(), 3 * total_rows);
+      mc->add(3, d4.ptr(), m);
     }
     // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
     std::string k0_key((const char*)k0.data(), k0.size());
@@ -1183,8 +1200,20 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, dout.ptr(), m * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_ac17_cp_decrypt_batch_prepared");
+    if (mc) {
+      mc->collect();
+      const auto &ok_c0 = mc->ok(0), &ok_rows = mc->ok(1), &ok_cp = mc->ok(2);
+      for (size_t j = 0; j < m; j++) {
+        const char* bad = nullptr;
+        for (int t = 0; t < 3 && !bad; t++) if (!ok_c0[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
+        for (size_t r = 3 * (size_t)ct_row_off[j]; r < 3 * (size_t)ct_row_off[j + 1] && !bad; r++)
+          if (!ok_rows[r]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
+        if (!bad && !ok_cp[j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
+        if (bad) (*errors)[live[j]] = bad;
+      }
+    }
   }
-  tm.lap("device + copies");
+  tm.lap(trusted ? "device + copies" : "device + copies, membership beside");
   // AES-GCM open on all cores; plaintext i has sealed_len - 28 bytes when everything is well-formed
   pt_off[0] = 0;
   std::vector<size_t> slot(n, (size_t)-1);
