@@ -12,8 +12,13 @@ real rabe (`Source("serde")` after `learn`); `codec_from_source` wraps it.  So t
     blob = wire_compat.to_canonical("ac17_cp_ct", json.loads(rabe_json), dec)      # -> hostlib.Obj.deserialize / *_decrypt_packed
     back = wire_compat.from_canonical("ac17_cp_ct", blob, enc)                     # -> serde_json::from_str on the rabe side
 
+The same shapes drive rabe's BORSH form (`*_borsh` below; borsh = fields in declaration order, Vec / String with a u32 length, an enum
+as its u8 variant index) -- what rabe-console writes by default: `-----BEGIN CT-----\n hex(deflate(borsh(struct))) \n-----END CT-----`
+(/root/reference/rabe-console/src/mod.rs:82-105, 1623-1683; `read_envelope` / `write_envelope`).
+
 The canonical side is the byte form of rabe_amd/csrc/host/host_abi.cpp (`ser` / `deser`).  No group arithmetic happens here."""
 import struct
+import zlib
 
 FR, G1, G2, GT = "fr", "g1", "g2", "gt"
 SIZE = {FR: 32, G1: 64, G2: 128, GT: 384}
@@ -88,6 +93,7 @@ def _struct(*fields):
 
 
 _AC17_SK = _struct(("k_0", ("fixed", 3, G2)), ("k", ("vec", ("tuple", ["str", ("fixed", 3, G1)]))), ("k_p", ("fixed", 3, G1)))
+_AC17_KP_SK = _struct(("k_0", ("fixed", 3, G2)), ("k", ("vec", ("tuple", ["str", ("fixed", 3, G1)]))), ("k_p", ("vec", G1)))   # kp_keygen: k_p = Vec::new() (:540)
 _AC17_CT = _struct(("c_0", ("fixed", 3, G2)), ("c", ("vec", ("tuple", ["str", ("fixed", 3, G1)]))), ("c_p", GT), ("ct", "bytes"))
 _BSW_ATTR = _struct(("string", "str"), ("g1", G1), ("g2", G2))
 SHAPES = {
@@ -95,7 +101,7 @@ SHAPES = {
     "ac17_msk": _struct(("g", G1), ("h", G2), ("g_k", ("fixed", 3, G1)), ("a", ("fixed", 2, FR)), ("b", ("fixed", 2, FR))),
     "ac17_cp_sk": _struct(("attr", ("vec", "str")), ("sk", _AC17_SK)),
     "ac17_cp_ct": _struct(("policy", "policy"), ("ct", _AC17_CT)),
-    "ac17_kp_sk": _struct(("policy", "policy"), ("sk", _AC17_SK)),
+    "ac17_kp_sk": _struct(("policy", "policy"), ("sk", _AC17_KP_SK)),
     "ac17_kp_ct": _struct(("attr", ("vec", "str")), ("ct", _AC17_CT)),
     "bsw_pk": _struct(("g1", G1), ("g2", G2), ("h", G1), ("f", G2), ("e_gg_alpha", GT)),
     "bsw_msk": _struct(("beta", FR), ("g2_alpha", G2)),
@@ -239,3 +245,126 @@ def codec_from_source(src, samples, zeros=None):
         ints = [int.from_bytes(raw[i:i + width], "little") for i in range(0, len(raw), width)]
         return _fill(shape, iter(ints))
     return dec, enc
+
+
+# ------------------------------------------------------------------------------------------------ borsh form of the same structs
+def _borsh_to_canon(shape, r, dec, size, w):
+    if isinstance(shape, str) and shape in SIZE:
+        w.raw(dec(shape, r.take(size[shape])))
+    elif shape == "str":
+        w.s(r.s())
+    elif shape == "bytes":
+        w.bytes_(r.bytes_())
+    elif shape == "policy":                                   # (String, PolicyLanguage): the enum is its variant index (JsonPolicy = 0)
+        w.s(r.s())
+        lang = r.u8()
+        if lang > 1:
+            raise ValueError("PolicyLanguage variant %d" % lang)
+        w.u8(lang)
+    elif shape[0] in ("vec", "fixed"):
+        n = r.u32()
+        if shape[0] == "fixed" and n != shape[1]:
+            raise ValueError("expected %d elements, got %d" % (shape[1], n))
+        w.u32(n)
+        for _ in range(n):
+            _borsh_to_canon(shape[-1], r, dec, size, w)
+    elif shape[0] == "tuple":
+        for sh in shape[1]:
+            _borsh_to_canon(sh, r, dec, size, w)
+    elif shape[0] == "optel":
+        w.raw(dec(shape[1], r.take(size[shape[1]])))
+    elif shape[0] == "struct":
+        for _name, sh in shape[1]:
+            _borsh_to_canon(sh, r, dec, size, w)
+    else:
+        raise ValueError(shape)
+
+
+def _canon_to_borsh(shape, r, enc, w):
+    if isinstance(shape, str) and shape in SIZE:
+        w.raw(enc(shape, r.take(SIZE[shape])))
+    elif shape == "str":
+        w.s(r.s())
+    elif shape == "bytes":
+        w.bytes_(r.bytes_())
+    elif shape == "policy":
+        w.s(r.s())
+        w.u8(r.u8())
+    elif shape[0] in ("vec", "fixed"):
+        n = r.u32()
+        if shape[0] == "fixed" and n != shape[1]:
+            raise ValueError("expected %d elements, got %d" % (shape[1], n))
+        w.u32(n)
+        for _ in range(n):
+            _canon_to_borsh(shape[-1], r, enc, w)
+    elif shape[0] == "tuple":
+        for sh in shape[1]:
+            _canon_to_borsh(sh, r, enc, w)
+    elif shape[0] == "optel":
+        w.raw(enc(shape[1], r.take(SIZE[shape[1]])))
+    elif shape[0] == "struct":
+        for _name, sh in shape[1]:
+            _canon_to_borsh(sh, r, enc, w)
+    else:
+        raise ValueError(shape)
+
+
+def to_canonical_borsh(kind, data, codec):
+    """borsh bytes of a rabe struct -> canonical record.  codec = (dec, enc, size) of `borsh_codec_from_source`."""
+    dec, _enc, size = codec
+    r, w = _R(data), _W()
+    _borsh_to_canon(SHAPES[kind], r, dec, size, w)
+    if r.o != len(r.b):
+        raise ValueError("trailing bytes after the borsh record")
+    return bytes(w.b)
+
+
+def from_canonical_borsh(kind, data, codec):
+    """canonical record -> the borsh bytes rabe's `try_from_slice` takes"""
+    _dec, enc, _size = codec
+    r, w = _R(data), _W()
+    _canon_to_borsh(SHAPES[kind], r, enc, w)
+    if r.o != len(r.b):
+        raise ValueError("trailing bytes after the canonical record")
+    return bytes(w.b)
+
+
+def borsh_codec_from_source(src, samples, zeros=None):
+    """(dec, enc, size) over a tests/refpin.py Source("borsh") whose layouts have been learnt.  `samples`: {kind: hex of one borsh element}
+    (its length is the kind's size on the wire, a length prefix included if the crate writes one); `zeros`: {kind: hex of the identity}."""
+    from oracle import bn254 as bn
+    from tests import refpin as rp
+    to_le = {FR: lambda v: int(v).to_bytes(32, "little"), G1: bn.g1_to_le, G2: bn.g2_to_le, GT: bn.gt_to_le}
+    from_le = {FR: lambda b: int.from_bytes(b, "little"), G1: bn.g1_from_le, G2: bn.g2_from_le, GT: bn.gt_from_le}
+    size = {k: len(bytes.fromhex(v)) for k, v in samples.items()}
+    prefixed = {k: size[k] == 32 * src.layout[k].n_fe + 4 for k in size}
+
+    def dec(kind, raw):
+        return to_le[kind](src.decode(kind, {"borsh": bytes(raw).hex(), "serde": None}))
+
+    def enc(kind, canon):
+        if kind in (G1, G2) and canon == bytes(len(canon)):
+            if not zeros or kind not in zeros:
+                raise ValueError("identity element of %s: pass its borsh form in `zeros`" % kind)
+            return bytes.fromhex(zeros[kind])
+        lay = src.layout[kind]
+        el = rp.encode_element(kind, from_le[kind](canon), lay.fe, lay.shape if kind in (G1, G2) else "affine",
+                               order=(lay.order[1] if lay.order else None), prefix=prefixed[kind])
+        return bytes.fromhex(el["borsh"])
+    return dec, enc, size
+
+
+# ------------------------------------------------------------------------------------------------ rabe-console's file envelope
+# label -> what the struct is (rabe-console/src/mod.rs:82-105): GP, SK, MSK, PK, CT, SAK, PAK, PAUK, SAUK
+def write_envelope(label, data):
+    """`ser_enc` (:1623-1636): head, lower-case hex of the raw-DEFLATE stream of the serialised struct, tail"""
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    return "-----BEGIN %s-----\n%s\n-----END %s-----" % (label, (c.compress(bytes(data)) + c.flush()).hex(), label)
+
+
+def read_envelope(text):
+    """`ser_dec_bin` (:1663-1683): the SECOND line of the file (`read_raw`, src/utils/file/mod.rs:70-76), hex -> inflate.  Returns (label, bytes)."""
+    lines = text.splitlines()
+    if len(lines) < 2 or not lines[0].startswith("-----BEGIN ") or not lines[0].endswith("-----"):
+        raise ValueError("not a rabe-console file")
+    return lines[0][len("-----BEGIN "):-5], zlib.decompress(bytes.fromhex(lines[1].strip()), -15)

@@ -244,6 +244,41 @@ def check_schemes(sch_j, srcs, gt_bytes_layout):
     return done
 
 
+def check_wire(sch_j, prim, srcs):
+    """rabe_amd/wire_compat.py against the reference's own structs: every struct of the transcripts imports (serde form) to a record the
+    C++ reader accepts, and where dump_vectors also wrote the struct's borsh bytes they import to the SAME record (field order, length
+    prefixes and the enum's variant index are the converter's claims about borsh)."""
+    from rabe_amd import hostlib as hl
+    from rabe_amd import wire_compat as wc
+    one = lambda key: prim[key][1]["out"]
+    samples = {"fr": one("fr_from_str"), "g1": one("g1_mul"), "g2": one("g2_mul"), "gt": one("gt_pow")}
+    zeros = {"g1": prim["group_ops"]["g1_zero"], "g2": prim["group_ops"]["g2_zero"]}
+    dec, enc = wc.codec_from_source(srcs["serde"], {k: v["serde"] for k, v in samples.items()}, {k: v["serde"] for k, v in zeros.items()})
+    codec = wc.borsh_codec_from_source(srcs["borsh"], {k: v["borsh"] for k, v in samples.items()}, {k: v["borsh"] for k, v in zeros.items()}) \
+        if "borsh" in srcs else None
+    table = [("ac17", "pk", "ac17_pk"), ("ac17", "msk", "ac17_msk"), ("ac17", "cp_sk", "ac17_cp_sk"), ("ac17", "cp_ct", "ac17_cp_ct"),
+             ("ac17", "kp_sk", "ac17_kp_sk"), ("ac17", "kp_ct", "ac17_kp_ct"), ("bsw", "pk", "bsw_pk"), ("bsw", "msk", "bsw_msk"), ("bsw", "sk", "bsw_sk"),
+             ("bsw", "ct", "bsw_ct"), ("lsw", "pk", "lsw_pk"), ("lsw", "msk", "lsw_msk"), ("lsw", "sk", "lsw_sk"), ("lsw", "ct", "lsw_ct"),
+             ("aw11", "gk", "aw11_gk"), ("aw11", "sk", "aw11_sk"), ("aw11", "ct", "aw11_ct")]
+    seen, both = 0, 0
+    for scheme, field, kind in table:
+        obj = sch_j.get(scheme, {}).get(field)
+        if obj is None:
+            continue
+        blob = wc.to_canonical(kind, obj, dec)
+        assert hl.Obj.deserialize(kind, blob).serialize() == blob, kind
+        seen += 1
+        hexed = sch_j[scheme].get(field + "_borsh")
+        if hexed and codec:
+            assert wc.to_canonical_borsh(kind, bytes.fromhex(hexed), codec) == blob, "borsh form of %s" % kind
+            both += 1
+    for i, obj in enumerate(sch_j.get("aw11", {}).get("pks", [])):
+        wc.to_canonical("aw11_pk", obj, dec)
+        wc.to_canonical("aw11_msk", sch_j["aw11"]["msks"][i], dec)
+        seen += 2
+    return seen, both
+
+
 # ------------------------------------------------------------------------------------------------ reference-dependent tests
 needs_ref = pytest.mark.skipif(not os.path.exists(PRIM), reason="tests/golden/ref_primitives.json absent: run integration/ref-harness "
                                "(cargo run --release --bin dump_vectors -- tests/golden) on a machine with Rust; parity stays unpinned until then")
@@ -261,6 +296,9 @@ def test_ref_scheme_transcripts_decrypt_with_the_oracle():
     prim = rp.load(PRIM)
     srcs, report = check_primitives(prim)
     assert check_schemes(rp.load(SCHEMES), srcs, report["into_vec_u8"]) == ["ac17", "bsw", "lsw", "aw11"]
+    seen, both = check_wire(rp.load(SCHEMES), prim, srcs)
+    print("wire_compat: %d structs imported, %d of them also from their borsh bytes" % (seen, both))
+    assert seen >= 17 and both >= 9
 
 
 @needs_ref
@@ -324,9 +362,11 @@ def synth_primitives(fe_r, fe_p, g_shape, g2_order, gt_order, serde_limb, prefix
         g = pairing_fn(p, q)
         prim["pairing"].append({"a": x, "b": y, "p": e["g1"](p), "q": e["g2"](q), "out": e["gt"](g), "into_vec_u8": gt_bytes(g).hex()})
     # the affine encoding of infinity is (0, 0); a Jacobian crate writes z = 0
+    pre = (lambda k: k.to_bytes(4, "little").hex()) if prefix else (lambda k: "")
     inf1 = rp.encode_element("g1", None, fe_p, "affine", serde_limb=serde_limb, prefix=prefix) if g_shape == "affine" else \
-        {"serde": list(bytes(96)), "borsh": bytes(96).hex(), "debug": ""}
-    inf2 = {"serde": list(bytes(128 if g_shape == "affine" else 192)), "borsh": bytes(128 if g_shape == "affine" else 192).hex(), "debug": ""}
+        {"serde": list(bytes(96)), "borsh": pre(96) + bytes(96).hex(), "debug": ""}
+    n2 = 128 if g_shape == "affine" else 192
+    inf2 = {"serde": list(bytes(n2)), "borsh": pre(n2) + bytes(n2).hex(), "debug": ""}
     prim["group_ops"] = {"g1_zero": inf1, "g2_zero": inf2, "gt_one": e["gt"](bn.GT_ONE), "g1_2_plus_3": e["g1"](bn.g1_mul(bn.G1_GEN, 5)),
                          "g1_neg_2": e["g1"](bn.g1_neg(bn.g1_mul(bn.G1_GEN, 2))), "gt_inverse_e11": e["gt"](bn.gt_inv(e11)),
                          "gt_mul": e["gt"](bn.gt_pow(e11, 4))}
@@ -437,3 +477,5 @@ def test_selftest_scheme_transcripts():
                    "ct": {"policy": [policy, "JsonPolicy"], "c_0": S("gt", ct["c_0"]), "c": [[t[0], S("gt", t[1]), S("g2", t[2]), S("g2", t[3])] for t in ct["c"]],
                           "ct": seal(msg)}}
     assert check_schemes(json.loads(json.dumps(out)), srcs, report["into_vec_u8"]) == ["ac17", "bsw", "lsw", "aw11"]
+    seen, _ = check_wire(json.loads(json.dumps(out)), json.loads(json.dumps(prim)), srcs)          # the same structs through rabe_amd/wire_compat.py
+    assert seen >= 10

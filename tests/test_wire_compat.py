@@ -93,11 +93,15 @@ def world(request):
     objs["aw11_sk"] = {"gid": "bob", "attr": [[n, S("g1", p)] for n, p in sk["attr"]]}
     objs["aw11_ct"] = {"policy": [policy, "JsonPolicy"], "c_0": S("gt", ct["c_0"]),
                        "c": [[t[0], S("gt", t[1]), S("g2", t[2]), S("g2", t[3])] for t in ct["c"]], "ct": seal(msg)}
-    return (dec, enc), json.loads(json.dumps(objs)), layout["g_shape"] == "affine"
+    bsamples = {"fr": prim["fr_from_str"][1]["out"]["borsh"], "g1": prim["g1_mul"][1]["out"]["borsh"], "g2": prim["g2_mul"][1]["out"]["borsh"],
+                "gt": prim["gt_pow"][1]["out"]["borsh"]}
+    bzeros = {"g1": prim["group_ops"]["g1_zero"]["borsh"], "g2": prim["group_ops"]["g2_zero"]["borsh"]}
+    borsh = wc.borsh_codec_from_source(srcs["borsh"], bsamples, bzeros)
+    return (dec, enc), json.loads(json.dumps(objs)), layout["g_shape"] == "affine", borsh
 
 
 def test_import_is_the_host_layers_canonical_record_and_export_restores_the_json(world):
-    (dec, enc), objs, unique = world
+    (dec, enc), objs, unique, _ = world
     for kind, obj in objs.items():
         blob = wc.to_canonical(kind, obj, dec)
         o = hl.Obj.deserialize(kind, blob)                      # the C++ reader accepts it (structure, ranges) ...
@@ -111,7 +115,7 @@ def test_import_is_the_host_layers_canonical_record_and_export_restores_the_json
 
 
 def test_malformed_serde_is_rejected(world):
-    (dec, enc), objs, _ = world
+    (dec, enc), objs, _, _ = world
     bad = json.loads(json.dumps(objs["ac17_cp_ct"]))
     bad["ct"]["c_0"] = bad["ct"]["c_0"][:2]                     # ASSUMPTION_SIZE + 1 elements expected
     with pytest.raises(ValueError):
@@ -124,10 +128,29 @@ def test_malformed_serde_is_rejected(world):
         wc.from_canonical("aw11_gk", wc.to_canonical("aw11_gk", objs["aw11_gk"], dec) + b"\0", enc)
 
 
+def test_borsh_form_and_the_console_envelope_round_trip(world):
+    """rabe-console's default on-disk form: borsh of the struct, raw deflate, hex between BEGIN / END lines"""
+    (dec, enc), objs, unique, codec = world
+    labels = {"ac17_cp_ct": "CT", "bsw_sk": "SK", "aw11_gk": "GP", "lsw_sk": "SK", "ac17_msk": "MSK", "bsw_pk": "PK"}
+    for kind, obj in objs.items():
+        blob = wc.to_canonical(kind, obj, dec)
+        b = wc.from_canonical_borsh(kind, blob, codec)
+        assert wc.to_canonical_borsh(kind, b, codec) == blob, kind            # borsh -> canonical is the inverse
+        if kind in labels:
+            text = wc.write_envelope(labels[kind], b)
+            assert text.count("\n") == 2 and text.splitlines()[1] == text.splitlines()[1].lower()
+            label, back = wc.read_envelope(text)
+            assert (label, back) == (labels[kind], b)
+    with pytest.raises(ValueError):
+        wc.to_canonical_borsh("aw11_gk", wc.from_canonical_borsh("aw11_gk", wc.to_canonical("aw11_gk", objs["aw11_gk"], dec), codec) + b"\0", codec)
+    with pytest.raises(ValueError):
+        wc.read_envelope("no envelope here")
+
+
 @pytest.mark.gpu
 def test_imported_rabe_form_ciphertexts_decrypt_on_the_engine(world):
     from rabe_amd.schemes import ac17, aw11, bsw, lsw
-    (dec, enc), objs, _ = world
+    (dec, enc), objs, _, _ = world
     host = hl.Host(0)
     imp = lambda kind: hl.Obj.deserialize(kind, wc.to_canonical(kind, objs[kind], dec), host)          # with the GPU membership checks
     assert ac17.cp_decrypt(host, imp("ac17_cp_sk"), imp("ac17_cp_ct")) == PLAINTEXT
