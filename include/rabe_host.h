@@ -82,6 +82,14 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
  * the order-r subgroup of Fq12 (rabe-bn: FieldError::NotMember) -- and a non-member fails its item only.  Set the flag only for
  * ciphertexts this process produced itself. */
 #define RABE_PACKED_TRUSTED 1u
+/* Environment of the packed entry points (read per call; defaults are what the measurements in DESIGN.md section 7 favour):
+ *   RABE_PACKED_LANES   chunks of one packed call in flight, each on its own engine lane (default 2; 1 = never chunk)
+ *   RABE_PACKED_CHUNK   fewest items per chunk (default: 8192 for ac17 -- two chunks from 16 384 items on --, never for bsw / lsw / aw11)
+ *   RABE_MEMBER_INLINE  run the decoding checks on the main stream before the kernels instead of beside them (A/B)
+ *   RABE_G_WINDOW       signed window width of AC17's g table in this layer (default 20 = +0.44 GB per public key; 16 = none extra)
+ *   RABE_NO_ARENA       every device buffer of a call its own hipMalloc again (diagnostics)
+ *   RABE_HOST_TIMING    stage timings on stderr
+ * Results never depend on any of them. */
 int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
                                     const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf,
                                     size_t pt_cap, uint64_t* pt_off /*[n_items+1]*/);
