@@ -122,6 +122,9 @@ int32_t rhip_g2_in_subgroup_by_order(rhip_ctx* ctx, size_t n, const rhip_g2* dev
 int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
 /* the same verdicts with the order test by the definition f^r = 1 (rhip_gt_is_member uses f^p = f^(6u^2) after the cyclotomic test) */
 int32_t rhip_gt_is_member_by_order(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
+/* verdicts folded per item on the device: dev_out[s] = AND of dev_flags[scale * dev_seg_off[s] .. scale * dev_seg_off[s + 1]),
+ * s < n_seg (dev_seg_off has n_seg + 1 entries: an item's rows; scale = elements per row) */
+int32_t rhip_flags_all(rhip_ctx* ctx, size_t n_seg, const uint32_t* dev_seg_off, uint32_t scale, const uint32_t* dev_flags, uint32_t* dev_out);
 
 int32_t rhip_gt_mul(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, const rhip_gt* dev_b, rhip_gt* dev_out);
 /* out[i] = product of a[off[i] .. off[i+1]) (1 for an empty segment): the Gt accumulation loops of aw11::decrypt :320-352 */

@@ -83,8 +83,8 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
  * ciphertexts this process produced itself. */
 #define RABE_PACKED_TRUSTED 1u
 /* Environment of the packed entry points (read per call; defaults are what the measurements in DESIGN.md section 7 favour):
- *   RABE_PACKED_LANES   chunks of one packed call in flight, each on its own engine lane (default 2; 1 = never chunk)
- *   RABE_PACKED_CHUNK   fewest items per chunk (default: 8192 for ac17 -- two chunks from 16 384 items on --, never for bsw / lsw / aw11)
+ *   RABE_PACKED_CHUNK   cut a packed call into chunks of at least this many items that run RABE_PACKED_LANES (default 2) at a time, each on
+ *                       its own engine lane; off by default -- measured no faster than one launch set once the unchunked call was tuned
  *   RABE_MEMBER_INLINE  run the decoding checks on the main stream before the kernels instead of beside them (A/B)
  *   RABE_G_WINDOW       signed window width of AC17's g table in this layer (default 20 = +0.44 GB per public key; 16 = none extra)
  *   RABE_NO_ARENA       every device buffer of a call its own hipMalloc again (diagnostics)

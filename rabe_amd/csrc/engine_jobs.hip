@@ -1223,6 +1223,23 @@ extern "C" int32_t rhip_gt_is_member_by_order(rhip_ctx* ctx, size_t n, const rhi
   KLAUNCH(ctx, "k_gt_is_member", k_gt_is_member, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, ok, 1);
   return RHIP_OK;
 }
+// the verdicts of a batch's elements folded per item on the device: out[s] = AND of flags[scale * seg_off[s] .. scale * seg_off[s + 1]).
+// A 131 072-item AC17 batch has 19.7 M row elements: their flags are 79 MB that nobody needs on the host.
+__global__ void __launch_bounds__(256) k_flags_all(size_t n_seg, const uint32_t* seg_off, uint32_t scale, const uint32_t* flags, uint32_t* out) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  uint32_t ok = 1;
+  const size_t hi = (size_t)scale * seg_off[s + 1];
+  for (size_t i = (size_t)scale * seg_off[s]; i < hi; i++) ok &= (flags[i] != 0) ? 1u : 0u;
+  out[s] = ok;
+}
+extern "C" int32_t rhip_flags_all(rhip_ctx* ctx, size_t n_seg, const uint32_t* seg_off, uint32_t scale, const uint32_t* flags, uint32_t* out) {
+  NEED(ctx);
+  if (!n_seg) return RHIP_OK;
+  if (!seg_off || !flags || !out || !scale) return RHIP_ERR_ARG;
+  KLAUNCH(ctx, "k_flags_all", k_flags_all, dim3(blocks_for(n_seg, 256)), dim3(256), 0, ctx->stream, n_seg, seg_off, scale, flags, out);
+  return RHIP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ generic pairing jobs
 // The shape every decrypt of the host layer plans to (rabe_amd/csrc/host/schemes.cpp: PairingJob), device-resident:

@@ -213,13 +213,15 @@ class Engine {
 class MemberChecks {
  public:
   explicit MemberChecks(Engine& eng);
-  void add(int which, const void* dev, size_t count);           // which: 1 G1 on curve, 2 G2 in the r-torsion, 3 Gt in the order-r subgroup
+  // which: 1 G1 on curve, 2 G2 in the r-torsion, 3 Gt in the order-r subgroup.  With `dev_seg_off` (n_seg + 1 device offsets, in rows of
+  // `scale` elements) the verdicts are folded per segment on the device: ok(k) then has n_seg entries instead of `count`.
+  void add(int which, const void* dev, size_t count, const uint32_t* dev_seg_off = nullptr, size_t n_seg = 0, uint32_t scale = 1);
   void collect();                                               // waits for the checks (not for the main context)
-  const std::vector<uint32_t>& ok(size_t k) const { return flags_[k]; }      // verdicts of the k-th add, one per element
+  const std::vector<uint32_t>& ok(size_t k) const { return flags_[k]; }      // verdicts of the k-th add
  private:
   Engine& eng_;
   rhip_ctx* cx_;
-  std::vector<DBuf> dev_;
+  std::vector<DBuf> dev_, scratch_;
   std::vector<std::vector<uint32_t>> flags_;
 };
 

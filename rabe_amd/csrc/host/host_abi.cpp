@@ -25,11 +25,12 @@ struct rabe_host {
 };
 static thread_local std::string g_err;
 
-// fewest items per chunk of a pipelined packed call (pipeline.cpp).  AC17 (host stages and copies are two thirds of a call): two chunks
-// from 16 384 items on, +6 % at 20 480 items, +15 % at 131 072.  bsw / lsw / aw11 at 100-200 leaves are GPU-bound (the kernels are 70-80 % of
-// a call) and two concurrent half-size launch sets run slower than one (-6 ... -10 %, tools/exp_r03x.sh): never chunked unless
+// fewest items per chunk of a pipelined packed call (pipeline.cpp).  Measured, not assumed (tools/bench_packed_pipeline.py, tools/exp_r03x.sh):
+// once the per-buffer hipMalloc / hipFree, the per-call line preparation and the 79 MB of per-element verdicts were gone from the
+// unchunked call, two half-size chunks on two lanes are no faster for ac17 (20 480 items 339 k -> 311 k ops/s, 65 536 458 k -> 433 k,
+// 131 072 406 k -> 402 k) and slower for the GPU-bound bsw / lsw / aw11 (-6 ... -10 %): no entry point is chunked unless
 // RABE_PACKED_CHUNK asks for it.
-static const size_t CHUNK_AC17 = 8192, CHUNK_BSW = (size_t)1 << 40, CHUNK_LSW = (size_t)1 << 40, CHUNK_AW11 = (size_t)1 << 40;
+static const size_t CHUNK_AC17 = (size_t)1 << 40, CHUNK_BSW = (size_t)1 << 40, CHUNK_LSW = (size_t)1 << 40, CHUNK_AW11 = (size_t)1 << 40;
 #define GUARD_BEGIN try {
 #define GUARD_END(h)                                                         \
   }                                                                          \

@@ -451,7 +451,8 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
-      mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total); mc->add(2, d_g2.ptr(), total); mc->add(3, d_cp.ptr(), m_items);
+      mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items); mc->add(2, d_g2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
+      mc->add(3, d_cp.ptr(), m_items);
     }
     // the key's prepared lines (d and every d_j.g2: 17 KB per point) are a function of the key alone: kept across calls
     rhip_bsw_sk_lines* lines = nullptr;
@@ -473,8 +474,7 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       const auto &ok_c = mc->ok(0), &ok_g1 = mc->ok(1), &ok_g2 = mc->ok(2), &ok_cp = mc->ok(3);
       for (size_t j = 0; j < m_items; j++) {
         const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
-        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1] && !bad; y++)
-          if (!ok_g1[y] || !ok_g2[y]) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
+        if (!bad && (!ok_g1[j] || !ok_g2[j])) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
         if (bad) (*errors)[live[j]] = bad;
       }
     }
@@ -743,7 +743,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
-      mc->add(1, d_d1.ptr(), total); mc->add(2, d_d2.ptr(), total);
+      mc->add(1, d_d1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items); mc->add(2, d_d2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
     }
     std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
     rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
@@ -759,8 +759,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
       mc->collect();
       const auto &ok1 = mc->ok(0), &ok2 = mc->ok(1);
       for (size_t j = 0; j < m_items; j++)
-        for (uint32_t y = leaf_off[j]; y < leaf_off[j + 1]; y++)
-          if (!ok1[y] || !ok2[y]) { (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)"; break; }
+        if (!ok1[j] || !ok2[j]) (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)";
     }
     for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
@@ -1047,7 +1046,8 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
-      mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total); mc->add(2, d_c2.ptr(), total); mc->add(2, d_c3.ptr(), total);
+      mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total, d_row_off.as<uint32_t>(), m_items); mc->add(2, d_c2.ptr(), total, d_row_off.as<uint32_t>(), m_items);
+      mc->add(2, d_c3.ptr(), total, d_row_off.as<uint32_t>(), m_items);
     }
     int32_t rc = rhip_aw11_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                          d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(),
@@ -1061,8 +1061,7 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
       mc->collect();
       const auto &ok0 = mc->ok(0), &ok1 = mc->ok(1), &ok2 = mc->ok(2), &ok3 = mc->ok(3);
       for (size_t j = 0; j < m_items; j++) {
-        bool bad = !ok0[j];
-        for (uint32_t y = row_off[j]; y < row_off[j + 1] && !bad; y++) bad = !ok1[y] || !ok2[y] || !ok3[y];
+        const bool bad = !ok0[j] || !ok1[j] || !ok2[j] || !ok3[j];
         if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
       }
     }

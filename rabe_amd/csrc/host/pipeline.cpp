@@ -4,8 +4,8 @@
 // other: host cores (record parsing, policy plans, draws), PCIe (staging copies), the GPU (membership pass, the scheme's kernels), PCIe
 // again, host cores again (KDF + AES-GCM, record assembly).  Run as one piece, every part waits for the others: of the 70 ms of an AC17
 // encrypt + decrypt of 20 480 items only ~25 are GPU time.  Here a batch is cut into chunks of items and the SAME entry point runs on
-// every chunk, two chunks at a time by default, each on its own worker thread and engine lane (common.h: a context = stream + workspaces, pinned
-// staging buffers, device arena) -- one chunk's parsing runs beside another's kernels and a third's copies.
+// every chunk, two chunks at a time, each on its own worker thread and engine lane (common.h: a context = stream + workspaces, pinned
+// staging buffers, device arena) -- one chunk's parsing runs beside another's kernels and a third's copies.  OFF by default: see `cut`.
 //
 // Results are those of the unchunked call, byte for byte:
 //  * records / plaintexts of chunk k land where the unchunked call puts them (producers: sized up front by the entry point's own sizing
@@ -51,10 +51,19 @@ struct GatedRng : Rng {
   ~GatedRng() override { pass(); }
   void take() { if (!in) { gate.enter(k); in = true; } }
   void pass() { if (!done) { take(); gate.leave(k); done = true; } }              // a chunk that ends without (further) draws
-  Fr next_fr() override { take(); return base.next_fr(); }
-  void fill(uint8_t* out, size_t n) override { take(); base.fill(out, n); }
+  Fr next_fr() override { guard(); return base.next_fr(); }
+  void fill(uint8_t* out, size_t n) override { guard(); base.fill(out, n); }
+  void guard() {
+    if (done) throw RabeError("pipelined batch: the entry point drew outside its draw bracket (results would depend on the chunking)");
+    take();
+  }
   bool unordered() const override { return base.unordered(); }
-  void begin_draws() override { take(); base.begin_draws(); }
+  void begin_draws() override {
+    // one bracket per call: a second one would draw after later chunks have already taken their turn
+    if (done) throw RabeError("pipelined batch: the entry point opened a second draw bracket (results would depend on the chunking)");
+    take();
+    base.begin_draws();
+  }
   void end_draws() override { base.end_draws(); pass(); }
 };
 
@@ -65,10 +74,11 @@ size_t env_size(const char* name, size_t dflt) {
   return v > 0 ? (size_t)v : dflt;
 }
 struct Cut { size_t chunks, per, lanes; };
-// Chunks of at least `min_chunk` items, one per lane.  Measured (tools/bench_packed_pipeline.py, AC17, 50 attributes): every stage of a
-// chunk has a fixed cost -- the host stages already use all cores, small launches under-fill the GPU -- so more, smaller chunks lose
-// what the overlap wins: 20 480 items 300 k ops/s unchunked, 318 k as 2 x 10 240, 206 k as 5 x 4096 on 3 lanes; 131 072 items 390 k
-// unchunked, 451 k as 2 x 65 536, 424 k as 8 x 16 384 on 3 lanes.  RABE_PACKED_CHUNK / RABE_PACKED_LANES override (tests: many tiny chunks).
+// Chunks of at least `min_chunk` items, one per lane.  Measured (tools/bench_packed_pipeline.py, AC17, 50 attributes, ops/s unchunked ->
+// two half-size chunks on two lanes, after the unchunked call lost its per-buffer allocations, per-call line preparation and per-element
+// verdict downloads): 20 480 items 339 k -> 311 k, 65 536 458 k -> 433 k, 131 072 406 k -> 402 k; finer chunks are worse still (20 480 as
+// 5 x 4096 on three lanes: 224 k) -- every stage of a chunk has a fixed cost, the host stages already use all cores, small launches
+// under-fill the GPU.  So host_abi.cpp passes min_chunk = "never"; RABE_PACKED_CHUNK / RABE_PACKED_LANES switch it on (the tests do).
 Cut cut(size_t n, size_t min_chunk) {
   size_t lanes = env_size("RABE_PACKED_LANES", 2);
   if (lanes > 8) lanes = 8;

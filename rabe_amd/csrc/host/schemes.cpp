@@ -108,20 +108,28 @@ rhip_ctx* Engine::side_ctx() {
 MemberChecks::MemberChecks(Engine& eng) : eng_(eng), cx_(getenv("RABE_MEMBER_INLINE") ? eng.ctx() : eng.side_ctx()) {
   if (cx_ != eng.ctx()) eng.check(rhip_ctx_wait_for(cx_, eng.ctx()), "rhip_ctx_wait_for");
 }
-void MemberChecks::add(int which, const void* dev, size_t count) {
-  flags_.emplace_back(count, 1u);
-  dev_.emplace_back(&eng_, count * 4);
+void MemberChecks::add(int which, const void* dev, size_t count, const uint32_t* dev_seg_off, size_t n_seg, uint32_t scale) {
+  const bool fold = dev_seg_off != nullptr;
+  flags_.emplace_back(fold ? n_seg : count, 1u);
+  dev_.emplace_back(&eng_, (fold ? n_seg : count) * 4);
   if (!count) return;
-  uint32_t* ok = dev_.back().as<uint32_t>();
+  DBuf per_element;
+  if (fold) per_element = DBuf(&eng_, count * 4);
+  uint32_t* ok = fold ? per_element.as<uint32_t>() : dev_.back().as<uint32_t>();
   int32_t rc = which == 1 ? rhip_g1_on_curve(cx_, count, (const rhip_g1*)dev, ok)
              : which == 2 ? rhip_g2_in_subgroup(cx_, count, (const rhip_g2*)dev, ok)
                           : rhip_gt_is_member(cx_, count, (const rhip_gt*)dev, ok);
   eng_.check(rc, "membership pass");
+  if (fold) {
+    eng_.check(rhip_flags_all(cx_, n_seg, dev_seg_off, scale, ok, dev_.back().as<uint32_t>()), "rhip_flags_all");
+    scratch_.push_back(std::move(per_element));            // lives until collect(): the side stream still reads it
+  }
 }
 void MemberChecks::collect() {
   for (size_t k = 0; k < flags_.size(); k++)
     if (!flags_[k].empty()) eng_.check(rhip_download_async(cx_, flags_[k].data(), dev_[k].ptr(), flags_[k].size() * 4), "download");
   eng_.check(rhip_sync(cx_), "rhip_sync (membership pass)");
+  scratch_.clear();
 }
 Engine::ArenaScope::~ArenaScope() {
   Lane& l = *e.lanes_[e.cur_lane()];
@@ -1187,7 +1195,7 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
       mc->add(2, d1.ptr(), 3 * m);
-      mc->add(1, d2.ptr(), 3 * total_rows);
+      mc->add(1, d2.ptr(), 3 * total_rows, d3.as<uint32_t>(), m, 3);
       mc->add(3, d4.ptr(), m);
     }
     // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
@@ -1206,8 +1214,7 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
       for (size_t j = 0; j < m; j++) {
         const char* bad = nullptr;
         for (int t = 0; t < 3 && !bad; t++) if (!ok_c0[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
-        for (size_t r = 3 * (size_t)ct_row_off[j]; r < 3 * (size_t)ct_row_off[j + 1] && !bad; r++)
-          if (!ok_rows[r]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
+        if (!bad && !ok_rows[j]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
         if (!bad && !ok_cp[j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
         if (bad) (*errors)[live[j]] = bad;
       }
