@@ -381,9 +381,11 @@ int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
  * rhip_aw11_pk: gk (g1, g2), the constant e(g1, g2) and, for each of the n_attrs attributes of the authorities in play,
  * (egg_alpha_x, g2 * y_x) (Aw11PublicKey.attr, :56-61) as window tables.  leaf_attr[leaf] (per policy leaf, beside the
  * flattened tree tables) = the attribute's index in those arrays.  The per-attribute tables are 8-bit windows (4.2 MB per
- * attribute).  16-bit windows as well (536 MB per attribute, 107 GB for 200: half the table entries per power) are OPT-IN through
- * the environment variable RABE_AW11_ATTR_W16=1, and even then only built while they leave a quarter of the device memory free.
- * Results do not depend on it. */
+ * attribute) plus, by default, SIGNED 10-bit windows built from them (26 x 512 entries = 6.8 MB per attribute, 1.4 GB for 200: 26 instead
+ * of 32 table entries per power, a negative digit is a conjugation in Gt / a negated y in G2; RABE_AW11_ATTR_BITS = 9 ... 14 picks another
+ * width, 8 none; only built while they leave half of the device memory free).  16-bit windows (536 MB per attribute, 107 GB for 200: 16
+ * entries per power) are OPT-IN through RABE_AW11_ATTR_W16=1, and even then only built while they leave a quarter of the device memory
+ * free.  Results do not depend on any of it. */
 typedef struct rhip_aw11_pk rhip_aw11_pk;
 int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* host_g1, const rhip_g2* host_g2, size_t n_attrs,
                             const rhip_gt* host_egg_alpha /*[n_attrs]*/, const rhip_g2* host_g2_y /*[n_attrs]*/, rhip_aw11_pk** out);

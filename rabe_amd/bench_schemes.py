@@ -765,7 +765,15 @@ class Aw11Bench:
                 "table_build_ms_per_public_key_set": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3),
                 "attribute_tables": "16-bit windows for the %d per-attribute bases (%.0f GB, opted in with RABE_AW11_ATTR_W16=1) "
                                     "-- 16 instead of 32 table entries per power" % (2 * self.n_attr, self.n_attr * 16 * 65535 * 512 / 1e9)
-                if os.environ.get("RABE_AW11_ATTR_W16", "0") == "1" else "8-bit windows for the per-attribute bases (0.8 GB; the default)"}
+                if os.environ.get("RABE_AW11_ATTR_W16", "0") == "1" else self.signed_tables_note()}
+
+    def signed_tables_note(self):
+        w = int(os.environ.get("RABE_AW11_ATTR_BITS", "10"))
+        if not 9 <= w <= 14:
+            return "8-bit windows for the per-attribute bases (0.8 GB)"
+        n = (255 + w - 1) // w
+        return ("signed %d-bit windows for the %d per-attribute bases (%d instead of 32 table entries per power; %.1f GB beside the 0.8 GB of 8-bit "
+                "tables they are built from; the default is 10 bits)" % (w, 2 * self.n_attr, n, self.n_attr * n * (1 << (w - 1)) * 512 / 1e9))
 
     def algorithmic_fpmul_per_item(self):
         # enc 201 fixed-base Gt pow (0.34 MM) + 200 var-base Gt pow (1.6 MM) + 400 fixed-base + 200 var-base G2 (2.1 MM);

@@ -252,15 +252,21 @@ struct rhip_gt_table { rhip_ctx* ctx; GtM* dev; GtM* dev16; };   // dev16: optio
 // `started` false: the first entry is copied instead of multiplied (and stays false when the scalar is 0).
 struct GtMOperand {
   const GtM* e;
+  bool conj = false;          // the entry's inverse (members of Gt are unitary: the inverse is the conjugate)
   __device__ __forceinline__ Fp6 half(int h) const {
     const uint32_t* p = e->l + 48 * h;
-    return Fp6{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
+    const Fp6 v{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
+    return (conj && h == 1) ? fp6_neg(v) : v;
   }
 };
 __device__ __forceinline__ void home_mul_entry(const GtM* e) { facc_mul(LdsHome{}, GtMOperand{e}); }
 __device__ __forceinline__ void home_take(bool& started, const GtM* e) {
   if (started) home_mul_entry(e);
   else { facc_set(LdsHome{}, GtMOperand{e}); started = true; }
+}
+__device__ __forceinline__ void home_take_signed(bool& started, const GtM* e, bool inverse) {
+  if (started) facc_mul(LdsHome{}, GtMOperand{e, inverse});
+  else { facc_set(LdsHome{}, GtMOperand{e, inverse}); started = true; }
 }
 static __device__ __noinline__ void home_table_pow_gt_w16(bool& started, const GtM* tbl, const uint32_t k[8]) {
 #pragma unroll 1
@@ -366,6 +372,28 @@ static __device__ __forceinline__ G1Jac table_mul_g1_wide_inl(const G1M* tbl, co
   return acc;
 }
 static __device__ __noinline__ G1Jac table_mul_g1_wide(const G1M* tbl, const uint32_t k[8], int w) { return table_mul_g1_wide_inl(tbl, k, w); }
+// The same signed w-bit recoding for tables with FULL windows (8 <= w <= 14; per-attribute bases of AW11): n = sgn_windows(w) windows
+// of 2^(w-1) entries each, T[i][|d|-1] = (|d| 2^(w i)) * base.  n w >= 255, so the last carry always lands in a window.
+__host__ __device__ inline int sgn_windows(int w) { return (255 + w - 1) / w; }
+__host__ __device__ inline size_t sgn_entries(int w) { return (size_t)sgn_windows(w) << (w - 1); }
+static __device__ __noinline__ G2Jac table_mul_g2_signed(G2Jac acc, const G2M* tbl, const uint32_t k[8], int w) {
+  const int n = sgn_windows(w);
+  const uint32_t half = 1u << (w - 1);
+  uint32_t carry = 0;
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const int bit = w * i;
+    const uint32_t raw = scalar_bits(k, bit, w) + carry;          // bit <= w (n - 1) < 255; bits past 255 read as zero
+    carry = raw > half ? 1u : 0u;
+    const uint32_t mag = carry ? (1u << w) - raw : raw;
+    if (mag) {
+      G2Aff e = ld_g2_m(tbl + ((size_t)i << (w - 1)) + (mag - 1));
+      if (carry) e.y = fp2_neg(e.y);
+      acc = jac_add_aff(acc, e);
+    }
+  }
+  return acc;
+}
 static __device__ __noinline__ G2Jac table_mul_g2(const G2M* tbl, const uint32_t k[8]) {
   G2Jac acc = jac_inf<Fp2>();
   for (int w = 0; w < TBL_WINDOWS; w++) {
@@ -399,6 +427,18 @@ static __device__ __noinline__ void home_table_pow_gt(bool& started, const GtM* 
   for (int w = 0; w < TBL_WINDOWS; w++) {
     const uint32_t d = scalar_byte(k, w);
     if (d) home_take(started, tbl + w * TBL_DIGITS + (d - 1));
+  }
+}
+static __device__ __noinline__ void home_table_pow_gt_signed(bool& started, const GtM* tbl, const uint32_t k[8], int w) {
+  const int n = sgn_windows(w);
+  const uint32_t half = 1u << (w - 1);
+  uint32_t carry = 0;
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const uint32_t raw = scalar_bits(k, w * i, w) + carry;
+    carry = raw > half ? 1u : 0u;
+    const uint32_t mag = carry ? (1u << w) - raw : raw;
+    if (mag) home_take_signed(started, tbl + ((size_t)i << (w - 1)) + (mag - 1), carry != 0);
   }
 }
 // the value forms (64-thread blocks only: they go through the home)

@@ -801,6 +801,11 @@ struct rhip_aw11_pk {
   // for work on a 288 GB part: 16 instead of 32 table entries per power).  Built when the device has the room (rhip_aw11_pk_create).
   GtM* attr_gt16;
   G2M* attr_g216;
+  // signed w-bit windows per attribute (the default: RABE_AW11_ATTR_BITS, 10 = 13 312 entries = 6.8 MB per attribute for both bases):
+  // sgn_windows(w) instead of 32 table entries per power, the sign of a digit is a conjugation (Gt) / a negated y (G2)
+  GtM* attr_gt_s;
+  G2M* attr_g2_s;
+  int s_bits;
 };
 extern "C" void rhip_aw11_pk_destroy(rhip_aw11_pk* pk) {
   if (!pk) return;
@@ -810,7 +815,42 @@ extern "C" void rhip_aw11_pk_destroy(rhip_aw11_pk* pk) {
   if (pk->attr_g2) (void)hipFree(pk->attr_g2);
   if (pk->attr_gt16) (void)hipFree(pk->attr_gt16);
   if (pk->attr_g216) (void)hipFree(pk->attr_g216);
+  if (pk->attr_gt_s) (void)hipFree(pk->attr_gt_s);
+  if (pk->attr_g2_s) (void)hipFree(pk->attr_g2_s);
   delete pk;
+}
+// signed-window tables from the 8-bit ones: entry (a, i, d-1) = (d << (w i)) * base_a, at most three 8-bit digits
+__global__ void __launch_bounds__(64, RB_MIN_WAVES) k_attr_tables_gt_signed(size_t n_attrs, int w, const GtM* t8, GtM* out) {
+  const size_t per = sgn_entries(w);
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = t < n_attrs * per;
+  if (!active) t = n_attrs * per - 1;
+  const size_t a = t / per, e = t % per;
+  const int i = (int)(e >> (w - 1));
+  const uint64_t d = (e & (((size_t)1 << (w - 1)) - 1)) + 1;
+  const int b = w * i, word = b >> 5, sh = b & 31;
+  const uint64_t lo = d << sh;
+  uint32_t m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) m[j] = (j == word) ? (uint32_t)lo : (j == word + 1) ? (uint32_t)(lo >> 32) : 0u;
+  bool started = false;
+  home_table_pow_gt(started, t8 + a * TBL_WINDOWS * TBL_DIGITS, m);
+  const Fp12 v = home_result(started);
+  if (active) st_gt_m(out + t, v);
+}
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_attr_tables_g2_signed(size_t n_attrs, int w, const G2M* t8, G2M* out) {
+  const size_t per = sgn_entries(w);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_attrs * per) return;
+  const size_t a = t / per, e = t % per;
+  const int i = (int)(e >> (w - 1));
+  const uint64_t d = (e & (((size_t)1 << (w - 1)) - 1)) + 1;
+  const int b = w * i, word = b >> 5, sh = b & 31;
+  const uint64_t lo = d << sh;
+  uint32_t m[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) m[j] = (j == word) ? (uint32_t)lo : (j == word + 1) ? (uint32_t)(lo >> 32) : 0u;
+  st_g2_m(out + t, jac_to_aff(table_mul_g2(t8 + a * TBL_WINDOWS * TBL_DIGITS, m)));
 }
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_attr_tables_gt(size_t n_attrs, const rhip_gt* base, GtM* tbl) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -838,7 +878,7 @@ extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const r
                                        const rhip_g2* host_g2_y, rhip_aw11_pk** out) {
   if (!ctx || !g1 || !g2 || !n_attrs || !host_egg_alpha || !host_g2_y || !out) return RHIP_ERR_ARG;
   *out = nullptr;
-  rhip_aw11_pk* pk = new rhip_aw11_pk{ctx, nullptr, nullptr, n_attrs, nullptr, nullptr, nullptr, nullptr};
+  rhip_aw11_pk* pk = new rhip_aw11_pk{ctx, nullptr, nullptr, n_attrs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   rhip_gt e;
   int32_t rc = rhip_host_pairing(ctx, g1, g2, &e);
   if (!rc) rc = rhip_g2_table_create(ctx, g2, &pk->g2);
@@ -891,6 +931,35 @@ extern "C" int32_t rhip_aw11_pk_create(rhip_ctx* ctx, const rhip_g1* g1, const r
       pk->attr_g216 = nullptr;
     }
   }
+  // signed windows per attribute (when the 16-bit tables were not asked for): RABE_AW11_ATTR_BITS = 8 keeps the plain 8-bit tables,
+  // 9 ... 14 builds signed tables of that width if they leave half of the device memory free
+  if (!pk->attr_gt16) {
+    int w = 10;
+    if (const char* eb = getenv("RABE_AW11_ATTR_BITS")) w = atoi(eb);
+    const size_t per_s = (w >= 9 && w <= 14) ? sgn_entries(w) : 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (per_s && free_b > n_attrs * per_s * (sizeof(GtM) + sizeof(G2M)) + total_b / 2) {
+      he = hipMalloc((void**)&pk->attr_gt_s, n_attrs * per_s * sizeof(GtM));
+      if (he == hipSuccess) he = hipMalloc((void**)&pk->attr_g2_s, n_attrs * per_s * sizeof(G2M));
+      if (he == hipSuccess) {
+        hipLaunchKernelGGL(k_attr_tables_gt_signed, dim3(blocks_for(n_attrs * per_s, 64)), dim3(64), 0, ctx->stream, n_attrs, w, (const GtM*)pk->attr_gt,
+                           pk->attr_gt_s);
+        hipLaunchKernelGGL(k_attr_tables_g2_signed, dim3(blocks_for(n_attrs * per_s, 128)), dim3(128), 0, ctx->stream, n_attrs, w, (const G2M*)pk->attr_g2,
+                           pk->attr_g2_s);
+        he = hipGetLastError();
+      }
+      if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+      if (he != hipSuccess) {
+        (void)hipGetLastError();
+        if (pk->attr_gt_s) (void)hipFree(pk->attr_gt_s);
+        if (pk->attr_g2_s) (void)hipFree(pk->attr_g2_s);
+        pk->attr_gt_s = nullptr;
+        pk->attr_g2_s = nullptr;
+      } else {
+        pk->s_bits = w;
+      }
+    }
+  }
   *out = pk;
   return RHIP_OK;
 }
@@ -911,7 +980,8 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_aw11_enc_scalars(size_t n
 // C1[row] = E^lambda * egg_alpha_x^r   (:272-274)
 __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
                                                                  const uint32_t* leaf_attr, const GtM* e_tbl, int e_w16, const GtM* attr_tbl,
-                                                                 int attr_w16, const rhip_fr* lam, const rhip_fr* rand, rhip_gt* c1) {
+                                                                 int attr_w16 /* 0: 8-bit, 1: 16-bit, 9..14: signed windows of that width */,
+                                                                 const rhip_fr* lam, const rhip_fr* rand, rhip_gt* c1) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_rows) return;
   const size_t item = owner_of(item_row_off, n_items, t);
@@ -921,13 +991,14 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_aw11_enc_c1(size_t total_r
   ld_scalar(kr, rand + t);
   bool started = false;       // E^lambda * egg_alpha_x^r as ONE running product on the lane's home value
   if (e_w16) home_table_pow_gt_w16(started, e_tbl, kl); else home_table_pow_gt(started, e_tbl, kl);
-  if (attr_w16) home_table_pow_gt_w16(started, attr_tbl + (size_t)a * TBL16_WINDOWS * TBL16_DIGITS, kr);
+  if (attr_w16 > 1) home_table_pow_gt_signed(started, attr_tbl + (size_t)a * sgn_entries(attr_w16), kr, attr_w16);
+  else if (attr_w16) home_table_pow_gt_w16(started, attr_tbl + (size_t)a * TBL16_WINDOWS * TBL16_DIGITS, kr);
   else home_table_pow_gt(started, attr_tbl + (size_t)a * TBL_WINDOWS * TBL_DIGITS, kr);
   store_gt(c1[t].l, home_result(started));
 }
 // C3[row] = (g2*y_x) * r + g2 * omega   (:275-277): two fixed-base sums on one accumulator
 __global__ void __launch_bounds__(128, RB_G2_WAVES) k_aw11_enc_c3(size_t total_rows, const uint32_t* item_row_off, size_t n_items, const uint32_t* item_tree_leaf,
-                                                                  const uint32_t* leaf_attr, const G2M* g2_tbl, const G2M* attr_tbl, int w16,
+                                                                  const uint32_t* leaf_attr, const G2M* g2_tbl, const G2M* attr_tbl, int w16, int g2_is_w16,
                                                                   const rhip_fr* omg, const rhip_fr* rand, rhip_g2* c3) {
   __shared__ uint32_t lds[2 * 8 * 128];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -939,7 +1010,23 @@ __global__ void __launch_bounds__(128, RB_G2_WAVES) k_aw11_enc_c3(size_t total_r
   ld_scalar(kr, rand + t);
   ld_scalar(kw, omg + t);
   G2Jac acc = jac_inf<Fp2>();
-  if (w16) {             // both tables with 16-bit windows: 2 x 16 entries
+  if (w16 > 1) {         // attribute base: signed w16-bit windows; g2: its 16-bit table (g2_tbl) or, without one, its 8-bit table
+    acc = table_mul_g2_signed(acc, attr_tbl + (size_t)a * sgn_entries(w16), kr, w16);
+    if (g2_is_w16) {
+#pragma unroll 1
+      for (int w = 0; w < TBL16_WINDOWS; w++) {
+        const uint32_t word = word_sel8(kw, w >> 1);
+        const uint32_t d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+        if (d) acc = jac_add_aff(acc, ld_g2_m(g2_tbl + (size_t)w * TBL16_DIGITS + (d - 1)));
+      }
+    } else {
+#pragma unroll 1
+      for (int w = 0; w < TBL_WINDOWS; w++) {
+        const uint32_t d = scalar_byte(kw, w);
+        if (d) acc = jac_add_aff(acc, ld_g2_m(g2_tbl + w * TBL_DIGITS + (d - 1)));
+      }
+    }
+  } else if (w16) {      // both tables with 16-bit windows: 2 x 16 entries
     const G2M* ta = attr_tbl + (size_t)a * TBL16_WINDOWS * TBL16_DIGITS;
 #pragma unroll 1
     for (int w = 0; w < 2 * TBL16_WINDOWS; w++) {
@@ -982,12 +1069,15 @@ extern "C" int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk
           item_tree_leaf, item_tree_gate, item_n_coef, tt, s, coef, item_coef_off, lam, omg);
   KLAUNCH(ctx, "k_aw11_enc_c1", k_aw11_enc_c1, dim3(blocks_for(total_rows, 64)), dim3(64), 0, ctx->stream, total_rows, item_row_off, n_items,
           item_tree_leaf, leaf_attr, (const GtM*)(et->dev16 ? et->dev16 : et->dev), et->dev16 ? 1 : 0,
-          (const GtM*)(pk->attr_gt16 ? pk->attr_gt16 : pk->attr_gt), pk->attr_gt16 ? 1 : 0, (const rhip_fr*)lam, rand, c1);
+          (const GtM*)(pk->attr_gt16 ? pk->attr_gt16 : pk->attr_gt_s ? pk->attr_gt_s : pk->attr_gt), pk->attr_gt16 ? 1 : pk->attr_gt_s ? pk->s_bits : 0,
+          (const rhip_fr*)lam, rand, c1);
   rc = rhip_g2_table_mul(ctx, pk->g2, total_rows, rand, c2);
   if (rc) return rc;
+  const bool both16 = pk->attr_g216 && pk->g2->dev16, sgn = !both16 && pk->attr_g2_s;
   KLAUNCH(ctx, "k_aw11_enc_c3", k_aw11_enc_c3, dim3(blocks_for(total_rows, 128)), dim3(128), 0, ctx->stream, total_rows, item_row_off, n_items,
-          item_tree_leaf, leaf_attr, (const G2M*)(pk->attr_g216 && pk->g2->dev16 ? pk->g2->dev16 : pk->g2->dev),
-          (const G2M*)(pk->attr_g216 && pk->g2->dev16 ? pk->attr_g216 : pk->attr_g2), (pk->attr_g216 && pk->g2->dev16) ? 1 : 0, (const rhip_fr*)omg, rand, c3);
+          item_tree_leaf, leaf_attr, (const G2M*)((both16 || sgn) && pk->g2->dev16 ? pk->g2->dev16 : pk->g2->dev),
+          (const G2M*)(both16 ? pk->attr_g216 : sgn ? pk->attr_g2_s : pk->attr_g2), both16 ? 1 : sgn ? pk->s_bits : 0, pk->g2->dev16 ? 1 : 0,
+          (const rhip_fr*)omg, rand, c3);
   return RHIP_OK;
 }
 // decrypt (aw11/mod.rs:298-366 restated in SURVEY.md Appendix B.5): item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 1:
