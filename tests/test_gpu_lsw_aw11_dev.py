@@ -140,7 +140,13 @@ W2 = ("or", [("and", [("leaf", "E"), ("leaf", "A")]), ("and", [("leaf", "C"), ("
 W3 = ("and", [("and", [("leaf", "A"), ("leaf", "B")]), ("and", [("leaf", "C"), ("and", [("leaf", "D"), ("leaf", "E")])])])
 
 
-def test_aw11_device_encrypt_decrypt_match_oracle(eng):
+@pytest.mark.parametrize("attr_bits", [None, "8", "9", "14"], ids=["default-signed-10", "plain-8", "signed-9", "signed-14"])
+def test_aw11_device_encrypt_decrypt_match_oracle(eng, attr_bits, monkeypatch):
+    """the same bytes whatever window form the per-attribute tables take (read by rhip_aw11_pk_create: RABE_AW11_ATTR_BITS)"""
+    if attr_bits is None:
+        monkeypatch.delenv("RABE_AW11_ATTR_BITS", raising=False)
+    else:
+        monkeypatch.setenv("RABE_AW11_ATTR_BITS", attr_bits)
     rng = SeededRng(43)
     gk = sch.aw11_setup(rng)
     auth = [sch.aw11_authgen(gk, ["A", "B", "C"], rng), sch.aw11_authgen(gk, ["D", "E"], rng)]
