@@ -88,6 +88,7 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
  *   RABE_MEMBER_INLINE  run the decoding checks on the main stream before the kernels instead of beside them (A/B)
  *   RABE_G_WINDOW       signed window width of AC17's g table in this layer (default 20 = +0.44 GB per public key; 16 = none extra)
  *   RABE_NO_ARENA       every device buffer of a call its own hipMalloc again (diagnostics)
+ *   RABE_ARENA_MAX_GB   cap of the grow-only device block a lane keeps between packed calls (default 16)
  *   RABE_HOST_TIMING    stage timings on stderr
  * Results never depend on any of them. */
 int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,

@@ -136,11 +136,15 @@ Engine::ArenaScope::~ArenaScope() {
   if (--l.arena_depth) return;
   rhip_sync(l.ctx);                               // nothing of this call may still read the block when the next call reuses it
   if (l.side) rhip_sync(l.side);
-  if (l.arena_want > l.arena_bytes) {             // grow for the next call
+  // grow for the next call -- up to a cap (RABE_ARENA_MAX_GB, default 16): the block is never given back, so one huge batch must not
+  // pin a large part of the device for the life of the engine; beyond the cap the buffers that do not fit are plain allocations again
+  static const size_t cap = [] { const char* e = getenv("RABE_ARENA_MAX_GB"); const long g = e ? atol(e) : 16; return (size_t)(g > 0 ? g : 0) << 30; }();
+  size_t want = l.arena_want + l.arena_want / 4 + (1u << 20);
+  if (want > cap) want = cap;
+  if (want > l.arena_bytes) {
     if (l.arena) rhip_free(l.ctx, l.arena);
     l.arena = nullptr;
     l.arena_bytes = 0;
-    const size_t want = l.arena_want + l.arena_want / 4 + (1u << 20);
     void* p = nullptr;
     if (rhip_malloc(l.ctx, want, &p) == RHIP_OK) { l.arena = (uint8_t*)p; l.arena_bytes = want; }
   }
