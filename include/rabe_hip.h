@@ -377,6 +377,19 @@ int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
                                const uint32_t* dev_sk_leaf_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
                                const rhip_g2_lines* ct_e2_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
 
+/* ---- Level B: GHW11 outsourced decryption (src/schemes/ghw11/mod.rs:227-295) ----------------------
+ * Group arithmetic of n_items calls of ghw11::transform under ONE transform key.  tk_lines = rhip_g2_lines_prepare over the key's G2
+ * elements in the order k_z, l_z, k_x[0], k_x[1], ... : every Miller loop of the batch replays prepared lines (no G2 arithmetic).
+ * Selection entry e: the ciphertext row (sel_ct_row, relative to the item's first row), the key attribute (sel_tk_attr) and the leaf's
+ * coefficient w.  Item i: entries sel_start[i] .. + m_i - 1, pairs [pair_off[i], pair_off[i+1]) with m_i + 2 of them.
+ *   out[i] = t = e(c1, k_z) / ( prod_e e(w_e D_e, K_e) * e(sum_e w_e C_e, l_z) )   as ONE product of m_i + 2 Miller values and one
+ * final exponentiation (the factors that share l_z collapse into one pairing of a multi-scalar sum). */
+int32_t rhip_ghw11_transform_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel,
+                                   const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                                   const uint32_t* dev_sel_ct_row, const uint32_t* dev_sel_tk_attr, const rhip_fr* dev_sel_coeff,
+                                   const rhip_g1* dev_ct_c1 /*[n_items]*/, const rhip_g1* dev_ct_c /*[rows]: ci*/, const rhip_g1* dev_ct_d /*[rows]: di*/,
+                                   const uint32_t* dev_ct_row_off /*[n_items+1]*/, const rhip_g2_lines* tk_lines, rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- Level B: AW11 multi-authority CP-ABE (src/schemes/aw11/mod.rs) -----------------------------------------------
  * rhip_aw11_pk: gk (g1, g2), the constant e(g1, g2) and, for each of the n_attrs attributes of the authorities in play,
  * (egg_alpha_x, g2 * y_x) (Aw11PublicKey.attr, :56-61) as window tables.  leaf_attr[leaf] (per policy leaf, beside the

@@ -185,6 +185,13 @@ int32_t rabe_ghw11_encrypt(rabe_host* h, const void* pk, const char* policy, int
 int32_t rabe_ghw11_transform(rabe_host* h, const void* ct, const void* tk, void** tct);
 /* n independent transforms in one launch set; status[i] = 0 ok / -1 (tk i does not satisfy ct i; tcts[i] = NULL) */
 int32_t rabe_ghw11_transform_batch(rabe_host* h, size_t n, const void* const* cts, const void* const* tks, int32_t* status, void** tcts);
+/* The outsourced half as a service: n_items Ghw11Ciphertext records in one blob (+ n_items + 1 offsets, ct_len; bounds and --
+ * unless RABE_PACKED_TRUSTED -- group membership of every decoded element are checked, an item fails alone with status -1) transformed under
+ * ONE transform key.  tct_buf + 768 i receives item i's Ghw11TransformCiphertext record (c | t; zeros where status[i] = -1); returns 1 when
+ * tct_cap < 768 n_items.  Device-resident: every G2 argument is the key's, so all m + 2 Miller loops of an item replay the key's prepared
+ * lines (kept across calls) and the rows that share l_z collapse into one pairing of a multi-scalar sum (ghw11/mod.rs:227-295). */
+int32_t rabe_ghw11_transform_packed(rabe_host* h, const void* tk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
+                                    const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* tct_buf, size_t tct_cap);
 /* `data` of the reference's decrypt_out is the ciphertext's data field: pass the ciphertext object */
 int32_t rabe_ghw11_decrypt_out(rabe_host* h, const void* tct, const void* rk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_ghw11_decrypt_out_gt(rabe_host* h, const void* tct, const void* rk, uint8_t out_gt[384]);

@@ -750,9 +750,9 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_it
   qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
 }
 // term offsets of the MSM: item i has m_i = pair_off[i+1] - pair_off[i] - 1 terms starting at pair_off[i] - i
-__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_term_off(size_t n_items, const uint32_t* pair_off, uint32_t* term_off) {
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_term_off(size_t n_items, const uint32_t* pair_off, uint32_t* term_off, uint32_t other = 1) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= n_items) term_off[i] = pair_off[i] - (uint32_t)i;
+  if (i <= n_items) term_off[i] = pair_off[i] - other * (uint32_t)i;          // `other`: pairs of an item that are not terms of its sum
 }
 extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
                                           const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
@@ -785,6 +785,76 @@ extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
           (const G1JM*)w_part, pair_off, pl.P, pl.qref);
   return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e1, out);
+}
+
+// ------------------------------------------------------------------------------------------------ GHW11 outsourced decryption
+// transform (ghw11/mod.rs:227-295; SURVEY.md 8f-1: "decrypt-as-a-service"): every G2 argument is one of the TRANSFORM KEY's
+// (k_z, l_z, k_x per attribute) -- fixed for a batch served under one key, so all m + 2 Miller loops of an item replay prepared
+// lines and no G2 arithmetic happens at all.  Item i owns pairs [pair_off[i], pair_off[i+1]) = m_i + 2:
+//   s < m : P = -(w_e * D[ct row]),              lines of k_x[tk attr]   (block 2 + attr)        (e = sel_start[i] + s)
+//   m     : P = C1[i],                           lines of k_z            (block 0)
+//   m + 1 : P = sum_e (-w_e) * C[ct row]  (MSM), lines of l_z            (block 1)
+//   t_i = FE( prod of the Miller values ) = e(c1, k_z) / ( prod_e e(w_e D_e, K_e) * e(sum_e w_e C_e, l_z) )
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_ghw11_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
+                                                                  const uint32_t* sel_ct_row, const uint32_t* sel_tk_attr, const rhip_fr* sel_coeff,
+                                                                  const rhip_g1* ct_c1, const rhip_g1* ct_c, const rhip_g1* ct_d, const uint32_t* ct_row_off,
+                                                                  const uint8_t* line_inf, G1M* P, uint32_t* qref, G1M* terms) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t t, item;
+  bool active;
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+  const uint32_t j = (uint32_t)(t - pair_off[item]);
+  const uint32_t m = pair_off[item + 1] - pair_off[item] - 2;
+  G1Aff base = aff_inf<Fp>();
+  uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t row = 0, line = 1;
+  if (j < m) {
+    const uint32_t e = sel_start[item] + j;
+    row = ct_row_off[item] + sel_ct_row[e];
+    base = load_g1(ct_d[row].l);
+    ld_scalar(k, sel_coeff + e);
+    line = 2 + sel_tk_attr[e];
+  } else if (j == m) {
+    base = load_g1(ct_c1[item].l);
+    line = 0;
+  }
+  bool p_inf;
+  scale_and_store(lds, active && j <= m, base, k, j < m, P + t, &p_inf);
+  if (!active) return;
+  if (j > m) { qref[t] = line_inf[1] ? RHIP_Q_SKIP : 1u; return; }          // P comes from k_msm_finish_g1 (which may turn the pair into a skip)
+  if (j < m) st_g1_q(terms + (t - 2 * item), load_g1(ct_c[row].l));
+  qref[t] = (p_inf || line_inf[line]) ? RHIP_Q_SKIP : line;
+}
+extern "C" int32_t rhip_ghw11_transform_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                              const uint32_t* sel_start, const uint32_t* sel_ct_row, const uint32_t* sel_tk_attr, const rhip_fr* sel_coeff,
+                                              const rhip_g1* ct_c1, const rhip_g1* ct_c, const rhip_g1* ct_d, const uint32_t* ct_row_off,
+                                              const rhip_g2_lines* tk_lines, rhip_gt* out) {
+  NEED(ctx);
+  if (!n_items) return RHIP_OK;
+  if (!total_pairs || !pair_off || !tk_lines || max_pairs < 2 || total_pairs < 2 * n_items) return RHIP_ERR_ARG;
+  PairLists pl;
+  int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
+  if (rc) return rc;
+  const size_t total_terms = total_pairs - 2 * n_items;
+  void *w_terms = nullptr, *w_masks = nullptr, *w_part = nullptr, *w_off = nullptr;
+  rc = rhip_ensure_work(ctx, 4, (total_terms ? total_terms : 1) * sizeof(G1M), &w_terms);
+  if (!rc) rc = rhip_ensure_work(ctx, 5, (n_sel ? n_sel : 1) * 16 * sizeof(uint32_t), &w_masks);
+  uint32_t L, C;
+  choose_msm_chunks(ctx, n_items, max_pairs - 2, &L, &C);
+  if (!rc) rc = rhip_ensure_work(ctx, 6, n_items * L * sizeof(G1JM), &w_part);
+  if (!rc) rc = rhip_ensure_work(ctx, 7, (n_items + 1) * sizeof(uint32_t), &w_off);
+  if (rc) return rc;
+  if (n_sel) KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
+  KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off, 2u);
+  const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
+  KLAUNCH(ctx, "k_ghw11_pairs", k_ghw11_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, ppi, sel_start, sel_ct_row, sel_tk_attr, sel_coeff, ct_c1, ct_c, ct_d, ct_row_off, (const uint8_t*)tk_lines->q_inf, pl.P,
+          pl.qref, (G1M*)w_terms);
+  KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
+          (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
+  KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
+          (const G1JM*)w_part, pair_off, pl.P, pl.qref);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, (const LineM*)tk_lines->lines, (const rhip_gt*)nullptr, out);
 }
 
 // ------------------------------------------------------------------------------------------------ AW11 multi-authority CP-ABE

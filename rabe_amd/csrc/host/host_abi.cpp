@@ -1001,6 +1001,17 @@ int32_t rabe_ghw11_transform_batch(rabe_host* h, size_t n, const void* const* ct
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_ghw11_transform_packed(rabe_host* h, const void* tk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                    int32_t* status, uint8_t* tct_buf, size_t tct_cap) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!ghw11::transform_packed(h->eng, *(const ghw11::Ghw11TransformKey*)tk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status,
+                               tct_buf, tct_cap, &errors))
+    return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
 int32_t rabe_ghw11_decrypt_out(rabe_host* h, const void* tct, const void* rk, const void* ct, uint8_t** plaintext, size_t* len) {
   GUARD_BEGIN
   return give_bytes(ghw11::decrypt_out(h->eng, *(const ghw11::Ghw11TransformCiphertext*)tct, *(const ghw11::Ghw11RetrieveKey*)rk,

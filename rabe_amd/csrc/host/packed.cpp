@@ -1074,5 +1074,198 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
 }
 }  // namespace aw11
 
+// ================================================================================================================= GHW11
+namespace ghw11 {
+namespace {
+void* make_tk_lines(Engine& eng, const void* arg) {          // arg: k_z | l_z | k_x[0] | k_x[1] ... (128 B each)
+  const std::string& pts = *(const std::string*)arg;
+  DBuf d(&eng, pts.data(), pts.size());
+  rhip_g2_lines* lines = nullptr;
+  eng.check(rhip_g2_lines_prepare(eng.ctx(), pts.size() / 128, d.as<rhip_g2>(), &lines), "rhip_g2_lines_prepare");
+  return lines;
+}
+void destroy_tk_lines(void* h) { rhip_g2_lines_destroy((rhip_g2_lines*)h); }
+}  // namespace
+
+// n calls of ghw11::transform (ghw11/mod.rs:227-295) under ONE transform key -- the outsourced half of a decryption, what a server
+// holding users' transform keys runs.  Records in: Ghw11Ciphertext (policy, c, c1, rows (name, c_i, d_i), sealed
+// data); records out: Ghw11TransformCiphertext = c | t, 768 bytes per item at out_buf + 768 i (zeros where status[i] = -1).
+// Per distinct policy: traverse_policy, calc_pruned, and per pruned (name, name_col) the FIRST coefficient named name_col, the FIRST
+// key attribute named `name`, the FIRST ciphertext row named name_col (:259-281); a missing one is the reference's unwrap panic.
+// Every G2 argument is the key's: the batch replays prepared lines (kept across calls) and does no G2 arithmetic.
+bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                      int32_t* status, uint8_t* out_buf, size_t out_cap, std::vector<std::string>* errors) {
+  Timer tm("ghw11::transform_packed");
+  Engine::ArenaScope arena(eng);
+  errors->assign(n, "");
+  if (!ct_off || (n && !ct_blob) || !status) throw RabeError("ghw11::transform_packed: null input");
+  if (!out_buf || out_cap < n * 768) return false;
+  (void)check_offsets(n, ct_off, ct_len, errors);
+  std::vector<std::string> attr;
+  for (const auto& a : tk.attr_key_z) attr.push_back(a.string);
+  struct Plan {
+    std::shared_ptr<const FlatPolicy> flat; std::string err;
+    struct E { std::string name_col; uint32_t tk_attr; Fr w; uint32_t std_ct_row; };
+    std::vector<E> ent;
+  };
+  std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
+  std::mutex plans_mu;
+  auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
+    std::lock_guard<std::mutex> g(plans_mu);
+    auto key = std::make_pair((int)lang, text);
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second;
+    auto pl = std::make_shared<Plan>();
+    try {
+      pl->flat = flat_policy(text, lang);
+      const auto& names = pl->flat->leaf_name_col;
+      if (!traverse_policy(attr, pl->flat->tree)) throw RabeError("Error: attributes in tk do not match policy in ct.");
+      PrunedList list;
+      if (!calc_pruned(attr, pl->flat->tree, &list)) throw RabeError("Error in Ghw11/decrypt: attributes in sk do not match policy in ct.");
+      for (const auto& cur : list) {
+        size_t a = 0, co = 0;
+        while (a < tk.attr_key_z.size() && tk.attr_key_z[a].string != cur.first) a++;
+        while (co < names.size() && names[co] != cur.second) co++;
+        if (a == tk.attr_key_z.size() || co == names.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+        pl->ent.push_back({cur.second, (uint32_t)a, pl->flat->leaf_coeff[co], (uint32_t)co});
+      }
+    } catch (const RabeError& ex) {
+      pl->err = ex.what();
+      if (pl->err.empty()) pl->err = "policy error";
+    } catch (const std::runtime_error& ex) {
+      pl->err = ex.what();
+    }
+    plans[key] = pl;
+    return pl;
+  };
+  struct View { const uint8_t* c; const uint8_t* c1; uint32_t rows; std::vector<const uint8_t*> ci, di; std::shared_ptr<Plan> plan;
+                std::vector<uint32_t> ct_row; bool standard; };
+  std::vector<View> v(n);
+  parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
+    try {
+      Cursor r{ct_blob + ct_off[i], ct_blob + ct_off[i + 1]};
+      auto pol = r.str();
+      const PolicyLanguage lang = *r.raw(1) ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      v[i].c = r.raw(384);
+      v[i].c1 = r.raw(64);
+      const uint32_t rows = r.u32();
+      if ((size_t)rows * 132 > (size_t)(r.end - r.p)) throw RabeError("deserialize: truncated input");
+      v[i].rows = rows;
+      v[i].ci.resize(rows);
+      v[i].di.resize(rows);
+      std::vector<std::pair<const char*, uint32_t>> names(rows);
+      for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].ci[y] = r.raw(64); v[i].di[y] = r.raw(64); }
+      const uint32_t dl = r.u32();
+      (void)r.raw(dl);                                   // the sealed data stays with the client (decrypt_out)
+      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      if (!pl->err.empty()) throw RabeError(pl->err);
+      v[i].plan = pl;
+      const auto& std_names = pl->flat->leaf_name_col;
+      bool standard = rows == std_names.size();
+      for (uint32_t y = 0; y < rows && standard; y++) standard = same(names[y], std_names[y]);
+      v[i].standard = standard;
+      if (!standard) {
+        for (const auto& e : pl->ent) {
+          uint32_t y = 0;
+          while (y < rows && !same(names[y], e.name_col)) y++;
+          if (y == rows) throw RabeError("called `Option::unwrap()` on a `None` value");
+          v[i].ct_row.push_back(y);
+        }
+      }
+    } catch (const RabeError& ex) {
+      (*errors)[i] = ex.what();
+      if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
+    }
+  });
+  tm.lap("parse + plan");
+  std::vector<size_t> live;
+  std::vector<uint32_t> row_off{0}, pair_off{0}, sel_start, sel_ct, sel_tk;
+  std::vector<Fr> sel_w;
+  std::map<const Plan*, uint32_t> shared_start;
+  size_t max_pairs = 2;
+  for (size_t i = 0; i < n; i++) {
+    if (!(*errors)[i].empty()) continue;
+    live.push_back(i);
+    row_off.push_back(row_off.back() + v[i].rows);
+    const Plan& pl = *v[i].plan;
+    if (v[i].standard) {
+      auto it = shared_start.find(&pl);
+      if (it == shared_start.end()) {
+        it = shared_start.insert({&pl, (uint32_t)sel_ct.size()}).first;
+        for (const auto& e : pl.ent) { sel_ct.push_back(e.std_ct_row); sel_tk.push_back(e.tk_attr); sel_w.push_back(e.w); }
+      }
+      sel_start.push_back(it->second);
+    } else {
+      sel_start.push_back((uint32_t)sel_ct.size());
+      for (size_t e = 0; e < pl.ent.size(); e++) { sel_ct.push_back(v[i].ct_row[e]); sel_tk.push_back(pl.ent[e].tk_attr); sel_w.push_back(pl.ent[e].w); }
+    }
+    const uint32_t m = (uint32_t)pl.ent.size();
+    pair_off.push_back(pair_off.back() + m + 2);
+    if ((size_t)m + 2 > max_pairs) max_pairs = m + 2;
+  }
+  const size_t m_items = live.size();
+  uint8_t* h_out = nullptr;
+  if (m_items) {
+    const size_t total = row_off[m_items];
+    uint8_t* h_l = eng.pinned(1, total * 128 + 4);
+    uint8_t* h_x = eng.pinned(2, m_items * (64 + 384 + 384));
+    parallel_for(m_items, [&](size_t j) {
+      const View& w = v[live[j]];
+      memcpy(h_x + 64 * j, w.c1, 64);
+      memcpy(h_x + m_items * 64 + 384 * j, w.c, 384);
+      for (uint32_t y = 0; y < w.rows; y++) {
+        memcpy(h_l + (size_t)(row_off[j] + y) * 64, w.ci[y], 64);
+        memcpy(h_l + total * 64 + (size_t)(row_off[j] + y) * 64, w.di[y], 64);
+      }
+    });
+    tm.lap("pack");
+    rhip_ctx* cx = eng.ctx();
+    std::string key((const char*)tk.k_z.data(), 128);
+    key.append((const char*)tk.l_z.data(), 128);
+    for (const auto& a : tk.attr_key_z) key.append((const char*)a.k_x.data(), 128);
+    rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("ghw11_tk_lines", key, make_tk_lines, &key, destroy_tk_lines, 4);
+    DBuf d_c1(&eng, m_items * 64), d_c(&eng, m_items * 384), d_ci(&eng, total * 64 + 4), d_di(&eng, total * 64 + 4), d_row_off = up32(eng, row_off),
+        d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_tk = up32(eng, sel_tk),
+        d_sel_w = up_bytes(eng, flatten_fr(sel_w)), d_out(&eng, m_items * 384);
+    eng.check(rhip_upload_async(cx, d_c1.ptr(), h_x, m_items * 64), "upload");
+    eng.check(rhip_upload_async(cx, d_ci.ptr(), h_l, total * 64), "upload");
+    eng.check(rhip_upload_async(cx, d_di.ptr(), h_l + total * 64, total * 64), "upload");
+    std::unique_ptr<MemberChecks> mc;
+    if (!trusted) {
+      eng.check(rhip_upload_async(cx, d_c.ptr(), h_x + m_items * 64, m_items * 384), "upload");
+      mc.reset(new MemberChecks(eng));
+      mc->add(1, d_c1.ptr(), m_items); mc->add(1, d_ci.ptr(), total, d_row_off.as<uint32_t>(), m_items);
+      mc->add(1, d_di.ptr(), total, d_row_off.as<uint32_t>(), m_items); mc->add(3, d_c.ptr(), m_items);
+    }
+    int32_t rc = rhip_ghw11_transform_batch(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
+                                            d_sel_ct.as<uint32_t>(), d_sel_tk.as<uint32_t>(), d_sel_w.as<rhip_fr>(), d_c1.as<rhip_g1>(), d_ci.as<rhip_g1>(),
+                                            d_di.as<rhip_g1>(), d_row_off.as<uint32_t>(), lines, d_out.as<rhip_gt>());
+    h_out = h_x + m_items * 448;
+    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
+    if (rc == RHIP_OK) rc = rhip_sync(cx);
+    eng.check(rc, "rhip_ghw11_transform_batch");
+    if (mc) {
+      mc->collect();
+      const auto &ok_c1 = mc->ok(0), &ok_ci = mc->ok(1), &ok_di = mc->ok(2), &ok_c = mc->ok(3);
+      for (size_t j = 0; j < m_items; j++)
+        if (!ok_c1[j] || !ok_ci[j] || !ok_di[j] || !ok_c[j]) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
+    }
+  }
+  tm.lap(trusted ? "device + copies" : "device + copies, membership beside");
+  std::vector<size_t> slot(n, (size_t)-1);
+  for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
+  parallel_for(n, [&](size_t i) {
+    uint8_t* o = out_buf + 768 * i;
+    if (!(*errors)[i].empty() || slot[i] == (size_t)-1) { memset(o, 0, 768); status[i] = -1; return; }
+    memcpy(o, v[i].c, 384);
+    memcpy(o + 384, h_out + 384 * slot[i], 384);
+    status[i] = 0;
+  });
+  tm.lap("assembly");
+  return true;
+}
+}  // namespace ghw11
+
 }  // namespace schemes
 }  // namespace rabe

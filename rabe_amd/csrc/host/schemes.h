@@ -166,6 +166,10 @@ Ghw11TransformCiphertext transform(Engine& eng, const Ghw11Ciphertext& ct, const
 // "decrypt-as-a-service": n independent transforms in one launch set; ok[i] false (with errors[i]) where tk i does not satisfy ct i
 std::vector<Ghw11TransformCiphertext> transform_batch(Engine& eng, const std::vector<const Ghw11Ciphertext*>& cts,
                                                       const std::vector<const Ghw11TransformKey*>& tks, std::vector<std::string>* errors);
+// packed form (packed.cpp): n ciphertext records in one blob + offsets, ONE transform key; out_buf + 768 i = Ghw11TransformCiphertext
+// record (c | t) of item i, zeros where status[i] = -1.  The device-resident path: every Miller loop replays the key's prepared lines.
+bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                      int32_t* status, uint8_t* out_buf, size_t out_cap, std::vector<std::string>* errors);
 Gt decrypt_out_gt(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk);
 Bytes decrypt_out(Engine& eng, const Ghw11TransformCiphertext& pct, const Ghw11RetrieveKey& rk, const Bytes& data);
 }  // namespace ghw11

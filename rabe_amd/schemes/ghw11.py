@@ -56,3 +56,18 @@ def decrypt_out(host, tct, rk, ct):
 
 def decrypt_out_gt(host, tct, rk):
     return host.out_gt("rabe_ghw11_decrypt_out_gt", tct.ptr, rk.ptr)
+
+
+def transform_packed(host, tk, ct_blob, ct_off, trusted=False):
+    """n transforms under one transform key over a blob of serialized ciphertexts (rabe_ghw11_transform_packed).
+    Returns (tct: numpy uint8 [n, 768] -- row i = the Ghw11TransformCiphertext record c | t --, status: numpy int32 [n])."""
+    import numpy as np
+    from ..hostlib import PACKED_TRUSTED, _as_u8, _np_ptr
+    n = len(ct_off) - 1
+    ct = _as_u8(ct_blob)
+    co = np.ascontiguousarray(ct_off, dtype=np.uint64)
+    out = np.zeros((max(n, 1), 768), dtype=np.uint8)
+    status = np.zeros(max(n, 1), dtype=np.int32)
+    host.call("rabe_ghw11_transform_packed", tk.ptr, ctypes.c_size_t(n), _np_ptr(ct), ctypes.c_size_t(ct.size), _np_ptr(co),
+              ctypes.c_uint32(PACKED_TRUSTED if trusted else 0), _np_ptr(status), _np_ptr(out), ctypes.c_size_t(out.size))
+    return out[:n], status[:n]

@@ -36,7 +36,7 @@ def test_header_declares_the_expected_surface():
                  "rhip_lsw_keygen_batch", "rhip_lsw_decrypt_batch", "rhip_aw11_pk_create", "rhip_aw11_encrypt_batch", "rhip_aw11_decrypt_batch",
                  "rhip_g2_lines_prepare", "rhip_host_fr_pow", "rhip_host_g1_on_curve", "rhip_host_g2_on_curve",
                  # round 3: decoding checks (fast + by-order forms), packed entry points of every scheme, LSW negative leaves, pipelining hook
-                 "rhip_g2_in_subgroup", "rhip_g2_in_subgroup_by_order", "rhip_gt_is_member", "rhip_gt_is_member_by_order", "rhip_flags_all",
+                 "rhip_g2_in_subgroup", "rhip_g2_in_subgroup_by_order", "rhip_gt_is_member", "rhip_gt_is_member_by_order", "rhip_flags_all", "rhip_ghw11_transform_batch",
                  "rhip_host_g2_in_subgroup", "rhip_host_gt_is_member", "rhip_lsw_keygen_batch_signed", "rhip_ctx_release_before_final_exp",
                  "rabe_ac17_cp_encrypt_packed", "rabe_ac17_cp_decrypt_packed", "rabe_bsw_encrypt_packed", "rabe_bsw_decrypt_packed",
                  "rabe_lsw_keygen_packed", "rabe_lsw_decrypt_packed", "rabe_aw11_encrypt_packed", "rabe_aw11_decrypt_packed"]:

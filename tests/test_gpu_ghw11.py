@@ -121,3 +121,57 @@ def test_ghw11_transform_batch(host):
             assert batch[i].serialize() == single.serialize()
             assert ghw11.decrypt_out(host, batch[i], rk, cts[i]) == pts[i]
     assert all(batch[i] is not None for i in range(n) if who[i] == 0)
+
+
+def test_ghw11_transform_packed_equals_object_api(host):
+    """rabe_ghw11_transform_packed (device-resident: every Miller loop replays the transform key's prepared lines, the rows that share l_z
+    are one pairing of a multi-scalar sum) against the object API (general pairing jobs, every G2 argument walked): the same 768 bytes per
+    item; a policy the key does not satisfy, a tampered row, a truncated record and bad offsets fail their own item only."""
+    import numpy as np
+    rnd = random.Random(77)
+    pk, msk = ghw11.setup(host)
+    attrs = ["a%d" % i for i in range(14)]
+
+    def tree(ns):
+        if len(ns) == 1:
+            return '{"name": "%s"}' % ns[0]
+        h = rnd.randrange(1, len(ns))
+        return '{"name": "%s", "children": [%s, %s]}' % (rnd.choice(["and", "or"]), tree(ns[:h]), tree(ns[h:]))
+    tk, rk = ghw11.tkgen(host, ghw11.keygen(host, pk, msk, attrs[:11]))                    # a3 .. never needs a11+; some policies do
+    pols = [tree(rnd.sample(attrs[:11], 7)) for _ in range(4)] + ['{"name": "and", "children": [{"name": "a1"}, {"name": "a13"}]}',
+                                                                  '{"name": "a2"}']
+    n = 26
+    pts = [PLAINTEXT + bytes([i]) for i in range(n)]
+    cts = [ghw11.encrypt(host, pk, pols[i % len(pols)], hl.JSON_POLICY, pts[i]) for i in range(n)]
+    recs = [c.serialize() for c in cts]
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    blob = b"".join(recs)
+    for trusted in (False, True):
+        out, status = ghw11.transform_packed(host, tk, blob, off, trusted=trusted)
+        for i in range(n):
+            if i % len(pols) == 4:                                  # needs a13: the key does not satisfy the policy
+                assert status[i] == -1 and not out[i].any()
+                continue
+            assert status[i] == 0
+            single = ghw11.transform(host, cts[i], tk)
+            assert out[i].tobytes() == single.serialize(), i
+            assert ghw11.decrypt_out(host, hl.Obj.deserialize("ghw11_tct", out[i].tobytes()), rk, cts[i]) == pts[i]
+    # damage: item 1's first row point off its curve (checked mode), item 7 truncated by its offsets, item 12 with non-monotone offsets
+    raw = bytearray(blob)
+    rec = int(off[1])
+    pl = int.from_bytes(raw[rec:rec + 4], "little")
+    first = rec + 4 + pl + 1 + 384 + 64 + 4
+    nl = int.from_bytes(raw[first:first + 4], "little")
+    raw[first + 4 + nl] ^= 1
+    o = off.copy()
+    cut = bytes(raw[:int(off[8]) - 30]) + bytes(raw[int(off[8]):])
+    o[8:] -= 30
+    o2 = o.copy()
+    o2[13] = np.uint64(int(o2[12]) - 4)
+    out, status = ghw11.transform_packed(host, tk, cut, o2)
+    want = [0 if i % len(pols) != 4 else -1 for i in range(n)]
+    for i in (1, 7, 12, 13):
+        want[i] = -1
+    assert list(status) == want
+    good = ghw11.transform(host, cts[2], tk).serialize()
+    assert out[2].tobytes() == good
