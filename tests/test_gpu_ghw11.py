@@ -61,6 +61,9 @@ def test_ghw11_matches_golden(host):
         tct = ghw11.transform(host, ct, tk)
         g = hl.parse_obj("ghw11_tct", tct.serialize())
         assert g["t"] == hb(c["t"]) and g["c"] == hb(c["ct"]["c"])
+        rec = ct.serialize()                                         # the device-resident packed path against the same golden value
+        out, st = ghw11.transform_packed(host, tk, rec, [0, len(rec)])
+        assert st[0] == 0 and out[0].tobytes() == hb(c["ct"]["c"]) + hb(c["t"])
         assert ghw11.decrypt_out_gt(host, tct, rk) == hb(c["decrypted"]) == hb(c["msg"])
         assert ghw11.decrypt_out(host, tct, rk, ct) == PLAINTEXT
 
