@@ -77,6 +77,7 @@ jobs = {}
 jobs["miller_loop_multi, 14 pairs: 7 prepared + 7 walking (a bsw chunk with a prepared key)"] = count_multi([1, 0] * 7)
 jobs["miller_loop_multi, 14 walking pairs (bsw / lsw / aw11 chunk, nothing prepared)"] = count_multi([0] * 14)
 jobs["miller_loop_multi, 6 pairs: 3 prepared + 3 walking (an ac17 item with a prepared key)"] = count_multi([1, 0] * 3)
+jobs["miller_loop_multi, 14 prepared pairs (a ghw11 transform chunk: every G2 argument is the transform key's)"] = count_multi([1] * 14)
 jobs["miller_loop_multi, 6 walking pairs (an ac17 item, nothing prepared)"] = count_multi([0] * 6)
 jobs["miller_loop_multi, 2 walking pairs"] = count_multi([0, 0])
 jobs["miller_loop_multi, 1 walking pair"] = count_multi([0])
