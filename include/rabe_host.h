@@ -91,6 +91,12 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
  *   RABE_ARENA_MAX_GB   cap of the grow-only device block a lane keeps between packed calls (default 16)
  *   RABE_HOST_TIMING    stage timings on stderr
  * Results never depend on any of them. */
+/* A key authority issuing keys in bulk: n_items calls of ac17::cp_keygen (src/schemes/ac17/mod.rs:191-264) under one master key.  The
+ * attribute lists are given once (n_sets lists, list s = the next counts[s] entries of `attributes`), item i gets list item_set[i].
+ * sk_buf receives the Ac17CpSecretKey records (sk_off: n_items + 1 offsets, always filled; returns 1 when sk_cap is too small, before any
+ * randomness is drawn).  Items that share a list are one launch of the Level B keygen kernels; the master key's window tables are kept. */
+int32_t rabe_ac17_cp_keygen_packed(rabe_host* h, const void* msk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                   const uint32_t* item_set /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
                                     const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf,
                                     size_t pt_cap, uint64_t* pt_off /*[n_items+1]*/);

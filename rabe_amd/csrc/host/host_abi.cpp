@@ -466,6 +466,16 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
   }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
+int32_t rabe_ac17_cp_keygen_packed(rabe_host* h, const void* msk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                   const uint32_t* item_set, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets(n_sets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_sets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return ac17::cp_keygen_packed(h->eng, h->rng(), *(const ac17::Ac17MasterKey*)msk, sets, n_items, item_set, sk_buf, sk_cap, sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
 int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
                                     uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
   GUARD_BEGIN

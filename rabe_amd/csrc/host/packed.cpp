@@ -192,6 +192,151 @@ void open_all(size_t n, const std::vector<Sealed>& sealed, const std::vector<siz
 
 }  // namespace
 
+// ================================================================================================================= AC17 keygen
+namespace ac17 {
+namespace {
+struct MskTables { rhip_g1_table* g = nullptr; rhip_g2_table* h = nullptr; };
+void* make_msk_tables(Engine& eng, const void* arg) {
+  const Ac17MasterKey& msk = *(const Ac17MasterKey*)arg;
+  std::unique_ptr<MskTables> t(new MskTables());
+  eng.check(rhip_g1_table_create(eng.ctx(), (const rhip_g1*)msk.g.data(), &t->g), "rhip_g1_table_create");
+  int32_t rc = rhip_g1_table_add_w16(eng.ctx(), t->g);
+  if (!rc) rc = rhip_g2_table_create(eng.ctx(), (const rhip_g2*)msk.h.data(), &t->h);
+  if (!rc) rc = rhip_g2_table_add_w16(eng.ctx(), t->h);
+  if (rc) { rhip_g1_table_destroy(t->g); if (t->h) rhip_g2_table_destroy(t->h); eng.check(rc, "master-key tables"); }
+  return t.release();
+}
+void destroy_msk_tables(void* h) {
+  MskTables* t = (MskTables*)h;
+  rhip_g1_table_destroy(t->g);
+  rhip_g2_table_destroy(t->h);
+  delete t;
+}
+}  // namespace
+
+// n calls of ac17::cp_keygen (ac17/mod.rs:191-264) under one master key -- a key authority issuing keys in bulk.  Item i gets the
+// attribute list sets[item_set[i]]; draw order per item as in the reference: r0, r1, sigma per attribute (list order), sigma'.
+// Record = Ac17CpSecretKey: attribute strings, k_0[3], rows (name, k[3]), k_p[3].  Items that share a list run as one launch of the
+// Level B kernels (the label hashes of a list are computed once); the window tables of the master key's g and h are kept across calls.
+bool cp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
+                      const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("ac17::cp_keygen_packed");
+  Engine::ArenaScope arena(eng);
+  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
+  if (n && (!item_set || !out_off)) throw RabeError("cp_keygen_packed: null input");
+  std::vector<size_t> fixed(sets.size());
+  for (size_t s = 0; s < sets.size(); s++) {
+    if (sets[s].empty()) throw RabeError("empty attributes!");
+    fixed[s] = 4 + 4 + 384 + 4 + 4 + 192;
+    for (const auto& a : sets[s]) fixed[s] += (4 + a.size()) + (4 + a.size() + 4 + 192);
+  }
+  for (size_t i = 0; i < n; i++) if (item_set[i] >= sets.size()) throw RabeError("cp_keygen_packed: item_set out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_set[i]];
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  // items grouped by attribute list (stable: the order inside a group is the item order)
+  std::vector<std::vector<size_t>> members(sets.size());
+  for (size_t i = 0; i < n; i++) members[item_set[i]].push_back(i);
+  std::vector<size_t> slot(n), sig_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) sig_off[i + 1] = sig_off[i] + sets[item_set[i]].size();
+  // randomness, item after item: r0, r1, sigma_y ..., sigma'
+  uint8_t* h_r = eng.pinned(0, n * 96 + sig_off[n] * 32 + 32);
+  uint8_t* h_sp = h_r + n * 64;
+  uint8_t* h_sig = h_sp + n * 32;
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    Fr r0 = r.next_fr(), r1 = r.next_fr();
+    memcpy(h_r + 64 * i, r0.l, 32);
+    memcpy(h_r + 64 * i + 32, r1.l, 32);
+    for (size_t y = sig_off[i]; y < sig_off[i + 1]; y++) { Fr sg = r.next_fr(); memcpy(h_sig + 32 * y, sg.l, 32); }
+    Fr sp = r.next_fr();
+    memcpy(h_sp + 32 * i, sp.l, 32);
+  });
+  tm.lap("draws");
+  const MskTables* tb;
+  {
+    std::string key((const char*)msk.g.data(), 64);
+    key.append((const char*)msk.h.data(), 128);
+    tb = (const MskTables*)eng.aux("ac17_msk_tables", key, make_msk_tables, &msk, destroy_msk_tables, 4);
+  }
+  std::vector<Fr> H01;
+  for (int l = 0; l < 3; l++)
+    for (int t = 0; t < 2; t++) H01.push_back(sha3_hash_fr(std::string("01") + std::to_string(l) + std::to_string(t)));
+  std::vector<Fr> a_inv(2);
+  for (int t = 0; t < 2; t++)
+    if (!fr_inv(msk.a[t], &a_inv[t])) throw std::runtime_error("called `Option::unwrap()` on a `None` value (Fr::inverse of zero)");
+  DBuf dgk = up_bytes(eng, flatten(msk.g_k)), da = up_bytes(eng, flatten_fr(a_inv)), db = up_bytes(eng, flatten_fr(msk.b)), dH01 = up_bytes(eng, flatten_fr(H01));
+  rhip_ctx* cx = eng.ctx();
+  // per group: gather its items' randomness into contiguous staging, launch, fetch
+  struct Group { size_t first_out; size_t cnt; size_t n_attr; };
+  std::vector<Group> groups(sets.size());
+  size_t tot_items = 0, tot_rows = 0;
+  for (size_t s = 0; s < sets.size(); s++) { groups[s] = {tot_items, members[s].size(), sets[s].size()}; tot_items += members[s].size(); tot_rows += members[s].size() * sets[s].size(); }
+  uint8_t* g_r = eng.pinned(1, tot_items * 96 + tot_rows * 32 + 32);              // r | sigma' | sigma, group-major
+  uint8_t* g_sp = g_r + tot_items * 64;
+  uint8_t* g_sig = g_sp + tot_items * 32;
+  std::vector<size_t> grp_row0(sets.size() + 1, 0);
+  for (size_t s = 0; s < sets.size(); s++) grp_row0[s + 1] = grp_row0[s] + members[s].size() * sets[s].size();
+  for (size_t s = 0; s < sets.size(); s++)
+    parallel_for(members[s].size(), [&](size_t q) {
+      const size_t i = members[s][q], o = groups[s].first_out + q;
+      slot[i] = o;
+      memcpy(g_r + 64 * o, h_r + 64 * i, 64);
+      memcpy(g_sp + 32 * o, h_sp + 32 * i, 32);
+      memcpy(g_sig + 32 * (grp_row0[s] + q * sets[s].size()), h_sig + 32 * sig_off[i], 32 * sets[s].size());
+    });
+  DBuf d_r(&eng, tot_items * 64), d_sp(&eng, tot_items * 32), d_sig(&eng, tot_rows * 32 + 4), d_k0(&eng, tot_items * 384), d_k(&eng, tot_rows * 192 + 4),
+      d_kp(&eng, tot_items * 192);
+  eng.check(rhip_upload_async(cx, d_r.ptr(), g_r, tot_items * 64), "upload");
+  eng.check(rhip_upload_async(cx, d_sp.ptr(), g_sp, tot_items * 32), "upload");
+  eng.check(rhip_upload_async(cx, d_sig.ptr(), g_sig, tot_rows * 32), "upload");
+  std::vector<DBuf> dH;
+  for (size_t s = 0; s < sets.size(); s++) {
+    if (members[s].empty()) { dH.emplace_back(); continue; }
+    std::vector<Fr> H;
+    for (const auto& attr : sets[s])
+      for (int l = 0; l < 3; l++)
+        for (int t = 0; t < 2; t++) H.push_back(sha3_hash_fr(attr + std::to_string(l) + std::to_string(t)));
+    dH.push_back(up_bytes(eng, flatten_fr(H)));
+    const Group& g = groups[s];
+    eng.check(rhip_ac17_cp_keygen_batch(cx, tb->g, tb->h, dgk.as<rhip_g1>(), da.as<rhip_fr>(), db.as<rhip_fr>(), g.cnt, g.n_attr, dH.back().as<rhip_fr>(),
+                                        dH01.as<rhip_fr>(), (const rhip_fr*)(d_r.as<uint8_t>() + 64 * g.first_out),
+                                        (const rhip_fr*)(d_sig.as<uint8_t>() + 32 * grp_row0[s]), (const rhip_fr*)(d_sp.as<uint8_t>() + 32 * g.first_out),
+                                        (rhip_g2*)(d_k0.as<uint8_t>() + 384 * g.first_out), (rhip_g1*)(d_k.as<uint8_t>() + 192 * grp_row0[s]),
+                                        (rhip_g1*)(d_kp.as<uint8_t>() + 192 * g.first_out)), "rhip_ac17_cp_keygen_batch");
+  }
+  uint8_t* h_k = eng.pinned(2, tot_rows * 192 + tot_items * (384 + 192) + 4);
+  uint8_t* h_k0 = h_k + tot_rows * 192;
+  uint8_t* h_kp = h_k0 + tot_items * 384;
+  eng.check(rhip_download_async(cx, h_k, d_k.ptr(), tot_rows * 192), "download");
+  eng.check(rhip_download_async(cx, h_k0, d_k0.ptr(), tot_items * 384), "download");
+  eng.check(rhip_download_async(cx, h_kp, d_kp.ptr(), tot_items * 192), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const size_t s = item_set[i], o = slot[i], q = o - groups[s].first_out;
+    const auto& attrs = sets[s];
+    uint8_t* w = out_buf + out_off[i];
+    put_u32(w, (uint32_t)attrs.size()); w += 4;
+    for (const auto& a : attrs) { put_u32(w, (uint32_t)a.size()); w += 4; memcpy(w, a.data(), a.size()); w += a.size(); }
+    put_u32(w, 3); w += 4;
+    memcpy(w, h_k0 + 384 * o, 384); w += 384;
+    put_u32(w, (uint32_t)attrs.size()); w += 4;
+    const uint8_t* rows = h_k + 192 * (grp_row0[s] + q * attrs.size());
+    for (size_t y = 0; y < attrs.size(); y++) {
+      put_u32(w, (uint32_t)attrs[y].size()); w += 4;
+      memcpy(w, attrs[y].data(), attrs[y].size()); w += attrs[y].size();
+      put_u32(w, 3); w += 4;
+      memcpy(w, rows + 192 * y, 192); w += 192;
+    }
+    put_u32(w, 3); w += 4;
+    memcpy(w, h_kp + 192 * o, 192);
+  });
+  tm.lap("assembly");
+  return true;
+}
+}  // namespace ac17
+
 // ================================================================================================================= BSW
 namespace bsw {
 namespace {

@@ -37,6 +37,9 @@ Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext&
 std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies,
                                                const std::vector<Bytes>& plaintexts, PolicyLanguage language);
 typedef schemes::DecryptResult DecryptResult;
+// n keys under one master key in one call (packed.cpp): item i gets the attribute list sets[item_set[i]]; records = Ac17CpSecretKey
+bool cp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
+                      const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 // packed forms: n ciphertexts = one blob of canonical records + offsets (schemes.cpp: "packed batches")
 bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                        const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);

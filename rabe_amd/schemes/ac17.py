@@ -134,6 +134,27 @@ def cp_encrypt_packed(host, pk, policies, item_policy, pt_blob, pt_off, language
     return buf[:int(co[n])], co
 
 
+def cp_keygen_packed(host, msk, attr_sets, item_set, out=None):
+    """n keys under one master key (rabe_ac17_cp_keygen_packed): attr_sets = distinct attribute lists, item_set[i] indexes them.
+    Returns (sk_blob: numpy uint8 view of the Ac17CpSecretKey records, sk_off: numpy uint64 [n+1])."""
+    import numpy as np
+    n = len(item_set)
+    flat = [a for s_ in attr_sets for a in s_]
+    arr, _ = _strs(flat)
+    counts = (ctypes.c_size_t * max(len(attr_sets), 1))(*[len(s_) for s_ in attr_sets])
+    it = np.ascontiguousarray(item_set, dtype=np.uint32)
+    so = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_ac17_cp_keygen_packed(host.h, msk.ptr, arr, counts, ctypes.c_size_t(len(attr_sets)), ctypes.c_size_t(n), _np_ptr(it),
+                                                 _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(so))
+        if rc != 1:
+            break
+        buf = np.empty(int(so[n]), dtype=np.uint8)
+    hostlib_check(rc, host)
+    return buf[:int(so[n])], so
+
+
 PACKED_TRUSTED = 1
 
 

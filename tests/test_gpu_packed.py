@@ -114,3 +114,31 @@ def test_packed_decrypt_validates_offsets_and_membership(host):
     out, out_off, status = ac17.cp_decrypt_packed(host, sk, bytes(bad), ct_off)
     assert list(status) == [0, 0, 0, -1, 0]
     assert rec3 < cp_at
+
+
+def test_packed_keygen_equals_object_keygen_on_the_same_tape(host):
+    """rabe_ac17_cp_keygen_packed: n keys in one call (items that share an attribute list are one launch of the Level B keygen kernels) =
+    n calls of cp_keygen on the same randomness, byte for byte; the keys decrypt."""
+    pk, msk = ac17.setup(host)
+    sets = [["A", "B"], ["A", "B", "C", "D"], ["C"]]
+    item_set = [0, 1, 2, 1, 0, 1, 2, 0, 1]
+    n = len(item_set)
+    tape = [1000003 * (i + 11) + 7 for i in range(8 * n)]                   # r0, r1, sigma per attribute, sigma' per item
+    host.set_tape(tape)
+    objs = [ac17.cp_keygen(host, msk, sets[s]) for s in item_set]
+    host.set_tape(tape)
+    blob, off = ac17.cp_keygen_packed(host, msk, sets, item_set)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    ct = ac17.cp_encrypt(host, pk, '"A" and ("C" or "D")', b"bulk keys", hl.HUMAN_POLICY)
+    for i in (1, 3):
+        assert ac17.cp_decrypt(host, hl.Obj.deserialize("ac17_cp_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"bulk keys"
+    with pytest.raises(hl.RabeError):
+        ac17.cp_keygen_packed(host, msk, [["A"], []], [0, 1])               # `empty attributes!` (:199) fails the call
+    # a bulk run on OS randomness: 2000 keys over 50 attributes, every key opens a ciphertext under an AND of five of its attributes
+    attrs = ["a%d" % i for i in range(50)]
+    blob, off = ac17.cp_keygen_packed(host, msk, [attrs, attrs[:25]], np.arange(2000, dtype=np.uint32) % 2)
+    ct = ac17.cp_encrypt(host, pk, '"a1" and ("a7" and ("a13" and ("a19" and "a24")))', b"x" * 40, hl.HUMAN_POLICY)     # AC17: binary ANDs
+    for i in (0, 1, 1998, 1999):
+        assert ac17.cp_decrypt(host, hl.Obj.deserialize("ac17_cp_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"x" * 40
