@@ -213,6 +213,14 @@ void destroy_msk_tables(void* h) {
   delete t;
 }
 }  // namespace
+// window tables of a master key's g and h, built on first use and kept (cp_keygen, cp_keygen_packed)
+void msk_tables(Engine& eng, const Ac17MasterKey& msk, rhip_g1_table** g, rhip_g2_table** h) {
+  std::string key((const char*)msk.g.data(), 64);
+  key.append((const char*)msk.h.data(), 128);
+  const MskTables* tb = (const MskTables*)eng.aux("ac17_msk_tables", key, make_msk_tables, &msk, destroy_msk_tables, 4);
+  *g = tb->g;
+  *h = tb->h;
+}
 
 // n calls of ac17::cp_keygen (ac17/mod.rs:191-264) under one master key -- a key authority issuing keys in bulk.  Item i gets the
 // attribute list sets[item_set[i]]; draw order per item as in the reference: r0, r1, sigma per attribute (list order), sigma'.
@@ -253,12 +261,9 @@ bool cp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std
     memcpy(h_sp + 32 * i, sp.l, 32);
   });
   tm.lap("draws");
-  const MskTables* tb;
-  {
-    std::string key((const char*)msk.g.data(), 64);
-    key.append((const char*)msk.h.data(), 128);
-    tb = (const MskTables*)eng.aux("ac17_msk_tables", key, make_msk_tables, &msk, destroy_msk_tables, 4);
-  }
+  MskTables tables;
+  msk_tables(eng, msk, &tables.g, &tables.h);
+  const MskTables* tb = &tables;
   std::vector<Fr> H01;
   for (int l = 0; l < 3; l++)
     for (int t = 0; t < 2; t++) H01.push_back(sha3_hash_fr(std::string("01") + std::to_string(l) + std::to_string(t)));

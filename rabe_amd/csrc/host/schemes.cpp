@@ -654,8 +654,7 @@ Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
   std::vector<Fr> a_inv{must_inv(msk.a[0]), must_inv(msk.a[1])};
   rhip_g1_table* gt = nullptr;
   rhip_g2_table* ht = nullptr;
-  eng.check(rhip_g1_table_create(eng.ctx(), (const rhip_g1*)msk.g.data(), &gt), "rhip_g1_table_create");
-  eng.check(rhip_g2_table_create(eng.ctx(), (const rhip_g2*)msk.h.data(), &ht), "rhip_g2_table_create");
+  msk_tables(eng, msk, &gt, &ht);                // kept across calls (a key authority issues many keys under one master key)
   auto fgk = flatten(msk.g_k), fa = flatten_fr(a_inv), fb = flatten_fr(msk.b), fH = flatten_fr(H), fH01 = flatten_fr(H01), fr_ = flatten_fr(r),
        fs = flatten_fr(sigma), fsp = flatten_fr({sigma_p});
   DBuf dgk(&eng, fgk.data(), fgk.size()), da(&eng, fa.data(), fa.size()), db(&eng, fb.data(), fb.size()), dH(&eng, fH.data(), fH.size()),
@@ -667,8 +666,6 @@ Ac17CpSecretKey cp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
   std::vector<G2> k0;
   std::vector<G1> k, kp;
   if (rc == RHIP_OK) { k0 = fetch<128>(dk0, 3); k = fetch<64>(dk, n * 3); kp = fetch<64>(dkp, 3); }
-  rhip_g1_table_destroy(gt);
-  rhip_g2_table_destroy(ht);
   eng.check(rc, "rhip_ac17_cp_keygen_batch");
   Ac17CpSecretKey out;
   out.attr = attributes;

@@ -37,6 +37,7 @@ Bytes cp_decrypt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext&
 std::vector<Ac17CpCiphertext> cp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies,
                                                const std::vector<Bytes>& plaintexts, PolicyLanguage language);
 typedef schemes::DecryptResult DecryptResult;
+void msk_tables(Engine& eng, const Ac17MasterKey& msk, rhip_g1_table** g, rhip_g2_table** h);     // packed.cpp: cached window tables of msk.g / msk.h
 // n keys under one master key in one call (packed.cpp): item i gets the attribute list sets[item_set[i]]; records = Ac17CpSecretKey
 bool cp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
                       const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
