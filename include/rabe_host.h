@@ -106,6 +106,16 @@ int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, i
 int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct);
 int32_t rabe_ac17_kp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
+/* The KP pair packed (conventions of rabe_ac17_cp_{encrypt,decrypt}_packed; records = Ac17KpCiphertext): n_items encrypts, item i under the
+ * attribute list item_set[i] of the n_sets lists given once (list s = the next counts[s] entries of `attributes`); n_items decrypts
+ * with ONE key (whose policy is checked against every ciphertext's attribute list).  Same kernels as the CP pair
+ * (src/schemes/ac17/mod.rs:556-675). */
+int32_t rabe_ac17_kp_encrypt_packed(rabe_host* h, const void* pk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                    const uint32_t* item_set /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
+                                    uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
+int32_t rabe_ac17_kp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len,
+                                    const uint64_t* ct_off /*[n_items+1]*/, uint32_t flags, int32_t* status /*[n_items]*/, uint8_t* pt_buf, size_t pt_cap,
+                                    uint64_t* pt_off /*[n_items+1]*/);
 /* n independent kp_encrypt / kp_decrypt calls in one launch set; item i's attributes are the next counts[i] entries of `attributes` */
 int32_t rabe_ac17_kp_encrypt_batch(rabe_host* h, const void* pk, size_t n, const char* const* attributes, const size_t* counts,
                                    const uint8_t* const* datas, const size_t* lens, void** cts);

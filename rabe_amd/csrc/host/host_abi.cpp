@@ -491,6 +491,28 @@ int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_ac17_kp_encrypt_packed(rabe_host* h, const void* pk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                    const uint32_t* item_set, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
+  GUARD_BEGIN
+  if (!item_set || !pt_off || !ct_off) throw RabeError("kp_encrypt_packed: null input");
+  std::vector<std::vector<std::string>> sets(n_sets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_sets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return ac17::kp_encrypt_packed(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, sets, n_items, item_set, pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_ac17_kp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off,
+                                    uint32_t flags, int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  std::vector<std::string> errors;
+  if (!ac17::kp_decrypt_packed(h->eng, *(const ac17::Ac17KpSecretKey*)sk, n_items, ct_blob, ct_len, ct_off, (flags & RABE_PACKED_TRUSTED) != 0, status,
+                               pt_buf, pt_cap, pt_off, &errors))
+    return 1;
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+  GUARD_END(h)
+}
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                 const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
   GUARD_BEGIN

@@ -924,20 +924,48 @@ static std::shared_ptr<const EncPolicy> enc_policy(const std::string& pol, Polic
 }
 // out_buf / out_cap: caller-allocated (reusable) output; out_off: n + 1 caller-allocated entries, always filled.  Returns false
 // -- before any randomness is drawn or work is done -- when out_cap < out_off[n], the size the records need.
+// KP-ABE's encrypt (:556-616) is the same arithmetic with a table of plain label hashes: rows = the attribute list, no MSP columns.  The
+// record differs only in its head (the attribute strings instead of policy text + language).
+static std::shared_ptr<const EncPolicy> enc_attr_set(const std::vector<std::string>& attrs) {
+  auto e = std::make_shared<EncPolicy>();
+  e->msp.pi = attrs;
+  e->msp.m.assign(attrs.size(), std::vector<int8_t>{0});
+  for (const auto& a : attrs)
+    for (int l = 0; l < 3; l++)
+      for (int t = 0; t < 2; t++) e->tab.push_back(sha3_hash_fr(a + std::to_string(l) + std::to_string(t)));
+  e->fixed_bytes = 4 + 4 + 3 * 128 + 4 + 384 + 4;
+  for (const auto& a : attrs) e->fixed_bytes += (4 + a.size()) + (4 + a.size() + 4 + 3 * 64);
+  return e;
+}
+static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::shared_ptr<const EncPolicy>>& pols,
+                                const std::vector<std::string>* policies /* CP: the texts; KP: nullptr */, PolicyLanguage language, size_t n,
+                                const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                        const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
-  StageTimer tm("ac17::cp_encrypt_packed");
+  std::vector<std::shared_ptr<const EncPolicy>> pols;
+  for (const auto& pol : policies) pols.push_back(enc_policy(pol, language));
+  return encrypt_packed_core(eng, rng, pk, pols, &policies, language, n, item_policy, pt_blob, pt_off, out_buf, out_cap, out_off);
+}
+// n calls of ac17::kp_encrypt: item i is encrypted under the attribute list sets[item_set[i]]; records = Ac17KpCiphertext
+bool kp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set,
+                       const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  std::vector<std::shared_ptr<const EncPolicy>> pols;
+  for (const auto& a : sets) pols.push_back(enc_attr_set(a));
+  return encrypt_packed_core(eng, rng, pk, pols, nullptr, PolicyLanguage::JsonPolicy, n, item_set, pt_blob, pt_off, out_buf, out_cap, out_off);
+}
+static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::shared_ptr<const EncPolicy>>& pols,
+                                const std::vector<std::string>* policies, PolicyLanguage language, size_t n,
+                                const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  StageTimer tm(policies ? "ac17::cp_encrypt_packed" : "ac17::kp_encrypt_packed");
   Engine::ArenaScope arena(eng);
   if (pk.h_a.size() != 3 || pk.e_gh_ka.size() != 2) throw RabeError("malformed Ac17PublicKey");
-  std::vector<std::shared_ptr<const EncPolicy>> pols;
   std::vector<uint32_t> a_off{0};
   std::vector<Fr> A;
-  for (const auto& pol : policies) {
-    pols.push_back(enc_policy(pol, language));
-    A.insert(A.end(), pols.back()->tab.begin(), pols.back()->tab.end());
-    a_off.push_back(a_off.back() + (uint32_t)pols.back()->msp.m.size());
+  for (const auto& e : pols) {
+    A.insert(A.end(), e->tab.begin(), e->tab.end());
+    a_off.push_back(a_off.back() + (uint32_t)e->msp.m.size());
   }
-  for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("cp_encrypt_packed: item_policy out of range");
+  for (size_t i = 0; i < n; i++) if (item_policy[i] >= pols.size()) throw RabeError("encrypt_packed: item_policy out of range");
   out_off[0] = 0;
   for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + pols[item_policy[i]]->fixed_bytes + (pt_off[i + 1] - pt_off[i]) + 28;
   if (!out_buf || out_cap < out_off[n]) return false;
@@ -996,11 +1024,16 @@ bool cp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std
     parallel_for(n, [&](size_t i) {               // record assembly + KDF + AES-GCM per item, on all cores
       const size_t p_ = item_policy[i];
       const AbePolicy& msp = pols[p_]->msp;
-      const std::string& pol = policies[p_];
       uint8_t* w = ob + out_off[i];
-      put_u32(w, (uint32_t)pol.size()); w += 4;
-      memcpy(w, pol.data(), pol.size()); w += pol.size();
-      *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
+      if (policies) {                             // Ac17CpCiphertext: policy text + language
+        const std::string& pol = (*policies)[p_];
+        put_u32(w, (uint32_t)pol.size()); w += 4;
+        memcpy(w, pol.data(), pol.size()); w += pol.size();
+        *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
+      } else {                                    // Ac17KpCiphertext: the attribute strings
+        put_u32(w, (uint32_t)msp.pi.size()); w += 4;
+        for (const auto& a : msp.pi) { put_u32(w, (uint32_t)a.size()); w += 4; memcpy(w, a.data(), a.size()); w += a.size(); }
+      }
       put_u32(w, 3); w += 4;
       memcpy(w, h_x + 384 * i, 384); w += 384;
       put_u32(w, (uint32_t)msp.m.size()); w += 4;
@@ -1039,9 +1072,30 @@ static void destroy_ac17_sk_lines(void* h) { rhip_ac17_sk_lines_destroy((rhip_ac
 // pass on the GPU (coordinates < p, rows on the G1 curve, c_0 in the r-torsion of the twist, c_p in the order-r subgroup of Fq12:
 // what rabe-bn's decoding establishes, FieldError::NotMember) -- the Gt arithmetic downstream (cyclotomic squarings, conjugate as
 // inverse) is only valid inside the subgroup.  `trusted` is for ciphertexts this process produced itself.
+// KP-ABE's decrypt (:625-675) is the same product of pairings with the roles of the two sides' names swapped: the policy is the KEY's, the
+// attribute list the ciphertext's (its record starts with the attribute strings instead of policy text + language); k_p is absent.
+struct DecKey {
+  const Ac17SecretKey& sk;
+  const std::vector<std::string>* cp_attrs;      // CP: the key's attributes; the policy comes with every ciphertext
+  const PolicyRef* kp_policy;                    // KP: the key's policy; the attributes come with every ciphertext
+};
+static bool decrypt_packed_core(Engine& eng, const DecKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                                int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
                        int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
-  StageTimer tm("ac17::cp_decrypt_packed");
+  if (sk.sk.k_p.size() != 3) throw RabeError("malformed Ac17CpSecretKey");
+  return decrypt_packed_core(eng, DecKey{sk.sk, &sk.attr, nullptr}, n, ct_blob, ct_len, ct_off, trusted, status, pt_buf, pt_cap, pt_off, errors);
+}
+bool kp_decrypt_packed(Engine& eng, const Ac17KpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                       int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  if (!(sk.sk.k_p.empty() || sk.sk.k_p.size() == 3)) throw RabeError("malformed Ac17KpSecretKey");
+  return decrypt_packed_core(eng, DecKey{sk.sk, nullptr, &sk.policy}, n, ct_blob, ct_len, ct_off, trusted, status, pt_buf, pt_cap, pt_off, errors);
+}
+static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                                int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  const bool kp = key.kp_policy != nullptr;
+  const Ac17SecretKey& core = key.sk;
+  StageTimer tm(kp ? "ac17::kp_decrypt_packed" : "ac17::cp_decrypt_packed");
   Engine::ArenaScope arena(eng);
   errors->assign(n, "");
   if (!ct_off || (n && !ct_blob)) throw RabeError("cp_decrypt_packed: null input");
@@ -1052,8 +1106,10 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     else span += ct_off[i + 1] - ct_off[i];
   }
   if (!pt_buf || pt_cap < span) return false;
-  if (sk.sk.k_0.size() != 3 || sk.sk.k_p.size() != 3) throw RabeError("malformed Ac17CpSecretKey");
-  for (const auto& row : sk.sk.k) if (row.second.size() != 3) throw RabeError("malformed Ac17CpSecretKey: a row does not have 3 elements");
+  if (core.k_0.size() != 3) throw RabeError("malformed AC17 secret key");
+  for (const auto& row : core.k) if (row.second.size() != 3) throw RabeError("malformed AC17 secret key: a row does not have 3 elements");
+  PolicyNode kp_tree;                            // KP: the key's policy, parsed once (a policy that does not parse fails the call like kp_decrypt)
+  if (kp) kp_tree = parse_or_error(key.kp_policy->first, key.kp_policy->second);
   // per distinct policy text (items of a batch repeat a few): the tree, the verdict for this key, the key-side selection and --
   // for the row layout the first item with that policy shows -- the ciphertext-side selection
   struct PolPlan {
@@ -1079,11 +1135,20 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
     e->text.assign((const char*)txt, len);
     e->lang = lang;
     try {
-      PolicyNode tree = parse_or_error(e->text, lang);
-      if (!traverse_policy(sk.attr, tree)) throw RabeError("Error in cp_decrypt: attributes in SK do not match policy in CT.");
-      if (!calc_pruned(sk.attr, tree, &e->lst)) throw RabeError("Error: attributes in sk do not match policy in ct.");
+      if (kp) {                                  // e->text = the record's head: u32 count, then (u32 length, bytes) per attribute
+        std::vector<std::string> attrs;
+        const uint8_t* q = (const uint8_t*)e->text.data();
+        const uint32_t cnt = get_u32(q); q += 4;
+        for (uint32_t k = 0; k < cnt; k++) { const uint32_t l = get_u32(q); q += 4; attrs.emplace_back((const char*)q, l); q += l; }
+        if (!traverse_policy(attrs, kp_tree)) throw RabeError("Error in kp_decrypt: attributes in ct do not match policy in sk.");
+        if (!calc_pruned(attrs, kp_tree, &e->lst)) throw RabeError("Error in kp_decrypt: pruned attributes in sk do not match policy in ct.");
+      } else {
+        PolicyNode tree = parse_or_error(e->text, lang);
+        if (!traverse_policy(*key.cp_attrs, tree)) throw RabeError("Error in cp_decrypt: attributes in SK do not match policy in CT.");
+        if (!calc_pruned(*key.cp_attrs, tree, &e->lst)) throw RabeError("Error: attributes in sk do not match policy in ct.");
+      }
       for (const auto& cur : e->lst)
-        for (size_t r = 0; r < sk.sk.k.size(); r++) if (sk.sk.k[r].first == cur.first) e->sk_sel.push_back((uint32_t)r);
+        for (size_t r = 0; r < core.k.size(); r++) if (core.k[r].first == cur.first) e->sk_sel.push_back((uint32_t)r);
     } catch (const RabeError& ex) {
       e->err = ex.what();
       if (e->err.empty()) e->err = "policy error";
@@ -1101,10 +1166,21 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
       const uint8_t* p = ct_blob + ct_off[i];
       const uint8_t* end = ct_blob + ct_off[i + 1];
       auto need = [&](size_t k) { if ((size_t)(end - p) < k) throw RabeError("deserialize: truncated input"); };
-      need(4); const uint32_t pl = get_u32(p); p += 4;
-      need((size_t)pl + 1);
-      const uint8_t* pol = p; p += pl;
-      const PolicyLanguage lang = *p++ ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      const uint8_t* pol;                         // what the plan is keyed by: CP the policy text, KP the whole attribute head
+      uint32_t pl;
+      PolicyLanguage lang = PolicyLanguage::JsonPolicy;
+      if (kp) {
+        pol = p;
+        need(4); const uint32_t cnt = get_u32(p); p += 4;
+        if ((size_t)cnt * 4 > (size_t)(end - p)) throw RabeError("deserialize: truncated input");
+        for (uint32_t k = 0; k < cnt; k++) { need(4); const uint32_t l = get_u32(p); p += 4; need(l); p += l; }
+        pl = (uint32_t)(p - pol);
+      } else {
+        need(4); pl = get_u32(p); p += 4;
+        need((size_t)pl + 1);
+        pol = p; p += pl;
+        lang = *p++ ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy;
+      }
       need(4 + 384); if (get_u32(p) != 3) throw RabeError("deserialize: c_0 does not have 3 elements"); p += 4;
       v[i].c0 = p; p += 384;
       need(4); const uint32_t rows = get_u32(p); p += 4;
@@ -1179,12 +1255,13 @@ bool cp_decrypt_packed(Engine& eng, const Ac17CpSecretKey& sk, size_t n, const u
       for (uint32_t r = 0; r < w.rows; r++) memcpy(dst + 192 * r, w.row_ptr[r], 192);
     });
     tm.lap("pack");
-    std::vector<uint8_t> k0 = flatten(sk.sk.k_0), kp = flatten(sk.sk.k_p), kk;
-    for (const auto& row : sk.sk.k) for (const auto& x : row.second) kk.insert(kk.end(), x.begin(), x.end());
-    std::vector<uint32_t> sk_row_off{0, (uint32_t)sk.sk.k.size()}, sk_idx(m, 0);
+    std::vector<uint8_t> k0 = flatten(core.k_0), kp_bytes = core.k_p.size() == 3 ? flatten(core.k_p) : std::vector<uint8_t>(3 * 64, 0), kk;   // KP: prod_h starts from G1::zero()
+    for (const auto& row : core.k) for (const auto& x : row.second) kk.insert(kk.end(), x.begin(), x.end());
+    if (kk.empty()) kk.assign(64, 0);
+    std::vector<uint32_t> sk_row_off{0, (uint32_t)core.k.size()}, sk_idx(m, 0);
     rhip_ctx* cx = eng.ctx();
     DBuf d1(&eng, m * 384), d2(&eng, total_rows * 192), d3(&eng, ct_row_off.data(), ct_row_off.size() * 4), d4(&eng, m * 384),
-        d5(&eng, k0.data(), k0.size()), d6(&eng, kk.data(), kk.size()), d7(&eng, sk_row_off.data(), 8), d8(&eng, kp.data(), kp.size()),
+        d5(&eng, k0.data(), k0.size()), d6(&eng, kk.data(), kk.size()), d7(&eng, sk_row_off.data(), 8), d8(&eng, kp_bytes.data(), kp_bytes.size()),
         d9(&eng, sk_idx.data(), m * 4), d10(&eng, ct_sel.data(), ct_sel.size() * 4), d11(&eng, ct_sel_off.data(), ct_sel_off.size() * 4),
         d12(&eng, sk_sel.data(), sk_sel.size() * 4), d13(&eng, sk_sel_off.data(), sk_sel_off.size() * 4), dout(&eng, m * 384);
     eng.check(rhip_upload_async(cx, d1.ptr(), h_x, m * 384), "upload");

@@ -57,6 +57,11 @@ Bytes kp_decrypt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext&
 Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
 std::vector<Ac17KpCiphertext> kp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& attribute_sets,
                                                const std::vector<Bytes>& datas);
+// packed forms of the KP pair (schemes.cpp: the CP entry points with the record head and the roles of the names swapped)
+bool kp_encrypt_packed(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set,
+                       const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
+bool kp_decrypt_packed(Engine& eng, const Ac17KpSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,
+                       int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 std::vector<DecryptResult> kp_decrypt_batch(Engine& eng, const std::vector<const Ac17KpSecretKey*>& sks, const std::vector<const Ac17KpCiphertext*>& cts);
 }  // namespace ac17
 

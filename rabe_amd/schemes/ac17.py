@@ -155,6 +155,34 @@ def cp_keygen_packed(host, msk, attr_sets, item_set, out=None):
     return buf[:int(so[n])], so
 
 
+def kp_encrypt_packed(host, pk, attr_sets, item_set, pt_blob, pt_off, out=None):
+    """n KP-ABE encrypts (rabe_ac17_kp_encrypt_packed): item i under the attribute list attr_sets[item_set[i]]; records = Ac17KpCiphertext.
+    Returns (ct_blob view, ct_off uint64 [n+1])."""
+    import numpy as np
+    n = len(item_set)
+    arr, _ = _strs([a for s_ in attr_sets for a in s_])
+    counts = (ctypes.c_size_t * max(len(attr_sets), 1))(*[len(s_) for s_ in attr_sets])
+    it = np.ascontiguousarray(item_set, dtype=np.uint32)
+    po = np.ascontiguousarray(pt_off, dtype=np.uint64)
+    pt = _as_u8(pt_blob)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_ac17_kp_encrypt_packed(host.h, pk.ptr, arr, counts, ctypes.c_size_t(len(attr_sets)), ctypes.c_size_t(n), _np_ptr(it), _np_ptr(pt),
+                                                  _np_ptr(po), _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(co))
+        if rc != 1:
+            break
+        buf = np.empty(int(co[n]), dtype=np.uint8)
+    hostlib_check(rc, host)
+    return buf[:int(co[n])], co
+
+
+def kp_decrypt_packed(host, sk, ct_blob, ct_off, out=None, trusted=False):
+    """n KP-ABE decrypts with one key (rabe_ac17_kp_decrypt_packed).  Returns (pt_blob view, pt_off uint64 [n+1], status int32 [n])."""
+    from ..hostlib import packed_decrypt
+    return packed_decrypt(host, "rabe_ac17_kp_decrypt_packed", [sk.ptr], ct_blob, ct_off, out=out, trusted=trusted)
+
+
 PACKED_TRUSTED = 1
 
 

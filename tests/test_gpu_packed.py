@@ -142,3 +142,38 @@ def test_packed_keygen_equals_object_keygen_on_the_same_tape(host):
     ct = ac17.cp_encrypt(host, pk, '"a1" and ("a7" and ("a13" and ("a19" and "a24")))', b"x" * 40, hl.HUMAN_POLICY)     # AC17: binary ANDs
     for i in (0, 1, 1998, 1999):
         assert ac17.cp_decrypt(host, hl.Obj.deserialize("ac17_cp_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"x" * 40
+
+
+def test_kp_packed_equals_object_api_and_fails_items_alone(host):
+    """rabe_ac17_kp_{encrypt,decrypt}_packed: Ac17KpCiphertext records byte-identical to kp_encrypt_batch on the same tape; one key's policy
+    against every ciphertext's attribute list -- a list that does not satisfy it, a tampered record and bad offsets fail their own item."""
+    pk, msk = ac17.setup(host)
+    sets = [["B", "C"], ["A"], ["B", "D"], ["A", "C", "D"]]
+    n = 11
+    item_set = [i % 4 for i in range(n)]
+    pts = [b"kp plaintext %d " % i * (i % 3 + 1) for i in range(n)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+    tape = [1000003 * (i + 3) + 19 for i in range(4 * n)]                    # s0, s1, msg exponent, nonce per item
+    host.set_tape(tape)
+    objs = ac17.kp_encrypt_batch(host, pk, [sets[s] for s in item_set], pts)
+    host.set_tape(tape)
+    blob, ct_off = ac17.kp_encrypt_packed(host, pk, sets, item_set, b"".join(pts), off)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes(), i
+    sk = ac17.kp_keygen(host, msk, '{"name": "or", "children": [{"name": "A"}, {"name": "and", "children": [{"name": "B"}, {"name": "C"}]}]}', hl.JSON_POLICY)
+    for trusted in (False, True):
+        out, out_off, status = ac17.kp_decrypt_packed(host, sk, blob, ct_off, trusted=trusted)
+        want = [0, 0, -1, 0] * 3                                               # ["B", "D"] does not satisfy A or (B and C)
+        assert list(status) == want[:n]
+        for i in range(n):
+            got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+            assert got == (pts[i] if want[i] == 0 else b"")
+            if want[i] == 0:
+                assert ac17.kp_decrypt(host, sk, hl.Obj.deserialize("ac17_kp_ct", blob[int(ct_off[i]):int(ct_off[i + 1])].tobytes())) == pts[i]
+    raw = bytearray(blob.tobytes())
+    raw[int(ct_off[2]) - 3] ^= 0x40                                            # item 1's sealed bytes
+    o = ct_off.copy()
+    o[10] = np.uint64(int(o[9]) - 8)                                           # item 9: non-monotone offsets
+    out, out_off, status = ac17.kp_decrypt_packed(host, sk, bytes(raw), o)
+    assert list(status[:10]) == [0, -1, -1, 0, 0, 0, -1, 0, 0, -1]

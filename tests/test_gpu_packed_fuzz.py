@@ -78,6 +78,15 @@ def test_corrupted_records_fail_alone(host, trusted):
         b, o = corrupt(rnd, recs, victims)
         out, oo, st = ac17.cp_decrypt_packed(host, sk, b, o, trusted=trusted)
         check(st, split(out, oo, n), pts, victims)
+    # ---- AC17 KP (the same core with the record head and the roles swapped)
+    blob, off = ac17.kp_encrypt_packed(host, pk, [["A", "B"], ["A", "C", "D"]], [i % 2 for i in range(n)], b"".join(pts), offsets(pts))
+    recs = split(blob, off, n)
+    ksk = ac17.kp_keygen(host, msk, '"A" and ("B" or "C")', hl.HUMAN_POLICY)
+    for _ in range(12):
+        victims = set(rnd.sample(range(n), 4))
+        b, o = corrupt(rnd, recs, victims)
+        out, oo, st = ac17.kp_decrypt_packed(host, ksk, b, o, trusted=trusted)
+        check(st, split(out, oo, n), pts, victims)
     # ---- BSW
     pk, msk = bsw.setup(host)
     blob, off = bsw.encrypt_packed(host, pk, ['"A" and "B" and "C"', '"A" or ("B" and "D")'], [i % 2 for i in range(n)], b"".join(pts), offsets(pts),
