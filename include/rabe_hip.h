@@ -377,6 +377,18 @@ int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
                                const uint32_t* dev_sk_leaf_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
                                const rhip_g2_lines* ct_e2_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
 
+/* The same with ONE ciphertext for every item (dev_ct_e2 [1], dev_ct_e1j = its attribute rows) -- n fresh keys against one ciphertext, what
+ * BASELINE config 4 measures and rabe_lsw_decrypt_packed does.  The scaled G1 arguments c_e * E1_e then depend on the selection entry
+ * alone: items that share a policy share their entries (dev_sel_start), so the scalings are computed once per ENTRY (n_sel of them)
+ * instead of once per pair.  Results are those of rhip_lsw_decrypt_batch with dev_ct_idx = all zero. */
+int32_t rhip_lsw_decrypt_batch_one_ct(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel,
+                                      const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                                      const uint32_t* dev_sel_sk_leaf, const uint32_t* dev_sel_ct_attr, const rhip_fr* dev_sel_coeff,
+                                      const rhip_gt* dev_ct_e1 /*[n_items]: e1 replicated*/, const rhip_g2* dev_ct_e2 /*[1]*/,
+                                      const rhip_g1* dev_ct_e1j /*[the ciphertext's attribute rows]*/, const rhip_g1* dev_sk_d1, const rhip_g2* dev_sk_d2,
+                                      const uint32_t* dev_sk_leaf_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
+                                      const rhip_g2_lines* ct_e2_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- Level B: GHW11 outsourced decryption (src/schemes/ghw11/mod.rs:227-295) ----------------------
  * Group arithmetic of n_items calls of ghw11::transform under ONE transform key.  tk_lines = rhip_g2_lines_prepare over the key's G2
  * elements in the order k_z, l_z, k_x[0], k_x[1], ... : every Miller loop of the batch replays prepared lines (no G2 arithmetic).

@@ -566,9 +566,14 @@ class LswBench:
                          self.d_alpha, self.d_coef, self.d_item_coef_off, self.d_rand, d1, d2)
         if self.r.args.only_encrypt:
             return
-        E.lsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_sk, self.d_sel_ct,
-                          self.d_sel_z, self.d_ct_e1, self.d_ct_e2, self.d_ct_e1j, self.d_ct_attr_off, self.d_ct_idx, d1, d2, self.d_leaf_off, None,
-                          self.e2_lines, out)
+        if os.environ.get("RABE_LSW_GENERAL_DECRYPT"):        # A/B: the general entry point (a ciphertext index per item)
+            E.lsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_sk, self.d_sel_ct,
+                              self.d_sel_z, self.d_ct_e1, self.d_ct_e2, self.d_ct_e1j, self.d_ct_attr_off, self.d_ct_idx, d1, d2, self.d_leaf_off, None,
+                              self.e2_lines, out)
+            return
+        # every fresh key decrypts the one pre-made ciphertext: the one-ciphertext entry point (scaled ciphertext rows once per selection entry)
+        E.lsw_decrypt_one_ct_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_sk, self.d_sel_ct,
+                                 self.d_sel_z, self.d_ct_e1, self.d_ct_e2, self.d_ct_e1j, d1, d2, self.d_leaf_off, None, self.e2_lines, out)
 
     def check(self, lane, g):
         n = g * self.B

@@ -711,27 +711,35 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_it
                                                                     const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
                                                                     const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2,
                                                                     const uint32_t* sk_leaf_off, const uint32_t* sk_idx, const uint8_t* e2_line_inf,
-                                                                    G1M* P, G2M* Q, uint32_t* qref, G1M* terms) {
+                                                                    G1M* P, G2M* Q, uint32_t* qref, G1M* terms, const G1M* psel, const uint8_t* psel_inf,
+                                                                    int one_ct) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
   size_t t, item;
   bool active;
   pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
-  const uint32_t ct = ct_idx ? ct_idx[item] : (uint32_t)item;
+  const uint32_t ct = one_ct ? 0u : ct_idx ? ct_idx[item] : (uint32_t)item;
   const uint32_t sk = sk_idx ? sk_idx[item] : (uint32_t)item;
   const bool last = (j == m);
   G1Aff base = aff_inf<Fp>();
   uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t leaf = 0;
+  uint32_t leaf = 0, e = 0;
   if (!last) {
-    const uint32_t e = sel_start[item] + j;
+    e = sel_start[item] + j;
     leaf = sk_leaf_off[sk] + sel_sk_leaf[e];
-    base = load_g1(ct_e1j[ct_attr_off[ct] + sel_ct_attr[e]].l);
-    ld_scalar(k, sel_coeff + e);
   }
   bool p_inf;
-  scale_and_store(lds, active && !last, base, k, false, P + t, &p_inf);
+  if (psel) {                                  // one ciphertext for all items: c_e * E1_e was computed once per selection entry (k_lsw_scale_entries)
+    p_inf = last || psel_inf[e] != 0;
+    if (active && !p_inf) st_g1_q(P + t, ld_g1_q(psel + e));
+  } else {
+    if (!last) {
+      base = load_g1(ct_e1j[(one_ct ? 0u : ct_attr_off[ct]) + sel_ct_attr[e]].l);
+      ld_scalar(k, sel_coeff + e);
+    }
+    scale_and_store(lds, active && !last, base, k, false, P + t, &p_inf);
+  }
   if (!active) return;
   if (last) {
     if (e2_line_inf) {                                   // prepared lines of the ciphertexts' e2: block = ciphertext index
@@ -754,11 +762,45 @@ __global__ void __launch_bounds__(256, RB_MIN_WAVES) k_term_off(size_t n_items, 
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n_items) term_off[i] = pair_off[i] - other * (uint32_t)i;          // `other`: pairs of an item that are not terms of its sum
 }
+// one ciphertext for the whole batch: the scaled G1 arguments depend on the selection entry alone -- entry e: c_e * E1[sel_ct_attr[e]]
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_scale_entries(size_t n_sel, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff, const rhip_g1* ct_e1j,
+                                                                        G1M* psel, uint8_t* psel_inf) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = e < n_sel;
+  if (!active) e = n_sel - 1;
+  uint32_t k[8];
+  ld_scalar(k, sel_coeff + e);
+  bool inf;
+  scale_and_store(lds, active, load_g1(ct_e1j[sel_ct_attr[e]].l), k, false, psel + e, &inf);
+  if (active) psel_inf[e] = inf ? 1 : 0;
+}
+static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
+                                const rhip_gt* ct_e1, const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
+                                const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2, const uint32_t* sk_leaf_off,
+                                const uint32_t* sk_idx, const rhip_g2_lines* ct_e2_lines, rhip_gt* out, bool one_ct);
 extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
                                           const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
                                           const rhip_gt* ct_e1, const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
                                           const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2, const uint32_t* sk_leaf_off,
                                           const uint32_t* sk_idx, const rhip_g2_lines* ct_e2_lines, rhip_gt* out) {
+  return lsw_decrypt_impl(ctx, n_items, max_pairs, total_pairs, n_sel, pair_off, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e1, ct_e2, ct_e1j,
+                          ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx, ct_e2_lines, out, false);
+}
+extern "C" int32_t rhip_lsw_decrypt_batch_one_ct(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                                 const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
+                                                 const rhip_gt* ct_e1, const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const rhip_g1* sk_d1,
+                                                 const rhip_g2* sk_d2, const uint32_t* sk_leaf_off, const uint32_t* sk_idx,
+                                                 const rhip_g2_lines* ct_e2_lines, rhip_gt* out) {
+  return lsw_decrypt_impl(ctx, n_items, max_pairs, total_pairs, n_sel, pair_off, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e1, ct_e2, ct_e1j,
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, sk_d1, sk_d2, sk_leaf_off, sk_idx, ct_e2_lines, out, true);
+}
+static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                const uint32_t* sel_start, const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
+                                const rhip_gt* ct_e1, const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
+                                const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2, const uint32_t* sk_leaf_off,
+                                const uint32_t* sk_idx, const rhip_g2_lines* ct_e2_lines, rhip_gt* out, bool one_ct) {
   NEED(ctx);
   if (!n_items) return RHIP_OK;
   if (!total_pairs || !pair_off || !n_sel) return RHIP_ERR_ARG;
@@ -777,9 +819,20 @@ extern "C" int32_t rhip_lsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
   KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
   KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
   const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
+  G1M* psel = nullptr;
+  uint8_t* psel_inf = nullptr;
+  if (one_ct && n_sel < total_pairs - n_items) {          // fewer entries than pairs: items share entries, scale per entry
+    void* w_sel = nullptr;
+    rc = rhip_ensure_work(ctx, 8, n_sel * (sizeof(G1M) + 1) + 64, &w_sel);
+    if (rc) return rc;
+    psel = (G1M*)w_sel;
+    psel_inf = (uint8_t*)(psel + n_sel);
+    KLAUNCH(ctx, "k_lsw_scale_entries", k_lsw_scale_entries, dim3(blocks_for(n_sel, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_sel, sel_ct_attr, sel_coeff,
+            ct_e1j, psel, psel_inf);
+  }
   KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
           pair_off, ppi, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
-          (const uint8_t*)(ct_e2_lines ? ct_e2_lines->q_inf : nullptr), pl.P, pl.Q, pl.qref, (G1M*)w_terms);
+          (const uint8_t*)(ct_e2_lines ? ct_e2_lines->q_inf : nullptr), pl.P, pl.Q, pl.qref, (G1M*)w_terms, (const G1M*)psel, (const uint8_t*)psel_inf, one_ct ? 1 : 0);
   KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,

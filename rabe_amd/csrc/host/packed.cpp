@@ -883,11 +883,10 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     std::vector<uint8_t> e1j, e1rep(m_items * 384);
     for (const auto& a : ct.ej) e1j.insert(e1j.end(), a.e1.begin(), a.e1.end());
     for (size_t j = 0; j < m_items; j++) memcpy(e1rep.data() + 384 * j, ct.e1.data(), 384);
-    std::vector<uint32_t> ct_attr_off{0, (uint32_t)ct.ej.size()}, ct_idx(m_items, 0);
+
     DBuf d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off), d_pair_off = up32(eng, pair_off),
         d_sel_start = up32(eng, sel_start), d_sel_sk = up32(eng, sel_sk), d_sel_ct = up32(eng, sel_ct), d_sel_z = up_bytes(eng, flatten_fr(sel_z)),
-        d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j), d_ct_attr_off = up32(eng, ct_attr_off),
-        d_ct_idx = up32(eng, ct_idx), d_out(&eng, m_items * 384);
+        d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j), d_out(&eng, m_items * 384);
     eng.check(rhip_upload_async(cx, d_d1.ptr(), h_l, total * 64), "upload");
     eng.check(rhip_upload_async(cx, d_d2.ptr(), h_l + total * 64, total * 128), "upload");
     std::unique_ptr<MemberChecks> mc;
@@ -897,10 +896,11 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     }
     std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
     rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
-    int32_t rc = rhip_lsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_sk.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
-                                        d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
-                                        d_e1j.as<rhip_g1>(), d_ct_attr_off.as<uint32_t>(), d_ct_idx.as<uint32_t>(), d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(),
-                                        d_leaf_off.as<uint32_t>(), (const uint32_t*)nullptr, lines, d_out.as<rhip_gt>());
+    // one ciphertext for all keys: the scaled ciphertext rows are computed once per selection entry (keys that share a policy share them)
+    int32_t rc = rhip_lsw_decrypt_batch_one_ct(cx, m_items, max_pairs, pair_off[m_items], sel_sk.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
+                                               d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
+                                               d_e1j.as<rhip_g1>(), d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), (const uint32_t*)nullptr, lines,
+                                               d_out.as<rhip_gt>());
     h_out = eng.pinned(2, m_items * 384);
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);

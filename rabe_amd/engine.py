@@ -458,6 +458,14 @@ def lsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_s
                                               _p(e2_lines), _p(d_out)))
 
 
+def lsw_decrypt_one_ct_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_sel_start, d_sel_sk_leaf, d_sel_ct_attr, d_sel_coeff, d_ct_e1,
+                           d_ct_e2, d_ct_e1j, d_sk_d1, d_sk_d2, d_sk_leaf_off, d_sk_idx, e2_lines, d_out):
+    """every item decrypts the SAME ciphertext (rhip_lsw_decrypt_batch_one_ct): the scaled G1 arguments are computed once per selection entry"""
+    eng._check(eng.lib.rhip_lsw_decrypt_batch_one_ct(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _sz(n_sel), _p(d_pair_off), _p(d_sel_start),
+                                                     _p(d_sel_sk_leaf), _p(d_sel_ct_attr), _p(d_sel_coeff), _p(d_ct_e1), _p(d_ct_e2), _p(d_ct_e1j),
+                                                     _p(d_sk_d1), _p(d_sk_d2), _p(d_sk_leaf_off), _p(d_sk_idx), _p(e2_lines), _p(d_out)))
+
+
 class Aw11Pk:
     def __init__(self, eng, g1, g2, egg_alpha, g2_y):
         self.eng = eng

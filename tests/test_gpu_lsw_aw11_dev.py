@@ -92,6 +92,48 @@ def test_lsw_device_keygen_decrypt_match_oracle(eng):
                           eng.upload_u32(offsets([len(a) for a in ct_attrs])), eng.upload_u32([c for _, c in items]), d_d1, d_d2, d_leaf_off, None,
                           e2_lines, d_out)
         assert eng.download(d_out) == want, "prepared e2" if e2_lines else "walking e2"
+    # ---- the one-ciphertext entry point (n keys against ciphertext 0): selection entries SHARED by the items of one policy, so the scaled
+    # ciphertext rows are computed once per entry; the same bytes as the oracle / the general entry point
+    its = [i for i, (_, c) in enumerate(items) if c == 0] * 3                       # items 0, 1, 2, 4 repeated: policies 0, 1, 2, 0
+    shared_start, sel_sk1, sel_ct1, sel_z1 = {}, [], [], []
+    for i in its:
+        p = items[i][0]
+        if p not in shared_start:
+            shared_start[p] = len(sel_sk1)
+            a, b = sel_start[i], (sel_start[i + 1] if i + 1 < n else len(sel_sk))
+            sel_sk1 += sel_sk[a:b]
+            sel_ct1 += sel_ct[a:b]
+            sel_z1 += sel_z[a:b]
+    po1 = [0]
+    for i in its:
+        po1.append(po1[-1] + pair_off[i + 1] - pair_off[i])
+    assert len(sel_sk1) < po1[-1] - len(its)                                            # fewer entries than scaled pairs: the shared path runs
+    d_e2_0 = eng.upload(bn.g2_to_le(cts[0]["e2"]))
+    lines0 = E.G2Lines(eng, 1, d_e2_0)
+    d_out = eng.alloc(len(its) * 384)
+    E.lsw_decrypt_one_ct_dev(eng, len(its), max(b - a for a, b in zip(po1, po1[1:])), po1[-1], len(sel_sk1), eng.upload_u32(po1),
+                             eng.upload_u32([shared_start[items[i][0]] for i in its]), eng.upload_u32(sel_sk1), eng.upload_u32(sel_ct1),
+                             eng.upload(b"".join(le(z) for z in sel_z1)), eng.upload(bn.gt_to_le(cts[0]["e1"]) * len(its)), d_e2_0,
+                             eng.upload(b"".join(bn.g1_to_le(row[1]) for row in cts[0]["ej"])), d_d1, d_d2, d_leaf_off, eng.upload_u32(its), lines0, d_out)
+    assert eng.download(d_out) == bn.gt_to_le(msgs[0]) * len(its)
+    # the same entry point with one entry list PER ITEM (nothing shared: as many entries as scaled pairs): the per-pair scaling path
+    own = [i for i, (_, c) in enumerate(items) if c == 0]
+    st2, sk2, ct2, z2, po2 = [], [], [], [], [0]
+    for i in own:
+        a, b = sel_start[i], (sel_start[i + 1] if i + 1 < n else len(sel_sk))
+        st2.append(len(sk2))
+        sk2 += sel_sk[a:b]
+        ct2 += sel_ct[a:b]
+        z2 += sel_z[a:b]
+        po2.append(po2[-1] + pair_off[i + 1] - pair_off[i])
+    assert len(sk2) == po2[-1] - len(own)
+    d_out = eng.alloc(len(own) * 384)
+    E.lsw_decrypt_one_ct_dev(eng, len(own), max(b - a for a, b in zip(po2, po2[1:])), po2[-1], len(sk2), eng.upload_u32(po2), eng.upload_u32(st2),
+                             eng.upload_u32(sk2), eng.upload_u32(ct2), eng.upload(b"".join(le(z) for z in z2)), eng.upload(bn.gt_to_le(cts[0]["e1"]) * len(own)),
+                             d_e2_0, eng.upload(b"".join(bn.g1_to_le(row[1]) for row in cts[0]["ej"])), d_d1, d_d2, d_leaf_off, eng.upload_u32(own), None,
+                             d_out)
+    assert eng.download(d_out) == bn.gt_to_le(msgs[0]) * len(own)
+    lines0.destroy()
     lines.destroy()
     dpk.destroy()
 
