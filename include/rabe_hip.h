@@ -333,6 +333,18 @@ int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, 
                                const uint32_t* dev_sk_attr_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items]*/,
                                const rhip_bsw_sk_lines* sk_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
 
+/* The same with ONE secret key for every item (dev_sk_d [1], dev_sk_dj_* = its attribute rows, dev_sk_attr_off = {0, n}) -- what
+ * rabe_bsw_decrypt_packed does and BASELINE config 3 measures.  The key-side G1 arguments -z_e * Dj.g1 then depend on the selection
+ * entry alone: ciphertexts that share a policy share their entries (dev_sel_start), so those scalings are computed once per ENTRY (n_sel
+ * of them) instead of once per pair.  Results are those of rhip_bsw_decrypt_batch with dev_sk_idx = all zero. */
+int32_t rhip_bsw_decrypt_batch_one_sk(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel,
+                                      const uint32_t* dev_pair_off /*[n_items+1]*/, const uint32_t* dev_sel_start /*[n_items]*/,
+                                      const uint32_t* dev_sel_ct_leaf, const uint32_t* dev_sel_sk_attr, const rhip_fr* dev_sel_coeff,
+                                      const rhip_g1* dev_ct_c /*[n_items]*/, const rhip_gt* dev_ct_cp /*[n_items]*/,
+                                      const rhip_g1* dev_ct_cy_g1, const rhip_g2* dev_ct_cy_g2, const uint32_t* dev_ct_leaf_off /*[n_items+1]*/,
+                                      const rhip_g2* dev_sk_d /*[1]*/, const rhip_g1* dev_sk_dj_g1, const rhip_g2* dev_sk_dj_g2,
+                                      const uint32_t* dev_sk_attr_off /*[2]*/, const rhip_bsw_sk_lines* sk_lines /* or NULL */, rhip_gt* dev_out /*[n_items]*/);
+
 /* ---- Level B: LSW KP-ABE (src/schemes/lsw/mod.rs) ----------------------------------------------------------------
  * rhip_lsw_keygen_batch: positive leaves; rhip_lsw_keygen_batch_signed: positive and negative ("!x", :137-146).  The reference's
  * decrypt has no negative branch at all (a TODO, :265-278): the host layer reproduces what it does instead. */

@@ -325,6 +325,7 @@ class BswBench:
             sel_sk += ska
             sel_z += z
             so += len(idx)
+        self.n_sel = so
         leaf_off, pair_off, coef_off = [0], [0], [0]
         for p in pol:
             leaf_off.append(leaf_off[-1] + tt.n_leaves(p))
@@ -366,9 +367,14 @@ class BswBench:
                           self.d_secret, self.d_coef, self.d_item_coef_off, self.d_msg, c, cp, g1, g2)
         if self.r.args.only_encrypt:
             return
-        E.bsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.d_pair_off, self.d_sel_start, self.d_sel_ct, self.d_sel_sk,
-                          self.d_sel_z, c, cp, g1, g2, self.d_leaf_off, self.d_sk_d, self.d_sk_g1, self.d_sk_g2, self.d_sk_attr_off,
-                          self.d_sk_idx, self.sk_lines, out)
+        if os.environ.get("RABE_BSW_GENERAL_DECRYPT"):        # A/B: the general entry point (a key index per item)
+            E.bsw_decrypt_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.d_pair_off, self.d_sel_start, self.d_sel_ct, self.d_sel_sk,
+                              self.d_sel_z, c, cp, g1, g2, self.d_leaf_off, self.d_sk_d, self.d_sk_g1, self.d_sk_g2, self.d_sk_attr_off,
+                              self.d_sk_idx, self.sk_lines, out)
+            return
+        # one key decrypts every ciphertext of the batch: the one-key entry point (the key's scaled Dj.g1 once per selection entry)
+        E.bsw_decrypt_one_sk_dev(e_, n, self.max_pairs, g * self.pairs_per_batch, self.n_sel, self.d_pair_off, self.d_sel_start, self.d_sel_ct, self.d_sel_sk,
+                                 self.d_sel_z, c, cp, g1, g2, self.d_leaf_off, self.d_sk_d, self.d_sk_g1, self.d_sk_g2, self.d_sk_attr_off, self.sk_lines, out)
 
     def check(self, lane, g):
         n = g * self.B * 384

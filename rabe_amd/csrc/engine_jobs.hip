@@ -379,19 +379,30 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_it
                                                                     const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
                                                                     const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
                                                                     uint32_t lines_d_base, int prepared, const uint8_t* line_inf, G1M* P, G2M* Q,
-                                                                    uint32_t* qref) {
+                                                                    uint32_t* qref, const G1M* psel, const uint8_t* psel_inf, int compact) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
   size_t t, item;
   bool active;
-  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
-  const uint32_t j = (uint32_t)(t - pair_off[item]);
-  const uint32_t m = (pair_off[item + 1] - pair_off[item] - 1) >> 1;
-  const uint32_t sk = sk_idx[item];
+  uint32_t j, m;
+  if (compact) {      // uniform batch, one key: only the pairs that still need a scaling get a lane -- positions 0, 2, .. 2m-2 and 2m
+    const uint32_t mm = (ppi - 1) >> 1;
+    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, n_items * (size_t)(mm + 1), pair_off, mm + 1, &t, &item, &active);
+    const uint32_t jj = (uint32_t)(t - item * (size_t)(mm + 1));
+    m = mm;
+    j = jj < mm ? 2 * jj : 2 * mm;
+    t = item * (size_t)ppi + j;
+  } else {
+    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+    j = (uint32_t)(t - pair_off[item]);
+    m = (pair_off[item + 1] - pair_off[item] - 1) >> 1;
+  }
+  const uint32_t sk = sk_idx ? sk_idx[item] : 0u;           // NULL: one key for the whole batch
   G1Aff base;
   uint32_t k[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   bool negate;
   const rhip_g2* qsrc;
-  uint32_t line = RHIP_Q_WALK;
+  uint32_t line = RHIP_Q_WALK, entry = 0;
+  bool from_entry = false;
   if (j == 2 * m) {
     base = load_g1(ct_c[item].l);
     negate = true;
@@ -411,10 +422,20 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_it
       base = load_g1(sk_dj_g1[attr].l);
       negate = true;
       qsrc = ct_cy_g2 + leaf;
+      if (psel) {                               // one key: -z_e * Dj.g1 depends on the selection entry alone (k_bsw_scale_entries)
+        from_entry = true;
+        entry = e;
+        base = aff_inf<Fp>();                   // the lane still takes part in the block's inversion, with nothing to scale
+        k[0] = 1; k[1] = k[2] = k[3] = k[4] = k[5] = k[6] = k[7] = 0;
+      }
     }
   }
   bool p_inf;
-  scale_and_store(lds, active, base, k, negate, P + t, &p_inf);
+  scale_and_store(lds, active && !from_entry, base, k, negate, P + t, &p_inf);
+  if (from_entry) {
+    p_inf = psel_inf[entry] != 0;
+    if (active && !p_inf) st_g1_q(P + t, ld_g1_q(psel + entry));
+  }
   if (!active) return;
   if (line != RHIP_Q_WALK) {
     qref[t] = (p_inf || line_inf[line]) ? RHIP_Q_SKIP : line;
@@ -455,12 +476,65 @@ extern "C" int32_t rhip_bsw_sk_prepare(rhip_ctx* ctx, size_t n_sk, size_t total_
   *out = new rhip_bsw_sk_lines{l, total_attrs, n_sk};
   return RHIP_OK;
 }
+// the odd pairs of a uniform one-key batch: P = the entry's scaled key element, Q = the ciphertext's Cy.g2 (a walking pair)
+__global__ void __launch_bounds__(256, RB_MIN_WAVES) k_bsw_entry_pairs(size_t n_items, uint32_t ppi, const uint32_t* sel_start, const uint32_t* sel_ct_leaf,
+                                                                      const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const G1M* psel,
+                                                                      const uint8_t* psel_inf, G1M* P, G2M* Q, uint32_t* qref) {
+  const uint32_t m = (ppi - 1) >> 1;
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_items * (size_t)m) return;
+  const size_t item = v / m;
+  const uint32_t s_ = (uint32_t)(v % m);
+  const size_t t = item * (size_t)ppi + 2 * s_ + 1;
+  const uint32_t e = sel_start[item] + s_;
+  const G2Aff q = load_g2(ct_cy_g2[ct_leaf_off[item] + sel_ct_leaf[e]].l);
+  const bool skip = psel_inf[e] != 0 || aff_is_inf(q);
+  if (!skip) { st_g1_q(P + t, ld_g1_q(psel + e)); st_g2_q(Q + t, q); }
+  qref[t] = skip ? RHIP_Q_SKIP : RHIP_Q_WALK;
+}
+// one key for the whole batch: entry e -> -z_e * Dj.g1[sel_sk_attr[e]]
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_scale_entries(size_t n_sel, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff, const rhip_g1* sk_dj_g1,
+                                                                        G1M* psel, uint8_t* psel_inf) {
+  __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = e < n_sel;
+  if (!active) e = n_sel - 1;
+  uint32_t k[8];
+  ld_scalar(k, sel_coeff + e);
+  bool inf;
+  scale_and_store(lds, active, load_g1(sk_dj_g1[sel_sk_attr[e]].l), k, true, psel + e, &inf);
+  if (active) psel_inf[e] = inf ? 1 : 0;
+}
+static int32_t bsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                const uint32_t* sel_start, const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr,
+                                const rhip_fr* sel_coeff, const rhip_g1* ct_c, const rhip_gt* ct_cp, const rhip_g1* ct_cy_g1,
+                                const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
+                                const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
+                                const rhip_bsw_sk_lines* sk_lines, rhip_gt* out);
 extern "C" int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, const uint32_t* pair_off,
                                           const uint32_t* sel_start, const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr,
                                           const rhip_fr* sel_coeff, const rhip_g1* ct_c, const rhip_gt* ct_cp, const rhip_g1* ct_cy_g1,
                                           const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
                                           const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
                                           const rhip_bsw_sk_lines* sk_lines, rhip_gt* out) {
+  if (!sk_idx) return RHIP_ERR_ARG;
+  return bsw_decrypt_impl(ctx, n_items, max_pairs, total_pairs, 0, pair_off, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cp, ct_cy_g1, ct_cy_g2,
+                          ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2, sk_attr_off, sk_idx, sk_lines, out);
+}
+extern "C" int32_t rhip_bsw_decrypt_batch_one_sk(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                                 const uint32_t* sel_start, const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr,
+                                                 const rhip_fr* sel_coeff, const rhip_g1* ct_c, const rhip_gt* ct_cp, const rhip_g1* ct_cy_g1,
+                                                 const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
+                                                 const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const rhip_bsw_sk_lines* sk_lines, rhip_gt* out) {
+  return bsw_decrypt_impl(ctx, n_items, max_pairs, total_pairs, n_sel, pair_off, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cp, ct_cy_g1, ct_cy_g2,
+                          ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2, sk_attr_off, (const uint32_t*)nullptr, sk_lines, out);
+}
+static int32_t bsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, size_t n_sel, const uint32_t* pair_off,
+                                const uint32_t* sel_start, const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr,
+                                const rhip_fr* sel_coeff, const rhip_g1* ct_c, const rhip_gt* ct_cp, const rhip_g1* ct_cy_g1,
+                                const rhip_g2* ct_cy_g2, const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
+                                const rhip_g2* sk_dj_g2, const uint32_t* sk_attr_off, const uint32_t* sk_idx,
+                                const rhip_bsw_sk_lines* sk_lines, rhip_gt* out) {
   NEED(ctx);
   if (!n_items) return RHIP_OK;
   if (!total_pairs || !pair_off) return RHIP_ERR_ARG;
@@ -468,10 +542,26 @@ extern "C" int32_t rhip_bsw_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t 
   int32_t rc = alloc_pair_lists(ctx, total_pairs, &pl);
   if (rc) return rc;
   const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
-  KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+  G1M* psel = nullptr;
+  uint8_t* psel_inf = nullptr;
+  if (!sk_idx && n_sel && 2 * n_sel < total_pairs - n_items) {     // one key and shared entries: its scaled Dj.g1 once per entry
+    void* w_sel = nullptr;
+    rc = rhip_ensure_work(ctx, 8, n_sel * (sizeof(G1M) + 1) + 64, &w_sel);
+    if (rc) return rc;
+    psel = (G1M*)w_sel;
+    psel_inf = (uint8_t*)(psel + n_sel);
+    KLAUNCH(ctx, "k_bsw_scale_entries", k_bsw_scale_entries, dim3(blocks_for(n_sel, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_sel, sel_sk_attr, sel_coeff,
+            sk_dj_g1, psel, psel_inf);
+  }
+  const int compact = (psel && ppi >= 3) ? 1 : 0;        // uniform batch: the odd pairs are copies (k_bsw_entry_pairs), the others get the lanes
+  const size_t lanes = compact ? pair_lanes(n_items, n_items * (size_t)((ppi + 1) / 2), (ppi + 1) / 2) : pair_lanes(n_items, total_pairs, ppi);
+  KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(lanes, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
           total_pairs, pair_off, ppi, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
           sk_attr_off, sk_idx, (uint32_t)(sk_lines ? sk_lines->total_attrs : 0), sk_lines ? 1 : 0,
-          (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref);
+          (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref, (const G1M*)psel, (const uint8_t*)psel_inf, compact);
+  if (compact)
+    KLAUNCH(ctx, "k_bsw_entry_pairs", k_bsw_entry_pairs, dim3(blocks_for(n_items * (size_t)((ppi - 1) / 2), 256)), dim3(256), 0, ctx->stream, n_items, ppi, sel_start,
+            sel_ct_leaf, ct_cy_g2, ct_leaf_off, (const G1M*)psel, (const uint8_t*)psel_inf, pl.P, pl.Q, pl.qref);
   return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
 }
 

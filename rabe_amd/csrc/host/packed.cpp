@@ -588,12 +588,12 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     rhip_ctx* cx = eng.ctx();
     std::vector<uint8_t> kg1, kg2;
     for (const auto& a : sk.d_j) { kg1.insert(kg1.end(), a.g1.begin(), a.g1.end()); kg2.insert(kg2.end(), a.g2.begin(), a.g2.end()); }
-    std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.d_j.size()}, sk_idx(m_items, 0);
+    std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.d_j.size()};
     auto fz = flatten_fr(sel_z);
     DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off),
         d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_sk = up32(eng, sel_sk),
         d_sel_z = up_bytes(eng, fz), d_skd(&eng, sk.d.data(), 128), d_kg1 = up_bytes(eng, kg1), d_kg2 = up_bytes(eng, kg2),
-        d_sk_attr_off = up32(eng, sk_attr_off), d_sk_idx = up32(eng, sk_idx), d_out(&eng, m_items * 384);
+        d_sk_attr_off = up32(eng, sk_attr_off), d_out(&eng, m_items * 384);
     eng.check(rhip_upload_async(cx, d_c.ptr(), h_x, m_items * 64), "upload");
     eng.check(rhip_upload_async(cx, d_cp.ptr(), h_x + m_items * 64, m_items * 384), "upload");
     eng.check(rhip_upload_async(cx, d_g1.ptr(), h_l, total * 64), "upload");
@@ -611,10 +611,11 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       for (const auto& a : sk.d_j) key.append((const char*)a.g2.data(), 128);
       lines = (rhip_bsw_sk_lines*)eng.aux("bsw_sk_lines", key, make_sk_lines, &key, destroy_sk_lines, 4);
     }
-    int32_t rc = rhip_bsw_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(), d_sel_ct.as<uint32_t>(),
-                                        d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(), d_g1.as<rhip_g1>(),
-                                        d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(), d_kg2.as<rhip_g2>(),
-                                        d_sk_attr_off.as<uint32_t>(), d_sk_idx.as<uint32_t>(), lines, d_out.as<rhip_gt>());
+    // one key for all ciphertexts: its scaled Dj.g1 are computed once per selection entry (ciphertexts that share a policy share them)
+    int32_t rc = rhip_bsw_decrypt_batch_one_sk(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
+                                               d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(),
+                                               d_g1.as<rhip_g1>(), d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(),
+                                               d_kg2.as<rhip_g2>(), d_sk_attr_off.as<uint32_t>(), lines, d_out.as<rhip_gt>());
     h_out = h_x + m_items * 448;
     if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
     if (rc == RHIP_OK) rc = rhip_sync(cx);

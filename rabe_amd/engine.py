@@ -421,6 +421,15 @@ def bsw_decrypt_dev(eng, n_items, max_pairs, total_pairs, d_pair_off, d_sel_star
                                               _p(d_sk_attr_off), _p(d_sk_idx), _p(sk_lines), _p(d_out)))
 
 
+def bsw_decrypt_one_sk_dev(eng, n_items, max_pairs, total_pairs, n_sel, d_pair_off, d_sel_start, d_sel_ct_leaf, d_sel_sk_attr, d_sel_coeff,
+                           d_ct_c, d_ct_cp, d_ct_cy_g1, d_ct_cy_g2, d_ct_leaf_off, d_sk_d, d_sk_dj_g1, d_sk_dj_g2, d_sk_attr_off, sk_lines, d_out):
+    """every item is decrypted with the SAME key (rhip_bsw_decrypt_batch_one_sk): -z_e * Dj.g1 is computed once per selection entry"""
+    eng._check(eng.lib.rhip_bsw_decrypt_batch_one_sk(eng.ctx, _sz(n_items), _sz(max_pairs), _sz(total_pairs), _sz(n_sel), _p(d_pair_off), _p(d_sel_start),
+                                                     _p(d_sel_ct_leaf), _p(d_sel_sk_attr), _p(d_sel_coeff), _p(d_ct_c), _p(d_ct_cp), _p(d_ct_cy_g1),
+                                                     _p(d_ct_cy_g2), _p(d_ct_leaf_off), _p(d_sk_d), _p(d_sk_dj_g1), _p(d_sk_dj_g2), _p(d_sk_attr_off),
+                                                     _p(sk_lines), _p(d_out)))
+
+
 class LswPk:
     def __init__(self, eng, g1, g2):
         self.eng = eng

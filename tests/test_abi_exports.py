@@ -33,7 +33,7 @@ def test_header_declares_the_expected_surface():
                  "rabe_aw11_decrypt_batch",
                  # device-level Level B of the other three schemes and what the rabe-bn replacement crate binds
                  "rhip_bsw_pk_create", "rhip_bsw_encrypt_batch", "rhip_bsw_sk_prepare", "rhip_bsw_decrypt_batch", "rhip_lsw_pk_create",
-                 "rhip_lsw_keygen_batch", "rhip_lsw_decrypt_batch", "rhip_lsw_decrypt_batch_one_ct", "rhip_aw11_pk_create", "rhip_aw11_encrypt_batch", "rhip_aw11_decrypt_batch",
+                 "rhip_bsw_decrypt_batch_one_sk", "rhip_lsw_keygen_batch", "rhip_lsw_decrypt_batch", "rhip_lsw_decrypt_batch_one_ct", "rhip_aw11_pk_create", "rhip_aw11_encrypt_batch", "rhip_aw11_decrypt_batch",
                  "rhip_g2_lines_prepare", "rhip_host_fr_pow", "rhip_host_g1_on_curve", "rhip_host_g2_on_curve",
                  # round 3: decoding checks (fast + by-order forms), packed entry points of every scheme, LSW negative leaves, pipelining hook
                  "rhip_g2_in_subgroup", "rhip_g2_in_subgroup_by_order", "rhip_gt_is_member", "rhip_gt_is_member_by_order", "rhip_flags_all", "rhip_ghw11_transform_batch",

@@ -127,3 +127,16 @@ def test_bsw_device_decrypt_many_chunks(eng, world):
                       eng.upload_u32([0, 9, 18, 27]), eng.upload(bn.g2_to_le(sk["d"])), eng.upload(b"".join(bn.g1_to_le(d["g1"]) for d in sk["d_j"])),
                       eng.upload(b"".join(bn.g2_to_le(d["g2"]) for d in sk["d_j"])), eng.upload_u32([0, 9]), eng.upload_u32([0] * n), None, d_out)
     assert eng.download(d_out) == bn.gt_to_le(msg) * n
+    # the one-key entry point: the three items share their nine selection entries, so the key's scaled Dj.g1 are computed once per entry
+    # (9 entries, 27 key-side pairs) -- with walking and with prepared key lines
+    d_skd, d_g2s = eng.upload(bn.g2_to_le(sk["d"])), eng.upload(b"".join(bn.g2_to_le(d["g2"]) for d in sk["d_j"]))
+    lines = E.BswSkLines(eng, 1, 9, d_skd, d_g2s) if hasattr(E, "BswSkLines") else None
+    for ln in ([None, lines] if lines else [None]):
+        d_out = eng.alloc(n * 384)
+        E.bsw_decrypt_one_sk_dev(eng, n, 19, 19 * n, 9, eng.upload_u32([0, 19, 38, 57]), eng.upload_u32([0, 0, 0]), eng.upload_u32(list(range(9))),
+                                 eng.upload_u32(list(range(9))), eng.upload(b"".join(le(x) for x in z)),
+                                 eng.upload(bn.g1_to_le(ct["c"]) * n), eng.upload(bn.gt_to_le(ct["c_p"]) * n),
+                                 eng.upload(b"".join(bn.g1_to_le(y["g1"]) for y in ct["c_y"]) * n), eng.upload(b"".join(bn.g2_to_le(y["g2"]) for y in ct["c_y"]) * n),
+                                 eng.upload_u32([0, 9, 18, 27]), d_skd, eng.upload(b"".join(bn.g1_to_le(d["g1"]) for d in sk["d_j"])), d_g2s,
+                                 eng.upload_u32([0, 9]), ln, d_out)
+        assert eng.download(d_out) == bn.gt_to_le(msg) * n
