@@ -52,11 +52,11 @@ from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_sum
 #   instrumented counts of this engine's own code (tests/count_muls.py).
 SURVEY_MILLER_FPMUL = 8000          # "Miller loop (optimal ate, 65-bit loop) ~ 8 kM"
 SURVEY_MIXED_ADD_FPMUL = 11
-IMPL_MILLER_FPMUL = 8983            # tests/count_muls.py: miller_loop (NAF chain) with Jacobian P
-IMPL_MILLER2_FPMUL = 12170          # tests/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
+IMPL_MILLER_FPMUL = 8723            # tests/count_muls.py: miller_loop (NAF chain) with Jacobian P
+IMPL_MILLER2_FPMUL = 11910          # tests/count_muls.py: miller_loop_pair_parked (A replays prepared lines, B Jacobian, merged lines), two pairings
 IMPL_FINAL_EXP_FPMUL = 7553         # tests/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
-IMPL_MILLER_MULTI6_FPMUL = 30711    # tests/count_muls.py: miller_loop_multi, an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
-IMPL_MILLER_MULTI6_WALK_FPMUL = 38754   # the same with nothing prepared
+IMPL_MILLER_MULTI6_FPMUL = 29931    # tests/count_muls.py: miller_loop_multi, an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
+IMPL_MILLER_MULTI6_WALK_FPMUL = 37194   # the same with nothing prepared
 
 
 def parse_args():

@@ -407,9 +407,9 @@ class BswBench:
                 "k_table_mul_g1": (n + 1) * 352.0, "k_table_pow_gt_mul": 1700.0, "k_bsw_enc_scalars": 0.0}
 
     def impl_fpmul_per_item(self):
-        # tests/count_muls.py: miller_loop_multi 4.9 kM per pair with half of the pairs replaying prepared lines, 6.24 kM all walking
+        # tests/count_muls.py: miller_loop_multi 4.77 kM per pair with half of the pairs replaying prepared lines, 5.98 kM all walking
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
-        return {"k_miller_multi": (2 * m + 1) * (4900.0 if self.sk_lines else 6240.0), "k_bsw_dec_pairs": 2 * m * 2750.0, "k_final_exp": 7553.0 + 15 * 54}
+        return {"k_miller_multi": (2 * m + 1) * (4766.0 if self.sk_lines else 5976.0), "k_bsw_dec_pairs": 2 * m * 2750.0, "k_final_exp": 7553.0 + 15 * 54}
 
     def algorithmic_bytes_per_step(self):
         B, n = self.B, self.n_attr
@@ -609,7 +609,7 @@ class LswBench:
 
     def impl_fpmul_per_item(self):
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
-        return {"k_miller_multi": (m + 1) * 6240.0, "k_lsw_dec_pairs": m * 2750.0, "k_msm_partial_g1": m * 1080.0}
+        return {"k_miller_multi": (m + 1) * 5976.0, "k_lsw_dec_pairs": m * 2750.0, "k_msm_partial_g1": m * 1080.0}
 
     def algorithmic_bytes_per_step(self):
         return self.leaves_per_batch * (192 + 32 + 32) + self.B * (384 + 384) + self.pairs_per_batch * 4
@@ -797,7 +797,7 @@ class Aw11Bench:
 
     def impl_fpmul_per_item(self):
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
-        return {"k_miller_multi": (m + 1) * 6240.0}
+        return {"k_miller_multi": (m + 1) * 5976.0}
 
     def algorithmic_bytes_per_step(self):
         return self.rows_per_batch * (384 + 256 + 32) * 2 + self.B * (32 + 384 * 3) + self.pairs_per_batch * 4

@@ -89,12 +89,12 @@ RB_MID Fp2Pair c3_dbl_r1(int L, const G2Hom& t) {
 struct DblMid { Fp2 a, b, e, f, g, h, i, j; };
 RB_MID DblMid c3_dbl_mid(const Fp2Pair& r0, const Fp2Pair& r1, const Fp2Pair& r2) {
   DblMid m;
-  m.a = fp2_mul_fp(r0.p, fp_two_inv());            // XY/2
+  m.a = fp2_half(r0.p);                            // XY/2
   m.b = r1.p;                                      // Y^2
   const Fp2& c = r1.q;                             // Z^2
   m.e = fp2_mul(twist_b(), fp2_add(fp2_dbl(c), c));   // 3 b' Z^2   (replicated)
   m.f = fp2_add(fp2_dbl(m.e), m.e);
-  m.g = fp2_mul_fp(fp2_add(m.b, m.f), fp_two_inv());
+  m.g = fp2_half(fp2_add(m.b, m.f));
   m.h = fp2_sub(r0.q, fp2_add(m.b, c));            // 2YZ
   m.i = fp2_sub(m.e, m.b);
   m.j = r2.p;                                      // X^2

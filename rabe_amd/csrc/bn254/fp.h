@@ -251,6 +251,27 @@ RB_HD Mont<M> neg(const Mont<M>& a) {
   return r;
 }
 #endif
+// a / 2 mod m: (a + (a odd ? m : 0)) >> 1 -- a + m < 2^255, so nothing leaves the 8 limbs.  Division by two is linear, so it is the same
+// in the Montgomery domain; it stands where a multiplication by the constant 1/2 stood (the G2 doubling step: two per Fq2 halving).
+template <class M>
+RB_HD Mont<M> half(const Mont<M>& a) {
+  const uint32_t mask = 0u - (a.v[0] & 1u);
+  uint32_t t[8], u[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { t[i] = a.v[i]; u[i] = M::mod(i) & mask; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RB_SAFE_CARRY)
+  limbs_add8(t, u);
+#else
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = addc32(t[i], u[i], c);
+#endif
+  Mont<M> r;
+#pragma unroll
+  for (int i = 0; i < 7; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  r.v[7] = t[7] >> 1;
+  return r;
+}
 // 2a mod m: shift left by one, then one conditional subtraction
 template <class M>
 RB_HD Mont<M> dbl(const Mont<M>& a) {

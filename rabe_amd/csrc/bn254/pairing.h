@@ -28,13 +28,12 @@ struct LineCoeffs {
 // Doubling step: T <- 2T, returns the tangent line coefficients.  (Costello et al., as used for
 // D-type twists: cy = -2YZ, cx = 3X^2, c0 = 3b'Z^2 - Y^2.)
 RB_MID LineCoeffs g2hom_double(G2Hom& r) {
-  const Fp two_inv = fp_two_inv();
-  Fp2 a = fp2_mul_fp(fp2_mul(r.x, r.y), two_inv);
+  Fp2 a = fp2_half(fp2_mul(r.x, r.y));               // halvings by shift (fp.h: half), not by a multiplication with 1/2
   Fp2 b = fp2_sqr(r.y);
   Fp2 c = fp2_sqr(r.z);
   Fp2 e = fp2_mul(twist_b(), fp2_add(fp2_dbl(c), c));   // 3 b' Z^2
   Fp2 f = fp2_add(fp2_dbl(e), e);                       // 9 b' Z^2
-  Fp2 g = fp2_mul_fp(fp2_add(b, f), two_inv);
+  Fp2 g = fp2_half(fp2_add(b, f));
   Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));   // 2YZ
   Fp2 i = fp2_sub(e, b);
   Fp2 j = fp2_sqr(r.x);

@@ -21,6 +21,7 @@ RB_HD Fp2 fp2_add(const Fp2& a, const Fp2& b) { return Fp2{add(a.c0, b.c0), add(
 RB_HD Fp2 fp2_sub(const Fp2& a, const Fp2& b) { return Fp2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 RB_HD Fp2 fp2_neg(const Fp2& a) { return Fp2{neg(a.c0), neg(a.c1)}; }
 RB_HD Fp2 fp2_dbl(const Fp2& a) { return Fp2{dbl(a.c0), dbl(a.c1)}; }
+RB_HD Fp2 fp2_half(const Fp2& a) { return Fp2{half(a.c0), half(a.c1)}; }
 RB_HD Fp2 fp2_conj(const Fp2& a) { return Fp2{a.c0, neg(a.c1)}; }
 
 // Karatsuba: 3 Fp multiplications.  Out of line; the four Fp operands travel in 32 VGPRs.
