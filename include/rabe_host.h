@@ -139,6 +139,11 @@ int32_t rabe_bsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, c
  * n_items + 1 offsets per side, caller-allocated buffers, per-item status, ct_len / RABE_PACKED_TRUSTED for untrusted input).  These
  * feed the device-resident path (rhip_bsw_{encrypt,decrypt}_batch): share generation, fixed-base multiplications, the folded
  * pairing product and one final exponentiation per item all happen on HBM-resident arrays (src/schemes/bsw/mod.rs:217-318). */
+/* Bulk key issuing for bsw (conventions of rabe_ac17_cp_keygen_packed): n_items calls of bsw::keygen (src/schemes/bsw/mod.rs:125-152) under one
+ * master key, records = CpAbeSecretKey.  Every key element is a fixed-base multiple of a generator (d = g2_alpha/beta + g2*(r/beta)):
+ * three window-table launches for the whole batch.  An empty attribute list (for which bsw::keygen returns None) fails the call. */
+int32_t rabe_bsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, const size_t* counts, size_t n_sets,
+                               size_t n_items, const uint32_t* item_set /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                 const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
                                 uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);

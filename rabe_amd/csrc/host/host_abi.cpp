@@ -513,6 +513,17 @@ int32_t rabe_ac17_kp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_bsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, const size_t* counts, size_t n_sets,
+                               size_t n_items, const uint32_t* item_set, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets(n_sets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_sets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return bsw::keygen_packed(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, *(const bsw::CpAbeMasterKey*)msk, sets, n_items, item_set, sk_buf, sk_cap,
+                            sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                 const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
   GUARD_BEGIN

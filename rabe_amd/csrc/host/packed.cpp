@@ -361,7 +361,110 @@ void* make_sk_lines(Engine& eng, const void* arg) {          // arg: d | d_j[0].
   return lines;
 }
 void destroy_sk_lines(void* h) { rhip_bsw_sk_lines_destroy((rhip_bsw_sk_lines*)h); }
+struct GenTables { rhip_g1_table* g1 = nullptr; rhip_g2_table* g2 = nullptr; };
+void* make_gen_tables(Engine& eng, const void* arg) {
+  const CpAbePublicKey& pk = *(const CpAbePublicKey*)arg;
+  std::unique_ptr<GenTables> t(new GenTables());
+  eng.check(rhip_g1_table_create(eng.ctx(), (const rhip_g1*)pk.g1.data(), &t->g1), "rhip_g1_table_create");
+  int32_t rc = rhip_g1_table_add_w16(eng.ctx(), t->g1);
+  if (!rc) rc = rhip_g2_table_create(eng.ctx(), (const rhip_g2*)pk.g2.data(), &t->g2);
+  if (!rc) rc = rhip_g2_table_add_w16(eng.ctx(), t->g2);
+  if (rc) { rhip_g1_table_destroy(t->g1); if (t->g2) rhip_g2_table_destroy(t->g2); eng.check(rc, "generator tables"); }
+  return t.release();
+}
+void destroy_gen_tables(void* h) {
+  GenTables* t = (GenTables*)h;
+  rhip_g1_table_destroy(t->g1);
+  rhip_g2_table_destroy(t->g2);
+  delete t;
+}
 }  // namespace
+
+// n calls of bsw::keygen (bsw/mod.rs:125-152) under one master key -- a key authority issuing keys in bulk.  Item i gets the attribute list
+// sets[item_set[i]]; draw order per item: r (:130), then r_j per attribute (:142).  Record = CpAbeSecretKey: d, rows (name, g1*r_j,
+// g2*r + (g2*h(j))*r_j).  Every element is a fixed-base multiple of a generator: d = g2_alpha/beta + g2*(r/beta) (the first term is
+// computed once per call), D_j.g1 = g1*r_j, D_j.g2 = g2*(r + h(j) r_j) -- three window-table launches for the whole batch.
+bool keygen_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
+                   const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("bsw::keygen_packed");
+  Engine::ArenaScope arena(eng);
+  if (n && (!item_set || !out_off)) throw RabeError("bsw::keygen_packed: null input");
+  std::vector<size_t> fixed(sets.size());
+  std::vector<std::vector<Fr>> hashes(sets.size());
+  for (size_t s = 0; s < sets.size(); s++) {
+    if (sets[s].empty()) throw RabeError("bsw::keygen_packed: an empty attribute list (bsw::keygen returns None for it)");
+    fixed[s] = 128 + 4;
+    for (const auto& a : sets[s]) { fixed[s] += 4 + a.size() + 64 + 128; hashes[s].push_back(sha3_hash_fr(a)); }
+  }
+  for (size_t i = 0; i < n; i++) if (item_set[i] >= sets.size()) throw RabeError("bsw::keygen_packed: item_set out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_set[i]];
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  Fr beta_inv;
+  if (!fr_inv(msk.beta, &beta_inv)) throw std::runtime_error("called `Option::unwrap()` on a `None` value (Fr::inverse of zero)");
+  std::vector<size_t> row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) row_off[i + 1] = row_off[i] + sets[item_set[i]].size();
+  const size_t total = row_off[n];
+  uint8_t* h_k = eng.pinned(0, (n + 2 * total) * 32 + 32);          // r/beta per key | r_j per row | r + h(j) r_j per row
+  uint8_t* h_kd = h_k;
+  uint8_t* h_k1 = h_k + n * 32;
+  uint8_t* h_k2 = h_k1 + total * 32;
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    const Fr ri = r.next_fr();
+    const Fr kd = fr_mul(ri, beta_inv);
+    memcpy(h_kd + 32 * i, kd.l, 32);
+    const auto& hs = hashes[item_set[i]];
+    for (size_t y = 0; y < hs.size(); y++) {
+      const Fr rj = r.next_fr();
+      const Fr k2 = fr_add(ri, fr_mul(hs[y], rj));
+      memcpy(h_k1 + 32 * (row_off[i] + y), rj.l, 32);
+      memcpy(h_k2 + 32 * (row_off[i] + y), k2.l, 32);
+    }
+  });
+  tm.lap("draws + scalars");
+  const GenTables* tb;
+  {
+    std::string key((const char*)pk.g1.data(), 64);
+    key.append((const char*)pk.g2.data(), 128);
+    tb = (const GenTables*)eng.aux("bsw_gen_tables", key, make_gen_tables, &pk, destroy_gen_tables, 4);
+  }
+  const G2 a_const = eng.g2_mul({msk.g2_alpha}, {beta_inv})[0];          // g2_alpha / beta, once per call
+  std::vector<uint8_t> a_rep(n * 128);
+  for (size_t i = 0; i < n; i++) memcpy(a_rep.data() + 128 * i, a_const.data(), 128);
+  rhip_ctx* cx = eng.ctx();
+  DBuf d_kd(&eng, n * 32), d_k1(&eng, total * 32 + 4), d_k2(&eng, total * 32 + 4), d_a = up_bytes(eng, a_rep), d_dp(&eng, n * 128), d_d(&eng, n * 128),
+      d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4);
+  eng.check(rhip_upload_async(cx, d_kd.ptr(), h_kd, n * 32), "upload");
+  eng.check(rhip_upload_async(cx, d_k1.ptr(), h_k1, total * 32), "upload");
+  eng.check(rhip_upload_async(cx, d_k2.ptr(), h_k2, total * 32), "upload");
+  eng.check(rhip_g2_table_mul(cx, tb->g2, n, d_kd.as<rhip_fr>(), d_dp.as<rhip_g2>()), "rhip_g2_table_mul");
+  eng.check(rhip_g2_add(cx, n, d_a.as<rhip_g2>(), d_dp.as<rhip_g2>(), d_d.as<rhip_g2>()), "rhip_g2_add");
+  eng.check(rhip_g1_table_mul(cx, tb->g1, total, d_k1.as<rhip_fr>(), d_g1.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g2_table_mul(cx, tb->g2, total, d_k2.as<rhip_fr>(), d_g2.as<rhip_g2>()), "rhip_g2_table_mul");
+  uint8_t* h_o = eng.pinned(1, n * 128 + total * 192 + 4);
+  uint8_t* h_g1 = h_o + n * 128;
+  uint8_t* h_g2 = h_g1 + total * 64;
+  eng.check(rhip_download_async(cx, h_o, d_d.ptr(), n * 128), "download");
+  eng.check(rhip_download_async(cx, h_g1, d_g1.ptr(), total * 64), "download");
+  eng.check(rhip_download_async(cx, h_g2, d_g2.ptr(), total * 128), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const auto& attrs = sets[item_set[i]];
+    uint8_t* w = out_buf + out_off[i];
+    memcpy(w, h_o + 128 * i, 128); w += 128;
+    put_u32(w, (uint32_t)attrs.size()); w += 4;
+    for (size_t y = 0; y < attrs.size(); y++) {
+      put_u32(w, (uint32_t)attrs[y].size()); w += 4;
+      memcpy(w, attrs[y].data(), attrs[y].size()); w += attrs[y].size();
+      memcpy(w, h_g1 + 64 * (row_off[i] + y), 64); w += 64;
+      memcpy(w, h_g2 + 128 * (row_off[i] + y), 128); w += 128;
+    }
+  });
+  tm.lap("assembly");
+  return true;
+}
 
 // n calls of bsw::encrypt (bsw/mod.rs:217-251).  Draw order per item: secret (:228), msg (:229), the gate coefficients of
 // gen_shares_policy (secretsharing/mod.rs:128-134), the AES nonce (aes/mod.rs:17).  Record = CpAbeCiphertext:

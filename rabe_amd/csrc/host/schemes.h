@@ -89,6 +89,9 @@ std::vector<CpAbeCiphertext> encrypt_batch(Engine& eng, Rng& rng, const CpAbePub
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const CpAbeSecretKey*>& sks, const std::vector<const CpAbeCiphertext*>& cts);
 // the same two batches with packed input and output (packed.cpp): one blob of canonical records + offsets per side, caller-allocated
 // buffers, the device-resident Level B path (rhip_bsw_{encrypt,decrypt}_batch).  Conventions as ac17::cp_{encrypt,decrypt}_packed.
+// n keys under one master key in one call (packed.cpp): item i gets the attribute list sets[item_set[i]]; records = CpAbeSecretKey
+bool keygen_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
+                   const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,
                     const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, bool trusted,

@@ -177,3 +177,31 @@ def test_aw11_packed_equals_object_api_and_round_trips(host):
     raw[c0:c0 + 384] = b"".join((11 + i).to_bytes(32, "little") for i in range(12))
     out, out_off, status = aw11.decrypt_packed(host, gk, sk, bytes(raw), ct_off)
     assert list(status) == [0, 0, -1, 0, 0, 0, 0, 0, 0]
+
+
+def test_bsw_packed_keygen_equals_object_keygen_on_the_same_tape(host):
+    """rabe_bsw_keygen_packed: n keys in one call (three window-table launches: d = g2_alpha/beta + g2*(r/beta), g1*r_j, g2*(r + h(j) r_j)) =
+    n calls of bsw::keygen on the same randomness, byte for byte; the keys decrypt; an empty attribute list fails the call."""
+    from rabe_amd.schemes import bsw
+    pk, msk = bsw.setup(host)
+    sets = [["A", "B"], ["A", "B", "C", "D"], ["C"]]
+    item_set = [0, 1, 2, 1, 0, 1, 2, 0, 1]
+    n = len(item_set)
+    tape = [1000003 * (i + 13) + 23 for i in range(6 * n)]                  # r, then r_j per attribute, per item
+    host.set_tape(tape)
+    objs = [bsw.keygen(host, pk, msk, sets[s]) for s in item_set]
+    host.set_tape(tape)
+    blob, off = bsw.keygen_packed(host, pk, msk, sets, item_set)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    ct = bsw.encrypt(host, pk, '"A" and ("C" or "D")', hl.HUMAN_POLICY, b"bulk bsw keys")
+    for i in (1, 3):
+        assert bsw.decrypt(host, hl.Obj.deserialize("bsw_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"bulk bsw keys"
+    with pytest.raises(hl.RabeError):
+        bsw.keygen_packed(host, pk, msk, [["A"], []], [0, 1])
+    attrs = ["a%d" % i for i in range(100)]
+    blob, off = bsw.keygen_packed(host, pk, msk, [attrs, attrs[:40]], np.arange(1500, dtype=np.uint32) % 2)
+    ct = bsw.encrypt(host, pk, " and ".join('"a%d"' % i for i in (1, 7, 13, 19, 39)), hl.HUMAN_POLICY, b"x" * 40)
+    for i in (0, 1, 1498, 1499):
+        assert bsw.decrypt(host, hl.Obj.deserialize("bsw_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"x" * 40
