@@ -190,6 +190,12 @@ int32_t rabe_aw11_decrypt_batch(rabe_host* h, const void* gk, size_t n, const vo
 /* Packed forms over the device-resident path (rhip_aw11_{encrypt,decrypt}_batch; src/schemes/aw11/mod.rs:241-366), conventions as
  * rabe_ac17_cp_{encrypt,decrypt}_packed.  Every policy leaf must name an attribute of one of the authority keys (the reference drops
  * other rows silently, :269-271; rabe_aw11_encrypt reproduces that). */
+/* Bulk key issuing by one authority (conventions of rabe_ac17_cp_keygen_packed): n_items calls of aw11::keygen (src/schemes/aw11/mod.rs:165-231),
+ * user gids[i] gets the attribute list item_set[i]; records = Aw11SecretKey.  No randomness: K_x = g1 * (alpha_x + h(gid) y_x), one
+ * window-table launch for the whole batch. */
+int32_t rabe_aw11_keygen_packed(rabe_host* h, const void* gk, const void* msk, const char* const* gids /*[n_items]*/, const char* const* attributes,
+                                const size_t* counts, size_t n_sets, size_t n_items, const uint32_t* item_set /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap,
+                                uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* const* policies, size_t n_policies,
                                  int32_t language, size_t n_items, const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob,
                                  const uint64_t* pt_off /*[n_items+1]*/, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);

@@ -579,6 +579,17 @@ int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, co
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_aw11_keygen_packed(rabe_host* h, const void* gk, const void* msk, const char* const* gids, const char* const* attributes, const size_t* counts,
+                                size_t n_sets, size_t n_items, const uint32_t* item_set, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets(n_sets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_sets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return aw11::keygen_packed(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11MasterKey*)msk, strs(gids, n_items), sets, n_items, item_set, sk_buf,
+                             sk_cap, sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
 int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* const* policies, size_t n_policies,
                                  int32_t language, size_t n_items, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off,
                                  uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {

@@ -1158,6 +1158,89 @@ bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::v
   return true;
 }
 
+namespace {
+void* make_g1_table(Engine& eng, const void* arg) {
+  const G1& g1 = *(const G1*)arg;
+  rhip_g1_table* t = nullptr;
+  eng.check(rhip_g1_table_create(eng.ctx(), (const rhip_g1*)g1.data(), &t), "rhip_g1_table_create");
+  const int32_t rc = rhip_g1_table_add_w16(eng.ctx(), t);
+  if (rc) { rhip_g1_table_destroy(t); eng.check(rc, "rhip_g1_table_add_w16"); }
+  return t;
+}
+void destroy_g1_table(void* h) { rhip_g1_table_destroy((rhip_g1_table*)h); }
+}  // namespace
+// n calls of aw11::keygen (aw11/mod.rs:165-231) by ONE authority: user i (gids[i]) gets the attribute list sets[item_set[i]].  No randomness:
+// K_x = g1*alpha_x + H(gid)*y_x with H(gid) = g1*h(gid) is g1*(alpha_x + h(gid) y_x) -- one window-table launch for the whole batch.
+// Record = Aw11SecretKey: gid, rows (upper-cased attribute name, K_x).  An attribute the authority does not own is the reference's
+// unwrap panic (:213); an empty gid or list its RabeError.
+bool keygen_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::vector<std::string>& gids,
+                   const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("aw11::keygen_packed");
+  Engine::ArenaScope arena(eng);
+  if (n && (!item_set || !out_off)) throw RabeError("aw11::keygen_packed: null input");
+  if (gids.size() != n) throw RabeError("aw11::keygen_packed: one gid per item");
+  std::vector<std::vector<const Aw11MkAttr*>> auth(sets.size());
+  std::vector<std::vector<std::string>> names(sets.size());
+  std::vector<size_t> fixed(sets.size());
+  for (size_t s = 0; s < sets.size(); s++) {
+    if (sets[s].empty()) throw RabeError("empty _attributes");
+    fixed[s] = 4 + 4;
+    for (const auto& a : sets[s]) {
+      if (a.empty()) throw RabeError("empty _attributes");
+      const Aw11MkAttr* hit = nullptr;
+      for (const auto& m : msk.attr) if (m.name == a) { hit = &m; break; }
+      if (!hit) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
+      auth[s].push_back(hit);
+      names[s].push_back(upper(hit->name));
+      fixed[s] += 4 + names[s].back().size() + 64;
+    }
+  }
+  for (size_t i = 0; i < n; i++) {
+    if (item_set[i] >= sets.size()) throw RabeError("aw11::keygen_packed: item_set out of range");
+    if (gids[i].empty()) throw RabeError("empty _name");
+  }
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_set[i]] + gids[i].size();
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  std::vector<size_t> row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) row_off[i + 1] = row_off[i] + sets[item_set[i]].size();
+  const size_t total = row_off[n];
+  uint8_t* h_k = eng.pinned(0, total * 32 + 32);
+  parallel_for(n, [&](size_t i) {
+    const Fr hg = sha3_hash_fr(gids[i]);
+    const auto& au = auth[item_set[i]];
+    for (size_t y = 0; y < au.size(); y++) {
+      const Fr k = fr_add(au[y]->alpha, fr_mul(hg, au[y]->y));
+      memcpy(h_k + 32 * (row_off[i] + y), k.l, 32);
+    }
+  });
+  tm.lap("scalars");
+  const rhip_g1_table* tb = (const rhip_g1_table*)eng.aux("aw11_g1_table", std::string((const char*)gk.g1.data(), 64), make_g1_table, &gk.g1, destroy_g1_table, 4);
+  rhip_ctx* cx = eng.ctx();
+  DBuf d_k(&eng, total * 32 + 4), d_out(&eng, total * 64 + 4);
+  eng.check(rhip_upload_async(cx, d_k.ptr(), h_k, total * 32), "upload");
+  eng.check(rhip_g1_table_mul(cx, tb, total, d_k.as<rhip_fr>(), d_out.as<rhip_g1>()), "rhip_g1_table_mul");
+  uint8_t* h_o = eng.pinned(1, total * 64 + 4);
+  eng.check(rhip_download_async(cx, h_o, d_out.ptr(), total * 64), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const auto& nm = names[item_set[i]];
+    uint8_t* w = out_buf + out_off[i];
+    put_u32(w, (uint32_t)gids[i].size()); w += 4;
+    memcpy(w, gids[i].data(), gids[i].size()); w += gids[i].size();
+    put_u32(w, (uint32_t)nm.size()); w += 4;
+    for (size_t y = 0; y < nm.size(); y++) {
+      put_u32(w, (uint32_t)nm[y].size()); w += 4;
+      memcpy(w, nm[y].data(), nm[y].size()); w += nm[y].size();
+      memcpy(w, h_o + 64 * (row_off[i] + y), 64); w += 64;
+    }
+  });
+  tm.lap("assembly");
+  return true;
+}
+
 // n calls of aw11::decrypt (aw11/mod.rs:298-366) with one key.  Per distinct policy: traverse_policy, calc_pruned, and per pruned
 // (name, name_col) the FIRST key attribute named `name`, the FIRST ciphertext row named name_col (literal spelling, :325-333) and the
 // FIRST coefficient named name_col.

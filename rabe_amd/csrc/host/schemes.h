@@ -150,6 +150,9 @@ std::vector<Aw11Ciphertext> encrypt_batch(Engine& eng, Rng& rng, const Aw11Globa
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const Aw11GlobalKey& gk, const std::vector<const Aw11SecretKey*>& sks,
                                          const std::vector<const Aw11Ciphertext*>& cts);
 // packed forms (packed.cpp) over rhip_aw11_{encrypt,decrypt}_batch; conventions as ac17::cp_{encrypt,decrypt}_packed
+// n keys issued by one authority in one call (packed.cpp): user gids[i] gets the attribute list sets[item_set[i]]; records = Aw11SecretKey
+bool keygen_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& msk, const std::vector<std::string>& gids,
+                   const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::vector<const Aw11PublicKey*>& pks, const std::vector<std::string>& policies,
                     PolicyLanguage language, size_t n, const uint32_t* item_policy, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf,
                     size_t out_cap, uint64_t* out_off);

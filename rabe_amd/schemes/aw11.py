@@ -73,3 +73,25 @@ def encrypt_packed(host, gk, pks, policies, item_policy, pt_blob, pt_off, langua
 def decrypt_packed(host, gk, sk, ct_blob, ct_off, out=None, trusted=False):
     from ..hostlib import packed_decrypt
     return packed_decrypt(host, "rabe_aw11_decrypt_packed", (gk.ptr, sk.ptr), ct_blob, ct_off, out, trusted)
+
+
+def keygen_packed(host, gk, msk, gids, attr_sets, item_set, out=None):
+    """n keys issued by one authority (rabe_aw11_keygen_packed): user gids[i] gets attr_sets[item_set[i]].
+    Returns (sk_blob: numpy uint8 view of the Aw11SecretKey records, sk_off: numpy uint64 [n+1])."""
+    import numpy as np
+    from ..hostlib import _check, _np_ptr, _strs
+    n = len(item_set)
+    garr, _ = _strs(list(gids))
+    arr, _ = _strs([a for s_ in attr_sets for a in s_])
+    counts = (ctypes.c_size_t * max(len(attr_sets), 1))(*[len(s_) for s_ in attr_sets])
+    it = np.ascontiguousarray(item_set, dtype=np.uint32)
+    so = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_aw11_keygen_packed(host.h, gk.ptr, msk.ptr, garr, arr, counts, ctypes.c_size_t(len(attr_sets)), ctypes.c_size_t(n), _np_ptr(it),
+                                              _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(so))
+        if rc != 1:
+            break
+        buf = np.empty(int(so[n]), dtype=np.uint8)
+    _check(rc, host.h)
+    return buf[:int(so[n])], so

@@ -205,3 +205,30 @@ def test_bsw_packed_keygen_equals_object_keygen_on_the_same_tape(host):
     ct = bsw.encrypt(host, pk, " and ".join('"a%d"' % i for i in (1, 7, 13, 19, 39)), hl.HUMAN_POLICY, b"x" * 40)
     for i in (0, 1, 1498, 1499):
         assert bsw.decrypt(host, hl.Obj.deserialize("bsw_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"x" * 40
+
+
+def test_aw11_packed_keygen_equals_object_keygen(host):
+    """rabe_aw11_keygen_packed: n users' keys from one authority in one call (K_x = g1 * (alpha_x + h(gid) y_x): one window-table launch) =
+    n calls of aw11::keygen, byte for byte (no randomness involved); the keys decrypt; an attribute of another authority fails the call."""
+    from rabe_amd.schemes import aw11
+    gk = aw11.setup(host)
+    pk1, msk1 = aw11.authgen(host, gk, ["A", "B", "C", "D"])
+    sets = [["A", "B"], ["A", "B", "C", "D"], ["C"]]
+    item_set = [0, 1, 2, 1, 0, 1]
+    gids = ["user-%d" % i for i in range(len(item_set))]
+    objs = [aw11.keygen(host, gk, msk1, gids[i], sets[s]) for i, s in enumerate(item_set)]
+    blob, off = aw11.keygen_packed(host, gk, msk1, gids, sets, item_set)
+    for i in range(len(item_set)):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    ct = aw11.encrypt(host, gk, [pk1], '{"name": "and", "children": [{"name": "A"}, {"name": "or", "children": [{"name": "C"}, {"name": "D"}]}]}',
+                      hl.JSON_POLICY, b"bulk aw11 keys")
+    for i in (1, 3):
+        assert aw11.decrypt(host, gk, hl.Obj.deserialize("aw11_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"bulk aw11 keys"
+    with pytest.raises(hl.RabePanic):
+        aw11.keygen_packed(host, gk, msk1, ["x"], [["E"]], [0])            # not this authority's attribute: the reference's unwrap panic (:213)
+    with pytest.raises(hl.RabeError):
+        aw11.keygen_packed(host, gk, msk1, [""], [["A"]], [0])
+    n = 3000
+    blob, off = aw11.keygen_packed(host, gk, msk1, ["u%05d" % i for i in range(n)], sets, np.arange(n, dtype=np.uint32) % 3)
+    k = aw11.keygen(host, gk, msk1, "u02998", sets[2998 % 3])
+    assert k.serialize() == blob[int(off[2998]):int(off[2999])].tobytes()
