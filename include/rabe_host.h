@@ -167,6 +167,12 @@ int32_t rabe_lsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, c
  * rabe_ac17_cp_{encrypt,decrypt}_packed.  keygen handles negative leaves ("!x", lsw/mod.rs:137-146) on the device as well; a decrypt
  * whose pruned selection reaches a negative attribute fails that item -- the reference's own decrypt has no negative branch (a TODO,
  * :265-278), and rabe_lsw_decrypt reproduces what it does instead. */
+/* n_items calls of lsw::encrypt (src/schemes/lsw/mod.rs:180-219), item i under the attribute list item_set[i] of the n_sets lists given once;
+ * records = KpAbeCiphertext (conventions of rabe_ac17_cp_encrypt_packed).  Every element is a fixed-base multiple of a public-key element
+ * (the reference's sx[0] index quirk :197-200 included): window-table launches for the whole batch. */
+int32_t rabe_lsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                const uint32_t* item_set /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
+                                uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);
 int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language,
                                size_t n_items, const uint32_t* item_policy /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, const uint8_t* sk_blob, size_t sk_len,

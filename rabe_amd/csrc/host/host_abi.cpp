@@ -551,6 +551,16 @@ int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, co
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_lsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* attributes, const size_t* counts, size_t n_sets, size_t n_items,
+                                const uint32_t* item_set, const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets(n_sets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_sets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return lsw::encrypt_packed(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, sets, n_items, item_set, pt_blob, pt_off, ct_buf, ct_cap, ct_off) ? 0 : 1;
+  GUARD_END(h)
+}
 int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                const uint32_t* item_policy, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
   GUARD_BEGIN

@@ -762,6 +762,158 @@ void* make_e2_lines(Engine& eng, const void* arg) {
 void destroy_e2_lines(void* h) { rhip_g2_lines_destroy((rhip_g2_lines*)h); }
 }  // namespace
 
+namespace {
+struct EncTables { rhip_g1_table* g1 = nullptr; rhip_g1_table* g1_b = nullptr; rhip_g1_table* g1_b2 = nullptr; rhip_g1_table* h_b = nullptr;
+                   rhip_g2_table* g2 = nullptr; rhip_gt_table* egg = nullptr; };
+void destroy_enc_tables(void* h) {
+  EncTables* t = (EncTables*)h;
+  if (t->g1) rhip_g1_table_destroy(t->g1);
+  if (t->g1_b) rhip_g1_table_destroy(t->g1_b);
+  if (t->g1_b2) rhip_g1_table_destroy(t->g1_b2);
+  if (t->h_b) rhip_g1_table_destroy(t->h_b);
+  if (t->g2) rhip_g2_table_destroy(t->g2);
+  if (t->egg) rhip_gt_table_destroy(t->egg);
+  delete t;
+}
+void* make_enc_tables(Engine& eng, const void* arg) {
+  const KpAbePublicKey& pk = *(const KpAbePublicKey*)arg;
+  EncTables* t = new EncTables();
+  rhip_ctx* cx = eng.ctx();
+  int32_t rc = rhip_g1_table_create(cx, (const rhip_g1*)pk.g1.data(), &t->g1);
+  if (!rc) rc = rhip_g1_table_add_w16(cx, t->g1);
+  if (!rc) rc = rhip_g1_table_create(cx, (const rhip_g1*)pk.g1_b.data(), &t->g1_b);
+  if (!rc) rc = rhip_g1_table_add_w16(cx, t->g1_b);
+  if (!rc) rc = rhip_g1_table_create(cx, (const rhip_g1*)pk.g1_b2.data(), &t->g1_b2);
+  if (!rc) rc = rhip_g1_table_add_w16(cx, t->g1_b2);
+  if (!rc) rc = rhip_g1_table_create(cx, (const rhip_g1*)pk.h_b.data(), &t->h_b);
+  if (!rc) rc = rhip_g1_table_add_w16(cx, t->h_b);
+  if (!rc) rc = rhip_g2_table_create(cx, (const rhip_g2*)pk.g2.data(), &t->g2);
+  if (!rc) rc = rhip_g2_table_add_w16(cx, t->g2);
+  if (!rc) rc = rhip_gt_table_create(cx, (const rhip_gt*)pk.e_gg_alpha.data(), &t->egg);
+  if (!rc) rc = rhip_gt_table_add_w16(cx, t->egg);
+  if (rc) { destroy_enc_tables(t); eng.check(rc, "lsw public-key tables"); }
+  return t;
+}
+}  // namespace
+// n calls of lsw::encrypt (lsw/mod.rs:180-219): item i under the attribute list sets[item_set[i]].  Draw order per item: secret (:188), one
+// sx per attribute (:196-200, with the reference's index quirk: sx[0] loses sx[i], not the new element), the message exponent, the nonce.
+// Record = KpAbeCiphertext: e1 = e_gg_alpha^secret * msg, e2 = g2*secret, rows (name, g1*(h(a) secret), g1_b*sx_i, g1_b2*(sx_i h(a)) + h_b*sx_i),
+// sealed plaintext.  Every element is a fixed-base multiple of a public-key element: window-table launches for the whole batch.
+bool encrypt_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set,
+                    const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("lsw::encrypt_packed");
+  Engine::ArenaScope arena(eng);
+  if (n && (!item_set || !pt_off || !out_off)) throw RabeError("lsw::encrypt_packed: null input");
+  std::vector<size_t> fixed(sets.size());
+  std::vector<std::vector<Fr>> hashes(sets.size());
+  for (size_t s = 0; s < sets.size(); s++) {
+    if (sets[s].empty()) throw RabeError("attributes or data empty");
+    fixed[s] = 384 + 128 + 4 + 4;
+    for (const auto& a : sets[s]) { fixed[s] += 4 + a.size() + 3 * 64; hashes[s].push_back(sha3_hash_fr(a)); }
+  }
+  for (size_t i = 0; i < n; i++) {
+    if (item_set[i] >= sets.size()) throw RabeError("lsw::encrypt_packed: item_set out of range");
+    if (pt_off[i + 1] <= pt_off[i]) throw RabeError("attributes or data empty");
+  }
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + fixed[item_set[i]] + (pt_off[i + 1] - pt_off[i]) + 28;
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  std::vector<size_t> row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) row_off[i + 1] = row_off[i] + sets[item_set[i]].size();
+  const size_t total = row_off[n];
+  // scalars: per item secret | msg exponent; per row h*secret | sx_i | sx_i*h
+  uint8_t* h_k = eng.pinned(0, (2 * n + 3 * total) * 32 + 32);
+  uint8_t* h_sec = h_k;
+  uint8_t* h_rho = h_sec + n * 32;
+  uint8_t* h_a = h_rho + n * 32;
+  uint8_t* h_b = h_a + total * 32;
+  uint8_t* h_c = h_b + total * 32;
+  std::vector<std::array<uint8_t, 12>> nonces(n);
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    const Fr secret = r.next_fr();
+    const auto& hs = hashes[item_set[i]];
+    std::vector<Fr> sx{secret};
+    for (size_t y = 0; y < hs.size(); y++) {
+      sx.push_back(r.next_fr());
+      sx[0] = fr_sub(sx[0], sx[y]);                 // :197-200 as it is written
+    }
+    for (size_t y = 0; y < hs.size(); y++) {
+      const Fr a = fr_mul(hs[y], secret), c = fr_mul(sx[y], hs[y]);
+      memcpy(h_a + 32 * (row_off[i] + y), a.l, 32);
+      memcpy(h_b + 32 * (row_off[i] + y), sx[y].l, 32);
+      memcpy(h_c + 32 * (row_off[i] + y), c.l, 32);
+    }
+    const Fr rho = r.next_fr();
+    memcpy(h_sec + 32 * i, secret.l, 32);
+    memcpy(h_rho + 32 * i, rho.l, 32);
+    r.fill(nonces[i].data(), 12);
+  });
+  tm.lap("draws + scalars");
+  const EncTables* tb;
+  {
+    std::string key((const char*)pk.g1.data(), 64);
+    key.append((const char*)pk.g2.data(), 128).append((const char*)pk.g1_b.data(), 64).append((const char*)pk.g1_b2.data(), 64).append((const char*)pk.h_b.data(), 64);
+    key.append((const char*)pk.e_gg_alpha.data(), 384);
+    tb = (const EncTables*)eng.aux("lsw_enc_tables", key, make_enc_tables, &pk, destroy_enc_tables, 2);
+  }
+  rhip_gt_table* gen = eng.gt_generator_table();
+  rhip_ctx* cx = eng.ctx();
+  DBuf d_k(&eng, (2 * n + 3 * total) * 32 + 4), d_msg(&eng, n * 384), d_pw(&eng, n * 384), d_e1(&eng, n * 384), d_e2(&eng, n * 128), d_r1(&eng, total * 64 + 4),
+      d_r2(&eng, total * 64 + 4), d_t1(&eng, total * 64 + 4), d_t2(&eng, total * 64 + 4), d_r3(&eng, total * 64 + 4);
+  eng.check(rhip_upload_async(cx, d_k.ptr(), h_k, (2 * n + 3 * total) * 32), "upload");
+  const rhip_fr* k_sec = d_k.as<rhip_fr>();
+  const rhip_fr* k_rho = k_sec + n;
+  const rhip_fr* k_a = k_rho + n;
+  const rhip_fr* k_b = k_a + total;
+  const rhip_fr* k_c = k_b + total;
+  eng.check(rhip_gt_table_pow(cx, gen, n, k_rho, d_msg.as<rhip_gt>()), "rhip_gt_table_pow");                 // rng.gen::<Gt>() = e(g1, g2)^rho
+  eng.check(rhip_gt_table_pow(cx, tb->egg, n, k_sec, d_pw.as<rhip_gt>()), "rhip_gt_table_pow");
+  eng.check(rhip_gt_mul(cx, n, d_pw.as<rhip_gt>(), d_msg.as<rhip_gt>(), d_e1.as<rhip_gt>()), "rhip_gt_mul");
+  eng.check(rhip_g2_table_mul(cx, tb->g2, n, k_sec, d_e2.as<rhip_g2>()), "rhip_g2_table_mul");
+  eng.check(rhip_g1_table_mul(cx, tb->g1, total, k_a, d_r1.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_table_mul(cx, tb->g1_b, total, k_b, d_r2.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_table_mul(cx, tb->g1_b2, total, k_c, d_t1.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_table_mul(cx, tb->h_b, total, k_b, d_t2.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_add(cx, total, d_t1.as<rhip_g1>(), d_t2.as<rhip_g1>(), d_r3.as<rhip_g1>()), "rhip_g1_add");
+  uint8_t* h_o = eng.pinned(1, n * (384 + 384 + 128) + total * 192 + 4);
+  uint8_t* h_e1 = h_o;
+  uint8_t* h_msg = h_e1 + n * 384;
+  uint8_t* h_e2 = h_msg + n * 384;
+  uint8_t* h_r1 = h_e2 + n * 128;
+  uint8_t* h_r2 = h_r1 + total * 64;
+  uint8_t* h_r3 = h_r2 + total * 64;
+  eng.check(rhip_download_async(cx, h_e1, d_e1.ptr(), n * 384), "download");
+  eng.check(rhip_download_async(cx, h_msg, d_msg.ptr(), n * 384), "download");
+  eng.check(rhip_download_async(cx, h_e2, d_e2.ptr(), n * 128), "download");
+  eng.check(rhip_download_async(cx, h_r1, d_r1.ptr(), total * 64), "download");
+  eng.check(rhip_download_async(cx, h_r2, d_r2.ptr(), total * 64), "download");
+  eng.check(rhip_download_async(cx, h_r3, d_r3.ptr(), total * 64), "download");
+  eng.check(rhip_sync(cx), "rhip_sync");
+  tm.lap("device + copies");
+  parallel_for(n, [&](size_t i) {
+    const auto& attrs = sets[item_set[i]];
+    uint8_t* w = out_buf + out_off[i];
+    memcpy(w, h_e1 + 384 * i, 384); w += 384;
+    memcpy(w, h_e2 + 128 * i, 128); w += 128;
+    put_u32(w, (uint32_t)attrs.size()); w += 4;
+    for (size_t y = 0; y < attrs.size(); y++) {
+      const size_t row = row_off[i] + y;
+      put_u32(w, (uint32_t)attrs[y].size()); w += 4;
+      memcpy(w, attrs[y].data(), attrs[y].size()); w += attrs[y].size();
+      memcpy(w, h_r1 + 64 * row, 64); w += 64;
+      memcpy(w, h_r2 + 64 * row, 64); w += 64;
+      memcpy(w, h_r3 + 64 * row, 64); w += 64;
+    }
+    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
+    put_u32(w, (uint32_t)(len + 28)); w += 4;
+    Bytes sealed = encrypt_symmetric(h_msg + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
+    memcpy(w, sealed.data(), sealed.size());
+  });
+  tm.lap("assembly + AES");
+  return true;
+}
+
 // n calls of lsw::keygen (lsw/mod.rs:121-170).  Draw order per item: the gate coefficients of gen_shares_policy(alpha1), then one
 // `random` per share (:136).  Record = KpAbeSecretKey: policy text, language, leaf count, per leaf (name, d1, d2, d3, d4, d5) with
 // d3..d5 the identity for positive leaves and d1, d2 the identity for negative ones ("!x", :137-146: rhip_lsw_keygen_batch_signed).

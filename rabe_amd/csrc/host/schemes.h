@@ -118,6 +118,9 @@ std::vector<KpAbeSecretKey> keygen_batch(Engine& eng, Rng& rng, const KpAbePubli
 std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const KpAbeSecretKey*>& sks, const std::vector<const KpAbeCiphertext*>& cts);
 // packed forms (packed.cpp) over rhip_lsw_{keygen,decrypt}_batch: n keys as one blob of KpAbeSecretKey records; decrypt takes the n keys
 // and ONE ciphertext (BASELINE config 4).  Positive attributes only -- policies / selections with "!x" take the object API.
+// n ciphertexts in one call (packed.cpp): item i under the attribute list sets[item_set[i]]; records = KpAbeCiphertext
+bool encrypt_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set,
+                    const uint8_t* pt_blob, const uint64_t* pt_off, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeMasterKey& msk, const std::vector<std::string>& policies,
                    PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint8_t* sk_blob, size_t sk_len, const uint64_t* sk_off, bool trusted,

@@ -55,3 +55,26 @@ def decrypt_packed(host, ct, sk_blob, sk_off, out=None, trusted=False):
     """n keys against ONE ciphertext object -> (pt_blob, pt_off, status)"""
     from ..hostlib import packed_decrypt
     return packed_decrypt(host, "rabe_lsw_decrypt_packed", (ct.ptr,), sk_blob, sk_off, out, trusted)
+
+
+def encrypt_packed(host, pk, attr_sets, item_set, pt_blob, pt_off, out=None):
+    """n encrypts (rabe_lsw_encrypt_packed): item i under the attribute list attr_sets[item_set[i]]; records = KpAbeCiphertext.
+    Returns (ct_blob view, ct_off uint64 [n+1])."""
+    import numpy as np
+    from ..hostlib import _as_u8, _check, _np_ptr, _strs
+    n = len(item_set)
+    arr, _ = _strs([a for s_ in attr_sets for a in s_])
+    counts = (ctypes.c_size_t * max(len(attr_sets), 1))(*[len(s_) for s_ in attr_sets])
+    it = np.ascontiguousarray(item_set, dtype=np.uint32)
+    po = np.ascontiguousarray(pt_off, dtype=np.uint64)
+    pt = _as_u8(pt_blob)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_lsw_encrypt_packed(host.h, pk.ptr, arr, counts, ctypes.c_size_t(len(attr_sets)), ctypes.c_size_t(n), _np_ptr(it), _np_ptr(pt),
+                                              _np_ptr(po), _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(co))
+        if rc != 1:
+            break
+        buf = np.empty(int(co[n]), dtype=np.uint8)
+    _check(rc, host.h)
+    return buf[:int(co[n])], co

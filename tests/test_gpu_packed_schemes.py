@@ -232,3 +232,37 @@ def test_aw11_packed_keygen_equals_object_keygen(host):
     blob, off = aw11.keygen_packed(host, gk, msk1, ["u%05d" % i for i in range(n)], sets, np.arange(n, dtype=np.uint32) % 3)
     k = aw11.keygen(host, gk, msk1, "u02998", sets[2998 % 3])
     assert k.serialize() == blob[int(off[2998]):int(off[2999])].tobytes()
+
+
+def test_lsw_packed_encrypt_equals_object_encrypt_on_the_same_tape(host):
+    """rabe_lsw_encrypt_packed: n ciphertexts in one call (window-table launches over the public key's elements, the reference's sx[0] quirk
+    included) = n calls of lsw::encrypt on the same randomness, byte for byte; keys decrypt them, packed and object-wise."""
+    from rabe_amd.schemes import lsw
+    pk, msk = lsw.setup(host)
+    sets = [["A", "B"], ["A", "B", "C", "D"], ["C"]]
+    item_set = [0, 1, 2, 1, 0, 1, 2]
+    n = len(item_set)
+    pts = [b"lsw packed plaintext %d " % i * (i % 3 + 1) for i in range(n)]
+    tape = [1000003 * (i + 17) + 31 for i in range(8 * n)]                  # secret, sx per attribute, msg exponent, nonce per item
+    host.set_tape(tape)
+    objs = [lsw.encrypt(host, pk, sets[s], pts[i]) for i, s in enumerate(item_set)]
+    host.set_tape(tape)
+    blob, off = lsw.encrypt_packed(host, pk, sets, item_set, b"".join(pts), offsets(pts))
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    sk = lsw.keygen(host, pk, msk, '{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}', hl.JSON_POLICY)
+    for i in (0, 1, 3):
+        assert lsw.decrypt(host, sk, hl.Obj.deserialize("lsw_ct", blob[int(off[i]):int(off[i + 1])].tobytes())) == pts[i]
+    with pytest.raises(hl.RabeError):
+        lsw.encrypt_packed(host, pk, [["A"], []], [0, 1], b"xy", [0, 1, 2])             # `attributes or data empty` (:185)
+    with pytest.raises(hl.RabeError):
+        lsw.encrypt_packed(host, pk, [["A"]], [0, 0], b"x", [0, 1, 1])                  # an empty plaintext
+    # a bulk run on OS randomness: every ciphertext opens with a key whose policy its attributes satisfy
+    attrs = ["a%d" % i for i in range(60)]
+    m = 1200
+    big = [b"p%04d" % i for i in range(m)]
+    blob, off = lsw.encrypt_packed(host, pk, [attrs, attrs[:30]], np.arange(m, dtype=np.uint32) % 2, b"".join(big), offsets(big))
+    sk = lsw.keygen(host, pk, msk, '{"name": "and", "children": [{"name": "a3"}, {"name": "or", "children": [{"name": "a29"}, {"name": "zz"}]}]}', hl.JSON_POLICY)
+    for i in (0, 1, m - 2, m - 1):
+        assert lsw.decrypt(host, sk, hl.Obj.deserialize("lsw_ct", blob[int(off[i]):int(off[i + 1])].tobytes())) == big[i]
