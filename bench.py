@@ -45,7 +45,7 @@ for _i, _a in enumerate(sys.argv):
     elif _a.startswith("--hw-queues="):
         os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
 
-from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, same_on_all_ranks, split_steps, timed_regions  # noqa: E402
+from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, same_on_all_ranks, split_steps, timed_regions  # noqa: E402
 
 # Algorithmic work, in Fp multiplications (1 Fp mul = 136 32x32 multiply-adds: 8-limb CIOS), per lane:
 #   SURVEY.md 8d constants (the "algorithmic minimum" the roofline is priced against) and the
@@ -156,7 +156,7 @@ def main():
     local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     if args.config != 2:
-        from rabe_amd import bench_schemes
+        from benchkit import schemes as bench_schemes
         return bench_schemes.run(args, world, rank, local_rank)
 
     from rabe_amd import Engine

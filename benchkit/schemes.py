@@ -12,7 +12,7 @@ import os
 import random
 import time
 
-from rabe_amd.benchlib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, split_steps, timed_regions
+from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, split_steps, timed_regions
 
 
 def run(args, world, rank, local_rank):

@@ -452,6 +452,55 @@ int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
                                 const uint32_t* dev_sk_attr_off /*[n_sk+1]*/, const uint32_t* dev_sk_idx /*[n_items] or NULL*/,
                                 rhip_gt* dev_out /*[n_items]*/);
 
+/* ---- Level S: the KEM -> DEM step and label hashing on the device (rabe_amd/csrc/engine_sym.hip) ------------------------------
+ * Replaces, for batches, src/utils/aes/mod.rs:10-55 (`encrypt_symmetric` :10, `decrypt_symmetric` :29, `kdf` :47: key = SHA3-256(bytes(Gt)),
+ * AES-256-GCM, sealed form = nonce(12) || ciphertext || tag(16)) and src/utils/hash/mod.rs:10-31 (`sha3_hash_fr`: Fr::from_slice(SHA3-256)).
+ * The Gt of an encrypt / decrypt stays in HBM; only plaintext and record bytes cross PCIe.  No memory table is indexed by a secret
+ * (the AES S-box lives in a register of the wave and is read through the lane crossbar).
+ *
+ * Offsets are byte offsets into the named blob; dev_len[i] = plaintext length of item i.  The host states the shape of the batch:
+ * dev_blk_off[n+1] = prefix sums of ceil(len/16) (one lane per 16-byte block), dev_seg_off[n+1] = prefix sums of ceil(blocks/64) (GHASH runs
+ * per 64-block segment, folded with powers of H).  dev_ws: rhip_seal_workspace_bytes(n, total_segments) bytes of device scratch. */
+/* SHA3-256 (FIPS 202) of n byte strings data[off[i] .. off[i+1]); digests 32 bytes each */
+int32_t rhip_sha3_256_batch(rhip_ctx* ctx, size_t n, const uint8_t* dev_data, const uint64_t* dev_off /*[n+1]*/, uint8_t* dev_digest /*[n][32]*/);
+/* hash/mod.rs:23-31 sha3_hash_fr: the digest as a big-endian integer reduced mod r, canonical little-endian rhip_fr */
+int32_t rhip_sha3_fr_batch(rhip_ctx* ctx, size_t n, const uint8_t* dev_data, const uint64_t* dev_off /*[n+1]*/, rhip_fr* dev_out /*[n]*/);
+/* aes/mod.rs:47-55 kdf: key_i = SHA3-256(bytes(gt[idx ? idx[i] : i])), bytes = 12 coefficients as 32 big-endian bytes each */
+int32_t rhip_gt_kdf_batch(rhip_ctx* ctx, size_t n, const rhip_gt* dev_gt, const uint32_t* dev_gt_idx /*[n] or NULL*/, uint8_t* dev_keys /*[n][32]*/);
+/* AES-256 (FIPS 197) of n blocks under n keys (known-answer tests) */
+int32_t rhip_aes256_encrypt_blocks(rhip_ctx* ctx, size_t n, const uint8_t* dev_keys /*[n][32]*/, const uint8_t* dev_in /*[n][16]*/, uint8_t* dev_out /*[n][16]*/);
+size_t rhip_seal_workspace_bytes(size_t n, size_t total_segments);
+/* AES-256-GCM (SP 800-38D; 96-bit nonce, no AAD) with explicit keys.  seal != 0: in = plaintext at dev_in_off[i], out = nonce || ct || tag at
+ * dev_out_off[i] (len_prefix != 0 also writes the u32 length len + 28 in the four bytes BEFORE it: the record's length field);
+ * seal == 0: in = the sealed bytes at dev_in_off[i] (nonce read from there), out = plaintext at dev_out_off[i], dev_ok[i] = tag verified
+ * (a failed item's plaintext bytes are zeros). */
+int32_t rhip_aes256_gcm_batch(rhip_ctx* ctx, int32_t seal, size_t n, const uint8_t* dev_keys /*[n][32]*/, const uint8_t* dev_nonce /*[n][12], seal only*/,
+                              const uint8_t* dev_in, const uint64_t* dev_in_off /*[n]*/, uint8_t* dev_out, const uint64_t* dev_out_off /*[n]*/,
+                              const uint32_t* dev_len /*[n]*/, const uint32_t* dev_blk_off /*[n+1]*/, size_t total_blocks,
+                              const uint32_t* dev_seg_off /*[n+1]*/, size_t total_segments, int32_t len_prefix, uint32_t* dev_ok /*[n], open only*/,
+                              void* dev_ws);
+/* n calls of encrypt_symmetric(gt_i, plaintext_i) with explicit nonces (the reference draws them from thread_rng, aes/mod.rs:17) */
+int32_t rhip_seal_batch(rhip_ctx* ctx, size_t n, const rhip_gt* dev_gt /*[n]*/, const uint8_t* dev_nonce /*[n][12]*/, const uint8_t* dev_pt,
+                        const uint64_t* dev_pt_off /*[n]*/, uint8_t* dev_out, const uint64_t* dev_sealed_off /*[n]*/, const uint32_t* dev_len /*[n]*/,
+                        const uint32_t* dev_blk_off /*[n+1]*/, size_t total_blocks, const uint32_t* dev_seg_off /*[n+1]*/, size_t total_segments,
+                        int32_t len_prefix, void* dev_ws);
+/* n calls of decrypt_symmetric(gt[idx ? idx[i] : i], sealed_i); dev_len[i] = sealed length - 28 */
+int32_t rhip_open_batch(rhip_ctx* ctx, size_t n, const rhip_gt* dev_gt, const uint32_t* dev_gt_idx /*[n] or NULL*/, const uint8_t* dev_blob,
+                        const uint64_t* dev_sealed_off /*[n]*/, uint8_t* dev_pt, const uint64_t* dev_pt_off /*[n]*/, const uint32_t* dev_len /*[n]*/,
+                        const uint32_t* dev_blk_off /*[n+1]*/, size_t total_blocks, const uint32_t* dev_seg_off /*[n+1]*/, size_t total_segments,
+                        uint32_t* dev_ok /*[n]*/, void* dev_ws);
+/* Records of a batch written from their parts on the device (the struct layouts of src/schemes/ac17/mod.rs:58-135 etc. in the canonical byte
+ * form of rabe_obj_serialize): byte b of item i's record = dev_map[dev_layout_off[dev_layout[i]] + b], where a map word 0xFF0000vv is the
+ * literal byte vv (policy text, names, counts -- one template per distinct policy) and k << 24 | o is byte o of item i's part in source
+ * k: dev_src[k] + dev_src_item_off[k * n + i].  rhip_gather_parts is the reverse for a decrypt: part p of a layout copies dev_part_len[p]
+ * bytes from record offset dev_part_src[p] to dev_dst[dev_part_k[p]] + dev_dst_item_off[k * n + i] + dev_part_dst[p]. */
+int32_t rhip_assemble_records(rhip_ctx* ctx, size_t n, uint8_t* dev_out, const uint64_t* dev_out_off /*[n]*/, const uint32_t* dev_layout /*[n]*/,
+                              const uint32_t* dev_layout_off, const uint32_t* dev_map, uint32_t n_src, const uint8_t* const* dev_src,
+                              const uint64_t* dev_src_item_off /*[n_src][n]*/);
+int32_t rhip_gather_parts(rhip_ctx* ctx, size_t n, const uint8_t* dev_blob, const uint64_t* dev_rec_off /*[n]*/, const uint32_t* dev_layout /*[n]*/,
+                          const uint32_t* dev_layout_off, const uint32_t* dev_part_src, const uint32_t* dev_part_dst, const uint32_t* dev_part_len,
+                          const uint32_t* dev_part_k, uint8_t* const* dev_dst, const uint64_t* dev_dst_item_off /*[n_dst][n]*/);
+
 /* ---- measurement helper: integer-multiply issue-rate microbenchmark (the roofline denominator) --
  * Runs `iters` dependent-free v_mad_u64_u32 per lane on every CU and returns elapsed milliseconds
  * and the number of multiply-adds executed. */

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
-SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "host", "schemes.cpp"),
+SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_sym.hip"),
+           os.path.join(CSRC, "host", "schemes.cpp"),
            os.path.join(CSRC, "host", "host_abi.cpp"), os.path.join(CSRC, "host", "packed.cpp"),
            os.path.join(CSRC, "host", "pipeline.cpp")]
 

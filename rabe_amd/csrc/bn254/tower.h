@@ -226,6 +226,9 @@ struct Fp12 {
 };
 RB_HD Fp12 fp12_one() { return Fp12{fp6_one(), fp6_zero()}; }
 RB_HD bool fp12_eq(const Fp12& a, const Fp12& b) { return fp6_eq(a.c0, b.c0) & fp6_eq(a.c1, b.c1); }
+RB_HD bool fp12_is_zero(const Fp12& a) {
+  return fp2_is_zero(a.c0.a0) & fp2_is_zero(a.c0.a1) & fp2_is_zero(a.c0.a2) & fp2_is_zero(a.c1.a0) & fp2_is_zero(a.c1.a1) & fp2_is_zero(a.c1.a2);
+}
 RB_HD Fp12 fp12_conj(const Fp12& a) { return Fp12{a.c0, fp6_neg(a.c1)}; }
 
 RB_MID Fp12 fp12_mul(const Fp12& a, const Fp12& b) {

@@ -12,6 +12,8 @@
 //   k_g2_prepare_lines, k_ac17_dec_miller2       the same with a prepared key: two pairings per lane on one accumulator
 //   k_*_c3                                        three cooperating lanes per pairing (small launches)
 // There is no CPU fallback anywhere in this file: without a HIP device every entry point fails.
+#include <mutex>
+#include <set>
 #include "engine_internal.h"
 
 
@@ -77,6 +79,9 @@ int32_t rhip_ensure_work(rhip_ctx* ctx, int slot, size_t bytes, void** out) {
 }
 
 static std::string g_create_err;   // diagnostics for a failed rhip_ctx_create (no ctx exists yet)
+// live contexts: rhip_ctx_release_before_final_exp stores a pointer to ANOTHER context, which may be destroyed first
+static std::mutex g_live_mu;
+static std::set<rhip_ctx*> g_live;
 static int32_t create_fail(const char* what, hipError_t e) {
   g_create_err = std::string(what) + ": " + hipGetErrorString(e);
   return RHIP_ERR_NO_DEVICE;
@@ -102,11 +107,20 @@ extern "C" int32_t rhip_ctx_create(int32_t device, rhip_ctx** out) {
   e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return create_fail("hipStreamCreateWithFlags", e); }
   c->stream = c->own_stream;
+  {
+    std::lock_guard<std::mutex> g(g_live_mu);
+    g_live.insert(c);
+  }
   *out = c;
   return RHIP_OK;
 }
 extern "C" void rhip_ctx_destroy(rhip_ctx* ctx) {
   if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> g(g_live_mu);          // nobody keeps waiting for (or releasing) a context that is going away
+    g_live.erase(ctx);
+    for (rhip_ctx* o : g_live) if (o->fe_waiter == ctx) o->fe_waiter = nullptr;
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -228,7 +242,9 @@ extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* de
 // set) then run beside it instead of behind it.  One-shot; without a following pairing launch nothing is held.
 extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter) {
   if (!ctx || ctx == waiter) return RHIP_ERR_ARG;
-  ctx->fe_waiter = waiter;          // NULL withdraws a pending request (e.g. before the waiter's context is destroyed)
+  std::lock_guard<std::mutex> g(g_live_mu);
+  if (waiter && !g_live.count(waiter)) return RHIP_ERR_ARG;
+  ctx->fe_waiter = waiter;          // NULL withdraws a pending request; rhip_ctx_destroy(waiter) withdraws it too
   return RHIP_OK;
 }
 extern "C" int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other) {
@@ -1102,9 +1118,11 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
   if (rc) return rc;
   uint32_t* started = nullptr;
   const size_t blocks = blocks_for(n_items, RB_FE_BLOCK);
-  if (ctx->fe_waiter) {                     // rhip_ctx_release_before_final_exp: the other context's stream goes on from here
-    rhip_ctx* w = ctx->fe_waiter;
-    ctx->fe_waiter = nullptr;
+  std::unique_lock<std::mutex> live(g_live_mu);          // the waiter cannot be destroyed while its stream is being touched
+  rhip_ctx* w = ctx->fe_waiter;
+  ctx->fe_waiter = nullptr;
+  if (w && !g_live.count(w)) w = nullptr;
+  if (w) {                                  // rhip_ctx_release_before_final_exp: the other context's stream goes on from here
     if (!ctx->fe_started) HIP_TRY(ctx, hipMalloc((void**)&ctx->fe_started, 256));
     started = (uint32_t*)ctx->fe_started;
     HIP_TRY(ctx, hipMemsetAsync(started, 0, 4, ctx->stream));
@@ -1118,6 +1136,7 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
     const uint32_t target = (uint32_t)(blocks < (size_t)ctx->n_cu ? blocks : (size_t)ctx->n_cu);
     hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
   }
+  live.unlock();
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks), dim3(RB_FE_BLOCK), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
           (uint32_t*)ctx->fe_ws, lanes, started);
   return RHIP_OK;

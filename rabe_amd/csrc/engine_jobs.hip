@@ -1483,7 +1483,8 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_is_member(size_t n, con
   const Fp12 f = load_gt(a[i].l);
   const Fp12 f2 = fp12_frob_fn(f, 2);
   const Fp12 f4 = fp12_frob_fn(f2, 2);
-  bool good = wire_words_canonical(a[i].l, 12) && fp12_eq(fp12_mul_fn(f4, f), f2);
+  // 0 satisfies both Frobenius identities (every map here sends 0 to 0) but is not a unit: rejected first, as f^r = 1 rejects it
+  bool good = wire_words_canonical(a[i].l, 12) && !fp12_is_zero(f) && fp12_eq(fp12_mul_fn(f4, f), f2);
   if (good) {
     if (mode == 1) {
       uint32_t k[8];

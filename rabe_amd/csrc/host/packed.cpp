@@ -596,7 +596,7 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
         for (size_t y = 0; y < pl->flat->leaf_name_col.size(); y++)
           if (pl->flat->leaf_name_col[y] == pr.second) pl->ent.push_back({pr.second, (uint32_t)dj, pl->flat->leaf_coeff[y], (uint32_t)std_row});
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       pl->err = ex.what();
       if (pl->err.empty()) pl->err = "policy error";
     }
@@ -638,7 +638,7 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
           v[i].ct_row.push_back(y);               // y == rows: no such row -> the entry is skipped below
         }
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       (*errors)[i] = ex.what();
       if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
     }
@@ -1052,7 +1052,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
         if (cr == ct.ej.size() || co == pl->flat->leaf_name_col.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
         pl->ent.push_back({a.first, (uint32_t)cr, pl->flat->leaf_coeff[co], (uint32_t)sr});
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       pl->err = ex.what();
       if (pl->err.empty()) pl->err = "policy error";
     }
@@ -1090,7 +1090,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
       } else {
         for (const auto& e : pl->ent) if (e.std_sk_row >= rows) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       (*errors)[i] = ex.what();
       if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
     }
@@ -1433,7 +1433,7 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
         if (sr == sk.attr.size() || co == pl->flat->leaf_name_col.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
         pl->ent.push_back({cur.second, (uint32_t)sr, pl->flat->leaf_coeff[co], (uint32_t)cr});
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       pl->err = ex.what();
       if (pl->err.empty()) pl->err = "policy error";
     }
@@ -1470,7 +1470,7 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
         if (y >= rows) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
         if (!standard) v[i].ct_row.push_back(y);
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       (*errors)[i] = ex.what();
       if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
     }
@@ -1618,11 +1618,9 @@ bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const 
         if (a == tk.attr_key_z.size() || co == names.size()) throw std::runtime_error("called `Option::unwrap()` on a `None` value");
         pl->ent.push_back({cur.second, (uint32_t)a, pl->flat->leaf_coeff[co], (uint32_t)co});
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       pl->err = ex.what();
       if (pl->err.empty()) pl->err = "policy error";
-    } catch (const std::runtime_error& ex) {
-      pl->err = ex.what();
     }
     plans[key] = pl;
     return pl;
@@ -1662,7 +1660,7 @@ bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const 
           v[i].ct_row.push_back(y);
         }
       }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       (*errors)[i] = ex.what();
       if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
     }

@@ -1149,7 +1149,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
       }
       for (const auto& cur : e->lst)
         for (size_t r = 0; r < core.k.size(); r++) if (core.k[r].first == cur.first) e->sk_sel.push_back((uint32_t)r);
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       e->err = ex.what();
       if (e->err.empty()) e->err = "policy error";
     }
@@ -1224,7 +1224,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
       }
       if (shared) v[i].ct_sel = &pp->ct_sel;
       else { select(&v[i].own_sel); v[i].ct_sel = &v[i].own_sel; }
-    } catch (const RabeError& ex) {
+    } catch (const std::exception& ex) {
       (*errors)[i] = ex.what();
       if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
     }

@@ -226,7 +226,7 @@ def decrypt_symmetric(gt, data):
     return _take_bytes(p, n)
 
 
-# ------------------------------------------------------------------ parser of the canonical byte form (tests compare it with the oracle)
+# ------------------------------------------------------------------ parser of the canonical byte form (the tests compare it with the CPU checker)
 class Reader:
     def __init__(self, b):
         self.b, self.o = b, 0

@@ -8,7 +8,7 @@ What the reference does on the host before and after its group loops, restated f
 Policies here are already-parsed trees: ("leaf", name) | ("and", [l, r]) | ("or", [children...]);
 `to_json` renders the reference's JSON policy language (src/json.policy.pest) for the same tree.
 The full text parsers live in the C++ host layer (rabe_amd/csrc/host/) -- this module is the
-benchmark's / tests' plumbing and does not import oracle/.
+benchmark's / tests' plumbing and imports nothing of the CPU checker.
 """
 import hashlib
 

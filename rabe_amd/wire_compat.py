@@ -5,10 +5,11 @@ group elements inside are rabe-bn's own serde forms -- whose layout is unknown h
 the converter that needs nothing but that layout: it walks rabe's struct shapes (field names and tuple positions as the reference
 declares them) and hands every Fr / G1 / G2 / Gt it meets to an ELEMENT CODEC -- `dec(kind, serde_value) -> canonical bytes` and
 `enc(kind, canonical bytes) -> serde_value`.  tests/refpin.py learns such a codec from the vectors integration/ref-harness dumps from
-real rabe (`Source("serde")` after `learn`); `codec_from_source` wraps it.  So the day `tests/golden/ref_*.json` exist:
+real rabe (`Source("serde")` after `learn`); tests/wire_codec.py wraps that into a codec.  The codec is always an ARGUMENT here: this
+module imports neither the CPU checker nor the test suite.  So the day `tests/golden/ref_*.json` exist:
 
     src = refpin.Source("serde"); ...learn...                     (tests/test_ref_pin.py does this)
-    dec, enc = wire_compat.codec_from_source(src, samples)
+    dec, enc = tests.wire_codec.codec_from_source(src, samples)
     blob = wire_compat.to_canonical("ac17_cp_ct", json.loads(rabe_json), dec)      # -> hostlib.Obj.deserialize / *_decrypt_packed
     back = wire_compat.from_canonical("ac17_cp_ct", blob, enc)                     # -> serde_json::from_str on the rabe side
 
@@ -197,56 +198,6 @@ def from_canonical(kind, data, enc):
     return out
 
 
-# ------------------------------------------------------------------------------------------------ element codecs
-def _shape_of(v):
-    """nesting of a serde element value, for re-filling: ints become None"""
-    if isinstance(v, list):
-        return [_shape_of(x) for x in v]
-    if isinstance(v, dict):
-        return {k: _shape_of(x) for k, x in v.items()}
-    return None
-
-
-def _fill(shape, it):
-    if isinstance(shape, list):
-        return [_fill(x, it) for x in shape]
-    if isinstance(shape, dict):
-        return {k: _fill(x, it) for k, x in shape.items()}
-    return next(it)
-
-
-def codec_from_source(src, samples, zeros=None):
-    """(dec, enc) over a tests/refpin.py Source whose layouts have been learnt.  `samples`: {kind: one serde element value of that kind}
-    (any element of the dumped vectors) -- its nesting and integer width are the template `enc` fills.  `zeros`: {kind: the serde value
-    of the group's identity} (ref_primitives.json: group_ops.g1_zero / g2_zero), emitted verbatim for an all-zero canonical element."""
-    from oracle import bn254 as bn
-    from tests import refpin as rp
-    to_le = {FR: lambda v: int(v).to_bytes(32, "little"), G1: bn.g1_to_le, G2: bn.g2_to_le, GT: bn.gt_to_le}
-    from_le = {FR: lambda b: int.from_bytes(b, "little"), G1: bn.g1_from_le, G2: bn.g2_from_le, GT: bn.gt_from_le}
-    templates = {}
-    for kind, sample in samples.items():
-        ints = rp.flatten_ints(sample)
-        lay = src.layout[kind]
-        templates[kind] = (_shape_of(sample), (32 * lay.n_fe) // len(ints))          # bytes per integer of the serde form
-
-    def dec(kind, value):
-        return to_le[kind](src.decode(kind, {"serde": value, "borsh": ""}))
-
-    def enc(kind, canon):
-        if kind in (G1, G2) and canon == bytes(len(canon)):
-            if not zeros or kind not in zeros:
-                raise ValueError("identity element of %s: pass its serde form in `zeros`" % kind)
-            return zeros[kind]
-        lay = src.layout[kind]
-        el = rp.encode_element(kind, from_le[kind](canon), lay.fe, lay.shape if kind in (G1, G2) else "affine",
-                               order=(lay.order[1] if lay.order else None))
-        raw = bytes.fromhex(el["borsh"])
-        shape, width = templates[kind]
-        ints = [int.from_bytes(raw[i:i + width], "little") for i in range(0, len(raw), width)]
-        return _fill(shape, iter(ints))
-    return dec, enc
-
-
 # ------------------------------------------------------------------------------------------------ borsh form of the same structs
 def _borsh_to_canon(shape, r, dec, size, w):
     if isinstance(shape, str) and shape in SIZE:
@@ -310,7 +261,7 @@ def _canon_to_borsh(shape, r, enc, w):
 
 
 def to_canonical_borsh(kind, data, codec):
-    """borsh bytes of a rabe struct -> canonical record.  codec = (dec, enc, size) of `borsh_codec_from_source`."""
+    """borsh bytes of a rabe struct -> canonical record.  codec = (dec, enc, size), e.g. of tests/wire_codec.py `borsh_codec_from_source`."""
     dec, _enc, size = codec
     r, w = _R(data), _W()
     _borsh_to_canon(SHAPES[kind], r, dec, size, w)
@@ -327,31 +278,6 @@ def from_canonical_borsh(kind, data, codec):
     if r.o != len(r.b):
         raise ValueError("trailing bytes after the canonical record")
     return bytes(w.b)
-
-
-def borsh_codec_from_source(src, samples, zeros=None):
-    """(dec, enc, size) over a tests/refpin.py Source("borsh") whose layouts have been learnt.  `samples`: {kind: hex of one borsh element}
-    (its length is the kind's size on the wire, a length prefix included if the crate writes one); `zeros`: {kind: hex of the identity}."""
-    from oracle import bn254 as bn
-    from tests import refpin as rp
-    to_le = {FR: lambda v: int(v).to_bytes(32, "little"), G1: bn.g1_to_le, G2: bn.g2_to_le, GT: bn.gt_to_le}
-    from_le = {FR: lambda b: int.from_bytes(b, "little"), G1: bn.g1_from_le, G2: bn.g2_from_le, GT: bn.gt_from_le}
-    size = {k: len(bytes.fromhex(v)) for k, v in samples.items()}
-    prefixed = {k: size[k] == 32 * src.layout[k].n_fe + 4 for k in size}
-
-    def dec(kind, raw):
-        return to_le[kind](src.decode(kind, {"borsh": bytes(raw).hex(), "serde": None}))
-
-    def enc(kind, canon):
-        if kind in (G1, G2) and canon == bytes(len(canon)):
-            if not zeros or kind not in zeros:
-                raise ValueError("identity element of %s: pass its borsh form in `zeros`" % kind)
-            return bytes.fromhex(zeros[kind])
-        lay = src.layout[kind]
-        el = rp.encode_element(kind, from_le[kind](canon), lay.fe, lay.shape if kind in (G1, G2) else "affine",
-                               order=(lay.order[1] if lay.order else None), prefix=prefixed[kind])
-        return bytes.fromhex(el["borsh"])
-    return dec, enc, size
 
 
 # ------------------------------------------------------------------------------------------------ rabe-console's file envelope

@@ -138,3 +138,81 @@ def test_corrupted_records_fail_alone(host, trusted):
                 assert st[i] == 0 and out[i].tobytes() == good[i], i
             else:
                 assert st[i] in (0, -1)
+
+
+# ---------------------------------------------------------------- targeted damage (errors that are not RabeError)
+def _head(rec):
+    plen = int.from_bytes(rec[:4], "little")
+    return plen, 4 + plen + 1                             # policy length, offset of what follows (policy text, language byte)
+
+
+def rename_first_row(rec, fixed):
+    """the name of the first row (it follows `fixed` bytes of elements and the row count) gets another first letter: the record stays
+    well-formed, but the name the policy asks for is gone -- the reference's `.unwrap()` on a `None` (a panic there, -1 here)"""
+    b = bytearray(rec)
+    _plen, o = _head(rec)
+    o += fixed + 4
+    nlen = int.from_bytes(b[o:o + 4], "little")
+    assert 0 < nlen < 32
+    b[o + 4] = ord("Z")
+    return bytes(b)
+
+
+def with_policy(rec, text, lang_byte=None):
+    """the same record under another policy text"""
+    plen, o = _head(rec)
+    raw = text.encode()
+    lang = rec[4 + plen:4 + plen + 1] if lang_byte is None else bytes([lang_byte])
+    return len(raw).to_bytes(4, "little") + raw + lang + rec[o:]
+
+
+PANIC_JSON = ['{"name": "and", "children": [{"name": "A"}]}',          # a gate with a single child (secretsharing/mod.rs:167,187)
+              '{"name": "or", "children": [{"name": 7}, {"name": "A"}]}',   # a numeric leaf (pest/json.rs:14-17: unwrap on an atomic rule)
+              '{"name": "and"']                                          # not a policy at all
+
+
+@pytest.mark.parametrize("trusted", [False, True], ids=["checked", "trusted"])
+def test_a_renamed_row_or_a_panicking_policy_fails_alone(host, trusted):
+    from rabe_amd.schemes import aw11, bsw, lsw
+    n = 20                                                   # > 16: the host's parallel_for takes its threaded path
+    pts = [PT + bytes([i]) for i in range(n)]
+    victims = {3: "rename", 7: 0, 11: 1, 17: 2, 19: "rename"}
+
+    def damage(recs, fixed):
+        out = list(recs)
+        for i, how in victims.items():
+            out[i] = rename_first_row(recs[i], fixed) if how == "rename" else with_policy(recs[i], PANIC_JSON[how], 0)
+        return b"".join(out), offsets(out)
+
+    def expect(st, plains, want):
+        for i in range(n):
+            if i in victims:
+                assert st[i] == -1, (i, victims[i], st[i])
+            else:
+                assert st[i] == 0 and plains[i] == want[i], i
+
+    jpols = ['{"name": "and", "children": [{"name": "A"}, {"name": "B"}]}', '{"name": "and", "children": [{"name": "A"}, {"name": "C"}]}']
+    # ---- BSW ciphertext: policy, language, c (64), c_p (384), rows
+    pk, msk = bsw.setup(host)
+    blob, off = bsw.encrypt_packed(host, pk, jpols, [i % 2 for i in range(n)], b"".join(pts), offsets(pts), hl.JSON_POLICY)
+    sk = bsw.keygen(host, pk, msk, ["A", "B", "C"])
+    b, o = damage(split(blob, off, n), 64 + 384)
+    out, oo, st = bsw.decrypt_packed(host, sk, b, o, trusted=trusted)
+    expect(st, split(out, oo, n), pts)
+    # ---- LSW key record: policy, language, rows
+    pk, msk = lsw.setup(host)
+    blob, off = lsw.keygen_packed(host, pk, msk, jpols, [i % 2 for i in range(n)], hl.JSON_POLICY)
+    ct = lsw.encrypt(host, pk, ["A", "B", "C"], PT)
+    b, o = damage(split(blob, off, n), 0)
+    out, oo, st = lsw.decrypt_packed(host, ct, b, o, trusted=trusted)
+    expect(st, split(out, oo, n), [PT] * n)
+    # ---- AW11 ciphertext: policy, language, c_0 (384), rows
+    gk = aw11.setup(host)
+    pk1, msk1 = aw11.authgen(host, gk, ["A", "B"])
+    pk2, msk2 = aw11.authgen(host, gk, ["C"])
+    blob, off = aw11.encrypt_packed(host, gk, [pk1, pk2], jpols, [i % 2 for i in range(n)], b"".join(pts), offsets(pts), hl.JSON_POLICY)
+    sk = aw11.keygen(host, gk, msk1, "alice", ["A", "B"])
+    aw11.add_to_attribute(host, gk, msk2, "C", sk)
+    b, o = damage(split(blob, off, n), 384)
+    out, oo, st = aw11.decrypt_packed(host, gk, sk, b, o, trusted=trusted)
+    expect(st, split(out, oo, n), pts)

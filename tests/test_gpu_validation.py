@@ -169,6 +169,7 @@ def test_fast_gt_membership_test_agrees_with_the_order_test():
     c0 = int.from_bytes(raw[0][:32], "little")
     if c0 + bn.P < 1 << 256:
         raw.append((c0 + bn.P).to_bytes(32, "little") + raw[0][32:])              # a member with a non-canonical first coefficient
+    raw.append(bytes(384))                                                          # 0: every Frobenius identity holds for it, yet it is no unit
     want = [1] * 7 + [0] * 6 + [0] * 4 + [0] * 4 + [0] * (len(raw) - 21)
     eng = Engine(0)
     d = eng.upload(b"".join(raw))

@@ -250,11 +250,12 @@ def check_wire(sch_j, prim, srcs):
     prefixes and the enum's variant index are the converter's claims about borsh)."""
     from rabe_amd import hostlib as hl
     from rabe_amd import wire_compat as wc
+    from tests import wire_codec as wcodec
     one = lambda key: prim[key][1]["out"]
     samples = {"fr": one("fr_from_str"), "g1": one("g1_mul"), "g2": one("g2_mul"), "gt": one("gt_pow")}
     zeros = {"g1": prim["group_ops"]["g1_zero"], "g2": prim["group_ops"]["g2_zero"]}
-    dec, enc = wc.codec_from_source(srcs["serde"], {k: v["serde"] for k, v in samples.items()}, {k: v["serde"] for k, v in zeros.items()})
-    codec = wc.borsh_codec_from_source(srcs["borsh"], {k: v["borsh"] for k, v in samples.items()}, {k: v["borsh"] for k, v in zeros.items()}) \
+    dec, enc = wcodec.codec_from_source(srcs["serde"], {k: v["serde"] for k, v in samples.items()}, {k: v["serde"] for k, v in zeros.items()})
+    codec = wcodec.borsh_codec_from_source(srcs["borsh"], {k: v["borsh"] for k, v in samples.items()}, {k: v["borsh"] for k, v in zeros.items()}) \
         if "borsh" in srcs else None
     table = [("ac17", "pk", "ac17_pk"), ("ac17", "msk", "ac17_msk"), ("ac17", "cp_sk", "ac17_cp_sk"), ("ac17", "cp_ct", "ac17_cp_ct"),
              ("ac17", "kp_sk", "ac17_kp_sk"), ("ac17", "kp_ct", "ac17_kp_ct"), ("bsw", "pk", "bsw_pk"), ("bsw", "msk", "bsw_msk"), ("bsw", "sk", "bsw_sk"),

@@ -14,6 +14,7 @@ from oracle import schemes as sch
 from oracle.tape import SeededRng
 from rabe_amd import hostlib as hl
 from rabe_amd import wire_compat as wc
+from tests import wire_codec as wcodec
 from tests import refpin as rp
 from tests import test_ref_pin as trp
 
@@ -31,7 +32,7 @@ def world(request):
     samples = {"fr": prim["fr_from_str"][1]["out"]["serde"], "g1": prim["g1_mul"][1]["out"]["serde"], "g2": prim["g2_mul"][1]["out"]["serde"],
                "gt": prim["gt_pow"][1]["out"]["serde"]}
     zeros = {"g1": prim["group_ops"]["g1_zero"]["serde"], "g2": prim["group_ops"]["g2_zero"]["serde"]}
-    dec, enc = wc.codec_from_source(src, samples, zeros)
+    dec, enc = wcodec.codec_from_source(src, samples, zeros)
     S = lambda kind, v: e[kind](v)["serde"]
     Z1, Z2 = zeros["g1"], zeros["g2"]
     from tests.test_host_kats import aes256_gcm
@@ -96,7 +97,7 @@ def world(request):
     bsamples = {"fr": prim["fr_from_str"][1]["out"]["borsh"], "g1": prim["g1_mul"][1]["out"]["borsh"], "g2": prim["g2_mul"][1]["out"]["borsh"],
                 "gt": prim["gt_pow"][1]["out"]["borsh"]}
     bzeros = {"g1": prim["group_ops"]["g1_zero"]["borsh"], "g2": prim["group_ops"]["g2_zero"]["borsh"]}
-    borsh = wc.borsh_codec_from_source(srcs["borsh"], bsamples, bzeros)
+    borsh = wcodec.borsh_codec_from_source(srcs["borsh"], bsamples, bzeros)
     return (dec, enc), json.loads(json.dumps(objs)), layout["g_shape"] == "affine", borsh
 
 
