@@ -45,7 +45,7 @@ for _i, _a in enumerate(sys.argv):
     elif _a.startswith("--hw-queues="):
         os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
 
-from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, same_on_all_ranks, split_steps, timed_regions  # noqa: E402
+from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, cpu_model, regions_summary, same_on_all_ranks, split_steps, timed_regions  # noqa: E402
 
 # Algorithmic work, in Fp multiplications (1 Fp mul = 136 32x32 multiply-adds: 8-limb CIOS), per lane:
 #   SURVEY.md 8d constants (the "algorithmic minimum" the roofline is priced against) and the
@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--policies", type=int, default=16)
     ap.add_argument("--tree", default="flat", choices=["flat", "nested", "mixed"],
                     help="configs 3-5: shape of the access tree (flat n-ary AND / balanced binary ANDs / AND over two-leaf ORs)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="a batch of mixed shapes: every policy draws its leaf count from 10 .. --attrs (config 2: rows per ciphertext, configs 3: pairs per item)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--group", type=int, default=16, help="steps submitted as ONE launch set (their batches are contiguous in HBM)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -213,7 +215,14 @@ def main():
 
     # ---------------------------------------------------------------- policies (host: parse/MSP/prune are string work)
     prnd = random.Random(args.seed)          # the same policies on every rank
-    trees = [hp.random_binary_tree(attrs, prnd) for _ in range(args.policies)]
+    if args.ragged:                          # a batch of mixed shapes: every policy over 10 .. --attrs of the attributes
+        trees = []
+        for _ in range(args.policies):
+            names = list(attrs)
+            prnd.shuffle(names)
+            trees.append(hp.random_binary_tree(names[:prnd.randrange(10, len(attrs) + 1)], prnd))
+    else:
+        trees = [hp.random_binary_tree(attrs, prnd) for _ in range(args.policies)]
     t_prep = time.perf_counter()
     tables, sels, pol_rows, nnz = [], [], [], []
     for t in trees:
@@ -238,7 +247,8 @@ def main():
         assert sum(sizes) == args.steps
     G = max(sizes)
     GB = G * B
-    item_pol = [i % args.policies for i in range(GB)]
+    # ragged: the items of one policy are contiguous inside every step's batch (a caller that batches mixed shapes groups them)
+    item_pol = [((i % B) * args.policies // B) if args.ragged else i % args.policies for i in range(GB)]
     ct_row_off = [0]
     ct_sel_all, sk_sel_all, ct_sel_off, sk_sel_off = [], [], [0], [0]
     for i in range(GB):
@@ -684,16 +694,22 @@ def configs_leg(args):
     env = dict(os.environ)
     for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k_, None)
-    for cfg, steps in ((3, 4), (4, 4), (5, 8)):
+    # (key, config, steps, extra flags, items of the CPU sample): "3_mixed" is SURVEY 8d's 50 %-OR variant of config 3, the "_ragged" legs draw
+    # every policy's leaf count from 10 .. the config's (a batch of mixed shapes)
+    legs = (("2_ragged", 2, 16, ["--ragged", "--no-single-batch", "--no-configs-leg", "--no-host-io-leg", "--wide-window", "0"], 0),
+            ("3", 3, 4, [], 5), ("3_mixed", 3, 4, ["--tree", "mixed"], 0), ("3_ragged", 3, 4, ["--ragged"], 0), ("4", 4, 4, [], 2), ("5", 5, 8, [], 3))
+    for key, cfg, steps, extra, cpu_n in legs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--steps", str(steps), "--warmup", str(steps),
-               "--min-time", str(args.configs_min_time), "--no-cpu-baseline", "--seed", str(args.seed)]
+               "--min-time", str(args.configs_min_time), "--seed", str(args.seed), "--no-object-api"] + extra
+        cmd += ["--cpu-sample", str(cpu_n)] if cpu_n and not args.no_cpu_baseline else ["--no-cpu-baseline"]
         t0 = time.perf_counter()
         try:
-            pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
             d = json.loads(line)
             rf = d.get("roofline", {})
-            out[str(cfg)] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            out[key] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                             "pairings_per_item": d["config"].get("pairings_per_item"), "cpu_baseline": d.get("cpu_baseline"),
                              "batch_per_gpu": d["config"]["batch_per_gpu"], "workload": d["config"]["workload"],
                              "steps_per_launch_set": d["config"]["steps_per_launch_set"], "roundtrip_bit_exact": d["roundtrip_bit_exact"],
                              "timed_regions": {"count": d["timed_regions"]["count"], "ms_mean": d["timed_regions"]["ms_mean"]},
@@ -701,7 +717,7 @@ def configs_leg(args):
                                           "frac_survey": rf.get("frac_survey"), "peak": rf.get("peak"), "kernels_ms": rf.get("kernels_ms")},
                              "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as ex:
-            out[str(cfg)] = {"error": repr(ex)[:300]}
+            out[key] = {"error": repr(ex)[:300]}
     return out
 
 
@@ -842,7 +858,7 @@ def cpu_baseline_multicore(args, tree):
         return None
     n = sum(d[0] for d in done)
     busy = max(d[1] for d in done)
-    return {"value": round(n / busy, 3), "unit": "ops/s", "cores": len(done), "kind": "port",
+    return {"value": round(n / busy, 3), "unit": "ops/s", "cores": len(done), "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d processes x %d AC17 encrypt+decrypt at %d attributes, slowest process %.1f s in its timed loop (%.1f s wall with "
                       "interpreter start-up and key set-up); same C restatement as cpu_baseline" % (len(done), per, args.attrs, busy, wall)}
 
@@ -859,7 +875,7 @@ def cpu_baseline(args, tree):
     if have_c:
         n = args.cpu_sample or 96
         _outs, dt = cport.ac17_encdec(policy, args.attrs, n, seed=args.seed)
-        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                 "sample": "%d AC17 encrypt+decrypt (policy parse + MSP + group loops) at %d attributes in %.1f s; C restatement "
                           "of the reference's operation order (oracle/c/rabe_ref.c: binary double-and-add for every G*Fr, "
                           "per-row hash-to-group, one final exponentiation per pairing), single thread like the reference"
@@ -887,7 +903,7 @@ def cpu_baseline(args, tree):
     t_dec = time.perf_counter() - t0
     assert out == msg
     est = t_enc * args.attrs / n_attr + t_dec
-    return {"value": round(1.0 / est, 6), "unit": "ops/s", "cores": 1, "kind": "port",
+    return {"value": round(1.0 / est, 6), "unit": "ops/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
             "sample": "pure-Python big-int oracle (reference operation order): 1 encrypt+decrypt at %d attributes measured "
                       "(%.1f s + %.1f s), encrypt scaled linearly to %d attributes" % (n_attr, t_enc, t_dec, args.attrs)}
 

@@ -73,3 +73,15 @@ def regions_summary(regions, steps):
     return {"count": len(regions), "steps_each": steps, "ms_min": round(1e3 * min(regions), 3), "ms_mean": round(1e3 * mean, 3),
             "ms_max": round(1e3 * max(regions), 3),
             "note": "every region times exactly --steps steps between barrier + synchronize; repeated until --min-time s are covered; value uses the mean"}
+
+
+def cpu_model():
+    """model name of the host CPU (stated with every CPU number)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()

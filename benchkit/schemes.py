@@ -12,7 +12,7 @@ import os
 import random
 import time
 
-from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, regions_summary, split_steps, timed_regions
+from benchkit.lib import G1_GEN, G2_GEN, MAC_PER_FPMUL, ExtBuf, cpu_model, regions_summary, split_steps, timed_regions
 
 
 def run(args, world, rank, local_rank):
@@ -308,6 +308,9 @@ class BswBench:
     def make_tree(self, prnd):
         names = list(self.attrs)
         prnd.shuffle(names)
+        if self.r.args.ragged:                   # a batch of mixed shapes: 10 .. n_attr leaves per policy (an even count for the mixed tree)
+            k = prnd.randrange(10, self.n_attr + 1)
+            names = names[:k - (k % 2)]
         return make_tree(self.r.args.tree, names)
 
     def prepare(self, G, lanes):
@@ -316,7 +319,9 @@ class BswBench:
         B, P = self.B, len(self.trees)
         GB = G * B
         self.G, self.lanes = G, lanes
-        pol = [i % P for i in range(GB)]
+        # items of one policy are interleaved (uniform shapes) or -- ragged -- contiguous runs of B / P items inside every step's batch:
+        # a caller that batches mixed shapes groups them (the host layer's packed decrypt does), so that a wave sees one shape
+        pol = [((i % B) * P // B) if r.args.ragged else i % P for i in range(GB)]
         sel_start_p, so = [], 0
         sel_ct, sel_sk, sel_z = [], [], []
         for idx, ska, z in self.sel:
@@ -394,7 +399,8 @@ class BswBench:
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
         return {"workload": "BSW CP-ABE, %d-leaf %s access tree (%d distinct policies), batch %d encrypt+decrypt per GPU"
                             % (self.n_attr, self.r.args.tree, len(self.trees), self.B),
-                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "pruned_leaves_avg": round(m, 2),
+                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "ragged": bool(self.r.args.ragged),
+                "leaves_per_policy": [self.tt.n_leaves(p) for p in range(len(self.trees))], "pruned_leaves_avg": round(m, 2),
                 "pairings_per_item": round(2 * m + 1, 1), "prepared_key": self.sk_lines is not None,
                 "table_build_ms_per_public_key": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
 
@@ -421,7 +427,7 @@ class BswBench:
             return {"error": "oracle/c not built"}
         n = self.r.args.cpu_sample or 12
         dt = cport.bsw_encdec(self.n_attr, n, tree=self.r.args.tree, seed=self.r.args.seed)
-        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                 "sample": "%d BSW encrypt+decrypt at %d leaves (%s tree) in %.1f s; the reference's operation order (bsw/mod.rs:217-318: binary "
                           "double-and-add for every G*Fr, two multiplications for (g2*h(name))*q, one full pairing per e(.,.), Gt::pow per leaf) "
                           "over the C primitives of oracle/c/rabe_ref.c, single thread like the reference" % (n, self.n_attr, self.r.args.tree, dt)}
@@ -620,7 +626,7 @@ class LswBench:
             return {"error": "oracle/c not built"}
         n = self.r.args.cpu_sample or 6
         dt = cport.lsw_keygen_dec(self.n_attr, n, tree=self.r.args.tree, seed=self.r.args.seed)
-        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                 "sample": "%d LSW keygen+decrypt at %d leaves (%s tree) in %.1f s; the reference's operation order (lsw/mod.rs:121-170,228-290: "
                           "three G1 and one G2 binary double-and-add multiplications per leaf in keygen, two full pairings and a Gt::pow per leaf "
                           "in decrypt) over the C primitives of oracle/c/rabe_ref.c, single thread like the reference"
@@ -809,7 +815,7 @@ class Aw11Bench:
         n = self.r.args.cpu_sample or 4
         tree = "nested" if self.r.args.tree == "flat" else self.r.args.tree
         dt = cport.aw11_encdec(self.n_attr, n, tree=tree, seed=self.r.args.seed)
-        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "kind": "port",
+        return {"value": round(n / dt, 4), "unit": "ops/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
                 "sample": "%d AW11 encrypt+decrypt at %d attributes (%s tree) in %.1f s; the reference's operation order (aw11/mod.rs:241-289,298-366: "
                           "a pairing e(g1,g2) and two Gt::pow per row in encrypt, two full pairings and a Gt::pow per row in decrypt, binary "
                           "double-and-add everywhere) over the C primitives of oracle/c/rabe_ref.c, single thread like the reference"

@@ -74,6 +74,8 @@ int32_t rhip_host_alloc(rhip_ctx* ctx, size_t bytes, void** host);
 int32_t rhip_host_free(rhip_ctx* ctx, void* host);
 int32_t rhip_upload_async(rhip_ctx* ctx, void* dev, const void* host_pinned, size_t bytes);
 int32_t rhip_download_async(rhip_ctx* ctx, void* host_pinned, const void* dev, size_t bytes);
+/* stream-ordered fill (the host layer wipes staging areas that held master-key-derived scalars) */
+int32_t rhip_memset_async(rhip_ctx* ctx, void* dev, int32_t byte, size_t bytes);
 /* cross-context ordering without a host round trip: work submitted to `ctx` after this call starts only when everything
  * submitted to `other` so far has finished (event record + stream wait): e.g. a copy context that drains one batch's
  * outputs while the compute context already runs the next kernels */

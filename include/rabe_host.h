@@ -31,6 +31,13 @@ enum {   /* object kinds for rabe_obj_free / rabe_obj_serialize / rabe_obj_deser
 };
 enum { RABE_JSON_POLICY = 0, RABE_HUMAN_POLICY = 1 };   /* PolicyLanguage, src/utils/policy/pest/mod.rs:18-23 */
 
+/* ABI revision of this header.  An argument list that changes keeps its symbol name only together with a bump of this number (revision 3
+ * inserted ct_len and flags into the packed decrypts): a caller passes the revision it was COMPILED against -- rabe_host_open is the macro
+ * for that -- and a library of another revision refuses with -3 instead of reading shifted arguments.  rabe_host_create does not check. */
+#define RABE_HOST_ABI_VERSION 4
+int32_t rabe_host_abi_version(void);
+int32_t rabe_host_create_checked(int32_t abi_version, int32_t device, rabe_host** out);
+#define rabe_host_open(device, out) rabe_host_create_checked(RABE_HOST_ABI_VERSION, (device), (out))
 int32_t rabe_host_create(int32_t device, rabe_host** out);
 void rabe_host_destroy(rabe_host* h);
 const char* rabe_host_last_error(rabe_host* h);          /* h may be NULL: error of the last host-free call on this thread */

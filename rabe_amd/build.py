@@ -15,7 +15,7 @@ OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
 SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_sym.hip"),
            os.path.join(CSRC, "host", "schemes.cpp"),
            os.path.join(CSRC, "host", "host_abi.cpp"), os.path.join(CSRC, "host", "packed.cpp"),
-           os.path.join(CSRC, "host", "pipeline.cpp")]
+           os.path.join(CSRC, "host", "pipeline.cpp"), os.path.join(CSRC, "host", "records.cpp")]
 
 
 def _headers(src=None):

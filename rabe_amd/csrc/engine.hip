@@ -205,6 +205,11 @@ extern "C" int32_t rhip_upload(rhip_ctx* ctx, void* dev, const void* host, size_
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return RHIP_OK;
 }
+extern "C" int32_t rhip_memset_async(rhip_ctx* ctx, void* dev, int32_t byte, size_t bytes) {
+  if (!ctx) return RHIP_ERR_ARG;
+  if (bytes) HIP_TRY(ctx, hipMemsetAsync(dev, byte, bytes, ctx->stream));
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_download(rhip_ctx* ctx, void* host, const void* dev, size_t bytes) {
   if (!ctx) return RHIP_ERR_ARG;
   HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -226,11 +231,13 @@ extern "C" int32_t rhip_host_free(rhip_ctx* ctx, void* host) {
 }
 extern "C" int32_t rhip_upload_async(rhip_ctx* ctx, void* dev, const void* host, size_t bytes) {
   if (!ctx) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));          // callable from a helper thread (the host layer uploads a blob beside its parsing)
   HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   return RHIP_OK;
 }
 extern "C" int32_t rhip_download_async(rhip_ctx* ctx, void* host, const void* dev, size_t bytes) {
   if (!ctx) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   return RHIP_OK;
 }

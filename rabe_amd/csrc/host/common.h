@@ -138,6 +138,9 @@ class Engine {
     explicit ArenaScope(Engine& eng);
     ~ArenaScope();
   };
+  // The current call stages secret material (master-key-derived scalars of a bulk keygen): when its outermost ArenaScope ends, what the
+  // call used of the lane's device arena and of its pinned staging buffers is overwritten with zeros -- both outlive the call otherwise.
+  void scrub_when_done();
   // the lane's SIDE context (a second stream, created on first use): work that may run beside the main context's kernels
   rhip_ctx* side_ctx();
   void* arena_take(size_t bytes);                  // nullptr: no scope active or block full
@@ -166,6 +169,9 @@ class Engine {
   std::map<std::string, size_t> seen_[3];   // uses so far of the heavier bases (G1, G2, Gt)
   // grow-only pinned host staging buffers (slot 0..3) for the packed batch entry points: PCIe copies at full rate
   uint8_t* pinned(int slot, size_t bytes);
+  // slot 3 as a bump allocator for the call's parameter packs (records.h: ParamPack): every take stays valid -- asynchronous copies
+  // may still read it -- until the outermost ArenaScope of the call ends; a take the block cannot hold waits for the stream first
+  uint8_t* pinned_bump(size_t bytes);
   // window table of the Gt generator e(G1::one(), G2::one()) (random Gt messages of a batch in one launch, on device)
   rhip_gt_table* gt_generator_table();
   // device-side key handles of the packed entry points (rhip_bsw_pk, rhip_lsw_pk, rhip_aw11_pk), cached by the key's bytes and
@@ -181,6 +187,9 @@ class Engine {
     uint8_t* arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0, arena_want = 0;
     int arena_depth = 0;
+    size_t pin3_used = 0;
+    size_t pin_touched[4] = {0, 0, 0, 0};          // bytes of each pinned slot handed out since the outermost scope began
+    bool scrub = false;
   };
   std::vector<std::unique_ptr<Lane>> lanes_;
   int device_ = 0;

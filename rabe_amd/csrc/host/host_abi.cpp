@@ -300,6 +300,15 @@ int32_t rabe_host_create(int32_t device, rabe_host** out) {
   return 0;
   GUARD_END((rabe_host*)nullptr)
 }
+int32_t rabe_host_abi_version(void) { return RABE_HOST_ABI_VERSION; }
+int32_t rabe_host_create_checked(int32_t abi_version, int32_t device, rabe_host** out) {
+  if (out) *out = nullptr;
+  if (abi_version != RABE_HOST_ABI_VERSION) {
+    g_err = "rabe_host.h revision " + std::to_string(abi_version) + " does not match the library's (" + std::to_string(RABE_HOST_ABI_VERSION) + ")";
+    return -3;
+  }
+  return rabe_host_create(device, out);
+}
 void rabe_host_destroy(rabe_host* h) { delete h; }
 const char* rabe_host_last_error(rabe_host* h) { return h ? h->err.c_str() : g_err.c_str(); }
 int32_t rabe_host_set_fixed_base_min(rabe_host* h, size_t n) {

@@ -7,6 +7,7 @@
 // assembly, KDF + AES-GCM.  Records are the byte form rabe_obj_serialize gives the corresponding struct (host_abi.cpp), so packed
 // and object APIs interoperate.
 #include "schemes.h"
+#include "records.h"
 
 #include <chrono>
 #include <functional>
@@ -170,25 +171,8 @@ struct Cursor {
 };
 inline bool same(const std::pair<const char*, uint32_t>& a, const std::string& b) { return a.second == b.size() && memcmp(a.first, b.data(), b.size()) == 0; }
 
-// AES-GCM open of every live item into the caller's buffer (status / offsets as in ac17::cp_decrypt_packed)
+// where an item's sealed plaintext sits in the caller's blob (opened on the device: records.h, open_sealed_records)
 struct Sealed { const uint8_t* p = nullptr; uint32_t len = 0; };
-void open_all(size_t n, const std::vector<Sealed>& sealed, const std::vector<size_t>& slot, const uint8_t* h_gt, int32_t* status, uint8_t* pt_buf,
-              uint64_t* pt_off, std::vector<std::string>* errors) {
-  pt_off[0] = 0;
-  for (size_t i = 0; i < n; i++) pt_off[i + 1] = pt_off[i] + ((*errors)[i].empty() && sealed[i].len >= 28 ? sealed[i].len - 28 : 0);
-  parallel_for(n, [&](size_t i) {
-    status[i] = -1;
-    if (!(*errors)[i].empty()) return;
-    Bytes pt;
-    if (sealed[i].len >= 28 && decrypt_symmetric(h_gt + 384 * slot[i], sealed[i].p, sealed[i].len, &pt) && pt.size() == sealed[i].len - 28) {
-      memcpy(pt_buf + pt_off[i], pt.data(), pt.size());
-      status[i] = 0;
-    } else {
-      memset(pt_buf + pt_off[i], 0, (size_t)(pt_off[i + 1] - pt_off[i]));
-      (*errors)[i] = "decryption error: aead::Error";
-    }
-  });
-}
 
 }  // namespace
 
@@ -230,6 +214,7 @@ bool cp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std
                       const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("ac17::cp_keygen_packed");
   Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // master-key-derived scalars pass through the staging buffers
   if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
   if (n && (!item_set || !out_off)) throw RabeError("cp_keygen_packed: null input");
   std::vector<size_t> fixed(sets.size());
@@ -388,6 +373,7 @@ bool keygen_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeM
                    const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("bsw::keygen_packed");
   Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // master-key-derived scalars pass through the staging buffers
   if (n && (!item_set || !out_off)) throw RabeError("bsw::keygen_packed: null input");
   std::vector<size_t> fixed(sets.size());
   std::vector<std::vector<Fr>> hashes(sets.size());
@@ -518,39 +504,28 @@ bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::
                                    dt.path_gate.as<uint32_t>(), dt.path_x.as<uint32_t>(), dt.gate_k.as<uint32_t>(), dt.gate_coef_off.as<uint32_t>(),
                                    dt.leaf_hash.as<rhip_fr>(), dsec, dsec + 2 * n, d_coef_off.as<uint32_t>(), d_msg.as<rhip_gt>(), d_c.as<rhip_g1>(),
                                    d_cp.as<rhip_gt>(), d_g1.as<rhip_g1>(), d_g2.as<rhip_g2>()), "rhip_bsw_encrypt_batch");
-  uint8_t* h_l = eng.pinned(1, total * 192);                // g1 rows | g2 rows
-  uint8_t* h_x = eng.pinned(2, n * (64 + 384 + 384));       // c | c_p | msg
-  eng.check(rhip_download_async(cx, h_l, d_g1.ptr(), total * 64), "download");
-  eng.check(rhip_download_async(cx, h_l + total * 64, d_g2.ptr(), total * 128), "download");
-  eng.check(rhip_download_async(cx, h_x, d_c.ptr(), n * 64), "download");
-  eng.check(rhip_download_async(cx, h_x + n * 64, d_cp.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_x + n * 448, d_msg.ptr(), n * 384), "download");
-  eng.check(rhip_sync(cx), "rhip_sync");
-  tm.lap("device + copies");
-  parallel_for(n, [&](size_t i) {
-    const size_t p_ = item_policy[i];
+  // records and sealing on the device (records.h)
+  std::vector<RecordLayout> layouts(policies.size());
+  for (size_t p_ = 0; p_ < policies.size(); p_++) {
+    RecordLayout& L = layouts[p_];
     const FlatPolicy& f = *pols[p_];
-    const std::string& pol = policies[p_];
-    uint8_t* w = out_buf + out_off[i];
-    put_u32(w, (uint32_t)pol.size()); w += 4;
-    memcpy(w, pol.data(), pol.size()); w += pol.size();
-    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
-    memcpy(w, h_x + 64 * i, 64); w += 64;
-    memcpy(w, h_x + n * 64 + 384 * i, 384); w += 384;
-    put_u32(w, (uint32_t)f.leaf_name.size()); w += 4;
+    L.str(policies[p_]);
+    L.u8((language == PolicyLanguage::HumanPolicy) ? 1 : 0);
+    L.src(0, 0, 64);
+    L.src(1, 0, 384);
+    L.u32((uint32_t)f.leaf_name.size());
     for (size_t y = 0; y < f.leaf_name.size(); y++) {
-      const std::string& nm = f.leaf_name_col[y];
-      put_u32(w, (uint32_t)nm.size()); w += 4;
-      memcpy(w, nm.data(), nm.size()); w += nm.size();
-      memcpy(w, h_l + (size_t)(leaf_off[i] + y) * 64, 64); w += 64;
-      memcpy(w, h_l + total * 64 + (size_t)(leaf_off[i] + y) * 128, 128); w += 128;
+      L.str(f.leaf_name_col[y]);
+      L.src(2, (uint32_t)(64 * y), 64);
+      L.src(3, (uint32_t)(128 * y), 128);
     }
-    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
-    put_u32(w, (uint32_t)(len + 28)); w += 4;
-    Bytes sealed = encrypt_symmetric(h_x + n * 448 + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
-    memcpy(w, sealed.data(), sealed.size());
-  });
-  tm.lap("assembly + AES");
+    if (L.bytes() + 4 != fixed[p_]) throw RabeError("bsw::encrypt_packed: record layout and size disagree");
+  }
+  std::vector<uint64_t> src_off(4 * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 64ull * i; src_off[n + i] = 384ull * i; src_off[2 * n + i] = 64ull * leaf_off[i]; src_off[3 * n + i] = 128ull * leaf_off[i]; }
+  emit_sealed_records(eng, layouts, n, item_policy, {d_c.ptr(), d_cp.ptr(), d_g1.ptr(), d_g2.ptr()}, src_off, d_msg.ptr(), (const uint8_t*)nonces.data(),
+                      pt_blob, pt_off, out_off, out_buf);
+  tm.lap("device: group arithmetic, records, sealing; one copy out");
   return true;
 }
 
@@ -566,6 +541,7 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
   if (!ct_off || (n && !ct_blob)) throw RabeError("bsw::decrypt_packed: null input");
   const uint64_t span = check_offsets(n, ct_off, ct_len, errors);
   if (!pt_buf || pt_cap < span) return false;
+  BlobGather gather(eng, ct_blob, ct_len);          // the blob starts for the device now, beside the parsing below (records.h)
   std::vector<std::string> attr;
   for (const auto& v : sk.d_j) attr.push_back(v.string);
   struct Plan {
@@ -672,35 +648,43 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     if ((size_t)2 * m + 1 > max_pairs) max_pairs = 2 * m + 1;
   }
   const size_t m_items = live.size();
-  uint8_t* h_out = nullptr;
-  std::vector<size_t> slot(n, (size_t)-1);
+  std::vector<uint64_t> sealed_off(m_items);
+  std::vector<uint32_t> sealed_len(m_items);
+  DBuf d_out(&eng, m_items * 384 + 4);
   if (m_items) {
     const size_t total = leaf_off[m_items];
-    uint8_t* h_l = eng.pinned(1, total * 192 + 4);
-    uint8_t* h_x = eng.pinned(2, m_items * (64 + 384 + 384));
-    parallel_for(m_items, [&](size_t j) {
+    DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4);
+    std::vector<uint64_t> dst_off(4 * m_items);
+    for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
-      memcpy(h_x + 64 * j, w.c, 64);
-      memcpy(h_x + m_items * 64 + 384 * j, w.cp, 384);
-      for (uint32_t y = 0; y < w.rows; y++) {
-        memcpy(h_l + (size_t)(leaf_off[j] + y) * 64, w.g1[y], 64);
-        memcpy(h_l + total * 64 + (size_t)(leaf_off[j] + y) * 128, w.g2[y], 128);
+      const uint8_t* rec = ct_blob + ct_off[live[j]];
+      sealed_off[j] = (uint64_t)(sealed[live[j]].p - ct_blob);
+      sealed_len[j] = sealed[live[j]].len;
+      dst_off[j] = 64ull * j; dst_off[m_items + j] = 384ull * j; dst_off[2 * m_items + j] = 64ull * leaf_off[j]; dst_off[3 * m_items + j] = 128ull * leaf_off[j];
+      int shape = w.standard ? gather.find(w.plan.get()) : -1;          // standard layout: policy text and names as encrypt writes them -> one skeleton
+      if (shape < 0) {
+        std::vector<RecordLayout::Part> parts;
+        parts.push_back({(uint32_t)(w.c - rec), 64, 0, 0});
+        parts.push_back({(uint32_t)(w.cp - rec), 384, 1, 0});
+        for (uint32_t y = 0; y < w.rows; y++) {
+          parts.push_back({(uint32_t)(w.g1[y] - rec), 64, 2, 64 * y});
+          parts.push_back({(uint32_t)(w.g2[y] - rec), 128, 3, 128 * y});
+        }
+        shape = (int)gather.add_shape(w.standard ? (const void*)w.plan.get() : nullptr, std::move(parts));
       }
-    });
-    tm.lap("pack");
+      gather.item(ct_off[live[j]], (uint32_t)shape);
+    }
+    tm.lap("shapes");
     rhip_ctx* cx = eng.ctx();
     std::vector<uint8_t> kg1, kg2;
     for (const auto& a : sk.d_j) { kg1.insert(kg1.end(), a.g1.begin(), a.g1.end()); kg2.insert(kg2.end(), a.g2.begin(), a.g2.end()); }
     std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.d_j.size()};
     auto fz = flatten_fr(sel_z);
-    DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off),
+    DBuf d_leaf_off = up32(eng, leaf_off),
         d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_sk = up32(eng, sel_sk),
         d_sel_z = up_bytes(eng, fz), d_skd(&eng, sk.d.data(), 128), d_kg1 = up_bytes(eng, kg1), d_kg2 = up_bytes(eng, kg2),
-        d_sk_attr_off = up32(eng, sk_attr_off), d_out(&eng, m_items * 384);
-    eng.check(rhip_upload_async(cx, d_c.ptr(), h_x, m_items * 64), "upload");
-    eng.check(rhip_upload_async(cx, d_cp.ptr(), h_x + m_items * 64, m_items * 384), "upload");
-    eng.check(rhip_upload_async(cx, d_g1.ptr(), h_l, total * 64), "upload");
-    eng.check(rhip_upload_async(cx, d_g2.ptr(), h_l + total * 64, total * 128), "upload");
+        d_sk_attr_off = up32(eng, sk_attr_off);
+    gather.run({d_c.ptr(), d_cp.ptr(), d_g1.ptr(), d_g2.ptr()}, dst_off);
     std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
@@ -719,9 +703,6 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
                                                d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(),
                                                d_g1.as<rhip_g1>(), d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(),
                                                d_kg2.as<rhip_g2>(), d_sk_attr_off.as<uint32_t>(), lines, d_out.as<rhip_gt>());
-    h_out = h_x + m_items * 448;
-    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
-    if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_bsw_decrypt_batch");
     if (mc) {
       mc->collect();
@@ -732,11 +713,10 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
         if (bad) (*errors)[live[j]] = bad;
       }
     }
-    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
-  tm.lap("device + copies");
-  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
-  tm.lap("AES open");
+  // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
+  open_sealed_records(eng, n, live, d_out.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
 }  // namespace bsw
@@ -876,41 +856,28 @@ bool encrypt_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const std::
   eng.check(rhip_g1_table_mul(cx, tb->g1_b2, total, k_c, d_t1.as<rhip_g1>()), "rhip_g1_table_mul");
   eng.check(rhip_g1_table_mul(cx, tb->h_b, total, k_b, d_t2.as<rhip_g1>()), "rhip_g1_table_mul");
   eng.check(rhip_g1_add(cx, total, d_t1.as<rhip_g1>(), d_t2.as<rhip_g1>(), d_r3.as<rhip_g1>()), "rhip_g1_add");
-  uint8_t* h_o = eng.pinned(1, n * (384 + 384 + 128) + total * 192 + 4);
-  uint8_t* h_e1 = h_o;
-  uint8_t* h_msg = h_e1 + n * 384;
-  uint8_t* h_e2 = h_msg + n * 384;
-  uint8_t* h_r1 = h_e2 + n * 128;
-  uint8_t* h_r2 = h_r1 + total * 64;
-  uint8_t* h_r3 = h_r2 + total * 64;
-  eng.check(rhip_download_async(cx, h_e1, d_e1.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_msg, d_msg.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_e2, d_e2.ptr(), n * 128), "download");
-  eng.check(rhip_download_async(cx, h_r1, d_r1.ptr(), total * 64), "download");
-  eng.check(rhip_download_async(cx, h_r2, d_r2.ptr(), total * 64), "download");
-  eng.check(rhip_download_async(cx, h_r3, d_r3.ptr(), total * 64), "download");
-  eng.check(rhip_sync(cx), "rhip_sync");
-  tm.lap("device + copies");
-  parallel_for(n, [&](size_t i) {
-    const auto& attrs = sets[item_set[i]];
-    uint8_t* w = out_buf + out_off[i];
-    memcpy(w, h_e1 + 384 * i, 384); w += 384;
-    memcpy(w, h_e2 + 128 * i, 128); w += 128;
-    put_u32(w, (uint32_t)attrs.size()); w += 4;
-    for (size_t y = 0; y < attrs.size(); y++) {
-      const size_t row = row_off[i] + y;
-      put_u32(w, (uint32_t)attrs[y].size()); w += 4;
-      memcpy(w, attrs[y].data(), attrs[y].size()); w += attrs[y].size();
-      memcpy(w, h_r1 + 64 * row, 64); w += 64;
-      memcpy(w, h_r2 + 64 * row, 64); w += 64;
-      memcpy(w, h_r3 + 64 * row, 64); w += 64;
+  // records and sealing on the device (records.h); layout = attribute set
+  std::vector<RecordLayout> layouts(sets.size());
+  for (size_t p_ = 0; p_ < sets.size(); p_++) {
+    RecordLayout& L = layouts[p_];
+    L.src(0, 0, 384);
+    L.src(1, 0, 128);
+    L.u32((uint32_t)sets[p_].size());
+    for (size_t y = 0; y < sets[p_].size(); y++) {
+      L.str(sets[p_][y]);
+      L.src(2, (uint32_t)(64 * y), 64);
+      L.src(3, (uint32_t)(64 * y), 64);
+      L.src(4, (uint32_t)(64 * y), 64);
     }
-    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
-    put_u32(w, (uint32_t)(len + 28)); w += 4;
-    Bytes sealed = encrypt_symmetric(h_msg + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
-    memcpy(w, sealed.data(), sealed.size());
-  });
-  tm.lap("assembly + AES");
+  }
+  std::vector<uint64_t> src_off(5 * n);
+  for (size_t i = 0; i < n; i++) {
+    src_off[i] = 384ull * i; src_off[n + i] = 128ull * i;
+    src_off[2 * n + i] = src_off[3 * n + i] = src_off[4 * n + i] = 64ull * row_off[i];
+  }
+  emit_sealed_records(eng, layouts, n, item_set, {d_e1.ptr(), d_e2.ptr(), d_r1.ptr(), d_r2.ptr(), d_r3.ptr()}, src_off, d_msg.ptr(),
+                      (const uint8_t*)nonces.data(), pt_blob, pt_off, out_off, out_buf);
+  tm.lap("device: group arithmetic, records, sealing; one copy out");
   return true;
 }
 
@@ -921,6 +888,7 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
                    PolicyLanguage language, size_t n, const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("lsw::keygen_packed");
   Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // master-key-derived scalars pass through the staging buffers
   std::vector<std::shared_ptr<const FlatPolicy>> pols;
   std::vector<std::vector<std::string>> striped(policies.size());
   std::vector<size_t> fixed(policies.size());
@@ -1023,6 +991,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
   (void)check_offsets(n, sk_off, sk_len, errors);
   const size_t pt_each = ct.ct.size() >= 28 ? ct.ct.size() - 28 : 0;
   if (!pt_buf || pt_cap < n * pt_each) return false;
+  BlobGather gather(eng, sk_blob, sk_len);          // the blob starts for the device now, beside the parsing below (records.h)
   std::vector<std::string> attr;
   for (const auto& a : ct.ej) attr.push_back(a.name);
   struct Plan {
@@ -1122,29 +1091,36 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     if ((size_t)m + 1 > max_pairs) max_pairs = m + 1;
   }
   const size_t m_items = live.size();
-  uint8_t* h_out = nullptr;
-  std::vector<size_t> slot(n, (size_t)-1);
+  DBuf d_out(&eng, m_items * 384 + 4);
   if (m_items) {
     const size_t total = leaf_off[m_items];
-    uint8_t* h_l = eng.pinned(1, total * 192 + 4);
-    parallel_for(m_items, [&](size_t j) {
+    DBuf d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4);
+    std::vector<uint64_t> dst_off(2 * m_items);
+    for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
-      for (uint32_t y = 0; y < w.rows; y++) {
-        memcpy(h_l + (size_t)(leaf_off[j] + y) * 64, w.d1[y], 64);
-        memcpy(h_l + total * 64 + (size_t)(leaf_off[j] + y) * 128, w.d2[y], 128);
+      const uint8_t* rec = sk_blob + sk_off[live[j]];
+      dst_off[j] = 64ull * leaf_off[j]; dst_off[m_items + j] = 128ull * leaf_off[j];
+      int shape = w.standard ? gather.find(w.plan.get()) : -1;
+      if (shape < 0) {
+        std::vector<RecordLayout::Part> parts;
+        for (uint32_t y = 0; y < w.rows; y++) {
+          parts.push_back({(uint32_t)(w.d1[y] - rec), 64, 0, 64 * y});
+          parts.push_back({(uint32_t)(w.d2[y] - rec), 128, 1, 128 * y});
+        }
+        shape = (int)gather.add_shape(w.standard ? (const void*)w.plan.get() : nullptr, std::move(parts));
       }
-    });
-    tm.lap("pack");
+      gather.item(sk_off[live[j]], (uint32_t)shape);
+    }
+    tm.lap("shapes");
     rhip_ctx* cx = eng.ctx();
     std::vector<uint8_t> e1j, e1rep(m_items * 384);
     for (const auto& a : ct.ej) e1j.insert(e1j.end(), a.e1.begin(), a.e1.end());
     for (size_t j = 0; j < m_items; j++) memcpy(e1rep.data() + 384 * j, ct.e1.data(), 384);
 
-    DBuf d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4), d_leaf_off = up32(eng, leaf_off), d_pair_off = up32(eng, pair_off),
+    DBuf d_leaf_off = up32(eng, leaf_off), d_pair_off = up32(eng, pair_off),
         d_sel_start = up32(eng, sel_start), d_sel_sk = up32(eng, sel_sk), d_sel_ct = up32(eng, sel_ct), d_sel_z = up_bytes(eng, flatten_fr(sel_z)),
-        d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j), d_out(&eng, m_items * 384);
-    eng.check(rhip_upload_async(cx, d_d1.ptr(), h_l, total * 64), "upload");
-    eng.check(rhip_upload_async(cx, d_d2.ptr(), h_l + total * 64, total * 128), "upload");
+        d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j);
+    gather.run({d_d1.ptr(), d_d2.ptr()}, dst_off);
     std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
@@ -1157,9 +1133,6 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
                                                d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
                                                d_e1j.as<rhip_g1>(), d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), (const uint32_t*)nullptr, lines,
                                                d_out.as<rhip_gt>());
-    h_out = eng.pinned(2, m_items * 384);
-    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
-    if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_lsw_decrypt_batch");
     if (mc) {
       mc->collect();
@@ -1167,13 +1140,13 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
       for (size_t j = 0; j < m_items; j++)
         if (!ok1[j] || !ok2[j]) (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)";
     }
-    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
-  tm.lap("device + copies");
-  std::vector<Sealed> sealed(n);
-  for (size_t i = 0; i < n; i++) { sealed[i].p = ct.ct.data(); sealed[i].len = (uint32_t)ct.ct.size(); }
-  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
-  tm.lap("AES open");
+  // the ONE ciphertext's sealed data, opened under every key's Gt on the device (KDF + AES-GCM; the Gt never leaves HBM)
+  DBuf d_sealed(&eng, ct.ct.data(), ct.ct.size());
+  std::vector<uint64_t> sealed_off(m_items, 0);
+  std::vector<uint32_t> sealed_len(m_items, (uint32_t)ct.ct.size());
+  open_sealed_records(eng, n, live, d_out.ptr(), d_sealed.as<uint8_t>(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
 }  // namespace lsw
@@ -1274,39 +1247,26 @@ bool encrypt_packed(Engine& eng, Rng& rng, const Aw11GlobalKey& gk, const std::v
                                     dt.gate_coef_off.as<uint32_t>(), d_leaf_attr.as<uint32_t>(), din, din + 2 * n, d_coef_off.as<uint32_t>(),
                                     din + 2 * n + total_coef, d_msg.as<rhip_gt>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(), d_c2.as<rhip_g2>(),
                                     d_c3.as<rhip_g2>()), "rhip_aw11_encrypt_batch");
-  uint8_t* h_l = eng.pinned(1, total * 640 + 4);              // c1 rows | c2 rows | c3 rows
-  uint8_t* h_x = eng.pinned(2, n * 768);                      // c_0 | msg
-  eng.check(rhip_download_async(cx, h_l, d_c1.ptr(), total * 384), "download");
-  eng.check(rhip_download_async(cx, h_l + total * 384, d_c2.ptr(), total * 128), "download");
-  eng.check(rhip_download_async(cx, h_l + total * 512, d_c3.ptr(), total * 128), "download");
-  eng.check(rhip_download_async(cx, h_x, d_c0.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_x + n * 384, d_msg.ptr(), n * 384), "download");
-  eng.check(rhip_sync(cx), "rhip_sync");
-  tm.lap("device + copies");
-  parallel_for(n, [&](size_t i) {
-    const size_t p_ = item_policy[i];
-    const std::string& pol = policies[p_];
-    uint8_t* w = out_buf + out_off[i];
-    put_u32(w, (uint32_t)pol.size()); w += 4;
-    memcpy(w, pol.data(), pol.size()); w += pol.size();
-    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
-    memcpy(w, h_x + 384 * i, 384); w += 384;
-    put_u32(w, (uint32_t)row_name[p_].size()); w += 4;
+  // records and sealing on the device (records.h)
+  std::vector<RecordLayout> layouts(policies.size());
+  for (size_t p_ = 0; p_ < policies.size(); p_++) {
+    RecordLayout& L = layouts[p_];
+    L.str(policies[p_]);
+    L.u8((language == PolicyLanguage::HumanPolicy) ? 1 : 0);
+    L.src(0, 0, 384);
+    L.u32((uint32_t)row_name[p_].size());
     for (size_t y = 0; y < row_name[p_].size(); y++) {
-      const std::string& nm = row_name[p_][y];
-      const size_t row = row_off[i] + y;
-      put_u32(w, (uint32_t)nm.size()); w += 4;
-      memcpy(w, nm.data(), nm.size()); w += nm.size();
-      memcpy(w, h_l + row * 384, 384); w += 384;
-      memcpy(w, h_l + total * 384 + row * 128, 128); w += 128;
-      memcpy(w, h_l + total * 512 + row * 128, 128); w += 128;
+      L.str(row_name[p_][y]);
+      L.src(1, (uint32_t)(384 * y), 384);
+      L.src(2, (uint32_t)(128 * y), 128);
+      L.src(3, (uint32_t)(128 * y), 128);
     }
-    const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
-    put_u32(w, (uint32_t)(len + 28)); w += 4;
-    Bytes sealed = encrypt_symmetric(h_x + n * 384 + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
-    memcpy(w, sealed.data(), sealed.size());
-  });
-  tm.lap("assembly + AES");
+  }
+  std::vector<uint64_t> src_off(4 * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 384ull * i; src_off[n + i] = 384ull * row_off[i]; src_off[2 * n + i] = src_off[3 * n + i] = 128ull * row_off[i]; }
+  emit_sealed_records(eng, layouts, n, item_policy, {d_c0.ptr(), d_c1.ptr(), d_c2.ptr(), d_c3.ptr()}, src_off, d_msg.ptr(), (const uint8_t*)nonces.data(),
+                      pt_blob, pt_off, out_off, out_buf);
+  tm.lap("device: group arithmetic, records, sealing; one copy out");
   return true;
 }
 
@@ -1329,6 +1289,7 @@ bool keygen_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11MasterKey& ms
                    const std::vector<std::vector<std::string>>& sets, size_t n, const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
   Timer tm("aw11::keygen_packed");
   Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // master-key-derived scalars pass through the staging buffers
   if (n && (!item_set || !out_off)) throw RabeError("aw11::keygen_packed: null input");
   if (gids.size() != n) throw RabeError("aw11::keygen_packed: one gid per item");
   std::vector<std::vector<const Aw11MkAttr*>> auth(sets.size());
@@ -1404,6 +1365,7 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
   if (!ct_off || (n && !ct_blob)) throw RabeError("aw11::decrypt_packed: null input");
   const uint64_t span = check_offsets(n, ct_off, ct_len, errors);
   if (!pt_buf || pt_cap < span) return false;
+  BlobGather gather(eng, ct_blob, ct_len);          // the blob starts for the device now, beside the parsing below (records.h)
   std::vector<std::string> str_attr;
   for (const auto& a : sk.attr) str_attr.push_back(a.first);
   struct Plan {
@@ -1502,36 +1464,43 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     if ((size_t)m + 1 > max_pairs) max_pairs = m + 1;
   }
   const size_t m_items = live.size();
-  uint8_t* h_out = nullptr;
-  std::vector<size_t> slot(n, (size_t)-1);
+  std::vector<uint64_t> sealed_off(m_items);
+  std::vector<uint32_t> sealed_len(m_items);
+  DBuf d_out(&eng, m_items * 384 + 4);
   if (m_items) {
     const size_t total = row_off[m_items];
-    uint8_t* h_l = eng.pinned(1, total * 640 + 4);
-    uint8_t* h_x = eng.pinned(2, m_items * 768);
-    parallel_for(m_items, [&](size_t j) {
+    DBuf d_c0(&eng, m_items * 384), d_c1(&eng, total * 384 + 4), d_c2(&eng, total * 128 + 4), d_c3(&eng, total * 128 + 4);
+    std::vector<uint64_t> dst_off(4 * m_items);
+    for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
-      memcpy(h_x + 384 * j, w.c0, 384);
-      for (uint32_t y = 0; y < w.rows; y++) {
-        const size_t row = row_off[j] + y;
-        memcpy(h_l + row * 384, w.c1[y], 384);
-        memcpy(h_l + total * 384 + row * 128, w.c2[y], 128);
-        memcpy(h_l + total * 512 + row * 128, w.c3[y], 128);
+      const uint8_t* rec = ct_blob + ct_off[live[j]];
+      sealed_off[j] = (uint64_t)(sealed[live[j]].p - ct_blob);
+      sealed_len[j] = sealed[live[j]].len;
+      dst_off[j] = 384ull * j; dst_off[m_items + j] = 384ull * row_off[j]; dst_off[2 * m_items + j] = dst_off[3 * m_items + j] = 128ull * row_off[j];
+      int shape = w.standard ? gather.find(w.plan.get()) : -1;
+      if (shape < 0) {
+        std::vector<RecordLayout::Part> parts;
+        parts.push_back({(uint32_t)(w.c0 - rec), 384, 0, 0});
+        for (uint32_t y = 0; y < w.rows; y++) {
+          parts.push_back({(uint32_t)(w.c1[y] - rec), 384, 1, 384 * y});
+          parts.push_back({(uint32_t)(w.c2[y] - rec), 128, 2, 128 * y});
+          parts.push_back({(uint32_t)(w.c3[y] - rec), 128, 3, 128 * y});
+        }
+        shape = (int)gather.add_shape(w.standard ? (const void*)w.plan.get() : nullptr, std::move(parts));
       }
-    });
-    tm.lap("pack");
+      gather.item(ct_off[live[j]], (uint32_t)shape);
+    }
+    tm.lap("shapes");
     rhip_ctx* cx = eng.ctx();
     G1 hash = eng.g1_mul({gk.g1}, {sha3_hash_fr(sk.gid)})[0];            // H(gid) = g1 * h(gid), hashed inside decrypt (:318)
     std::vector<uint8_t> kk;
     for (const auto& a : sk.attr) kk.insert(kk.end(), a.second.begin(), a.second.end());
     std::vector<uint32_t> sk_attr_off{0, (uint32_t)sk.attr.size()}, sk_idx(m_items, 0);
-    DBuf d_c0(&eng, m_items * 384), d_c1(&eng, total * 384 + 4), d_c2(&eng, total * 128 + 4), d_c3(&eng, total * 128 + 4), d_row_off = up32(eng, row_off),
+    DBuf d_row_off = up32(eng, row_off),
         d_pair_off = up32(eng, pair_off), d_sel_start = up32(eng, sel_start), d_sel_ct = up32(eng, sel_ct), d_sel_sk = up32(eng, sel_sk),
         d_sel_z = up_bytes(eng, flatten_fr(sel_z)), d_hash(&eng, hash.data(), 64), d_kk = up_bytes(eng, kk), d_sk_attr_off = up32(eng, sk_attr_off),
-        d_sk_idx = up32(eng, sk_idx), d_out(&eng, m_items * 384);
-    eng.check(rhip_upload_async(cx, d_c0.ptr(), h_x, m_items * 384), "upload");
-    eng.check(rhip_upload_async(cx, d_c1.ptr(), h_l, total * 384), "upload");
-    eng.check(rhip_upload_async(cx, d_c2.ptr(), h_l + total * 384, total * 128), "upload");
-    eng.check(rhip_upload_async(cx, d_c3.ptr(), h_l + total * 512, total * 128), "upload");
+        d_sk_idx = up32(eng, sk_idx);
+    gather.run({d_c0.ptr(), d_c1.ptr(), d_c2.ptr(), d_c3.ptr()}, dst_off);
     std::unique_ptr<MemberChecks> mc;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
@@ -1542,9 +1511,6 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
                                          d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(),
                                          d_c2.as<rhip_g2>(), d_c3.as<rhip_g2>(), d_row_off.as<uint32_t>(), d_hash.as<rhip_g1>(), d_kk.as<rhip_g1>(),
                                          d_sk_attr_off.as<uint32_t>(), d_sk_idx.as<uint32_t>(), d_out.as<rhip_gt>());
-    h_out = h_x + m_items * 384;
-    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, d_out.ptr(), m_items * 384);
-    if (rc == RHIP_OK) rc = rhip_sync(cx);
     eng.check(rc, "rhip_aw11_decrypt_batch");
     if (mc) {
       mc->collect();
@@ -1554,11 +1520,10 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
         if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
       }
     }
-    for (size_t j = 0; j < m_items; j++) slot[live[j]] = j;
   }
-  tm.lap("device + copies");
-  open_all(n, sealed, slot, h_out, status, pt_buf, pt_off, errors);
-  tm.lap("AES open");
+  // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
+  open_sealed_records(eng, n, live, d_out.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
 }  // namespace aw11

@@ -2,11 +2,16 @@
 // String / Fr work happens here exactly where the reference does it on the CPU; every group operation is a
 // batched launch of the HIP engine (no CPU group arithmetic exists in this layer).
 #include "schemes.h"
+#include "records.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <exception>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -94,11 +99,30 @@ uint8_t* Engine::pinned(int slot, size_t bytes) {
     check(rhip_host_alloc(l.ctx, want, &l.pin[slot]), "rhip_host_alloc");
     l.pin_bytes[slot] = want;
   }
+  if (bytes > l.pin_touched[slot]) l.pin_touched[slot] = bytes;
   return (uint8_t*)l.pin[slot];
+}
+void Engine::scrub_when_done() { lanes_[cur_lane()]->scrub = true; }
+uint8_t* Engine::pinned_bump(size_t bytes) {
+  Lane& l = *lanes_[cur_lane()];
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (l.pin3_used + need > l.pin_bytes[3]) {
+    check(rhip_sync(l.ctx), "rhip_sync");            // copies out of the old block have finished: it can go
+    if (l.pin[3]) rhip_host_free(l.ctx, l.pin[3]);
+    l.pin[3] = nullptr;
+    l.pin_bytes[3] = 0;
+    const size_t want = 2 * (l.pin3_used + need) + (1u << 20);
+    check(rhip_host_alloc(l.ctx, want, &l.pin[3]), "rhip_host_alloc");
+    l.pin_bytes[3] = want;
+    l.pin3_used = 0;
+  }
+  uint8_t* p = (uint8_t*)l.pin[3] + l.pin3_used;
+  l.pin3_used += need;
+  return p;
 }
 Engine::ArenaScope::ArenaScope(Engine& eng) : e(eng) {
   Lane& l = *e.lanes_[e.cur_lane()];
-  if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; }
+  if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; l.pin3_used = 0; l.scrub = false; for (auto& t : l.pin_touched) t = 0; }
 }
 rhip_ctx* Engine::side_ctx() {
   Lane& l = *lanes_[cur_lane()];
@@ -136,6 +160,12 @@ Engine::ArenaScope::~ArenaScope() {
   if (--l.arena_depth) return;
   rhip_sync(l.ctx);                               // nothing of this call may still read the block when the next call reuses it
   if (l.side) rhip_sync(l.side);
+  if (l.scrub) {                                  // scrub_when_done(): secrets do not outlive the call in staging memory
+    if (l.arena && l.arena_used) { rhip_memset_async(l.ctx, l.arena, 0, l.arena_used); rhip_sync(l.ctx); }
+    for (int s = 0; s < 3; s++) if (l.pin[s] && l.pin_touched[s]) memset(l.pin[s], 0, l.pin_touched[s] < l.pin_bytes[s] ? l.pin_touched[s] : l.pin_bytes[s]);
+    if (l.pin[3] && l.pin3_used) memset(l.pin[3], 0, l.pin3_used < l.pin_bytes[3] ? l.pin3_used : l.pin_bytes[3]);
+    l.scrub = false;
+  }
   // grow for the next call -- up to a cap (RABE_ARENA_MAX_GB, default 16): the block is never given back, so one huge batch must not
   // pin a large part of the device for the life of the engine; beyond the cap the buffers that do not fit are plain allocations again
   static const size_t cap = [] { const char* e = getenv("RABE_ARENA_MAX_GB"); const long g = e ? atol(e) : 16; return (size_t)(g > 0 ? g : 0) << 30; }();
@@ -555,30 +585,94 @@ static std::vector<schemes::DecryptResult> open_jobs(Engine& e, const std::vecto
 }
 // Host-side planning of a batch (share generation, hashing, pruning: string and Fr work) runs on all cores; the
 // randomness is pulled from the generator beforehand, item after item, so results do not depend on the thread count.
-void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt > 64) nt = 64;
-  if (n < 16 || nt < 2) { for (size_t i = 0; i < n; i++) fn(i); return; }
+// A persistent pool (round 3 spawned and joined up to 64 threads per call: ~2 ms of a packed call's ~25 ms, several times per call).
+// A call hands out `tickets` for its job; pool threads that take one run the job's index loop beside the caller, who always takes
+// part itself -- so a parallel_for from inside a pool thread (or from several caller threads at once: the pipelined entry points)
+// cannot deadlock, it only finds fewer helpers.
+namespace {
+struct PfJob {
+  size_t n;
+  const std::function<void(size_t)>* fn;
   std::atomic<size_t> next{0};
+  std::atomic<int> helpers{0};          // pool threads still inside this job
   std::exception_ptr first;
   std::mutex mu;
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++) {
-    th.emplace_back([&]() {
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= n) return;
-        try {
-          fn(i);
-        } catch (...) {
-          std::lock_guard<std::mutex> g(mu);
-          if (!first) first = std::current_exception();
-        }
+  std::condition_variable done;
+  void run() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      try {
+        (*fn)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!first) first = std::current_exception();
       }
-    });
+    }
   }
-  for (auto& x : th) x.join();
-  if (first) std::rethrow_exception(first);
+};
+class PfPool {
+ public:
+  static PfPool& get() { static PfPool* p = new PfPool(); return *p; }          // leaked on purpose: no join at process exit
+  unsigned size() const { return (unsigned)threads_.size(); }
+  void offer(const std::shared_ptr<PfJob>& job, unsigned tickets) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (unsigned t = 0; t < tickets; t++) q_.push_back(job);
+    }
+    if (tickets == 1) cv_.notify_one(); else cv_.notify_all();
+  }
+  // tickets nobody took yet are withdrawn (the caller finished the indices itself)
+  void withdraw(const std::shared_ptr<PfJob>& job) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto it = q_.begin(); it != q_.end();) it = (*it == job) ? q_.erase(it) : it + 1;
+  }
+ private:
+  PfPool() {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 64) nt = 64;
+    if (nt < 2) nt = 2;
+    for (unsigned t = 0; t + 1 < nt; t++) threads_.emplace_back([this] { loop(); });
+    for (auto& t : threads_) t.detach();
+  }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<PfJob> job;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return !q_.empty(); });
+        job = q_.front();
+        q_.pop_front();
+        job->helpers.fetch_add(1);
+      }
+      job->run();
+      {
+        std::lock_guard<std::mutex> g(job->mu);
+        job->helpers.fetch_sub(1);
+      }
+      job->done.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::shared_ptr<PfJob>> q_;
+  std::vector<std::thread> threads_;
+};
+}  // namespace
+void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+  PfPool& pool = PfPool::get();
+  if (n < 16 || pool.size() == 0) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  auto job = std::make_shared<PfJob>();
+  job->n = n;
+  job->fn = &fn;
+  pool.offer(job, (unsigned)std::min<size_t>(pool.size(), n - 1));
+  job->run();
+  pool.withdraw(job);                        // from here on no new helper can enter (taking a ticket and `helpers++` happen under the pool's lock)
+  {
+    std::unique_lock<std::mutex> g(job->mu);
+    job->done.wait(g, [&] { return job->helpers.load() == 0; });
+  }
+  if (job->first) std::rethrow_exception(job->first);
 }
 // Items of one batch usually repeat a few policies: the parsed tree and its Lagrange coefficients (pure functions of
 // the policy text) are computed once per distinct (text, language) within a call.
@@ -1011,47 +1105,34 @@ static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, 
   eng.check(rhip_gt_table_pow(cx, egt, n, drho.as<rhip_fr>(), dm.as<rhip_gt>()), "rhip_gt_table_pow");
   eng.check(rhip_ac17_cp_encrypt_batch(cx, dpk, n, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), total_rows, ds.as<rhip_fr>(),
                                        dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>()), "rhip_ac17_cp_encrypt_batch");
-  uint8_t* h_c = eng.pinned(1, total_rows * 192);
-  uint8_t* h_x = eng.pinned(2, n * (384 + 384 + 384));          // c_0 | c_p | msg per item
-  eng.check(rhip_download_async(cx, h_c, dc.ptr(), total_rows * 192), "download");
-  eng.check(rhip_download_async(cx, h_x, dc0.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_x + n * 384, dcp.ptr(), n * 384), "download");
-  eng.check(rhip_download_async(cx, h_x + 2 * n * 384, dm.ptr(), n * 384), "download");
-  uint8_t* ob = out_buf;
-  {
-    eng.check(rhip_sync(cx), "rhip_sync");
-    tm.lap("device + copies");
-    parallel_for(n, [&](size_t i) {               // record assembly + KDF + AES-GCM per item, on all cores
-      const size_t p_ = item_policy[i];
-      const AbePolicy& msp = pols[p_]->msp;
-      uint8_t* w = ob + out_off[i];
-      if (policies) {                             // Ac17CpCiphertext: policy text + language
-        const std::string& pol = (*policies)[p_];
-        put_u32(w, (uint32_t)pol.size()); w += 4;
-        memcpy(w, pol.data(), pol.size()); w += pol.size();
-        *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
-      } else {                                    // Ac17KpCiphertext: the attribute strings
-        put_u32(w, (uint32_t)msp.pi.size()); w += 4;
-        for (const auto& a : msp.pi) { put_u32(w, (uint32_t)a.size()); w += 4; memcpy(w, a.data(), a.size()); w += a.size(); }
-      }
-      put_u32(w, 3); w += 4;
-      memcpy(w, h_x + 384 * i, 384); w += 384;
-      put_u32(w, (uint32_t)msp.m.size()); w += 4;
-      const uint8_t* rows = h_c + (size_t)row_off[i] * 192;
-      for (size_t r = 0; r < msp.m.size(); r++) {
-        put_u32(w, (uint32_t)msp.pi[r].size()); w += 4;
-        memcpy(w, msp.pi[r].data(), msp.pi[r].size()); w += msp.pi[r].size();
-        put_u32(w, 3); w += 4;
-        memcpy(w, rows + 192 * r, 192); w += 192;
-      }
-      memcpy(w, h_x + n * 384 + 384 * i, 384); w += 384;
-      const size_t len = (size_t)(pt_off[i + 1] - pt_off[i]);
-      put_u32(w, (uint32_t)(len + 28)); w += 4;
-      Bytes sealed = encrypt_symmetric(h_x + 2 * n * 384 + 384 * i, pt_blob + pt_off[i], len, nonces[i].data());
-      memcpy(w, sealed.data(), sealed.size());
-    });
+  // records and sealing on the device (records.h): per policy a template of the literal bytes with the elements dropped in
+  std::vector<RecordLayout> layouts(pols.size());
+  for (size_t p_ = 0; p_ < pols.size(); p_++) {
+    RecordLayout& L = layouts[p_];
+    const AbePolicy& msp = pols[p_]->msp;
+    if (policies) {                               // Ac17CpCiphertext: policy text + language
+      L.str((*policies)[p_]);
+      L.u8((language == PolicyLanguage::HumanPolicy) ? 1 : 0);
+    } else {                                      // Ac17KpCiphertext: the attribute strings
+      L.u32((uint32_t)msp.pi.size());
+      for (const auto& a : msp.pi) L.str(a);
+    }
+    L.u32(3);
+    L.src(0, 0, 384);
+    L.u32((uint32_t)msp.m.size());
+    for (size_t r = 0; r < msp.m.size(); r++) {
+      L.str(msp.pi[r]);
+      L.u32(3);
+      L.src(1, (uint32_t)(192 * r), 192);
+    }
+    L.src(2, 0, 384);
+    if (L.bytes() + 4 != pols[p_]->fixed_bytes) throw RabeError("ac17 encrypt_packed: record layout and size disagree");
   }
-  tm.lap("assembly + AES");
+  std::vector<uint64_t> src_off(3 * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 384ull * i; src_off[n + i] = 192ull * row_off[i]; src_off[2 * n + i] = 384ull * i; }
+  emit_sealed_records(eng, layouts, n, item_policy, {dc0.ptr(), dc.ptr(), dcp.ptr()}, src_off, dm.ptr(), (const uint8_t*)nonces.data(), pt_blob, pt_off,
+                      out_off, out_buf);
+  tm.lap("device: group arithmetic, records, sealing; one copy out");
   return true;
 }
 
@@ -1156,6 +1237,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
     bucket.push_back(e);
     return e.get();
   };
+  BlobGather gather(eng, ct_blob, ct_len);          // the blob starts for the device now, beside the parsing below (records.h)
   struct View { const uint8_t* c0; const uint8_t* cp; const uint8_t* sealed; uint32_t sealed_len; uint32_t rows; const uint8_t* first_row;
                 std::vector<const uint8_t*> row_ptr; const std::vector<uint32_t>* ct_sel; const std::vector<uint32_t>* sk_sel;
                 std::vector<uint32_t> own_sel; };
@@ -1242,82 +1324,90 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
     sk_sel_off.push_back((uint32_t)sk_sel.size());
   }
   const size_t m = live.size();
-  uint8_t* h_out = nullptr;
-  if (m) {
-    const size_t total_rows = ct_row_off[m];
-    uint8_t* h_c = eng.pinned(1, total_rows * 192);
-    uint8_t* h_x = eng.pinned(2, m * (384 + 384 + 384));
-    parallel_for(m, [&](size_t j) {
-      const View& w = v[live[j]];
-      memcpy(h_x + 384 * j, w.c0, 384);
-      memcpy(h_x + m * 384 + 384 * j, w.cp, 384);
-      uint8_t* dst = h_c + (size_t)ct_row_off[j] * 192;
-      for (uint32_t r = 0; r < w.rows; r++) memcpy(dst + 192 * r, w.row_ptr[r], 192);
-    });
-    tm.lap("pack");
-    std::vector<uint8_t> k0 = flatten(core.k_0), kp_bytes = core.k_p.size() == 3 ? flatten(core.k_p) : std::vector<uint8_t>(3 * 64, 0), kk;   // KP: prod_h starts from G1::zero()
-    for (const auto& row : core.k) for (const auto& x : row.second) kk.insert(kk.end(), x.begin(), x.end());
-    if (kk.empty()) kk.assign(64, 0);
-    std::vector<uint32_t> sk_row_off{0, (uint32_t)core.k.size()}, sk_idx(m, 0);
-    rhip_ctx* cx = eng.ctx();
-    DBuf d1(&eng, m * 384), d2(&eng, total_rows * 192), d3(&eng, ct_row_off.data(), ct_row_off.size() * 4), d4(&eng, m * 384),
-        d5(&eng, k0.data(), k0.size()), d6(&eng, kk.data(), kk.size()), d7(&eng, sk_row_off.data(), 8), d8(&eng, kp_bytes.data(), kp_bytes.size()),
-        d9(&eng, sk_idx.data(), m * 4), d10(&eng, ct_sel.data(), ct_sel.size() * 4), d11(&eng, ct_sel_off.data(), ct_sel_off.size() * 4),
-        d12(&eng, sk_sel.data(), sk_sel.size() * 4), d13(&eng, sk_sel_off.data(), sk_sel_off.size() * 4), dout(&eng, m * 384);
-    eng.check(rhip_upload_async(cx, d1.ptr(), h_x, m * 384), "upload");
-    eng.check(rhip_upload_async(cx, d4.ptr(), h_x + m * 384, m * 384), "upload");
-    eng.check(rhip_upload_async(cx, d2.ptr(), h_c, total_rows * 192), "upload");
-    // decoding checks over the staged records, on the side context beside the decrypt kernels; a non-member fails its item only (the
-    // batch still runs: the kernels terminate on any input, the item's result is discarded below)
-    std::unique_ptr<MemberChecks> mc;
-    if (!trusted) {
-      mc.reset(new MemberChecks(eng));
-      mc->add(2, d1.ptr(), 3 * m);
-      mc->add(1, d2.ptr(), 3 * total_rows, d3.as<uint32_t>(), m, 3);
-      mc->add(3, d4.ptr(), m);
-    }
-    // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
-    std::string k0_key((const char*)k0.data(), k0.size());
-    rhip_ac17_sk_lines* lines = (rhip_ac17_sk_lines*)eng.aux("ac17_sk_lines", k0_key, make_ac17_sk_lines, &k0_key, destroy_ac17_sk_lines, 4);
-    int32_t rc = rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3.as<uint32_t>(), d4.as<rhip_gt>(), lines,
-                                                     d6.as<rhip_g1>(), d7.as<uint32_t>(), d8.as<rhip_g1>(), d9.as<uint32_t>(), d10.as<uint32_t>(),
-                                                     d11.as<uint32_t>(), d12.as<uint32_t>(), d13.as<uint32_t>(), dout.as<rhip_gt>());
-    h_out = h_x + 2 * m * 384;
-    if (rc == RHIP_OK) rc = rhip_download_async(cx, h_out, dout.ptr(), m * 384);
-    if (rc == RHIP_OK) rc = rhip_sync(cx);
-    eng.check(rc, "rhip_ac17_cp_decrypt_batch_prepared");
-    if (mc) {
-      mc->collect();
-      const auto &ok_c0 = mc->ok(0), &ok_rows = mc->ok(1), &ok_cp = mc->ok(2);
-      for (size_t j = 0; j < m; j++) {
-        const char* bad = nullptr;
-        for (int t = 0; t < 3 && !bad; t++) if (!ok_c0[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
-        if (!bad && !ok_rows[j]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
-        if (!bad && !ok_cp[j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
-        if (bad) (*errors)[live[j]] = bad;
+  if (!m) {
+    pt_off[0] = 0;
+    for (size_t i = 0; i < n; i++) { pt_off[i + 1] = 0; status[i] = -1; }
+    return true;
+  }
+  const size_t total_rows = ct_row_off[m];
+  rhip_ctx* cx = eng.ctx();
+  // The elements are gathered out of the device copy of the blob.  Items that share a policy and its row names share one part list --
+  // their records have the same skeleton, hence the same relative offsets (checked on the ends); any other item brings its own.
+  std::vector<uint64_t> sealed_off(m);
+  std::vector<uint32_t> sealed_len(m);
+  auto parts_of = [&](const View& w, const uint8_t* rec) {
+    std::vector<RecordLayout::Part> parts;
+    parts.push_back({(uint32_t)(w.c0 - rec), 384, 0, 0});
+    for (uint32_t r = 0; r < w.rows; r++) parts.push_back({(uint32_t)(w.row_ptr[r] - rec), 192, 1, 192 * r});
+    parts.push_back({(uint32_t)(w.cp - rec), 384, 2, 0});
+    return parts;
+  };
+  struct Ends { uint32_t c0, row0, cp, rows; };
+  std::unordered_map<const void*, Ends> ends;
+  for (size_t j = 0; j < m; j++) {
+    const View& w = v[live[j]];
+    const uint8_t* rec = ct_blob + ct_off[live[j]];
+    sealed_off[j] = (uint64_t)(w.sealed - ct_blob);
+    sealed_len[j] = w.sealed_len;
+    const Ends e{(uint32_t)(w.c0 - rec), w.rows ? (uint32_t)(w.row_ptr[0] - rec) : 0u, (uint32_t)(w.cp - rec), w.rows};
+    int shape = -1;
+    if (w.ct_sel != &w.own_sel) {
+      shape = gather.find(w.ct_sel);
+      if (shape < 0) {
+        shape = (int)gather.add_shape(w.ct_sel, parts_of(w, rec));
+        ends[w.ct_sel] = e;
+      } else {
+        const Ends& f = ends[w.ct_sel];
+        if (f.c0 != e.c0 || f.row0 != e.row0 || f.cp != e.cp || f.rows != e.rows) shape = -1;
       }
     }
+    if (shape < 0) shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
+    gather.item(ct_off[live[j]], (uint32_t)shape);
   }
-  tm.lap(trusted ? "device + copies" : "device + copies, membership beside");
-  // AES-GCM open on all cores; plaintext i has sealed_len - 28 bytes when everything is well-formed
-  pt_off[0] = 0;
-  std::vector<size_t> slot(n, (size_t)-1);
-  for (size_t j = 0; j < m; j++) slot[live[j]] = j;
-  for (size_t i = 0; i < n; i++) pt_off[i + 1] = pt_off[i] + ((*errors)[i].empty() && v[i].sealed_len >= 28 ? v[i].sealed_len - 28 : 0);
-  uint8_t* pb = pt_buf;
-  parallel_for(n, [&](size_t i) {
-    status[i] = -1;
-    if (!(*errors)[i].empty()) return;
-    Bytes pt;
-    if (v[i].sealed_len >= 28 && decrypt_symmetric(h_out + 384 * slot[i], v[i].sealed, v[i].sealed_len, &pt) && pt.size() == v[i].sealed_len - 28) {
-      memcpy(pb + pt_off[i], pt.data(), pt.size());
-      status[i] = 0;
-    } else {
-      memset(pb + pt_off[i], 0, (size_t)(pt_off[i + 1] - pt_off[i]));
-      (*errors)[i] = "decryption error: aead::Error";
+  std::vector<uint8_t> k0 = flatten(core.k_0), kp_bytes = core.k_p.size() == 3 ? flatten(core.k_p) : std::vector<uint8_t>(3 * 64, 0), kk;   // KP: prod_h starts from G1::zero()
+  for (const auto& row : core.k) for (const auto& x : row.second) kk.insert(kk.end(), x.begin(), x.end());
+  if (kk.empty()) kk.assign(64, 0);
+  std::vector<uint32_t> sk_row_off{0, (uint32_t)core.k.size()}, sk_idx(m, 0);
+  DBuf d1(&eng, m * 384), d2(&eng, total_rows * 192 + 4), d4(&eng, m * 384), dout(&eng, m * 384);
+  std::vector<uint64_t> dst_off(3 * m);
+  for (size_t j = 0; j < m; j++) { dst_off[j] = 384ull * j; dst_off[m + j] = 192ull * ct_row_off[j]; dst_off[2 * m + j] = 384ull * j; }
+  ParamPack pp(eng);
+  const size_t h3 = pp.add(ct_row_off), h6 = pp.add(kk), h7 = pp.add(sk_row_off), h8 = pp.add(kp_bytes), h9 = pp.add(sk_idx),
+               h10 = pp.add(ct_sel), h11 = pp.add(ct_sel_off), h12 = pp.add(sk_sel), h13 = pp.add(sk_sel_off);
+  pp.upload();
+  tm.lap("selection tables");
+  gather.run({d1.ptr(), d2.ptr(), d4.ptr()}, dst_off);
+  const uint32_t* d3 = pp.dev<uint32_t>(h3);
+  // decoding checks over the gathered elements, on the side context beside the decrypt kernels; a non-member fails its item only (the
+  // batch still runs: the kernels terminate on any input, the item's result is discarded below)
+  std::unique_ptr<MemberChecks> mc;
+  if (!trusted) {
+    mc.reset(new MemberChecks(eng));
+    mc->add(2, d1.ptr(), 3 * m);
+    mc->add(1, d2.ptr(), 3 * total_rows, d3, m, 3);
+    mc->add(3, d4.ptr(), m);
+  }
+  // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
+  std::string k0_key((const char*)k0.data(), k0.size());
+  rhip_ac17_sk_lines* lines = (rhip_ac17_sk_lines*)eng.aux("ac17_sk_lines", k0_key, make_ac17_sk_lines, &k0_key, destroy_ac17_sk_lines, 4);
+  eng.check(rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3, d4.as<rhip_gt>(), lines, pp.dev<rhip_g1>(h6),
+                                                pp.dev<uint32_t>(h7), pp.dev<rhip_g1>(h8), pp.dev<uint32_t>(h9), pp.dev<uint32_t>(h10),
+                                                pp.dev<uint32_t>(h11), pp.dev<uint32_t>(h12), pp.dev<uint32_t>(h13), dout.as<rhip_gt>()),
+            "rhip_ac17_cp_decrypt_batch_prepared");
+  if (mc) {
+    mc->collect();
+    const auto &ok_c0 = mc->ok(0), &ok_rows = mc->ok(1), &ok_cp = mc->ok(2);
+    for (size_t j = 0; j < m; j++) {
+      const char* bad = nullptr;
+      for (int t = 0; t < 3 && !bad; t++) if (!ok_c0[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
+      if (!bad && !ok_rows[j]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
+      if (!bad && !ok_cp[j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
+      if (bad) (*errors)[live[j]] = bad;
     }
-  });
-  tm.lap("AES open");
+  }
+  // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
+  open_sealed_records(eng, n, live, dout.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
 

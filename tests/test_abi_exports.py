@@ -20,6 +20,7 @@ def declared_symbols():
     for header, prefix in (("rabe_hip.h", "rhip_"), ("rabe_host.h", "rabe_")):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # macros (rabe_host_open) are not symbols
         out |= set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text))
     return sorted(out)
 
