@@ -781,12 +781,50 @@ def object_api_leg(args, trees):
         t1 = time.perf_counter()
         out = ac17.cp_decrypt_batch(host, [sk] * n, cts)
         t2 = time.perf_counter()
-        return {"ops_per_s": packed["ops_per_s"], "packed": packed,
-                "objects": {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "plaintexts_match": out == pts},
+        objects = {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "plaintexts_match": out == pts}
+        del cts
+        threads = threads_leg(host, pk, sk, pols)
+        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "threads": threads,
+                "objects": objects,
                 "note": "policy text + plaintext bytes -> canonical ciphertext records -> plaintext bytes through the C ABI of the host layer; "
                         "parse/MSP/pruning/KDF/AES-GCM, record assembly and the PCIe copies are inside the timed region (best of 3 for `packed`)"}
     finally:
         host.close()
+
+
+def threads_leg(host, pk, sk, pols):
+    """The reference's API shape under load: host threads that issue rabe_ac17_cp_encrypt / rabe_ac17_cp_decrypt ONE CALL AT A TIME on one
+    host handle, through the submission queue (include/rabe_host.h: concurrent calls are collected into packed batches).  `blocking`:
+    every thread waits for each call (throughput = threads / latency of a launch set: what the API shape allows); `in_flight`: every
+    thread keeps `depth` submitted calls in flight (rabe_*_submit / rabe_ticket_wait)."""
+    import ctypes
+    from rabe_amd import hostlib as hl
+    host.set_coalescing(True, window_us=200)          # a batch stays open for 0.2 ms: the threads that were released together join it
+    out = {"window_us": 200}
+    try:
+        arr, npol = hl._strs(pols)
+        prev = [0] * 6
+        for name, T, depth, seconds in (("blocking", 64, 1, 1.5), ("blocking_1024", 1024, 1, 1.5), ("in_flight", 64, 64, 2.0)):
+            ops, bad = ctypes.c_uint64(), ctypes.c_uint64()
+            t0 = time.perf_counter()
+            hl._check(host.lib.rabe_bench_ac17_threads(host.h, pk.ptr, sk.ptr, arr, npol, hl.JSON_POLICY, ctypes.c_uint32(T), ctypes.c_uint32(depth),
+                                                       ctypes.c_double(seconds), ctypes.byref(ops), ctypes.byref(bad)), host.h)
+            dt = time.perf_counter() - t0
+            st = (ctypes.c_uint64 * 6)()
+            host.lib.rabe_host_queue_stats(host.h, st)
+            d_ = [int(st[k]) - prev[k] for k in range(5)]
+            prev = [int(st[k]) for k in range(6)]
+            out[name] = {"threads": T, "calls_in_flight_per_thread": depth, "ops_per_s": round(ops.value / dt, 1), "ops": ops.value,
+                         "seconds": round(dt, 2), "plaintexts_match": bad.value == 0,
+                         "queue": {"batches": d_[0], "requests": d_[1], "packed_calls": d_[2], "ran_singly": d_[3],
+                                   "ms_inside_batches": round(d_[4] / 1e3, 1), "requests_per_batch": round(d_[1] / max(d_[0], 1), 1)}}
+    finally:
+        host.set_coalescing(False)
+    out["note"] = ("one call per ciphertext from native host threads on ONE host handle (rabe_bench_ac17_threads calls the public entry points); calls that "
+                   "arrive while a batch runs are collected into the next packed batch (group commit). A blocking caller has one call in flight, so "
+                   "`blocking*` is bounded by threads / (latency of an encrypt launch set + a decrypt launch set, ~20 ms); `in_flight` is the same API "
+                   "with 64 submitted calls per thread (rabe_*_submit / rabe_ticket_wait)")
+    return out
 
 
 def pmc_traffic(kernel):

@@ -190,21 +190,30 @@ def packed_api_leg(args, b):
                 if rep and (best is None or dt < best[0]):
                     best = (dt, r_)
             return best
+
+        def io_buffers(first_call):
+            """caller-allocated, RE-USED output buffers, as a server keeps them (the first call also builds tables and staging areas:
+            untimed): fresh pages cost a page fault each when the device's copy lands in them (185 MB: 11.5 instead of 3.3 ms)"""
+            blob0, _ = first_call()
+            ct_buf = np.zeros(blob0.size, dtype=np.uint8)
+            return ct_buf, np.zeros(blob0.size, dtype=np.uint8)
         if args.config == 3:
             from rabe_amd.schemes import bsw
             pk, msk = bsw.setup(host)
             sk = bsw.keygen(host, pk, msk, b.attrs)
-            te, (blob, off) = best_of(lambda: bsw.encrypt_packed(host, pk, pols, item_pol, pt_blob, pt_off))
-            td, (o, _, st) = best_of(lambda: bsw.decrypt_packed(host, sk, blob, off))
-            tt_, (o2, _, st2) = best_of(lambda: bsw.decrypt_packed(host, sk, blob, off, trusted=True))
+            ct_buf, pt_buf = io_buffers(lambda: bsw.encrypt_packed(host, pk, pols, item_pol, pt_blob, pt_off))
+            te, (blob, off) = best_of(lambda: bsw.encrypt_packed(host, pk, pols, item_pol, pt_blob, pt_off, out=ct_buf))
+            td, (o, _, st) = best_of(lambda: bsw.decrypt_packed(host, sk, blob, off, out=pt_buf))
+            tt_, (o2, _, st2) = best_of(lambda: bsw.decrypt_packed(host, sk, blob, off, out=pt_buf, trusted=True))
             ok = o.tobytes() == pt_blob.tobytes() and not st.any() and o2.tobytes() == pt_blob.tobytes() and not st2.any()
         elif args.config == 4:
             from rabe_amd.schemes import lsw
             pk, msk = lsw.setup(host)
             ct = lsw.encrypt(host, pk, b.attrs, pts[0])
-            te, (blob, off) = best_of(lambda: lsw.keygen_packed(host, pk, msk, pols, item_pol))
-            td, (o, _, st) = best_of(lambda: lsw.decrypt_packed(host, ct, blob, off))
-            tt_, (o2, _, st2) = best_of(lambda: lsw.decrypt_packed(host, ct, blob, off, trusted=True))
+            ct_buf, pt_buf = io_buffers(lambda: lsw.keygen_packed(host, pk, msk, pols, item_pol))
+            te, (blob, off) = best_of(lambda: lsw.keygen_packed(host, pk, msk, pols, item_pol, out=ct_buf))
+            td, (o, _, st) = best_of(lambda: lsw.decrypt_packed(host, ct, blob, off, out=pt_buf))
+            tt_, (o2, _, st2) = best_of(lambda: lsw.decrypt_packed(host, ct, blob, off, out=pt_buf, trusted=True))
             ok = o.tobytes() == pts[0] * n and not st.any() and o2.tobytes() == pts[0] * n and not st2.any()
         else:
             from rabe_amd.schemes import aw11
@@ -216,9 +225,10 @@ def packed_api_leg(args, b):
                 for nm in b.attrs[a * per:(a + 1) * per]:
                     aw11.add_to_attribute(host, gk, auth[a][1], nm, sk)
             pks = [a[0] for a in auth]
-            te, (blob, off) = best_of(lambda: aw11.encrypt_packed(host, gk, pks, pols, item_pol, pt_blob, pt_off))
-            td, (o, _, st) = best_of(lambda: aw11.decrypt_packed(host, gk, sk, blob, off))
-            tt_, (o2, _, st2) = best_of(lambda: aw11.decrypt_packed(host, gk, sk, blob, off, trusted=True))
+            ct_buf, pt_buf = io_buffers(lambda: aw11.encrypt_packed(host, gk, pks, pols, item_pol, pt_blob, pt_off))
+            te, (blob, off) = best_of(lambda: aw11.encrypt_packed(host, gk, pks, pols, item_pol, pt_blob, pt_off, out=ct_buf))
+            td, (o, _, st) = best_of(lambda: aw11.decrypt_packed(host, gk, sk, blob, off, out=pt_buf))
+            tt_, (o2, _, st2) = best_of(lambda: aw11.decrypt_packed(host, gk, sk, blob, off, out=pt_buf, trusted=True))
             ok = o.tobytes() == pt_blob.tobytes() and not st.any() and o2.tobytes() == pt_blob.tobytes() and not st2.any()
         first = "keygen_s" if args.config == 4 else "encrypt_s"
         out.update({"ops_per_s": round(n / (te + td), 1), first: round(te, 4), "decrypt_s": round(td, 4), "decrypt_trusted_s": round(tt_, 4),

@@ -34,12 +34,41 @@ enum { RABE_JSON_POLICY = 0, RABE_HUMAN_POLICY = 1 };   /* PolicyLanguage, src/u
 /* ABI revision of this header.  An argument list that changes keeps its symbol name only together with a bump of this number (revision 3
  * inserted ct_len and flags into the packed decrypts): a caller passes the revision it was COMPILED against -- rabe_host_open is the macro
  * for that -- and a library of another revision refuses with -3 instead of reading shifted arguments.  rabe_host_create does not check. */
-#define RABE_HOST_ABI_VERSION 4
+#define RABE_HOST_ABI_VERSION 5
 int32_t rabe_host_abi_version(void);
 int32_t rabe_host_create_checked(int32_t abi_version, int32_t device, rabe_host** out);
 #define rabe_host_open(device, out) rabe_host_create_checked(RABE_HOST_ABI_VERSION, (device), (out))
 int32_t rabe_host_create(int32_t device, rabe_host** out);
 void rabe_host_destroy(rabe_host* h);
+/* ---- submission queue: one call at a time, many callers ------------------------------------------------------------------------
+ * The reference's API is one call per ciphertext (src/schemes/ac17/mod.rs:274-279, :385-388; rabe-console/src/mod.rs:1098, 1310) and one
+ * call is one small launch set: milliseconds of latency for microseconds of chip time.  With the queue ON, the one-call encrypt / decrypt
+ * entry points of ac17 (CP), bsw, lsw and aw11 below may be called from MANY THREADS on one rabe_host: calls that arrive while a batch is
+ * running are collected and run as one packed batch (group commit: the batch grows with the load; window_us > 0 additionally holds every
+ * batch open for that long).  Randomness is drawn in arrival order: one caller on a fixed tape gets the bytes of the unqueued path.
+ * Errors of a threaded caller: rabe_host_last_error(NULL) (per thread).  Every other entry point stays single-owner.
+ * The *_submit forms queue a call and return at once; rabe_ticket_wait blocks until the result is there (and may run the queued batch
+ * itself -- there is no service thread), hands out the ciphertext object (encrypt) or the plaintext (decrypt, rabe_bytes_free) and frees
+ * the ticket.  Key objects and, for decrypts, the ciphertext object must stay alive until the wait returns; plaintexts are copied. */
+typedef struct rabe_ticket rabe_ticket;
+int32_t rabe_host_set_coalescing(rabe_host* h, int32_t on, uint32_t window_us);
+/* what the queue has done so far: batches run, requests in them, groups (= packed calls), requests that ran singly, microseconds spent
+ * inside batches, largest batch */
+int32_t rabe_host_queue_stats(rabe_host* h, uint64_t out[6]);
+int32_t rabe_ac17_cp_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket);
+int32_t rabe_ac17_cp_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket);
+int32_t rabe_bsw_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket);
+int32_t rabe_bsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket);
+int32_t rabe_lsw_encrypt_submit(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* pt, size_t len, rabe_ticket** ticket);
+int32_t rabe_lsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket);
+int32_t rabe_aw11_encrypt_submit(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
+                                 const uint8_t* data, size_t len, rabe_ticket** ticket);
+int32_t rabe_aw11_decrypt_submit(rabe_host* h, const void* gk, const void* sk, const void* ct, rabe_ticket** ticket);
+int32_t rabe_ticket_wait(rabe_host* h, rabe_ticket* ticket, void** obj /*encrypt*/, uint8_t** out, size_t* len /*decrypt*/);
+/* measurement helper: `threads` native host threads issue rabe_ac17_cp_encrypt + rabe_ac17_cp_decrypt one call at a time on this host
+ * (depth 1), or keep `depth` submitted calls in flight each, for `seconds`; *ops = verified encrypt+decrypt cycles, *bad = the others */
+int32_t rabe_bench_ac17_threads(rabe_host* h, const void* pk, const void* sk, const char* const* policies, size_t n_policies, int32_t language,
+                                uint32_t threads, uint32_t depth, double seconds, uint64_t* ops, uint64_t* bad);
 const char* rabe_host_last_error(rabe_host* h);          /* h may be NULL: error of the last host-free call on this thread */
 /* Explicit randomness: the next calls draw their Fr values from this tape, in the reference's
  * draw order, instead of the OS generator.  n = 0 switches back to OS randomness. */
@@ -110,6 +139,12 @@ int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
 
 /* KP-ABE variant (src/schemes/ac17/mod.rs:439-675) */
 int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, int32_t language, void** sk);
+/* n_items calls of ac17::kp_keygen (src/schemes/ac17/mod.rs:439-547) under one master key, item i under policies[item_policy[i]]: the triple
+ * loop over rows x columns x (l, t) (:479-538) is Fr work on all host cores, the 3 rows + 3 elements per key are ONE fixed-base launch set,
+ * the records (Ac17KpSecretKey: policy, k_0, rows, an empty k_p) are written on the device.  Buffers / return value as
+ * rabe_ac17_cp_keygen_packed (1 = sk_cap too small, sk_off[n_items] says what is needed). */
+int32_t rabe_ac17_kp_keygen_packed(rabe_host* h, const void* msk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                   const uint32_t* item_policy /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct);
 int32_t rabe_ac17_kp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** plaintext, size_t* len);
 int32_t rabe_ac17_kp_decrypt_gt(rabe_host* h, const void* sk, const void* ct, uint8_t out_gt[384]);
@@ -151,6 +186,12 @@ int32_t rabe_bsw_decrypt_batch(rabe_host* h, size_t n, const void* const* sks, c
  * three window-table launches for the whole batch.  An empty attribute list (for which bsw::keygen returns None) fails the call. */
 int32_t rabe_bsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, const char* const* attributes, const size_t* counts, size_t n_sets,
                                size_t n_items, const uint32_t* item_set /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
+/* n_items calls of bsw::delegate (src/schemes/bsw/mod.rs:162-206) on ONE key: item i delegates `sk` to the attribute list item_subset[i] of the
+ * n_subsets lists given once (flattened in `attributes`, `counts` each).  d' = d + f * r, rows D_j + (g1 * r_j, g2 * (h(j) r_j + r)): window-table
+ * launches and batched additions for the whole batch, records (CpAbeSecretKey) written on the device.  A subset that is empty or not contained
+ * in the key (delegate returns None) fails the call; buffers / return value as rabe_bsw_keygen_packed. */
+int32_t rabe_bsw_delegate_packed(rabe_host* h, const void* pk, const void* sk, const char* const* attributes, const size_t* counts, size_t n_subsets,
+                                 size_t n_items, const uint32_t* item_subset /*[n_items]*/, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off /*[n_items+1]*/);
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
                                 const uint32_t* item_policy /*[n_items]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n_items+1]*/,
                                 uint8_t* ct_buf, size_t ct_cap, uint64_t* ct_off /*[n_items+1]*/);

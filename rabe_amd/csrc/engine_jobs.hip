@@ -188,19 +188,29 @@ struct DevMultiAcc : LdsHomeT<4> {
   }
 };
 // lane t = chunk * n_items + item: a wave holds 64 items at the same chunk position, so that batches of equally shaped
-// items run without divergence and read the same prepared lines.  Chunk c of an item = its pairs
-// [pair_off[item] + c C, min(pair_off[item] + (c+1) C, pair_off[item+1])).  Output: mill[item * L + c].
+// items run without divergence and read the same prepared lines.  An item of p pairs uses ceil(p / C) of its L chunks and splits its pairs
+// EVENLY over them (a ragged batch: 29 pairs at C = 13 are 10 + 10 + 9, not 13 + 13 + 3); the chunks it does not use write the unit and
+// leave at once (a Miller loop without pairs would still square its accumulator 65 times).  Output: mill[item * L + c].
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                   const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
                                                                   GtM* mill) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items * L) return;
-  const size_t c = t / n_items, item = t % n_items;
+  // Chunk row c is rotated by c blocks: consecutive blocks go to consecutive XCDs (8 of them, 32 CUs each), and in a batch grouped by shape
+  // block g of EVERY row holds the same policy -- unrotated, the rows of a many-leaf policy pile up on one XCD (measured: a ragged BSW
+  // batch whose largest policy sat on XCD 0 in every row took two rounds there, 103 ms instead of ~50).
+  const size_t c = t / n_items, item = (t % n_items + c * RB_MILLER_BLOCK) % n_items;
   // pair_off == NULL: every item owns exactly `uniform` pairs
   const uint64_t lo = pair_off ? pair_off[item] : (uint64_t)item * uniform, hi = pair_off ? pair_off[item + 1] : (uint64_t)(item + 1) * uniform;
-  const uint64_t first = lo + (uint64_t)c * C;
-  int cnt = 0;
-  if (first < hi) cnt = (int)((hi - first < C) ? (hi - first) : C);
+  const uint32_t p_item = (uint32_t)(hi - lo);
+  const uint32_t nch = (p_item + C - 1) / C;
+  if (c >= nch) {                                // nothing for this chunk (whole waves, when the batch is grouped by shape)
+    st_gt_m(mill + item * L + c, fp12_one());
+    return;
+  }
+  const uint32_t base = p_item / nch, rem = p_item % nch, cc = (uint32_t)c;
+  const uint64_t first = lo + (uint64_t)cc * base + (cc < rem ? cc : rem);
+  const int cnt = (int)(base + (cc < rem ? 1u : 0u));
   // workspace: [wave][pair slot][quad][lane of the wave] -- one coalesced 1 KB access per quad, and everything a wave touches
   // during its whole run sits in one contiguous C x 12 KB block (page locality)
   const DevMultiAcc acc{{}, P + first, Q + first, qref + first, lines, cnt, ws + (t >> 6) * ((size_t)C * 12 * 64) + (t & 63), ws_stride};
@@ -211,15 +221,18 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, RB_MIN_WAVES) k_miller_multi(
 // wave per SIMD, so a launch of W waves takes ceil(W / #SIMDs) rounds of one lane's time; a lane's time is the shared
 // squarings (65 x 36 Fp multiplications) plus ~5.5 k per pair (tests/count_muls.py).  Pick the C that minimises rounds x
 // lane time: e.g. 4096 items x 201 pairs -> C = 14, L = 15: 960 waves, one round (C = 12 would need a second round for 64 waves).
-static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs, uint32_t* L, uint32_t* C) {
+// A ragged batch (total_pairs < n_items x max_pairs; items grouped by shape, so that the chunks an item does not use are whole waves
+// that leave at once) is priced at the waves that do work: sum_i ceil(p_i / c) / 64 ~ (total_pairs / c + n_items / 2) / 64.
+static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, uint32_t* L, uint32_t* C) {
   if (max_pairs < 1) max_pairs = 1;
+  const bool ragged = total_pairs && total_pairs < n_items * max_pairs;
   const size_t simds = (size_t)ctx->n_cu * 4;
   double best = 0;
   size_t best_c = 2;
   for (size_t c = 1; c <= 64; c++) {
     const size_t l = (max_pairs + c - 1) / c;
-    const size_t c_eff = (max_pairs + l - 1) / l;
-    const size_t waves = (n_items * l + 63) / 64;
+    const size_t c_eff = ragged ? c : (max_pairs + l - 1) / l;
+    const size_t waves = ragged ? (total_pairs / c + n_items / 2 + 63) / 64 : (n_items * l + 63) / 64;
     const size_t rounds = (waves + simds - 1) / simds;
     // an odd chunk leaves one line unmerged (13 instead of 11.5 Fq2 products for it): small launches still prefer it -- a lone batch
     // of 4096 six-pair items runs as 384 waves of one pair each instead of 192 of two
@@ -228,15 +241,15 @@ static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs,
     if (l == 1) break;
   }
   const size_t l = (max_pairs + best_c - 1) / best_c;
-  const size_t c = (max_pairs + l - 1) / l;
+  const size_t c = ragged ? best_c : (max_pairs + l - 1) / l;
   *L = (uint32_t)l;
   *C = (uint32_t)c;
 }
 // Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
-static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, const PairLists& pl, const LineM* lines,
-                              const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
+static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
+                              const LineM* lines, const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
   uint32_t L, C;
-  choose_chunks(ctx, n_items, max_pairs, &L, &C);
+  choose_chunks(ctx, n_items, max_pairs, pair_off ? total_pairs : 0, &L, &C);
   const size_t lanes = n_items * L;
   const size_t lanes_pad = (lanes + 63) / 64 * 64;
   void* ws = nullptr;
@@ -562,7 +575,7 @@ static int32_t bsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
   if (compact)
     KLAUNCH(ctx, "k_bsw_entry_pairs", k_bsw_entry_pairs, dim3(blocks_for(n_items * (size_t)((ppi - 1) / 2), 256)), dim3(256), 0, ctx->stream, n_items, ppi, sel_start,
             sel_ct_leaf, ct_cy_g2, ct_leaf_off, (const G1M*)psel, (const uint8_t*)psel_inf, pl.P, pl.Q, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
 }
 
 // ------------------------------------------------------------------------------------------------ shared-doubling sums
@@ -927,7 +940,7 @@ static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
           (const G1JM*)w_part, pair_off, pl.P, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e1, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e1, out);
 }
 
 // ------------------------------------------------------------------------------------------------ GHW11 outsourced decryption
@@ -997,7 +1010,7 @@ extern "C" int32_t rhip_ghw11_transform_batch(rhip_ctx* ctx, size_t n_items, siz
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
           (const G1JM*)w_part, pair_off, pl.P, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, (const LineM*)tk_lines->lines, (const rhip_gt*)nullptr, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)tk_lines->lines, (const rhip_gt*)nullptr, out);
 }
 
 // ------------------------------------------------------------------------------------------------ AW11 multi-authority CP-ABE
@@ -1427,7 +1440,7 @@ extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t
   KLAUNCH(ctx, "k_gt_multiexp_partial", k_gt_multiexp_partial, dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const GtM*)t_c1, (const uint32_t*)w_masks, 1, p_gt);
   KLAUNCH(ctx, "k_gt_lead", k_gt_lead, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, L, ct_c0, (const GtM*)p_gt, lead);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, pl, (const LineM*)nullptr, (const rhip_gt*)lead, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)nullptr, (const rhip_gt*)lead, out);
 }
 
 // ------------------------------------------------------------------------------------------------ membership of decoded elements
@@ -1623,7 +1636,7 @@ extern "C" int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_p
     KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
             (const G1JM*)w_part, (const uint32_t*)cpo, pl.P, pl.qref);
   }
-  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), pl, (const LineM*)nullptr, lead, out);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), 0, pl, (const LineM*)nullptr, lead, out);
 }
 
 
@@ -1688,7 +1701,7 @@ static int32_t ac17_decrypt_shared(rhip_ctx* ctx, size_t n_items, const rhip_g2*
   KLAUNCH(ctx, "k_ac17_dec_pairs", k_ac17_dec_pairs, dim3(blocks_for((n_items * 3 + 63) / 64 * 128, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, ct_c0, ct_c,
           ct_row_off, sk_k0, (const uint8_t*)(sk_lines ? sk_lines->q_inf : nullptr), sk_lines ? 1 : 0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off,
           sk_sel, sk_sel_off, pl.P, pl.Q, pl.qref);
-  return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, ct_cp, out);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, 0, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, ct_cp, out);
 }
 // which AC17 decrypt path a launch takes: 0 = shared accumulators (this file), 1 = one lane per pairing / couple (engine.hip).
 // RABE_AC17_DEC_PATH overrides for A/B runs.  Small launches keep the pairwise kernels (their three-lane form is latency-optimised).

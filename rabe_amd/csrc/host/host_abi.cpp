@@ -8,6 +8,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+
 #include "../../../include/rabe_host.h"
 #include "schemes.h"
 
@@ -15,11 +24,42 @@ using namespace rabe;
 using namespace rabe::host;
 using namespace rabe::schemes;
 
+// One queued call of the submission queue (below: "submission queue"); the blocking one-call entry points build one on their stack.
+struct rabe_ticket {
+  enum Op { AC17_ENC, AC17_DEC, BSW_ENC, BSW_DEC, LSW_ENC, LSW_DEC, AW11_ENC, AW11_DEC };
+  Op op;
+  const void* a = nullptr;                 // pk (encrypt) / sk (decrypt) / gk (aw11)
+  const void* b = nullptr;                 // aw11 decrypt: sk
+  std::vector<const void*> pks;            // aw11 encrypt: the authorities' public keys
+  std::string policy;
+  int32_t language = 0;
+  std::vector<std::string> attrs;          // lsw encrypt
+  Bytes pt;                                // plaintext (a copy: an asynchronous caller may reuse its buffer)
+  const void* ct = nullptr;                // decrypt: the ciphertext object (the caller keeps it alive until the wait)
+  bool done = false;
+  int32_t rc = 0;
+  std::string err;
+  void* obj = nullptr;                     // encrypt: the ciphertext object
+  Bytes out;                               // decrypt: the plaintext
+};
 struct rabe_host {
   Engine eng;
   OsRng os;
   std::unique_ptr<TapeRng> tape;
   std::string err;
+  // submission queue: concurrent one-at-a-time calls collected into packed batches (rabe_host_set_coalescing)
+  bool coalesce = false;
+  uint32_t window_us = 0;
+  std::mutex q_mu;
+  std::condition_variable q_cv;             // "a batch has finished"
+  std::condition_variable q_arrival;        // "something was queued" (the leader's window)
+  std::deque<rabe_ticket*> q;
+  // up to Q_LANES batches run at once, each on its own engine lane (stream, staging, arena) with its own OS randomness source: a small
+  // batch is bound by the latency of its launch sets, not by the chip, so batches side by side multiply the rate.  On a tape: one.
+  enum { Q_LANES = 6 };
+  bool q_lane_busy[Q_LANES] = {false, false, false, false, false, false};
+  OsRng q_rng[Q_LANES];
+  uint64_t q_stats[6] = {0, 0, 0, 0, 0, 0};  // batches, requests, groups, requests run singly, microseconds inside batches, largest batch
   explicit rabe_host(int device) : eng(device) {}
   Rng& rng() { return tape ? (Rng&)*tape : (Rng&)os; }
 };
@@ -37,7 +77,14 @@ static const size_t CHUNK_AC17 = (size_t)1 << 40, CHUNK_BSW = (size_t)1 << 40, C
   catch (const RabeError& e) { set_err(h, e.what()); return -1; }            \
   catch (const PolicyError& e) { set_err(h, e.what()); return -1; }          \
   catch (const std::exception& e) { set_err(h, std::string("panic: ") + e.what()); return -2; }
-static void set_err(rabe_host* h, const std::string& s) { g_err = s; if (h) h->err = s; }
+static void set_err(rabe_host* h, const std::string& s) {
+  g_err = s;
+  if (h) {                                       // several threads may share a host when its submission queue is on
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    h->err = s;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ serialisation
 struct W {
@@ -290,6 +337,252 @@ static std::vector<std::string> strs(const char* const* a, size_t n) {
 }
 static PolicyLanguage lang_of(int32_t l) { return l == RABE_HUMAN_POLICY ? PolicyLanguage::HumanPolicy : PolicyLanguage::JsonPolicy; }
 
+extern "C" void rabe_obj_free(int32_t kind, void* o);
+
+// ------------------------------------------------------------------------------------------------ submission queue
+// The reference's API is one call per ciphertext (ac17/mod.rs:274-279, :385-388; rabe-console/src/mod.rs:1098, 1310), and one call is
+// one small launch set: milliseconds of latency for microseconds of chip time.  With the queue on (rabe_host_set_coalescing), calls that
+// arrive while a batch is running are collected and go through the PACKED entry points as one batch (group commit: the batch size
+// adapts to the load, no timer is needed; window_us > 0 additionally holds a batch open for that long).  Whoever waits first on an
+// unfinished ticket runs the queue: no service thread.  Randomness is drawn in arrival order, so a single caller on a fixed tape gets
+// the bytes of the unqueued path.
+namespace rabe { void parallel_for(size_t n, const std::function<void(size_t)>& fn); }
+namespace {
+typedef rabe_ticket T;
+thread_local Rng* tl_queue_rng = nullptr;          // the running batch's randomness source (a lane's own, or the host's tape)
+Rng& qrng(rabe_host* h) { return tl_queue_rng ? *tl_queue_rng : h->rng(); }
+void fail(T* t, const std::string& why, int32_t rc = -1) { t->rc = rc; t->err = why; }
+// one call on its own, exactly as the unqueued entry points run it: the fallback when a batch as a whole throws (e.g. one request's
+// policy does not parse: it fails alone)
+void run_single(rabe_host* h, T* t) {
+  try {
+    switch (t->op) {
+      case T::AC17_ENC: t->obj = new ac17::Ac17CpCiphertext(ac17::cp_encrypt(h->eng, qrng(h), *(const ac17::Ac17PublicKey*)t->a, t->policy, t->pt, lang_of(t->language))); break;
+      case T::AC17_DEC: t->out = ac17::cp_decrypt(h->eng, *(const ac17::Ac17CpSecretKey*)t->a, *(const ac17::Ac17CpCiphertext*)t->ct); break;
+      case T::BSW_ENC: t->obj = new bsw::CpAbeCiphertext(bsw::encrypt(h->eng, qrng(h), *(const bsw::CpAbePublicKey*)t->a, t->policy, lang_of(t->language), t->pt)); break;
+      case T::BSW_DEC: t->out = bsw::decrypt(h->eng, *(const bsw::CpAbeSecretKey*)t->a, *(const bsw::CpAbeCiphertext*)t->ct); break;
+      case T::LSW_ENC: t->obj = new lsw::KpAbeCiphertext(lsw::encrypt(h->eng, qrng(h), *(const lsw::KpAbePublicKey*)t->a, t->attrs, t->pt)); break;
+      case T::LSW_DEC: t->out = lsw::decrypt(h->eng, *(const lsw::KpAbeSecretKey*)t->a, *(const lsw::KpAbeCiphertext*)t->ct); break;
+      case T::AW11_ENC: {
+        std::vector<const aw11::Aw11PublicKey*> v;
+        for (const void* p : t->pks) v.push_back((const aw11::Aw11PublicKey*)p);
+        t->obj = new aw11::Aw11Ciphertext(aw11::encrypt(h->eng, qrng(h), *(const aw11::Aw11GlobalKey*)t->a, v, t->policy, lang_of(t->language), t->pt));
+        break;
+      }
+      case T::AW11_DEC: t->out = aw11::decrypt(h->eng, *(const aw11::Aw11GlobalKey*)t->a, *(const aw11::Aw11SecretKey*)t->b, *(const aw11::Aw11Ciphertext*)t->ct); break;
+    }
+    t->rc = 0;
+  } catch (const RabeError& e) { fail(t, e.what());
+  } catch (const PolicyError& e) { fail(t, e.what());
+  } catch (const std::exception& e) { fail(t, std::string("panic: ") + e.what(), -2); }
+}
+// encrypt requests of one group -> one packed call -> one object per request
+void run_encrypt_group(rabe_host* h, const std::vector<T*>& g, int32_t kind,
+                       const std::function<bool(const std::vector<std::string>&, const uint32_t*, const uint8_t*, const uint64_t*, uint8_t*, size_t, uint64_t*)>& packed) {
+  const size_t n = g.size();
+  std::vector<std::string> pols;
+  std::map<std::string, uint32_t> seen;
+  std::vector<uint32_t> item(n);
+  std::vector<uint64_t> pt_off(n + 1, 0), out_off(n + 1, 0);
+  Bytes pt;
+  for (size_t i = 0; i < n; i++) {
+    auto it = seen.find(g[i]->policy);
+    if (it == seen.end()) { it = seen.insert({g[i]->policy, (uint32_t)pols.size()}).first; pols.push_back(g[i]->policy); }
+    item[i] = it->second;
+    pt.insert(pt.end(), g[i]->pt.begin(), g[i]->pt.end());
+    pt_off[i + 1] = pt.size();
+  }
+  if (pt.empty()) pt.push_back(0);
+  (void)packed(pols, item.data(), pt.data(), pt_off.data(), nullptr, 0, out_off.data());          // sizes only: nothing is drawn or computed
+  Bytes buf((size_t)out_off[n] + 1);
+  if (!packed(pols, item.data(), pt.data(), pt_off.data(), buf.data(), buf.size(), out_off.data())) throw RabeError("submission queue: packed encrypt refused its buffer");
+  rabe::parallel_for(n, [&](size_t i) {
+    R r(buf.data() + out_off[i], (size_t)(out_off[i + 1] - out_off[i]));
+    g[i]->obj = deser(r, kind);
+    g[i]->rc = 0;
+  });
+}
+// decrypt requests of one group (one key) -> records -> one packed call (objects of this process: no membership pass, like the
+// one-call path) -> one plaintext per request
+void run_decrypt_group(rabe_host* h, const std::vector<T*>& g, int32_t ct_kind,
+                       const std::function<bool(size_t, const uint8_t*, size_t, const uint64_t*, int32_t*, uint8_t*, size_t, uint64_t*, std::vector<std::string>*)>& packed) {
+  const size_t n = g.size();
+  std::vector<Bytes> rec(n);
+  rabe::parallel_for(n, [&](size_t i) { W w; ser(w, ct_kind, g[i]->ct); rec[i].swap(w.b); });
+  std::vector<uint64_t> off(n + 1, 0), pt_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + rec[i].size();
+  Bytes blob((size_t)off[n] + 1), out((size_t)off[n] + 1);
+  rabe::parallel_for(n, [&](size_t i) { memcpy(blob.data() + off[i], rec[i].data(), rec[i].size()); });
+  std::vector<int32_t> status(n, -1);
+  std::vector<std::string> errors;
+  if (!packed(n, blob.data(), (size_t)off[n], off.data(), status.data(), out.data(), out.size(), pt_off.data(), &errors))
+    throw RabeError("submission queue: packed decrypt refused its buffer");
+  for (size_t i = 0; i < n; i++) {
+    if (status[i] == 0) { g[i]->out.assign(out.begin() + pt_off[i], out.begin() + pt_off[i + 1]); g[i]->rc = 0; }
+    else fail(g[i], i < errors.size() && !errors[i].empty() ? errors[i] : "decryption failed");
+  }
+}
+void run_group(rabe_host* h, const std::vector<T*>& g) {
+  T* f = g[0];
+  Engine& eng = h->eng;
+  const PolicyLanguage lang = lang_of(f->language);
+  switch (f->op) {
+    case T::AC17_ENC:
+      run_encrypt_group(h, g, RABE_AC17_CP_CT, [&](const std::vector<std::string>& pols, const uint32_t* item, const uint8_t* pt, const uint64_t* po, uint8_t* ob, size_t oc, uint64_t* oo) {
+        return ac17::cp_encrypt_packed(eng, qrng(h), *(const ac17::Ac17PublicKey*)f->a, pols, lang, g.size(), item, pt, po, ob, oc, oo); });
+      break;
+    case T::AC17_DEC:
+      run_decrypt_group(h, g, RABE_AC17_CP_CT, [&](size_t n, const uint8_t* b, size_t bl, const uint64_t* o, int32_t* st, uint8_t* pb, size_t pc, uint64_t* po, std::vector<std::string>* er) {
+        return ac17::cp_decrypt_packed(eng, *(const ac17::Ac17CpSecretKey*)f->a, n, b, bl, o, true, st, pb, pc, po, er); });
+      break;
+    case T::BSW_ENC:
+      run_encrypt_group(h, g, RABE_BSW_CT, [&](const std::vector<std::string>& pols, const uint32_t* item, const uint8_t* pt, const uint64_t* po, uint8_t* ob, size_t oc, uint64_t* oo) {
+        return bsw::encrypt_packed(eng, qrng(h), *(const bsw::CpAbePublicKey*)f->a, pols, lang, g.size(), item, pt, po, ob, oc, oo); });
+      break;
+    case T::BSW_DEC:
+      run_decrypt_group(h, g, RABE_BSW_CT, [&](size_t n, const uint8_t* b, size_t bl, const uint64_t* o, int32_t* st, uint8_t* pb, size_t pc, uint64_t* po, std::vector<std::string>* er) {
+        return bsw::decrypt_packed(eng, *(const bsw::CpAbeSecretKey*)f->a, n, b, bl, o, true, st, pb, pc, po, er); });
+      break;
+    case T::AW11_ENC: {
+      std::vector<const aw11::Aw11PublicKey*> v;
+      for (const void* p : f->pks) v.push_back((const aw11::Aw11PublicKey*)p);
+      run_encrypt_group(h, g, RABE_AW11_CT, [&](const std::vector<std::string>& pols, const uint32_t* item, const uint8_t* pt, const uint64_t* po, uint8_t* ob, size_t oc, uint64_t* oo) {
+        return aw11::encrypt_packed(eng, qrng(h), *(const aw11::Aw11GlobalKey*)f->a, v, pols, lang, g.size(), item, pt, po, ob, oc, oo); });
+      break;
+    }
+    case T::AW11_DEC:
+      run_decrypt_group(h, g, RABE_AW11_CT, [&](size_t n, const uint8_t* b, size_t bl, const uint64_t* o, int32_t* st, uint8_t* pb, size_t pc, uint64_t* po, std::vector<std::string>* er) {
+        return aw11::decrypt_packed(eng, *(const aw11::Aw11GlobalKey*)f->a, *(const aw11::Aw11SecretKey*)f->b, n, b, bl, o, true, st, pb, pc, po, er); });
+      break;
+    case T::LSW_ENC: {                         // the packed form is keyed by attribute LISTS: the requests' lists are the sets
+      const size_t n = g.size();
+      std::vector<std::vector<std::string>> sets;
+      std::map<std::vector<std::string>, uint32_t> seen;
+      std::vector<uint32_t> item(n);
+      std::vector<uint64_t> pt_off(n + 1, 0), out_off(n + 1, 0);
+      Bytes pt;
+      for (size_t i = 0; i < n; i++) {
+        auto it = seen.find(g[i]->attrs);
+        if (it == seen.end()) { it = seen.insert({g[i]->attrs, (uint32_t)sets.size()}).first; sets.push_back(g[i]->attrs); }
+        item[i] = it->second;
+        pt.insert(pt.end(), g[i]->pt.begin(), g[i]->pt.end());
+        pt_off[i + 1] = pt.size();
+      }
+      if (pt.empty()) pt.push_back(0);
+      const lsw::KpAbePublicKey& pk = *(const lsw::KpAbePublicKey*)f->a;
+      (void)lsw::encrypt_packed(eng, qrng(h), pk, sets, n, item.data(), pt.data(), pt_off.data(), nullptr, 0, out_off.data());
+      Bytes buf((size_t)out_off[n] + 1);
+      if (!lsw::encrypt_packed(eng, qrng(h), pk, sets, n, item.data(), pt.data(), pt_off.data(), buf.data(), buf.size(), out_off.data()))
+        throw RabeError("submission queue: packed encrypt refused its buffer");
+      rabe::parallel_for(n, [&](size_t i) {
+        R r(buf.data() + out_off[i], (size_t)(out_off[i + 1] - out_off[i]));
+        g[i]->obj = deser(r, RABE_LSW_CT);
+        g[i]->rc = 0;
+      });
+      break;
+    }
+    case T::LSW_DEC: {                         // arbitrary (key, ciphertext) pairs: the object-level batch (general pairing jobs)
+      std::vector<const lsw::KpAbeSecretKey*> sks;
+      std::vector<const lsw::KpAbeCiphertext*> cts;
+      for (T* t : g) { sks.push_back((const lsw::KpAbeSecretKey*)t->a); cts.push_back((const lsw::KpAbeCiphertext*)t->ct); }
+      auto r = lsw::decrypt_batch(eng, sks, cts);
+      for (size_t i = 0; i < g.size(); i++) {
+        if (r[i].ok) { g[i]->out = r[i].plaintext; g[i]->rc = 0; }
+        else fail(g[i], r[i].error);
+      }
+      break;
+    }
+  }
+}
+// everything queued, in arrival order, grouped by what one packed call can take (operation, key object(s), language)
+void run_queue_batch(rabe_host* h, const std::vector<T*>& batch) {
+  std::vector<std::vector<T*>> groups;
+  for (T* t : batch) {
+    bool placed = false;
+    for (auto& g : groups) {
+      T* f = g[0];
+      if (f->op == t->op && (t->op == T::LSW_DEC || (f->a == t->a && f->b == t->b && f->pks == t->pks)) &&
+          ((t->op != T::AC17_ENC && t->op != T::BSW_ENC && t->op != T::AW11_ENC) || f->language == t->language)) {
+        g.push_back(t);
+        placed = true;
+        break;
+      }
+    }
+    if (!placed) groups.push_back({t});
+  }
+  size_t singles = 0;
+  for (auto& g : groups) if (g.size() == 1) singles++;
+  {
+    std::lock_guard<std::mutex> lk(h->q_mu);
+    h->q_stats[2] += groups.size();
+    h->q_stats[3] += singles;
+  }
+  for (auto& g : groups) {
+    if (g.size() == 1) { run_single(h, g[0]); continue; }
+    try {
+      run_group(h, g);
+    } catch (const std::exception&) {          // e.g. one request's policy does not parse: every request gets its own verdict
+      for (T* t : g) {
+        if (t->obj) { rabe_obj_free(t->op == T::AC17_ENC ? RABE_AC17_CP_CT : t->op == T::BSW_ENC ? RABE_BSW_CT : t->op == T::LSW_ENC ? RABE_LSW_CT : RABE_AW11_CT, t->obj); t->obj = nullptr; }
+        t->out.clear();
+        run_single(h, t);
+      }
+    }
+  }
+}
+void queue_submit(rabe_host* h, T* t) {
+  {
+    std::lock_guard<std::mutex> g(h->q_mu);
+    h->q.push_back(t);
+  }
+  h->q_arrival.notify_one();                   // only a leader inside its window listens; finished batches are announced on q_cv
+}
+// blocks until `t` is done; the first waiter that finds no leader becomes one and runs whatever is queued
+void queue_wait(rabe_host* h, T* t) {
+  std::unique_lock<std::mutex> lk(h->q_mu);
+  while (!t->done) {
+    int lane = -1;
+    const int max_lanes = h->tape ? 1 : (int)rabe_host::Q_LANES;          // a tape is drawn in arrival order: one batch at a time
+    if (!h->q.empty())
+      for (int k = 0; k < max_lanes && lane < 0; k++) if (!h->q_lane_busy[k]) lane = k;
+    if (lane < 0) { h->q_cv.wait(lk); continue; }
+    h->q_lane_busy[lane] = true;
+    if (h->window_us) {                        // hold the batch open: arrivals inside the window join it
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(h->window_us);
+      while (h->q_arrival.wait_until(lk, deadline) != std::cv_status::timeout) {}
+    }
+    std::vector<T*> batch(h->q.begin(), h->q.end());
+    h->q.clear();
+    lk.unlock();
+    const auto b0 = std::chrono::steady_clock::now();
+    {
+      Engine::LaneScope on_lane(lane);
+      tl_queue_rng = h->tape ? nullptr : (Rng*)&h->q_rng[lane];
+      run_queue_batch(h, batch);
+      tl_queue_rng = nullptr;
+    }
+    const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - b0).count();
+    lk.lock();
+    for (T* x : batch) x->done = true;
+    h->q_stats[0] += 1;
+    h->q_stats[1] += batch.size();
+    h->q_stats[4] += us;
+    if (batch.size() > h->q_stats[5]) h->q_stats[5] = batch.size();
+    h->q_lane_busy[lane] = false;
+    h->q_cv.notify_all();
+  }
+}
+// a blocking one-call entry point through the queue
+int32_t queue_call(rabe_host* h, T* t, void** obj, uint8_t** out, size_t* len) {
+  queue_submit(h, t);
+  queue_wait(h, t);
+  if (t->rc != 0) { set_err(h, t->err); return t->rc; }
+  if (obj) *obj = t->obj;
+  if (out) return give_bytes(t->out, out, len);
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int32_t rabe_host_create(int32_t device, rabe_host** out) {
@@ -325,6 +618,134 @@ int32_t rabe_host_set_tape(rabe_host* h, const uint8_t* fr_le32, size_t n) {
   return 0;
 }
 void rabe_bytes_free(void* p) { free(p); }
+
+// ---- submission queue (see above): switch, asynchronous submits, wait
+int32_t rabe_host_set_coalescing(rabe_host* h, int32_t on, uint32_t window_us) {
+  if (!h) return -1;
+  GUARD_BEGIN
+  if (on) h->eng.ensure_lanes(rabe_host::Q_LANES);          // before any thread is handed one
+  std::lock_guard<std::mutex> g(h->q_mu);
+  h->coalesce = on != 0;
+  h->window_us = window_us;
+  return 0;
+  GUARD_END(h)
+}
+int32_t rabe_host_queue_stats(rabe_host* h, uint64_t out[6]) {
+  if (!h || !out) return -1;
+  std::lock_guard<std::mutex> g(h->q_mu);
+  for (int i = 0; i < 6; i++) out[i] = h->q_stats[i];
+  return 0;
+}
+static int32_t submit_new(rabe_host* h, rabe_ticket* t, rabe_ticket** out) {
+  if (!h || !out) { delete t; return -1; }
+  *out = t;
+  queue_submit(h, t);
+  return 0;
+}
+int32_t rabe_ac17_cp_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AC17_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_ac17_cp_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AC17_DEC; t->a = sk; t->ct = ct;
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_bsw_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::BSW_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_bsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::BSW_DEC; t->a = sk; t->ct = ct;
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_lsw_encrypt_submit(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::LSW_ENC; t->a = pk; t->attrs = strs(attributes, n); t->pt.assign(pt, pt + len);
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_lsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::LSW_DEC; t->a = sk; t->ct = ct;
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_aw11_encrypt_submit(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
+                                 const uint8_t* data, size_t len, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AW11_ENC; t->a = gk; t->pks.assign(pks, pks + n_pks); t->policy = policy; t->language = language;
+  t->pt.assign(data, data + len);
+  return submit_new(h, t, ticket);
+}
+int32_t rabe_aw11_decrypt_submit(rabe_host* h, const void* gk, const void* sk, const void* ct, rabe_ticket** ticket) {
+  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AW11_DEC; t->a = gk; t->b = sk; t->ct = ct;
+  return submit_new(h, t, ticket);
+}
+// Measurement helper (bench.py: object_api.threads): `threads` native host threads call the PUBLIC one-call entry points on one host --
+// depth 1: rabe_ac17_cp_encrypt then rabe_ac17_cp_decrypt, blocking; depth > 1: that many rabe_*_submit calls in flight per thread -- for
+// `seconds`, checking every plaintext.  Native threads: an interpreter's global lock would be what is measured otherwise.
+int32_t rabe_bench_ac17_threads(rabe_host* h, const void* pk, const void* sk, const char* const* policies, size_t n_policies, int32_t language,
+                                uint32_t threads, uint32_t depth, double seconds, uint64_t* ops, uint64_t* bad) {
+  if (!h || !pk || !sk || !policies || !n_policies || !threads || !depth || !ops || !bad) return -1;
+  std::atomic<uint64_t> n_ok{0}, n_bad{0};
+  const auto stop = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
+  std::vector<std::thread> th;
+  for (uint32_t tid = 0; tid < threads; tid++) {
+    th.emplace_back([&, tid]() {
+      uint64_t k = 0;
+      while (std::chrono::steady_clock::now() < stop) {
+        std::vector<Bytes> pts(depth);
+        for (uint32_t j = 0; j < depth; j++) {
+          const char* msg = "dance like no one's watching, encrypt like everyone is!";
+          pts[j].assign(msg, msg + strlen(msg));
+          pts[j].push_back((uint8_t)tid); pts[j].push_back((uint8_t)(k + j)); pts[j].push_back((uint8_t)((k + j) >> 8));
+        }
+        if (depth == 1) {
+          void* ct = nullptr;
+          uint8_t* out = nullptr;
+          size_t len = 0;
+          bool ok = rabe_ac17_cp_encrypt(h, pk, policies[(tid + k) % n_policies], language, pts[0].data(), pts[0].size(), &ct) == 0 &&
+                    rabe_ac17_cp_decrypt(h, sk, ct, &out, &len) == 0 && len == pts[0].size() && memcmp(out, pts[0].data(), len) == 0;
+          if (out) free(out);
+          if (ct) rabe_obj_free(RABE_AC17_CP_CT, ct);
+          (ok ? n_ok : n_bad)++;
+        } else {
+          std::vector<rabe_ticket*> tk(depth, nullptr);
+          std::vector<void*> cts(depth, nullptr);
+          for (uint32_t j = 0; j < depth; j++)
+            rabe_ac17_cp_encrypt_submit(h, pk, policies[(tid + k + j) % n_policies], language, pts[j].data(), pts[j].size(), &tk[j]);
+          for (uint32_t j = 0; j < depth; j++) if (tk[j]) rabe_ticket_wait(h, tk[j], &cts[j], nullptr, nullptr);
+          for (uint32_t j = 0; j < depth; j++) { tk[j] = nullptr; if (cts[j]) rabe_ac17_cp_decrypt_submit(h, sk, cts[j], &tk[j]); }
+          for (uint32_t j = 0; j < depth; j++) {
+            uint8_t* out = nullptr;
+            size_t len = 0;
+            const bool ok = tk[j] && rabe_ticket_wait(h, tk[j], nullptr, &out, &len) == 0 && len == pts[j].size() && memcmp(out, pts[j].data(), len) == 0;
+            if (out) free(out);
+            if (cts[j]) rabe_obj_free(RABE_AC17_CP_CT, cts[j]);
+            (ok ? n_ok : n_bad)++;
+          }
+        }
+        k += depth;
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  *ops = n_ok.load();
+  *bad = n_bad.load();
+  return 0;
+}
+int32_t rabe_ticket_wait(rabe_host* h, rabe_ticket* t, void** obj, uint8_t** out, size_t* len) {
+  if (!h || !t) return -1;
+  queue_wait(h, t);
+  int32_t rc = t->rc;
+  if (rc != 0) set_err(h, t->err);
+  else {
+    const bool enc = t->op == rabe_ticket::AC17_ENC || t->op == rabe_ticket::BSW_ENC || t->op == rabe_ticket::LSW_ENC || t->op == rabe_ticket::AW11_ENC;
+    if (enc) {
+      if (obj) { *obj = t->obj; t->obj = nullptr; }
+    } else if (out && len) {
+      rc = give_bytes(t->out, out, len);
+    }
+  }
+  if (t->obj) rabe_obj_free(t->op == rabe_ticket::AC17_ENC ? RABE_AC17_CP_CT : t->op == rabe_ticket::BSW_ENC ? RABE_BSW_CT : t->op == rabe_ticket::LSW_ENC ? RABE_LSW_CT : RABE_AW11_CT, t->obj);
+  delete t;
+  return rc;
+}
 
 void rabe_obj_free(int32_t kind, void* o) {
   switch (kind) {
@@ -436,12 +857,20 @@ int32_t rabe_ac17_cp_keygen(rabe_host* h, const void* msk, const char* const* at
 }
 int32_t rabe_ac17_cp_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, void** ct) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::AC17_ENC; t.a = pk; t.policy = policy; t.language = language; t.pt.assign(pt, pt + len);
+    return queue_call(h, &t, ct, nullptr, nullptr);
+  }
   *ct = new ac17::Ac17CpCiphertext(ac17::cp_encrypt(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, policy, Bytes(pt, pt + len), lang_of(language)));
   return 0;
   GUARD_END(h)
 }
 int32_t rabe_ac17_cp_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::AC17_DEC; t.a = sk; t.ct = ct;
+    return queue_call(h, &t, nullptr, out, len);
+  }
   return give_bytes(ac17::cp_decrypt(h->eng, *(const ac17::Ac17CpSecretKey*)sk, *(const ac17::Ac17CpCiphertext*)ct), out, len);
   GUARD_END(h)
 }
@@ -531,6 +960,17 @@ int32_t rabe_bsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, co
     for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
   return bsw::keygen_packed(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, *(const bsw::CpAbeMasterKey*)msk, sets, n_items, item_set, sk_buf, sk_cap,
                             sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
+int32_t rabe_bsw_delegate_packed(rabe_host* h, const void* pk, const void* sk, const char* const* attributes, const size_t* counts, size_t n_subsets,
+                                 size_t n_items, const uint32_t* item_subset, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  std::vector<std::vector<std::string>> sets(n_subsets);
+  size_t at = 0;
+  for (size_t s = 0; s < n_subsets; s++)
+    for (size_t k = 0; k < counts[s]; k++) sets[s].push_back(attributes[at++]);
+  return bsw::delegate_packed(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, *(const bsw::CpAbeSecretKey*)sk, sets, n_items, item_subset, sk_buf, sk_cap,
+                              sk_off) ? 0 : 1;
   GUARD_END(h)
 }
 int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
@@ -664,6 +1104,13 @@ int32_t rabe_ac17_kp_keygen(rabe_host* h, const void* msk, const char* policy, i
   return 0;
   GUARD_END(h)
 }
+int32_t rabe_ac17_kp_keygen_packed(rabe_host* h, const void* msk, const char* const* policies, size_t n_policies, int32_t language, size_t n_items,
+                                   const uint32_t* item_policy, uint8_t* sk_buf, size_t sk_cap, uint64_t* sk_off) {
+  GUARD_BEGIN
+  return ac17::kp_keygen_packed(h->eng, h->rng(), *(const ac17::Ac17MasterKey*)msk, strs(policies, n_policies), lang_of(language), n_items, item_policy, sk_buf,
+                                sk_cap, sk_off) ? 0 : 1;
+  GUARD_END(h)
+}
 int32_t rabe_ac17_kp_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* data, size_t len, void** ct) {
   GUARD_BEGIN
   *ct = new ac17::Ac17KpCiphertext(ac17::kp_encrypt(h->eng, h->rng(), *(const ac17::Ac17PublicKey*)pk, strs(attributes, n), Bytes(data, data + len)));
@@ -732,12 +1179,20 @@ int32_t rabe_bsw_keygen(rabe_host* h, const void* pk, const void* msk, const cha
 }
 int32_t rabe_bsw_encrypt(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, void** ct) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::BSW_ENC; t.a = pk; t.policy = policy; t.language = language; t.pt.assign(pt, pt + len);
+    return queue_call(h, &t, ct, nullptr, nullptr);
+  }
   *ct = new bsw::CpAbeCiphertext(bsw::encrypt(h->eng, h->rng(), *(const bsw::CpAbePublicKey*)pk, policy, lang_of(language), Bytes(pt, pt + len)));
   return 0;
   GUARD_END(h)
 }
 int32_t rabe_bsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::BSW_DEC; t.a = sk; t.ct = ct;
+    return queue_call(h, &t, nullptr, out, len);
+  }
   return give_bytes(bsw::decrypt(h->eng, *(const bsw::CpAbeSecretKey*)sk, *(const bsw::CpAbeCiphertext*)ct), out, len);
   GUARD_END(h)
 }
@@ -785,12 +1240,20 @@ int32_t rabe_lsw_keygen(rabe_host* h, const void* pk, const void* msk, const cha
 }
 int32_t rabe_lsw_encrypt(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* pt, size_t len, void** ct) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::LSW_ENC; t.a = pk; t.attrs = strs(attributes, n); t.pt.assign(pt, pt + len);
+    return queue_call(h, &t, ct, nullptr, nullptr);
+  }
   *ct = new lsw::KpAbeCiphertext(lsw::encrypt(h->eng, h->rng(), *(const lsw::KpAbePublicKey*)pk, strs(attributes, n), Bytes(pt, pt + len)));
   return 0;
   GUARD_END(h)
 }
 int32_t rabe_lsw_decrypt(rabe_host* h, const void* sk, const void* ct, uint8_t** out, size_t* len) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::LSW_DEC; t.a = sk; t.ct = ct;
+    return queue_call(h, &t, nullptr, out, len);
+  }
   return give_bytes(lsw::decrypt(h->eng, *(const lsw::KpAbeSecretKey*)sk, *(const lsw::KpAbeCiphertext*)ct), out, len);
   GUARD_END(h)
 }
@@ -852,6 +1315,10 @@ int32_t rabe_aw11_add_to_attribute(rabe_host* h, const void* gk, const void* msk
 int32_t rabe_aw11_encrypt(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
                           const uint8_t* data, size_t len, void** ct) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::AW11_ENC; t.a = gk; t.pks.assign(pks, pks + n_pks); t.policy = policy; t.language = language; t.pt.assign(data, data + len);
+    return queue_call(h, &t, ct, nullptr, nullptr);
+  }
   std::vector<const aw11::Aw11PublicKey*> v;
   for (size_t i = 0; i < n_pks; i++) v.push_back((const aw11::Aw11PublicKey*)pks[i]);
   *ct = new aw11::Aw11Ciphertext(aw11::encrypt(h->eng, h->rng(), *(const aw11::Aw11GlobalKey*)gk, v, policy, lang_of(language), Bytes(data, data + len)));
@@ -860,6 +1327,10 @@ int32_t rabe_aw11_encrypt(rabe_host* h, const void* gk, const void* const* pks, 
 }
 int32_t rabe_aw11_decrypt(rabe_host* h, const void* gk, const void* sk, const void* ct, uint8_t** out, size_t* len) {
   GUARD_BEGIN
+  if (h && h->coalesce) {
+    rabe_ticket t; t.op = rabe_ticket::AW11_DEC; t.a = gk; t.b = sk; t.ct = ct;
+    return queue_call(h, &t, nullptr, out, len);
+  }
   return give_bytes(aw11::decrypt(h->eng, *(const aw11::Aw11GlobalKey*)gk, *(const aw11::Aw11SecretKey*)sk, *(const aw11::Aw11Ciphertext*)ct), out, len);
   GUARD_END(h)
 }

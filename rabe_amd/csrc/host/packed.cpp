@@ -12,6 +12,8 @@
 #include <chrono>
 #include <functional>
 #include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -170,6 +172,39 @@ struct Cursor {
   std::pair<const char*, uint32_t> str() { uint32_t l = u32(); return {(const char*)raw(l), l}; }
 };
 inline bool same(const std::pair<const char*, uint32_t>& a, const std::string& b) { return a.second == b.size() && memcmp(a.first, b.data(), b.size()) == 0; }
+
+// The plans of one call by (language, policy text), looked up WITHOUT copying the text and without serialising the readers: every item
+// of a batch asks for its policy's plan, the texts are kilobytes (a 200-leaf policy: ~10 KB), and a mutex around a std::map of strings
+// made the parse stage of a 4096-item call 8 ms long.  Misses go through the caller's (locking) maker and are remembered here.
+template <class Plan>
+class FastPlans {
+ public:
+  std::shared_ptr<Plan> find(const char* txt, size_t len, PolicyLanguage lang) {
+    const uint64_t h = hash(txt, len, lang);
+    std::shared_lock<std::shared_mutex> g(mu_);
+    auto it = tab_.find(h);
+    if (it != tab_.end())
+      for (const auto& e : it->second) if (e.lang == lang && e.text.size() == len && memcmp(e.text.data(), txt, len) == 0) return e.plan;
+    return nullptr;
+  }
+  void put(const char* txt, size_t len, PolicyLanguage lang, const std::shared_ptr<Plan>& plan) {
+    const uint64_t h = hash(txt, len, lang);
+    std::unique_lock<std::shared_mutex> g(mu_);
+    auto& bucket = tab_[h];
+    for (const auto& e : bucket) if (e.lang == lang && e.text.size() == len && memcmp(e.text.data(), txt, len) == 0) return;
+    bucket.push_back(Entry{std::string(txt, len), lang, plan});
+  }
+ private:
+  struct Entry { std::string text; PolicyLanguage lang; std::shared_ptr<Plan> plan; };
+  static uint64_t hash(const char* txt, size_t len, PolicyLanguage lang) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)lang;
+    for (size_t i = 0; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, txt + i, 8); h = (h ^ w) * 1099511628211ull; }
+    for (size_t i = len & ~(size_t)7; i < len; i++) h = (h ^ (uint8_t)txt[i]) * 1099511628211ull;
+    return h;
+  }
+  std::shared_mutex mu_;
+  std::unordered_map<uint64_t, std::vector<Entry>> tab_;
+};
 
 // where an item's sealed plaintext sits in the caller's blob (opened on the device: records.h, open_sealed_records)
 struct Sealed { const uint8_t* p = nullptr; uint32_t len = 0; };
@@ -452,6 +487,104 @@ bool keygen_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeM
   return true;
 }
 
+// n calls of bsw::delegate (bsw/mod.rs:162-206) on ONE key: item i delegates `sk` to subsets[item_subset[i]].  Draw order per item: r
+// (:178), then r_j per attribute of the subset in its order (:183).  d' = d + f * r; per attribute (D_j.g1 + g1 * r_j,
+// D_j.g2 + g2 * (h(j) r_j + r)): three window-table launches (f's table is built on first use and kept) and three batched additions;
+// records = CpAbeSecretKey, written on the device.  A subset that is empty or not contained in the key's attributes (is_subset,
+// tools/mod.rs:24-28 -- delegate returns None) fails the call.
+namespace {
+void* make_f_table(Engine& eng, const void* arg) {
+  rhip_g2_table* t = nullptr;
+  eng.check(rhip_g2_table_create(eng.ctx(), (const rhip_g2*)((const G2*)arg)->data(), &t), "rhip_g2_table_create");
+  int32_t rc = rhip_g2_table_add_w16(eng.ctx(), t);
+  if (rc) { rhip_g2_table_destroy(t); eng.check(rc, "rhip_g2_table_add_w16"); }
+  return t;
+}
+void destroy_f_table(void* h) { rhip_g2_table_destroy((rhip_g2_table*)h); }
+}  // namespace
+bool delegate_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeSecretKey& sk, const std::vector<std::vector<std::string>>& subsets, size_t n,
+                     const uint32_t* item_subset, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  Timer tm("bsw::delegate_packed");
+  Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // the key's elements pass through the staging buffers
+  if (n && (!item_subset || !out_off)) throw RabeError("bsw::delegate_packed: null input");
+  std::vector<std::vector<uint32_t>> row_of(subsets.size());          // subset attribute -> the key's row
+  std::vector<std::vector<Fr>> hashes(subsets.size());
+  std::vector<RecordLayout> layouts(subsets.size());
+  for (size_t s_ = 0; s_ < subsets.size(); s_++) {
+    if (subsets[s_].empty()) throw RabeError("bsw::delegate_packed: an empty subset (bsw::delegate returns None for it)");
+    RecordLayout& L = layouts[s_];
+    L.src(0, 0, 128);
+    L.u32((uint32_t)subsets[s_].size());
+    for (size_t y = 0; y < subsets[s_].size(); y++) {
+      const std::string& a = subsets[s_][y];
+      uint32_t r = 0;
+      while (r < sk.d_j.size() && sk.d_j[r].string != a) r++;
+      if (r == sk.d_j.size()) throw RabeError("bsw::delegate_packed: the subset is not contained in the key's attributes (bsw::delegate returns None)");
+      row_of[s_].push_back(r);
+      hashes[s_].push_back(sha3_hash_fr(a));
+      L.str(a);
+      L.src(1, (uint32_t)(64 * y), 64);
+      L.src(2, (uint32_t)(128 * y), 128);
+    }
+  }
+  for (size_t i = 0; i < n; i++) if (item_subset[i] >= subsets.size()) throw RabeError("bsw::delegate_packed: item_subset out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + layouts[item_subset[i]].bytes();
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  std::vector<size_t> row_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) row_off[i + 1] = row_off[i] + subsets[item_subset[i]].size();
+  const size_t total = row_off[n];
+  uint8_t* h_k = eng.pinned(0, (n + 2 * total) * 32 + 32);          // r per item | r_j per row | h(j) r_j + r per row
+  uint8_t* h_kr = h_k;
+  uint8_t* h_k1 = h_k + n * 32;
+  uint8_t* h_k2 = h_k1 + total * 32;
+  uint8_t* h_old = eng.pinned(1, n * 128 + total * 192 + 4);         // d per item | D_j.g1 per row | D_j.g2 per row
+  uint8_t* h_o1 = h_old + n * 128;
+  uint8_t* h_o2 = h_o1 + total * 64;
+  draw_items(rng, n, [&](Rng& r, size_t i) {
+    const Fr ri = r.next_fr();
+    memcpy(h_kr + 32 * i, ri.l, 32);
+    memcpy(h_old + 128 * i, sk.d.data(), 128);
+    const size_t s_ = item_subset[i];
+    for (size_t y = 0; y < hashes[s_].size(); y++) {
+      const Fr rj = r.next_fr();
+      const Fr k2 = fr_add(fr_mul(hashes[s_][y], rj), ri);
+      memcpy(h_k1 + 32 * (row_off[i] + y), rj.l, 32);
+      memcpy(h_k2 + 32 * (row_off[i] + y), k2.l, 32);
+      memcpy(h_o1 + 64 * (row_off[i] + y), sk.d_j[row_of[s_][y]].g1.data(), 64);
+      memcpy(h_o2 + 128 * (row_off[i] + y), sk.d_j[row_of[s_][y]].g2.data(), 128);
+    }
+  });
+  tm.lap("draws + scalars");
+  const GenTables* tb;
+  {
+    std::string key((const char*)pk.g1.data(), 64);
+    key.append((const char*)pk.g2.data(), 128);
+    tb = (const GenTables*)eng.aux("bsw_gen_tables", key, make_gen_tables, &pk, destroy_gen_tables, 4);
+  }
+  rhip_g2_table* ft = (rhip_g2_table*)eng.aux("bsw_f_table", std::string((const char*)pk.f.data(), 128), make_f_table, &pk.f, destroy_f_table, 4);
+  rhip_ctx* cx = eng.ctx();
+  DBuf d_k(&eng, (n + 2 * total) * 32 + 32), d_old(&eng, n * 128 + total * 192 + 4), d_fr(&eng, n * 128), d_m1(&eng, total * 64 + 4), d_m2(&eng, total * 128 + 4),
+      d_d(&eng, n * 128), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4);
+  eng.check(rhip_upload_async(cx, d_k.ptr(), h_k, (n + 2 * total) * 32), "upload");
+  eng.check(rhip_upload_async(cx, d_old.ptr(), h_old, n * 128 + total * 192), "upload");
+  const rhip_fr* kr = d_k.as<rhip_fr>();
+  const uint8_t* old = d_old.as<uint8_t>();
+  eng.check(rhip_g2_table_mul(cx, ft, n, kr, d_fr.as<rhip_g2>()), "rhip_g2_table_mul");
+  eng.check(rhip_g2_add(cx, n, (const rhip_g2*)old, d_fr.as<rhip_g2>(), d_d.as<rhip_g2>()), "rhip_g2_add");
+  eng.check(rhip_g1_table_mul(cx, tb->g1, total, kr + n, d_m1.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_add(cx, total, (const rhip_g1*)(old + n * 128), d_m1.as<rhip_g1>(), d_g1.as<rhip_g1>()), "rhip_g1_add");
+  eng.check(rhip_g2_table_mul(cx, tb->g2, total, kr + n + total, d_m2.as<rhip_g2>()), "rhip_g2_table_mul");
+  eng.check(rhip_g2_add(cx, total, (const rhip_g2*)(old + n * 128 + total * 64), d_m2.as<rhip_g2>(), d_g2.as<rhip_g2>()), "rhip_g2_add");
+  std::vector<uint64_t> src_off(3 * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 128ull * i; src_off[n + i] = 64ull * row_off[i]; src_off[2 * n + i] = 128ull * row_off[i]; }
+  emit_plain_records(eng, layouts, n, item_subset, {d_d.ptr(), d_g1.ptr(), d_g2.ptr()}, src_off, out_off, out_buf);
+  tm.lap("device: fixed-base multiplications, additions, records; one copy out");
+  return true;
+}
+
 // n calls of bsw::encrypt (bsw/mod.rs:217-251).  Draw order per item: secret (:228), msg (:229), the gate coefficients of
 // gen_shares_policy (secretsharing/mod.rs:128-134), the AES nonce (aes/mod.rs:17).  Record = CpAbeCiphertext:
 //   policy text, language, c, c_p, leaf count, per leaf (name_col, g1 * q_y, (g2 * h(name)) * q_y), sealed plaintext.
@@ -551,6 +684,7 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
   };
   std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
   std::mutex plans_mu;
+  FastPlans<Plan> fast_plans;
   auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
     std::lock_guard<std::mutex> g(plans_mu);
     auto key = std::make_pair((int)lang, text);
@@ -600,7 +734,8 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].g1[y] = r.raw(64); v[i].g2[y] = r.raw(128); }
       sealed[i].len = r.u32();
       sealed[i].p = r.raw(sealed[i].len);
-      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      auto pl = fast_plans.find(pol.first, pol.second, lang);
+      if (!pl) { pl = plan_of(std::string(pol.first, pol.second), lang); fast_plans.put(pol.first, pol.second, lang, pl); }
       if (!pl->err.empty()) throw RabeError(pl->err);
       v[i].plan = pl;
       const auto& std_names = pl->flat->leaf_name_col;
@@ -1001,6 +1136,7 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
   };
   std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
   std::mutex plans_mu;
+  FastPlans<Plan> fast_plans;
   auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
     std::lock_guard<std::mutex> g(plans_mu);
     auto key = std::make_pair((int)lang, text);
@@ -1043,7 +1179,8 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
       v[i].d2.resize(rows);
       std::vector<std::pair<const char*, uint32_t>> names(rows);
       for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].d1[y] = r.raw(64); v[i].d2[y] = r.raw(128); (void)r.raw(192); }
-      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      auto pl = fast_plans.find(pol.first, pol.second, lang);
+      if (!pl) { pl = plan_of(std::string(pol.first, pol.second), lang); fast_plans.put(pol.first, pol.second, lang, pl); }
       if (!pl->err.empty()) throw RabeError(pl->err);
       v[i].plan = pl;
       bool standard = rows == pl->std_names.size();
@@ -1375,6 +1512,7 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
   };
   std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
   std::mutex plans_mu;
+  FastPlans<Plan> fast_plans;
   auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
     std::lock_guard<std::mutex> g(plans_mu);
     auto key = std::make_pair((int)lang, text);
@@ -1420,7 +1558,8 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
       for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].c1[y] = r.raw(384); v[i].c2[y] = r.raw(128); v[i].c3[y] = r.raw(128); }
       sealed[i].len = r.u32();
       sealed[i].p = r.raw(sealed[i].len);
-      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      auto pl = fast_plans.find(pol.first, pol.second, lang);
+      if (!pl) { pl = plan_of(std::string(pol.first, pol.second), lang); fast_plans.put(pol.first, pol.second, lang, pl); }
       if (!pl->err.empty()) throw RabeError(pl->err);
       v[i].plan = pl;
       bool standard = rows == pl->std_names.size();
@@ -1564,6 +1703,7 @@ bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const 
   };
   std::map<std::pair<int, std::string>, std::shared_ptr<Plan>> plans;
   std::mutex plans_mu;
+  FastPlans<Plan> fast_plans;
   auto plan_of = [&](const std::string& text, PolicyLanguage lang) -> std::shared_ptr<Plan> {
     std::lock_guard<std::mutex> g(plans_mu);
     auto key = std::make_pair((int)lang, text);
@@ -1610,7 +1750,8 @@ bool transform_packed(Engine& eng, const Ghw11TransformKey& tk, size_t n, const 
       for (uint32_t y = 0; y < rows; y++) { names[y] = r.str(); v[i].ci[y] = r.raw(64); v[i].di[y] = r.raw(64); }
       const uint32_t dl = r.u32();
       (void)r.raw(dl);                                   // the sealed data stays with the client (decrypt_out)
-      auto pl = plan_of(std::string(pol.first, pol.second), lang);
+      auto pl = fast_plans.find(pol.first, pol.second, lang);
+      if (!pl) { pl = plan_of(std::string(pol.first, pol.second), lang); fast_plans.put(pol.first, pol.second, lang, pl); }
       if (!pl->err.empty()) throw RabeError(pl->err);
       v[i].plan = pl;
       const auto& std_names = pl->flat->leaf_name_col;

@@ -114,6 +114,30 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
   tm.lap("copy out");
 }
 
+void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
+                        const std::vector<const void*>& dev_src, const std::vector<uint64_t>& src_item_off, const uint64_t* out_off, uint8_t* out_buf) {
+  if (!n) return;
+  const size_t n_src = dev_src.size();
+  if (src_item_off.size() != n_src * n) throw RabeError("emit_plain_records: src_item_off has the wrong size");
+  std::vector<uint32_t> layout_off{0}, map;
+  for (const auto& l : layouts) {
+    map.insert(map.end(), l.map.begin(), l.map.end());
+    layout_off.push_back((uint32_t)map.size());
+  }
+  for (size_t i = 0; i < n; i++)
+    if (out_off[i] + layouts[item_layout[i]].bytes() != out_off[i + 1]) throw RabeError("emit_plain_records: record sizes do not add up");
+  rhip_ctx* cx = eng.ctx();
+  ParamPack pp(eng);
+  const size_t h_out_off = pp.add(out_off, n * 8), h_layout = pp.add(item_layout, n * 4), h_loff = pp.add(layout_off), h_map = pp.add(map),
+               h_src = pp.add(dev_src), h_sio = pp.add(src_item_off);
+  pp.upload();
+  DBuf d_out(&eng, (size_t)out_off[n]);
+  eng.check(rhip_assemble_records(cx, n, d_out.as<uint8_t>(), pp.dev<uint64_t>(h_out_off), pp.dev<uint32_t>(h_layout), pp.dev<uint32_t>(h_loff),
+                                  pp.dev<uint32_t>(h_map), (uint32_t)n_src, pp.dev<const uint8_t*>(h_src), pp.dev<uint64_t>(h_sio)),
+            "rhip_assemble_records");
+  eng.check(rhip_download(cx, out_buf + out_off[0], d_out.as<uint8_t>() + out_off[0], (size_t)(out_off[n] - out_off[0])), "download (records)");
+}
+
 struct BlobGather::Up { std::future<int32_t> f; };
 BlobGather::BlobGather(Engine& eng, const uint8_t* blob, size_t len) : eng_(eng), d_blob_(&eng, len ? len : 4), up_(new Up) {
   rhip_ctx* const cx = eng.ctx();

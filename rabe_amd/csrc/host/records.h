@@ -56,6 +56,11 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
                          const uint8_t* nonces /*[n][12]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n+1]*/,
                          const uint64_t* out_off /*[n+1]*/, uint8_t* out_buf);
 
+// The same without a sealed part (bulk key issuing): a record is exactly its layout's bytes.
+void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
+                        const std::vector<const void*>& dev_src, const std::vector<uint64_t>& src_item_off, const uint64_t* out_off /*[n+1]*/,
+                        uint8_t* out_buf);
+
 // Head of a packed decrypt: the caller's blob goes to the device as it is -- the copy starts at construction, on a helper thread, so it
 // runs beside the host's parsing of the records -- and the elements are gathered out of it there (rhip_gather_parts).  A SHAPE is the part
 // list of one record skeleton; items whose records share policy text and row names share a shape (same skeleton, same relative offsets).

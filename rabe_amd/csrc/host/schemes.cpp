@@ -1313,17 +1313,27 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   });
   tm.lap("parse + plan");
   std::vector<size_t> live;
-  std::vector<uint32_t> ct_row_off{0}, ct_sel, sk_sel, ct_sel_off{0}, sk_sel_off{0};
-  for (size_t i = 0; i < n; i++) {
-    if (!(*errors)[i].empty()) continue;
-    live.push_back(i);
-    ct_row_off.push_back(ct_row_off.back() + v[i].rows);
-    ct_sel.insert(ct_sel.end(), v[i].ct_sel->begin(), v[i].ct_sel->end());
-    sk_sel.insert(sk_sel.end(), v[i].sk_sel->begin(), v[i].sk_sel->end());
-    ct_sel_off.push_back((uint32_t)ct_sel.size());
-    sk_sel_off.push_back((uint32_t)sk_sel.size());
-  }
+  for (size_t i = 0; i < n; i++) if ((*errors)[i].empty()) live.push_back(i);
   const size_t m = live.size();
+  // offsets first (a scan), then the selection lists copied into place on all cores (65 536 items x ~30 entries x 2: 6 ms when serial)
+  std::vector<uint32_t> ct_row_off(m + 1, 0), ct_sel_off(m + 1, 0), sk_sel_off(m + 1, 0);
+  for (size_t j = 0; j < m; j++) {
+    const View& w = v[live[j]];
+    ct_row_off[j + 1] = ct_row_off[j] + w.rows;
+    ct_sel_off[j + 1] = ct_sel_off[j] + (uint32_t)w.ct_sel->size();
+    sk_sel_off[j + 1] = sk_sel_off[j] + (uint32_t)w.sk_sel->size();
+  }
+  std::vector<uint32_t> ct_sel(ct_sel_off[m]), sk_sel(sk_sel_off[m]);
+  {
+    const size_t per = 1024, blocks = (m + per - 1) / per;
+    parallel_for(blocks, [&](size_t b) {
+      for (size_t j = b * per; j < m && j < (b + 1) * per; j++) {
+        const View& w = v[live[j]];
+        if (!w.ct_sel->empty()) memcpy(ct_sel.data() + ct_sel_off[j], w.ct_sel->data(), w.ct_sel->size() * 4);
+        if (!w.sk_sel->empty()) memcpy(sk_sel.data() + sk_sel_off[j], w.sk_sel->data(), w.sk_sel->size() * 4);
+      }
+    });
+  }
   if (!m) {
     pt_off[0] = 0;
     for (size_t i = 0; i < n; i++) { pt_off[i + 1] = 0; status[i] = -1; }
@@ -1412,19 +1422,29 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
 }
 
 // ---------------------------------------------------------------------------------------------- KP-ABE
-Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang) {   // :439-547
-  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
-  PolicyNode tree = parse_or_error(policy, lang);
-  AbePolicy msp = calculate_msp(tree);
+// The Fr half of kp_keygen (:455-538) for one key: 3 scalars per MSP row (multiples of g), in row order, and br = (b0 r0, b1 r1, r0 + r1)
+// (multiples of h).  `hashes`: the label hashes of a policy -- rows h(pi_i || l || t) then columns h("0" || j || l || t), l major -- which do
+// not depend on the key.
+struct KpPolicy { AbePolicy msp; std::vector<Fr> row_h /*[rows][t][l]*/, col_h /*[cols][t][l], j = 0 unused*/; };
+static KpPolicy kp_policy(const std::string& policy, PolicyLanguage lang) {
+  KpPolicy kp;
+  kp.msp = calculate_msp(parse_or_error(policy, lang));
+  const size_t cols = kp.msp.m[0].size(), rows = kp.msp.m.size();
+  kp.col_h.assign(cols * 6, fr_zero());
+  for (size_t j = 1; j < cols; j++)
+    for (int t = 0; t < 2; t++)
+      for (int l = 0; l < 3; l++) kp.col_h[(j * 2 + t) * 3 + l] = sha3_hash_fr(std::string("0") + std::to_string(j) + std::to_string(l) + std::to_string(t));
+  kp.row_h.resize(rows * 6);
+  for (size_t i = 0; i < rows; i++)
+    for (int t = 0; t < 2; t++)
+      for (int l = 0; l < 3; l++) kp.row_h[(i * 2 + t) * 3 + l] = sha3_hash_fr(kp.msp.pi[i] + std::to_string(l) + std::to_string(t));
+  return kp;
+}
+static void kp_keygen_scalars(const Ac17MasterKey& msk, const KpPolicy& kp, const Fr a_inv[2], const Fr& r0, const Fr& r1, const Fr* sigma_prime,
+                              const Fr* sigma, Fr* scal /*[3 rows]*/, Fr br[3]) {
+  const AbePolicy& msp = kp.msp;
   const size_t cols = msp.m[0].size(), rows = msp.m.size();
-  // draw order: r0, r1 (:455-459); sigma'_1..sigma'_{c-1} (:471-474); sigma_i per row (:481)
-  Fr r0 = rng.next_fr(), r1 = rng.next_fr();
-  Fr br[3] = {fr_mul(msk.b[0], r0), fr_mul(msk.b[1], r1), fr_add(r0, r1)};
-  std::vector<Fr> sigma_prime;
-  for (size_t j = 0; j + 1 < cols; j++) sigma_prime.push_back(rng.next_fr());
-  std::vector<Fr> sigma;
-  for (size_t i = 0; i < rows; i++) sigma.push_back(rng.next_fr());
-  Fr a_inv[2] = {must_inv(msk.a[0]), must_inv(msk.a[1])};
+  br[0] = fr_mul(msk.b[0], r0); br[1] = fr_mul(msk.b[1], r1); br[2] = fr_add(r0, r1);
   // T[j][t] = sum_{j' <= j} ( sum_l h("0"||j'||l||t) br_l / a_t - sigma'_{j'-1} ): the reference's `_temp` is declared
   // outside the column loop and never reset (:496), so it accumulates over the columns -- restated verbatim.
   std::vector<Fr> T(cols * 2, fr_zero());
@@ -1432,31 +1452,46 @@ Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
     Fr acc = fr_zero();
     for (size_t j = 1; j < cols; j++) {
       Fr hsum = fr_zero();
-      for (int l = 0; l < 3; l++)
-        hsum = fr_add(hsum, fr_mul(sha3_hash_fr(std::string("0") + std::to_string(j) + std::to_string(l) + std::to_string(t)), br[l]));
+      for (int l = 0; l < 3; l++) hsum = fr_add(hsum, fr_mul(kp.col_h[(j * 2 + t) * 3 + l], br[l]));
       acc = fr_add(acc, fr_sub(fr_mul(hsum, a_inv[t]), sigma_prime[j - 1]));
       T[j * 2 + t] = acc;
     }
   }
-  std::vector<Fr> scal;
   for (size_t i = 0; i < rows; i++) {
     for (int t = 0; t < 2; t++) {
       Fr hsum = sigma[i];
-      for (int l = 0; l < 3; l++) hsum = fr_add(hsum, fr_mul(sha3_hash_fr(msp.pi[i] + std::to_string(l) + std::to_string(t)), br[l]));
+      for (int l = 0; l < 3; l++) hsum = fr_add(hsum, fr_mul(kp.row_h[(i * 2 + t) * 3 + l], br[l]));
       Fr k = fr_mul(hsum, a_inv[t]);
       for (size_t j = 1; j < cols; j++) {
         if (msp.m[i][j] == 1) k = fr_add(k, T[j * 2 + t]);
         else if (msp.m[i][j] == -1) k = fr_sub(k, T[j * 2 + t]);
       }
-      scal.push_back(k);
+      scal[3 * i + t] = k;
     }
     Fr k3 = fr_neg(sigma[i]);
     for (size_t j = 1; j < cols; j++) {
       if (msp.m[i][j] == 1) k3 = fr_sub(k3, sigma_prime[j - 1]);
       else if (msp.m[i][j] == -1) k3 = fr_add(k3, sigma_prime[j - 1]);
     }
-    scal.push_back(k3);
+    scal[3 * i + 2] = k3;
   }
+}
+Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang) {   // :439-547
+  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
+  const KpPolicy kp = kp_policy(policy, lang);
+  const AbePolicy& msp = kp.msp;
+  const size_t cols = msp.m[0].size(), rows = msp.m.size();
+  // draw order: r0, r1 (:455-459); sigma'_1..sigma'_{c-1} (:471-474); sigma_i per row (:481)
+  Fr r0 = rng.next_fr(), r1 = rng.next_fr();
+  std::vector<Fr> sigma_prime;
+  for (size_t j = 0; j + 1 < cols; j++) sigma_prime.push_back(rng.next_fr());
+  std::vector<Fr> sigma;
+  for (size_t i = 0; i < rows; i++) sigma.push_back(rng.next_fr());
+  Fr a_inv[2] = {must_inv(msk.a[0]), must_inv(msk.a[1])};
+  std::vector<Fr> scal(3 * rows);
+  Fr br[3];
+  sigma_prime.push_back(fr_zero());              // never read (cols - 1 entries are), keeps .data() valid for a one-column policy
+  kp_keygen_scalars(msk, kp, a_inv, r0, r1, sigma_prime.data(), sigma.data(), scal.data(), br);
   std::vector<G1> pts = eng.g1_mul(std::vector<G1>(scal.size(), msk.g), scal);
   // +/- g_k[t] where the first MSP column is +/-1
   std::vector<G1> add_a, add_b;
@@ -1474,6 +1509,101 @@ Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const
   out.sk.k_0 = eng.g2_mul({msk.h, msk.h, msk.h}, {br[0], br[1], br[2]});
   for (size_t i = 0; i < rows; i++) out.sk.k.push_back({msp.pi[i], {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}});
   return out;
+}
+// n calls of ac17::kp_keygen (:439-547) under one master key: item i's policy = policies[item_policy[i]].  Draw order per item as above.
+// The Fr half runs on all host cores; the group half is ONE fixed-base launch per group (window tables of msk.g / msk.h, kept across
+// calls), one batched addition for the rows whose first MSP column is +/-1 (+/- g_k), and the records are written on the device.
+// Record = Ac17KpSecretKey: policy text, language, k_0 (3 G2), rows (name, 3 G1), an empty k_p.  Buffers as cp_keygen_packed.
+bool kp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& policies, PolicyLanguage lang, size_t n,
+                      const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  StageTimer tm("ac17::kp_keygen_packed");
+  Engine::ArenaScope arena(eng);
+  eng.scrub_when_done();          // master-key-derived scalars pass through the staging buffers
+  if (msk.a.size() != 2 || msk.b.size() != 2 || msk.g_k.size() != 3) throw RabeError("malformed Ac17MasterKey: a, b must have 2 and g_k 3 elements");
+  if (n && (!item_policy || !out_off)) throw RabeError("kp_keygen_packed: null input");
+  std::vector<KpPolicy> kps;
+  std::vector<RecordLayout> layouts(policies.size());
+  for (size_t p_ = 0; p_ < policies.size(); p_++) {
+    kps.push_back(kp_policy(policies[p_], lang));
+    RecordLayout& L = layouts[p_];
+    const AbePolicy& msp = kps.back().msp;
+    L.str(policies[p_]);
+    L.u8(lang == PolicyLanguage::HumanPolicy ? 1 : 0);
+    L.u32(3);
+    L.src(0, 0, 384);
+    L.u32((uint32_t)msp.m.size());
+    for (size_t r = 0; r < msp.m.size(); r++) { L.str(msp.pi[r]); L.u32(3); L.src(1, (uint32_t)(192 * r), 192); }
+    L.u32(0);                                   // k_p: empty for a KP key
+  }
+  for (size_t i = 0; i < n; i++) if (item_policy[i] >= policies.size()) throw RabeError("kp_keygen_packed: item_policy out of range");
+  out_off[0] = 0;
+  for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + layouts[item_policy[i]].bytes();
+  if (!out_buf || out_cap < out_off[n]) return false;
+  if (!n) return true;
+  std::vector<uint32_t> row_off(n + 1, 0), draw_off(n + 1, 0);
+  for (size_t i = 0; i < n; i++) {
+    const AbePolicy& msp = kps[item_policy[i]].msp;
+    row_off[i + 1] = row_off[i] + (uint32_t)msp.m.size();
+    draw_off[i + 1] = draw_off[i] + 2 + (uint32_t)(msp.m[0].size() - 1) + (uint32_t)msp.m.size();
+  }
+  const size_t total_rows = row_off[n];
+  std::vector<Fr> draws(draw_off[n] + 1);
+  {
+    struct Turn { Rng& r; explicit Turn(Rng& x) : r(x) { r.begin_draws(); } ~Turn() { r.end_draws(); } } turn(rng);
+    if (rng.unordered() && n >= 1024) {
+      const size_t blocks = (n + 255) / 256;
+      parallel_for(blocks, [&](size_t b) {
+        OsRng local;
+        for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) for (uint32_t d = draw_off[i]; d < draw_off[i + 1]; d++) draws[d] = local.next_fr();
+      });
+    } else {
+      for (size_t d = 0; d < draw_off[n]; d++) draws[d] = rng.next_fr();
+    }
+  }
+  tm.lap("policies + draws");
+  Fr a_inv[2] = {must_inv(msk.a[0]), must_inv(msk.a[1])};
+  uint8_t* h_scal = eng.pinned(0, total_rows * 96 + n * 96 + 32);          // row scalars | br
+  uint8_t* h_br = h_scal + total_rows * 96;
+  uint8_t* h_add = eng.pinned(1, total_rows * 192 + 4);                     // +/- g_k[t] per row element, the point at infinity where nothing is added
+  G1 neg_gk[3];
+  {
+    std::vector<G1> ng = eng.g1_mul(msk.g_k, std::vector<Fr>(3, fr_neg(fr_one())));
+    for (int t = 0; t < 3; t++) neg_gk[t] = ng[t];
+  }
+  parallel_for(n, [&](size_t i) {
+    const KpPolicy& kp = kps[item_policy[i]];
+    const size_t cols = kp.msp.m[0].size(), rows = kp.msp.m.size();
+    const Fr* d = draws.data() + draw_off[i];
+    std::vector<Fr> scal(3 * rows);
+    Fr br[3];
+    kp_keygen_scalars(msk, kp, a_inv, d[0], d[1], d + 2, d + 2 + (cols - 1), scal.data(), br);
+    memcpy(h_scal + 96 * (size_t)row_off[i], scal.data(), 96 * rows);
+    memcpy(h_br + 96 * i, br, 96);
+    uint8_t* ad = h_add + 192 * (size_t)row_off[i];
+    for (size_t r = 0; r < rows; r++)
+      for (int t = 0; t < 3; t++) {
+        const int8_t c = kp.msp.m[r][0];
+        if (c == 0) memset(ad + 192 * r + 64 * t, 0, 64);
+        else memcpy(ad + 192 * r + 64 * t, (c == 1 ? msk.g_k[t] : neg_gk[t]).data(), 64);
+      }
+  });
+  tm.lap("scalars");
+  rhip_g1_table* gt = nullptr;
+  rhip_g2_table* ht = nullptr;
+  msk_tables(eng, msk, &gt, &ht);
+  rhip_ctx* cx = eng.ctx();
+  DBuf d_scal(&eng, total_rows * 96 + n * 96), d_add(&eng, total_rows * 192 + 4), d_pts(&eng, total_rows * 192 + 4), d_k(&eng, total_rows * 192 + 4),
+      d_k0(&eng, n * 384);
+  eng.check(rhip_upload_async(cx, d_scal.ptr(), h_scal, total_rows * 96 + n * 96), "upload");
+  eng.check(rhip_upload_async(cx, d_add.ptr(), h_add, total_rows * 192), "upload");
+  eng.check(rhip_g1_table_mul(cx, gt, 3 * total_rows, d_scal.as<rhip_fr>(), d_pts.as<rhip_g1>()), "rhip_g1_table_mul");
+  eng.check(rhip_g1_add(cx, 3 * total_rows, d_pts.as<rhip_g1>(), d_add.as<rhip_g1>(), d_k.as<rhip_g1>()), "rhip_g1_add");
+  eng.check(rhip_g2_table_mul(cx, ht, 3 * n, (const rhip_fr*)(d_scal.as<uint8_t>() + total_rows * 96), d_k0.as<rhip_g2>()), "rhip_g2_table_mul");
+  std::vector<uint64_t> src_off(2 * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 384ull * i; src_off[n + i] = 192ull * row_off[i]; }
+  emit_plain_records(eng, layouts, n, item_policy, {d_k0.ptr(), d_k.ptr()}, src_off, out_off, out_buf);
+  tm.lap("device: fixed-base multiplications, records; one copy out");
+  return true;
 }
 
 std::vector<Ac17KpCiphertext> kp_encrypt_batch(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::vector<std::string>>& attribute_sets,

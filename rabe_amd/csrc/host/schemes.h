@@ -52,6 +52,10 @@ std::vector<DecryptResult> cp_decrypt_batch(Engine& eng, const std::vector<const
 Gt cp_decrypt_gt(Engine& eng, const Ac17CpSecretKey& sk, const Ac17CpCiphertext& ct);
 // KP-ABE variant (:439-675), same kernels
 Ac17KpSecretKey kp_keygen(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::string& policy, PolicyLanguage lang);
+// n calls of kp_keygen under one master key in one launch set (the triple loop of ac17/mod.rs:479-538 as Fr work on all host cores + one
+// fixed-base launch); records = Ac17KpSecretKey, written on the device.  Buffers / return value as cp_keygen_packed.
+bool kp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std::vector<std::string>& policies, PolicyLanguage lang, size_t n,
+                      const uint32_t* item_policy, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 Ac17KpCiphertext kp_encrypt(Engine& eng, Rng& rng, const Ac17PublicKey& pk, const std::vector<std::string>& attributes, const Bytes& data);
 Bytes kp_decrypt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
 Gt kp_decrypt_gt(Engine& eng, const Ac17KpSecretKey& sk, const Ac17KpCiphertext& ct);
@@ -90,6 +94,9 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const Cp
 // the same two batches with packed input and output (packed.cpp): one blob of canonical records + offsets per side, caller-allocated
 // buffers, the device-resident Level B path (rhip_bsw_{encrypt,decrypt}_batch).  Conventions as ac17::cp_{encrypt,decrypt}_packed.
 // n keys under one master key in one call (packed.cpp): item i gets the attribute list sets[item_set[i]]; records = CpAbeSecretKey
+// n calls of bsw::delegate on one key (packed.cpp): item i delegates `sk` to subsets[item_subset[i]]; records = CpAbeSecretKey
+bool delegate_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeSecretKey& sk, const std::vector<std::vector<std::string>>& subsets, size_t n,
+                     const uint32_t* item_subset, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool keygen_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const CpAbeMasterKey& msk, const std::vector<std::vector<std::string>>& sets, size_t n,
                    const uint32_t* item_set, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
 bool encrypt_packed(Engine& eng, Rng& rng, const CpAbePublicKey& pk, const std::vector<std::string>& policies, PolicyLanguage language, size_t n,

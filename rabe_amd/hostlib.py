@@ -32,7 +32,7 @@ def _lib():
 def _check(rc, host=None):
     if rc == 0:
         return
-    msg = _lib().rabe_host_last_error(host)
+    msg = _lib().rabe_host_last_error(None)          # the calling thread's last error (a host may be shared by threads: submission queue)
     msg = msg.decode() if msg else ""
     if rc == -2:
         raise RabePanic(msg)
@@ -110,6 +110,22 @@ class Host:
     def set_fixed_base_min(self, n):
         """elements sharing one base before G*Fr / Gt^Fr calls switch to a cached fixed-base table (results are the same)"""
         _check(self.lib.rabe_host_set_fixed_base_min(self.h, ctypes.c_size_t(int(n))), self.h)
+
+    # ---- submission queue (include/rabe_host.h): one-call encrypt / decrypt from many threads, collected into packed batches
+    def set_coalescing(self, on=True, window_us=0):
+        _check(self.lib.rabe_host_set_coalescing(self.h, ctypes.c_int32(1 if on else 0), ctypes.c_uint32(window_us)), self.h)
+
+    def submit(self, fn, *args):
+        """queue one call (fn = a rabe_*_submit entry point) -> ticket for `wait`"""
+        t = ctypes.c_void_p()
+        _check(getattr(self.lib, fn)(self.h, *args, ctypes.byref(t)), self.h)
+        return t
+
+    def wait(self, ticket, kind=None):
+        """result of a queued call: an Obj of `kind` (encrypt) or the plaintext bytes (decrypt, kind None)"""
+        obj, p, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        _check(self.lib.rabe_ticket_wait(self.h, ticket, ctypes.byref(obj), ctypes.byref(p), ctypes.byref(n)), self.h)
+        return Obj(kind, obj) if kind else _take_bytes(p, n)
 
     def clear_tape(self):
         _check(self.lib.rabe_host_set_tape(self.h, None, ctypes.c_size_t(0)), self.h)

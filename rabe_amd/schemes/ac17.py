@@ -155,6 +155,13 @@ def cp_keygen_packed(host, msk, attr_sets, item_set, out=None):
     return buf[:int(so[n])], so
 
 
+def kp_keygen_packed(host, msk, policies, item_policy, language=JSON_POLICY, out=None):
+    """n KP-ABE keys under one master key (rabe_ac17_kp_keygen_packed): item i's policy = policies[item_policy[i]].
+    Returns (sk_blob view of the Ac17KpSecretKey records, sk_off uint64 [n+1])."""
+    from ..hostlib import packed_produce
+    return packed_produce(host, "rabe_ac17_kp_keygen_packed", (msk.ptr,), policies, item_policy, language, (), out)
+
+
 def kp_encrypt_packed(host, pk, attr_sets, item_set, pt_blob, pt_off, out=None):
     """n KP-ABE encrypts (rabe_ac17_kp_encrypt_packed): item i under the attribute list attr_sets[item_set[i]]; records = Ac17KpCiphertext.
     Returns (ct_blob view, ct_off uint64 [n+1])."""

@@ -89,3 +89,24 @@ def keygen_packed(host, pk, msk, attr_sets, item_set, out=None):
         buf = np.empty(int(so[n]), dtype=np.uint8)
     _check(rc, host.h)
     return buf[:int(so[n])], so
+
+
+def delegate_packed(host, pk, sk, subsets, item_subset, out=None):
+    """n delegations of ONE key (rabe_bsw_delegate_packed): item i gets the attribute list subsets[item_subset[i]].
+    Returns (sk_blob view of the CpAbeSecretKey records, sk_off uint64 [n+1])."""
+    import numpy as np
+    from ..hostlib import _check, _np_ptr
+    n = len(item_subset)
+    arr, _ = _strs([a for s_ in subsets for a in s_])
+    counts = (ctypes.c_size_t * max(len(subsets), 1))(*[len(s_) for s_ in subsets])
+    it = np.ascontiguousarray(item_subset, dtype=np.uint32)
+    so = np.zeros(n + 1, dtype=np.uint64)
+    buf = out if out is not None else np.empty(0, dtype=np.uint8)
+    for _ in range(2):
+        rc = host.lib.rabe_bsw_delegate_packed(host.h, pk.ptr, sk.ptr, arr, counts, ctypes.c_size_t(len(subsets)), ctypes.c_size_t(n), _np_ptr(it),
+                                               _np_ptr(buf), ctypes.c_size_t(buf.size), _np_ptr(so))
+        if rc != 1:
+            break
+        buf = np.empty(int(so[n]), dtype=np.uint8)
+    _check(rc, host.h)
+    return buf[:int(so[n])], so

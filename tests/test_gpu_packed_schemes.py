@@ -266,3 +266,69 @@ def test_lsw_packed_encrypt_equals_object_encrypt_on_the_same_tape(host):
     sk = lsw.keygen(host, pk, msk, '{"name": "and", "children": [{"name": "a3"}, {"name": "or", "children": [{"name": "a29"}, {"name": "zz"}]}]}', hl.JSON_POLICY)
     for i in (0, 1, m - 2, m - 1):
         assert lsw.decrypt(host, sk, hl.Obj.deserialize("lsw_ct", blob[int(off[i]):int(off[i + 1])].tobytes())) == big[i]
+
+
+def test_ac17_kp_packed_keygen_equals_object_keygen_on_the_same_tape(host):
+    """rabe_ac17_kp_keygen_packed: n calls of ac17::kp_keygen (ac17/mod.rs:439-547; the `_temp` accumulation over the columns :496 included)
+    as Fr work on the host cores + one fixed-base launch set, records written on the device = the objects' bytes on the same tape; the keys
+    decrypt KP ciphertexts; policies with and without a +/-1 in the first MSP column (the +/- g_k additions), one-column policies."""
+    from rabe_amd.schemes import ac17
+    pk, msk = ac17.setup(host)
+    pols = ['"A" and ("B" or "C")', '"A" or "B"', '"A"', '("A" and "B") and ("C" and ("D" or "E"))']
+    item_pol = [0, 1, 2, 3, 3, 0, 2, 1, 0]
+    n = len(item_pol)
+    tape = [1000003 * (i + 5) + 11 for i in range(16 * n)]
+    host.set_tape(tape)
+    objs = [ac17.kp_keygen(host, msk, pols[p], hl.HUMAN_POLICY) for p in item_pol]
+    host.set_tape(tape)
+    blob, off = ac17.kp_keygen_packed(host, msk, pols, item_pol, hl.HUMAN_POLICY)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    ct = ac17.kp_encrypt(host, pk, ["A", "B", "C", "D"], b"bulk kp keys")
+    for i in range(n):
+        sk = hl.Obj.deserialize("ac17_kp_sk", blob[int(off[i]):int(off[i + 1])].tobytes())
+        assert ac17.kp_decrypt(host, sk, ct) == b"bulk kp keys", i
+    # a larger batch on OS randomness: every key decrypts
+    attrs = ["a%d" % i for i in range(40)]
+    big = [" and ".join('"%s"' % a for a in attrs[:k]) if k < 3 else '("%s" and "%s") and ("%s" or "%s")' % tuple(attrs[k:k + 4]) for k in (1, 2, 5, 9)]
+    blob, off = ac17.kp_keygen_packed(host, msk, big, np.arange(1200, dtype=np.uint32) % 4, hl.HUMAN_POLICY)
+    ct = ac17.kp_encrypt(host, pk, attrs, b"y" * 33)
+    for i in (0, 1, 2, 3, 1198, 1199):
+        assert ac17.kp_decrypt(host, hl.Obj.deserialize("ac17_kp_sk", blob[int(off[i]):int(off[i + 1])].tobytes()), ct) == b"y" * 33
+    with pytest.raises((hl.RabeError, hl.RabePanic)):
+        ac17.kp_keygen_packed(host, msk, ['"A" and'], [0], hl.HUMAN_POLICY)
+
+
+def test_bsw_packed_delegate_equals_object_delegate_on_the_same_tape(host):
+    """rabe_bsw_delegate_packed: n calls of bsw::delegate (bsw/mod.rs:162-206) on one key = the objects' bytes on the same tape; the delegated
+    keys decrypt what their subset satisfies and nothing else; a subset outside the key fails the call (delegate returns None)."""
+    from rabe_amd.schemes import bsw
+    pk, msk = bsw.setup(host)
+    sk = bsw.keygen(host, pk, msk, ["A", "B", "C", "D", "E"])
+    subsets = [["A", "B"], ["C"], ["E", "A", "D"], ["A", "B", "C", "D", "E"]]
+    item = [0, 1, 2, 3, 2, 0, 1]
+    n = len(item)
+    tape = [1000003 * (i + 29) + 7 for i in range(7 * n)]
+    host.set_tape(tape)
+    objs = [bsw.delegate(host, pk, sk, subsets[s]) for s in item]
+    host.set_tape(tape)
+    blob, off = bsw.delegate_packed(host, pk, sk, subsets, item)
+    host.clear_tape()
+    for i in range(n):
+        assert objs[i].serialize() == blob[int(off[i]):int(off[i + 1])].tobytes(), i
+    ct_ab = bsw.encrypt(host, pk, '"A" and "B"', hl.HUMAN_POLICY, b"delegated")
+    ct_c = bsw.encrypt(host, pk, '"C"', hl.HUMAN_POLICY, b"delegated c")
+    keys = [hl.Obj.deserialize("bsw_sk", blob[int(off[i]):int(off[i + 1])].tobytes()) for i in range(n)]
+    assert bsw.decrypt(host, keys[0], ct_ab) == b"delegated" and bsw.decrypt(host, keys[3], ct_ab) == b"delegated"
+    assert bsw.decrypt(host, keys[1], ct_c) == b"delegated c"
+    with pytest.raises(hl.RabeError):
+        bsw.decrypt(host, keys[1], ct_ab)
+    with pytest.raises(hl.RabeError):
+        bsw.delegate_packed(host, pk, sk, [["A", "Z"]], [0])
+    with pytest.raises(hl.RabeError):
+        bsw.delegate_packed(host, pk, sk, [[]], [0])
+    blob, off = bsw.delegate_packed(host, pk, sk, subsets, np.arange(2000, dtype=np.uint32) % 4)        # OS randomness, more than one launch tile
+    for i in (0, 3, 1996, 1999):
+        k = hl.Obj.deserialize("bsw_sk", blob[int(off[i]):int(off[i + 1])].tobytes())
+        assert bsw.decrypt(host, k, ct_ab) == b"delegated"
