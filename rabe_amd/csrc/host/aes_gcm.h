@@ -1,7 +1,9 @@
 // KDF + AES-256-GCM of the reference's KEM/DEM step (src/utils/aes/mod.rs:10-55):
 //   key = SHA3-256(bytes(Gt)); output = nonce(12) || ciphertext || tag(16).
-// Host-side, negligible cost next to the group arithmetic; stays on the CPU exactly as
-// in the reference.  `bytes(Gt)` is rabe-bn's `Into<Vec<u8>> for Gt`, whose layout is not visible in
+// The packed entry points do this step on the DEVICE (engine_sym.hip); this is the host's form for the one-call object API and the
+// checker of the device path.  On x86-64 with AES-NI + PCLMULQDQ (every host this runs on) the block cipher is `aesenc` and GHASH a
+// carry-less multiplication: no table indexed by key-dependent bytes (constant time, ~1 cycle per byte).  The portable table form
+// below stays as the fallback and as its cross-check (RABE_AES_PORTABLE=1 forces it; tests/test_host_kats.py runs both).  `bytes(Gt)` is rabe-bn's `Into<Vec<u8>> for Gt`, whose layout is not visible in
 // /root/reference: gt_kdf_bytes() below is the single place that choice is made
 // (12 Fp coefficients in tower order, each 32-byte big-endian).
 #pragma once
@@ -106,8 +108,155 @@ inline void inc32(uint8_t ctr[16]) {
 }
 }  // namespace aesdetail
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+}}  // namespace rabe::host
+#include <immintrin.h>
+#include <stdlib.h>
+namespace rabe { namespace host {
+namespace aeshw {
+#define RABE_AESNI __attribute__((target("aes,pclmul,ssse3,sse4.1")))
+inline bool available() {
+  static const bool ok = [] {
+    const char* e = getenv("RABE_AES_PORTABLE");
+    if (e && *e && *e != '0') return false;
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("aes") && __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("sse4.1");
+  }();
+  return ok;
+}
+struct Key { __m128i rk[15]; };
+RABE_AESNI inline __m128i expand_a(__m128i k, __m128i assist) {          // even round keys (FIPS 197 key expansion with RotWord / Rcon)
+  assist = _mm_shuffle_epi32(assist, 0xff);
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  return _mm_xor_si128(k, assist);
+}
+RABE_AESNI inline __m128i expand_b(__m128i k, __m128i prev) {            // odd round keys (SubWord only)
+  __m128i assist = _mm_shuffle_epi32(_mm_aeskeygenassist_si128(prev, 0), 0xaa);
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  k = _mm_xor_si128(k, _mm_slli_si128(k, 4));
+  return _mm_xor_si128(k, assist);
+}
+RABE_AESNI inline void expand(const uint8_t key[32], Key* k) {
+  __m128i a = _mm_loadu_si128((const __m128i*)key), b = _mm_loadu_si128((const __m128i*)(key + 16));
+  k->rk[0] = a; k->rk[1] = b;
+#define RABE_AES_STEP(i, rcon) a = expand_a(a, _mm_aeskeygenassist_si128(b, rcon)); k->rk[i] = a; b = expand_b(b, a); k->rk[i + 1] = b;
+  RABE_AES_STEP(2, 0x01) RABE_AES_STEP(4, 0x02) RABE_AES_STEP(6, 0x04) RABE_AES_STEP(8, 0x08) RABE_AES_STEP(10, 0x10) RABE_AES_STEP(12, 0x20)
+#undef RABE_AES_STEP
+  k->rk[14] = expand_a(a, _mm_aeskeygenassist_si128(b, 0x40));
+}
+RABE_AESNI inline __m128i encrypt(const Key& k, __m128i x) {
+  x = _mm_xor_si128(x, k.rk[0]);
+  for (int r = 1; r < 14; r++) x = _mm_aesenc_si128(x, k.rk[r]);
+  return _mm_aesenclast_si128(x, k.rk[14]);
+}
+// GF(2^128) product in GCM's bit order on byte-reversed operands (Gueron / Kounavis: carry-less multiply, shift left by one, reduce)
+RABE_AESNI inline __m128i gfmul(__m128i a, __m128i b) {
+  __m128i t3 = _mm_clmulepi64_si128(a, b, 0x00), t4 = _mm_clmulepi64_si128(a, b, 0x10), t5 = _mm_clmulepi64_si128(a, b, 0x01),
+          t6 = _mm_clmulepi64_si128(a, b, 0x11);
+  t4 = _mm_xor_si128(t4, t5);
+  t5 = _mm_slli_si128(t4, 8);
+  t4 = _mm_srli_si128(t4, 8);
+  t3 = _mm_xor_si128(t3, t5);
+  t6 = _mm_xor_si128(t6, t4);
+  __m128i t7 = _mm_srli_epi32(t3, 31), t8 = _mm_srli_epi32(t6, 31);
+  t3 = _mm_slli_epi32(t3, 1);
+  t6 = _mm_slli_epi32(t6, 1);
+  __m128i t9 = _mm_srli_si128(t7, 12);
+  t8 = _mm_slli_si128(t8, 4);
+  t7 = _mm_slli_si128(t7, 4);
+  t3 = _mm_or_si128(t3, t7);
+  t6 = _mm_or_si128(t6, t8);
+  t6 = _mm_or_si128(t6, t9);
+  t7 = _mm_slli_epi32(t3, 31);
+  t8 = _mm_slli_epi32(t3, 30);
+  t9 = _mm_slli_epi32(t3, 25);
+  t7 = _mm_xor_si128(t7, t8);
+  t7 = _mm_xor_si128(t7, t9);
+  t8 = _mm_srli_si128(t7, 4);
+  t7 = _mm_slli_si128(t7, 12);
+  t3 = _mm_xor_si128(t3, t7);
+  __m128i t2 = _mm_srli_epi32(t3, 1);
+  t4 = _mm_srli_epi32(t3, 2);
+  t5 = _mm_srli_epi32(t3, 7);
+  t2 = _mm_xor_si128(t2, t4);
+  t2 = _mm_xor_si128(t2, t5);
+  t2 = _mm_xor_si128(t2, t8);
+  t3 = _mm_xor_si128(t3, t2);
+  return _mm_xor_si128(t6, t3);
+}
+RABE_AESNI inline __m128i bswap(__m128i x) { return _mm_shuffle_epi8(x, _mm_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)); }
+RABE_AESNI inline __m128i load_partial(const uint8_t* p, size_t n) {
+  uint8_t b[16] = {0};
+  memcpy(b, p, n);
+  return _mm_loadu_si128((const __m128i*)b);
+}
+// ciphertext bytes in `ct` (len), H and E_K(J0) from the key: the tag
+RABE_AESNI inline void tag_of(const Key& k, const uint8_t nonce[12], const uint8_t* ct, size_t len, uint8_t tag[16]) {
+  const __m128i h = bswap(encrypt(k, _mm_setzero_si128()));
+  __m128i y = _mm_setzero_si128();
+  for (size_t off = 0; off < len; off += 16) {
+    const size_t n = len - off < 16 ? len - off : 16;
+    y = gfmul(_mm_xor_si128(y, bswap(n == 16 ? _mm_loadu_si128((const __m128i*)(ct + off)) : load_partial(ct + off, n))), h);
+  }
+  uint8_t lens[16] = {0};
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) lens[15 - i] = (uint8_t)(bits >> (8 * i));
+  y = gfmul(_mm_xor_si128(y, bswap(_mm_loadu_si128((const __m128i*)lens))), h);
+  uint8_t j0[16];
+  memcpy(j0, nonce, 12); j0[12] = j0[13] = j0[14] = 0; j0[15] = 1;
+  _mm_storeu_si128((__m128i*)tag, _mm_xor_si128(bswap(y), encrypt(k, _mm_loadu_si128((const __m128i*)j0))));
+}
+RABE_AESNI inline void ctr(const Key& k, const uint8_t nonce[12], const uint8_t* in, size_t len, uint8_t* out) {
+  uint8_t c[16];
+  memcpy(c, nonce, 12);
+  uint32_t n32 = 2;
+  for (size_t off = 0; off < len; off += 16, n32++) {
+    c[12] = (uint8_t)(n32 >> 24); c[13] = (uint8_t)(n32 >> 16); c[14] = (uint8_t)(n32 >> 8); c[15] = (uint8_t)n32;
+    const __m128i ks = encrypt(k, _mm_loadu_si128((const __m128i*)c));
+    const size_t n = len - off < 16 ? len - off : 16;
+    if (n == 16) {
+      _mm_storeu_si128((__m128i*)(out + off), _mm_xor_si128(ks, _mm_loadu_si128((const __m128i*)(in + off))));
+    } else {
+      uint8_t b[16];
+      _mm_storeu_si128((__m128i*)b, _mm_xor_si128(ks, load_partial(in + off, n)));
+      memcpy(out + off, b, n);
+    }
+  }
+}
+RABE_AESNI inline std::vector<uint8_t> gcm_encrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* pt, size_t len) {
+  Key k;
+  expand(key, &k);
+  std::vector<uint8_t> out(len + 16);
+  ctr(k, nonce, pt, len, out.data());
+  tag_of(k, nonce, out.data(), len, out.data() + len);
+  return out;
+}
+RABE_AESNI inline bool gcm_decrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* ct_tag, size_t len_with_tag, std::vector<uint8_t>* pt) {
+  if (len_with_tag < 16) return false;
+  const size_t len = len_with_tag - 16;
+  Key k;
+  expand(key, &k);
+  uint8_t tag[16];
+  tag_of(k, nonce, ct_tag, len, tag);
+  uint8_t diff = 0;
+  for (int i = 0; i < 16; i++) diff |= (uint8_t)(tag[i] ^ ct_tag[len + i]);
+  if (diff) return false;
+  pt->assign(len, 0);
+  ctr(k, nonce, ct_tag, len, pt->data());
+  return true;
+}
+#undef RABE_AESNI
+}  // namespace aeshw
+#endif
+
 // AES-256-GCM, 96-bit nonce, no AAD.  out = ciphertext || tag.
 inline std::vector<uint8_t> aes256_gcm_encrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* pt, size_t len) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (aeshw::available()) return aeshw::gcm_encrypt(key, nonce, pt, len);
+#endif
   using namespace aesdetail;
   Aes256 aes(key);
   uint8_t h[16], zero[16] = {0}, j0[16], ctr[16], ks[16];
@@ -129,6 +278,9 @@ inline std::vector<uint8_t> aes256_gcm_encrypt(const uint8_t key[32], const uint
 }
 // returns false on authentication failure
 inline bool aes256_gcm_decrypt(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* ct_tag, size_t len_with_tag, std::vector<uint8_t>* pt) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (aeshw::available()) return aeshw::gcm_decrypt(key, nonce, ct_tag, len_with_tag, pt);
+#endif
   using namespace aesdetail;
   if (len_with_tag < 16) return false;
   size_t len = len_with_tag - 16;

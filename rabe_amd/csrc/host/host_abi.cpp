@@ -56,8 +56,8 @@ struct rabe_host {
   std::deque<rabe_ticket*> q;
   // up to Q_LANES batches run at once, each on its own engine lane (stream, staging, arena) with its own OS randomness source: a small
   // batch is bound by the latency of its launch sets, not by the chip, so batches side by side multiply the rate.  On a tape: one.
-  enum { Q_LANES = 6 };
-  bool q_lane_busy[Q_LANES] = {false, false, false, false, false, false};
+  enum { Q_LANES = 3 };
+  bool q_lane_busy[Q_LANES] = {false, false, false};
   OsRng q_rng[Q_LANES];
   uint64_t q_stats[6] = {0, 0, 0, 0, 0, 0};  // batches, requests, groups, requests run singly, microseconds inside batches, largest batch
   explicit rabe_host(int device) : eng(device) {}

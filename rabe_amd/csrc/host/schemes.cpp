@@ -1196,6 +1196,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   struct PolPlan {
     std::string text; PolicyLanguage lang; std::string err; PrunedList lst; std::vector<uint32_t> sk_sel;
     std::mutex mu; std::atomic<bool> have_rows{false}; std::vector<std::string> row_names; std::vector<uint32_t> ct_sel;
+    int shape = -1; uint32_t e_c0 = 0, e_row0 = 0, e_cp = 0, e_rows = 0;          // the gather shape of its records (filled after the parse, serially)
   };
   std::unordered_map<uint64_t, std::vector<std::shared_ptr<PolPlan>>> plans;
   std::shared_mutex plans_mu;
@@ -1240,7 +1241,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   BlobGather gather(eng, ct_blob, ct_len);          // the blob starts for the device now, beside the parsing below (records.h)
   struct View { const uint8_t* c0; const uint8_t* cp; const uint8_t* sealed; uint32_t sealed_len; uint32_t rows; const uint8_t* first_row;
                 std::vector<const uint8_t*> row_ptr; const std::vector<uint32_t>* ct_sel; const std::vector<uint32_t>* sk_sel;
-                std::vector<uint32_t> own_sel; };
+                std::vector<uint32_t> own_sel; PolPlan* plan = nullptr; };
   std::vector<View> v(n);
   parallel_for(n, [&](size_t i) {
     if (!(*errors)[i].empty()) return;
@@ -1285,6 +1286,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
       PolPlan* pp = plan_of(pol, pl, lang);
       if (!pp->err.empty()) throw RabeError(pp->err);
       v[i].sk_sel = &pp->sk_sel;
+      v[i].plan = pp;
       auto select = [&](std::vector<uint32_t>* out) {          // the name-matching loop of ac17/mod.rs:403-408 as an index list
         for (const auto& cur : pp->lst)
           for (uint32_t r = 0; r < rows; r++)
@@ -1323,17 +1325,25 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
     ct_sel_off[j + 1] = ct_sel_off[j] + (uint32_t)w.ct_sel->size();
     sk_sel_off[j + 1] = sk_sel_off[j] + (uint32_t)w.sk_sel->size();
   }
-  std::vector<uint32_t> ct_sel(ct_sel_off[m]), sk_sel(sk_sel_off[m]);
+  // the lists themselves are written straight into pinned staging (65 536 items: 2 x 8 MB) and uploaded from there
+  const size_t n_ct_sel = ct_sel_off[m], n_sk_sel = sk_sel_off[m];
+  uint32_t* const ct_sel = (uint32_t*)eng.pinned_bump((n_ct_sel + n_sk_sel + 2) * 4);
+  uint32_t* const sk_sel = ct_sel + n_ct_sel + 1;
   {
     const size_t per = 1024, blocks = (m + per - 1) / per;
     parallel_for(blocks, [&](size_t b) {
       for (size_t j = b * per; j < m && j < (b + 1) * per; j++) {
         const View& w = v[live[j]];
-        if (!w.ct_sel->empty()) memcpy(ct_sel.data() + ct_sel_off[j], w.ct_sel->data(), w.ct_sel->size() * 4);
-        if (!w.sk_sel->empty()) memcpy(sk_sel.data() + sk_sel_off[j], w.sk_sel->data(), w.sk_sel->size() * 4);
+        if (!w.ct_sel->empty()) memcpy(ct_sel + ct_sel_off[j], w.ct_sel->data(), w.ct_sel->size() * 4);
+        if (!w.sk_sel->empty()) memcpy(sk_sel + sk_sel_off[j], w.sk_sel->data(), w.sk_sel->size() * 4);
       }
     });
   }
+  // uploaded at once: a later take from the same pinned block may move the block (Engine::pinned_bump waits for the stream first)
+  DBuf d_sel(&eng, (n_ct_sel + n_sk_sel + 2) * 4);
+  eng.check(rhip_upload_async(eng.ctx(), d_sel.ptr(), ct_sel, (n_ct_sel + n_sk_sel + 2) * 4), "upload (selection lists)");
+  const uint32_t* const d_ct_sel = d_sel.as<uint32_t>();
+  const uint32_t* const d_sk_sel = d_ct_sel + n_ct_sel + 1;
   if (!m) {
     pt_off[0] = 0;
     for (size_t i = 0; i < n; i++) { pt_off[i + 1] = 0; status[i] = -1; }
@@ -1352,24 +1362,20 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
     parts.push_back({(uint32_t)(w.cp - rec), 384, 2, 0});
     return parts;
   };
-  struct Ends { uint32_t c0, row0, cp, rows; };
-  std::unordered_map<const void*, Ends> ends;
   for (size_t j = 0; j < m; j++) {
     const View& w = v[live[j]];
     const uint8_t* rec = ct_blob + ct_off[live[j]];
     sealed_off[j] = (uint64_t)(w.sealed - ct_blob);
     sealed_len[j] = w.sealed_len;
-    const Ends e{(uint32_t)(w.c0 - rec), w.rows ? (uint32_t)(w.row_ptr[0] - rec) : 0u, (uint32_t)(w.cp - rec), w.rows};
+    const uint32_t e_c0 = (uint32_t)(w.c0 - rec), e_row0 = w.rows ? (uint32_t)(w.row_ptr[0] - rec) : 0u, e_cp = (uint32_t)(w.cp - rec);
     int shape = -1;
-    if (w.ct_sel != &w.own_sel) {
-      shape = gather.find(w.ct_sel);
-      if (shape < 0) {
-        shape = (int)gather.add_shape(w.ct_sel, parts_of(w, rec));
-        ends[w.ct_sel] = e;
-      } else {
-        const Ends& f = ends[w.ct_sel];
-        if (f.c0 != e.c0 || f.row0 != e.row0 || f.cp != e.cp || f.rows != e.rows) shape = -1;
+    if (w.ct_sel != &w.own_sel) {                 // the plan's shared row layout: its shape is remembered in the plan itself
+      PolPlan* pp = w.plan;
+      if (pp->shape < 0) {
+        pp->shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
+        pp->e_c0 = e_c0; pp->e_row0 = e_row0; pp->e_cp = e_cp; pp->e_rows = w.rows;
       }
+      if (pp->e_c0 == e_c0 && pp->e_row0 == e_row0 && pp->e_cp == e_cp && pp->e_rows == w.rows) shape = pp->shape;
     }
     if (shape < 0) shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
     gather.item(ct_off[live[j]], (uint32_t)shape);
@@ -1383,8 +1389,9 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   for (size_t j = 0; j < m; j++) { dst_off[j] = 384ull * j; dst_off[m + j] = 192ull * ct_row_off[j]; dst_off[2 * m + j] = 384ull * j; }
   ParamPack pp(eng);
   const size_t h3 = pp.add(ct_row_off), h6 = pp.add(kk), h7 = pp.add(sk_row_off), h8 = pp.add(kp_bytes), h9 = pp.add(sk_idx),
-               h10 = pp.add(ct_sel), h11 = pp.add(ct_sel_off), h12 = pp.add(sk_sel), h13 = pp.add(sk_sel_off);
+               h11 = pp.add(ct_sel_off), h13 = pp.add(sk_sel_off);
   pp.upload();
+
   tm.lap("selection tables");
   gather.run({d1.ptr(), d2.ptr(), d4.ptr()}, dst_off);
   const uint32_t* d3 = pp.dev<uint32_t>(h3);
@@ -1401,8 +1408,8 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   std::string k0_key((const char*)k0.data(), k0.size());
   rhip_ac17_sk_lines* lines = (rhip_ac17_sk_lines*)eng.aux("ac17_sk_lines", k0_key, make_ac17_sk_lines, &k0_key, destroy_ac17_sk_lines, 4);
   eng.check(rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3, d4.as<rhip_gt>(), lines, pp.dev<rhip_g1>(h6),
-                                                pp.dev<uint32_t>(h7), pp.dev<rhip_g1>(h8), pp.dev<uint32_t>(h9), pp.dev<uint32_t>(h10),
-                                                pp.dev<uint32_t>(h11), pp.dev<uint32_t>(h12), pp.dev<uint32_t>(h13), dout.as<rhip_gt>()),
+                                                pp.dev<uint32_t>(h7), pp.dev<rhip_g1>(h8), pp.dev<uint32_t>(h9), d_ct_sel,
+                                                pp.dev<uint32_t>(h11), d_sk_sel, pp.dev<uint32_t>(h13), dout.as<rhip_gt>()),
             "rhip_ac17_cp_decrypt_batch_prepared");
   if (mc) {
     mc->collect();

@@ -171,3 +171,18 @@ def test_encrypt_symmetric_is_kdf_then_gcm():
     nonce, pt = rnd.randbytes(12), b"dance like no one's watching, encrypt like everyone is!"
     key = hashlib.sha3_256(b"".join(gt[32 * i:32 * i + 32][::-1] for i in range(12))).digest()      # 12 x 32-byte big-endian
     assert hl.encrypt_symmetric(gt, pt, nonce) == nonce + b"".join(aes256_gcm(key, nonce, pt))
+
+
+def test_both_host_implementations_pass_the_vectors():
+    """aes_gcm.h has two forms: AES-NI + PCLMULQDQ (no table indexed by secret bytes) where the CPU has them, and the portable table form.
+    The process-wide choice is made once (RABE_AES_PORTABLE=1 forces the portable one): the vectors above run again in a child under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RABE_AES_PORTABLE"):
+        pytest.skip("already the forced-portable child")
+    env = dict(os.environ, RABE_AES_PORTABLE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-k", "gcm or symmetric or fips197"], env=env, cwd=root,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert pr.returncode == 0, pr.stdout.decode()[-2000:]
