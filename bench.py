@@ -722,10 +722,11 @@ def configs_leg(args):
 
 
 def object_api_leg(args, trees):
-    """AC17 config 2 through the reference-shaped object API of the C++ host layer: policy strings and plaintext bytes in,
-    canonical ciphertext records out (AES-GCM sealing included) and back to plaintext bytes -- what a caller of the scheme
-    functions sees, per-item host work (parse, MSP, pruning, KDF + AES, record assembly) inside the timed region.
-    `packed`: rabe_ac17_cp_{encrypt,decrypt}_packed (one blob + offsets per batch); `objects`: one handle per ciphertext."""
+    """AC17 config 2 through the reference-shaped API of the C++ host layer: policy strings and plaintext bytes in, canonical ciphertext
+    records out (AES-GCM sealing included) and back to plaintext bytes -- what a caller of the scheme functions sees; parse, MSP, pruning
+    on the host, KDF + AES-GCM and record assembly on the device, the PCIe copies: all inside the timed region.
+    `packed` / `packed_full_group`: rabe_ac17_cp_{encrypt,decrypt}_packed (one blob + offsets per call) at 5 and 16 steps' worth of items;
+    `threads`: the one-call API from many threads through the submission queue; `objects`: one handle per ciphertext, one batch call."""
     import numpy as np
     from rabe_amd import hostlib as hl
     from rabe_amd import hostprep as hp
@@ -736,44 +737,48 @@ def object_api_leg(args, trees):
         pk, msk = ac17.setup(host)
         sk = ac17.cp_keygen(host, msk, attrs)
         pols = [hp.to_json(t) for t in trees]
-        n = 5 * args.batch                 # one packed call carries five steps' worth of items (a single 4096-item launch under-fills the chip)
-        pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
-        # ---- packed
-        item_pol = np.arange(n, dtype=np.uint32) % len(pols)
-        pt_blob = b"".join(pts)
-        pt_off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
-        pt_np = np.frombuffer(pt_blob, dtype=np.uint8)
-        # caller-allocated, re-used buffers (the first round also builds the tables and the pinned staging buffers: untimed)
-        ct_buf, _ = ac17.cp_encrypt_packed(host, pk, pols, item_pol, pt_np, pt_off)
-        ct_buf = np.empty(ct_buf.size, dtype=np.uint8)
-        ct_buf[:] = 0
-        pt_buf = np.zeros(ct_buf.size, dtype=np.uint8)
-        best = None
-        best_tr = None
-        ok_packed = True
-        for rep in range(4):
-            t0 = time.perf_counter()
-            ct_blob, ct_off = ac17.cp_encrypt_packed(host, pk, pols, item_pol, pt_np, pt_off, out=ct_buf)
-            t1 = time.perf_counter()
-            out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf)          # checked: membership pass on
-            t2 = time.perf_counter()
-            ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any() and (out_off == pt_off).all()
-            out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf, trusted=True)
-            t3 = time.perf_counter()
-            ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any()
-            if rep and (best is None or t2 - t0 < best[0]):
-                best = (t2 - t0, t1 - t0, t2 - t1)
-            if rep and (best_tr is None or t3 - t2 < best_tr):
-                best_tr = t3 - t2
-        packed = {"ops_per_s": round(n / best[0], 1), "encrypt_s": round(best[1], 4), "decrypt_s": round(best[2], 4), "batch": n,
-                  "decrypt_trusted_s": round(best_tr, 4), "ops_per_s_trusted": round(n / (best[1] + best_tr), 1),
-                  "ciphertext_bytes": int(ct_blob.size), "plaintexts_match": bool(ok_packed),
-                  "note": "decrypt_s includes the batched group-membership pass over every decoded element (c_0 in G2's r-torsion, rows on the G1 "
+
+        def packed_leg(n, reps):
+            pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
+            item_pol = np.arange(n, dtype=np.uint32) % len(pols)
+            pt_blob = b"".join(pts)
+            pt_off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+            pt_np = np.frombuffer(pt_blob, dtype=np.uint8)
+            # caller-allocated, re-used buffers (the first round also builds the tables and the pinned staging buffers: untimed)
+            ct_buf, _ = ac17.cp_encrypt_packed(host, pk, pols, item_pol, pt_np, pt_off)
+            ct_buf = np.empty(ct_buf.size, dtype=np.uint8)
+            ct_buf[:] = 0
+            pt_buf = np.zeros(ct_buf.size, dtype=np.uint8)
+            best = None
+            best_tr = None
+            ok_packed = True
+            for rep in range(reps):
+                t0 = time.perf_counter()
+                ct_blob, ct_off = ac17.cp_encrypt_packed(host, pk, pols, item_pol, pt_np, pt_off, out=ct_buf)
+                t1 = time.perf_counter()
+                out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf)          # checked: membership pass on
+                t2 = time.perf_counter()
+                ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any() and (out_off == pt_off).all()
+                out_blob, out_off, status = ac17.cp_decrypt_packed(host, sk, ct_blob, ct_off, out=pt_buf, trusted=True)
+                t3 = time.perf_counter()
+                ok_packed = ok_packed and out_blob.tobytes() == pt_blob and not status.any()
+                if rep and (best is None or t2 - t0 < best[0]):
+                    best = (t2 - t0, t1 - t0, t2 - t1)
+                if rep and (best_tr is None or t3 - t2 < best_tr):
+                    best_tr = t3 - t2
+            return {"ops_per_s": round(n / best[0], 1), "encrypt_s": round(best[1], 4), "decrypt_s": round(best[2], 4), "batch": n,
+                    "decrypt_trusted_s": round(best_tr, 4), "ops_per_s_trusted": round(n / (best[1] + best_tr), 1),
+                    "ciphertext_bytes": int(ct_blob.size), "plaintexts_match": bool(ok_packed)}
+        # one packed call carries five steps' worth of items (a single 4096-item launch under-fills the chip) ...
+        packed = packed_leg(5 * args.batch, 4)
+        packed["note"] = ("decrypt_s includes the batched group-membership pass over every decoded element (c_0 in G2's r-torsion, rows on the G1 "
                           "curve, c_p in Gt's order-r subgroup, coordinates < p): the default for external ciphertexts; *_trusted skips it "
-                          "(RABE_PACKED_TRUSTED)"}
-        # ---- one object handle per ciphertext (round 1's path), one step's worth
+                          "(RABE_PACKED_TRUSTED). KDF + AES-256-GCM and record assembly run on the device (round 4)")
+        # ... and sixteen: the size of the device-level launch groups, where the decrypt's final exponentiation fills the chip
+        packed_full = packed_leg(16 * args.batch, 3)
         n = args.batch
-        pts = pts[:n]
+        pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
+        # ---- one object handle per ciphertext (round 1's path), one step's worth
         items = [pols[i % len(pols)] for i in range(n)]
         ac17.cp_decrypt_batch(host, [sk] * 64, ac17.cp_encrypt_batch(host, pk, items[:64], pts[:64], hl.JSON_POLICY))
         t0 = time.perf_counter()
@@ -784,7 +789,7 @@ def object_api_leg(args, trees):
         objects = {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "plaintexts_match": out == pts}
         del cts
         threads = threads_leg(host, pk, sk, pols)
-        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "threads": threads,
+        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "packed_full_group": packed_full, "threads": threads,
                 "objects": objects,
                 "note": "policy text + plaintext bytes -> canonical ciphertext records -> plaintext bytes through the C ABI of the host layer; "
                         "parse/MSP/pruning/KDF/AES-GCM, record assembly and the PCIe copies are inside the timed region (best of 3 for `packed`)"}

@@ -80,6 +80,11 @@ int32_t rhip_memset_async(rhip_ctx* ctx, void* dev, int32_t byte, size_t bytes);
  * submitted to `other` so far has finished (event record + stream wait): e.g. a copy context that drains one batch's
  * outputs while the compute context already runs the next kernels */
 int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other);
+/* a point of a context's stream that a HOST thread can wait for without waiting for the stream's later work (rhip_event_wait blocks until
+ * everything submitted to ctx before rhip_event_record has finished, and frees the event) */
+typedef struct rhip_event rhip_event;
+int32_t rhip_event_record(rhip_ctx* ctx, rhip_event** out);
+int32_t rhip_event_wait(rhip_event* ev);
 /* Pipelining two launch sets on two contexts (streams): `waiter`'s stream is held until ctx's NEXT decrypt (any entry point that runs
  * the shared-accumulator Miller kernel) has issued its Miller loops; what is left on ctx then is its final exponentiation (one wave per
  * item), beside which the waiter's encrypt kernels can run.  One-shot.  Typical use: a small launch set on ctx, the next large one on

@@ -254,6 +254,27 @@ extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* wa
   ctx->fe_waiter = waiter;          // NULL withdraws a pending request; rhip_ctx_destroy(waiter) withdraws it too
   return RHIP_OK;
 }
+// a point of a context's stream a HOST thread can wait for (the host layer's helper threads wait for one part's copy, not for the stream)
+struct rhip_event { hipEvent_t ev; int device; };
+extern "C" int32_t rhip_event_record(rhip_ctx* ctx, rhip_event** out) {
+  if (!ctx || !out) return RHIP_ERR_ARG;
+  *out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipEvent_t ev;
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ctx->stream);
+  if (e != hipSuccess) { (void)hipEventDestroy(ev); return fail(ctx, e, "hipEventRecord"); }
+  *out = new rhip_event{ev, ctx->device};
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_event_wait(rhip_event* ev) {          // blocks the calling thread until the recorded point has been reached; frees the event
+  if (!ev) return RHIP_ERR_ARG;
+  (void)hipSetDevice(ev->device);
+  const hipError_t e = hipEventSynchronize(ev->ev);
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return e == hipSuccess ? RHIP_OK : RHIP_ERR_HIP;
+}
 extern "C" int32_t rhip_ctx_wait_for(rhip_ctx* ctx, rhip_ctx* other) {
   if (!ctx || !other) return RHIP_ERR_ARG;
   hipEvent_t ev;

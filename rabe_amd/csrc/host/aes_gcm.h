@@ -248,6 +248,13 @@ RABE_AESNI inline bool gcm_decrypt(const uint8_t key[32], const uint8_t nonce[12
   ctr(k, nonce, ct_tag, len, pt->data());
   return true;
 }
+// raw keystream E_K(iv + 0), E_K(iv + 1), ... (64-bit little-endian counter in the low half of the block): the batch randomness source
+RABE_AESNI inline void keystream(const Key& k, uint64_t iv_hi, uint64_t* counter, uint8_t* out, size_t n_blocks) {
+  for (size_t b = 0; b < n_blocks; b++) {
+    const __m128i x = _mm_set_epi64x((long long)iv_hi, (long long)(*counter)++);
+    _mm_storeu_si128((__m128i*)(out + 16 * b), encrypt(k, x));
+  }
+}
 #undef RABE_AESNI
 }  // namespace aeshw
 #endif

@@ -146,7 +146,7 @@ void draw_items(Rng& rng, size_t n, DRAW draw) {
     // an item of these schemes draws hundreds of values (one per gate coefficient and leaf): small blocks, so that every core draws
     const size_t per = 16, blocks = (n + per - 1) / per;
     parallel_for(blocks, [&](size_t b) {
-      OsRng local;
+      BatchRng local;
       for (size_t i = b * per; i < n && i < (b + 1) * per; i++) draw(local, i);
     });
   } else {
@@ -1064,7 +1064,6 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
        d_in(&eng, 64 + (total_coef + total + 1) * 32), d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4);
   eng.check(rhip_upload_async(cx, d_in.ptr(), h_in, 64 + (total_coef + total) * 32), "upload");
   const rhip_fr* din = d_in.as<rhip_fr>();
-  uint8_t* h_l = eng.pinned(1, total * (192 + (any_negative ? 192 : 0)) + 4);       // d1 rows | d2 rows [| d3 | d4 | d5 rows]
   DBuf d_d345;
   if (!any_negative) {
     eng.check(rhip_lsw_keygen_batch(cx, dpk, n, total, d_leaf_off.as<uint32_t>(), d_tl.as<uint32_t>(), d_tg.as<uint32_t>(), dt.path_off.as<uint32_t>(),
@@ -1082,34 +1081,33 @@ bool keygen_packed(Engine& eng, Rng& rng, const KpAbePublicKey& pk, const KpAbeM
                                            dt.leaf_hash.as<rhip_fr>(), d_neg.as<uint32_t>(), din, d_b.as<rhip_fr>(), (const rhip_g1*)msk.h_g1.data(),
                                            din + 2, d_coef_off.as<uint32_t>(), din + 2 + total_coef, d_d1.as<rhip_g1>(), d_d2.as<rhip_g2>(), d3,
                                            d3 + total, d3 + 2 * total), "rhip_lsw_keygen_batch_signed");
-    eng.check(rhip_download_async(cx, h_l + total * 192, d_d345.ptr(), total * 192), "download");
   }
-  eng.check(rhip_download_async(cx, h_l, d_d1.ptr(), total * 64), "download");
-  eng.check(rhip_download_async(cx, h_l + total * 64, d_d2.ptr(), total * 128), "download");
-  eng.check(rhip_sync(cx), "rhip_sync");
-  tm.lap("device + copies");
-  parallel_for(n, [&](size_t i) {
-    const size_t p_ = item_policy[i];
-    const std::string& pol = policies[p_];
-    uint8_t* w = out_buf + out_off[i];
-    put_u32(w, (uint32_t)pol.size()); w += 4;
-    memcpy(w, pol.data(), pol.size()); w += pol.size();
-    *w++ = (language == PolicyLanguage::HumanPolicy) ? 1 : 0;
-    put_u32(w, (uint32_t)striped[p_].size()); w += 4;
+  // the records are written on the device (records.h): policy text, leaf names and counts from the policy's template, the elements dropped
+  // in (d3 .. d5 are the point at infinity -- zeros -- for a policy without negative leaves)
+  std::vector<RecordLayout> layouts(policies.size());
+  for (size_t p_ = 0; p_ < policies.size(); p_++) {
+    RecordLayout& L = layouts[p_];
+    L.str(policies[p_]);
+    L.u8((language == PolicyLanguage::HumanPolicy) ? 1 : 0);
+    L.u32((uint32_t)striped[p_].size());
     for (size_t y = 0; y < striped[p_].size(); y++) {
-      const std::string& nm = striped[p_][y];
-      put_u32(w, (uint32_t)nm.size()); w += 4;
-      memcpy(w, nm.data(), nm.size()); w += nm.size();
-      memcpy(w, h_l + (size_t)(leaf_off[i] + y) * 64, 64); w += 64;
-      memcpy(w, h_l + total * 64 + (size_t)(leaf_off[i] + y) * 128, 128); w += 128;
-      if (any_negative) {
-        for (int k3 = 0; k3 < 3; k3++) { memcpy(w, h_l + total * 192 + ((size_t)k3 * total + leaf_off[i] + y) * 64, 64); w += 64; }
-      } else {
-        memset(w, 0, 192); w += 192;
-      }
+      L.str(striped[p_][y]);
+      L.src(0, (uint32_t)(64 * y), 64);
+      L.src(1, (uint32_t)(128 * y), 128);
+      if (any_negative) { L.src(2, (uint32_t)(64 * y), 64); L.src(3, (uint32_t)(64 * y), 64); L.src(4, (uint32_t)(64 * y), 64); }
+      else { const uint8_t zeros[192] = {0}; L.lit(zeros, 192); }
     }
-  });
-  tm.lap("assembly");
+  }
+  std::vector<const void*> srcs{d_d1.ptr(), d_d2.ptr()};
+  std::vector<uint64_t> src_off((any_negative ? 5 : 2) * n);
+  for (size_t i = 0; i < n; i++) { src_off[i] = 64ull * leaf_off[i]; src_off[n + i] = 128ull * leaf_off[i]; }
+  if (any_negative) {
+    const uint8_t* d3 = d_d345.as<uint8_t>();
+    srcs.push_back(d3); srcs.push_back(d3 + total * 64); srcs.push_back(d3 + 2 * total * 64);
+    for (size_t i = 0; i < n; i++) src_off[2 * n + i] = src_off[3 * n + i] = src_off[4 * n + i] = 64ull * leaf_off[i];
+  }
+  emit_plain_records(eng, layouts, n, item_policy, srcs, src_off, out_off, out_buf);
+  tm.lap("device: shares, fixed-base multiplications, records; one copy out");
   return true;
 }
 

@@ -1,13 +1,17 @@
 // records.cpp -- device-side tails of the packed entry points: see records.h
 #include "records.h"
 
+#include <algorithm>
 #include <chrono>
+#include <functional>
 #include <future>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-namespace rabe { namespace schemes {
+namespace rabe {
+void parallel_for(size_t n, const std::function<void(size_t)>& fn);          // schemes.cpp
+namespace schemes {
 
 namespace {
 // RABE_HOST_TIMING: what the tails spend where (with a stream sync at every lap, so that device time is attributed to its stage)
@@ -59,7 +63,8 @@ void sym_shape(const std::vector<uint32_t>& len, std::vector<uint32_t>* blk_off,
 
 void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
                          const std::vector<const void*>& dev_src, const std::vector<uint64_t>& src_item_off, const void* d_msg,
-                         const uint8_t* nonces, const uint8_t* pt_blob, const uint64_t* pt_off, const uint64_t* out_off, uint8_t* out_buf) {
+                         const uint8_t* nonces, const uint8_t* pt_blob, const uint64_t* pt_off, const uint64_t* out_off, uint8_t* out_buf,
+                         PendingCopy* defer) {
   if (!n) return;
   TailTimer tm(eng, "emit_sealed_records");
   tm.lap("kernels queued before the tail");
@@ -99,19 +104,53 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
     eng.check(rhip_upload_async(cx, d_pt_big.ptr(), pt_blob + pt_off[0], (size_t)pt_bytes), "upload (plaintexts)");
     d_pt = d_pt_big.as<uint8_t>();
   }
-  DBuf d_out(&eng, (size_t)out_off[n]), d_ws(&eng, rhip_seal_workspace_bytes(n, seg_off[n]));
-  eng.check(rhip_assemble_records(cx, n, d_out.as<uint8_t>(), pp.dev<uint64_t>(h_out_off), pp.dev<uint32_t>(h_layout), pp.dev<uint32_t>(h_loff),
+  // the records of this call start at out_off[0] of the caller's buffer: the device block holds them from its first byte, the kernels
+  // get a base pointer shifted by out_off[0]
+  const size_t out_bytes = (size_t)(out_off[n] - out_off[0]);
+  DBuf d_out_buf(&eng, out_bytes ? out_bytes : 4), d_ws(&eng, rhip_seal_workspace_bytes(n, seg_off[n]));
+  uint8_t* const d_out = d_out_buf.as<uint8_t>() - out_off[0];
+  eng.check(rhip_assemble_records(cx, n, d_out, pp.dev<uint64_t>(h_out_off), pp.dev<uint32_t>(h_layout), pp.dev<uint32_t>(h_loff),
                                   pp.dev<uint32_t>(h_map), (uint32_t)n_src, pp.dev<const uint8_t*>(h_src), pp.dev<uint64_t>(h_sio)),
             "rhip_assemble_records");
   tm.lap("rhip_assemble_records");
   // pt_off is relative to pt_blob; the device copy starts at pt_off[0]
-  eng.check(rhip_seal_batch(cx, n, (const rhip_gt*)d_msg, pp.dev<uint8_t>(h_nonce), d_pt - pt_off[0], pp.dev<uint64_t>(h_pt_off), d_out.as<uint8_t>(),
+  eng.check(rhip_seal_batch(cx, n, (const rhip_gt*)d_msg, pp.dev<uint8_t>(h_nonce), d_pt - pt_off[0], pp.dev<uint64_t>(h_pt_off), d_out,
                             pp.dev<uint64_t>(h_soff), pp.dev<uint32_t>(h_len), pp.dev<uint32_t>(h_blk), blk_off[n], pp.dev<uint32_t>(h_seg), seg_off[n],
                             1, d_ws.ptr()),
             "rhip_seal_batch");
   tm.lap("rhip_seal_batch");
-  eng.check(rhip_download(cx, out_buf + out_off[0], d_out.as<uint8_t>() + out_off[0], (size_t)(out_off[n] - out_off[0])), "download (records)");
+  if (defer) {
+    // device -> pinned staging on the side stream, then staging -> the caller's buffer on a helper thread that waits for THIS copy only
+    // (a copy straight into pageable memory occupies the runtime for its whole length).  Measured: the runtime
+    // performs a large D2H copy as a blit KERNEL that covers the chip, so the next part's kernels slow down by what the copy takes --
+    // no net overlap; callers therefore cut a batch into parts only when asked to (RABE_AC17_ENC_PARTS)
+    rhip_ctx* const side = eng.side_ctx();
+    eng.check(rhip_ctx_wait_for(side, cx), "rhip_ctx_wait_for");          // the copy starts when everything queued so far is done
+    uint8_t* const dst = out_buf + out_off[0];
+    uint8_t* const pin = eng.pinned_bump(out_bytes);
+    eng.check(rhip_download_async(side, pin, d_out_buf.ptr(), out_bytes), "download (records)");
+    rhip_event* ev = nullptr;
+    eng.check(rhip_event_record(side, &ev), "rhip_event_record");
+    auto fut = std::make_shared<std::future<int32_t>>(std::async(std::launch::async, [ev, dst, pin, out_bytes]() -> int32_t {
+      const int32_t rc = rhip_event_wait(ev);
+      if (rc) return rc;
+      const size_t piece = (size_t)1 << 20, pieces = (out_bytes + piece - 1) / piece;
+      parallel_for(pieces, [&](size_t k) { const size_t o = k * piece; memcpy(dst + o, pin + o, std::min(piece, out_bytes - o)); });
+      return 0;
+    }));
+    defer->d_out = std::move(d_out_buf);
+    defer->fut = fut;
+    return;
+  }
+  eng.check(rhip_download(cx, out_buf + out_off[0], d_out_buf.ptr(), out_bytes), "download (records)");
   tm.lap("copy out");
+}
+void PendingCopy::wait(Engine& eng) {
+  if (!fut) return;
+  auto f = std::static_pointer_cast<std::future<int32_t>>(fut);
+  const int32_t rc = f->get();
+  fut.reset();
+  eng.check(rc, "download (records)");
 }
 
 void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
@@ -140,9 +179,11 @@ void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, s
 
 struct BlobGather::Up { std::future<int32_t> f; };
 BlobGather::BlobGather(Engine& eng, const uint8_t* blob, size_t len) : eng_(eng), d_blob_(&eng, len ? len : 4), up_(new Up) {
-  rhip_ctx* const cx = eng.ctx();
+  // hipMemcpyAsync out of pageable memory occupies the calling thread for the length of the copy: a helper thread takes it -- and the
+  // lane's SIDE stream, because calls on one stream serialise inside the runtime: on the main stream the host's own small uploads
+  // (selection tables, parameter packs) waited for the blob (65 536 AC17 items: 12.5 ms) instead of running beside it
+  rhip_ctx* const cx = eng.side_ctx();
   void* const dst = d_blob_.ptr();
-  // hipMemcpyAsync out of pageable memory occupies the calling thread for the length of the copy: a helper thread takes it
   up_->f = std::async(std::launch::async, [cx, dst, blob, len]() -> int32_t { return len ? rhip_upload_async(cx, dst, blob, len) : RHIP_OK; });
 }
 BlobGather::~BlobGather() {
@@ -163,6 +204,7 @@ uint32_t BlobGather::add_shape(const void* key, std::vector<RecordLayout::Part> 
 void BlobGather::run(const std::vector<void*>& dst, const std::vector<uint64_t>& dst_item_off) {
   const size_t m = rec_off_.size();
   eng_.check(up_->f.get(), "upload (records)");
+  eng_.check(rhip_ctx_wait_for(eng_.ctx(), eng_.side_ctx()), "rhip_ctx_wait_for");          // the gather starts when the blob is there
   if (!m) return;
   if (dst_item_off.size() != dst.size() * m) throw RabeError("BlobGather: dst_item_off has the wrong size");
   pp_.reset(new ParamPack(eng_));
@@ -228,4 +270,5 @@ void open_sealed_records(Engine& eng, size_t n, const std::vector<size_t>& live,
   }
 }
 
-}}  // namespace rabe::schemes
+}  // namespace schemes
+}  // namespace rabe

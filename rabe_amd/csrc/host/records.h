@@ -51,10 +51,18 @@ void sym_shape(const std::vector<uint32_t>& len, std::vector<uint32_t>* blk_off,
 // Tail of a packed encrypt.  layouts[l]: the record shape of layout l; item i has layout item_layout[i], its record starts at
 // out_off[i] and is layouts[l].bytes() + 4 + (plaintext length + 28) bytes long.  dev_src[k] / src_item_off[k * n + i]: where item i's
 // part in source k starts (device).  d_msg: the n Gt messages (device).  Writes the n finished records to out_buf.
+// With `defer`, the copy of the finished records into out_buf is handed to a helper thread on the lane's SIDE stream (it starts when the
+// kernels queued so far are done) and the call returns at once: a caller that cuts its batch into parts launches the next part's group
+// arithmetic beside it (PendingCopy::wait before the buffers are read; the parts of one call share one ArenaScope).
+struct PendingCopy {
+  DBuf d_out;
+  std::shared_ptr<void> fut;          // std::future<int32_t>
+  void wait(Engine& eng);
+};
 void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
                          const std::vector<const void*>& dev_src, const std::vector<uint64_t>& src_item_off, const void* d_msg,
                          const uint8_t* nonces /*[n][12]*/, const uint8_t* pt_blob, const uint64_t* pt_off /*[n+1]*/,
-                         const uint64_t* out_off /*[n+1]*/, uint8_t* out_buf);
+                         const uint64_t* out_off /*[n+1]*/, uint8_t* out_buf, PendingCopy* defer = nullptr);
 
 // The same without a sealed part (bulk key issuing): a record is exactly its layout's bytes.
 void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,

@@ -47,6 +47,46 @@ void OsRng::fill(uint8_t* out, size_t n) {
   }
 }
 
+BatchRng::BatchRng() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (host::aeshw::available()) {
+    uint8_t seed[40];
+    os.fill(seed, sizeof seed);
+    auto* k = new host::aeshw::Key;
+    host::aeshw::expand(seed, k);
+    memcpy(&iv_hi, seed + 32, 8);
+    memset(seed, 0, sizeof seed);
+    key = k;
+  }
+#endif
+}
+BatchRng::~BatchRng() {
+  memset(pool, 0, sizeof pool);
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (key) {
+    memset(key, 0, sizeof(host::aeshw::Key));
+    delete (host::aeshw::Key*)key;
+  }
+#endif
+}
+void BatchRng::fill(uint8_t* out, size_t n) {
+  if (!key) { os.fill(out, n); return; }
+  while (n) {
+    if (pool_pos == sizeof(pool)) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+      host::aeshw::keystream(*(const host::aeshw::Key*)key, iv_hi, &counter, pool, sizeof(pool) / 16);
+#endif
+      pool_pos = 0;
+    }
+    const size_t k = std::min(n, sizeof(pool) - pool_pos);
+    memcpy(out, pool + pool_pos, k);
+    memset(pool + pool_pos, 0, k);            // consumed randomness does not linger
+    pool_pos += k;
+    out += k;
+    n -= k;
+  }
+}
+
 int& Engine::tl_lane() {
   static thread_local int lane = 0;
   return lane;
@@ -103,11 +143,26 @@ uint8_t* Engine::pinned(int slot, size_t bytes) {
   return (uint8_t*)l.pin[slot];
 }
 void Engine::scrub_when_done() { lanes_[cur_lane()]->scrub = true; }
+void Engine::pinned_reserve(size_t bytes) {
+  Lane& l = *lanes_[cur_lane()];
+  if (l.pin3_used + bytes <= l.pin_bytes[3]) return;
+  // grow NOW, at a point where nothing of this call reads the block on a helper thread: what is already in it moves along
+  check(rhip_sync(l.ctx), "rhip_sync");
+  if (l.side) check(rhip_sync(l.side), "rhip_sync");
+  void* fresh = nullptr;
+  const size_t want = l.pin3_used + bytes + bytes / 8 + (1u << 20);
+  check(rhip_host_alloc(l.ctx, want, &fresh), "rhip_host_alloc");
+  if (l.pin[3] && l.pin3_used) memcpy(fresh, l.pin[3], l.pin3_used);
+  if (l.pin[3]) rhip_host_free(l.ctx, l.pin[3]);
+  l.pin[3] = fresh;
+  l.pin_bytes[3] = want;
+}
 uint8_t* Engine::pinned_bump(size_t bytes) {
   Lane& l = *lanes_[cur_lane()];
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (l.pin3_used + need > l.pin_bytes[3]) {
     check(rhip_sync(l.ctx), "rhip_sync");            // copies out of the old block have finished: it can go
+    if (l.side) check(rhip_sync(l.side), "rhip_sync");
     if (l.pin[3]) rhip_host_free(l.ctx, l.pin[3]);
     l.pin[3] = nullptr;
     l.pin_bytes[3] = 0;
@@ -1080,7 +1135,7 @@ static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, 
     if (rng.unordered() && n >= 1024) {          // OS randomness has no order: blocks of items draw on their own sources
       const size_t blocks = (n + 255) / 256;
       parallel_for(blocks, [&](size_t b) {
-        OsRng local;
+        BatchRng local;
         for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) draw_item(local, i);
       });
     } else {
@@ -1097,14 +1152,11 @@ static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, 
   rhip_ac17_pk* dpk = eng.ac17_pk(pk.g, pk.h_a, pk.e_gh_ka);
   rhip_gt_table* egt = eng.gt_generator_table();
   auto fA = flatten_fr(A);
-  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, item_a_off.data(), n * 4), dro(&eng, row_off.data(), (n + 1) * 4), ds(&eng, n * 64), drho(&eng, n * 32),
-      dm(&eng, n * 384), dc0(&eng, n * 3 * 128), dc(&eng, total_rows * 3 * 64), dcp(&eng, n * 384);
+  DBuf dA(&eng, fA.data(), fA.size()), dio(&eng, item_a_off.data(), n * 4), ds(&eng, n * 64), drho(&eng, n * 32),
+      dm(&eng, n * 384), dc0(&eng, n * 3 * 128), dc(&eng, total_rows * 3 * 64 + 4), dcp(&eng, n * 384);
   rhip_ctx* cx = eng.ctx();
   eng.check(rhip_upload_async(cx, ds.ptr(), h_s, n * 64), "upload");
   eng.check(rhip_upload_async(cx, drho.ptr(), h_rho, n * 32), "upload");
-  eng.check(rhip_gt_table_pow(cx, egt, n, drho.as<rhip_fr>(), dm.as<rhip_gt>()), "rhip_gt_table_pow");
-  eng.check(rhip_ac17_cp_encrypt_batch(cx, dpk, n, dA.as<rhip_fr>(), dio.as<uint32_t>(), dro.as<uint32_t>(), total_rows, ds.as<rhip_fr>(),
-                                       dm.as<rhip_gt>(), dc0.as<rhip_g2>(), dc.as<rhip_g1>(), dcp.as<rhip_gt>()), "rhip_ac17_cp_encrypt_batch");
   // records and sealing on the device (records.h): per policy a template of the literal bytes with the elements dropped in
   std::vector<RecordLayout> layouts(pols.size());
   for (size_t p_ = 0; p_ < pols.size(); p_++) {
@@ -1128,11 +1180,45 @@ static bool encrypt_packed_core(Engine& eng, Rng& rng, const Ac17PublicKey& pk, 
     L.src(2, 0, 384);
     if (L.bytes() + 4 != pols[p_]->fixed_bytes) throw RabeError("ac17 encrypt_packed: record layout and size disagree");
   }
-  std::vector<uint64_t> src_off(3 * n);
-  for (size_t i = 0; i < n; i++) { src_off[i] = 384ull * i; src_off[n + i] = 192ull * row_off[i]; src_off[2 * n + i] = 384ull * i; }
-  emit_sealed_records(eng, layouts, n, item_policy, {dc0.ptr(), dc.ptr(), dcp.ptr()}, src_off, dm.ptr(), (const uint8_t*)nonces.data(), pt_blob, pt_off,
-                      out_off, out_buf);
-  tm.lap("device: group arithmetic, records, sealing; one copy out");
+  // The batch can go through the device in PARTS of >= 16 384 items, a part's records copied out (10.4 KB per item at 50 rows, 15 ms per
+  // 65 536 items) on the side stream while the next part's group arithmetic runs; randomness was drawn above for the whole batch, item
+  // after item, so the bytes do not depend on the cut (tests/test_gpu_packed.py).  OFF by default (RABE_AC17_ENC_PARTS=4 turns it on):
+  // measured no faster -- 37.2 against 36.9 ms at 65 536 items -- because the runtime's D2H copy of such a block is a blit kernel that
+  // covers the chip: k_table_pow_gt of the next part takes 5.3 instead of 1.3 ms under it.
+  static const size_t max_parts = [] { const char* e = getenv("RABE_AC17_ENC_PARTS"); const long v = e ? atol(e) : 1; return (size_t)(v > 0 ? v : 1); }();
+  const size_t parts = std::max<size_t>(1, std::min<size_t>(max_parts, n / 16384));
+  std::vector<PendingCopy> pending(parts);
+  if (parts > 1) eng.pinned_reserve((size_t)out_off[n] + parts * ((size_t)8 << 20) + 300 * n);          // staging of every part + their parameter packs: no growth inside the loop
+  // every part's row offsets (relative to the part's first row), uploaded once and asynchronously: nothing inside the loop may wait for
+  // the stream, or the host would queue part k + 1 only after part k has finished
+  std::vector<uint32_t> ro_all(n + parts);
+  std::vector<size_t> ro_at(parts);
+  for (size_t part = 0, at = 0; part < parts; part++) {
+    const size_t lo = n * part / parts, hi = n * (part + 1) / parts;
+    ro_at[part] = at;
+    for (size_t i = lo; i <= hi; i++) ro_all[at++] = row_off[i] - row_off[lo];
+  }
+  uint8_t* const h_ro = eng.pinned_bump(ro_all.size() * 4);
+  memcpy(h_ro, ro_all.data(), ro_all.size() * 4);
+  DBuf d_ro_all(&eng, ro_all.size() * 4);
+  eng.check(rhip_upload_async(cx, d_ro_all.ptr(), h_ro, ro_all.size() * 4), "upload");
+  for (size_t part = 0; part < parts; part++) {
+    const size_t lo = n * part / parts, hi = n * (part + 1) / parts, np = hi - lo;
+    const uint32_t* const ro = ro_all.data() + ro_at[part];
+    const uint32_t* const dro_p = d_ro_all.as<uint32_t>() + ro_at[part];
+    const size_t rows_p = ro[np];
+    rhip_g1* const dc_p = (rhip_g1*)(dc.as<uint8_t>() + 192ull * row_off[lo]);
+    eng.check(rhip_gt_table_pow(cx, egt, np, drho.as<rhip_fr>() + lo, dm.as<rhip_gt>() + lo), "rhip_gt_table_pow");
+    eng.check(rhip_ac17_cp_encrypt_batch(cx, dpk, np, dA.as<rhip_fr>(), dio.as<uint32_t>() + lo, dro_p, rows_p, ds.as<rhip_fr>() + 2 * lo,
+                                         dm.as<rhip_gt>() + lo, dc0.as<rhip_g2>() + 3 * lo, dc_p, dcp.as<rhip_gt>() + lo), "rhip_ac17_cp_encrypt_batch");
+    std::vector<uint64_t> src_off(3 * np);
+    for (size_t i = 0; i < np; i++) { src_off[i] = 384ull * i; src_off[np + i] = 192ull * ro[i]; src_off[2 * np + i] = 384ull * i; }
+    emit_sealed_records(eng, layouts, np, item_policy + lo, {dc0.as<uint8_t>() + 384ull * lo, (const void*)dc_p, dcp.as<uint8_t>() + 384ull * lo}, src_off,
+                        dm.as<uint8_t>() + 384ull * lo, (const uint8_t*)nonces.data() + 12 * lo, pt_blob, pt_off + lo, out_off + lo, out_buf,
+                        parts > 1 ? &pending[part] : nullptr);
+  }
+  for (auto& pc : pending) pc.wait(eng);
+  tm.lap("device: group arithmetic, records, sealing; copies out beside the next part");
   return true;
 }
 
@@ -1560,7 +1646,7 @@ bool kp_keygen_packed(Engine& eng, Rng& rng, const Ac17MasterKey& msk, const std
     if (rng.unordered() && n >= 1024) {
       const size_t blocks = (n + 255) / 256;
       parallel_for(blocks, [&](size_t b) {
-        OsRng local;
+        BatchRng local;
         for (size_t i = b * 256; i < n && i < (b + 1) * 256; i++) for (uint32_t d = draw_off[i]; d < draw_off[i + 1]; d++) draws[d] = local.next_fr();
       });
     } else {

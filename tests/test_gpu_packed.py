@@ -177,3 +177,41 @@ def test_kp_packed_equals_object_api_and_fails_items_alone(host):
     o[10] = np.uint64(int(o[9]) - 8)                                           # item 9: non-monotone offsets
     out, out_off, status = ac17.kp_decrypt_packed(host, sk, bytes(raw), o)
     assert list(status[:10]) == [0, -1, -1, 0, 0, 0, -1, 0, 0, -1]
+
+
+def test_a_batch_cut_into_parts_gives_the_bytes_of_its_halves():
+    """A packed encrypt can go through the device in parts whose copies out run beside the next part's arithmetic (schemes.cpp:
+    encrypt_packed_core, RABE_AC17_ENC_PARTS; off by default -- measured no faster).  The cut must not show in the bytes: 32 768 items in
+    one call on a tape = the first 16 384 and the last 16 384 in two calls (one part each) continuing the same tape; the batch decrypts.
+    Runs in a child process: the setting is read once per process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RABE_AC17_ENC_PARTS") != "4":
+        env = dict(os.environ, RABE_AC17_ENC_PARTS="4")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "cut_into_parts"], env=env, cwd=root,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert pr.returncode == 0, pr.stdout.decode()[-3000:]
+        return
+    host = hl.Host(0)
+    pk, msk = ac17.setup(host)
+    n = 32768
+    item_pol = np.arange(n, dtype=np.uint32) % 3
+    pts = [b"part %d" % i for i in range(n)]
+    pt_blob = b"".join(pts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+    tape = [(1000003 * (i + 3) + 17) % (1 << 200) for i in range(4 * n)]
+    host.set_tape(tape)
+    blob, ct_off = ac17.cp_encrypt_packed(host, pk, POLS, item_pol, pt_blob, off, hl.HUMAN_POLICY)
+    host.set_tape(tape)
+    h = n // 2
+    b1, o1 = ac17.cp_encrypt_packed(host, pk, POLS, item_pol[:h], pt_blob[:int(off[h])], off[:h + 1], hl.HUMAN_POLICY)
+    b2, o2 = ac17.cp_encrypt_packed(host, pk, POLS, item_pol[h:], pt_blob[int(off[h]):], off[h:] - off[h], hl.HUMAN_POLICY)
+    host.clear_tape()
+    assert blob[:int(ct_off[h])].tobytes() == b1.tobytes()
+    assert blob[int(ct_off[h]):].tobytes() == b2.tobytes()
+    sk = ac17.cp_keygen(host, msk, ["A", "B", "C", "D"])
+    out, out_off, status = ac17.cp_decrypt_packed(host, sk, blob, ct_off, trusted=True)
+    assert not status.any() and out.tobytes() == pt_blob
+    host.close()
