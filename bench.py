@@ -809,7 +809,7 @@ def threads_leg(host, pk, sk, pols):
     try:
         arr, npol = hl._strs(pols)
         prev = [0] * 6
-        for name, T, depth, seconds in (("blocking", 64, 1, 1.5), ("blocking_1024", 1024, 1, 1.5), ("in_flight", 64, 64, 2.0)):
+        for name, T, depth, seconds in (("blocking", 64, 1, 1.5), ("blocking_1024", 1024, 1, 1.5), ("in_flight", 64, 64, 2.0), ("in_flight_256", 64, 256, 2.5)):
             ops, bad = ctypes.c_uint64(), ctypes.c_uint64()
             t0 = time.perf_counter()
             hl._check(host.lib.rabe_bench_ac17_threads(host.h, pk.ptr, sk.ptr, arr, npol, hl.JSON_POLICY, ctypes.c_uint32(T), ctypes.c_uint32(depth),

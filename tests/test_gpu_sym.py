@@ -119,3 +119,26 @@ def test_seal_and_open_are_the_references_symmetric_pair(eng):
     back, ok = sym.open_(eng, gts, got, idx)
     assert ok == [0 if i in (5, 6) else 1 for i in range(n)]
     assert all(back[i] == pts[i] for i in range(n) if i not in (5, 6))
+
+
+def test_long_plaintexts_fold_hundreds_of_ghash_segments(eng):
+    """a 300 KB and a 1 MB plaintext beside short ones in one batch: CTR is one lane per block, GHASH one lane per 64-block segment folded
+    with H^64 per item -- the same bytes as the host layer's one-at-a-time function (AES-NI / PCLMULQDQ or the portable code)"""
+    rnd = random.Random(11)
+    lens = [300 * 1024 + 5, 7, 1 << 20, 0, 1024 * 64, 1024 * 64 + 1]
+    gts = [b"".join(rnd.randrange(1 << 250).to_bytes(32, "little") for _ in range(12)) for _ in lens]
+    nonces = [rnd.randbytes(12) for _ in lens]
+    pts = [rnd.randbytes(n) for n in lens]
+    got = sym.seal(eng, gts, nonces, pts)
+    for g, nonce, pt, s in zip(gts, nonces, pts, got):
+        assert s == hl.encrypt_symmetric(g, pt, nonce), len(pt)
+    back, ok = sym.open_(eng, gts, got)
+    assert ok == [1] * len(lens) and back == pts
+    bad = bytearray(got[2])
+    bad[12 + 700000] ^= 4                      # one bit deep inside the 1 MB ciphertext
+    back, ok = sym.open_(eng, gts, got[:2] + [bytes(bad)] + got[3:])
+    assert ok == [1, 1, 0, 1, 1, 1] and back[2] == bytes(len(pts[2]))
+
+
+def test_empty_batches_are_no_ops(eng):
+    assert sym.sha3_256(eng, []) == [] and sym.gt_kdf(eng, []) == [] and sym.seal(eng, [], [], []) == []
