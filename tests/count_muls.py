@@ -45,6 +45,14 @@ res["pairing via prepared lines (affine P) + final_exp incl. line preparation"] 
 res["paired miller (A prepared incl. preparation, B jacobian) + final_exp"] = count("hs_pairing_pair", P, Q, P, Q)
 res["paired miller, parked + merged lines (as k_ac17_dec_miller2) incl. preparation + final_exp"] = count("hs_pairing_pair_parked", P, Q, P, Q)
 res["g2_prepare_lines (88 line triples) incl. io"] = count("hs_g2_prepare", Q, out=192)
+# the same 88 line triples by AFFINE steps, the shared inversion itself not charged, Montgomery's trick (3 Fq2
+# products per element and step) charged -- to be compared with the projective preparation above
+res["g2 lines by affine steps + 3 Fq2 products per step for a simultaneous inversion (inversion itself not counted) incl. io"] = \
+    count("hs_g2_prepare_affine", Q, out=192)
+_a, _b = (ctypes.c_uint32 * 96)(), (ctypes.c_uint32 * 96)()
+HS.hs_pairing_affine_lines(b2c(P), b2c(Q), _a)
+HS.hs_pairing_prepared(b2c(P), b2c(Q), _b)
+assert bytes(_a) == bytes(_b), "affine lines give another pairing value"
 m = (ctypes.c_uint32 * 96)()
 HS.hs_miller(b2c(P), b2c(Q), m)
 res["final_exponentiation incl. 12 loads 12 stores"] = count("hs_final_exp", bytes(m))

@@ -125,6 +125,66 @@ void hs_g2_prepare(const uint32_t* q, uint32_t* out /* first line, 48 words */) 
   g2_prepare_lines(load_g2(q), lines);
   store_fp2(out, lines[0].cy); store_fp2(out + 16, lines[0].cx); store_fp2(out + 32, lines[0].c0);
 }
+// ---- what AFFINE walking steps would cost.  The 88 line triples of a G2 point by affine chord-and-tangent
+// steps; the step's inversion is NOT computed here but its input collected (a device version would invert the denominators of all of a
+// lane's walking pairs, and of the block, together): `hs_g2_prepare_affine` counts everything else -- the step formulas plus the three
+// Fq2 products per element that Montgomery's simultaneous inversion adds -- and returns lines whose pairing value must equal the
+// projective ones' (they differ by Fq2 factors, which the final exponentiation removes).
+static int affine_lines(const G2Aff& q, LineCoeffs* out, int trick_products_per_step) {
+  G2Aff t = q;
+  const G2Aff qn = aff_neg(q);
+  int n = 0;
+  auto dbl = [&]() {
+    const Fp2 x2 = fp2_sqr(t.x);
+    const Fp2 num = fp2_add(fp2_dbl(x2), x2);                    // 3 x^2
+    const Fp2 den = fp2_dbl(t.y);
+    const unsigned long long before = ::rb_mul_counter;
+    const Fp2 inv = fp2_inv(den);
+    ::rb_mul_counter = before;                                   // the inversion itself is shared: not charged to the step
+    for (int k = 0; k < trick_products_per_step; k++) (void)fp2_mul(num, den);          // Montgomery's trick: 3 products per element
+    const Fp2 lam = fp2_mul(num, inv);
+    const Fp2 x3 = fp2_sub(fp2_sqr(lam), fp2_dbl(t.x));
+    const Fp2 lx = fp2_mul(lam, t.x);
+    const Fp2 y3 = fp2_sub(fp2_sub(lx, fp2_mul(lam, x3)), t.y);
+    // line through T with slope lam, evaluated as cy * yP + cx * xP w + c0 w^3: cy = 1, cx = -lam, c0 = lam x - y
+    out[n++] = LineCoeffs{fp2_one(), fp2_neg(lam), fp2_sub(lx, t.y)};
+    t = G2Aff{x3, y3};
+  };
+  auto add = [&](const G2Aff& r) {
+    const Fp2 num = fp2_sub(r.y, t.y), den = fp2_sub(r.x, t.x);
+    const unsigned long long before = ::rb_mul_counter;
+    const Fp2 inv = fp2_inv(den);
+    ::rb_mul_counter = before;
+    for (int k = 0; k < trick_products_per_step; k++) (void)fp2_mul(num, den);
+    const Fp2 lam = fp2_mul(num, inv);
+    const Fp2 x3 = fp2_sub(fp2_sub(fp2_sqr(lam), t.x), r.x);
+    const Fp2 lx = fp2_mul(lam, t.x);
+    const Fp2 y3 = fp2_sub(fp2_sub(lx, fp2_mul(lam, x3)), t.y);
+    out[n++] = LineCoeffs{fp2_one(), fp2_neg(lam), fp2_sub(lx, t.y)};
+    t = G2Aff{x3, y3};
+  };
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    dbl();
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    if (pos | ngt) add(pos ? q : qn);
+  }
+  add(g2_frob1(q));
+  add(aff_neg(g2_frob2(q)));
+  return n;
+}
+void hs_g2_prepare_affine(const uint32_t* q, uint32_t* out /* first line, 48 words */) {
+  LineCoeffs lines[RB_MILLER_LINES];
+  affine_lines(load_g2(q), lines, 3);
+  store_fp2(out, lines[0].cy); store_fp2(out + 16, lines[0].cx); store_fp2(out + 32, lines[0].c0);
+}
+void hs_pairing_affine_lines(const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff P = load_g1(p);
+  G2Aff Q = load_g2(q);
+  LineCoeffs lines[RB_MILLER_LINES];
+  affine_lines(Q, lines, 0);
+  store_gt(out, final_exponentiation(miller_loop_prepared(miller_p_from_aff(P), aff_is_inf(P), aff_is_inf(Q), HostLineLoad{lines})));
+}
 // FE( miller_pair(pa, prepared qa; pb, qb) ) = e(pa, qa) * e(pb, qb)
 void hs_pairing_pair(const uint32_t* pa, const uint32_t* qa, const uint32_t* pb, const uint32_t* qb, uint32_t* out) {
   G1Aff PA = load_g1(pa), PB = load_g1(pb);
