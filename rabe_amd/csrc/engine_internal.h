@@ -47,9 +47,9 @@ struct rhip_ctx {
   void* fe_ws = nullptr;
   size_t fe_ws_bytes = 0;
   // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
-  enum { N_WORK = 9 };
-  void* work[N_WORK] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t work_bytes[N_WORK] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  enum { N_WORK = 10 };
+  void* work[N_WORK] = {};
+  size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
   int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
   void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)

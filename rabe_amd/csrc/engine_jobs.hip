@@ -191,10 +191,34 @@ struct DevMultiAcc : LdsHomeT<4> {
 // items run without divergence and read the same prepared lines.  An item of p pairs uses ceil(p / C) of its L chunks and splits its pairs
 // EVENLY over them (a ragged batch: 29 pairs at C = 13 are 10 + 10 + 9, not 13 + 13 + 3); the chunks it does not use write the unit and
 // leave at once (a Miller loop without pairs would still square its accumulator 65 times).  Output: mill[item * L + c].
+//
+// A RAGGED batch (plan != NULL) runs from a work list instead: the chunks that exist, largest first (k_plan_*, below), lane t = entry t of
+// the list.  Every block of the launch then has work, the blocks of one size are spread over the XCDs by the round-robin of consecutive
+// blocks, and the longest ones start first; C was chosen ON THE DEVICE from the batch's histogram of pair counts.  Output: the compact
+// mill[chunk_off[item] + c].
+struct MillerPlan {
+  uint32_t C, W, L, pad;
+  uint32_t base[66];            // base[s]: where the entries of s pairs start in the list (sizes descending)
+  uint32_t cursor[66];
+};
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                   const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
-                                                                  GtM* mill) {
+                                                                  GtM* mill, const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (plan) {
+    if (t >= plan->W) return;
+    const uint32_t Cp = plan->C;
+    const uint2 w = work[t];
+    const uint64_t lo = pair_off[w.x], hi = pair_off[w.x + 1];
+    const uint32_t p_item = (uint32_t)(hi - lo), nch = (p_item + Cp - 1) / Cp;
+    const uint32_t base = p_item / nch, rem = p_item % nch, cc = w.y;
+    const uint64_t first = lo + (uint64_t)cc * base + (cc < rem ? cc : rem);
+    const int cnt = (int)(base + (cc < rem ? 1u : 0u));
+    const DevMultiAcc acc{{}, P + first, Q + first, qref + first, lines, cnt, ws + (t >> 6) * ((size_t)Cp * 12 * 64) + (t & 63), ws_stride};
+    const Fp12 f = miller_loop_multi(acc);
+    st_gt_m(mill + chunk_off[w.x] + cc, f);
+    return;
+  }
   if (t >= n_items * L) return;
   // Chunk row c is rotated by c blocks: consecutive blocks go to consecutive XCDs (8 of them, 32 CUs each), and in a batch grouped by shape
   // block g of EVERY row holds the same policy -- unrotated, the rows of a many-leaf policy pile up on one XCD (measured: a ragged BSW
@@ -245,9 +269,166 @@ static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs,
   *L = (uint32_t)l;
   *C = (uint32_t)c;
 }
+// ---- the plan of a ragged batch, made on the device (the pair counts live there; nothing comes back to the host)
+// hist[p] = number of items with p pairs
+__global__ void k_plan_hist(size_t n_items, const uint32_t* pair_off, uint32_t max_pairs, uint32_t* hist) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  uint32_t p = pair_off[i + 1] - pair_off[i];
+  if (p > max_pairs) p = max_pairs;                 // cannot happen for a caller that states max_pairs truthfully; keeps the table in bounds
+  // a batch grouped by shape: whole waves agree -- one atomic per distinct value of the wave
+  uint64_t todo = __ballot(1);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const uint32_t v = (uint32_t)__shfl((int)p, lead);
+    const uint64_t same = __ballot(p == v) & todo;
+    if ((int)(threadIdx.x & 63) == lead) atomicAdd(hist + v, (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+// One block of 1024: candidate C = 1 + (tid & 63), sixteen threads per candidate share the histogram.  For each candidate the list's
+// size distribution cnt[s] (an item of p pairs has ceil(p / C) chunks, p mod nch of them one pair longer), then the launch priced as
+// rounds of n_cu blocks over the list sorted by size -- a round costs what its FIRST (largest) block costs: the shared squarings (2340
+// Fp multiplications) + 5500 per pair (+ 600 for an unmerged odd line) -- plus the product of an item's chunk values in k_final_exp.
+__global__ void __launch_bounds__(1024) k_plan_choose(const uint32_t* hist, uint32_t max_pairs, uint32_t n_items, uint32_t c_lo, uint32_t c_hi, uint32_t n_cu,
+                                                      MillerPlan* plan) {
+  __shared__ uint32_t cnt[64][66];
+  __shared__ float cost[64];
+  const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
+  const uint32_t C = (uint32_t)j + 1;
+  for (int k = tid; k < 64 * 66; k += 1024) (&cnt[0][0])[k] = 0;
+  __syncthreads();
+  const bool live = C >= c_lo && C <= c_hi;
+  if (live)
+    for (uint32_t p = 1 + (uint32_t)part; p <= max_pairs; p += 16) {
+      const uint32_t h = hist[p];
+      if (!h) continue;
+      const uint32_t nch = (p + C - 1) / C, base = p / nch, rem = p % nch;
+      if (rem) atomicAdd(&cnt[j][base + 1], h * rem);
+      atomicAdd(&cnt[j][base], h * (nch - rem));
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float c = 3.0e38f;
+    if (live) {
+      const uint64_t R = (uint64_t)n_cu * RB_MILLER_BLOCK;
+      uint64_t pos = 0, next = 0;
+      c = 0;
+      for (int sz = 64; sz >= 1; sz--) {
+        const uint32_t n = cnt[j][sz];
+        if (!n) continue;
+        while (next < pos + n) { c += 2340.0f + 5500.0f * (float)sz + ((sz & 1) ? 600.0f : 0.0f); next += R; }
+        pos += n;
+      }
+      const uint32_t fe_rounds = (n_items + n_cu * 256u - 1) / (n_cu * 256u)   /* k_final_exp: blocks of 256 */;
+      c += 60.0f * (float)((max_pairs + C - 1) / C) * (float)fe_rounds;
+      cnt[j][65] = (uint32_t)pos;
+    }
+    cost[j] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = (int)c_lo - 1;
+    for (int k = 0; k < 64; k++)
+      if (cost[k] < cost[best] || (cost[k] == cost[best] && k > best)) best = k;          // ties: the larger chunk (fewer lanes)
+    plan->C = (uint32_t)best + 1;
+    plan->W = cnt[best][65];
+    plan->L = (max_pairs + (uint32_t)best) / ((uint32_t)best + 1);
+    uint32_t at = 0;
+    for (int sz = 65; sz >= 0; sz--) {
+      plan->base[sz] = at;
+      plan->cursor[sz] = at;
+      if (sz >= 1 && sz <= 64) at += cnt[best][sz];
+    }
+  }
+}
+// chunk_off[i] = number of chunks of the items before i (one block; a thread owns a run of items)
+__global__ void __launch_bounds__(1024) k_plan_scan(size_t n_items, const uint32_t* pair_off, const MillerPlan* plan, uint32_t* chunk_off) {
+  __shared__ uint32_t part[1024];
+  const uint32_t C = plan->C;
+  const size_t per = (n_items + 1023) / 1024, lo = (size_t)threadIdx.x * per, hi = lo + per < n_items ? lo + per : n_items;
+  uint32_t sum = 0;
+  for (size_t i = lo; i < hi; i++) sum += (pair_off[i + 1] - pair_off[i] + C - 1) / C;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t at = part[threadIdx.x] - sum;
+  for (size_t i = lo; i < hi; i++) {
+    chunk_off[i] = at;
+    at += (pair_off[i + 1] - pair_off[i] + C - 1) / C;
+  }
+  if (threadIdx.x == 1023) chunk_off[n_items] = part[1023];
+}
+// The list: candidate t = chunk row c x item (64 neighbouring items at the same chunk position stay neighbours: they replay the same
+// prepared lines), appended to the run of its size; one atomic per distinct size of a wave.  Grid-stride: the number of rows is the plan's.
+__global__ void __launch_bounds__(256) k_plan_fill(size_t n_items, const uint32_t* pair_off, MillerPlan* plan, uint2* work) {
+  const uint32_t C = plan->C, L = plan->L;
+  const size_t n_pad = (n_items + 63) / 64 * 64, total = n_pad * L, step = (size_t)gridDim.x * blockDim.x;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += step) {
+    const size_t c = t / n_pad, item = t % n_pad;
+    uint32_t sz = 0;
+    if (item < n_items) {
+      const uint32_t p = pair_off[item + 1] - pair_off[item], nch = (p + C - 1) / C;
+      if (c < nch) sz = p / nch + (c < p % nch ? 1u : 0u);
+    }
+    uint64_t todo = __ballot(sz != 0);
+    const int lane = (int)(threadIdx.x & 63);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const uint32_t v = (uint32_t)__shfl((int)sz, lead);
+      const uint64_t same = __ballot(sz == v) & todo;
+      uint32_t at = 0;
+      if (lane == lead) at = atomicAdd(&plan->cursor[v], (uint32_t)__popcll(same));
+      at = (uint32_t)__shfl((int)at, lead);
+      if (sz == v && sz) work[at + (uint32_t)__popcll(same & ((1ull << lane) - 1))] = make_uint2((uint32_t)item, (uint32_t)c);
+      todo &= ~same;
+    }
+  }
+}
 // Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
 static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
                               const LineM* lines, const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
+  if (pair_off && total_pairs && total_pairs < n_items * max_pairs && !getenv("RABE_NO_MILLER_PLAN")) {
+    // ragged: plan on the device.  Bounds of what the plan may choose: no fewer pairs per chunk than four rounds' worth of lanes need
+    // (more lanes only add shared squarings), no more than 64; the buffers are sized for the worst of the range.
+    const size_t R = (size_t)ctx->n_cu * RB_MILLER_BLOCK;
+    size_t c_lo = total_pairs / (4 * R);
+    if (c_lo < 1) c_lo = 1;
+    size_t c_hi = max_pairs < 64 ? max_pairs : 64;
+    if (c_lo > c_hi) c_lo = c_hi;
+    const size_t w_max = total_pairs / c_lo + n_items + 64;
+    const size_t hist_words = (max_pairs + 2 + 3) / 4 * 4;
+    const size_t plan_words = (sizeof(MillerPlan) / 4 + 3) / 4 * 4;
+    const size_t off_words = (n_items + 1 + 3) / 4 * 4;
+    void* pb = nullptr;
+    int32_t rc = rhip_ensure_work(ctx, 9, (plan_words + hist_words + off_words) * 4 + w_max * sizeof(uint2), &pb);
+    if (rc) return rc;
+    MillerPlan* plan = (MillerPlan*)pb;
+    uint32_t* hist = (uint32_t*)pb + plan_words;
+    uint32_t* chunk_off = hist + hist_words;
+    uint2* work = (uint2*)(chunk_off + off_words);
+    void* ws = nullptr;
+    rc = rhip_ensure_work(ctx, 3, (total_pairs + n_items * (c_hi - 1) + 64 * c_hi + 64) * 12 * sizeof(uint4), &ws);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, w_max * sizeof(GtM));
+    if (rc) return rc;
+    GtM* mill = (GtM*)ctx->scratch;
+    HIP_TRY(ctx, hipMemsetAsync(hist, 0, hist_words * 4, ctx->stream));
+    KLAUNCH(ctx, "k_plan_hist", k_plan_hist, dim3(blocks_for(n_items, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t)max_pairs, hist);
+    KLAUNCH(ctx, "k_plan_choose", k_plan_choose, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)hist, (uint32_t)max_pairs, (uint32_t)n_items, (uint32_t)c_lo,
+            (uint32_t)c_hi, (uint32_t)ctx->n_cu, plan);
+    KLAUNCH(ctx, "k_plan_scan", k_plan_scan, dim3(1), dim3(1024), 0, ctx->stream, n_items, pair_off, (const MillerPlan*)plan, chunk_off);
+    KLAUNCH(ctx, "k_plan_fill", k_plan_fill, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, n_items, pair_off, plan, work);
+    KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(w_max, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs,
+            (const G1M*)pl.P, (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)plan, (const uint2*)work,
+            (const uint32_t*)chunk_off);
+    return launch_final_exp(ctx, n_items, (const uint32_t*)chunk_off, 1u, (const GtM*)mill, mul_in, out);
+  }
   uint32_t L, C;
   choose_chunks(ctx, n_items, max_pairs, pair_off ? total_pairs : 0, &L, &C);
   const size_t lanes = n_items * L;
@@ -259,7 +440,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
-          (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill);
+          (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)nullptr, (const uint2*)nullptr, (const uint32_t*)nullptr);
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
 }
 
@@ -1636,7 +1817,7 @@ extern "C" int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_p
     KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
             (const G1JM*)w_part, (const uint32_t*)cpo, pl.P, pl.qref);
   }
-  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), 0, pl, (const LineM*)nullptr, lead, out);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), total, pl, (const LineM*)nullptr, lead, out);
 }
 
 

@@ -197,6 +197,21 @@ class Engine:
         raw = self.download(out, n_items * GT)
         return [raw[i * GT:(i + 1) * GT] for i in range(n_items)]
 
+    def pairing_jobs(self, offsets, p, q, scal=None, lead=None):
+        """rhip_pairing_jobs without a summed pair: out[i] = lead[i] * FE(prod_j ML(scal[j] * p[j], q[j])) over item i's pairs"""
+        n_items = len(offsets) - 1
+        off = self.upload_u32(offsets)
+        bp, bq = self.upload(b"".join(p) or b"\0"), self.upload(b"".join(q) or b"\0")
+        bs = self.upload(b"".join(scal)) if scal else None
+        bl = self.upload(b"".join(lead)) if lead else None
+        out = self.alloc(n_items * GT)
+        mx = max(offsets[i + 1] - offsets[i] for i in range(n_items))
+        self._check(self.lib.rhip_pairing_jobs(self.ctx, ctypes.c_size_t(n_items), ctypes.c_size_t(mx), ctypes.c_size_t(len(p)), off.ptr, bp.ptr,
+                                               bs.ptr if bs else None, bq.ptr, ctypes.c_size_t(0), ctypes.c_size_t(0), None, None, None, None,
+                                               bl.ptr if bl else None, out.ptr))
+        raw = self.download(out, n_items * GT)
+        return [raw[i * GT:(i + 1) * GT] for i in range(n_items)]
+
     # ------------------------------------------------------------------ pinned host buffers / stream-ordered copies
     def host_alloc(self, nbytes):
         p = ctypes.c_void_p()
