@@ -260,7 +260,7 @@ def pmc_traffic(kernel, config):
 class BswBench:
     """config 3: bsw::encrypt + bsw::decrypt, n-leaf access tree, one public key, one secret key with all attributes."""
     metric = "ABE ops/sec (BSW CP-ABE encrypt+decrypt)"
-    default_group = 2
+    default_group = 8                           # steps per launch set: 72.1 / 77.4 / 80.4 k ops/s at 2 / 4 / 8 (the final exponentiation's fixed 6.8 ms is shared by more items)
     survey_fpmul_per_item = 2.3e6               # SURVEY.md 8d, config 3 restructured work
     launches_per_submit = {"k_table_mul_g1": 2}
 
@@ -485,7 +485,7 @@ def rand_fr_bytes(irnd, n):
 class LswBench:
     """config 4: lsw::keygen + lsw::decrypt of a pre-made ciphertext, n positive leaves, a fresh key per item."""
     metric = "ABE ops/sec (LSW KP-ABE keygen+decrypt)"
-    default_group = 2
+    default_group = 8                           # 48.0 / 52.9 / 56.6 k ops/s at 2 / 4 / 8 steps per launch set
     survey_fpmul_per_item = 3.0e6               # SURVEY.md 8d, config 4 restructured work
     launches_per_submit = {}
 

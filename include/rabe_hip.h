@@ -126,6 +126,18 @@ int32_t rhip_g2_in_subgroup(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint3
 /* the same verdicts by the definition r * Q = O (rhip_g2_in_subgroup uses the BN-specific test [u+1]Q + psi([u]Q) + psi^2([u]Q) =
  * psi^3([2u]Q): one multiplication by the 63-bit curve parameter instead of the 254-bit order) -- kept for cross-checks */
 int32_t rhip_g2_in_subgroup_by_order(rhip_ctx* ctx, size_t n, const rhip_g2* dev_p, uint32_t* dev_ok);
+/* rhip_g2_in_subgroup of the listed elements only: dev_ok[k] = the verdict of dev_p[dev_idx[k]], k < n_idx */
+int32_t rhip_g2_in_subgroup_at(rhip_ctx* ctx, size_t n_idx, const uint32_t* dev_idx, const rhip_g2* dev_p, uint32_t* dev_ok);
+/* G2 membership as a by-product of a decrypt's Miller loops.  One-shot: the NEXT pair-list decrypt on this context (the shared-
+ * accumulator paths of rhip_{ac17_cp,bsw,lsw,aw11}_decrypt_batch*, rhip_pairing_jobs) examines every G2 argument it WALKS -- the
+ * untrusted side of a decrypt: c_0 (ac17), Cy.g2 (bsw), D2 (lsw), C2 (aw11) of the selected rows -- after its Miller loops:
+ * the running point then holds [6u+2]Q + psi(Q) - psi^2(Q), which is -psi^3(Q) exactly for the points of the twist that lie
+ * in G2 (engine_jobs.hip: k_walk_verdicts has the argument).  dev_fail[i] becomes 1 if an argument of item i fails,
+ * dev_count[i] grows by the number of arguments examined (a pair with an argument at infinity is skipped and not counted; a
+ * launch that takes another path counts nothing): the caller zeroes both arrays, compares the counts with what it expected to
+ * be examined and runs rhip_g2_in_subgroup(_at) on whatever was not.  Curve equation and coordinate range are not part of this
+ * verdict (rhip_g2_on_curve).  NULL, NULL withdraws the request. */
+int32_t rhip_ctx_collect_walk_verdicts(rhip_ctx* ctx, uint32_t* dev_fail, uint32_t* dev_count);
 int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);
 /* the same verdicts with the order test by the definition f^r = 1 (rhip_gt_is_member uses f^p = f^(6u^2) after the cyclotomic test) */
 int32_t rhip_gt_is_member_by_order(rhip_ctx* ctx, size_t n, const rhip_gt* dev_a, uint32_t* dev_ok);

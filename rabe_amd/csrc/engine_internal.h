@@ -53,6 +53,8 @@ struct rhip_ctx {
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
   int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
   void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)
+  uint32_t* walk_fail = nullptr;    // one-shot (rhip_ctx_collect_walk_verdicts): per-item verdict / count arrays of the next pair-list launch
+  uint32_t* walk_count = nullptr;
   rhip_ctx* fe_waiter = nullptr;   // one-shot (rhip_ctx_release_before_final_exp): released after this context's next Miller launch
   bool timing = false;
   struct Pending { std::string name; hipEvent_t e0, e1; };

@@ -269,6 +269,69 @@ static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs,
   *L = (uint32_t)l;
   *C = (uint32_t)c;
 }
+// ---- membership of the WALKING G2 arguments as a by-product of the Miller loops (rhip_ctx_collect_walk_verdicts).
+// When k_miller_multi is done, the workspace slot of a walking pair holds R = [6u+2]Q + psi(Q) - psi^2(Q): the loop's last two
+// additions are the Frobenius steps.  On G2 the twist's Frobenius psi acts as multiplication by p, and 6u+2 + p - p^2 + p^3 = 0 mod r
+// (the relation the optimal ate pairing rests on), so a member satisfies  R = -psi^3(Q).  Conversely, for Q on the twist
+// E'(Fp2) (order r * h2) the endomorphism f(psi) = (6u+2) + psi - psi^2 + psi^3 and the characteristic equation
+// chi(psi) = psi^2 - t psi + p = 0 give Res(f, chi) * Q = O, and Res(f, chi) = r * m with gcd(m, r * h2) = 1
+// (tests/test_walk_relation.py checks it with exact integers, and the same computation
+// reproduces the soundness of the El Housni-Guillevic test k_g2_in_subgroup uses): the order of Q divides r, Q is in G2.
+// Degenerate steps cannot forge the relation: the doubling and addition formulas (bn254/pairing.h) give Z3 a factor Z, the chord of
+// T = +-Q gives Z3 = 0, so a walk that leaves the formulas' domain ends with Z = 0 and is rejected.  The curve equation and the
+// coordinate range of Q are NOT established here (rhip_g2_on_curve does both); a pair that was skipped (an argument at infinity)
+// is not counted -- the caller compares the count with the number of elements it expected to see examined.
+// Same lane -> (item, chunk) map as k_miller_multi.
+__global__ void __launch_bounds__(256) k_walk_verdicts(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G2M* Q,
+                                                       const uint32_t* qref, const uint4* ws, const MillerPlan* plan, const uint2* work, uint32_t* fail,
+                                                       uint32_t* count) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t item;
+  uint64_t first;
+  uint32_t cnt, Cw;
+  if (plan) {
+    if (t >= plan->W) return;
+    Cw = plan->C;
+    const uint2 w = work[t];
+    item = w.x;
+    const uint64_t lo = pair_off[item], hi = pair_off[item + 1];
+    const uint32_t p_item = (uint32_t)(hi - lo), nch = (p_item + Cw - 1) / Cw, base = p_item / nch, rem = p_item % nch;
+    first = lo + (uint64_t)w.y * base + (w.y < rem ? w.y : rem);
+    cnt = base + (w.y < rem ? 1u : 0u);
+  } else {
+    if (t >= n_items * L) return;
+    Cw = C;
+    const size_t c = t / n_items;
+    item = (t % n_items + c * RB_MILLER_BLOCK) % n_items;
+    const uint64_t lo = pair_off ? pair_off[item] : (uint64_t)item * uniform, hi = pair_off ? pair_off[item + 1] : (uint64_t)(item + 1) * uniform;
+    const uint32_t p_item = (uint32_t)(hi - lo), nch = (p_item + C - 1) / C;
+    if (c >= nch) return;
+    const uint32_t base = p_item / nch, rem = p_item % nch, cc = (uint32_t)c;
+    first = lo + (uint64_t)cc * base + (cc < rem ? cc : rem);
+    cnt = base + (cc < rem ? 1u : 0u);
+  }
+  const uint4* wl = ws + (t >> 6) * ((size_t)Cw * 12 * 64) + (t & 63);
+  uint32_t seen = 0;
+  bool bad = false;
+  for (uint32_t j = 0; j < cnt; j++) {
+    if (qref[first + j] != RHIP_Q_WALK) continue;
+    const uint4* p = wl + (size_t)(12 * j) * 64;
+    Fp e[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const uint4 a = p[(size_t)(2 * k) * 64], b = p[(size_t)(2 * k + 1) * 64];
+      e[k].v[0] = a.x; e[k].v[1] = a.y; e[k].v[2] = a.z; e[k].v[3] = a.w;
+      e[k].v[4] = b.x; e[k].v[5] = b.y; e[k].v[6] = b.z; e[k].v[7] = b.w;
+    }
+    const Fp2 rx{e[0], e[1]}, ry{e[2], e[3]}, rz{e[4], e[5]};
+    const G2Aff s = aff_neg(g2_frob1(g2_frob2(ld_g2_q(Q + first + j))));
+    const bool ok = !fp2_is_zero(rz) && fp2_eq(rx, fp2_mul(s.x, rz)) && fp2_eq(ry, fp2_mul(s.y, rz));
+    seen++;
+    bad |= !ok;
+  }
+  if (seen) atomicAdd(count + item, seen);
+  if (bad) fail[item] = 1u;
+}
 // ---- the plan of a ragged batch, made on the device (the pair counts live there; nothing comes back to the host)
 // hist[p] = number of items with p pairs
 __global__ void k_plan_hist(size_t n_items, const uint32_t* pair_off, uint32_t max_pairs, uint32_t* hist) {
@@ -427,6 +490,11 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(w_max, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs,
             (const G1M*)pl.P, (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)plan, (const uint2*)work,
             (const uint32_t*)chunk_off);
+    if (ctx->walk_fail) {
+      KLAUNCH(ctx, "k_walk_verdicts", k_walk_verdicts, dim3(blocks_for(w_max, 256)), dim3(256), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, (const G2M*)pl.Q,
+              (const uint32_t*)pl.qref, (const uint4*)ws, (const MillerPlan*)plan, (const uint2*)work, ctx->walk_fail, ctx->walk_count);
+      ctx->walk_fail = ctx->walk_count = nullptr;
+    }
     return launch_final_exp(ctx, n_items, (const uint32_t*)chunk_off, 1u, (const GtM*)mill, mul_in, out);
   }
   uint32_t L, C;
@@ -441,6 +509,11 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   GtM* mill = (GtM*)ctx->scratch;
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
           (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)nullptr, (const uint2*)nullptr, (const uint32_t*)nullptr);
+  if (ctx->walk_fail) {
+    KLAUNCH(ctx, "k_walk_verdicts", k_walk_verdicts, dim3(blocks_for(lanes, 256)), dim3(256), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G2M*)pl.Q,
+            (const uint32_t*)pl.qref, (const uint4*)ws, (const MillerPlan*)nullptr, (const uint2*)nullptr, ctx->walk_fail, ctx->walk_count);
+    ctx->walk_fail = ctx->walk_count = nullptr;
+  }
   return launch_final_exp(ctx, n_items, (const uint32_t*)nullptr, L, (const GtM*)mill, mul_in, out);
 }
 
@@ -1644,11 +1717,12 @@ __device__ __noinline__ bool g2_jac_eq(const G2Jac& a, const G2Jac& b) {
 //   Q in G2  <=>  [u+1]Q + psi([u]Q) + psi^2([u]Q) = psi^3([2u]Q)
 // -- ONE multiplication by the 63-bit curve parameter u instead of the 254-bit order (7 k -> ~2.2 k field multiplications);
 // mode 1: the definition, r * Q = O.  tests/test_gpu_validation.py runs both on members and on cofactor-torsion points.
-__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_in_subgroup(size_t n, const rhip_g2* p, uint32_t* ok, int mode) {
+__global__ void __launch_bounds__(128, RB_MIN_WAVES) k_g2_in_subgroup(size_t n, const rhip_g2* p_all, uint32_t* ok, int mode, const uint32_t* idx) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const G2Aff P = load_g2(p[i].l);
-  bool good = wire_words_canonical(p[i].l, 4) && aff_on_curve(P);
+  const rhip_g2* pe = p_all + (idx ? (size_t)idx[i] : i);          // idx: the verdict of element idx[i] goes to ok[i]
+  const G2Aff P = load_g2(pe->l);
+  bool good = wire_words_canonical(pe->l, 4) && aff_on_curve(P);
   if (good && !aff_is_inf(P)) {                       // infinity is a member
     if (mode == 1) {
       uint32_t r[8];
@@ -1694,18 +1768,32 @@ __global__ void __launch_bounds__(64, RB_MIN_WAVES) k_gt_is_member(size_t n, con
   }
   ok[i] = good ? 1u : 0u;
 }
+extern "C" int32_t rhip_ctx_collect_walk_verdicts(rhip_ctx* ctx, uint32_t* dev_fail, uint32_t* dev_count) {
+  NEED(ctx);
+  if ((dev_fail == nullptr) != (dev_count == nullptr)) return RHIP_ERR_ARG;
+  ctx->walk_fail = dev_fail;
+  ctx->walk_count = dev_count;
+  return RHIP_OK;
+}
+extern "C" int32_t rhip_g2_in_subgroup_at(rhip_ctx* ctx, size_t n_idx, const uint32_t* idx, const rhip_g2* p, uint32_t* ok) {
+  NEED(ctx);
+  if (!n_idx) return RHIP_OK;
+  if (!idx) return RHIP_ERR_ARG;
+  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n_idx, 128)), dim3(128), 0, ctx->stream, n_idx, p, ok, 0, idx);
+  return RHIP_OK;
+}
 extern "C" int32_t rhip_g2_in_subgroup(rhip_ctx* ctx, size_t n, const rhip_g2* p, uint32_t* ok) {
   NEED(ctx);
   if (!n) return RHIP_OK;
   static const int mode = getenv("RABE_G2_CHECK_BY_ORDER") ? 1 : 0;          // the defining test r * Q = O, for A/B runs
-  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok, mode);
+  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok, mode, (const uint32_t*)nullptr);
   return RHIP_OK;
 }
 // the same verdicts by the definition (r * Q = O): the reference the fast test is checked against
 extern "C" int32_t rhip_g2_in_subgroup_by_order(rhip_ctx* ctx, size_t n, const rhip_g2* p, uint32_t* ok) {
   NEED(ctx);
   if (!n) return RHIP_OK;
-  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok, 1);
+  KLAUNCH(ctx, "k_g2_in_subgroup", k_g2_in_subgroup, dim3(blocks_for(n, 128)), dim3(128), 0, ctx->stream, n, p, ok, 1, (const uint32_t*)nullptr);
   return RHIP_OK;
 }
 extern "C" int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok) {

@@ -245,9 +245,14 @@ class Engine {
 class MemberChecks {
  public:
   explicit MemberChecks(Engine& eng);
-  // which: 1 G1 on curve, 2 G2 in the r-torsion, 3 Gt in the order-r subgroup.  With `dev_seg_off` (n_seg + 1 device offsets, in rows of
-  // `scale` elements) the verdicts are folded per segment on the device: ok(k) then has n_seg entries instead of `count`.
+  // which: 1 G1 on curve, 2 G2 in the r-torsion, 3 Gt in the order-r subgroup, 4 G2 on the twist with canonical coordinates (no subgroup
+  // test).  With `dev_seg_off` (n_seg + 1 device offsets, in rows of `scale` elements) the verdicts are folded per segment on the
+  // device: ok(k) then has n_seg entries instead of `count`.
   void add(int which, const void* dev, size_t count, const uint32_t* dev_seg_off = nullptr, size_t n_seg = 0, uint32_t scale = 1);
+  // the G2 subgroup test of the listed elements only: ok(k)[t] = verdict of element idx[t]
+  void add_g2_at(const void* dev, const std::vector<uint32_t>& idx);
+  rhip_ctx* ctx() const { return cx_; }
+  size_t add_count() const { return flags_.size(); }          // the index the next add's verdicts will have
   void collect();                                               // waits for the checks (not for the main context)
   const std::vector<uint32_t>& ok(size_t k) const { return flags_[k]; }      // verdicts of the k-th add
  private:
@@ -255,6 +260,39 @@ class MemberChecks {
   rhip_ctx* cx_;
   std::vector<DBuf> dev_, scratch_;
   std::vector<std::vector<uint32_t>> flags_;
+};
+
+bool walk_checks();
+// G2 elements of untrusted records whose subgroup membership the decrypt's OWN Miller loops establish (include/rabe_hip.h:
+// rhip_ctx_collect_walk_verdicts): the decrypt walks the ciphertext's G2 elements anyway, and the point its last step leaves behind
+// says whether the argument was a member -- 2.2 k field multiplications per element saved against the stand-alone test.  Everything a
+// decoder has to establish stays established: curve equation + coordinate range of EVERY element (a cheap pass on the side context),
+// the stand-alone subgroup test for the elements the decrypt does not walk (leaves the policy did not select), and for the elements of any
+// item whose walk examined fewer arguments than expected (a skipped pair, a launch path without verdicts).
+// Use: construct after MemberChecks (same place), `arm()` immediately before the scheme's decrypt call on the main context,
+// `finish()` after that call was enqueued and MemberChecks::collect() ran: ok[j] per segment (item).
+class WalkedG2 {
+ public:
+  // `count` elements in n_seg segments: rows [seg_off[j], seg_off[j + 1]) x scale elements (dev_seg_off: the same offsets on the device).
+  // walked_off == nullptr: the decrypt walks every element; else element indices walked_idx[walked_off[j] .. walked_off[j + 1]) of item j.
+  WalkedG2(Engine& eng, MemberChecks& mc, const void* dev_g2, size_t count, const uint32_t* dev_seg_off, const std::vector<uint32_t>& seg_off,
+           uint32_t scale, const std::vector<uint32_t>* walked_idx = nullptr, const std::vector<uint32_t>* walked_off = nullptr,
+           uint32_t extra_walks = 0 /* walking arguments per item that are not elements of this array (aw11: the sum of the C3 terms) */);
+  void arm();
+  void finish(std::vector<uint8_t>* ok);
+ private:
+  Engine& eng_;
+  MemberChecks& mc_;
+  const void* dev_;
+  size_t count_, n_seg_;
+  std::vector<uint32_t> seg_off_;
+  uint32_t scale_, extra_ = 0;
+  const std::vector<uint32_t>* widx_;
+  const std::vector<uint32_t>* woff_;
+  std::vector<uint32_t> rest_item_;          // item of every element tested stand-alone on the side context
+  size_t k_curve_ = 0, k_rest_ = 0;
+  bool has_rest_ = false;
+  DBuf d_verdicts_;                          // fail[n_seg] | count[n_seg]
 };
 
 template <class T, size_t N>

@@ -820,12 +820,6 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
         d_sel_z = up_bytes(eng, fz), d_skd(&eng, sk.d.data(), 128), d_kg1 = up_bytes(eng, kg1), d_kg2 = up_bytes(eng, kg2),
         d_sk_attr_off = up32(eng, sk_attr_off);
     gather.run({d_c.ptr(), d_cp.ptr(), d_g1.ptr(), d_g2.ptr()}, dst_off);
-    std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
-    if (!trusted) {
-      mc.reset(new MemberChecks(eng));
-      mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items); mc->add(2, d_g2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
-      mc->add(3, d_cp.ptr(), m_items);
-    }
     // the key's prepared lines (d and every d_j.g2: 17 KB per point) are a function of the key alone: kept across calls
     rhip_bsw_sk_lines* lines = nullptr;
     if (!sk.d_j.empty()) {
@@ -833,7 +827,33 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       for (const auto& a : sk.d_j) key.append((const char*)a.g2.data(), 128);
       lines = (rhip_bsw_sk_lines*)eng.aux("bsw_sk_lines", key, make_sk_lines, &key, destroy_sk_lines, 4);
     }
+    std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
+    std::unique_ptr<WalkedG2> walked;
+    std::vector<uint32_t> walked_idx, walked_off;
+    if (!trusted) {
+      mc.reset(new MemberChecks(eng));
+      mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
+      mc->add(3, d_cp.ptr(), m_items);
+      // Cy.g2 of every selected leaf is the walking argument of a pairing (the key's side replays prepared lines): the decrypt's own
+      // Miller loops say whether it is a member of G2; leaves the policy did not select get the stand-alone test (common.h: WalkedG2)
+      if (walk_checks() && lines) {
+        bool all = true;
+        for (size_t j = 0; j < m_items && all; j++) all = (pair_off[j + 1] - pair_off[j] - 1) / 2 == leaf_off[j + 1] - leaf_off[j];
+        if (!all) {
+          walked_off.push_back(0);
+          for (size_t j = 0; j < m_items; j++) {
+            const uint32_t mj = (pair_off[j + 1] - pair_off[j] - 1) / 2;
+            for (uint32_t e = 0; e < mj; e++) walked_idx.push_back(leaf_off[j] + sel_ct[sel_start[j] + e]);
+            walked_off.push_back((uint32_t)walked_idx.size());
+          }
+        }
+        walked.reset(new WalkedG2(eng, *mc, d_g2.ptr(), total, d_leaf_off.as<uint32_t>(), leaf_off, 1, all ? nullptr : &walked_idx, all ? nullptr : &walked_off));
+      } else {
+        mc->add(2, d_g2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
+      }
+    }
     // one key for all ciphertexts: its scaled Dj.g1 are computed once per selection entry (ciphertexts that share a policy share them)
+    if (walked) walked->arm();
     int32_t rc = rhip_bsw_decrypt_batch_one_sk(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                                d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c.as<rhip_g1>(), d_cp.as<rhip_gt>(),
                                                d_g1.as<rhip_g1>(), d_g2.as<rhip_g2>(), d_leaf_off.as<uint32_t>(), d_skd.as<rhip_g2>(), d_kg1.as<rhip_g1>(),
@@ -841,7 +861,10 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     eng.check(rc, "rhip_bsw_decrypt_batch");
     if (mc) {
       mc->collect();
-      const auto &ok_c = mc->ok(0), &ok_g1 = mc->ok(1), &ok_g2 = mc->ok(2), &ok_cp = mc->ok(3);
+      const auto &ok_c = mc->ok(0), &ok_g1 = mc->ok(1), &ok_cp = mc->ok(2);
+      std::vector<uint8_t> ok_g2;
+      if (walked) walked->finish(&ok_g2);
+      else { const auto& e = mc->ok(3); ok_g2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++) {
         const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
         if (!bad && (!ok_g1[j] || !ok_g2[j])) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
@@ -1256,13 +1279,33 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
         d_sel_start = up32(eng, sel_start), d_sel_sk = up32(eng, sel_sk), d_sel_ct = up32(eng, sel_ct), d_sel_z = up_bytes(eng, flatten_fr(sel_z)),
         d_e1 = up_bytes(eng, e1rep), d_e2(&eng, ct.e2.data(), 128), d_e1j = up_bytes(eng, e1j);
     gather.run({d_d1.ptr(), d_d2.ptr()}, dst_off);
-    std::unique_ptr<MemberChecks> mc;
-    if (!trusted) {
-      mc.reset(new MemberChecks(eng));
-      mc->add(1, d_d1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items); mc->add(2, d_d2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
-    }
     std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
     rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
+    std::unique_ptr<MemberChecks> mc;
+    std::unique_ptr<WalkedG2> walked;
+    std::vector<uint32_t> walked_idx, walked_off;
+    if (!trusted) {
+      mc.reset(new MemberChecks(eng));
+      mc->add(1, d_d1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
+      // D2 of every selected key leaf is the walking argument of a pairing (e2 replays prepared lines): membership out of the decrypt's
+      // own Miller loops, the stand-alone test for the leaves the selection left out (common.h: WalkedG2)
+      if (walk_checks() && lines) {
+        bool all = true;
+        for (size_t j = 0; j < m_items && all; j++) all = pair_off[j + 1] - pair_off[j] - 1 == leaf_off[j + 1] - leaf_off[j];
+        if (!all) {
+          walked_off.push_back(0);
+          for (size_t j = 0; j < m_items; j++) {
+            const uint32_t mj = pair_off[j + 1] - pair_off[j] - 1;
+            for (uint32_t e = 0; e < mj; e++) walked_idx.push_back(leaf_off[j] + sel_sk[sel_start[j] + e]);
+            walked_off.push_back((uint32_t)walked_idx.size());
+          }
+        }
+        walked.reset(new WalkedG2(eng, *mc, d_d2.ptr(), total, d_leaf_off.as<uint32_t>(), leaf_off, 1, all ? nullptr : &walked_idx, all ? nullptr : &walked_off));
+      } else {
+        mc->add(2, d_d2.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
+      }
+    }
+    if (walked) walked->arm();
     // one ciphertext for all keys: the scaled ciphertext rows are computed once per selection entry (keys that share a policy share them)
     int32_t rc = rhip_lsw_decrypt_batch_one_ct(cx, m_items, max_pairs, pair_off[m_items], sel_sk.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                                d_sel_sk.as<uint32_t>(), d_sel_ct.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_e1.as<rhip_gt>(), d_e2.as<rhip_g2>(),
@@ -1271,7 +1314,10 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     eng.check(rc, "rhip_lsw_decrypt_batch");
     if (mc) {
       mc->collect();
-      const auto &ok1 = mc->ok(0), &ok2 = mc->ok(1);
+      const auto& ok1 = mc->ok(0);
+      std::vector<uint8_t> ok2;
+      if (walked) walked->finish(&ok2);
+      else { const auto& e = mc->ok(1); ok2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++)
         if (!ok1[j] || !ok2[j]) (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)";
     }
@@ -1639,11 +1685,30 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
         d_sk_idx = up32(eng, sk_idx);
     gather.run({d_c0.ptr(), d_c1.ptr(), d_c2.ptr(), d_c3.ptr()}, dst_off);
     std::unique_ptr<MemberChecks> mc;
+    std::unique_ptr<WalkedG2> walked;
+    std::vector<uint32_t> walked_idx, walked_off;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
-      mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total, d_row_off.as<uint32_t>(), m_items); mc->add(2, d_c2.ptr(), total, d_row_off.as<uint32_t>(), m_items);
-      mc->add(2, d_c3.ptr(), total, d_row_off.as<uint32_t>(), m_items);
+      mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total, d_row_off.as<uint32_t>(), m_items);
+      mc->add(2, d_c3.ptr(), total, d_row_off.as<uint32_t>(), m_items);          // C3 enters its pairing as a SUM: every term keeps the stand-alone test
+      // C2 of every selected row is the walking argument of a pairing; one more argument walks per item (the sum of the C3 terms)
+      if (walk_checks()) {
+        bool all = true;
+        for (size_t j = 0; j < m_items && all; j++) all = pair_off[j + 1] - pair_off[j] - 1 == row_off[j + 1] - row_off[j];
+        if (!all) {
+          walked_off.push_back(0);
+          for (size_t j = 0; j < m_items; j++) {
+            const uint32_t mj = pair_off[j + 1] - pair_off[j] - 1;
+            for (uint32_t e = 0; e < mj; e++) walked_idx.push_back(row_off[j] + sel_ct[sel_start[j] + e]);
+            walked_off.push_back((uint32_t)walked_idx.size());
+          }
+        }
+        walked.reset(new WalkedG2(eng, *mc, d_c2.ptr(), total, d_row_off.as<uint32_t>(), row_off, 1, all ? nullptr : &walked_idx, all ? nullptr : &walked_off, 1));
+      } else {
+        mc->add(2, d_c2.ptr(), total, d_row_off.as<uint32_t>(), m_items);
+      }
     }
+    if (walked) walked->arm();
     int32_t rc = rhip_aw11_decrypt_batch(cx, m_items, max_pairs, pair_off[m_items], sel_ct.size(), d_pair_off.as<uint32_t>(), d_sel_start.as<uint32_t>(),
                                          d_sel_ct.as<uint32_t>(), d_sel_sk.as<uint32_t>(), d_sel_z.as<rhip_fr>(), d_c0.as<rhip_gt>(), d_c1.as<rhip_gt>(),
                                          d_c2.as<rhip_g2>(), d_c3.as<rhip_g2>(), d_row_off.as<uint32_t>(), d_hash.as<rhip_g1>(), d_kk.as<rhip_g1>(),
@@ -1651,7 +1716,10 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     eng.check(rc, "rhip_aw11_decrypt_batch");
     if (mc) {
       mc->collect();
-      const auto &ok0 = mc->ok(0), &ok1 = mc->ok(1), &ok2 = mc->ok(2), &ok3 = mc->ok(3);
+      const auto &ok0 = mc->ok(0), &ok1 = mc->ok(1), &ok3 = mc->ok(2);
+      std::vector<uint8_t> ok2;
+      if (walked) walked->finish(&ok2);
+      else { const auto& e = mc->ok(3); ok2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++) {
         const bool bad = !ok0[j] || !ok1[j] || !ok2[j] || !ok3[j];
         if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";

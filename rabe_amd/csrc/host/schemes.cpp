@@ -184,6 +184,8 @@ rhip_ctx* Engine::side_ctx() {
   if (!l.side) check(rhip_ctx_create(device_, &l.side), "rhip_ctx_create (side)");
   return l.side;
 }
+// RABE_NO_WALK_CHECKS=1: every G2 element gets the stand-alone subgroup test again (A/B runs)
+bool walk_checks() { static const bool off = getenv("RABE_NO_WALK_CHECKS") != nullptr; return !off; }
 MemberChecks::MemberChecks(Engine& eng) : eng_(eng), cx_(getenv("RABE_MEMBER_INLINE") ? eng.ctx() : eng.side_ctx()) {
   if (cx_ != eng.ctx()) eng.check(rhip_ctx_wait_for(cx_, eng.ctx()), "rhip_ctx_wait_for");
 }
@@ -197,11 +199,80 @@ void MemberChecks::add(int which, const void* dev, size_t count, const uint32_t*
   uint32_t* ok = fold ? per_element.as<uint32_t>() : dev_.back().as<uint32_t>();
   int32_t rc = which == 1 ? rhip_g1_on_curve(cx_, count, (const rhip_g1*)dev, ok)
              : which == 2 ? rhip_g2_in_subgroup(cx_, count, (const rhip_g2*)dev, ok)
+             : which == 4 ? rhip_g2_on_curve(cx_, count, (const rhip_g2*)dev, ok)
                           : rhip_gt_is_member(cx_, count, (const rhip_gt*)dev, ok);
   eng_.check(rc, "membership pass");
   if (fold) {
     eng_.check(rhip_flags_all(cx_, n_seg, dev_seg_off, scale, ok, dev_.back().as<uint32_t>()), "rhip_flags_all");
     scratch_.push_back(std::move(per_element));            // lives until collect(): the side stream still reads it
+  }
+}
+void MemberChecks::add_g2_at(const void* dev, const std::vector<uint32_t>& idx) {
+  flags_.emplace_back(idx.size(), 1u);
+  dev_.emplace_back(&eng_, idx.size() * 4);
+  if (idx.empty()) return;
+  // the index list goes up on the main context (asynchronously, from the lane's pinned staging); the side context waits for it
+  DBuf d_idx(&eng_, idx.size() * 4);
+  uint8_t* const h = eng_.pinned_bump(idx.size() * 4);
+  memcpy(h, idx.data(), idx.size() * 4);
+  eng_.check(rhip_upload_async(eng_.ctx(), d_idx.ptr(), h, idx.size() * 4), "upload");
+  if (cx_ != eng_.ctx()) eng_.check(rhip_ctx_wait_for(cx_, eng_.ctx()), "rhip_ctx_wait_for");
+  eng_.check(rhip_g2_in_subgroup_at(cx_, idx.size(), d_idx.as<uint32_t>(), (const rhip_g2*)dev, dev_.back().as<uint32_t>()), "rhip_g2_in_subgroup_at");
+  scratch_.push_back(std::move(d_idx));
+}
+WalkedG2::WalkedG2(Engine& eng, MemberChecks& mc, const void* dev_g2, size_t count, const uint32_t* dev_seg_off, const std::vector<uint32_t>& seg_off,
+                   uint32_t scale, const std::vector<uint32_t>* walked_idx, const std::vector<uint32_t>* walked_off, uint32_t extra_walks)
+    : eng_(eng), mc_(mc), dev_(dev_g2), count_(count), n_seg_(seg_off.size() - 1), seg_off_(seg_off), scale_(scale), extra_(extra_walks), widx_(walked_idx),
+      woff_(walked_off) {
+  k_curve_ = mc_.add_count();
+  mc_.add(4, dev_g2, count, dev_seg_off, n_seg_, scale);
+  if (woff_) {                                   // the complement of the walked elements: stand-alone, beside the decrypt
+    std::vector<uint8_t> walked(count, 0);
+    for (uint32_t e : *widx_) if (e < count) walked[e] = 1;
+    std::vector<uint32_t> rest;
+    for (size_t j = 0; j < n_seg_; j++)
+      for (size_t e = (size_t)seg_off_[j] * scale; e < (size_t)seg_off_[j + 1] * scale; e++)
+        if (!walked[e]) { rest.push_back((uint32_t)e); rest_item_.push_back((uint32_t)j); }
+    if (!rest.empty()) {
+      k_rest_ = mc_.add_count();
+      mc_.add_g2_at(dev_g2, rest);
+      has_rest_ = true;
+    }
+  }
+  d_verdicts_ = DBuf(&eng_, 2 * n_seg_ * 4);
+  eng_.check(rhip_memset_async(eng_.ctx(), d_verdicts_.ptr(), 0, 2 * n_seg_ * 4), "memset");
+}
+void WalkedG2::arm() {
+  eng_.check(rhip_ctx_collect_walk_verdicts(eng_.ctx(), d_verdicts_.as<uint32_t>(), d_verdicts_.as<uint32_t>() + n_seg_), "rhip_ctx_collect_walk_verdicts");
+}
+void WalkedG2::finish(std::vector<uint8_t>* ok) {
+  eng_.check(rhip_ctx_collect_walk_verdicts(eng_.ctx(), nullptr, nullptr), "rhip_ctx_collect_walk_verdicts");          // a path that did not consume the request
+  std::vector<uint32_t> v(2 * n_seg_);
+  eng_.check(rhip_download(eng_.ctx(), v.data(), d_verdicts_.ptr(), v.size() * 4), "download");
+  ok->assign(n_seg_, 1);
+  const auto& curve = mc_.ok(k_curve_);
+  for (size_t j = 0; j < n_seg_; j++) if (!curve[j] || v[j]) (*ok)[j] = 0;
+  if (has_rest_) {
+    const auto& r = mc_.ok(k_rest_);
+    for (size_t t = 0; t < r.size(); t++) if (!r[t]) (*ok)[rest_item_[t]] = 0;
+  }
+  // items whose walk examined fewer arguments than expected: their walked elements get the stand-alone test now
+  std::vector<uint32_t> again, again_item;
+  for (size_t j = 0; j < n_seg_; j++) {
+    if (!(*ok)[j]) continue;
+    const size_t lo = (size_t)seg_off_[j] * scale_, hi = (size_t)seg_off_[j + 1] * scale_;
+    const size_t expected = woff_ ? (size_t)((*woff_)[j + 1] - (*woff_)[j]) : hi - lo;
+    if (v[n_seg_ + j] == expected + extra_) continue;
+    if (woff_) for (uint32_t t = (*woff_)[j]; t < (*woff_)[j + 1]; t++) { again.push_back((*widx_)[t]); again_item.push_back((uint32_t)j); }
+    else for (size_t e = lo; e < hi; e++) { again.push_back((uint32_t)e); again_item.push_back((uint32_t)j); }
+  }
+  if (!again.empty()) {
+    DBuf d_idx(&eng_, again.size() * 4), d_ok(&eng_, again.size() * 4);
+    eng_.check(rhip_upload(eng_.ctx(), d_idx.ptr(), again.data(), again.size() * 4), "upload");
+    eng_.check(rhip_g2_in_subgroup_at(eng_.ctx(), again.size(), d_idx.as<uint32_t>(), (const rhip_g2*)dev_, d_ok.as<uint32_t>()), "rhip_g2_in_subgroup_at");
+    std::vector<uint32_t> r(again.size());
+    eng_.check(rhip_download(eng_.ctx(), r.data(), d_ok.ptr(), r.size() * 4), "download");
+    for (size_t t = 0; t < r.size(); t++) if (!r[t]) (*ok)[again_item[t]] = 0;
   }
 }
 void MemberChecks::collect() {
@@ -1484,25 +1555,43 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   // decoding checks over the gathered elements, on the side context beside the decrypt kernels; a non-member fails its item only (the
   // batch still runs: the kernels terminate on any input, the item's result is discarded below)
   std::unique_ptr<MemberChecks> mc;
+  std::unique_ptr<WalkedG2> walked;
+  DBuf seg_keep;
   if (!trusted) {
     mc.reset(new MemberChecks(eng));
-    mc->add(2, d1.ptr(), 3 * m);
     mc->add(1, d2.ptr(), 3 * total_rows, d3, m, 3);
     mc->add(3, d4.ptr(), m);
+    // c_0: the decrypt walks all three elements of every ciphertext -- their subgroup membership comes out of its Miller loops
+    if (walk_checks()) {
+      std::vector<uint32_t> seg(m + 1);
+      for (size_t j = 0; j <= m; j++) seg[j] = (uint32_t)j;
+      DBuf d_seg(&eng, (m + 1) * 4);
+      uint8_t* const hs = eng.pinned_bump((m + 1) * 4);
+      memcpy(hs, seg.data(), (m + 1) * 4);
+      eng.check(rhip_upload_async(cx, d_seg.ptr(), hs, (m + 1) * 4), "upload");
+      eng.check(rhip_ctx_wait_for(mc->ctx(), cx), "rhip_ctx_wait_for");
+      seg_keep = std::move(d_seg);
+      walked.reset(new WalkedG2(eng, *mc, d1.ptr(), 3 * m, seg_keep.as<uint32_t>(), seg, 3));
+    } else {
+      mc->add(2, d1.ptr(), 3 * m);
+    }
   }
   // the key's prepared k_0 lines are a function of the key alone: kept across calls (a server decrypts with the same key again and again)
   std::string k0_key((const char*)k0.data(), k0.size());
   rhip_ac17_sk_lines* lines = (rhip_ac17_sk_lines*)eng.aux("ac17_sk_lines", k0_key, make_ac17_sk_lines, &k0_key, destroy_ac17_sk_lines, 4);
+  if (walked) walked->arm();
   eng.check(rhip_ac17_cp_decrypt_batch_prepared(cx, m, d1.as<rhip_g2>(), d2.as<rhip_g1>(), d3, d4.as<rhip_gt>(), lines, pp.dev<rhip_g1>(h6),
                                                 pp.dev<uint32_t>(h7), pp.dev<rhip_g1>(h8), pp.dev<uint32_t>(h9), d_ct_sel,
                                                 pp.dev<uint32_t>(h11), d_sk_sel, pp.dev<uint32_t>(h13), dout.as<rhip_gt>()),
             "rhip_ac17_cp_decrypt_batch_prepared");
   if (mc) {
     mc->collect();
-    const auto &ok_c0 = mc->ok(0), &ok_rows = mc->ok(1), &ok_cp = mc->ok(2);
+    const auto &ok_rows = mc->ok(0), &ok_cp = mc->ok(1);
+    std::vector<uint8_t> ok_c0;
+    if (walked) walked->finish(&ok_c0);
+    else { const auto& e = mc->ok(2); ok_c0.assign(m, 1); for (size_t j = 0; j < m; j++) for (int t = 0; t < 3; t++) if (!e[3 * j + t]) ok_c0[j] = 0; }
     for (size_t j = 0; j < m; j++) {
-      const char* bad = nullptr;
-      for (int t = 0; t < 3 && !bad; t++) if (!ok_c0[3 * j + t]) bad = "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)";
+      const char* bad = !ok_c0[j] ? "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)" : nullptr;
       if (!bad && !ok_rows[j]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
       if (!bad && !ok_cp[j]) bad = "deserialize: c_p is not a member of Gt (FieldError::NotMember)";
       if (bad) (*errors)[live[j]] = bad;
