@@ -92,6 +92,9 @@ int32_t rhip_event_wait(rhip_event* ev);
  * is consumed by ctx's next final-exponentiation launch; waiter = NULL withdraws a pending one (a context must not be destroyed while
  * it is a pending waiter).  The hold is bounded: the waiter's stream polls for at most a few tens of milliseconds. */
 int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter);
+/* The same hold, released as soon as ctx's Miller loops are DONE (no wait for the final exponentiation's blocks to be resident): for a
+ * waiter with little work of its own -- the Gt membership checks of a packed decrypt run beside the final exponentiation this way. */
+int32_t rhip_ctx_release_after_miller(rhip_ctx* ctx, rhip_ctx* waiter);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------
  * rabe_bn surface replaced ("rabe_bn API surface actually used"):

@@ -252,7 +252,17 @@ extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* wa
   std::lock_guard<std::mutex> g(g_live_mu);
   if (waiter && !g_live.count(waiter)) return RHIP_ERR_ARG;
   ctx->fe_waiter = waiter;          // NULL withdraws a pending request; rhip_ctx_destroy(waiter) withdraws it too
+  ctx->fe_waiter_poll = true;
   return RHIP_OK;
+}
+// The same hold without the wait for resident final-exponentiation blocks: the waiter goes on as soon as the Miller loops are done.  For a
+// waiter whose kernels are small next to the final exponentiation (the host layer's Gt membership checks): the polling kernel of the full
+// form occupies the waiter's hardware queue, and a process with more streams than hardware queues may have put ctx's own stream on that
+// queue -- measured: the final exponentiation then starts only when the poll gives up (36 ms).
+extern "C" int32_t rhip_ctx_release_after_miller(rhip_ctx* ctx, rhip_ctx* waiter) {
+  const int32_t rc = rhip_ctx_release_before_final_exp(ctx, waiter);
+  if (rc == RHIP_OK) ctx->fe_waiter_poll = false;
+  return rc;
 }
 // a point of a context's stream a HOST thread can wait for (the host layer's helper threads wait for one part's copy, not for the stream)
 struct rhip_event { hipEvent_t ev; int device; };
@@ -1162,7 +1172,8 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
     if (e != hipSuccess) return fail(ctx, e, "rhip_ctx_release_before_final_exp");
     // ... and the final exponentiation's waves are resident (at most as many as there are SIMDs); ~2 ms of polling at most
     const uint32_t target = (uint32_t)(blocks < (size_t)ctx->n_cu ? blocks : (size_t)ctx->n_cu);
-    hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
+    if (ctx->fe_waiter_poll) hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
+    else started = nullptr;
   }
   live.unlock();
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks), dim3(RB_FE_BLOCK), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,

@@ -55,6 +55,7 @@ struct rhip_ctx {
   void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)
   uint32_t* walk_fail = nullptr;    // one-shot (rhip_ctx_collect_walk_verdicts): per-item verdict / count arrays of the next pair-list launch
   uint32_t* walk_count = nullptr;
+  bool fe_waiter_poll = true;      // false: the waiter is released when the Miller loops are done, without waiting for the final exponentiation's blocks
   rhip_ctx* fe_waiter = nullptr;   // one-shot (rhip_ctx_release_before_final_exp): released after this context's next Miller launch
   bool timing = false;
   struct Pending { std::string name; hipEvent_t e0, e1; };

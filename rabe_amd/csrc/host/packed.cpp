@@ -786,9 +786,15 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
   std::vector<uint64_t> sealed_off(m_items);
   std::vector<uint32_t> sealed_len(m_items);
   DBuf d_out(&eng, m_items * 384 + 4);
+  // what the walk's verdicts refer to outlives the block below: they are read after the open (records.h: retract_item)
+  std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
+  std::unique_ptr<WalkedG2> walked;
+  std::vector<uint32_t> walked_idx, walked_off;
+  DBuf d_g2;
   if (m_items) {
     const size_t total = leaf_off[m_items];
-    DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4), d_g2(&eng, total * 128 + 4);
+    DBuf d_c(&eng, m_items * 64), d_cp(&eng, m_items * 384), d_g1(&eng, total * 64 + 4);
+    d_g2 = DBuf(&eng, total * 128 + 4);
     std::vector<uint64_t> dst_off(4 * m_items);
     for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
@@ -827,9 +833,6 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       for (const auto& a : sk.d_j) key.append((const char*)a.g2.data(), 128);
       lines = (rhip_bsw_sk_lines*)eng.aux("bsw_sk_lines", key, make_sk_lines, &key, destroy_sk_lines, 4);
     }
-    std::unique_ptr<MemberChecks> mc;          // the decoding checks run on the side context, beside the decrypt kernels (common.h)
-    std::unique_ptr<WalkedG2> walked;
-    std::vector<uint32_t> walked_idx, walked_off;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
       mc->add(1, d_c.ptr(), m_items); mc->add(1, d_g1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
@@ -862,9 +865,8 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
     if (mc) {
       mc->collect();
       const auto &ok_c = mc->ok(0), &ok_g1 = mc->ok(1), &ok_cp = mc->ok(2);
-      std::vector<uint8_t> ok_g2;
-      if (walked) walked->finish(&ok_g2);
-      else { const auto& e = mc->ok(3); ok_g2.assign(e.begin(), e.end()); }
+      std::vector<uint8_t> ok_g2(m_items, 1);
+      if (!walked) { const auto& e = mc->ok(3); ok_g2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++) {
         const char* bad = !ok_c[j] ? "deserialize: c is not a point of G1 (FieldError::NotMember)" : !ok_cp[j] ? "deserialize: c_p is not a member of Gt (FieldError::NotMember)" : nullptr;
         if (!bad && (!ok_g1[j] || !ok_g2[j])) bad = "deserialize: a leaf element is not a group member (FieldError::NotMember)";
@@ -874,6 +876,12 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
   }
   // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
   open_sealed_records(eng, n, live, d_out.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  if (walked) {
+    std::vector<uint8_t> ok_g2;
+    walked->finish(&ok_g2);
+    for (size_t j = 0; j < m_items; j++)
+      if (!ok_g2[j]) retract_item(live[j], "deserialize: a leaf element is not a group member (FieldError::NotMember)", status, pt_buf, pt_off, errors);
+  }
   tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
@@ -1250,9 +1258,14 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
   }
   const size_t m_items = live.size();
   DBuf d_out(&eng, m_items * 384 + 4);
+  std::unique_ptr<MemberChecks> mc;
+  std::unique_ptr<WalkedG2> walked;          // read after the open (records.h: retract_item): it and what it refers to outlive the block
+  std::vector<uint32_t> walked_idx, walked_off;
+  DBuf d_d2;
   if (m_items) {
     const size_t total = leaf_off[m_items];
-    DBuf d_d1(&eng, total * 64 + 4), d_d2(&eng, total * 128 + 4);
+    DBuf d_d1(&eng, total * 64 + 4);
+    d_d2 = DBuf(&eng, total * 128 + 4);
     std::vector<uint64_t> dst_off(2 * m_items);
     for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
@@ -1281,9 +1294,6 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     gather.run({d_d1.ptr(), d_d2.ptr()}, dst_off);
     std::string e2_key((const char*)ct.e2.data(), 128);         // the ciphertext's prepared e2 lines: kept across calls
     rhip_g2_lines* lines = (rhip_g2_lines*)eng.aux("lsw_e2_lines", e2_key, make_e2_lines, &e2_key, destroy_e2_lines, 4);
-    std::unique_ptr<MemberChecks> mc;
-    std::unique_ptr<WalkedG2> walked;
-    std::vector<uint32_t> walked_idx, walked_off;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
       mc->add(1, d_d1.ptr(), total, d_leaf_off.as<uint32_t>(), m_items);
@@ -1315,9 +1325,8 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
     if (mc) {
       mc->collect();
       const auto& ok1 = mc->ok(0);
-      std::vector<uint8_t> ok2;
-      if (walked) walked->finish(&ok2);
-      else { const auto& e = mc->ok(1); ok2.assign(e.begin(), e.end()); }
+      std::vector<uint8_t> ok2(m_items, 1);
+      if (!walked) { const auto& e = mc->ok(1); ok2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++)
         if (!ok1[j] || !ok2[j]) (*errors)[live[j]] = "deserialize: a key element is not a group member (FieldError::NotMember)";
     }
@@ -1327,6 +1336,12 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
   std::vector<uint64_t> sealed_off(m_items, 0);
   std::vector<uint32_t> sealed_len(m_items, (uint32_t)ct.ct.size());
   open_sealed_records(eng, n, live, d_out.ptr(), d_sealed.as<uint8_t>(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  if (walked) {
+    std::vector<uint8_t> ok2;
+    walked->finish(&ok2);
+    for (size_t j = 0; j < m_items; j++)
+      if (!ok2[j]) retract_item(live[j], "deserialize: a key element is not a group member (FieldError::NotMember)", status, pt_buf, pt_off, errors);
+  }
   tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
@@ -1650,9 +1665,14 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
   std::vector<uint64_t> sealed_off(m_items);
   std::vector<uint32_t> sealed_len(m_items);
   DBuf d_out(&eng, m_items * 384 + 4);
+  std::unique_ptr<MemberChecks> mc;
+  std::unique_ptr<WalkedG2> walked;          // read after the open (records.h: retract_item): it and what it refers to outlive the block
+  std::vector<uint32_t> walked_idx, walked_off;
+  DBuf d_c2;
   if (m_items) {
     const size_t total = row_off[m_items];
-    DBuf d_c0(&eng, m_items * 384), d_c1(&eng, total * 384 + 4), d_c2(&eng, total * 128 + 4), d_c3(&eng, total * 128 + 4);
+    DBuf d_c0(&eng, m_items * 384), d_c1(&eng, total * 384 + 4), d_c3(&eng, total * 128 + 4);
+    d_c2 = DBuf(&eng, total * 128 + 4);
     std::vector<uint64_t> dst_off(4 * m_items);
     for (size_t j = 0; j < m_items; j++) {
       const View& w = v[live[j]];
@@ -1684,9 +1704,6 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
         d_sel_z = up_bytes(eng, flatten_fr(sel_z)), d_hash(&eng, hash.data(), 64), d_kk = up_bytes(eng, kk), d_sk_attr_off = up32(eng, sk_attr_off),
         d_sk_idx = up32(eng, sk_idx);
     gather.run({d_c0.ptr(), d_c1.ptr(), d_c2.ptr(), d_c3.ptr()}, dst_off);
-    std::unique_ptr<MemberChecks> mc;
-    std::unique_ptr<WalkedG2> walked;
-    std::vector<uint32_t> walked_idx, walked_off;
     if (!trusted) {
       mc.reset(new MemberChecks(eng));
       mc->add(3, d_c0.ptr(), m_items); mc->add(3, d_c1.ptr(), total, d_row_off.as<uint32_t>(), m_items);
@@ -1717,9 +1734,8 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
     if (mc) {
       mc->collect();
       const auto &ok0 = mc->ok(0), &ok1 = mc->ok(1), &ok3 = mc->ok(2);
-      std::vector<uint8_t> ok2;
-      if (walked) walked->finish(&ok2);
-      else { const auto& e = mc->ok(3); ok2.assign(e.begin(), e.end()); }
+      std::vector<uint8_t> ok2(m_items, 1);
+      if (!walked) { const auto& e = mc->ok(3); ok2.assign(e.begin(), e.end()); }
       for (size_t j = 0; j < m_items; j++) {
         const bool bad = !ok0[j] || !ok1[j] || !ok2[j] || !ok3[j];
         if (bad) (*errors)[live[j]] = "deserialize: a ciphertext element is not a group member (FieldError::NotMember)";
@@ -1728,6 +1744,12 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
   }
   // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
   open_sealed_records(eng, n, live, d_out.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  if (walked) {
+    std::vector<uint8_t> ok2;
+    walked->finish(&ok2);
+    for (size_t j = 0; j < m_items; j++)
+      if (!ok2[j]) retract_item(live[j], "deserialize: a ciphertext element is not a group member (FieldError::NotMember)", status, pt_buf, pt_off, errors);
+  }
   tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }

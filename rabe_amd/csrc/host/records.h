@@ -7,6 +7,7 @@
 // (rhip_gather_parts), and opens the sealed plaintexts there (rhip_open_batch): the Gt never leaves HBM on either side.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -99,5 +100,14 @@ class BlobGather {
 void open_sealed_records(Engine& eng, size_t n, const std::vector<size_t>& live, const void* d_gt, const uint8_t* d_blob,
                          const std::vector<uint64_t>& sealed_off, const std::vector<uint32_t>& sealed_len, int32_t* status, uint8_t* pt_buf,
                          uint64_t* pt_off, std::vector<std::string>* errors);
+
+// A verdict that arrives after open_sealed_records ran (the G2 membership a decrypt's own Miller loops establish, common.h: WalkedG2 --
+// reading it earlier would make the host wait for the pairings before it prepares the open): the item fails like an item whose tag did not
+// verify -- status -1, its plaintext slot zeroed -- with the decoder's error, which comes first in the reference's order of events.
+inline void retract_item(size_t i, const char* msg, int32_t* status, uint8_t* pt_buf, const uint64_t* pt_off, std::vector<std::string>* errors) {
+  if (status[i] == 0 && pt_off[i + 1] > pt_off[i]) memset(pt_buf + pt_off[i], 0, (size_t)(pt_off[i + 1] - pt_off[i]));
+  status[i] = -1;
+  (*errors)[i] = msg;
+}
 
 }}  // namespace rabe::schemes

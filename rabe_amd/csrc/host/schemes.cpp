@@ -194,18 +194,31 @@ void MemberChecks::add(int which, const void* dev, size_t count, const uint32_t*
   flags_.emplace_back(fold ? n_seg : count, 1u);
   dev_.emplace_back(&eng_, (fold ? n_seg : count) * 4);
   if (!count) return;
+  if (which == 3 && cx_ != eng_.ctx()) {          // Gt: beside the decrypt's final exponentiation (see collect())
+    if (!requested_) { eng_.check(rhip_ctx_release_after_miller(eng_.ctx(), cx_), "rhip_ctx_release_after_miller"); requested_ = true; }
+    later_.push_back({flags_.size() - 1, dev, count, dev_seg_off, n_seg, scale});
+    return;
+  }
+  launch(which, flags_.size() - 1, dev, count, dev_seg_off, n_seg, scale);
+}
+void MemberChecks::launch(int which, size_t k, const void* dev, size_t count, const uint32_t* dev_seg_off, size_t n_seg, uint32_t scale) {
+  const bool fold = dev_seg_off != nullptr;
   DBuf per_element;
   if (fold) per_element = DBuf(&eng_, count * 4);
-  uint32_t* ok = fold ? per_element.as<uint32_t>() : dev_.back().as<uint32_t>();
+  uint32_t* ok = fold ? per_element.as<uint32_t>() : dev_[k].as<uint32_t>();
   int32_t rc = which == 1 ? rhip_g1_on_curve(cx_, count, (const rhip_g1*)dev, ok)
              : which == 2 ? rhip_g2_in_subgroup(cx_, count, (const rhip_g2*)dev, ok)
              : which == 4 ? rhip_g2_on_curve(cx_, count, (const rhip_g2*)dev, ok)
                           : rhip_gt_is_member(cx_, count, (const rhip_gt*)dev, ok);
   eng_.check(rc, "membership pass");
   if (fold) {
-    eng_.check(rhip_flags_all(cx_, n_seg, dev_seg_off, scale, ok, dev_.back().as<uint32_t>()), "rhip_flags_all");
+    eng_.check(rhip_flags_all(cx_, n_seg, dev_seg_off, scale, ok, dev_[k].as<uint32_t>()), "rhip_flags_all");
     scratch_.push_back(std::move(per_element));            // lives until collect(): the side stream still reads it
   }
+}
+MemberChecks::~MemberChecks() {
+  // a request no decrypt consumed (an exception on the way) must not hold the side stream at some later launch
+  if (requested_) (void)rhip_ctx_release_after_miller(eng_.ctx(), nullptr);
 }
 void MemberChecks::add_g2_at(const void* dev, const std::vector<uint32_t>& idx) {
   flags_.emplace_back(idx.size(), 1u);
@@ -276,6 +289,12 @@ void WalkedG2::finish(std::vector<uint8_t>* ok) {
   }
 }
 void MemberChecks::collect() {
+  for (const auto& d : later_) launch(3, d.k, d.dev, d.count, d.seg, d.n_seg, d.scale);
+  later_.clear();
+  if (requested_) {            // consumed by the decrypt the caller queued -- or by nothing (a path without that launch): withdrawn, the checks ran at once
+    (void)rhip_ctx_release_after_miller(eng_.ctx(), nullptr);
+    requested_ = false;
+  }
   for (size_t k = 0; k < flags_.size(); k++)
     if (!flags_[k].empty()) eng_.check(rhip_download_async(cx_, flags_[k].data(), dev_[k].ptr(), flags_[k].size() * 4), "download");
   eng_.check(rhip_sync(cx_), "rhip_sync (membership pass)");
@@ -1587,9 +1606,8 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   if (mc) {
     mc->collect();
     const auto &ok_rows = mc->ok(0), &ok_cp = mc->ok(1);
-    std::vector<uint8_t> ok_c0;
-    if (walked) walked->finish(&ok_c0);
-    else { const auto& e = mc->ok(2); ok_c0.assign(m, 1); for (size_t j = 0; j < m; j++) for (int t = 0; t < 3; t++) if (!e[3 * j + t]) ok_c0[j] = 0; }
+    std::vector<uint8_t> ok_c0(m, 1);
+    if (!walked) { const auto& e = mc->ok(2); for (size_t j = 0; j < m; j++) for (int t = 0; t < 3; t++) if (!e[3 * j + t]) ok_c0[j] = 0; }
     for (size_t j = 0; j < m; j++) {
       const char* bad = !ok_c0[j] ? "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)" : nullptr;
       if (!bad && !ok_rows[j]) bad = "deserialize: a row element is not a point of G1 (FieldError::NotMember)";
@@ -1599,6 +1617,12 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   }
   // KDF + AES-GCM open on the device: the decrypted Gt never leaves HBM; plaintext bytes come back in one copy
   open_sealed_records(eng, n, live, dout.ptr(), gather.dev_blob(), sealed_off, sealed_len, status, pt_buf, pt_off, errors);
+  if (walked) {          // the walk's verdicts are read AFTER the open was queued behind the pairings (records.h: retract_item)
+    std::vector<uint8_t> ok_c0;
+    walked->finish(&ok_c0);
+    for (size_t j = 0; j < m; j++)
+      if (!ok_c0[j]) retract_item(live[j], "deserialize: c_0 element is not a member of G2 (FieldError::NotMember)", status, pt_buf, pt_off, errors);
+  }
   tm.lap(trusted ? "device: gather, pairings, open" : "device: gather, pairings, open; membership beside");
   return true;
 }
