@@ -47,7 +47,7 @@ struct rhip_ctx {
   void* fe_ws = nullptr;
   size_t fe_ws_bytes = 0;
   // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
-  enum { N_WORK = 10 };
+  enum { N_WORK = 11 };
   void* work[N_WORK] = {};
   size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg

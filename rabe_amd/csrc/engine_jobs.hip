@@ -113,8 +113,8 @@ __device__ __forceinline__ void scale_and_store(uint32_t* lds, bool active, G1Af
 // 64 consecutive items.  Items that share a policy share the scalar of their j-th pair, so the NAF chains of a wave run without
 // divergence -- lanes with different scalars execute the union of their additions, ~1.7x the work (k_bsw_dec_pairs 22.6 -> see
 // DESIGN.md section 8).  ppi == 0 (ragged batch): lane = pair.
-__device__ __forceinline__ void pair_lane(size_t v, size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, size_t* t, size_t* item,
-                                          bool* active) {
+__device__ __forceinline__ void pair_lane(size_t v, size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* tile_off, size_t* t,
+                                          size_t* item, bool* active) {
   if (ppi) {
     const size_t per_tile = (size_t)64 * ppi;
     const size_t tile = v / per_tile, r = v % per_tile;
@@ -123,16 +123,81 @@ __device__ __forceinline__ void pair_lane(size_t v, size_t n_items, size_t total
     if (!*active) it = n_items - 1;
     *item = it;
     *t = it * ppi + (r >> 6);
+  } else if (tile_off) {
+    // ragged batch, tiled (k_tile_offsets): tile = 64 consecutive items, its lanes = 64 x (largest pair count in the tile), lane r of the
+    // tile = pair r / 64 of item r % 64 -- a wave holds the j-th pair of 64 neighbouring items, like the uniform map, so that in a batch
+    // grouped by shape its lanes share scalar and kind of work (a lane = pair map puts scaled and copied pairs, and the scalars of one
+    // item's leaves, side by side in a wave: 2.4 x the time per scaling, measured on the mixed-shape config-3 batch)
+    const size_t n_tiles = (n_items + 63) / 64;
+    size_t lo = 0, hi = n_tiles;                    // the tile with tile_off[tile] <= v < tile_off[tile + 1]
+    while (hi - lo > 1) {
+      const size_t mid = (lo + hi) >> 1;
+      if (tile_off[mid] <= v) lo = mid; else hi = mid;
+    }
+    const size_t r = v - tile_off[lo];
+    size_t it = lo * 64 + (r & 63);
+    const uint32_t j = (uint32_t)(r >> 6);
+    bool act = v < tile_off[n_tiles] && it < n_items;
+    if (it >= n_items) it = n_items - 1;
+    const uint32_t p_it = pair_off[it + 1] - pair_off[it];
+    act = act && j < p_it;
+    *active = act;
+    *item = it;
+    *t = act ? (size_t)pair_off[it] + j : (p_it ? (size_t)pair_off[it] : total_pairs - 1);
+    if (!act && !p_it) *item = owner_of(pair_off, n_items, *t);
   } else {
     *active = v < total_pairs;
     *t = *active ? v : total_pairs - 1;
     *item = owner_of(pair_off, n_items, *t);
   }
 }
+// tile_off[k] = first lane of tile k, k <= n_tiles (one block; a thread owns a run of tiles)
+__global__ void __launch_bounds__(1024) k_tile_offsets(size_t n_items, const uint32_t* pair_off, uint32_t* tile_off) {
+  __shared__ uint32_t part[1024];
+  const size_t n_tiles = (n_items + 63) / 64;
+  const size_t per = (n_tiles + 1023) / 1024, lo = (size_t)threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  auto lanes_of = [&](size_t tile) {
+    uint32_t mx = 0;
+    const size_t i1 = tile * 64 + 64 < n_items ? tile * 64 + 64 : n_items;
+    for (size_t i = tile * 64; i < i1; i++) { const uint32_t p = pair_off[i + 1] - pair_off[i]; mx = p > mx ? p : mx; }
+    return 64u * mx;
+  };
+  uint32_t sum = 0;
+  for (size_t k = lo; k < hi; k++) sum += lanes_of(k);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t at = part[threadIdx.x] - sum;
+  for (size_t k = lo; k < hi; k++) { tile_off[k] = at; at += lanes_of(k); }
+  if (threadIdx.x == 1023) tile_off[n_tiles] = part[1023];
+}
 static inline uint32_t uniform_ppi(size_t n_items, size_t max_pairs, size_t total_pairs) {
   return (max_pairs && total_pairs == n_items * max_pairs) ? (uint32_t)max_pairs : 0u;
 }
 static inline size_t pair_lanes(size_t n_items, size_t total_pairs, uint32_t ppi) { return ppi ? (n_items + 63) / 64 * 64 * (size_t)ppi : total_pairs; }
+// lanes and tile table of a gather kernel's launch: uniform batches need none; a ragged one gets the tiled map (the grid is sized for the
+// bound 64 x max_pairs lanes per tile -- the lanes beyond the table's end leave at once).  RABE_NO_PAIR_TILES=1: lane = pair (A/B runs).
+static int32_t gather_lanes(rhip_ctx* ctx, size_t n_items, size_t max_pairs, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t** tile_off,
+                            size_t* lanes) {
+  *tile_off = nullptr;
+  *lanes = pair_lanes(n_items, total_pairs, ppi);
+  static const bool off = getenv("RABE_NO_PAIR_TILES") != nullptr;
+  if (ppi || off || !pair_off || !max_pairs || n_items < 64) return RHIP_OK;
+  const size_t n_tiles = (n_items + 63) / 64;
+  if (n_tiles * 64 * max_pairs >= ((size_t)1 << 32)) return RHIP_OK;          // the table holds 32-bit lane numbers
+  void* w = nullptr;
+  const int32_t rc = rhip_ensure_work(ctx, 10, (n_tiles + 1) * sizeof(uint32_t), &w);
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_tile_offsets", k_tile_offsets, dim3(1), dim3(1024), 0, ctx->stream, n_items, pair_off, (uint32_t*)w);
+  *tile_off = (const uint32_t*)w;
+  *lanes = n_tiles * 64 * max_pairs;
+  return RHIP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ the multi-pairing kernel
 // The Fq12 accumulator of a lane lives in LDS (LdsHomeT, engine_internal.h) -- nothing of the loop goes to scratch.  Blocks of four
@@ -640,7 +705,7 @@ extern "C" int32_t rhip_bsw_encrypt_batch(rhip_ctx* ctx, const rhip_bsw_pk* pk, 
 //   2s+1 : P = -z_e * Dj.g1,  Q = Cy.g2
 //   2m   : P = -c,            Q = d
 // (msg = c_p * FE(prod), bsw/mod.rs:282-308 restated in SURVEY.md Appendix B.4)
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* tile_off, const uint32_t* sel_start,
                                                                     const uint32_t* sel_ct_leaf, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
                                                                     const rhip_g1* ct_c, const rhip_g1* ct_cy_g1, const rhip_g2* ct_cy_g2,
                                                                     const uint32_t* ct_leaf_off, const rhip_g2* sk_d, const rhip_g1* sk_dj_g1,
@@ -653,13 +718,13 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_bsw_dec_pairs(size_t n_it
   uint32_t j, m;
   if (compact) {      // uniform batch, one key: only the pairs that still need a scaling get a lane -- positions 0, 2, .. 2m-2 and 2m
     const uint32_t mm = (ppi - 1) >> 1;
-    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, n_items * (size_t)(mm + 1), pair_off, mm + 1, &t, &item, &active);
+    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, n_items * (size_t)(mm + 1), pair_off, mm + 1, (const uint32_t*)nullptr, &t, &item, &active);
     const uint32_t jj = (uint32_t)(t - item * (size_t)(mm + 1));
     m = mm;
     j = jj < mm ? 2 * jj : 2 * mm;
     t = item * (size_t)ppi + j;
   } else {
-    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+    pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, tile_off, &t, &item, &active);
     j = (uint32_t)(t - pair_off[item]);
     m = (pair_off[item + 1] - pair_off[item] - 1) >> 1;
   }
@@ -821,9 +886,12 @@ static int32_t bsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
             sk_dj_g1, psel, psel_inf);
   }
   const int compact = (psel && ppi >= 3) ? 1 : 0;        // uniform batch: the odd pairs are copies (k_bsw_entry_pairs), the others get the lanes
-  const size_t lanes = compact ? pair_lanes(n_items, n_items * (size_t)((ppi + 1) / 2), (ppi + 1) / 2) : pair_lanes(n_items, total_pairs, ppi);
+  size_t lanes = 0;
+  const uint32_t* tile_off = nullptr;
+  if (compact) lanes = pair_lanes(n_items, n_items * (size_t)((ppi + 1) / 2), (ppi + 1) / 2);
+  else if ((rc = gather_lanes(ctx, n_items, max_pairs, total_pairs, pair_off, ppi, &tile_off, &lanes)) != RHIP_OK) return rc;
   KLAUNCH(ctx, "k_bsw_dec_pairs", k_bsw_dec_pairs, dim3(blocks_for(lanes, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
-          total_pairs, pair_off, ppi, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
+          total_pairs, pair_off, ppi, tile_off, sel_start, sel_ct_leaf, sel_sk_attr, sel_coeff, ct_c, ct_cy_g1, ct_cy_g2, ct_leaf_off, sk_d, sk_dj_g1, sk_dj_g2,
           sk_attr_off, sk_idx, (uint32_t)(sk_lines ? sk_lines->total_attrs : 0), sk_lines ? 1 : 0,
           (const uint8_t*)(sk_lines ? sk_lines->l->q_inf : nullptr), pl.P, pl.Q, pl.qref, (const G1M*)psel, (const uint8_t*)psel_inf, compact);
   if (compact)
@@ -1063,7 +1131,7 @@ extern "C" int32_t rhip_lsw_keygen_batch_signed(rhip_ctx* ctx, const rhip_lsw_pk
 //   s < m : P = c_e * E1[ct attr],                  Q = D2[key leaf]          (e = sel_start[i] + s)
 //   m     : P = sum_e (-c_e) * D1[key leaf]  (MSM),  Q = e2
 // This kernel does the scaled pairs and gathers the MSM's bases (D1, Montgomery) at terms[pair index - item].
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* tile_off, const uint32_t* sel_start,
                                                                     const uint32_t* sel_sk_leaf, const uint32_t* sel_ct_attr, const rhip_fr* sel_coeff,
                                                                     const rhip_g2* ct_e2, const rhip_g1* ct_e1j, const uint32_t* ct_attr_off,
                                                                     const uint32_t* ct_idx, const rhip_g1* sk_d1, const rhip_g2* sk_d2,
@@ -1073,7 +1141,7 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_lsw_dec_pairs(size_t n_it
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
   size_t t, item;
   bool active;
-  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, tile_off, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
   const uint32_t ct = one_ct ? 0u : ct_idx ? ct_idx[item] : (uint32_t)item;
@@ -1187,8 +1255,11 @@ static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
     KLAUNCH(ctx, "k_lsw_scale_entries", k_lsw_scale_entries, dim3(blocks_for(n_sel, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_sel, sel_ct_attr, sel_coeff,
             ct_e1j, psel, psel_inf);
   }
-  KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
-          pair_off, ppi, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
+  size_t g_lanes = 0;
+  const uint32_t* tile_off = nullptr;
+  if ((rc = gather_lanes(ctx, n_items, max_pairs, total_pairs, pair_off, ppi, &tile_off, &g_lanes)) != RHIP_OK) return rc;
+  KLAUNCH(ctx, "k_lsw_dec_pairs", k_lsw_dec_pairs, dim3(blocks_for(g_lanes, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, total_pairs,
+          pair_off, ppi, tile_off, sel_start, sel_sk_leaf, sel_ct_attr, sel_coeff, ct_e2, ct_e1j, ct_attr_off, ct_idx, sk_d1, sk_d2, sk_leaf_off, sk_idx,
           (const uint8_t*)(ct_e2_lines ? ct_e2_lines->q_inf : nullptr), pl.P, pl.Q, pl.qref, (G1M*)w_terms, (const G1M*)psel, (const uint8_t*)psel_inf, one_ct ? 1 : 0);
   KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
@@ -1205,14 +1276,14 @@ static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
 //   m     : P = C1[i],                           lines of k_z            (block 0)
 //   m + 1 : P = sum_e (-w_e) * C[ct row]  (MSM), lines of l_z            (block 1)
 //   t_i = FE( prod of the Miller values ) = e(c1, k_z) / ( prod_e e(w_e D_e, K_e) * e(sum_e w_e C_e, l_z) )
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_ghw11_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_ghw11_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* tile_off, const uint32_t* sel_start,
                                                                   const uint32_t* sel_ct_row, const uint32_t* sel_tk_attr, const rhip_fr* sel_coeff,
                                                                   const rhip_g1* ct_c1, const rhip_g1* ct_c, const rhip_g1* ct_d, const uint32_t* ct_row_off,
                                                                   const uint8_t* line_inf, G1M* P, uint32_t* qref, G1M* terms) {
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
   size_t t, item;
   bool active;
-  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, tile_off, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 2;
   G1Aff base = aff_inf<Fp>();
@@ -1257,8 +1328,11 @@ extern "C" int32_t rhip_ghw11_transform_batch(rhip_ctx* ctx, size_t n_items, siz
   if (n_sel) KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
   KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off, 2u);
   const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
-  KLAUNCH(ctx, "k_ghw11_pairs", k_ghw11_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
-          total_pairs, pair_off, ppi, sel_start, sel_ct_row, sel_tk_attr, sel_coeff, ct_c1, ct_c, ct_d, ct_row_off, (const uint8_t*)tk_lines->q_inf, pl.P,
+  size_t g_lanes = 0;
+  const uint32_t* tile_off = nullptr;
+  if ((rc = gather_lanes(ctx, n_items, max_pairs, total_pairs, pair_off, ppi, &tile_off, &g_lanes)) != RHIP_OK) return rc;
+  KLAUNCH(ctx, "k_ghw11_pairs", k_ghw11_pairs, dim3(blocks_for(g_lanes, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, ppi, tile_off, sel_start, sel_ct_row, sel_tk_attr, sel_coeff, ct_c1, ct_c, ct_d, ct_row_off, (const uint8_t*)tk_lines->q_inf, pl.P,
           pl.qref, (G1M*)w_terms);
   KLAUNCH(ctx, "k_msm_partial_g1", (k_msm_partial<Fp, G1M, G1JM>), dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
@@ -1565,7 +1639,7 @@ extern "C" int32_t rhip_aw11_encrypt_batch(rhip_ctx* ctx, const rhip_aw11_pk* pk
 //   m     : P = -H(gid),             Q = sum_e c_e * C3[ct row]   (G2 MSM)
 // and the leading factor c_0 * prod_e C1[ct row]^(-c_e)  (a Gt multi-exponentiation with shared squarings).
 // This kernel does the scaled pairs and gathers the MSM's bases (C3) and the multi-exponentiation's bases (C1), Montgomery.
-__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* sel_start,
+__global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_items, size_t total_pairs, const uint32_t* pair_off, uint32_t ppi, const uint32_t* tile_off, const uint32_t* sel_start,
                                                                      const uint32_t* sel_ct_row, const uint32_t* sel_sk_attr, const rhip_fr* sel_coeff,
                                                                      const rhip_g2* ct_c2, const uint32_t* ct_row_off, const rhip_g1* sk_hash,
                                                                      const rhip_g1* sk_k, const uint32_t* sk_attr_off, const uint32_t* sk_idx, G1M* P,
@@ -1573,7 +1647,7 @@ __global__ void __launch_bounds__(RB_PAIRS_BLOCK, 2) k_aw11_dec_pairs(size_t n_i
   __shared__ uint32_t lds[2 * 8 * RB_PAIRS_BLOCK];
   size_t t, item;
   bool active;
-  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, &t, &item, &active);
+  pair_lane((size_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, total_pairs, pair_off, ppi, tile_off, &t, &item, &active);
   const uint32_t j = (uint32_t)(t - pair_off[item]);
   const uint32_t m = pair_off[item + 1] - pair_off[item] - 1;
   const uint32_t sk = sk_idx ? sk_idx[item] : (uint32_t)item;
@@ -1681,8 +1755,11 @@ extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t
   KLAUNCH(ctx, "k_naf_masks", k_naf_masks, dim3(blocks_for(n_sel, 256)), dim3(256), 0, ctx->stream, n_sel, sel_coeff, (uint32_t*)w_masks);
   KLAUNCH(ctx, "k_term_off", k_term_off, dim3(blocks_for(n_items + 1, 256)), dim3(256), 0, ctx->stream, n_items, pair_off, (uint32_t*)w_off);
   const uint32_t ppi = uniform_ppi(n_items, max_pairs, total_pairs);
-  KLAUNCH(ctx, "k_aw11_dec_pairs", k_aw11_dec_pairs, dim3(blocks_for(pair_lanes(n_items, total_pairs, ppi), RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
-          total_pairs, pair_off, ppi, sel_start, sel_ct_row, sel_sk_attr, sel_coeff, ct_c2, ct_row_off, sk_hash, sk_k, sk_attr_off, sk_idx, pl.P, pl.Q,
+  size_t g_lanes = 0;
+  const uint32_t* tile_off = nullptr;
+  if ((rc = gather_lanes(ctx, n_items, max_pairs, total_pairs, pair_off, ppi, &tile_off, &g_lanes)) != RHIP_OK) return rc;
+  KLAUNCH(ctx, "k_aw11_dec_pairs", k_aw11_dec_pairs, dim3(blocks_for(g_lanes, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items,
+          total_pairs, pair_off, ppi, tile_off, sel_start, sel_ct_row, sel_sk_attr, sel_coeff, ct_c2, ct_row_off, sk_hash, sk_k, sk_attr_off, sk_idx, pl.P, pl.Q,
           pl.qref);
   if (total_terms)
     KLAUNCH(ctx, "k_aw11_gather_terms", k_aw11_gather_terms, dim3(blocks_for(total_terms, 64)), dim3(64), 0, ctx->stream, n_items, total_terms,
