@@ -289,6 +289,7 @@ class WalkedG2 {
            uint32_t extra_walks = 0 /* walking arguments per item that are not elements of this array (aw11: the sum of the C3 terms) */);
   void arm();
   void finish(std::vector<uint8_t>* ok);
+  ~WalkedG2();          // an armed request no decrypt consumed (an exception on the way) is withdrawn: its arrays go back to the arena
  private:
   Engine& eng_;
   MemberChecks& mc_;
@@ -300,7 +301,7 @@ class WalkedG2 {
   const std::vector<uint32_t>* woff_;
   std::vector<uint32_t> rest_item_;          // item of every element tested stand-alone on the side context
   size_t k_curve_ = 0, k_rest_ = 0;
-  bool has_rest_ = false;
+  bool has_rest_ = false, armed_ = false;
   DBuf d_verdicts_;                          // fail[n_seg] | count[n_seg]
 };
 

@@ -257,9 +257,14 @@ WalkedG2::WalkedG2(Engine& eng, MemberChecks& mc, const void* dev_g2, size_t cou
 }
 void WalkedG2::arm() {
   eng_.check(rhip_ctx_collect_walk_verdicts(eng_.ctx(), d_verdicts_.as<uint32_t>(), d_verdicts_.as<uint32_t>() + n_seg_), "rhip_ctx_collect_walk_verdicts");
+  armed_ = true;
+}
+WalkedG2::~WalkedG2() {
+  if (armed_) (void)rhip_ctx_collect_walk_verdicts(eng_.ctx(), nullptr, nullptr);
 }
 void WalkedG2::finish(std::vector<uint8_t>* ok) {
   eng_.check(rhip_ctx_collect_walk_verdicts(eng_.ctx(), nullptr, nullptr), "rhip_ctx_collect_walk_verdicts");          // a path that did not consume the request
+  armed_ = false;
   std::vector<uint32_t> v(2 * n_seg_);
   eng_.check(rhip_download(eng_.ctx(), v.data(), d_verdicts_.ptr(), v.size() * 4), "download");
   ok->assign(n_seg_, 1);
