@@ -79,3 +79,35 @@ def test_ragged_lists_with_scalars_and_leading_factors():
     plain = eng.pairing_jobs(off, scaled, qs, lead=lead)
     assert got == plain
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_match_the_one_lane_kernels(seed):
+    """random batch sizes and pair-count distributions (all equal but one, geometric, bimodal, a few giants): the planned launch against
+    k_miller + k_final_exp, item by item"""
+    from rabe_amd import Engine
+    rnd, P, Q = _elements(9, 100 + seed)
+    n_items = rnd.choice([1, 2, 63, 64, 65, 200, 513, 700])
+    kind = seed % 4
+    if kind == 0:
+        counts = [5] * n_items
+        counts[rnd.randrange(n_items)] = 6                       # uniform but for one item
+    elif kind == 1:
+        counts = [min(200, int(rnd.expovariate(0.15))) for _ in range(n_items)]
+    elif kind == 2:
+        counts = [rnd.choice([2, 2, 2, 90]) for _ in range(n_items)]
+    else:
+        counts = [rnd.randrange(0, 4) for _ in range(n_items)]
+        for _ in range(min(3, n_items)):
+            counts[rnd.randrange(n_items)] = rnd.randrange(130, 260)
+    if sum(counts) == 0:
+        counts[0] = 1
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c)
+    n = off[-1]
+    ps, qs = [P[rnd.randrange(9)] for _ in range(n)], [Q[rnd.randrange(9)] for _ in range(n)]
+    eng = Engine(0)
+    eng.set_pairing_mode(1)
+    assert eng.pairing_jobs(off, ps, qs) == eng.pairing_product(off, ps, qs)
+    eng.close()
