@@ -840,8 +840,11 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       // Cy.g2 of every selected leaf is the walking argument of a pairing (the key's side replays prepared lines): the decrypt's own
       // Miller loops say whether it is a member of G2; leaves the policy did not select get the stand-alone test (common.h: WalkedG2)
       if (walk_checks() && lines) {
+        // "every leaf is walked" may only be concluded from the counts for records in the standard layout (their selection is the plan's:
+        // distinct rows); rows matched by NAME can coincide in a crafted record, and then some other row is walked by nobody
         bool all = true;
-        for (size_t j = 0; j < m_items && all; j++) all = (pair_off[j + 1] - pair_off[j] - 1) / 2 == leaf_off[j + 1] - leaf_off[j];
+        for (size_t j = 0; j < m_items && all; j++)
+          all = v[live[j]].standard && (pair_off[j + 1] - pair_off[j] - 1) / 2 == leaf_off[j + 1] - leaf_off[j];
         if (!all) {
           walked_off.push_back(0);
           for (size_t j = 0; j < m_items; j++) {
@@ -1300,8 +1303,8 @@ bool decrypt_packed(Engine& eng, const KpAbeCiphertext& ct, size_t n, const uint
       // D2 of every selected key leaf is the walking argument of a pairing (e2 replays prepared lines): membership out of the decrypt's
       // own Miller loops, the stand-alone test for the leaves the selection left out (common.h: WalkedG2)
       if (walk_checks() && lines) {
-        bool all = true;
-        for (size_t j = 0; j < m_items && all; j++) all = pair_off[j + 1] - pair_off[j] - 1 == leaf_off[j + 1] - leaf_off[j];
+        bool all = true;          // concluded from the counts for standard-layout records only (see bsw::decrypt_packed)
+        for (size_t j = 0; j < m_items && all; j++) all = v[live[j]].standard && pair_off[j + 1] - pair_off[j] - 1 == leaf_off[j + 1] - leaf_off[j];
         if (!all) {
           walked_off.push_back(0);
           for (size_t j = 0; j < m_items; j++) {
@@ -1710,8 +1713,8 @@ bool decrypt_packed(Engine& eng, const Aw11GlobalKey& gk, const Aw11SecretKey& s
       mc->add(2, d_c3.ptr(), total, d_row_off.as<uint32_t>(), m_items);          // C3 enters its pairing as a SUM: every term keeps the stand-alone test
       // C2 of every selected row is the walking argument of a pairing; one more argument walks per item (the sum of the C3 terms)
       if (walk_checks()) {
-        bool all = true;
-        for (size_t j = 0; j < m_items && all; j++) all = pair_off[j + 1] - pair_off[j] - 1 == row_off[j + 1] - row_off[j];
+        bool all = true;          // concluded from the counts for standard-layout records only (see bsw::decrypt_packed)
+        for (size_t j = 0; j < m_items && all; j++) all = v[live[j]].standard && pair_off[j + 1] - pair_off[j] - 1 == row_off[j + 1] - row_off[j];
         if (!all) {
           walked_off.push_back(0);
           for (size_t j = 0; j < m_items; j++) {

@@ -194,7 +194,7 @@ void MemberChecks::add(int which, const void* dev, size_t count, const uint32_t*
   flags_.emplace_back(fold ? n_seg : count, 1u);
   dev_.emplace_back(&eng_, (fold ? n_seg : count) * 4);
   if (!count) return;
-  if (which == 3 && cx_ != eng_.ctx()) {          // Gt: beside the decrypt's final exponentiation (see collect())
+  if (which == 3 && cx_ != eng_.ctx() && count >= 4096) {          // Gt: beside the decrypt's final exponentiation (see collect()); a small batch's Miller kernel leaves the chip empty anyway
     if (!requested_) { eng_.check(rhip_ctx_release_after_miller(eng_.ctx(), cx_), "rhip_ctx_release_after_miller"); requested_ = true; }
     later_.push_back({flags_.size() - 1, dev, count, dev_seg_off, n_seg, scale});
     return;
