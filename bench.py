@@ -697,7 +697,7 @@ def configs_leg(args):
     # (key, config, steps, extra flags, items of the CPU sample): "3_mixed" is SURVEY 8d's 50 %-OR variant of config 3, the "_ragged" legs draw
     # every policy's leaf count from 10 .. the config's (a batch of mixed shapes)
     legs = (("2_ragged", 2, 16, ["--ragged", "--no-single-batch", "--no-configs-leg", "--no-host-io-leg", "--wide-window", "0"], 0),
-            ("3", 3, 8, [], 5), ("3_mixed", 3, 8, ["--tree", "mixed"], 0), ("3_ragged", 3, 8, ["--ragged"], 0), ("4", 4, 8, [], 2), ("5", 5, 8, [], 3))
+            ("3", 3, 8, [], 5), ("3_mixed", 3, 8, ["--tree", "mixed"], 0), ("3_ragged", 3, 8, ["--ragged"], 0), ("4", 4, 8, [], 2), ("4_ragged", 4, 8, ["--ragged", "--no-object-api"], 0), ("5", 5, 8, [], 3), ("5_ragged", 5, 8, ["--ragged", "--no-object-api"], 0))
     for key, cfg, steps, extra, cpu_n in legs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--steps", str(steps), "--warmup", str(steps),
                "--min-time", str(args.configs_min_time), "--seed", str(args.seed), "--no-object-api"] + extra

@@ -527,6 +527,9 @@ class LswBench:
         for _ in range(args.policies):
             names = list(self.attrs)
             prnd.shuffle(names)
+            if args.ragged:                      # keys of mixed shapes: 10 .. n_attr leaves per policy (an even count for the mixed tree)
+                k = prnd.randrange(10, self.n_attr + 1)
+                names = names[:k - (k % 2)]
             self.trees.append(make_tree(args.tree, names))
         t0 = time.perf_counter()
         self.tt = hp.TreeTables(self.trees)
@@ -546,7 +549,8 @@ class LswBench:
         B, P = self.B, len(self.trees)
         GB = G * B
         self.G, self.lanes = G, lanes
-        pol = [i % P for i in range(GB)]
+        # ragged: the items of one policy are contiguous inside every step's batch (like config 3's mixed-shape batch)
+        pol = [((i % B) * P // B) if r.args.ragged else i % P for i in range(GB)]
         sel_start_p, so, sel_sk, sel_ct, sel_z = [], 0, [], [], []
         for idx, cta, z in self.sel:
             sel_start_p.append(so)
@@ -611,7 +615,7 @@ class LswBench:
         m = sum(len(s[0]) for s in self.sel) / len(self.sel)
         return {"workload": "LSW KP-ABE, keygen under a %d-leaf %s policy (%d distinct) + decrypt of a pre-made %d-attribute ciphertext, batch %d per GPU"
                             % (self.n_attr, self.r.args.tree, len(self.trees), self.n_attr, self.B),
-                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "pruned_leaves_avg": round(m, 2),
+                "attrs": self.n_attr, "policies": len(self.trees), "tree": self.r.args.tree, "ragged": bool(self.r.args.ragged), "pruned_leaves_avg": round(m, 2),
                 "pairings_per_item": round(m + 1, 1), "reference_pairings_per_item": round(2 * m, 1), "prepared_ciphertext_e2": self.e2_lines is not None,
                 "table_build_ms_per_public_key": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3)}
 
@@ -697,6 +701,9 @@ class Aw11Bench:
         for _ in range(args.policies):
             names = list(self.attrs)
             prnd.shuffle(names)
+            if args.ragged:                      # ciphertexts of mixed shapes: policies over 10 .. n_attr of the attributes
+                k = prnd.randrange(10, self.n_attr + 1)
+                names = names[:k - (k % 2)]
             self.trees.append(make_tree("nested" if args.tree == "flat" else args.tree, names, binary_and_only=True))
         t0 = time.perf_counter()
         self.tt = hp.TreeTables(self.trees)
@@ -717,7 +724,7 @@ class Aw11Bench:
         B, P = self.B, len(self.trees)
         GB = G * B
         self.G, self.lanes = G, lanes
-        pol = [i % P for i in range(GB)]
+        pol = [((i % B) * P // B) if r.args.ragged else i % P for i in range(GB)]
         sel_start_p, so, sel_ct, sel_sk, sel_z = [], 0, [], [], []
         for idx, ska, z in self.sel:
             sel_start_p.append(so)
@@ -787,7 +794,8 @@ class Aw11Bench:
         tree = "nested" if self.r.args.tree == "flat" else self.r.args.tree
         return {"workload": "AW11 multi-authority CP-ABE, %d authorities x %d attributes, %s binary-AND policy over all %d (%d distinct), batch %d "
                             "encrypt+decrypt per GPU" % (self.n_auth, self.n_attr // self.n_auth, tree, self.n_attr, len(self.trees), self.B),
-                "attrs": self.n_attr, "authorities": self.n_auth, "policies": len(self.trees), "tree": tree, "pruned_leaves_avg": round(m, 2),
+                "attrs": self.n_attr, "authorities": self.n_auth, "policies": len(self.trees), "tree": tree, "ragged": bool(self.r.args.ragged),
+                "pruned_leaves_avg": round(m, 2),
                 "pairings_per_item": round(m + 1, 1), "reference_pairings_per_item": round(2 * m + m + 1, 1),
                 "table_build_ms_per_public_key_set": round(self.table_build_ms, 1), "host_prep_ms_per_policy": round(self.host_prep_ms_per_policy, 3),
                 "attribute_tables": "16-bit windows for the %d per-attribute bases (%.0f GB, opted in with RABE_AW11_ATTR_W16=1) "
