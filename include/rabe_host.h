@@ -292,6 +292,16 @@ int32_t rabe_bdabe_decrypt(rabe_host* h, const void* uk, const void* ct, uint8_t
 int32_t rabe_bdabe_decrypt_gt(rabe_host* h, const void* uk, const void* ct, uint8_t out_gt[384]);
 int32_t rabe_bdabe_decrypt_batch(rabe_host* h, size_t n, const void* const* uks, const void* const* cts, int32_t* status, uint8_t** plaintexts,
                                  size_t* lens);
+/* bdabe::decrypt (bdabe/mod.rs:359-399) / mke08::decrypt (mke08/mod.rs:343-380) of n_items serialized ciphertexts (one blob + n_items + 1
+ * offsets, ct_len) under ONE user key -- same conventions as rabe_ac17_cp_decrypt_packed: bounds and, unless RABE_PACKED_TRUSTED, group
+ * membership of every decoded element (one batched pass per group over the whole blob); status[i] = 0 / -1, plaintexts back to back in
+ * pt_buf at pt_off[i] (nothing for a failed item); returns 1 when pt_cap is too small (sum of the sealed lengths always suffices).  The
+ * pairings of the whole batch are one rhip_pairing_jobs launch set (<= 2 m + 3 Miller loops per item on a few accumulators, one final
+ * exponentiation per item), the sealed plaintexts are opened on the device (Level S): no Gt crosses PCIe. */
+int32_t rabe_bdabe_decrypt_packed(rabe_host* h, const void* uk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                  int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off);
+int32_t rabe_mke08_decrypt_packed(rabe_host* h, const void* uk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                  int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off);
 int32_t rabe_mke08_setup(rabe_host* h, void** pk, void** msk);
 int32_t rabe_mke08_keygen(rabe_host* h, const void* pk, const void* msk, const char* name, void** uk);
 int32_t rabe_mke08_authgen(rabe_host* h, const char* name, void** ska);

@@ -611,6 +611,86 @@ int32_t queue_call(rabe_host* h, T* t, void** obj, uint8_t** out, size_t* len) {
 }
 }  // namespace
 
+// ---- packed decrypts of the DNF schemes: the records of a blob become objects (all cores), the membership pass runs once per group over
+// every element of the blob, the objects go through the schemes' batch decrypt (one pairing-job launch set, sealed parts opened on the device)
+template <class CT>
+static std::vector<std::unique_ptr<CT>> parse_blob(rabe_host* h, int32_t kind, size_t n, const uint8_t* blob, size_t len, const uint64_t* off, bool trusted,
+                                                   std::vector<std::string>* errors) {
+  std::vector<std::unique_ptr<CT>> objs(n);
+  errors->assign(n, std::string());
+  struct Els { std::vector<size_t> g1, g2, gt; };
+  std::vector<Els> els(n);
+  for (size_t i = 0; i < n; i++)
+    if (off[i] > off[i + 1] || off[i + 1] > len) (*errors)[i] = "deserialize: record offsets outside the blob";
+  rabe::parallel_for(n, [&](size_t i) {
+    if (!(*errors)[i].empty()) return;
+    try {
+      R r(blob + off[i], (size_t)(off[i + 1] - off[i]));
+      objs[i].reset((CT*)deser(r, kind));
+      for (size_t o : r.g1s) els[i].g1.push_back((size_t)off[i] + o);
+      for (size_t o : r.g2s) els[i].g2.push_back((size_t)off[i] + o);
+      for (size_t o : r.gts) els[i].gt.push_back((size_t)off[i] + o);
+    } catch (const std::exception& ex) {
+      objs[i].reset();
+      (*errors)[i] = ex.what();
+      if ((*errors)[i].empty()) (*errors)[i] = "malformed record";
+    }
+  });
+  if (trusted) return objs;
+  Engine& e = h->eng;
+  Engine::ArenaScope scope(e);
+  auto pass = [&](int which, size_t sz, const char* what) {
+    std::vector<uint8_t> flat;
+    std::vector<uint32_t> owner;
+    for (size_t i = 0; i < n; i++) {
+      if (!objs[i]) continue;
+      const auto& v = which == 1 ? els[i].g1 : which == 2 ? els[i].g2 : els[i].gt;
+      for (size_t o : v) { flat.insert(flat.end(), blob + o, blob + o + sz); owner.push_back((uint32_t)i); }
+    }
+    if (owner.empty()) return;
+    DBuf din(&e, flat.data(), flat.size()), dok(&e, owner.size() * 4);
+    const int32_t rc = which == 1 ? rhip_g1_on_curve(e.ctx(), owner.size(), din.as<rhip_g1>(), dok.as<uint32_t>())
+                     : which == 2 ? rhip_g2_in_subgroup(e.ctx(), owner.size(), din.as<rhip_g2>(), dok.as<uint32_t>())
+                                  : rhip_gt_is_member(e.ctx(), owner.size(), din.as<rhip_gt>(), dok.as<uint32_t>());
+    e.check(rc, what);
+    std::vector<uint32_t> ok(owner.size());
+    dok.download(ok.data(), ok.size() * 4);
+    for (size_t t = 0; t < ok.size(); t++)
+      if (!ok[t] && (*errors)[owner[t]].empty())
+        (*errors)[owner[t]] = std::string("deserialize: a ") + what + " element is not a group member (FieldError::NotMember)";
+  };
+  pass(1, 64, "G1");
+  pass(2, 128, "G2");
+  pass(3, 384, "Gt");
+  for (size_t i = 0; i < n; i++) if (!(*errors)[i].empty()) objs[i].reset();
+  return objs;
+}
+template <class CT, class UK, class BATCH>
+static int32_t dnf_decrypt_packed(rabe_host* h, int32_t kind, const void* uk, size_t n, const uint8_t* blob, size_t len, const uint64_t* off, uint32_t flags,
+                                  int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, BATCH batch) {
+  std::vector<std::string> errors;
+  auto objs = parse_blob<CT>(h, kind, n, blob, len, off, (flags & RABE_PACKED_TRUSTED) != 0, &errors);
+  std::vector<const UK*> sks;
+  std::vector<const CT*> cts;
+  std::vector<size_t> who;
+  for (size_t i = 0; i < n; i++) if (objs[i]) { sks.push_back((const UK*)uk); cts.push_back(objs[i].get()); who.push_back(i); }
+  std::vector<DecryptResult> res;
+  if (!who.empty()) res = batch(sks, cts);
+  std::vector<const Bytes*> pt(n, nullptr);
+  for (size_t t = 0; t < who.size(); t++) {
+    if (res[t].ok) pt[who[t]] = &res[t].plaintext;
+    else errors[who[t]] = res[t].error.empty() ? std::string("decryption failed") : res[t].error;
+  }
+  pt_off[0] = 0;
+  for (size_t i = 0; i < n; i++) pt_off[i + 1] = pt_off[i] + (pt[i] ? pt[i]->size() : 0);
+  if (pt_off[n] > pt_cap || (pt_off[n] && !pt_buf)) return 1;
+  for (size_t i = 0; i < n; i++) {
+    status[i] = pt[i] ? 0 : -1;
+    if (pt[i] && !pt[i]->empty()) memcpy(pt_buf + pt_off[i], pt[i]->data(), pt[i]->size());
+  }
+  for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
+  return 0;
+}
 extern "C" {
 
 int32_t rabe_host_create(int32_t device, rabe_host** out) {
@@ -1449,6 +1529,22 @@ int32_t rabe_bdabe_decrypt_batch(rabe_host* h, size_t n, const void* const* uks,
   for (size_t i = 0; i < n; i++) { s.push_back((const bdabe::BdabeUserKey*)uks[i]); c.push_back((const bdabe::BdabeCiphertext*)cts[i]); }
   give_results(h, bdabe::decrypt_batch(h->eng, s, c), status, plaintexts, lens);
   return 0;
+  GUARD_END(h)
+}
+int32_t rabe_bdabe_decrypt_packed(rabe_host* h, const void* uk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                  int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  return dnf_decrypt_packed<bdabe::BdabeCiphertext, bdabe::BdabeUserKey>(
+      h, RABE_BDABE_CT, uk, n_items, ct_blob, ct_len, ct_off, flags, status, pt_buf, pt_cap, pt_off,
+      [&](const std::vector<const bdabe::BdabeUserKey*>& s, const std::vector<const bdabe::BdabeCiphertext*>& c) { return bdabe::decrypt_batch(h->eng, s, c); });
+  GUARD_END(h)
+}
+int32_t rabe_mke08_decrypt_packed(rabe_host* h, const void* uk, size_t n_items, const uint8_t* ct_blob, size_t ct_len, const uint64_t* ct_off, uint32_t flags,
+                                  int32_t* status, uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off) {
+  GUARD_BEGIN
+  return dnf_decrypt_packed<mke08::Mke08Ciphertext, mke08::Mke08UserKey>(
+      h, RABE_MKE08_CT, uk, n_items, ct_blob, ct_len, ct_off, flags, status, pt_buf, pt_cap, pt_off,
+      [&](const std::vector<const mke08::Mke08UserKey*>& s, const std::vector<const mke08::Mke08Ciphertext*>& c) { return mke08::decrypt_batch(h->eng, s, c); });
   GUARD_END(h)
 }
 int32_t rabe_mke08_setup(rabe_host* h, void** pk, void** msk) {

@@ -51,3 +51,10 @@ def decrypt_gt(host, uk, ct):
 
 def decrypt_batch(host, uks, cts):
     return batch_decrypt(host, "rabe_bdabe_decrypt_batch", (), uks, cts)
+
+
+def decrypt_packed(host, uk, ct_blob, ct_off, out=None, trusted=False):
+    """n serialized BdabeCiphertext records under ONE user key (rabe_bdabe_decrypt_packed).
+    Returns (pt_blob view, pt_off uint64 [n+1], status int32 [n])."""
+    from ..hostlib import packed_decrypt
+    return packed_decrypt(host, "rabe_bdabe_decrypt_packed", (uk.ptr,), ct_blob, ct_off, out, trusted)

@@ -381,6 +381,22 @@ def test_bdabe_reference_cases(host):
     # the batch form: per-item failures, the rest decrypt
     got = bdabe.decrypt_batch(host, [sk, sk, sk3, sk], [ct_and, ct_not, ct3, ct_or])
     assert got == [PLAINTEXT, None, PLAINTEXT, PLAINTEXT]
+    # the packed form (one blob of records under one key): the same plaintexts, a record the key does not satisfy, a truncated one and one
+    # with an element off its group fail alone
+    import numpy as np
+    recs = [c.serialize() for c in (ct_and, ct_not, ct_or, ct_human)] * 9
+    pts_want = [PLAINTEXT, None, PLAINTEXT, PLAINTEXT] * 9
+    bad = bytearray(recs[4])
+    bad[len(bad) // 2] ^= 0x40                       # somewhere inside an element or the sealed part
+    recs[4] = bytes(bad)
+    pts_want[4] = None
+    recs[8] = recs[8][:50]
+    pts_want[8] = None
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    for trusted in (False, True):
+        out, oo, st = bdabe.decrypt_packed(host, sk, b"".join(recs), off, trusted=trusted)
+        got = [bytes(out[int(oo[i]):int(oo[i + 1])]) if st[i] == 0 else None for i in range(len(recs))]
+        assert got == pts_want
     # a key that passes traverse_policy (it holds one OR branch) but satisfies no conjunction carried by the ciphertext: AES fails
     sk_x = bdabe.keygen(host, pk, a1, "u2")
     bdabe.request_attribute_sk(host, sk_x, a1, "aa1::X")
@@ -411,6 +427,13 @@ def test_mke08_reference_cases(host):
     sk_other = mke08.keygen(host, pk, msk, "user2")
     mke08.request_authority_sk(host, sk_other, "auth1::A", a1)
     assert mke08.decrypt_batch(host, [sk, sk_other, sk_other, sk], [cts[0], cts[0], cts[1], cts[2]]) == [PLAINTEXT, None, PLAINTEXT, PLAINTEXT]
+    import numpy as np
+    recs = [c.serialize() for c in cts] * 11
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    out, oo, st = mke08.decrypt_packed(host, sk, b"".join(recs), off)
+    assert not st.any() and all(bytes(out[int(oo[i]):int(oo[i + 1])]) == PLAINTEXT for i in range(len(recs)))
+    out, oo, st = mke08.decrypt_packed(host, sk_other, b"".join(recs), off, trusted=True)
+    assert [int(x) for x in st] == [-1, 0, -1] * 11            # sk_other holds auth1::A alone: only the plain OR opens
     with pytest.raises(hl.RabeError):
         mke08.request_authority_pk(host, pk, "auth2::B", a1)
     for o in (pk, msk, a1, sk, pks[0], cts[2]):
