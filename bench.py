@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--tree", default="flat", choices=["flat", "nested", "mixed"],
                     help="configs 3-5: shape of the access tree (flat n-ary AND / balanced binary ANDs / AND over two-leaf ORs)")
     ap.add_argument("--ragged", action="store_true",
-                    help="a batch of mixed shapes: every policy draws its leaf count from 10 .. --attrs (config 2: rows per ciphertext, configs 3: pairs per item)")
+                    help="a batch of mixed shapes: every policy draws its leaf count from 10 .. --attrs (config 2: rows per ciphertext; configs 3, 4, 5: pairs per item)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--group", type=int, default=16, help="steps submitted as ONE launch set (their batches are contiguous in HBM)")
     ap.add_argument("--inflight", type=int, default=0,
