@@ -4,6 +4,7 @@
 // launches the same functions as HIP kernels.
 #include "../../rabe_amd/csrc/bn254/io.h"
 #include "../../rabe_amd/csrc/bn254/coop3.h"
+#include "../../rabe_amd/csrc/bn254/coop6.h"
 #include <pthread.h>
 #include <string.h>
 
@@ -369,4 +370,79 @@ int hs_c3_pairing(const uint32_t* p, const uint32_t* zscale, const uint32_t* q, 
   return fp12_eq(jobs[0].out, jobs[1].out) && fp12_eq(jobs[0].out, jobs[2].out);
 }
 
+}  // extern "C"
+
+// ---- six-lane cooperative Fq12 arithmetic (coop6.h) emulated with six host threads per group: the group's slots are a shared
+// array, sync() is a thread barrier, everything else is the exact code the device lanes run.
+struct C6Shared { pthread_barrier_t bar; Fp2 rows[C6_ROWS][6]; };
+struct HostCX6 {
+  C6Shared* sh;
+  int k;
+  int role() const { return k; }
+  Fp2 ld(int row, int lane) const { return sh->rows[row][lane]; }
+  void st(int row, const Fp2& v) const { sh->rows[row][k] = v; }
+  void sync() const { pthread_barrier_wait(&sh->bar); }
+};
+// op: 0 a*b, 1 a^2, 2 cyclotomic a^2, 3 a * line (l0, l1, l3 in b's first three Fq2), 4 final exponentiation of a, 5 a^u,
+//     6 frob1, 7 frob2, 8 frob3, 9 Miller loop multi + final exponentiation (a, b unused)
+struct C6Job { HostCX6 cx; int op; Fp12 a, b; Fp2 out; HostMultiAcc acc; };
+static void* c6_worker(void* arg) {
+  C6Job* j = (C6Job*)arg;
+  const HostCX6 cx = j->cx;
+  const int k = cx.k;
+  const Fp2 ak = c6_coeff(j->a, k), bk = c6_coeff(j->b, k);
+  switch (j->op) {
+    case 0: j->out = c6_mul(cx, ak, bk); break;
+    case 1: c6_put_f(cx, ak); c6_sqr(cx); j->out = c6_mine(cx); break;
+    case 2: c6_put_f(cx, ak); c6_csqr(cx); j->out = c6_mine(cx); break;
+    case 3:
+      c6_put_f(cx, ak);
+      cx.sync();
+      if (k == 3) { cx.st(C6_L0, j->b.c0.a0); cx.st(C6_L1, j->b.c0.a1); cx.st(C6_L3, j->b.c0.a2); }
+      cx.sync();
+      j->out = c6_dot(cx, C6_OP_LINE, 3);
+      break;
+    case 4: j->out = c6_final_exponentiation(cx, ak); break;
+    case 5: j->out = c6_exp_u(cx, ak); break;
+    case 6: case 7: case 8: j->out = c6_frob(cx, ak, j->op - 5); break;
+    default: {
+      const Fp2 m = c6_miller_loop_multi(cx, j->acc, j->acc.count());
+      j->out = c6_final_exponentiation(cx, m);
+    }
+  }
+  return nullptr;
+}
+static void c6_run(int op, const Fp12& a, const Fp12& b, const HostMultiAcc* acc, uint32_t* out) {
+  C6Shared sh;
+  pthread_barrier_init(&sh.bar, nullptr, 6);
+  C6Job jobs[6];
+  pthread_t th[6];
+  for (int k = 0; k < 6; k++) {
+    jobs[k] = C6Job{HostCX6{&sh, k}, op, a, b, Fp2{}, acc ? *acc : HostMultiAcc{}};
+    pthread_create(&th[k], nullptr, c6_worker, &jobs[k]);
+  }
+  for (int k = 0; k < 6; k++) pthread_join(th[k], nullptr);
+  pthread_barrier_destroy(&sh.bar);
+  for (int k = 0; k < 6; k++) store_fp2(out + 16 * c6_tower_index(k), jobs[k].out);
+}
+extern "C" {
+void hs_c6_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { c6_run(op, load_gt(a), b ? load_gt(b) : fp12_one(), nullptr, out); }
+// FE( c6_miller_loop_multi ) over n pairs of one group; same arguments as hs_pairing_multi
+void hs_c6_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+  G1Aff* P = new G1Aff[n];
+  G2Aff* Q = new G2Aff[n];
+  LineCoeffs* lines = new LineCoeffs[(size_t)n * RB_MILLER_LINES];
+  G2Hom* T = new G2Hom[n];
+  int* kk = new int[n];
+  for (int j = 0; j < n; j++) {
+    P[j] = load_g1(p + 16 * j);
+    Q[j] = load_g2(q + 32 * j);
+    kk[j] = kinds[j];
+    if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
+    if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
+  }
+  const HostMultiAcc acc{n, kk, P, Q, lines, T, nullptr};
+  c6_run(9, fp12_one(), fp12_one(), &acc, out);
+  delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
+}
 }  // extern "C"

@@ -175,6 +175,34 @@ def gen_wide_mul3(out):
     out.append("}")
 
 
+def gen_wide_mac3(out):
+    out.append("// the same three products ADDED to the running 512-bit sums T0, T1, T2 (mod 2^512; bn254/coop6.h keeps the true sums below it):")
+    out.append("// every column starts with the sum's word (a multiply-add by the constant 1, as in redc2_fp), then the products of wide_mul3")
+    out.append("template <class A>")
+    out.append("RB_HD void wide_mac3(uint32_t* T0, uint32_t* T1, uint32_t* T2, const A& a0, const A& b0, const A& a1, const A& b1, const uint32_t* a2,")
+    out.append("                     const uint32_t* b2) {")
+    out.append("  uint64_t acc0 = 0, acc1 = 0, acc2 = 0, c0_, c1_, c2_;")
+    out.append("  uint32_t ovf0, ovf1, ovf2;")
+    for i in range(8):
+        out.append("  const uint32_t x0_%d = a0[%d], y0_%d = b0[%d], x1_%d = a1[%d], y1_%d = b1[%d], x2_%d = a2[%d], y2_%d = b2[%d];" % ((i,) * 12))
+    accs, ovfs, cars = ["acc0", "acc1", "acc2"], ["ovf0", "ovf1", "ovf2"], ["c0_", "c1_", "c2_"]
+    for k in range(16):
+        lo, hi = (0, k) if k < 8 else (k - 7, 7)
+        tops = [i for i in range(lo, hi + 1) if k >= 7 and (i == 7 or k - i == 7)]
+        rest = [i for i in range(lo, hi + 1) if i not in tops]
+        out.append("  // column %d" % k)
+        out.append("  const uint32_t t0_%d = T0[%d], t1_%d = T1[%d], t2_%d = T2[%d];" % ((k,) * 6))
+        macs = [(["t0_%d" % k, "t1_%d" % k, "t2_%d" % k], 1, "const", False)]
+        macs += [(["x%d_%d" % (c, i) for c in range(3)], ["y%d_%d" % (c, k - i) for c in range(3)], "v", False) for i in tops]
+        macs += [(["x%d_%d" % (c, i) for c in range(3)], ["y%d_%d" % (c, k - i) for c in range(3)], "v", True) for i in rest]
+        have = [False]
+        pack(out, 3, macs, accs, ovfs, cars, have)
+        out.append("  T0[%d] = (uint32_t)acc0; T1[%d] = (uint32_t)acc1; T2[%d] = (uint32_t)acc2;" % (k, k, k))
+        if k < 15:
+            shift(out, 3, have[0])
+    out.append("}")
+
+
 def gen_redc2(out, mod, safe, last_safe):
     out.append("// two Montgomery reductions over Fp of 512-bit values (< 2^256 p) in lockstep; results < p")
     out.append("RB_HD void redc2_fp(uint32_t* r0, uint32_t* r1, const uint32_t* W0, const uint32_t* W1) {")
@@ -258,6 +286,8 @@ def main():
         out.append("}")
     out.append("")
     gen_wide_mul3(out)
+    out.append("")
+    gen_wide_mac3(out)
     out.append("")
     gen_redc2(out, mod, redc_safe, redc_last)
     out.append("")
