@@ -1,6 +1,8 @@
 """Shared plumbing of bench.py's configurations: group splitting, repeated exactly-K-step timed regions, rank-consistent
 loop control, torch-owned device buffers.  Measurement only -- no group arithmetic here."""
 import ctypes
+import json
+import sys
 import time
 
 G1_GEN = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
@@ -34,7 +36,7 @@ def same_on_all_ranks(flag):
     """rank 0's decision, everywhere (loop control of the repeated timed regions)"""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return bool(flag)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
@@ -50,7 +52,7 @@ def timed_regions(run_steps, sync_all, min_time, max_regions=200):
     from rabe_amd import shard
 
     def barrier():
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.barrier()
 
     regions = []
@@ -85,3 +87,15 @@ def cpu_model():
         pass
     import platform
     return platform.processor() or platform.machine()
+
+
+def emit_line(result):
+    """rank 0's ONE JSON line, as the LAST line of stdout: RCCL writes a version banner through C stdio, which would otherwise be flushed
+    at exit -- after the line (found on the GPU box, RABE_FORCE_DIST run) -- so everything buffered is flushed first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(result), flush=True)

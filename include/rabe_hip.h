@@ -47,7 +47,12 @@ typedef struct rhip_ctx rhip_ctx;
 #define RHIP_ERR_NOT_MEMBER (-4)  /* an input point is not on the curve (rabe_bn::FieldError::NotMember, src/error.rs:60-69) */
 
 /* ---- context (one per host thread / per GPU; single owner) ------------------------------------ */
+/* The first context of a device runs a known-answer self-test of the BN254 field / tower arithmetic on every SIMD (adversarial
+ * carry patterns through every multiply-accumulate and carry-chain form; ~1 ms; bn254/selftest.h) and refuses the device
+ * (RHIP_ERR_HIP, message in rhip_last_error(NULL)) on any mismatch.  RABE_NO_SELFTEST=1 skips it. */
 int32_t rhip_ctx_create(int32_t device, rhip_ctx** out);
+/* number of distinct SIMDs the self-test of this context's device ran on (diagnostic) */
+int32_t rhip_ctx_selftest_info(rhip_ctx* ctx, uint32_t* simds_checked);
 void rhip_ctx_destroy(rhip_ctx* ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
 int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* hip_stream);
@@ -57,8 +62,10 @@ const char* rhip_last_error(rhip_ctx* ctx);
  * rhip_ctx_timing_read drains the record as "kernel_name total_ms launches\n" lines. */
 int32_t rhip_ctx_timing(rhip_ctx* ctx, int32_t enable);
 int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len);
-/* pairing kernels: 0 = auto (three cooperating lanes per pairing for launches that would under-fill the chip,
- * one lane per pairing otherwise), 1 = always one lane, 3 = always three lanes.  Results are identical. */
+/* pairing kernels: 0 = auto (cooperating lanes for launches that would under-fill the chip, one lane per item and chunk
+ * otherwise), 1 = always one lane, 3 = three lanes per pairing (pairwise paths), 6 = six lanes per Fq12 accumulator
+ * (k_miller_c6 / k_final_exp_c6: one Fq2 coefficient per lane).  Results are identical.  RABE_PAIRING_MODE in the
+ * environment of rhip_ctx_create presets the mode (A/B runs). */
 int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode);
 /* number of compute units / device name of the context's GPU */
 int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len);

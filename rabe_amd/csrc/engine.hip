@@ -107,6 +107,17 @@ extern "C" int32_t rhip_ctx_create(int32_t device, rhip_ctx** out) {
   e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return create_fail("hipStreamCreateWithFlags", e); }
   c->stream = c->own_stream;
+  if (const char* pm = getenv("RABE_PAIRING_MODE")) {           // A/B runs of whole test suites: 1 / 3 / 6 as rhip_ctx_set_pairing_mode
+    const int m = atoi(pm);
+    if (m == 1 || m == 3 || m == 6) c->pairing_mode = m;
+  }
+  // known answers of the field arithmetic on every SIMD of THIS device before anything is computed with it (bn254/selftest.h)
+  if (rhip_device_selftest(c, nullptr, nullptr) != RHIP_OK) {
+    g_create_err = c->err;
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RHIP_ERR_HIP;
+  }
   {
     std::lock_guard<std::mutex> g(g_live_mu);
     g_live.insert(c);
@@ -1176,17 +1187,19 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
     else started = nullptr;
   }
   live.unlock();
+  // the six-lane kernel (engine_coop.hip) for launches that leave most of the chip idle: the same values, a chain six times shorter
+  if (rhip_use_c6(ctx, n_items, 0)) return rhip_launch_final_exp_c6(ctx, n_items, off, stride, mill, mul_in, out, started);
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks), dim3(RB_FE_BLOCK), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
           (uint32_t*)ctx->fe_ws, lanes, started);
   return RHIP_OK;
 }
 bool rhip_use_c3(const rhip_ctx* ctx, size_t n_pairs) {
-  if (ctx->pairing_mode == 1) return false;
+  if (ctx->pairing_mode == 1 || ctx->pairing_mode == 6) return false;
   if (ctx->pairing_mode == 3) return true;
   return n_pairs * 3 <= (size_t)ctx->n_cu * 4 * 63 / 4;      // at most a quarter of the SIMDs busy with one lane each
 }
 extern "C" int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode) {
-  if (!ctx || (mode != 0 && mode != 1 && mode != 3)) return RHIP_ERR_ARG;
+  if (!ctx || (mode != 0 && mode != 1 && mode != 3 && mode != 6)) return RHIP_ERR_ARG;
   ctx->pairing_mode = mode;
   return RHIP_OK;
 }

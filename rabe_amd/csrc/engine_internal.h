@@ -51,7 +51,7 @@ struct rhip_ctx {
   void* work[N_WORK] = {};
   size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
-  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing
+  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per Fq12 accumulator (engine_coop.hip)
   void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)
   uint32_t* walk_fail = nullptr;    // one-shot (rhip_ctx_collect_walk_verdicts): per-item verdict / count arrays of the next pair-list launch
   uint32_t* walk_count = nullptr;
@@ -631,6 +631,28 @@ struct DevLineLoad {
     return LineCoeffs{ld_fp2_m(p), ld_fp2_m(p + 16), ld_fp2_m(p + 32)};
   }
 };
+
+// the multi-pairing kernels' launch geometry and the device-made plan of a ragged batch (engine_jobs.hip: k_plan_*, k_miller_multi;
+// engine_coop.hip: k_miller_c6 maps its groups to (item, chunk) exactly as k_miller_multi maps its lanes)
+#define RB_MILLER_BLOCK 256
+struct MillerPlan {
+  uint32_t C, W, L, pad;
+  uint32_t base[66];            // base[s]: where the entries of s pairs start in the list (sizes descending)
+  uint32_t cursor[66];
+};
+#define RHIP_Q_WALK 0xFFFFFFFFu
+#define RHIP_Q_SKIP 0xFFFFFFFEu
+// six-lane cooperative pairing kernels (engine_coop.hip, bn254/coop6.h)
+bool rhip_use_c6(const rhip_ctx* ctx, size_t n_items, size_t max_pairs);
+void rhip_choose_chunks_c6(const rhip_ctx* ctx, size_t n_items, size_t max_pairs, uint32_t* L, uint32_t* C);
+int32_t rhip_launch_miller_c6(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
+                              const uint32_t* qref, const void* lines, void* ws, void* mill, const MillerPlan* plan, const void* work, const uint32_t* chunk_off,
+                              size_t groups);
+int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                 uint32_t* started);
+
+// known-answer check of the field arithmetic on every SIMD (engine_coop.hip; once per device and process)
+int32_t rhip_device_selftest(rhip_ctx* ctx, uint32_t* simds, uint32_t* mismatches);
 
 // the pairwise AC17 decrypt paths of engine.hip (one lane per pairing / per pairing couple), behind the public entry points
 // of engine_jobs.hip

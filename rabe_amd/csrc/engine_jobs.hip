@@ -74,8 +74,6 @@ __device__ __forceinline__ bool fr_shorten(uint32_t k[8]) {
 // ------------------------------------------------------------------------------------------------ pair lists
 // A batch's pairs after the gather kernel: P (affine Montgomery), Q (affine Montgomery, walking pairs only) and
 // qref: RHIP_Q_WALK, RHIP_Q_SKIP (an argument at infinity: the pair contributes 1) or the prepared-line block of Q.
-#define RHIP_Q_WALK 0xFFFFFFFFu
-#define RHIP_Q_SKIP 0xFFFFFFFEu
 struct PairLists {
   G1M* P;
   G2M* Q;
@@ -203,7 +201,6 @@ static int32_t gather_lanes(rhip_ctx* ctx, size_t n_items, size_t max_pairs, siz
 // The Fq12 accumulator of a lane lives in LDS (LdsHomeT, engine_internal.h) -- nothing of the loop goes to scratch.  Blocks of four
 // waves: a block owns one CU (see rb_facc_lds4), so that a launch smaller than the chip leaves WHOLE CUs to whatever else is running
 // (launch sets in flight on other streams: their 256-thread blocks need a wave slot on every SIMD of a CU).
-#define RB_MILLER_BLOCK 256
 struct DevMultiAcc : LdsHomeT<4> {
   const G1M* P;
   const G2M* Q;
@@ -261,11 +258,6 @@ struct DevMultiAcc : LdsHomeT<4> {
 // the list.  Every block of the launch then has work, the blocks of one size are spread over the XCDs by the round-robin of consecutive
 // blocks, and the longest ones start first; C was chosen ON THE DEVICE from the batch's histogram of pair counts.  Output: the compact
 // mill[chunk_off[item] + c].
-struct MillerPlan {
-  uint32_t C, W, L, pad;
-  uint32_t base[66];            // base[s]: where the entries of s pairs start in the list (sizes descending)
-  uint32_t cursor[66];
-};
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, RB_MIN_WAVES) k_miller_multi(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                   const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, size_t ws_stride,
                                                                   GtM* mill, const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
@@ -552,6 +544,10 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
             (uint32_t)c_hi, (uint32_t)ctx->n_cu, plan);
     KLAUNCH(ctx, "k_plan_scan", k_plan_scan, dim3(1), dim3(1024), 0, ctx->stream, n_items, pair_off, (const MillerPlan*)plan, chunk_off);
     KLAUNCH(ctx, "k_plan_fill", k_plan_fill, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, n_items, pair_off, plan, work);
+    if (rhip_use_c6(ctx, n_items, max_pairs)) {
+      rc = rhip_launch_miller_c6(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, plan, work, chunk_off, w_max);
+      if (rc) return rc;
+    } else
     KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(w_max, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs,
             (const G1M*)pl.P, (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)plan, (const uint2*)work,
             (const uint32_t*)chunk_off);
@@ -563,7 +559,9 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     return launch_final_exp(ctx, n_items, (const uint32_t*)chunk_off, 1u, (const GtM*)mill, mul_in, out);
   }
   uint32_t L, C;
-  choose_chunks(ctx, n_items, max_pairs, pair_off ? total_pairs : 0, &L, &C);
+  const bool c6 = rhip_use_c6(ctx, n_items, max_pairs);
+  if (c6) rhip_choose_chunks_c6(ctx, n_items, max_pairs, &L, &C);
+  else choose_chunks(ctx, n_items, max_pairs, pair_off ? total_pairs : 0, &L, &C);
   const size_t lanes = n_items * L;
   const size_t lanes_pad = (lanes + 63) / 64 * 64;
   void* ws = nullptr;
@@ -572,6 +570,10 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   rc = ensure_scratch(ctx, lanes * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
+  if (c6) {       // six lanes per (item, chunk): engine_coop.hip; same (item, chunk) map and workspace layout, so the walk verdicts below apply unchanged
+    rc = rhip_launch_miller_c6(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, nullptr, nullptr, nullptr, lanes);
+    if (rc) return rc;
+  } else
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
           (const G2M*)pl.Q, (const uint32_t*)pl.qref, lines, (uint4*)ws, (size_t)64, mill, (const MillerPlan*)nullptr, (const uint2*)nullptr, (const uint32_t*)nullptr);
   if (ctx->walk_fail) {
@@ -2054,6 +2056,7 @@ static int32_t ac17_decrypt_shared(rhip_ctx* ctx, size_t n_items, const rhip_g2*
 static int ac17_dec_path(const rhip_ctx* ctx, size_t n_items) {
   static const int forced = getenv("RABE_AC17_DEC_PATH") ? atoi(getenv("RABE_AC17_DEC_PATH")) : -1;
   if (forced >= 0) return forced;
+  if (rhip_use_c6(ctx, n_items, 6)) return 0;            // small launches: six lanes per accumulator (engine_coop.hip) beat three lanes per pairing
   return rhip_use_c3(ctx, n_items * 6) ? 1 : 0;
 }
 extern "C" int32_t rhip_ac17_cp_decrypt_batch(rhip_ctx* ctx, size_t n_items, const rhip_g2* ct_c0, const rhip_g1* ct_c, const uint32_t* ct_row_off,

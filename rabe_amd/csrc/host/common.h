@@ -151,6 +151,15 @@ class Engine {
     explicit LaneScope(int lane);
     ~LaneScope();
   };
+  // Threads that work on the engine side by side (the submission queue's batch leaders, the pipelined packed calls) hold a Busy for
+  // the whole of their operation, up to and including the wait for their stream.  A cached device handle (`aux`, `ac17_pk`) that is
+  // evicted while any Busy is alive is parked, not destroyed -- another lane may have been handed the raw pointer and be about to
+  // launch with it, or have kernels running on it -- and the parked handles are destroyed when the last Busy ends.
+  struct Busy {
+    Engine& e;
+    explicit Busy(Engine& eng);
+    ~Busy();
+  };
   // Inside an ArenaScope, DBufs of the current lane are carved from one grow-only device block (no hipMalloc / hipFree -- the
   // latter synchronises the whole device -- per buffer); the block is recycled when the outermost scope ends (after a stream sync).
   // A request the block cannot hold falls back to hipMalloc and makes the block grow for the next call.
@@ -224,9 +233,14 @@ class Engine {
   std::map<std::string, rhip_g1_table*> t1_;
   std::map<std::string, rhip_g2_table*> t2_;
   std::map<std::string, rhip_gt_table*> tt_;
-  std::map<std::string, rhip_ac17_pk*> pk17_;
-  struct Aux { void* h; void (*destroy)(void*); };
+  struct Pk17 { rhip_ac17_pk* h; uint64_t used; };
+  std::map<std::string, Pk17> pk17_;
+  struct Aux { void* h; void (*destroy)(void*); uint64_t used; };
   std::map<std::string, std::map<std::string, Aux>> aux_;
+  uint64_t use_clock_ = 0;                         // least-recently-used eviction of the two caches above: ONE entry at a time
+  int busy_ = 0;                                   // live Busy scopes
+  std::vector<std::pair<void*, void (*)(void*)>> parked_;   // evicted while busy_ > 0
+  void retire(void* h, void (*destroy)(void*));    // destroy now (nobody else is working) or park
   rhip_gt_table* e_gen_tbl_ = nullptr;
   void destroy_table(rhip_g1_table* t);
   void destroy_table(rhip_g2_table* t);

@@ -555,11 +555,18 @@ void queue_wait(rabe_host* h, T* t) {
     h->q.clear();
     lk.unlock();
     const auto b0 = std::chrono::steady_clock::now();
-    {
+    try {
+      Engine::Busy working(h->eng);          // handles evicted from the engine's caches meanwhile are parked until every lane is done
       Engine::LaneScope on_lane(lane);
       tl_queue_rng = h->tape ? nullptr : (Rng*)&h->q_rng[lane];
       run_queue_batch(h, batch);
       tl_queue_rng = nullptr;
+    } catch (const std::exception& e) {      // e.g. bad_alloc while grouping: every ticket of the batch that has no verdict yet fails,
+      tl_queue_rng = nullptr;                // the lane is released and the waiters are woken -- nothing crosses the C boundary
+      for (T* x : batch) if (x->rc == 0 && !x->obj && x->out.empty()) { x->rc = -2; x->err = std::string("panic: ") + e.what(); }
+    } catch (...) {
+      tl_queue_rng = nullptr;
+      for (T* x : batch) if (x->rc == 0 && !x->obj && x->out.empty()) { x->rc = -2; x->err = "panic: unknown exception in the submission queue"; }
     }
     const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - b0).count();
     lk.lock();
@@ -745,45 +752,67 @@ int32_t rabe_host_queue_stats(rabe_host* h, uint64_t out[6]) {
   return 0;
 }
 static int32_t submit_new(rabe_host* h, rabe_ticket* t, rabe_ticket** out) {
-  if (!h || !out) { delete t; return -1; }
   *out = t;
   queue_submit(h, t);
   return 0;
 }
+// every *_submit validates its pointers before it touches them and never lets an exception (bad_alloc of the copies) out
+#define SUBMIT_BEGIN(cond)                                     \
+  if (!h || !ticket) return -1;                                \
+  *ticket = nullptr;                                           \
+  if (!(cond)) { set_err(h, "null argument"); return -1; }     \
+  rabe_ticket* t = nullptr;                                    \
+  try {                                                        \
+    t = new rabe_ticket;
+#define SUBMIT_END                                             \
+    return submit_new(h, t, ticket);                           \
+  } catch (const std::exception& e) { delete t; *ticket = nullptr; set_err(h, std::string("panic: ") + e.what()); return -2; }
 int32_t rabe_ac17_cp_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AC17_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(pk && policy && (pt || !len))
+  t->op = rabe_ticket::AC17_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
+  SUBMIT_END
 }
 int32_t rabe_ac17_cp_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AC17_DEC; t->a = sk; t->ct = ct;
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(sk && ct)
+  t->op = rabe_ticket::AC17_DEC; t->a = sk; t->ct = ct;
+  SUBMIT_END
 }
 int32_t rabe_bsw_encrypt_submit(rabe_host* h, const void* pk, const char* policy, int32_t language, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::BSW_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(pk && policy && (pt || !len))
+  t->op = rabe_ticket::BSW_ENC; t->a = pk; t->policy = policy; t->language = language; t->pt.assign(pt, pt + len);
+  SUBMIT_END
 }
 int32_t rabe_bsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::BSW_DEC; t->a = sk; t->ct = ct;
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(sk && ct)
+  t->op = rabe_ticket::BSW_DEC; t->a = sk; t->ct = ct;
+  SUBMIT_END
 }
 int32_t rabe_lsw_encrypt_submit(rabe_host* h, const void* pk, const char* const* attributes, size_t n, const uint8_t* pt, size_t len, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::LSW_ENC; t->a = pk; t->attrs = strs(attributes, n); t->pt.assign(pt, pt + len);
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(pk && (attributes || !n) && (pt || !len))
+  for (size_t i = 0; i < n; i++) if (!attributes[i]) { delete t; set_err(h, "null attribute"); return -1; }
+  t->op = rabe_ticket::LSW_ENC; t->a = pk; t->attrs = strs(attributes, n); t->pt.assign(pt, pt + len);
+  SUBMIT_END
 }
 int32_t rabe_lsw_decrypt_submit(rabe_host* h, const void* sk, const void* ct, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::LSW_DEC; t->a = sk; t->ct = ct;
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(sk && ct)
+  t->op = rabe_ticket::LSW_DEC; t->a = sk; t->ct = ct;
+  SUBMIT_END
 }
 int32_t rabe_aw11_encrypt_submit(rabe_host* h, const void* gk, const void* const* pks, size_t n_pks, const char* policy, int32_t language,
                                  const uint8_t* data, size_t len, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AW11_ENC; t->a = gk; t->pks.assign(pks, pks + n_pks); t->policy = policy; t->language = language;
+  SUBMIT_BEGIN(gk && (pks || !n_pks) && policy && (data || !len))
+  for (size_t i = 0; i < n_pks; i++) if (!pks[i]) { delete t; set_err(h, "null authority key"); return -1; }
+  t->op = rabe_ticket::AW11_ENC; t->a = gk; t->pks.assign(pks, pks + n_pks); t->policy = policy; t->language = language;
   t->pt.assign(data, data + len);
-  return submit_new(h, t, ticket);
+  SUBMIT_END
 }
 int32_t rabe_aw11_decrypt_submit(rabe_host* h, const void* gk, const void* sk, const void* ct, rabe_ticket** ticket) {
-  rabe_ticket* t = new rabe_ticket; t->op = rabe_ticket::AW11_DEC; t->a = gk; t->b = sk; t->ct = ct;
-  return submit_new(h, t, ticket);
+  SUBMIT_BEGIN(gk && sk && ct)
+  t->op = rabe_ticket::AW11_DEC; t->a = gk; t->b = sk; t->ct = ct;
+  SUBMIT_END
 }
+#undef SUBMIT_BEGIN
+#undef SUBMIT_END
 // Measurement helper (bench.py: object_api.threads): `threads` native host threads call the PUBLIC one-call entry points on one host --
 // depth 1: rabe_ac17_cp_encrypt then rabe_ac17_cp_decrypt, blocking; depth > 1: that many rabe_*_submit calls in flight per thread -- for
 // `seconds`, checking every plaintext.  Native threads: an interpreter's global lock would be what is measured otherwise.
@@ -839,7 +868,12 @@ int32_t rabe_bench_ac17_threads(rabe_host* h, const void* pk, const void* sk, co
 }
 int32_t rabe_ticket_wait(rabe_host* h, rabe_ticket* t, void** obj, uint8_t** out, size_t* len) {
   if (!h || !t) return -1;
-  queue_wait(h, t);
+  try {
+    queue_wait(h, t);
+  } catch (const std::exception& e) {          // the leader section guards itself; what is left is the mutex / condition variable
+    set_err(h, std::string("panic: ") + e.what());
+    return -2;                                 // the ticket stays with the queue: freeing it here could race with a leader
+  }
   int32_t rc = t->rc;
   if (rc != 0) set_err(h, t->err);
   else {

@@ -99,6 +99,7 @@ void fan_out(Engine& eng, const Cut& c, const std::function<void(size_t)>& run) 
   std::mutex mu;
   std::exception_ptr first;
   auto work = [&](int lane) {
+    Engine::Busy working(eng);
     Engine::LaneScope scope(lane);
     for (;;) {
       const size_t k = next.fetch_add(1);

@@ -114,10 +114,12 @@ rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std
   key.append((const char*)fe.data(), fe.size());
   std::lock_guard<std::recursive_mutex> lk(mu_);
   auto it = pk17_.find(key);
-  if (it != pk17_.end()) return it->second;
-  if (pk17_.size() >= 4) {                       // bounded: each entry holds ~1.7 GB of tables
-    for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
-    pk17_.clear();
+  if (it != pk17_.end()) { it->second.used = ++use_clock_; return it->second.h; }
+  if (pk17_.size() >= 4) {                       // bounded: each entry holds ~1.7 GB of tables; the least recently used one goes
+    auto lru = pk17_.begin();
+    for (auto c = pk17_.begin(); c != pk17_.end(); ++c) if (c->second.used < lru->second.used) lru = c;
+    retire(lru->second.h, [](void* h) { rhip_ac17_pk_destroy((rhip_ac17_pk*)h); });
+    pk17_.erase(lru);
   }
   rhip_ac17_pk* dpk = nullptr;
   check(rhip_ac17_pk_create(ctx(), (const rhip_g1*)g.data(), (const rhip_g2*)fha.data(), (const rhip_gt*)fe.data(), &dpk), "rhip_ac17_pk_create");
@@ -126,7 +128,7 @@ rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std
   int w = 20;
   if (const char* env = getenv("RABE_G_WINDOW")) w = atoi(env);
   if (w > 16) check(rhip_ac17_pk_set_g_window(ctx(), dpk, w), "rhip_ac17_pk_set_g_window");
-  pk17_[key] = dpk;
+  pk17_[key] = Pk17{dpk, ++use_clock_};
   return dpk;
 }
 uint8_t* Engine::pinned(int slot, size_t bytes) {
@@ -358,19 +360,38 @@ void* Engine::aux(const std::string& kind, const std::string& key, void* (*make)
   std::lock_guard<std::recursive_mutex> lk(mu_);
   auto& m = aux_[kind];
   auto it = m.find(key);
-  if (it != m.end()) return it->second.h;
-  if (m.size() >= cap) {
-    for (auto& c : m) c.second.destroy(c.second.h);
-    m.clear();
+  if (it != m.end()) { it->second.used = ++use_clock_; return it->second.h; }
+  if (m.size() >= cap && !m.empty()) {            // the least recently used entry goes; never one this call was just handed (cap >= 2)
+    auto lru = m.begin();
+    for (auto c = m.begin(); c != m.end(); ++c) if (c->second.used < lru->second.used) lru = c;
+    retire(lru->second.h, lru->second.destroy);
+    m.erase(lru);
   }
   void* h = make(*this, arg);
-  m[key] = Aux{h, destroy};
+  m[key] = Aux{h, destroy, ++use_clock_};
   return h;
 }
+void Engine::retire(void* h, void (*destroy)(void*)) {        // mu_ held
+  if (busy_ > 0) parked_.emplace_back(h, destroy);
+  else destroy(h);
+}
+Engine::Busy::Busy(Engine& eng) : e(eng) {
+  std::lock_guard<std::recursive_mutex> lk(e.mu_);
+  e.busy_++;
+}
+Engine::Busy::~Busy() {
+  std::vector<std::pair<void*, void (*)(void*)>> dead;
+  {
+    std::lock_guard<std::recursive_mutex> lk(e.mu_);
+    if (--e.busy_ == 0) dead.swap(e.parked_);
+  }
+  for (auto& d : dead) d.second(d.first);        // every operation that could have seen these handles has waited for its stream
+}
 Engine::~Engine() {
+  for (auto& d : parked_) d.second(d.first);
   for (auto& k : aux_) for (auto& c : k.second) c.second.destroy(c.second.h);
   if (e_gen_tbl_) rhip_gt_table_destroy(e_gen_tbl_);
-  for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second);
+  for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second.h);
   for (auto& c : t1_) rhip_g1_table_destroy(c.second);
   for (auto& c : t2_) rhip_g2_table_destroy(c.second);
   for (auto& c : tt_) rhip_gt_table_destroy(c.second);

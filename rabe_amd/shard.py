@@ -32,7 +32,7 @@ def max_over_ranks(value):
     """The bench's max-over-ranks of an elapsed time (the only collective on the timed path)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():        # a one-rank group still runs the collective (RABE_FORCE_DIST)
         return float(value)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

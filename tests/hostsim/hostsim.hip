@@ -5,6 +5,7 @@
 #include "../../rabe_amd/csrc/bn254/io.h"
 #include "../../rabe_amd/csrc/bn254/coop3.h"
 #include "../../rabe_amd/csrc/bn254/coop6.h"
+#include "../../rabe_amd/csrc/bn254/selftest.h"
 #include <pthread.h>
 #include <string.h>
 
@@ -446,3 +447,7 @@ void hs_c6_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint3
   delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
 }
 }  // extern "C"
+
+// the context-creation self-test's per-lane digest (bn254/selftest.h) on the CPU, and the compiled-in expectation
+extern "C" unsigned hs_selftest_digest(int lane) { return selftest_digest(lane); }
+extern "C" unsigned hs_selftest_expected(int lane) { constexpr uint32_t e[64] = RB_SELFTEST_EXPECT; return e[lane]; }

@@ -47,3 +47,37 @@ def test_two_ranks_under_torch_distributed_run():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     d = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["roundtrip_bit_exact"] is True and d["gather"]["matches_unsharded_order"] is True
+
+
+def run_bench_n(n, *extra, env_extra=None, timeout=1800):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--warmup", "1", "--min-time", "0", "--no-cpu-baseline",
+                          "--no-object-api", "--no-host-io-leg", "--no-single-batch", "--no-configs-leg", "--wide-window", "0"] + list(extra), env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]          # RCCL may print its own lines around rank 0's
+    assert lines, out.stdout.decode()[-1500:] + out.stderr.decode()[-1500:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("extra", [("--steps", "4", "--g-window", "20"), ("--config", "4", "--steps", "1", "--batch", "128", "--attrs", "24", "--policies", "4")])
+def test_rccl_collective_path_with_one_rank(extra):
+    """the branch the 8-GPU run takes -- init_process_group("nccl"), barrier, all_reduce and all_gather_into_tensor on DEVICE tensors --
+    executed here with a one-rank RCCL group (RABE_FORCE_DIST=1), so that the first multi-GPU run is not its first execution"""
+    d = run_bench_n(1, *extra, env_extra={"RABE_FORCE_DIST": "1", "RABE_DIST_BACKEND": "nccl"})
+    assert d["n_gpus"] == 1 and d["roundtrip_bit_exact"] is True
+    assert d["gather"]["backend"] == "nccl" and d["gather"]["collective"] == "all_gather_into_tensor"
+    assert d["gather"]["matches_unsharded_order"] is True
+
+
+@pytest.mark.parametrize("config", [4, 5])
+def test_eight_ranks_at_the_real_splits_of_configs_4_and_5(config):
+    """BASELINE configs 4 / 5 as `--gpus 8` launches them: 16384 / 8 = 2048 and 8192 / 8 = 1024 items per rank, 200 attributes, eight
+    ranks (sharing GPU 0 over gloo on this box), one step: shard_range's eight blocks, the gather and the unsharded-order check"""
+    d = run_bench_n(8, "--config", str(config), "--steps", "1", timeout=3000)
+    assert d["n_gpus"] == 8 and d["roundtrip_bit_exact"] is True
+    assert d["gather"]["matches_unsharded_order"] is True
+    assert d["config"]["batch_per_gpu"] == (2048 if config == 4 else 1024)

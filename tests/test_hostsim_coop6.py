@@ -100,3 +100,19 @@ def test_c6_multi_pairing(n, kinds):
         HS.hs_c6_pairing_multi(n, (ctypes.c_int * n)(*kinds), b2c(p2), b2c(q), o)
         exp2 = sum(a * b for i, ((a, b), kd) in enumerate(zip(ks, kinds)) if kd != 2 and i != 0) % bn.R
         assert bytes(o) == bn.gt_to_le(bn.gt_pow(e, exp2))
+
+
+def test_selftest_digests_host_build_equals_exact_integer_generator():
+    """bn254/selftest.h (what rhip_ctx_create runs on every SIMD) compiled for the host gives the digests tools/gen_selftest.py
+    computed with exact integers -- two independent implementations of the 64 lanes' known answers"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_selftest", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_selftest.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    HS.hs_selftest_digest.restype = ctypes.c_uint
+    HS.hs_selftest_expected.restype = ctypes.c_uint
+    for lane in range(64):
+        want = gen.digest(lane)
+        assert HS.hs_selftest_expected(lane) == want, "regenerate selftest_gen.h"
+        assert HS.hs_selftest_digest(lane) == want, lane
