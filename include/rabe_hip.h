@@ -56,6 +56,8 @@ int32_t rhip_ctx_selftest_info(rhip_ctx* ctx, uint32_t* simds_checked);
 void rhip_ctx_destroy(rhip_ctx* ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
 int32_t rhip_ctx_set_stream(rhip_ctx* ctx, void* hip_stream);
+/* make the context's device the calling thread's current HIP device (a host thread that serves several contexts / devices) */
+int32_t rhip_ctx_make_current(rhip_ctx* ctx);
 int32_t rhip_sync(rhip_ctx* ctx);
 const char* rhip_last_error(rhip_ctx* ctx);
 /* per-kernel timing with HIP events on the launch stream (measurement only; off by default).

@@ -39,6 +39,20 @@ int32_t rabe_host_abi_version(void);
 int32_t rabe_host_create_checked(int32_t abi_version, int32_t device, rabe_host** out);
 #define rabe_host_open(device, out) rabe_host_create_checked(RABE_HOST_ABI_VERSION, (device), (out))
 int32_t rabe_host_create(int32_t device, rabe_host** out);
+/* ---- device group: ONE host over several GPUs of a node ----------------------------------------------------------------------
+ * Every encrypt / keygen / decrypt call is independent (the reference's schemes are pure functions of their arguments and fresh
+ * randomness), so a batch shards by item: the packed entry points of the four BASELINE schemes -- rabe_ac17_cp_{encrypt,decrypt}_packed,
+ * rabe_bsw_{encrypt,decrypt}_packed, rabe_lsw_{keygen,decrypt}_packed, rabe_aw11_{encrypt,decrypt}_packed -- cut their n_items into one
+ * contiguous block per device (sizes differ by at most one, blocks in device order), run every block on its own host thread and engine
+ * (each device builds its replica of a key's window tables / prepared lines on first use and keeps it), and the records / plaintexts /
+ * status entries land in the caller's buffers exactly where the single-device call puts them.  Randomness is drawn block after block
+ * from the host's one source, so on a tape (rabe_host_set_tape) the bytes do not depend on the number of devices.  No data-path
+ * collective: the only exchange is the results arriving in host memory.  A device may be listed more than once (two engines, i.e. two
+ * streams with their own workspaces, on one GPU) -- how a one-GPU box tests the split.  Every other entry point runs on devices[0].
+ * Status: as rabe_host_create_checked. */
+int32_t rabe_host_open_group_checked(int32_t abi_version, size_t n_devices, const int32_t* devices, rabe_host** out);
+#define rabe_host_open_group(n_devices, devices, out) rabe_host_open_group_checked(RABE_HOST_ABI_VERSION, (n_devices), (devices), (out))
+int32_t rabe_host_group_size(rabe_host* h);          /* engines of the host: 1 for rabe_host_open */
 void rabe_host_destroy(rabe_host* h);
 /* ---- submission queue: one call at a time, many callers ------------------------------------------------------------------------
  * The reference's API is one call per ciphertext (src/schemes/ac17/mod.rs:274-279, :385-388; rabe-console/src/mod.rs:1098, 1310) and one

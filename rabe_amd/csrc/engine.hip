@@ -186,6 +186,13 @@ extern "C" int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len) {
   buf[len - 1] = 0;
   return RHIP_OK;
 }
+// the calling thread's current HIP device becomes the context's (HIP's current device is per thread; kernels are launched on the
+// context's stream, which belongs to its device): the host layer's worker threads call this once before they work on an engine
+extern "C" int32_t rhip_ctx_make_current(rhip_ctx* ctx) {
+  NEED(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return RHIP_OK;
+}
 extern "C" const char* rhip_last_error(rhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len) {
   if (!ctx) return RHIP_ERR_ARG;
@@ -1492,6 +1499,7 @@ extern "C" int32_t rhip_gt_table_pow(rhip_ctx* ctx, const rhip_gt_table* t, size
   NEED(ctx);
   if (!t) return RHIP_ERR_ARG;
   if (!n) return RHIP_OK;
+  if (rhip_use_c6_gt_pow(ctx, n)) return rhip_launch_gt_table_pow_c6(ctx, t->dev, nullptr, 0, n, k, 1u, nullptr, out);
   KLAUNCH(ctx, "k_table_pow_gt", k_table_pow_gt, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, (const GtM*)t->dev, n, k, out);
   return RHIP_OK;
 }
@@ -1549,6 +1557,8 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
           (const G2M*)(g2w16 ? pk->h_a[0]->dev16 : pk->h_a[0]->dev), (const G2M*)(g2w16 ? pk->h_a[1]->dev16 : pk->h_a[1]->dev),
           (const G2M*)(g2w16 ? pk->h_a[2]->dev16 : pk->h_a[2]->dev), n_items, s, c0, g2w16 ? 1 : 0);
   const bool gt16 = pk->e[0]->dev16 && pk->e[1]->dev16;
+  if (rhip_use_c6_gt_pow(ctx, n_items))          // small launches: six lanes per running product (engine_coop.hip), the same field elements
+    return rhip_launch_gt_table_pow_c6(ctx, gt16 ? pk->e[0]->dev16 : pk->e[0]->dev, gt16 ? pk->e[1]->dev16 : pk->e[1]->dev, gt16 ? 1 : 0, n_items, s, 2u, msg, cp);
   KLAUNCH(ctx, "k_ac17_enc_cp", k_ac17_enc_cp, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream,
           (const GtM*)(gt16 ? pk->e[0]->dev16 : pk->e[0]->dev), (const GtM*)(gt16 ? pk->e[1]->dev16 : pk->e[1]->dev), n_items, s, msg, cp,
           gt16 ? 1 : 0);

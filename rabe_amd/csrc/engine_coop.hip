@@ -209,6 +209,57 @@ __global__ void __launch_bounds__(64, RB_C6_WAVES) k_final_exp_c6(size_t n_items
   if (active) store_fp2(out[item].l + 16 * ti, r);
 }
 
+// out[i] = (mul_in ? mul_in[i] : 1) * t0^k[stride i] * (t1 ? t1^k[stride i + 1] : 1): the fixed-base Gt powers of an encrypt (`c_p = msg *
+// e_gh_ka[0]^s0 * e_gh_ka[1]^s1`, src/schemes/ac17/mod.rs:357-360; the Gt messages of a batch) as ONE running product per group: a
+// window digit's table entry goes into the multiplier row, the accumulator is multiplied by it.  w16: 16 windows of 65535 entries,
+// else 32 of 255 (engine_internal.h: TBL16_* / TBL_*).  The products of a wave's groups run in lockstep; a zero digit (no entry) only
+// skips the commit.
+__global__ void __launch_bounds__(64, RB_C6_WAVES) k_gt_table_pow_c6(const GtM* t0, const GtM* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride,
+                                                                     const rhip_gt* mul_in, rhip_gt* out) {
+  __shared__ uint4 rows[C6_LDS_QUADS];
+  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g, ti = c6_tower_index(r);
+  const size_t item = (size_t)blockIdx.x * C6_GROUPS + g;
+  const bool active = g < C6_GROUPS && item < n_items;
+  const DevCX6 cx = dev_cx6(rows, lane, g, r);
+  Fp2 acc = r == 0 ? fp2_one() : fp2_zero();
+  if (active && mul_in) acc = load_fp2(mul_in[item].l + 16 * ti);
+  c6_put_f(cx, acc);
+  const int n_win = w16 ? TBL16_WINDOWS : TBL_WINDOWS;
+#pragma unroll 1
+  for (int t = 0; t < 2; t++) {
+    const GtM* tbl = t ? t1 : t0;
+    if (!tbl) break;
+    uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) ld_scalar(kk, k + item * kstride + t);
+#pragma unroll 1
+    for (int w = 0; w < n_win; w++) {
+      uint32_t d;
+      if (w16) {
+        uint32_t word;
+        switch (w >> 1) {
+          case 0: word = kk[0]; break;
+          case 1: word = kk[1]; break;
+          case 2: word = kk[2]; break;
+          case 3: word = kk[3]; break;
+          case 4: word = kk[4]; break;
+          case 5: word = kk[5]; break;
+          case 6: word = kk[6]; break;
+          default: word = kk[7]; break;
+        }
+        d = (w & 1) ? (word >> 16) : (word & 0xffffu);
+      } else {
+        d = scalar_byte(kk, w);
+      }
+      Fp2 e = fp2_zero();
+      if (d) e = ld_fp2_m((tbl + (size_t)w * (w16 ? TBL16_DIGITS : TBL_DIGITS) + (d - 1))->l + 16 * ti);
+      c6_put(cx, C6_B, e);
+      const Fp2 m = c6_dot(cx, C6_OP_MUL, 0);
+      if (d) c6_put_f(cx, m);
+    }
+  }
+  if (active) store_fp2(out[item].l + 16 * ti, c6_mine(cx));
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // When the six-lane kernels run.  Mode 6 (rhip_ctx_set_pairing_mode, or RABE_PAIRING_MODE=6 in the environment of rhip_ctx_create):
 // always.  Mode 0 (auto; RABE_C6_AUTO=0 turns it off): where they are faster, by the measured instruction counts
@@ -324,4 +375,18 @@ int32_t rhip_device_selftest(rhip_ctx* ctx, uint32_t* simds, uint32_t* mismatche
 extern "C" int32_t rhip_ctx_selftest_info(rhip_ctx* ctx, uint32_t* simds_checked) {
   if (!ctx || !simds_checked) return RHIP_ERR_ARG;
   return rhip_device_selftest(ctx, simds_checked, nullptr);
+}
+
+int32_t rhip_launch_gt_table_pow_c6(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
+                                    rhip_gt* out) {
+  KLAUNCH(ctx, "k_gt_table_pow_c6", k_gt_table_pow_c6, dim3(blocks_for(n_items, C6_GROUPS)), dim3(64), 0, ctx->stream, (const GtM*)t0, (const GtM*)t1, w16, n_items, k,
+          kstride, mul_in, out);
+  return RHIP_OK;
+}
+// the fixed-base Gt kernels: 32 (16-bit windows) or 64 dependent products per item in one lane against ~5 k instructions each here
+bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items) {
+  if (ctx->pairing_mode == 6) return true;
+  if (ctx->pairing_mode != 0) return false;
+  static const int auto_on = getenv("RABE_C6_AUTO") ? atoi(getenv("RABE_C6_AUTO")) : 1;
+  return auto_on && n_items <= (size_t)ctx->n_cu * 4 * 32;
 }

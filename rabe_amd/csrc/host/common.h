@@ -144,6 +144,8 @@ class Engine {
   // chunk's record parsing / AES runs beside another's kernels and a third's PCIe copies.  The calling thread picks its lane with a
   // LaneScope; everything below (`ctx`, `pinned`, DBuf) then refers to that lane.  Tables and key handles are shared by all lanes.
   rhip_ctx* ctx() const { return lanes_[cur_lane()]->ctx; }
+  int device() const { return device_; }
+  void make_current() const { check(rhip_ctx_make_current(lanes_[0]->ctx), "rhip_ctx_make_current"); }
   void ensure_lanes(size_t count);                 // call before handing lanes to threads
   size_t lanes() const { return lanes_.size(); }
   struct LaneScope {

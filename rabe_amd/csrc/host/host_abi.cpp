@@ -60,7 +60,15 @@ struct rabe_host {
   bool q_lane_busy[Q_LANES] = {false, false, false};
   OsRng q_rng[Q_LANES];
   uint64_t q_stats[6] = {0, 0, 0, 0, 0, 0};  // batches, requests, groups, requests run singly, microseconds inside batches, largest batch
+  // a device GROUP (rabe_host_open_group): the host's own engine + one more per further entry of the device list.  The packed entry
+  // points of ac17 / bsw / lsw / aw11 split their items into one contiguous block per engine (pipeline.cpp); everything else runs on `eng`.
+  std::vector<std::unique_ptr<Engine>> peers;
   explicit rabe_host(int device) : eng(device) {}
+  std::vector<Engine*> engines() {
+    std::vector<Engine*> v{&eng};
+    for (auto& p : peers) v.push_back(p.get());
+    return v;
+  }
   Rng& rng() { return tape ? (Rng&)*tape : (Rng&)os; }
 };
 static thread_local std::string g_err;
@@ -717,6 +725,22 @@ int32_t rabe_host_create_checked(int32_t abi_version, int32_t device, rabe_host*
   }
   return rabe_host_create(device, out);
 }
+int32_t rabe_host_open_group_checked(int32_t abi_version, size_t n_devices, const int32_t* devices, rabe_host** out) {
+  if (out) *out = nullptr;
+  if (abi_version != RABE_HOST_ABI_VERSION) {
+    g_err = "rabe_host.h revision " + std::to_string(abi_version) + " does not match the library's (" + std::to_string(RABE_HOST_ABI_VERSION) + ")";
+    return -3;
+  }
+  if (!out || !n_devices || !devices || n_devices > 64) { g_err = "rabe_host_open_group: 1 .. 64 devices"; return -1; }
+  GUARD_BEGIN
+  std::unique_ptr<rabe_host> h(new rabe_host(devices[0]));
+  for (size_t i = 1; i < n_devices; i++) h->peers.emplace_back(new Engine(devices[i]));
+  h->eng.make_current();
+  *out = h.release();
+  return 0;
+  GUARD_END((rabe_host*)nullptr)
+}
+int32_t rabe_host_group_size(rabe_host* h) { return h ? (int32_t)(1 + h->peers.size()) : -1; }
 void rabe_host_destroy(rabe_host* h) { delete h; }
 const char* rabe_host_last_error(rabe_host* h) { return h ? h->err.c_str() : g_err.c_str(); }
 int32_t rabe_host_set_fixed_base_min(rabe_host* h, size_t n) {
@@ -1040,8 +1064,8 @@ int32_t rabe_ac17_cp_encrypt_packed(rabe_host* h, const void* pk, const char* co
   const auto pols = strs(policies, n_policies);
   const auto lang = lang_of(language);
   if (!item_policy || !pt_off || !ct_off) throw RabeError("cp_encrypt_packed: null input");
-  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_AC17, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
-    return ac17::cp_encrypt_packed(h->eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  return pipeline::produce(h->engines(), h->rng(), n_items, CHUNK_AC17, [&](Engine& eng, size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return ac17::cp_encrypt_packed(eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
   }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
@@ -1061,9 +1085,9 @@ int32_t rabe_ac17_cp_decrypt_packed(rabe_host* h, const void* sk, size_t n_items
   std::vector<std::string> errors;
   const auto& key = *(const ac17::Ac17CpSecretKey*)sk;
   const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
-  if (!pipeline::consume(h->eng, n_items, CHUNK_AC17, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+  if (!pipeline::consume(h->engines(), n_items, CHUNK_AC17, ct_off, ct_len, [&](Engine& eng, size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
                                                                            std::vector<std::string>* errs) {
-        return ac17::cp_decrypt_packed(h->eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+        return ac17::cp_decrypt_packed(eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
       }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
@@ -1121,8 +1145,8 @@ int32_t rabe_bsw_encrypt_packed(rabe_host* h, const void* pk, const char* const*
   const auto pols = strs(policies, n_policies);
   const auto lang = lang_of(language);
   if (!item_policy || !pt_off || !ct_off) throw RabeError("bsw::encrypt_packed: null input");
-  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_BSW, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
-    return bsw::encrypt_packed(h->eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  return pipeline::produce(h->engines(), h->rng(), n_items, CHUNK_BSW, [&](Engine& eng, size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return bsw::encrypt_packed(eng, r, key, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
   }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
@@ -1132,9 +1156,9 @@ int32_t rabe_bsw_decrypt_packed(rabe_host* h, const void* sk, size_t n_items, co
   std::vector<std::string> errors;
   const auto& key = *(const bsw::CpAbeSecretKey*)sk;
   const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
-  if (!pipeline::consume(h->eng, n_items, CHUNK_BSW, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+  if (!pipeline::consume(h->engines(), n_items, CHUNK_BSW, ct_off, ct_len, [&](Engine& eng, size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
                                                                           std::vector<std::string>* errs) {
-        return bsw::decrypt_packed(h->eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+        return bsw::decrypt_packed(eng, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
       }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
@@ -1159,8 +1183,8 @@ int32_t rabe_lsw_keygen_packed(rabe_host* h, const void* pk, const void* msk, co
   const auto pols = strs(policies, n_policies);
   const auto lang = lang_of(language);
   if (!item_policy || !sk_off) throw RabeError("lsw::keygen_packed: null input");
-  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_LSW, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
-    return lsw::keygen_packed(h->eng, r, key, master, pols, lang, hi - lo, item_policy + lo, out, cap, off);
+  return pipeline::produce(h->engines(), h->rng(), n_items, CHUNK_LSW, [&](Engine& eng, size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return lsw::keygen_packed(eng, r, key, master, pols, lang, hi - lo, item_policy + lo, out, cap, off);
   }, sk_buf, sk_cap, sk_off) ? 0 : 1;
   GUARD_END(h)
 }
@@ -1170,9 +1194,9 @@ int32_t rabe_lsw_decrypt_packed(rabe_host* h, const void* ct, size_t n_items, co
   std::vector<std::string> errors;
   const auto& c = *(const lsw::KpAbeCiphertext*)ct;
   const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
-  if (!pipeline::consume(h->eng, n_items, CHUNK_LSW, sk_off, sk_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+  if (!pipeline::consume(h->engines(), n_items, CHUNK_LSW, sk_off, sk_len, [&](Engine& eng, size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
                                                                           std::vector<std::string>* errs) {
-        return lsw::decrypt_packed(h->eng, c, hi - lo, sk_blob, sk_len, sk_off + lo, trusted, st, pt, cap, off, errs);
+        return lsw::decrypt_packed(eng, c, hi - lo, sk_blob, sk_len, sk_off + lo, trusted, st, pt, cap, off, errs);
       }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }
@@ -1200,8 +1224,8 @@ int32_t rabe_aw11_encrypt_packed(rabe_host* h, const void* gk, const void* const
   const auto pols = strs(policies, n_policies);
   const auto lang = lang_of(language);
   if (!item_policy || !pt_off || !ct_off) throw RabeError("aw11::encrypt_packed: null input");
-  return pipeline::produce(h->eng, h->rng(), n_items, CHUNK_AW11, [&](size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
-    return aw11::encrypt_packed(h->eng, r, g, p, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
+  return pipeline::produce(h->engines(), h->rng(), n_items, CHUNK_AW11, [&](Engine& eng, size_t lo, size_t hi, Rng& r, uint8_t* out, size_t cap, uint64_t* off) {
+    return aw11::encrypt_packed(eng, r, g, p, pols, lang, hi - lo, item_policy + lo, pt_blob, pt_off + lo, out, cap, off);
   }, ct_buf, ct_cap, ct_off) ? 0 : 1;
   GUARD_END(h)
 }
@@ -1212,9 +1236,9 @@ int32_t rabe_aw11_decrypt_packed(rabe_host* h, const void* gk, const void* sk, s
   const auto& g = *(const aw11::Aw11GlobalKey*)gk;
   const auto& key = *(const aw11::Aw11SecretKey*)sk;
   const bool trusted = (flags & RABE_PACKED_TRUSTED) != 0;
-  if (!pipeline::consume(h->eng, n_items, CHUNK_AW11, ct_off, ct_len, [&](size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
+  if (!pipeline::consume(h->engines(), n_items, CHUNK_AW11, ct_off, ct_len, [&](Engine& eng, size_t lo, size_t hi, int32_t* st, uint8_t* pt, size_t cap, uint64_t* off,
                                                                            std::vector<std::string>* errs) {
-        return aw11::decrypt_packed(h->eng, g, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
+        return aw11::decrypt_packed(eng, g, key, hi - lo, ct_blob, ct_len, ct_off + lo, trusted, st, pt, cap, off, errs);
       }, status, pt_buf, pt_cap, pt_off, &errors))
     return 1;
   for (const auto& e : errors) if (!e.empty()) { set_err(h, e); break; }

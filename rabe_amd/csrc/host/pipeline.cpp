@@ -73,13 +73,24 @@ size_t env_size(const char* name, size_t dflt) {
   long v = atol(e);
   return v > 0 ? (size_t)v : dflt;
 }
-struct Cut { size_t chunks, per, lanes; };
+// chunk k = items [lo(k), hi(k)): `base` items each, the first `extra` chunks one more (rabe_amd/shard.py: shard_range has the same rule)
+struct Cut {
+  size_t chunks, lanes, base, extra, n;
+  size_t lo(size_t k) const { const size_t v = k * base + (k < extra ? k : extra); return v < n ? v : n; }
+  size_t hi(size_t k) const { const size_t v = lo(k) + base + (k < extra ? 1 : 0); return v < n ? v : n; }
+};
+static Cut even_cut(size_t n, size_t chunks, size_t lanes) { return {chunks, lanes, n / chunks, n % chunks, n}; }
 // Chunks of at least `min_chunk` items, one per lane.  Measured (tools/bench_packed_pipeline.py, AC17, 50 attributes, ops/s unchunked ->
 // two half-size chunks on two lanes, after the unchunked call lost its per-buffer allocations, per-call line preparation and per-element
 // verdict downloads): 20 480 items 339 k -> 311 k, 65 536 458 k -> 433 k, 131 072 406 k -> 402 k; finer chunks are worse still (20 480 as
 // 5 x 4096 on three lanes: 224 k) -- every stage of a chunk has a fixed cost, the host stages already use all cores, small launches
 // under-fill the GPU.  So host_abi.cpp passes min_chunk = "never"; RABE_PACKED_CHUNK / RABE_PACKED_LANES switch it on (the tests do).
-Cut cut(size_t n, size_t min_chunk) {
+// A device group is cut into one block per engine, whatever the environment says.
+Cut cut(size_t n_engines, size_t n, size_t min_chunk) {
+  if (n_engines > 1) {
+    const size_t chunks = n < n_engines ? (n ? n : 1) : n_engines;
+    return even_cut(n, chunks, chunks);
+  }
   size_t lanes = env_size("RABE_PACKED_LANES", 2);
   if (lanes > 8) lanes = 8;
   const bool forced = getenv("RABE_PACKED_CHUNK") != nullptr;
@@ -87,66 +98,74 @@ Cut cut(size_t n, size_t min_chunk) {
   size_t chunks = n / (min_chunk ? min_chunk : 1);
   const size_t cap = forced ? 2 * lanes : lanes;
   if (chunks > cap) chunks = cap;
-  if (chunks < 2 || lanes < 2) return {1, n, 1};
+  if (chunks < 2 || lanes < 2) return {1, 1, n, 0, n};
   const size_t per = (n + chunks - 1) / chunks;
   chunks = (n + per - 1) / per;
-  return {chunks, per, lanes < chunks ? lanes : chunks};
+  Cut c{chunks, lanes < chunks ? lanes : chunks, per, 0, n};
+  return c;
 }
-// run(k) for every chunk, `lanes` at a time, chunks handed out in order; the first exception is rethrown after all workers ended
-void fan_out(Engine& eng, const Cut& c, const std::function<void(size_t)>& run) {
-  eng.ensure_lanes(c.lanes);
+// run(k, engine) for every chunk; the first exception is rethrown after all workers ended.  One engine: `lanes` chunks at a time on its
+// lanes, chunks handed out in order.  A group: chunk k on engine k, lane 0, one thread each, the engine's device current in that thread.
+void fan_out(const std::vector<Engine*>& engines, const Cut& c, const std::function<void(size_t, Engine&)>& run) {
   std::atomic<size_t> next{0};
   std::mutex mu;
   std::exception_ptr first;
-  auto work = [&](int lane) {
-    Engine::Busy working(eng);
-    Engine::LaneScope scope(lane);
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= c.chunks) return;
-      try {
-        run(k);
-      } catch (...) {
-        std::lock_guard<std::mutex> g(mu);
-        if (!first) first = std::current_exception();
+  const bool group = engines.size() > 1;
+  if (!group) engines[0]->ensure_lanes(c.lanes);
+  auto work = [&](size_t w) {
+    Engine& eng = *engines[group ? w : 0];
+    try {
+      eng.make_current();
+      Engine::Busy working(eng);
+      Engine::LaneScope scope(group ? 0 : (int)w);
+      for (;;) {
+        const size_t k = group ? w : next.fetch_add(1);
+        if (k >= c.chunks) return;
+        run(k, eng);
+        if (group) return;
       }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu);
+      if (!first) first = std::current_exception();
     }
   };
   std::vector<std::thread> th;
-  for (size_t l = 1; l < c.lanes; l++) th.emplace_back(work, (int)l);
+  const size_t workers = group ? c.chunks : c.lanes;
+  for (size_t w = 1; w < workers; w++) th.emplace_back(work, w);
   work(0);
   for (auto& t : th) t.join();
+  if (group) engines[0]->make_current();            // the caller's thread goes on with the host's own engine
   if (first) std::rethrow_exception(first);
 }
 
 }  // namespace
 
-bool produce(Engine& eng, Rng& rng, size_t n, size_t min_chunk, const ProduceFn& call, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
-  const Cut c = cut(n, min_chunk);
-  if (c.chunks == 1) return call(0, n, rng, out_buf, out_cap, out_off);
+bool produce(const std::vector<Engine*>& engines, Rng& rng, size_t n, size_t min_chunk, const ProduceFn& call, uint8_t* out_buf, size_t out_cap, uint64_t* out_off) {
+  const Cut c = cut(engines.size(), n, min_chunk);
+  if (c.chunks == 1) return call(*engines[0], 0, n, rng, out_buf, out_cap, out_off);
   // the entry point's own sizing pass (no buffer: it fills the offsets and returns before drawing anything)
-  (void)call(0, n, rng, nullptr, 0, out_off);
+  (void)call(*engines[0], 0, n, rng, nullptr, 0, out_off);
   if (!out_buf || out_cap < out_off[n]) return false;
   DrawGate gate;
   std::atomic<bool> ok{true};
-  fan_out(eng, c, [&](size_t k) {
-    const size_t lo = k * c.per, hi = lo + c.per < n ? lo + c.per : n;
+  fan_out(engines, c, [&](size_t k, Engine& eng) {
+    const size_t lo = c.lo(k), hi = c.hi(k);
     GatedRng r(rng, gate, k);
     std::vector<uint64_t> off(hi - lo + 1);
-    if (!call(lo, hi, r, out_buf + out_off[lo], (size_t)(out_off[hi] - out_off[lo]), off.data())) ok = false;
+    if (!call(eng, lo, hi, r, out_buf + out_off[lo], (size_t)(out_off[hi] - out_off[lo]), off.data())) ok = false;
     else if (off[hi - lo] != out_off[hi] - out_off[lo]) throw RabeError("pipelined batch: a chunk's records do not have the announced size");
   });
   return ok;
 }
 
-bool consume(Engine& eng, size_t n, size_t min_chunk, const uint64_t* in_off, size_t in_len, const ConsumeFn& call, int32_t* status, uint8_t* pt_buf,
-             size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
-  const Cut c = cut(n, min_chunk);
-  if (c.chunks == 1 || !in_off) return call(0, n, status, pt_buf, pt_cap, pt_off, errors);
+bool consume(const std::vector<Engine*>& engines, size_t n, size_t min_chunk, const uint64_t* in_off, size_t in_len, const ConsumeFn& call, int32_t* status,
+             uint8_t* pt_buf, size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors) {
+  const Cut c = cut(engines.size(), n, min_chunk);
+  if (c.chunks == 1 || !in_off) return call(*engines[0], 0, n, status, pt_buf, pt_cap, pt_off, errors);
   // what the entry points require of the plaintext buffer: the total size of the well-formed records (packed.cpp: check_offsets)
   std::vector<uint64_t> span(c.chunks + 1, 0);
   for (size_t k = 0; k < c.chunks; k++) {
-    const size_t lo = k * c.per, hi = lo + c.per < n ? lo + c.per : n;
+    const size_t lo = c.lo(k), hi = c.hi(k);
     uint64_t s = 0;
     for (size_t i = lo; i < hi; i++) if (in_off[i] <= in_off[i + 1] && in_off[i + 1] <= in_len) s += in_off[i + 1] - in_off[i];
     span[k + 1] = span[k] + s;
@@ -155,10 +174,10 @@ bool consume(Engine& eng, size_t n, size_t min_chunk, const uint64_t* in_off, si
   std::vector<std::vector<uint64_t>> off(c.chunks);
   std::vector<std::vector<std::string>> errs(c.chunks);
   std::atomic<bool> ok{true};
-  fan_out(eng, c, [&](size_t k) {
-    const size_t lo = k * c.per, hi = lo + c.per < n ? lo + c.per : n;
+  fan_out(engines, c, [&](size_t k, Engine& eng) {
+    const size_t lo = c.lo(k), hi = c.hi(k);
     off[k].assign(hi - lo + 1, 0);
-    if (!call(lo, hi, status + lo, pt_buf + span[k], (size_t)(span[k + 1] - span[k]), off[k].data(), &errs[k])) ok = false;
+    if (!call(eng, lo, hi, status + lo, pt_buf + span[k], (size_t)(span[k + 1] - span[k]), off[k].data(), &errs[k])) ok = false;
   });
   if (!ok) return false;
   // close the slices up: plaintexts contiguous in item order, as the unchunked call leaves them
@@ -166,7 +185,7 @@ bool consume(Engine& eng, size_t n, size_t min_chunk, const uint64_t* in_off, si
   pt_off[0] = 0;
   uint64_t cur = 0;
   for (size_t k = 0; k < c.chunks; k++) {
-    const size_t lo = k * c.per, cnt = off[k].size() - 1;
+    const size_t lo = c.lo(k), cnt = off[k].size() - 1;
     const uint64_t len = off[k][cnt];
     if (len && cur != span[k]) memmove(pt_buf + cur, pt_buf + span[k], (size_t)len);
     for (size_t i = 0; i < cnt; i++) {

@@ -254,10 +254,15 @@ std::vector<DecryptResult> decrypt_batch(Engine& eng, const std::vector<const Mk
 // own engine lane; results are those of the unchunked call.  `call(lo, hi, ...)` is the entry point bound to items [lo, hi).
 #include <functional>
 namespace rabe { namespace pipeline {
-typedef std::function<bool(size_t lo, size_t hi, Rng& rng, uint8_t* out, size_t cap, uint64_t* off)> ProduceFn;
-typedef std::function<bool(size_t lo, size_t hi, int32_t* status, uint8_t* pt, size_t cap, uint64_t* pt_off, std::vector<std::string>* errors)> ConsumeFn;
+// `eng`: the engine the chunk runs on -- the host's own, or the member of a device GROUP (rabe_host_open_group) that owns the block
+typedef std::function<bool(Engine& eng, size_t lo, size_t hi, Rng& rng, uint8_t* out, size_t cap, uint64_t* off)> ProduceFn;
+typedef std::function<bool(Engine& eng, size_t lo, size_t hi, int32_t* status, uint8_t* pt, size_t cap, uint64_t* pt_off, std::vector<std::string>* errors)> ConsumeFn;
+// engines: one entry = a plain host (min_chunk / RABE_PACKED_CHUNK / RABE_PACKED_LANES decide about chunks on its lanes, default: none);
+// several = a device group: the items are cut into contiguous blocks, one per engine (sizes differ by at most one, in engine order),
+// every block runs on its own thread with its engine's device current.  Outputs land where the unsplit call puts them and an ordered
+// randomness source is drawn block after block -- the bytes do not depend on the split.
 // min_chunk: fewest items a chunk may hold (RABE_PACKED_CHUNK overrides); RABE_PACKED_LANES: chunks in flight (default 2, 1 = unchunked)
-bool produce(Engine& eng, Rng& rng, size_t n, size_t min_chunk, const ProduceFn& call, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
-bool consume(Engine& eng, size_t n, size_t min_chunk, const uint64_t* in_off, size_t in_len, const ConsumeFn& call, int32_t* status, uint8_t* pt_buf,
+bool produce(const std::vector<Engine*>& engines, Rng& rng, size_t n, size_t min_chunk, const ProduceFn& call, uint8_t* out_buf, size_t out_cap, uint64_t* out_off);
+bool consume(const std::vector<Engine*>& engines, size_t n, size_t min_chunk, const uint64_t* in_off, size_t in_len, const ConsumeFn& call, int32_t* status, uint8_t* pt_buf,
              size_t pt_cap, uint64_t* pt_off, std::vector<std::string>* errors);
 }}  // namespace rabe::pipeline

@@ -89,13 +89,22 @@ class Obj:
 class Host:
     """One GPU context + randomness source.  `Host()` fails loudly without a HIP device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """devices: a list of HIP device indices opens a device GROUP (include/rabe_host.h: rabe_host_open_group) -- the packed entry
+        points of ac17 / bsw / lsw / aw11 then shard their items over the listed devices (a device may be listed more than once)"""
         self.lib = _lib()
         h = ctypes.c_void_p()
-        rc = self.lib.rabe_host_create(ctypes.c_int32(device), ctypes.byref(h))
+        if devices is not None:
+            arr = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.rabe_host_open_group_checked(ctypes.c_int32(self.lib.rabe_host_abi_version()), ctypes.c_size_t(len(devices)), arr, ctypes.byref(h))
+        else:
+            rc = self.lib.rabe_host_create(ctypes.c_int32(device), ctypes.byref(h))
         if rc != 0:
             raise EngineError("rabe_host_create failed: %s" % (self.lib.rabe_host_last_error(None) or b"").decode())
         self.h = h
+
+    def group_size(self):
+        return int(self.lib.rabe_host_group_size(self.h))
 
     def close(self):
         if self.h:

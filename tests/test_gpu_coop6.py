@@ -75,6 +75,20 @@ def test_many_items_fill_several_waves(eng):
         assert six[i] == bn.gt_to_le(bn.gt_pow(e, exp))
 
 
+def test_fixed_base_gt_powers_six_lanes_equal_one_lane_and_oracle(eng):
+    """rhip_gt_table_pow through k_gt_table_pow_c6 (one running product per group of six lanes) and through k_table_pow_gt"""
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    base = bn.gt_pow(e, 0xABCDEF12345)
+    tbl = eng.gt_table(bn.gt_to_le(base))
+    ks = [0, 1, 2, 255, 256, bn.R - 1, (1 << 253) + 5] + [RND.randrange(bn.R) for _ in range(30)]
+    sc = [int(k).to_bytes(32, "little") for k in ks]
+    one, six = _both_modes(eng, lambda: tbl.mul(sc))
+    tbl.destroy()
+    assert one == six
+    for k, got in list(zip(ks, six))[:12]:
+        assert got == bn.gt_to_le(bn.gt_pow(base, k))
+
+
 @pytest.mark.parametrize("module", ["tests/test_gpu_ac17.py", "tests/test_gpu_bsw_dev.py", "tests/test_gpu_lsw_aw11_dev.py", "tests/test_gpu_ghw11.py",
                                     "tests/test_gpu_walk_verdicts.py", "tests/test_gpu_ragged_plan.py"])
 def test_scheme_suites_pass_with_six_lane_kernels_forced(module):
