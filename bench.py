@@ -768,7 +768,7 @@ def object_api_leg(args, trees):
         sk = ac17.cp_keygen(host, msk, attrs)
         pols = [hp.to_json(t) for t in trees]
 
-        def packed_leg(n, reps):
+        def packed_leg(n, reps, host=host):
             pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
             item_pol = np.arange(n, dtype=np.uint32) % len(pols)
             pt_blob = b"".join(pts)
@@ -806,6 +806,22 @@ def object_api_leg(args, trees):
                           "(RABE_PACKED_TRUSTED). KDF + AES-256-GCM and record assembly run on the device (round 4)")
         # ... and sixteen: the size of the device-level launch groups, where the decrypt's final exponentiation fills the chip
         packed_full = packed_leg(16 * args.batch, 3)
+        # ... and the same sixteen steps' worth through a device GROUP (include/rabe_host.h: rabe_host_open_group): every visible GPU, or --
+        # on a one-GPU box -- two engines on GPU 0, i.e. the call cut into two blocks that run side by side (one block's copies and host
+        # stages beside the other's kernels)
+        packed_group = None
+        try:
+            import torch
+            n_dev = torch.cuda.device_count()
+            devs = list(range(n_dev)) if n_dev > 1 else [0, 0]
+            ghost = hl.Host(devices=devs)
+            try:
+                packed_group = packed_leg(16 * args.batch, 3, host=ghost)
+                packed_group["devices"] = devs
+            finally:
+                ghost.close()
+        except Exception as ex:          # the leg is informational
+            packed_group = {"error": repr(ex)[:300]}
         n = args.batch
         pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
         # ---- one object handle per ciphertext (round 1's path), one step's worth
@@ -819,7 +835,7 @@ def object_api_leg(args, trees):
         objects = {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "plaintexts_match": out == pts}
         del cts
         threads = threads_leg(host, pk, sk, pols)
-        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "packed_full_group": packed_full, "threads": threads,
+        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "packed_full_group": packed_full, "packed_group": packed_group, "threads": threads,
                 "objects": objects,
                 "note": "policy text + plaintext bytes -> canonical ciphertext records -> plaintext bytes through the C ABI of the host layer; "
                         "parse/MSP/pruning/KDF/AES-GCM, record assembly and the PCIe copies are inside the timed region (best of 3 for `packed`)"}
