@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
-SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_coop.hip"), os.path.join(CSRC, "engine_sym.hip"),
+SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_coop.hip"), os.path.join(CSRC, "engine_coop_w1.hip"), os.path.join(CSRC, "engine_sym.hip"),
            os.path.join(CSRC, "host", "schemes.cpp"),
            os.path.join(CSRC, "host", "host_abi.cpp"), os.path.join(CSRC, "host", "packed.cpp"),
            os.path.join(CSRC, "host", "pipeline.cpp"), os.path.join(CSRC, "host", "records.cpp")]
@@ -28,6 +28,8 @@ def _headers(src=None):
     is_dev = src is None or not is_host
     if is_host:
         deps.append(os.path.join(inc, "rabe_host.h"))
+    if src is not None and os.path.basename(src) == "engine_coop_w1.hip":          # that unit IS engine_coop.hip, compiled for one wave per SIMD
+        deps.append(os.path.join(CSRC, "engine_coop.hip"))
     for root, _dirs, files in os.walk(CSRC):
         if (root == host_dir and not is_host) or (root != host_dir and not is_dev):
             continue
@@ -36,7 +38,7 @@ def _headers(src=None):
 
 
 LIB_SAFE = os.path.join(HERE, "librabe_hip_safe.so")          # the RB_SAFE_CARRY build of the same sources (fp.h): an A/B reference
-DEVICE_SOURCES = SOURCES[:3]
+DEVICE_SOURCES = SOURCES[:4]
 
 
 def _obj(src, safe=False):

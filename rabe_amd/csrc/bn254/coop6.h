@@ -252,10 +252,94 @@ template <class CX> RB_HD Fp2 c6_mul(CX cx, const Fp2& a, const Fp2& b) {      /
   return r;
 }
 
+// ---- one line event of ONE pair on TWO lanes (A = even lane, B = its odd neighbour): the G2 step of pairing.h (g2hom_double /
+// g2hom_add: the same field elements, so the same line and the same running point) with its ten to fifteen Fq2 products split over the
+// two lanes.  Lanes of a wave share one instruction stream, so the split is written as ROUNDS: in every round both lanes execute the
+// same Fq2 multiplication (or squaring) on operands chosen by their role -- two different code paths would simply run one after the
+// other.  Intermediate values are handed over through the lanes' slots of rows L0 / L1 / L3; lane A ends with the scaled line
+// (l0, l1, l3) in ITS slots of those rows.  The running point lives where acc keeps it, coordinate by coordinate.
+//   doubling (2 squarings + 4 products deep, against 6 + 4 + 2 scalings in one lane):
+//     A:  C = Z^2      E = 3 b' C    E^2      | G^2          (-H) yP      (3 J) xP        -> Y3 = G^2 - 3 E^2, l3 = E - B
+//     B:  J = X^2      Y Z           B = Y^2  | X Y          A (B - F)    B H             -> X3, Z3            (A = X Y / 2, H = 2 Y Z)
+//   addition (1 squaring + 7 products deep, against 2 + 11 + 2 scalings):
+//     A:  qy Z | theta^2    theta qx    Z c    lambda yP | theta (g - h)    e Y    (-theta) xP    -> Y3, l3 = theta qx - lambda qy
+//     B:  qx Z | lambda^2   lambda qy   e      g = X d   | lambda h         Z e    --             -> X3, Z3
+// A pair that replays prepared lines joins the two scaling rounds; a pair without a step runs along on zeros.
+// ACC additionally provides  Fp2 ld_tc(int j, int c) / void st_tc(int j, int c, const Fp2&)  (c = 0, 1, 2: X, Y, Z of pair j's point).
+RB_HD Fp2 fp2_from_fp(const Fp& a) { return Fp2{a, zero<FpParams>()}; }
+template <class CX, class ACC>
+RB_HD void c6_pair_step(CX cx, ACC acc, int j, bool have, int kind, int mode, int ln) {
+  const int k = cx.role();
+  const bool isB = k & 1, walk = have && kind == MP_WALK, lines = have && kind == MP_LINES && !isB;
+  const int other = isB ? k - 1 : k + 1;
+  const Fp2 Z0 = fp2_zero();
+  MillerP p{zero<FpParams>(), zero<FpParams>(), zero<FpParams>(), false};
+  LineCoeffs pl{Z0, Z0, Z0};
+  if (have && !isB && kind != MP_SKIP) p = acc.p(j);
+  if (lines) pl = acc.line(j, ln);
+  Fp2 l0 = Z0, l1 = Z0, l3 = pl.c0;
+  if (mode == MS_DBL) {
+    Fp2 x = Z0, y = Z0, z = Z0;
+    if (walk) { z = acc.ld_tc(j, 2); if (isB) { x = acc.ld_tc(j, 0); y = acc.ld_tc(j, 1); } }
+    const Fp2 r1 = fp2_sqr(isB ? x : z);                                   // A: C      B: J
+    const Fp2 r2 = fp2_mul(isB ? y : twist_b(), isB ? z : fp2_add(fp2_dbl(r1), r1));      // A: E      B: Y Z
+    const Fp2 r3 = fp2_sqr(isB ? y : r2);                                  // A: E^2    B: B
+    const Fp2 f3 = fp2_add(fp2_dbl(r2), r2), h2 = fp2_dbl(r2);             // A: F = 3 E            B: H = 2 Y Z
+    if (walk) { cx.st(C6_L0, isB ? r3 : f3); if (isB) { cx.st(C6_L1, h2); cx.st(C6_L3, r1); } }
+    cx.sync();
+    Fp2 o0 = Z0, o1 = Z0, o2 = Z0;
+    if (walk) { o0 = cx.ld(C6_L0, other); if (!isB) { o1 = cx.ld(C6_L1, other); o2 = cx.ld(C6_L3, other); } }       // A: B, H, J    B: F
+    cx.sync();
+    const Fp2 g = fp2_half(fp2_add(o0, f3));
+    const Fp2 r4 = fp2_mul(isB ? x : g, isB ? y : g);                      // A: G^2    B: X Y
+    const Fp2 cy = lines ? pl.cy : fp2_neg(o1), cxl = lines ? pl.cx : fp2_add(fp2_dbl(o2), o2);
+    const Fp2 r5 = fp2_mul(isB ? fp2_half(r4) : cy, isB ? fp2_sub(r3, o0) : fp2_from_fp(p.py));      // A: l0     B: X3 = A (B - F)
+    const Fp2 r6 = fp2_mul(isB ? r3 : cxl, isB ? h2 : fp2_from_fp(p.px));                            // A: l1     B: Z3 = B H
+    if (walk && isB) { acc.st_tc(j, 0, r5); acc.st_tc(j, 2, r6); }
+    if (walk && !isB) { acc.st_tc(j, 1, fp2_sub(r4, fp2_add(fp2_dbl(r3), r3))); l3 = fp2_sub(r2, o0); }
+    l0 = r5; l1 = r6;
+  } else {
+    G2Aff q{Z0, Z0};
+    if (walk) {
+      q = acc.q(j);
+      if (mode == MS_ADD_NEG) q.y = fp2_neg(q.y);
+      else if (mode == MS_FROB1) q = g2_frob1(q);
+      else if (mode == MS_FROB2) q = aff_neg(g2_frob2(q));
+    }
+    Fp2 z = Z0, xy = Z0;
+    if (walk) { z = acc.ld_tc(j, 2); xy = acc.ld_tc(j, isB ? 0 : 1); }    // B: X, A: Y
+    const Fp2 t0 = fp2_sub(xy, fp2_mul(isB ? q.x : q.y, z));               // A: theta  B: lambda
+    if (walk) cx.st(C6_L0, t0);
+    cx.sync();
+    Fp2 t1 = Z0;
+    if (walk) t1 = cx.ld(C6_L0, other);                                    // A: lambda B: theta
+    cx.sync();
+    const Fp2 r2 = fp2_sqr(t0);                                            // A: c      B: d
+    const Fp2 r3 = fp2_mul(t0, isB ? q.y : q.x);                           // A: theta qx           B: lambda qy
+    const Fp2 r4 = fp2_mul(isB ? t0 : z, r2);                              // A: f = Z c            B: e = lambda d
+    const Fp2 r5 = fp2_mul(isB ? xy : (lines ? pl.cy : t1), isB ? r2 : fp2_from_fp(p.py));           // A: l0 (cy = lambda)   B: g = X d
+    if (walk) { cx.st(C6_L0, r4); if (isB) { cx.st(C6_L1, r5); cx.st(C6_L3, r3); } }
+    cx.sync();
+    Fp2 o0 = Z0, o1 = Z0, o2 = Z0;
+    if (walk) { o0 = cx.ld(C6_L0, other); if (!isB) { o1 = cx.ld(C6_L1, other); o2 = cx.ld(C6_L3, other); } }       // A: e, g, lambda qy    B: f
+    cx.sync();
+    const Fp2 e = isB ? r4 : o0, f = isB ? o0 : r4, g = isB ? r5 : o1;
+    const Fp2 h = fp2_sub(fp2_add(e, f), fp2_dbl(g));
+    const Fp2 r6 = fp2_mul(t0, isB ? h : fp2_sub(g, h));                   // A: theta (g - h)      B: X3 = lambda h
+    const Fp2 r7 = fp2_mul(isB ? z : e, isB ? e : xy);                     // A: e Y                B: Z3 = Z e
+    const Fp2 r8 = fp2_mul(lines ? pl.cx : fp2_neg(t0), fp2_from_fp(p.px));                          // A: l1 (cx = -theta)
+    if (walk && isB) { acc.st_tc(j, 0, r6); acc.st_tc(j, 2, r7); }
+    if (walk && !isB) { acc.st_tc(j, 1, fp2_sub(r6, r7)); l3 = fp2_sub(r3, o2); }
+    l0 = r5; l1 = r8;
+  }
+  if ((walk || lines) && !isB) { cx.st(C6_L0, l0); cx.st(C6_L1, l1); cx.st(C6_L3, l3); }
+  cx.sync();
+}
+
 // ---- Miller loop, any number of pairs of ONE group on one accumulator: the same value as miller_loop_multi (pairing.h), the same
-// ACC interface.  Pair j belongs to lane j mod 6: that lane walks its G2 point (or fetches its prepared line) and scales the line by
-// its P -- the six lanes of a group work on six pairs at once -- then the group multiplies the accumulator by the lines one after the
-// other.  cmax: the largest pair count among the groups that run in lockstep with this one (device: of the wave; host: count()).
+// ACC interface.  The group's pairs are taken three at a time: pair base + p belongs to lanes 2p and 2p + 1, which walk its G2 point
+// together (c6_pair_step) or fetch its prepared line and scale it by P -- then the group multiplies the accumulator by the three lines
+// one after the other.  cmax: the largest pair count among the groups that run in lockstep with this one (device: of the wave; host: count()).
 template <class CX, class ACC>
 RB_FN Fp2 c6_miller_loop_multi(CX cx, ACC acc, int cmax) {
   const int n = acc.count(), k = cx.role();
@@ -263,9 +347,10 @@ RB_FN Fp2 c6_miller_loop_multi(CX cx, ACC acc, int cmax) {
   for (int j = k; j < n; j += 6) {
     if (acc.kind(j) == MP_WALK) {
       const G2Aff q = acc.q(j);
-      acc.st_t(j, G2Hom{q.x, q.y, fp2_one()});
+      acc.st_tc(j, 0, q.x); acc.st_tc(j, 1, q.y); acc.st_tc(j, 2, fp2_one());
     }
   }
+  cx.sync();
   int i = RB_ATE_NAF_LEN - 2;
   bool add_pending = false;
 #pragma unroll 1
@@ -288,22 +373,16 @@ RB_FN Fp2 c6_miller_loop_multi(CX cx, ACC acc, int cmax) {
       i--;
     }
 #pragma unroll 1
-    for (int base = 0; base < cmax; base += 6) {
-      const int j = base + k;
-      LineCoeffs l;
-      const bool have = j < n && miller_multi_line(acc, j, mode, ln, l);
-      if (have) {
-        const MillerP p = acc.p(j);
-        cx.st(C6_L0, fp2_mul_fp(l.cy, p.py));
-        cx.st(C6_L1, fp2_mul_fp(l.cx, p.px));
-        cx.st(C6_L3, l.c0);
-      }
-      cx.sync();
-      const int m = cmax - base < 6 ? cmax - base : 6;
+    for (int base = 0; base < cmax; base += 3) {
+      const int j = base + (k >> 1);
+      const bool have = j < n;
+      const int kind = have ? acc.kind(j) : MP_SKIP;
+      c6_pair_step(cx, acc, j, have, kind, mode, ln);
+      const int m = cmax - base < 3 ? cmax - base : 3;
 #pragma unroll 1
       for (int jj = 0; jj < m; jj++) {
         const bool active = base + jj < n && acc.kind(base + jj) != MP_SKIP;       // the same for the six lanes of a group
-        const Fp2 r = c6_dot(cx, C6_OP_LINE, jj);
+        const Fp2 r = c6_dot(cx, C6_OP_LINE, 2 * jj);
         if (active) c6_put_f(cx, r);
       }
       cx.sync();

@@ -17,8 +17,19 @@
 #include "bn254/selftest.h"
 #include <mutex>
 
+// This file is compiled TWICE (engine_coop_w1.hip includes it with RB_C6_W1_UNIT): the kernels below exist in a variant built for two
+// resident waves per SIMD (256 registers: launches that fill the chip) and one built for ONE (the whole 512-entry file: nothing of the
+// Miller loop spills -- 12 % faster when a launch puts at most one wave on a SIMD anyway).  Two translation units because device
+// functions are not linked across units: every out-of-line function (c6_dot, fp2_mul_regs, fp6_inv, ...) then exists once per variant
+// with that variant's register budget -- in one unit the shared callees take the larger budget and the two-wave kernels lose their occupancy.
+#ifdef RB_C6_W1_UNIT
+#define RB_C6_WAVES 1
+#define C6K(name) name##_w1
+#else
 #ifndef RB_C6_WAVES
 #define RB_C6_WAVES 2
+#endif
+#define C6K(name) name
 #endif
 #define C6_GROUPS 10                                   // groups of six lanes per wave
 #define C6_LDS_QUADS (C6_ROWS * 4 * 64)                // 20 KB per wave: eight waves per CU
@@ -107,6 +118,15 @@ struct DevAcc6 {
     p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
     p[64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
   }
+  // one coordinate (c = 0, 1, 2: X, Y, Z) of pair j's running point: quads [4 c, 4 c + 4) of its twelve
+  __device__ __forceinline__ Fp2 ld_tc(int j, int c) const {
+    const uint4* p = ws + (size_t)(12 * j + 4 * c) * 64;
+    return Fp2{ld1(p), ld1(p + 2 * 64)};
+  }
+  __device__ __forceinline__ void st_tc(int j, int c, const Fp2& v) const {
+    uint4* p = ws + (size_t)(12 * j + 4 * c) * 64;
+    st1(p, v.c0); st1(p + 2 * 64, v.c1);
+  }
   __device__ __forceinline__ G2Hom ld_t(int j) const {
     const uint4* p = ws + (size_t)(12 * j) * 64;
     G2Hom t;
@@ -133,7 +153,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 // group G = chunk * n_items + item, the lane -> (item, chunk) map of k_miller_multi (engine_jobs.hip) with "lane" read as "group";
 // plan != NULL: entry G of the device-made work list of a ragged batch.  Output: mill[item * L + c] / mill[chunk_off[item] + c].
-__global__ void __launch_bounds__(64, RB_C6_WAVES) k_miller_c6(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
+__global__ void __launch_bounds__(64, RB_C6_WAVES) C6K(k_miller_c6)(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
                                                                const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, GtM* mill,
                                                                const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
   __shared__ uint4 rows[C6_LDS_QUADS];
@@ -179,7 +199,7 @@ __global__ void __launch_bounds__(64, RB_C6_WAVES) k_miller_c6(size_t n_items, u
 }
 
 // out[item] = (mul_in ? mul_in[item] : 1) * FE( prod_{j in [off[item], off[item+1])} mill[j] ), canonical -- k_final_exp's contract
-__global__ void __launch_bounds__(64, RB_C6_WAVES) k_final_exp_c6(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
+__global__ void __launch_bounds__(64, RB_C6_WAVES) C6K(k_final_exp_c6)(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
                                                                   rhip_gt* out, uint32_t* started) {
   __shared__ uint4 rows[C6_LDS_QUADS];
   if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }
@@ -214,7 +234,7 @@ __global__ void __launch_bounds__(64, RB_C6_WAVES) k_final_exp_c6(size_t n_items
 // window digit's table entry goes into the multiplier row, the accumulator is multiplied by it.  w16: 16 windows of 65535 entries,
 // else 32 of 255 (engine_internal.h: TBL16_* / TBL_*).  The products of a wave's groups run in lockstep; a zero digit (no entry) only
 // skips the commit.
-__global__ void __launch_bounds__(64, RB_C6_WAVES) k_gt_table_pow_c6(const GtM* t0, const GtM* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride,
+__global__ void __launch_bounds__(64, RB_C6_WAVES) C6K(k_gt_table_pow_c6)(const GtM* t0, const GtM* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride,
                                                                      const rhip_gt* mul_in, rhip_gt* out) {
   __shared__ uint4 rows[C6_LDS_QUADS];
   const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g, ti = c6_tower_index(r);
@@ -261,6 +281,34 @@ __global__ void __launch_bounds__(64, RB_C6_WAVES) k_gt_table_pow_c6(const GtM* 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// raw launches of this unit's variant
+int32_t C6K(rhip_c6_raw_miller)(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
+                                const uint32_t* qref, const void* lines, void* ws, void* mill, const MillerPlan* plan, const void* work, const uint32_t* chunk_off,
+                                size_t groups) {
+  KLAUNCH(ctx, "k_miller_c6", C6K(k_miller_c6), dim3(blocks_for(groups, C6_GROUPS)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, uniform, (const G1M*)P,
+          (const G2M*)Q, qref, (const LineM*)lines, (uint4*)ws, (GtM*)mill, plan, (const uint2*)work, chunk_off);
+  return RHIP_OK;
+}
+int32_t C6K(rhip_c6_raw_final_exp)(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                   uint32_t* started) {
+  KLAUNCH(ctx, "k_final_exp_c6", C6K(k_final_exp_c6), dim3(blocks_for(n_items, C6_GROUPS)), dim3(64), 0, ctx->stream, n_items, off, stride, (const GtM*)mill, mul_in,
+          out, started);
+  return RHIP_OK;
+}
+int32_t C6K(rhip_c6_raw_gt_table_pow)(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
+                                      rhip_gt* out) {
+  KLAUNCH(ctx, "k_gt_table_pow_c6", C6K(k_gt_table_pow_c6), dim3(blocks_for(n_items, C6_GROUPS)), dim3(64), 0, ctx->stream, (const GtM*)t0, (const GtM*)t1, w16, n_items,
+          k, kstride, mul_in, out);
+  return RHIP_OK;
+}
+#ifndef RB_C6_W1_UNIT
+int32_t rhip_c6_raw_miller_w1(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
+                              const uint32_t* qref, const void* lines, void* ws, void* mill, const MillerPlan* plan, const void* work, const uint32_t* chunk_off, size_t groups);
+int32_t rhip_c6_raw_final_exp_w1(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out, uint32_t* started);
+int32_t rhip_c6_raw_gt_table_pow_w1(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
+                                    rhip_gt* out);
+// a launch of at most one wave per SIMD takes the one-wave variant
+static bool c6_one_wave(const rhip_ctx* ctx, size_t groups) { return blocks_for(groups, C6_GROUPS) <= (unsigned)ctx->n_cu * 4; }
 // When the six-lane kernels run.  Mode 6 (rhip_ctx_set_pairing_mode, or RABE_PAIRING_MODE=6 in the environment of rhip_ctx_create):
 // always.  Mode 0 (auto; RABE_C6_AUTO=0 turns it off): where they are faster, by the measured instruction counts
 // (profiles/r05a_pmc_sq_lone_c6.txt; a lone wave issues one VALU instruction per ~5.2 cycles, two or more per SIMD one per ~4.5):
@@ -306,17 +354,17 @@ bool rhip_use_c6(const rhip_ctx* ctx, size_t n_items, size_t max_pairs) {
 int32_t rhip_launch_miller_c6(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, void* ws, void* mill, const MillerPlan* plan, const void* work, const uint32_t* chunk_off,
                               size_t groups) {
-  KLAUNCH(ctx, "k_miller_c6", k_miller_c6, dim3(blocks_for(groups, C6_GROUPS)), dim3(64), 0, ctx->stream, n_items, L, C, pair_off, uniform, (const G1M*)P, (const G2M*)Q,
-          qref, (const LineM*)lines, (uint4*)ws, (GtM*)mill, plan, (const uint2*)work, chunk_off);
-  return RHIP_OK;
+  return (c6_one_wave(ctx, groups) ? rhip_c6_raw_miller_w1 : rhip_c6_raw_miller)(ctx, n_items, L, C, pair_off, uniform, P, Q, qref, lines, ws, mill, plan, work, chunk_off,
+                                                                                 groups);
 }
 int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
                                  uint32_t* started) {
-  KLAUNCH(ctx, "k_final_exp_c6", k_final_exp_c6, dim3(blocks_for(n_items, C6_GROUPS)), dim3(64), 0, ctx->stream, n_items, off, stride, (const GtM*)mill, mul_in, out,
-          started);
-  return RHIP_OK;
+  return (c6_one_wave(ctx, n_items) ? rhip_c6_raw_final_exp_w1 : rhip_c6_raw_final_exp)(ctx, n_items, off, stride, mill, mul_in, out, started);
 }
-
+int32_t rhip_launch_gt_table_pow_c6(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
+                                    rhip_gt* out) {
+  return (c6_one_wave(ctx, n_items) ? rhip_c6_raw_gt_table_pow_w1 : rhip_c6_raw_gt_table_pow)(ctx, t0, t1, w16, n_items, k, kstride, mul_in, out);
+}
 // ------------------------------------------------------------------------------------------------ known-answer self-test
 // bn254/selftest.h on every SIMD of the device: every wave computes the 64 lanes' digests and compares them with the compiled-in
 // expectation; lane 0 records which SIMD the wave ran on (XCC_ID and the SE / SH / CU / SIMD fields of HW_ID).
@@ -377,12 +425,6 @@ extern "C" int32_t rhip_ctx_selftest_info(rhip_ctx* ctx, uint32_t* simds_checked
   return rhip_device_selftest(ctx, simds_checked, nullptr);
 }
 
-int32_t rhip_launch_gt_table_pow_c6(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
-                                    rhip_gt* out) {
-  KLAUNCH(ctx, "k_gt_table_pow_c6", k_gt_table_pow_c6, dim3(blocks_for(n_items, C6_GROUPS)), dim3(64), 0, ctx->stream, (const GtM*)t0, (const GtM*)t1, w16, n_items, k,
-          kstride, mul_in, out);
-  return RHIP_OK;
-}
 // the fixed-base Gt kernels: 32 (16-bit windows) or 64 dependent products per item in one lane against ~5 k instructions each here
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items) {
   if (ctx->pairing_mode == 6) return true;
@@ -390,3 +432,4 @@ bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items) {
   static const int auto_on = getenv("RABE_C6_AUTO") ? atoi(getenv("RABE_C6_AUTO")) : 1;
   return auto_on && n_items <= (size_t)ctx->n_cu * 4 * 32;
 }
+#endif  // !RB_C6_W1_UNIT

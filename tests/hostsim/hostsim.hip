@@ -272,6 +272,8 @@ struct HostMultiAcc {
   LineCoeffs line(int j, int k) const { return lines[j * RB_MILLER_LINES + k]; }
   G2Hom ld_t(int j) const { return T[j]; }
   void st_t(int j, const G2Hom& t) const { T[j] = t; }
+  Fp2 ld_tc(int j, int c) const { return c == 0 ? T[j].x : c == 1 ? T[j].y : T[j].z; }
+  void st_tc(int j, int c, const Fp2& v) const { (c == 0 ? T[j].x : c == 1 ? T[j].y : T[j].z) = v; }
 };
 template <class F>
 struct HostTerms {
