@@ -39,7 +39,8 @@ struct Wide3 {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 // wide_mac3 comes from tools/gen_fp_asm.py (fp_gfx950_gen.h): wide_mul3 with the running sums added in column by column
-RB_HD void wide3_mac(Wide3& T, const Fp2& x, const Fp2& y) {
+template <bool FIRST>
+RB_HD void wide3_mac_t(Wide3& T, const Fp2& x, const Fp2& y) {
   uint32_t sa[8], sb[8];
   { uint32_t c = 0;
 #pragma unroll
@@ -47,8 +48,11 @@ RB_HD void wide3_mac(Wide3& T, const Fp2& x, const Fp2& y) {
   { uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) sb[i] = addc32(y.c0.v[i], y.c1.v[i], c); }
-  wide_mac3(T.t0, T.t1, T.t2, x.c0.v, y.c0.v, x.c1.v, y.c1.v, sa, sb);
+  if (FIRST) wide_mul3(T.t0, T.t1, T.t2, x.c0.v, y.c0.v, x.c1.v, y.c1.v, sa, sb);        // the first product DEFINES the sums
+  else wide_mac3(T.t0, T.t1, T.t2, x.c0.v, y.c0.v, x.c1.v, y.c1.v, sa, sb);
 }
+RB_HD void wide3_mac(Wide3& T, const Fp2& x, const Fp2& y) { wide3_mac_t<false>(T, x, y); }
+RB_HD void wide3_first(Wide3& T, const Fp2& x, const Fp2& y) { wide3_mac_t<true>(T, x, y); }
 #else
 RB_HD void wide_mac1_portable(uint32_t* T, const uint32_t* a, const uint32_t* b) {     // T += a b mod 2^512
   for (int i = 0; i < 8; i++) {
@@ -77,6 +81,10 @@ RB_HD void wide3_mac(Wide3& T, const Fp2& x, const Fp2& y) {
   wide_mac1_portable(T.t0, a0, b0);
   wide_mac1_portable(T.t1, a1, b1);
   wide_mac1_portable(T.t2, sa, sb);
+}
+RB_HD void wide3_first(Wide3& T, const Fp2& x, const Fp2& y) {
+  for (int i = 0; i < 16; i++) { T.t0[i] = 0; T.t1[i] = 0; T.t2[i] = 0; }
+  wide3_mac(T, x, y);
 }
 RB_HD void redc_portable(uint32_t* r, const uint32_t* W) {       // W < 2^512, (W + m p) / 2^256 < 2^256 for every caller here
   uint32_t t[17];
@@ -107,7 +115,9 @@ RB_HD void wide3_zero(Wide3& T) {
 // sum of n <= 6 products (every operand < p): c0 = (T0 - T1 + 6 p^2) / R, c1 = (T2 - T0 - T1) / R mod p.
 // T2 < 24 p^2 < 2^512 (tools/gen_constants.py asserts it); both numerators are in [0, 12 p^2), so a reduction leaves < 3.27 p:
 // three conditional subtractions (one inside the reduction routine).
-RB_HD Fp2 wide3_finish(const Wide3& T) {
+// n: the number of products in the sums -- it bounds the value a reduction leaves, i.e. how many conditional subtractions follow
+// (with the fixed offset 6 p^2: c0 < ((n + 6) 0.1892 + 1) p, c1 < (2 n 0.1892 + 1) p)
+RB_HD Fp2 wide3_finish(const Wide3& T, int n = 6) {
   constexpr uint32_t off[16] = RB_FP_6P2;
   uint32_t W0[16], W1[16];
   { uint32_t br = 0;
@@ -129,10 +139,10 @@ RB_HD Fp2 wide3_finish(const Wide3& T) {
   redc_portable(c0, W0);
   redc_portable(c1, W1);
 #endif
-  cond_sub_mod<FpParams>(c0, 0);
-  cond_sub_mod<FpParams>(c0, 0);
-  cond_sub_mod<FpParams>(c1, 0);
-  cond_sub_mod<FpParams>(c1, 0);
+  cond_sub_mod<FpParams>(c0, 0);                 // n <= 4: c0 < 2.9 p, one more than the reduction's own
+  if (n > 4) cond_sub_mod<FpParams>(c0, 0);      // n <= 6: c0 < 3.27 p
+  if (n > 2) cond_sub_mod<FpParams>(c1, 0);      // n <= 2: c1 < 1.76 p (none); n <= 5: c1 < 2.9 p
+  if (n > 5) cond_sub_mod<FpParams>(c1, 0);      // n = 6: c1 < 3.27 p
   Fp2 r;
 #pragma unroll
   for (int i = 0; i < 8; i++) { r.c0.v[i] = c0[i]; r.c1.v[i] = c1[i]; }
@@ -188,20 +198,23 @@ RB_HD Fp2 fp2_select(bool c, const Fp2& a, const Fp2& b) {
 template <class CX>
 RB_FN Fp2 c6_dot(CX cx, int op, int j) {
   Wide3 T;
-  wide3_zero(T);
   const int n = c6_op_slots(op), k = cx.role();
+  {          // the first product defines the sums (no flags: SQR's halved / empty steps are its last two)
+    const C6Slot e = c6_slot(op, 0, k, j);
+    wide3_first(T, cx.ld(e.xrow, e.xlane), cx.ld(e.yrow, e.ylane));
+  }
 #pragma unroll 1
-  for (int s = 0; s < n; s++) {
+  for (int s = 1; s < n; s++) {
     const C6Slot e = c6_slot(op, s, k, j);
     const Fp2 x = cx.ld(e.xrow, e.xlane);
     Fp2 y = cx.ld(e.yrow, e.ylane);
-    if (op == C6_OP_SQR) {
+    if (op == C6_OP_SQR && s >= 2) {
       y = fp2_select(e.flag == 1, fp2_half(y), y);
       y = fp2_select(e.flag == 2, fp2_zero(), y);
     }
     wide3_mac(T, x, y);
   }
-  return wide3_finish(T);
+  return wide3_finish(T, n);
 }
 // publish the group's new value: row F gets r, row FX gets xi r
 template <class CX>

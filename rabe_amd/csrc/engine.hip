@@ -29,6 +29,22 @@ void rhip_ktime_end(rhip_ctx* ctx) {
   if (!ctx->timing || ctx->pending.empty()) return;
   (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
 }
+int32_t rhip_fork(rhip_ctx* ctx) {
+  if (!ctx->fork[0]) {
+    for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fork[i], hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_ev[i], hipEventDisableTiming));
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->fork_ev[0], ctx->stream));
+  for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->fork[i], ctx->fork_ev[0], 0));
+  return RHIP_OK;
+}
+int32_t rhip_join(rhip_ctx* ctx) {
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(ctx, hipEventRecord(ctx->fork_ev[1 + i], ctx->fork[i]));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->fork_ev[1 + i], 0));
+  }
+  return RHIP_OK;
+}
 int32_t rhip_fail(rhip_ctx* ctx, hipError_t e, const char* what) {
   if (ctx) {
     ctx->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -138,6 +154,8 @@ extern "C" void rhip_ctx_destroy(rhip_ctx* ctx) {
   if (ctx->fe_ws) (void)hipFree(ctx->fe_ws);
   if (ctx->fe_started) (void)hipFree(ctx->fe_started);
   for (int i = 0; i < rhip_ctx::N_WORK; i++) if (ctx->work[i]) (void)hipFree(ctx->work[i]);
+  for (int i = 0; i < 2; i++) if (ctx->fork[i]) { (void)hipStreamSynchronize(ctx->fork[i]); (void)hipStreamDestroy(ctx->fork[i]); }
+  for (int i = 0; i < 3; i++) if (ctx->fork_ev[i]) (void)hipEventDestroy(ctx->fork_ev[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1540,22 +1558,14 @@ extern "C" int32_t rhip_ac17_pk_set_g_window(rhip_ctx* ctx, rhip_ac17_pk* pk, in
   if (!pk) return RHIP_ERR_ARG;
   return rhip_g1_table_add_wide(ctx, pk->g, w_bits);
 }
-extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* A,
-                                              const uint32_t* item_A_off, const uint32_t* ct_row_off, size_t total_rows,
-                                              const rhip_fr* s, const rhip_gt* msg, rhip_g2* c0, rhip_g1* c, rhip_gt* cp) {
-  NEED(ctx);
-  if (!pk) return RHIP_ERR_ARG;
-  if (!n_items) return RHIP_OK;
-  if (total_rows) {
-    const rhip_g1_table* g = pk->g;
-    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, RB_ROWS_BLOCK)), dim3(RB_ROWS_BLOCK), 0, ctx->stream,
-            (const G1M*)(g->wide ? g->wide : g->dev16 ? g->dev16 : g->dev), n_items, total_rows, A, item_A_off, ct_row_off, s, c,
-            g->wide ? g->wide_bits : g->dev16 ? 1 : 0);
-  }
+static int32_t ac17_enc_c0_launch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* s, rhip_g2* c0) {
   const bool g2w16 = pk->h_a[0]->dev16 && pk->h_a[1]->dev16 && pk->h_a[2]->dev16;
   KLAUNCH(ctx, "k_ac17_enc_c0", k_ac17_enc_c0, dim3(blocks_for(n_items * 3, 128)), dim3(128), 0, ctx->stream,
           (const G2M*)(g2w16 ? pk->h_a[0]->dev16 : pk->h_a[0]->dev), (const G2M*)(g2w16 ? pk->h_a[1]->dev16 : pk->h_a[1]->dev),
           (const G2M*)(g2w16 ? pk->h_a[2]->dev16 : pk->h_a[2]->dev), n_items, s, c0, g2w16 ? 1 : 0);
+  return RHIP_OK;
+}
+static int32_t ac17_enc_cp_launch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* s, const rhip_gt* msg, rhip_gt* cp) {
   const bool gt16 = pk->e[0]->dev16 && pk->e[1]->dev16;
   if (rhip_use_c6_gt_pow(ctx, n_items))          // small launches: six lanes per running product (engine_coop.hip), the same field elements
     return rhip_launch_gt_table_pow_c6(ctx, gt16 ? pk->e[0]->dev16 : pk->e[0]->dev, gt16 ? pk->e[1]->dev16 : pk->e[1]->dev, gt16 ? 1 : 0, n_items, s, 2u, msg, cp);
@@ -1563,6 +1573,40 @@ extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk*
           (const GtM*)(gt16 ? pk->e[0]->dev16 : pk->e[0]->dev), (const GtM*)(gt16 ? pk->e[1]->dev16 : pk->e[1]->dev), n_items, s, msg, cp,
           gt16 ? 1 : 0);
   return RHIP_OK;
+}
+extern "C" int32_t rhip_ac17_cp_encrypt_batch(rhip_ctx* ctx, const rhip_ac17_pk* pk, size_t n_items, const rhip_fr* A,
+                                              const uint32_t* item_A_off, const uint32_t* ct_row_off, size_t total_rows,
+                                              const rhip_fr* s, const rhip_gt* msg, rhip_g2* c0, rhip_g1* c, rhip_gt* cp) {
+  NEED(ctx);
+  if (!pk) return RHIP_ERR_ARG;
+  if (!n_items) return RHIP_OK;
+  // c (rows), c_0 and c_p of a batch are independent: a launch too small to fill the chip with each of them runs the three side by side
+  // (RABE_ENC_FORK=0: one after the other)
+  static const int fork_on = getenv("RABE_ENC_FORK") ? atoi(getenv("RABE_ENC_FORK")) : 1;
+  const bool forked = fork_on && n_items <= 8192 && total_rows;
+  if (forked) { const int32_t rc = rhip_fork(ctx); if (rc) return rc; }
+  if (forked) {
+    int32_t rc = RHIP_OK;
+    {
+      RhipOnFork f(ctx, 0);
+      rc = ac17_enc_c0_launch(ctx, pk, n_items, s, c0);
+    }
+    if (!rc) {
+      RhipOnFork f(ctx, 1);
+      rc = ac17_enc_cp_launch(ctx, pk, n_items, s, msg, cp);
+    }
+    if (rc) return rc;
+  }
+  if (total_rows) {
+    const rhip_g1_table* g = pk->g;
+    KLAUNCH(ctx, "k_ac17_enc_rows", k_ac17_enc_rows, dim3(blocks_for(total_rows, RB_ROWS_BLOCK)), dim3(RB_ROWS_BLOCK), 0, ctx->stream,
+            (const G1M*)(g->wide ? g->wide : g->dev16 ? g->dev16 : g->dev), n_items, total_rows, A, item_A_off, ct_row_off, s, c,
+            g->wide ? g->wide_bits : g->dev16 ? 1 : 0);
+  }
+  if (forked) return rhip_join(ctx);
+  int32_t rc = ac17_enc_c0_launch(ctx, pk, n_items, s, c0);
+  if (rc) return rc;
+  return ac17_enc_cp_launch(ctx, pk, n_items, s, msg, cp);
 }
 extern "C" int32_t rhip_ac17_cp_keygen_batch(rhip_ctx* ctx, const rhip_g1_table* g_table, const rhip_g2_table* h_table, const rhip_g1* g_k,
                                              const rhip_fr* a_inv, const rhip_fr* b, size_t n_items, size_t n_attrs, const rhip_fr* H,

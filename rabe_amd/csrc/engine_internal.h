@@ -57,6 +57,10 @@ struct rhip_ctx {
   uint32_t* walk_count = nullptr;
   bool fe_waiter_poll = true;      // false: the waiter is released when the Miller loops are done, without waiting for the final exponentiation's blocks
   rhip_ctx* fe_waiter = nullptr;   // one-shot (rhip_ctx_release_before_final_exp): released after this context's next Miller launch
+  // two side streams for launch sets whose kernels are independent and too small to fill the chip one by one (rhip_fork / rhip_join,
+  // engine.hip): created on first use
+  hipStream_t fork[2] = {nullptr, nullptr};
+  hipEvent_t fork_ev[3] = {nullptr, nullptr, nullptr};
   bool timing = false;
   struct Pending { std::string name; hipEvent_t e0, e1; };
   std::vector<Pending> pending;
@@ -65,6 +69,15 @@ struct rhip_ctx {
 void rhip_ktime_begin(rhip_ctx* ctx, const char* name);
 void rhip_ktime_end(rhip_ctx* ctx);
 int32_t rhip_fail(rhip_ctx* ctx, hipError_t e, const char* what);
+// fork: the side streams wait for everything queued on ctx->stream so far; join: ctx->stream waits for what was queued on them since.
+// Between the two, `RhipOnFork f(ctx, i)` makes ctx->stream side stream i for the launches in its scope.
+int32_t rhip_fork(rhip_ctx* ctx);
+int32_t rhip_join(rhip_ctx* ctx);
+struct RhipOnFork {
+  rhip_ctx* c; hipStream_t main;
+  RhipOnFork(rhip_ctx* ctx, int i) : c(ctx), main(ctx->stream) { c->stream = c->fork[i]; }
+  ~RhipOnFork() { c->stream = main; }
+};
 int32_t rhip_ensure_scratch(rhip_ctx* ctx, size_t bytes);
 int32_t rhip_ensure_fe_ws(rhip_ctx* ctx, size_t bytes);
 int32_t rhip_ensure_work(rhip_ctx* ctx, int slot, size_t bytes, void** out);

@@ -16,6 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "engine_internal.h"
+// the S-box lookup below reads one register of the WAVE through ds_bpermute with `threadIdx.x & 63`: 64-wide wavefronts only
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "engine_sym.hip is written for 64-lane wavefronts (gfx950)"
+#endif
 
 namespace {
 

@@ -173,6 +173,10 @@ class Engine {
   // The current call stages secret material (master-key-derived scalars of a bulk keygen): when its outermost ArenaScope ends, what the
   // call used of the lane's device arena and of its pinned staging buffers is overwritten with zeros -- both outlive the call otherwise.
   void scrub_when_done();
+  // the lighter form for calls that only hold SESSION secrets (the Gt values and AES key schedules of a seal / open, the encryption
+  // scalars): what the call used of the device arena and of pinned slot 0 is zeroed -- not the staged record blobs (hundreds of MB of
+  // public ciphertext whose host-side memset would cost more than the call)
+  void scrub_session_when_done();
   // the lane's SIDE context (a second stream, created on first use): work that may run beside the main context's kernels
   rhip_ctx* side_ctx();
   void* arena_take(size_t bytes);                  // nullptr: no scope active or block full
@@ -204,6 +208,9 @@ class Engine {
   // slot 3 as a bump allocator for the call's parameter packs (records.h: ParamPack): every take stays valid -- asynchronous copies
   // may still read it -- until the outermost ArenaScope of the call ends; a take the block cannot hold waits for the stream first
   uint8_t* pinned_bump(size_t bytes);
+  // +1 / -1 around a helper thread that reads earlier takes of the current lane's block (records.h: PendingCopy): while the count is
+  // not zero pinned_bump refuses to replace the block (callers with outstanding copies reserve up front: pinned_reserve)
+  void pinned_hold(int delta);
   // makes sure the next takes of `bytes` in total do not move the block (a caller whose helper threads read earlier takes reserves first)
   void pinned_reserve(size_t bytes);
   // window table of the Gt generator e(G1::one(), G2::one()) (random Gt messages of a batch in one launch, on device)
@@ -222,8 +229,9 @@ class Engine {
     size_t arena_bytes = 0, arena_used = 0, arena_want = 0;
     int arena_depth = 0;
     size_t pin3_used = 0;
+    int pin3_hold = 0;
     size_t pin_touched[4] = {0, 0, 0, 0};          // bytes of each pinned slot handed out since the outermost scope began
-    bool scrub = false;
+    int scrub = 0;                                  // bit 0: device arena, bits 1..4: pinned slots 0..3
   };
   std::vector<std::unique_ptr<Lane>> lanes_;
   int device_ = 0;

@@ -56,8 +56,9 @@ struct rabe_host {
   std::deque<rabe_ticket*> q;
   // up to Q_LANES batches run at once, each on its own engine lane (stream, staging, arena) with its own OS randomness source: a small
   // batch is bound by the latency of its launch sets, not by the chip, so batches side by side multiply the rate.  On a tape: one.
-  enum { Q_LANES = 3 };
-  bool q_lane_busy[Q_LANES] = {false, false, false};
+  enum { Q_LANES = 8 };                       // capacity; q_lanes of them are used (RABE_QUEUE_LANES, default 3)
+  int q_lanes = 3;
+  bool q_lane_busy[Q_LANES] = {false, false, false, false, false, false, false, false};
   OsRng q_rng[Q_LANES];
   uint64_t q_stats[6] = {0, 0, 0, 0, 0, 0};  // batches, requests, groups, requests run singly, microseconds inside batches, largest batch
   // a device GROUP (rabe_host_open_group): the host's own engine + one more per further entry of the device list.  The packed entry
@@ -550,7 +551,7 @@ void queue_wait(rabe_host* h, T* t) {
   std::unique_lock<std::mutex> lk(h->q_mu);
   while (!t->done) {
     int lane = -1;
-    const int max_lanes = h->tape ? 1 : (int)rabe_host::Q_LANES;          // a tape is drawn in arrival order: one batch at a time
+    const int max_lanes = h->tape ? 1 : h->q_lanes;          // a tape is drawn in arrival order: one batch at a time
     if (!h->q.empty())
       for (int k = 0; k < max_lanes && lane < 0; k++) if (!h->q_lane_busy[k]) lane = k;
     if (lane < 0) { h->q_cv.wait(lk); continue; }
@@ -762,7 +763,10 @@ void rabe_bytes_free(void* p) { free(p); }
 int32_t rabe_host_set_coalescing(rabe_host* h, int32_t on, uint32_t window_us) {
   if (!h) return -1;
   GUARD_BEGIN
-  if (on) h->eng.ensure_lanes(rabe_host::Q_LANES);          // before any thread is handed one
+  if (on) {
+    if (const char* e = getenv("RABE_QUEUE_LANES")) { const int v = atoi(e); if (v >= 1 && v <= (int)rabe_host::Q_LANES) h->q_lanes = v; }
+    h->eng.ensure_lanes((size_t)h->q_lanes);          // before any thread is handed one
+  }
   std::lock_guard<std::mutex> g(h->q_mu);
   h->coalesce = on != 0;
   h->window_us = window_us;

@@ -842,9 +842,21 @@ bool decrypt_packed(Engine& eng, const CpAbeSecretKey& sk, size_t n, const uint8
       if (walk_checks() && lines) {
         // "every leaf is walked" may only be concluded from the counts for records in the standard layout (their selection is the plan's:
         // distinct rows); rows matched by NAME can coincide in a crafted record, and then some other row is walked by nobody
+        // ... and the count argument needs the selected rows of an item to be DISTINCT: it is verified, not assumed (two plan entries
+        // that named one row would leave another one walked by nobody)
         bool all = true;
-        for (size_t j = 0; j < m_items && all; j++)
-          all = v[live[j]].standard && (pair_off[j + 1] - pair_off[j] - 1) / 2 == leaf_off[j + 1] - leaf_off[j];
+        std::vector<uint8_t> seen;
+        for (size_t j = 0; j < m_items && all; j++) {
+          const uint32_t mj = (pair_off[j + 1] - pair_off[j] - 1) / 2, leaves = leaf_off[j + 1] - leaf_off[j];
+          all = v[live[j]].standard && mj == leaves;
+          if (!all) break;
+          seen.assign(leaves, 0);
+          for (uint32_t e = 0; e < mj && all; e++) {
+            const uint32_t row = sel_ct[sel_start[j] + e];
+            all = row < leaves && !seen[row];
+            if (all) seen[row] = 1;
+          }
+        }
         if (!all) {
           walked_off.push_back(0);
           for (size_t j = 0; j < m_items; j++) {

@@ -86,7 +86,8 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
   }
   sym_shape(len, &blk_off, &seg_off);
   rhip_ctx* cx = eng.ctx();
-  ParamPack pp(eng);
+  auto pp_owner = std::make_shared<ParamPack>(eng);
+  ParamPack& pp = *pp_owner;
   const size_t h_out_off = pp.add(out_off, n * 8), h_layout = pp.add(item_layout, n * 4), h_loff = pp.add(layout_off), h_map = pp.add(map),
                h_src = pp.add(dev_src), h_sio = pp.add(src_item_off), h_nonce = pp.add(nonces, n * 12), h_pt_off = pp.add(pt_off, n * 8),
                h_soff = pp.add(sealed_off), h_len = pp.add(len), h_blk = pp.add(blk_off), h_seg = pp.add(seg_off);
@@ -114,6 +115,7 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
             "rhip_assemble_records");
   tm.lap("rhip_assemble_records");
   // pt_off is relative to pt_blob; the device copy starts at pt_off[0]
+  eng.scrub_session_when_done();          // Gt session keys, AES key schedules and the encryption scalars do not outlive the call
   eng.check(rhip_seal_batch(cx, n, (const rhip_gt*)d_msg, pp.dev<uint8_t>(h_nonce), d_pt - pt_off[0], pp.dev<uint64_t>(h_pt_off), d_out,
                             pp.dev<uint64_t>(h_soff), pp.dev<uint32_t>(h_len), pp.dev<uint32_t>(h_blk), blk_off[n], pp.dev<uint32_t>(h_seg), seg_off[n],
                             1, d_ws.ptr()),
@@ -139,7 +141,12 @@ void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, 
       return 0;
     }));
     defer->d_out = std::move(d_out_buf);
+    defer->d_pt = std::move(d_pt_big);
+    defer->d_ws = std::move(d_ws);
+    defer->pp = pp_owner;
     defer->fut = fut;
+    defer->eng = &eng;
+    eng.pinned_hold(+1);               // the helper thread reads the lane's pinned block: it must not be replaced until wait()
     return;
   }
   eng.check(rhip_download(cx, out_buf + out_off[0], d_out_buf.ptr(), out_bytes), "download (records)");
@@ -150,7 +157,16 @@ void PendingCopy::wait(Engine& eng) {
   auto f = std::static_pointer_cast<std::future<int32_t>>(fut);
   const int32_t rc = f->get();
   fut.reset();
+  if (this->eng) { this->eng->pinned_hold(-1); this->eng = nullptr; }
   eng.check(rc, "download (records)");
+}
+PendingCopy::~PendingCopy() {          // a caller that unwinds without wait(): the helper thread is joined before the buffers go
+  if (fut) {
+    auto f = std::static_pointer_cast<std::future<int32_t>>(fut);
+    (void)f->get();
+    fut.reset();
+  }
+  if (eng) { eng->pinned_hold(-1); eng = nullptr; }
 }
 
 void emit_plain_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
@@ -256,6 +272,7 @@ void open_sealed_records(Engine& eng, size_t n, const std::vector<size_t>& live,
   pp.upload();
   const size_t total = (size_t)pt_off[n];
   DBuf d_pt(&eng, total ? total : 4), d_ok(&eng, q * 4), d_ws(&eng, rhip_seal_workspace_bytes(q, seg_off[q]));
+  eng.scrub_session_when_done();          // the decrypted Gt values and the AES key schedules do not outlive the call
   eng.check(rhip_open_batch(cx, q, (const rhip_gt*)d_gt, pp.dev<uint32_t>(h_idx), d_blob, pp.dev<uint64_t>(h_soff), d_pt.as<uint8_t>(),
                             pp.dev<uint64_t>(h_poff), pp.dev<uint32_t>(h_len), pp.dev<uint32_t>(h_blk), blk_off[q], pp.dev<uint32_t>(h_seg),
                             seg_off[q], d_ok.as<uint32_t>(), d_ws.ptr()),

@@ -57,8 +57,14 @@ void sym_shape(const std::vector<uint32_t>& len, std::vector<uint32_t>* blk_off,
 // arithmetic beside it (PendingCopy::wait before the buffers are read; the parts of one call share one ArenaScope).
 struct PendingCopy {
   DBuf d_out;
+  // everything the queued assemble / seal kernels still read when emit_sealed_records returns early: the parameter pack, a large
+  // plaintext block, the sealing workspace (arena blocks outlive the call anyway; hipMalloc'd fallbacks would not)
+  DBuf d_pt, d_ws;
+  std::shared_ptr<void> pp;
   std::shared_ptr<void> fut;          // std::future<int32_t>
+  Engine* eng = nullptr;              // set while the helper thread may still read the lane's pinned block (Engine::pinned_hold)
   void wait(Engine& eng);
+  ~PendingCopy();
 };
 void emit_sealed_records(Engine& eng, const std::vector<RecordLayout>& layouts, size_t n, const uint32_t* item_layout,
                          const std::vector<const void*>& dev_src, const std::vector<uint64_t>& src_item_off, const void* d_msg,

@@ -55,7 +55,7 @@ BatchRng::BatchRng() {
     auto* k = new host::aeshw::Key;
     host::aeshw::expand(seed, k);
     memcpy(&iv_hi, seed + 32, 8);
-    memset(seed, 0, sizeof seed);
+    explicit_bzero(seed, sizeof seed);
     key = k;
   }
 #endif
@@ -64,7 +64,7 @@ BatchRng::~BatchRng() {
   memset(pool, 0, sizeof pool);
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
   if (key) {
-    memset(key, 0, sizeof(host::aeshw::Key));
+    explicit_bzero(key, sizeof(host::aeshw::Key));
     delete (host::aeshw::Key*)key;
   }
 #endif
@@ -144,7 +144,8 @@ uint8_t* Engine::pinned(int slot, size_t bytes) {
   if (bytes > l.pin_touched[slot]) l.pin_touched[slot] = bytes;
   return (uint8_t*)l.pin[slot];
 }
-void Engine::scrub_when_done() { lanes_[cur_lane()]->scrub = true; }
+void Engine::scrub_when_done() { lanes_[cur_lane()]->scrub = 31; }
+void Engine::scrub_session_when_done() { lanes_[cur_lane()]->scrub |= 3; }
 void Engine::pinned_reserve(size_t bytes) {
   Lane& l = *lanes_[cur_lane()];
   if (l.pin3_used + bytes <= l.pin_bytes[3]) return;
@@ -163,6 +164,7 @@ uint8_t* Engine::pinned_bump(size_t bytes) {
   Lane& l = *lanes_[cur_lane()];
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (l.pin3_used + need > l.pin_bytes[3]) {
+    if (l.pin3_hold > 0) throw RabeError("pinned_bump: the staging block would move while a deferred copy still reads it (pinned_reserve first)");
     check(rhip_sync(l.ctx), "rhip_sync");            // copies out of the old block have finished: it can go
     if (l.side) check(rhip_sync(l.side), "rhip_sync");
     if (l.pin[3]) rhip_host_free(l.ctx, l.pin[3]);
@@ -177,9 +179,10 @@ uint8_t* Engine::pinned_bump(size_t bytes) {
   l.pin3_used += need;
   return p;
 }
+void Engine::pinned_hold(int delta) { lanes_[cur_lane()]->pin3_hold += delta; }
 Engine::ArenaScope::ArenaScope(Engine& eng) : e(eng) {
   Lane& l = *e.lanes_[e.cur_lane()];
-  if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; l.pin3_used = 0; l.scrub = false; for (auto& t : l.pin_touched) t = 0; }
+  if (l.arena_depth++ == 0) { l.arena_used = 0; l.arena_want = 0; l.pin3_used = 0; l.scrub = 0; for (auto& t : l.pin_touched) t = 0; }
 }
 rhip_ctx* Engine::side_ctx() {
   Lane& l = *lanes_[cur_lane()];
@@ -313,10 +316,11 @@ Engine::ArenaScope::~ArenaScope() {
   rhip_sync(l.ctx);                               // nothing of this call may still read the block when the next call reuses it
   if (l.side) rhip_sync(l.side);
   if (l.scrub) {                                  // scrub_when_done(): secrets do not outlive the call in staging memory
-    if (l.arena && l.arena_used) { rhip_memset_async(l.ctx, l.arena, 0, l.arena_used); rhip_sync(l.ctx); }
-    for (int s = 0; s < 3; s++) if (l.pin[s] && l.pin_touched[s]) memset(l.pin[s], 0, l.pin_touched[s] < l.pin_bytes[s] ? l.pin_touched[s] : l.pin_bytes[s]);
-    if (l.pin[3] && l.pin3_used) memset(l.pin[3], 0, l.pin3_used < l.pin_bytes[3] ? l.pin3_used : l.pin_bytes[3]);
-    l.scrub = false;
+    if ((l.scrub & 1) && l.arena && l.arena_used) { rhip_memset_async(l.ctx, l.arena, 0, l.arena_used); rhip_sync(l.ctx); }
+    for (int s = 0; s < 3; s++)
+      if ((l.scrub & (2 << s)) && l.pin[s] && l.pin_touched[s]) explicit_bzero(l.pin[s], l.pin_touched[s] < l.pin_bytes[s] ? l.pin_touched[s] : l.pin_bytes[s]);
+    if ((l.scrub & 16) && l.pin[3] && l.pin3_used) explicit_bzero(l.pin[3], l.pin3_used < l.pin_bytes[3] ? l.pin3_used : l.pin_bytes[3]);
+    l.scrub = 0;
   }
   // grow for the next call -- up to a cap (RABE_ARENA_MAX_GB, default 16): the block is never given back, so one huge batch must not
   // pin a large part of the device for the life of the engine; beyond the cap the buffers that do not fit are plain allocations again
@@ -1392,6 +1396,28 @@ static void destroy_ac17_sk_lines(void* h) { rhip_ac17_sk_lines_destroy((rhip_ac
 // inverse) is only valid inside the subgroup.  `trusted` is for ciphertexts this process produced itself.
 // KP-ABE's decrypt (:625-675) is the same product of pairings with the roles of the two sides' names swapped: the policy is the KEY's, the
 // attribute list the ciphertext's (its record starts with the attribute strings instead of policy text + language); k_p is absent.
+// plans of the packed decrypt, kept across calls: one bucket per key fingerprint (attributes or policy + row names), inside it one plan
+// per policy text.  A bucket that has grown past its cap is REPLACED (calls that still hold the old one finish on it).
+struct Ac17PolPlan {
+  std::string text; PolicyLanguage lang; std::string err; PrunedList lst; std::vector<uint32_t> sk_sel;
+  std::mutex mu; std::atomic<bool> have_rows{false}; std::vector<std::string> row_names; std::vector<uint32_t> ct_sel;
+};
+struct Ac17PlanBucket {
+  std::unordered_map<uint64_t, std::vector<std::shared_ptr<Ac17PolPlan>>> plans;
+  std::shared_mutex mu;
+  std::atomic<size_t> n{0};
+};
+struct Ac17PlanCache {
+  static std::shared_ptr<Ac17PlanBucket> get(const std::string& fingerprint) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, std::shared_ptr<Ac17PlanBucket>> m;
+    std::lock_guard<std::mutex> g(mu);
+    if (m.size() > 64) m.clear();                                     // keys come and go: bounded
+    auto& b = m[fingerprint];
+    if (!b || b->n.load() > 4096) b = std::make_shared<Ac17PlanBucket>();       // policies come and go as well
+    return b;
+  }
+};
 struct DecKey {
   const Ac17SecretKey& sk;
   const std::vector<std::string>* cp_attrs;      // CP: the key's attributes; the policy comes with every ciphertext
@@ -1429,14 +1455,21 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
   PolicyNode kp_tree;                            // KP: the key's policy, parsed once (a policy that does not parse fails the call like kp_decrypt)
   if (kp) kp_tree = parse_or_error(key.kp_policy->first, key.kp_policy->second);
   // per distinct policy text (items of a batch repeat a few): the tree, the verdict for this key, the key-side selection and --
-  // for the row layout the first item with that policy shows -- the ciphertext-side selection
-  struct PolPlan {
-    std::string text; PolicyLanguage lang; std::string err; PrunedList lst; std::vector<uint32_t> sk_sel;
-    std::mutex mu; std::atomic<bool> have_rows{false}; std::vector<std::string> row_names; std::vector<uint32_t> ct_sel;
-    int shape = -1; uint32_t e_c0 = 0, e_row0 = 0, e_cp = 0, e_rows = 0;          // the gather shape of its records (filled after the parse, serially)
-  };
-  std::unordered_map<uint64_t, std::vector<std::shared_ptr<PolPlan>>> plans;
-  std::shared_mutex plans_mu;
+  // for the row layout the first item with that policy shows -- the ciphertext-side selection.  The plans are a pure function of
+  // (key attributes / key policy, key row names, policy text): they are kept ACROSS calls (Ac17PlanCache above) -- a queue batch of a few
+  // dozen requests spent 1.5 of its 6 ms re-parsing and re-pruning the same sixteen policies.
+  typedef Ac17PolPlan PolPlan;
+  std::string fp(kp ? "K" : "C");
+  if (kp) { fp += key.kp_policy->first; fp.push_back((char)('0' + (int)key.kp_policy->second)); }
+  else for (const auto& a : *key.cp_attrs) { fp += a; fp.push_back('\x1f'); }
+  fp.push_back('\x1e');
+  for (const auto& row : core.k) { fp += row.first; fp.push_back('\x1f'); }
+  const std::shared_ptr<Ac17PlanBucket> bucket_owner = Ac17PlanCache::get(fp);
+  auto& plans = bucket_owner->plans;
+  std::shared_mutex& plans_mu = bucket_owner->mu;
+  // what a plan's shared row layout looks like in THIS call's gather (filled after the parse, serially)
+  struct PlanShape { int shape = -1; uint32_t e_c0 = 0, e_row0 = 0, e_cp = 0, e_rows = 0; };
+  std::unordered_map<const PolPlan*, PlanShape> shapes;
   auto plan_of = [&](const uint8_t* txt, size_t len, PolicyLanguage lang) -> PolPlan* {
     uint64_t h = 1469598103934665603ull ^ (uint64_t)lang;
     for (size_t i = 0; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, txt + i, 8); h = (h ^ w) * 1099511628211ull; }
@@ -1473,6 +1506,7 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
       if (e->err.empty()) e->err = "policy error";
     }
     bucket.push_back(e);
+    bucket_owner->n++;
     return e.get();
   };
   BlobGather gather(eng, ct_blob, ct_len);          // the blob starts for the device now, beside the parsing below (records.h)
@@ -1607,12 +1641,12 @@ static bool decrypt_packed_core(Engine& eng, const DecKey& key, size_t n, const 
     const uint32_t e_c0 = (uint32_t)(w.c0 - rec), e_row0 = w.rows ? (uint32_t)(w.row_ptr[0] - rec) : 0u, e_cp = (uint32_t)(w.cp - rec);
     int shape = -1;
     if (w.ct_sel != &w.own_sel) {                 // the plan's shared row layout: its shape is remembered in the plan itself
-      PolPlan* pp = w.plan;
-      if (pp->shape < 0) {
-        pp->shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
-        pp->e_c0 = e_c0; pp->e_row0 = e_row0; pp->e_cp = e_cp; pp->e_rows = w.rows;
+      PlanShape& ps = shapes[w.plan];
+      if (ps.shape < 0) {
+        ps.shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
+        ps.e_c0 = e_c0; ps.e_row0 = e_row0; ps.e_cp = e_cp; ps.e_rows = w.rows;
       }
-      if (pp->e_c0 == e_c0 && pp->e_row0 == e_row0 && pp->e_cp == e_cp && pp->e_rows == w.rows) shape = pp->shape;
+      if (ps.e_c0 == e_c0 && ps.e_row0 == e_row0 && ps.e_cp == e_cp && ps.e_rows == w.rows) shape = ps.shape;
     }
     if (shape < 0) shape = (int)gather.add_shape(nullptr, parts_of(w, rec));
     gather.item(ct_off[live[j]], (uint32_t)shape);
