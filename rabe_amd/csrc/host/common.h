@@ -148,6 +148,7 @@ class Engine {
   void make_current() const { check(rhip_ctx_make_current(lanes_[0]->ctx), "rhip_ctx_make_current"); }
   void ensure_lanes(size_t count);                 // call before handing lanes to threads
   size_t lanes() const { return lanes_.size(); }
+  static int current_lane() { return tl_lane(); }
   struct LaneScope {
     int prev;
     explicit LaneScope(int lane);
