@@ -490,9 +490,10 @@ def main():
             single["ops_per_s_%d_in_flight" % k_in] = round(16 * B / (sum(reg_k) / len(reg_k)), 1)
         single["roundtrip_bit_exact"] = all(b2[3].t[:B * 384].cpu().numpy().tobytes() == want[:B * 384] for _, b2, _ in extra)
         single["fraction_of_grouped_rate"] = round(single["ops_per_s_4_in_flight"] / value, 3)
-        single["note"] = ("one step per launch set (--group 1): a lone batch is 64 final-exponentiation waves and 192-384 Miller waves on 1024 SIMDs, and its "
-                          "latency is the serial chain Miller -> final exponentiation of one lane (~14 k dependent Fp multiplications); batches in flight "
-                          "on separate streams overlap each other's chains")
+        single["note"] = ("one step per launch set (--group 1): a lone batch leaves most SIMDs idle, so the engine takes the six-lane kernels for it by itself "
+                          "(k_miller_c6, k_final_exp_c6, k_gt_table_pow_c6: one Fq12 accumulator over six lanes, the same bytes; docs/coop6.md) and runs the three "
+                          "independent encrypt kernels side by side; round 4 (one lane per item): 16.7 ms / 245 k ops/s alone. Batches in flight on separate "
+                          "streams overlap each other's chains")
         result["single_batch"] = single
 
     # ---------------------------------------------------------------- informational: the same steps with host buffers
@@ -873,7 +874,7 @@ def threads_leg(host, pk, sk, pols):
         host.set_coalescing(False)
     out["note"] = ("one call per ciphertext from native host threads on ONE host handle (rabe_bench_ac17_threads calls the public entry points); calls that "
                    "arrive while a batch runs are collected into the next packed batch (group commit). A blocking caller has one call in flight, so "
-                   "`blocking*` is bounded by threads / (latency of an encrypt launch set + a decrypt launch set, ~20 ms); `in_flight` is the same API "
+                   "`blocking*` is bounded by threads / (latency of an encrypt batch + a decrypt batch: ~6 ms each way round 5, ~20 ms round 4); `in_flight` is the same API "
                    "with 64 submitted calls per thread (rabe_*_submit / rabe_ticket_wait)")
     return out
 
