@@ -22,6 +22,7 @@
 //   int  role() const                         k: the power of w this lane owns
 //   Fp2  ld(int row, int lane) const          slot of lane `lane` of my group in row `row`
 //   void st(int row, const Fp2&) const        my slot of row `row`
+//   bool all(bool) const                      true when every lane of the group passes true (device: a ballot; host: slots + barriers)
 //   void sync() const                         orders the group's slot traffic (device: the wave runs in lockstep and the LDS keeps a
 //                                             wave's accesses in order, so this is a compiler barrier only; host: a thread barrier)
 // Discipline: a slot written between two sync()s is not read by another lane between the same two.
@@ -468,6 +469,24 @@ template <class CX> RB_FN Fp2 c6_final_exponentiation(CX cx, const Fp2& f_in) {
   const Fp2 r = c6_mul(cx, c6_frob(cx, kk, 2), c6_mul(cx, c6_frob(cx, l, 1), nn));
   const Fp2 t = c6_mul(cx, c6_conj(cx, f), l);
   return c6_mul(cx, c6_frob(cx, t, 3), r);
+}
+
+// ---- membership in Gt, the order-r subgroup of Fq12* (engine_jobs.hip: k_gt_is_member, mode 0, value by value): the cyclotomic test
+// f^(p^4) f = f^(p^2), then the BN order test f^p = f^(6 u^2).  ok_k: what the lane already knows about its own coefficient (canonical
+// words).  CX additionally provides  bool all(bool) const  -- true when every lane of the group passes true.
+template <class CX> RB_FN bool c6_gt_is_member(CX cx, const Fp2& f, bool ok_k) {
+  const bool good = cx.all(ok_k) && !cx.all(fp2_is_zero(f));
+  const Fp2 f2 = c6_frob(cx, f, 2), f4 = c6_frob(cx, f2, 2);
+  const Fp2 t = c6_mul(cx, f4, f);
+  const bool cyc = cx.all(fp2_eq(t, f2));
+  const Fp2 h = c6_exp_u(cx, c6_exp_u(cx, f));                       // f^(u^2)
+  c6_put_f(cx, h);
+  c6_csqr(cx);
+  const Fp2 h2 = c6_mine(cx);
+  c6_csqr(cx);
+  const Fp2 r = c6_mul(cx, h2, c6_mine(cx));                          // h^2 * h^4 = f^(6 u^2)
+  const bool ord = cx.all(fp2_eq(r, c6_frob(cx, f, 1)));
+  return good && cyc && ord;
 }
 
 // tower position (Fq2 index in the 6-coefficient order c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2) of the coefficient of w^k

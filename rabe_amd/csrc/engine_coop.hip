@@ -42,7 +42,9 @@ struct DevCX6 {
   lds_quad* base;       // the wave's rows + the first lane of my group (reads)
   lds_quad* own;        // the wave's rows + my lane (writes)
   int k;
+  int first;            // lane of the wave my group starts at
   __device__ __forceinline__ int role() const { return k; }
+  __device__ __forceinline__ bool all(bool v) const { return ((__ballot(v) >> first) & 63ull) == 63ull; }
   __device__ __forceinline__ Fp2 ld(int row, int lane) const {
     const lds_quad* p = base + row * 256 + lane;
     const u32x4 a = p[0], b = p[64], c = p[128], d = p[192];
@@ -70,7 +72,7 @@ struct DevCX6 {
 // lanes 60..63 of a wave belong to no group: they run along on group 9's slots (reads) and write their own, unused, slots
 __device__ __forceinline__ DevCX6 dev_cx6(uint4* rows, int lane, int g, int k) {
   lds_quad* r = (lds_quad*)rows;
-  return DevCX6{r + (g < C6_GROUPS ? 6 * g : 58), r + lane, k};
+  return DevCX6{r + (g < C6_GROUPS ? 6 * g : 58), r + lane, k, g < C6_GROUPS ? 6 * g : 58};
 }
 
 __device__ __forceinline__ Fp ld_fp_q6(const uint4* p) {
@@ -280,8 +282,29 @@ __global__ void __launch_bounds__(64, RB_C6_WAVES) C6K(k_gt_table_pow_c6)(const 
   if (active) store_fp2(out[item].l + 16 * ti, c6_mine(cx));
 }
 
+// ok[i] = a[i] is a canonical encoding of a member of Gt (rhip_gt_is_member: k_gt_is_member's mode 0 on six lanes)
+__global__ void __launch_bounds__(64, RB_C6_WAVES) C6K(k_gt_is_member_c6)(size_t n, const rhip_gt* a, uint32_t* ok) {
+  __shared__ uint4 rows[C6_LDS_QUADS];
+  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g, ti = c6_tower_index(r);
+  const size_t item = (size_t)blockIdx.x * C6_GROUPS + g;
+  const bool active = g < C6_GROUPS && item < n;
+  const DevCX6 cx = dev_cx6(rows, lane, g, r);
+  Fp2 f = r == 0 ? fp2_one() : fp2_zero();
+  bool canon = true;
+  if (active) {
+    canon = wire_words_canonical(a[item].l + 16 * ti, 2);
+    f = load_fp2(a[item].l + 16 * ti);
+  }
+  const bool good = c6_gt_is_member(cx, f, canon);
+  if (active && r == 0) ok[item] = good ? 1u : 0u;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // raw launches of this unit's variant
+int32_t C6K(rhip_c6_raw_gt_is_member)(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok) {
+  KLAUNCH(ctx, "k_gt_is_member_c6", C6K(k_gt_is_member_c6), dim3(blocks_for(n, C6_GROUPS)), dim3(64), 0, ctx->stream, n, a, ok);
+  return RHIP_OK;
+}
 int32_t C6K(rhip_c6_raw_miller)(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                                 const uint32_t* qref, const void* lines, void* ws, void* mill, const MillerPlan* plan, const void* work, const uint32_t* chunk_off,
                                 size_t groups) {
@@ -307,6 +330,7 @@ int32_t rhip_c6_raw_miller_w1(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_
 int32_t rhip_c6_raw_final_exp_w1(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out, uint32_t* started);
 int32_t rhip_c6_raw_gt_table_pow_w1(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
                                     rhip_gt* out);
+int32_t rhip_c6_raw_gt_is_member_w1(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok);
 // a launch of at most one wave per SIMD takes the one-wave variant
 static bool c6_one_wave(const rhip_ctx* ctx, size_t groups) { return blocks_for(groups, C6_GROUPS) <= (unsigned)ctx->n_cu * 4; }
 // When the six-lane kernels run.  Mode 6 (rhip_ctx_set_pairing_mode, or RABE_PAIRING_MODE=6 in the environment of rhip_ctx_create):
@@ -425,6 +449,9 @@ extern "C" int32_t rhip_ctx_selftest_info(rhip_ctx* ctx, uint32_t* simds_checked
   return rhip_device_selftest(ctx, simds_checked, nullptr);
 }
 
+int32_t rhip_launch_gt_is_member_c6(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok) {
+  return (c6_one_wave(ctx, n) ? rhip_c6_raw_gt_is_member_w1 : rhip_c6_raw_gt_is_member)(ctx, n, a, ok);
+}
 // the fixed-base Gt kernels: 32 (16-bit windows) or 64 dependent products per item in one lane against ~5 k instructions each here
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items) {
   if (ctx->pairing_mode == 6) return true;

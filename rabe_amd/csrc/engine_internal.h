@@ -664,6 +664,7 @@ int32_t rhip_launch_miller_c6(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_
 int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
                                  uint32_t* started);
 
+int32_t rhip_launch_gt_is_member_c6(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok);
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items);
 int32_t rhip_launch_gt_table_pow_c6(rhip_ctx* ctx, const void* t0, const void* t1, int w16, size_t n_items, const rhip_fr* k, uint32_t kstride, const rhip_gt* mul_in,
                                     rhip_gt* out);

@@ -1879,6 +1879,9 @@ extern "C" int32_t rhip_gt_is_member(rhip_ctx* ctx, size_t n, const rhip_gt* a, 
   NEED(ctx);
   if (!n) return RHIP_OK;
   static const int mode = getenv("RABE_GT_CHECK_BY_ORDER") ? 1 : 0;
+  // up to ~30 k elements the six-lane form of the same test (engine_coop.hip: k_gt_is_member_c6) is ahead: 0.52 M instructions per wave
+  // of ten elements against one lane's 4.8 k-multiplication chain
+  if (mode == 0 && rhip_use_c6_gt_pow(ctx, n)) return rhip_launch_gt_is_member_c6(ctx, n, a, ok);
   KLAUNCH(ctx, "k_gt_is_member", k_gt_is_member, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, a, ok, mode);
   return RHIP_OK;
 }

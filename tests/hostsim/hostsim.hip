@@ -377,7 +377,7 @@ int hs_c3_pairing(const uint32_t* p, const uint32_t* zscale, const uint32_t* q, 
 
 // ---- six-lane cooperative Fq12 arithmetic (coop6.h) emulated with six host threads per group: the group's slots are a shared
 // array, sync() is a thread barrier, everything else is the exact code the device lanes run.
-struct C6Shared { pthread_barrier_t bar; Fp2 rows[C6_ROWS][6]; };
+struct C6Shared { pthread_barrier_t bar; Fp2 rows[C6_ROWS][6]; int flag[6]; };
 struct HostCX6 {
   C6Shared* sh;
   int k;
@@ -385,6 +385,14 @@ struct HostCX6 {
   Fp2 ld(int row, int lane) const { return sh->rows[row][lane]; }
   void st(int row, const Fp2& v) const { sh->rows[row][k] = v; }
   void sync() const { pthread_barrier_wait(&sh->bar); }
+  bool all(bool v) const {
+    sh->flag[k] = v;
+    pthread_barrier_wait(&sh->bar);
+    bool r = true;
+    for (int i = 0; i < 6; i++) r = r && sh->flag[i];
+    pthread_barrier_wait(&sh->bar);
+    return r;
+  }
 };
 // op: 0 a*b, 1 a^2, 2 cyclotomic a^2, 3 a * line (l0, l1, l3 in b's first three Fq2), 4 final exponentiation of a, 5 a^u,
 //     6 frob1, 7 frob2, 8 frob3, 9 Miller loop multi + final exponentiation (a, b unused)
@@ -408,6 +416,7 @@ static void* c6_worker(void* arg) {
     case 4: j->out = c6_final_exponentiation(cx, ak); break;
     case 5: j->out = c6_exp_u(cx, ak); break;
     case 6: case 7: case 8: j->out = c6_frob(cx, ak, j->op - 5); break;
+    case 10: j->out = c6_gt_is_member(cx, ak, true) ? fp2_one() : fp2_zero(); break;
     default: {
       const Fp2 m = c6_miller_loop_multi(cx, j->acc, j->acc.count());
       j->out = c6_final_exponentiation(cx, m);
@@ -430,6 +439,15 @@ static void c6_run(int op, const Fp12& a, const Fp12& b, const HostMultiAcc* acc
 }
 extern "C" {
 void hs_c6_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { c6_run(op, load_gt(a), b ? load_gt(b) : fp12_one(), nullptr, out); }
+// 1 when the six lanes agree that a is a member of Gt (c6_gt_is_member), 0 when they agree that it is not, -1 when they disagree
+int hs_c6_gt_is_member(const uint32_t* a) {
+  uint32_t out[96];
+  c6_run(10, load_gt(a), fp12_one(), nullptr, out);
+  const Fp12 v = load_gt(out);
+  int ones = 0;
+  for (int k = 0; k < 6; k++) ones += fp2_eq(c6_coeff(v, k), fp2_one()) ? 1 : 0;
+  return ones == 6 ? 1 : (ones == 0 ? 0 : -1);
+}
 // FE( c6_miller_loop_multi ) over n pairs of one group; same arguments as hs_pairing_multi
 void hs_c6_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out) {
   G1Aff* P = new G1Aff[n];

@@ -90,10 +90,13 @@ def test_fixed_base_gt_powers_six_lanes_equal_one_lane_and_oracle(eng):
 
 
 @pytest.mark.parametrize("module", ["tests/test_gpu_ac17.py", "tests/test_gpu_bsw_dev.py", "tests/test_gpu_lsw_aw11_dev.py", "tests/test_gpu_ghw11.py",
-                                    "tests/test_gpu_walk_verdicts.py", "tests/test_gpu_ragged_plan.py"])
+                                    "tests/test_gpu_walk_verdicts.py", "tests/test_gpu_ragged_plan.py", "tests/test_gpu_fullsize_parity.py",
+                                    "tests/test_gpu_configs.py"])
 def test_scheme_suites_pass_with_six_lane_kernels_forced(module):
     """the scheme-level GPU tests (every byte against the oracle / the golden fixtures) with RABE_PAIRING_MODE=6: every pairing
-    product of every decrypt goes through k_miller_c6 + k_final_exp_c6, prepared lines, walking pairs, ragged plans and walk verdicts included"""
+    product of every decrypt goes through k_miller_c6 + k_final_exp_c6, prepared lines, walking pairs, ragged plans and walk verdicts
+    included -- and the five BASELINE configurations at their full attribute counts and per-GPU batches (test_gpu_fullsize_parity: every
+    byte against the reference-order port; test_gpu_configs: full batches through the host layer)"""
     env = dict(os.environ, RABE_PAIRING_MODE="6")
     r = subprocess.run([sys.executable, "-m", "pytest", module, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=3000)

@@ -116,3 +116,14 @@ def test_selftest_digests_host_build_equals_exact_integer_generator():
         want = gen.digest(lane)
         assert HS.hs_selftest_expected(lane) == want, "regenerate selftest_gen.h"
         assert HS.hs_selftest_digest(lane) == want, lane
+
+
+def test_c6_gt_membership():
+    """c6_gt_is_member (k_gt_is_member_c6): members of Gt pass; a random Fq12, a cyclotomic element of the wrong order and zero do not"""
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    for g in (e, bn.gt_pow(e, 12345678901234567890), bn.FP12_ONE):
+        assert HS.hs_c6_gt_is_member(b2c(bn.gt_to_le(g))) == 1
+    assert HS.hs_c6_gt_is_member(b2c(bn.gt_to_le(rand_fp12()))) == 0
+    cyc = bn.fp12_pow(rand_fp12(), bn.FE_EASY)              # in the cyclotomic subgroup, order divides (p^4 - p^2 + 1): almost never r
+    assert HS.hs_c6_gt_is_member(b2c(bn.gt_to_le(cyc))) == 0
+    assert HS.hs_c6_gt_is_member(b2c(bytes(384))) == 0

@@ -155,3 +155,38 @@ def test_generated_header_is_current(tmp_path, monkeypatch):
     assert gen.column_plan(mod, False, 0, 0) == (safe, last)
     safe, last = plan(0, 1)
     assert gen.column_plan(mod, True, mod[7] + 1, mod[7] + 1) == (safe, last)
+
+
+def test_wide_mac3_uncaptured_products_and_sum_bounds():
+    """wide_mac3 (tools/gen_fp_asm.py; the multi-product sums of bn254/coop6.h): a column of the accumulate form is
+    incoming + T[k] (a multiply-add by 1, no capture) + the column's TOP-limb products (no capture) + the captured rest.  With exact
+    integers and worst-case limbs: nothing that issues without a capture can leave the 64-bit accumulator -- for operands below p and for
+    the Karatsuba sums below 2p -- and the sums themselves stay below 2^512 for the six products an operation accumulates at most."""
+    p = bn.P
+    for bound_a, bound_b in ((p - 1, p - 1), (2 * p - 2, 2 * p - 2)):
+        top_a, top_b = bound_a >> 224, bound_b >> 224                       # largest top limbs
+        incoming = 0
+        for k in range(16):
+            lo, hi = (0, k) if k < 8 else (k - 7, 7)
+            tops = top_products(k) if k < 15 else []
+            acc = incoming + W                                               # + T[k]
+            assert acc <= FULL
+            for i in tops:
+                acc += (top_a if i == 7 else W) * (top_b if k - i == 7 else W)
+                assert acc <= FULL, (k, i)
+            banked = 0
+            for i in range(lo, hi + 1):
+                if k < 15 and i not in tops:
+                    acc += W * W
+                    banked += acc >> 64
+                    acc &= FULL
+            incoming = (acc >> 32) + (banked << 32)                          # the next column starts from the high word + the banked carries
+            assert incoming < 1 << 37
+    # three sums of at most six products: T0, T1 < 6 p^2, T2 < 6 (2p)^2 = 24 p^2 < 2^512; the reduction's inputs are below 12 p^2 and
+    # leave less than 3.27 p (three conditional subtractions bring that below p)
+    assert 24 * p * p < 1 << 512
+    assert (12 * p * p) // (1 << 256) + p < 3.27 * p
+    for n, extra0, extra1 in ((2, 1, 0), (3, 1, 1), (4, 1, 1), (6, 2, 2)):    # coop6.h: wide3_finish's conditional subtractions by n
+        c0_max = ((n + 6) * p * p) // (1 << 256) + p                           # REDC output bound: (W + m p) / R < W / R + p
+        c1_max = (2 * n * p * p) // (1 << 256) + p
+        assert c0_max < (2 + extra0) * p and c1_max < (2 + extra1) * p
