@@ -1,0 +1,223 @@
+// The Miller loop of pairing.h (miller_loop_multi: any number of pairings on one Fq12 accumulator) on the reduced-radix
+// field core of fp29.h -- the same tower (Fq2 = Fp[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v)), the same
+// Costello-Lange-Naehrig steps, the same sparse line products, formula by formula, so that every value is the same field
+// element as in pairing.h and the canonical bytes that leave the kernel are identical (tests/test_hostsim_rr.py,
+// tests/test_gpu_rr.py).  What differs is the bookkeeping a redundant representation needs: additions and subtractions are
+// limb-wise and unreduced, the bounds travel in the types (fp29.h: FB<L, V>), and a value is normalised where a bound
+// would otherwise be exceeded -- the static_asserts of fp29.h decide where, not the author.
+//
+// `rabe_bn::pairing` call sites of the reference: src/schemes/ac17/mod.rs:415-418, bsw/mod.rs:291-294,308,
+// lsw/mod.rs:275-280, aw11/mod.rs:340-350.
+#pragma once
+#include "fp29.h"
+#include "pairing.h"
+
+namespace rabe { namespace bn254 { namespace rr {
+
+// always to F = FB<1, 1> (what is stored): norm() keeps a value bound of 2 where it is given one
+template <int L, int V> RB_HD F normf(const FB<L, V>& a) { return norm(FB<(L < 6 ? L : 6), (V < 3 ? 3 : V)>(a)); }
+RB_HD F normf(const F& a) { return a; }
+template <int L, int V> RB_HD F2 normf2(const F2B<L, V>& a) { return mk2(normf(a.c0), normf(a.c1)); }
+
+// ============================================================================ Fq6: three Fq2 coefficients, each with its own bounds
+template <class A0, class A1, class A2>
+struct F6T {
+  A0 a0; A1 a1; A2 a2;
+};
+typedef F6T<F2, F2, F2> F6;
+template <class A0, class A1, class A2> RB_HD F6T<A0, A1, A2> mk6(const A0& a0, const A1& a1, const A2& a2) { return F6T<A0, A1, A2>{a0, a1, a2}; }
+RB_HD F6 zero6() { return mk6(zero2(), zero2(), zero2()); }
+RB_HD F6 one6() { return mk6(one2(), zero2(), zero2()); }
+template <class A, class B> RB_HD auto add6(const A& a, const B& b) { return mk6(add2(a.a0, b.a0), add2(a.a1, b.a1), add2(a.a2, b.a2)); }
+template <class A> RB_HD auto norm6(const A& a) { return mk6(norm2(a.a0), norm2(a.a1), norm2(a.a2)); }
+
+// Karatsuba, 6 Fq2 multiplications; the coefficients of the operands may be weakly normalised sums (FB<1, 2>)
+template <class A, class B>
+RB_HD F6 mul6(const A& a, const B& b) {
+  const F2 v0 = mul2(a.a0, b.a0);
+  const F2 v1 = mul2(a.a1, b.a1);
+  const F2 v2 = mul2(a.a2, b.a2);
+  const F2 t0 = mul2(add2(a.a1, a.a2), add2(b.a1, b.a2));
+  const F2 t1 = mul2(add2(a.a0, a.a1), add2(b.a0, b.a1));
+  const F2 t2 = mul2(add2(a.a0, a.a2), add2(b.a0, b.a2));
+  return mk6(add_mul_xi2(v0, sub2(sub2(t0, v1), v2)), add_mul_xi2(sub2(sub2(t1, v0), v1), v2), normf2(add2(sub2(sub2(t2, v0), v2), v1)));
+}
+// a (b0 + b1 v): 5 Fq2 multiplications; the last coefficient comes back as the plain sum of two products (FB<2, 2>)
+template <class A, class B0, class B1>
+RB_HD F6T<F2, F2, F2B<2, 2>> mul6_by_01(const A& a, const B0& b0, const B1& b1) {
+  const F2 v0 = mul2(a.a0, b0);
+  const F2 v1 = mul2(a.a1, b1);
+  const F2 t0 = mul2(add2(a.a1, a.a2), b1);
+  const F2 t1 = mul2(add2(a.a0, a.a1), add2(b0, b1));
+  const F2 t2 = mul2(a.a2, b0);
+  return mk6(add_mul_xi2(v0, sub2(t0, v1)), normf2(sub2(sub2(t1, v0), v1)), add2(t2, v1));
+}
+template <class A, class B> RB_HD F6 mul6_fp2(const A& a, const B& b) { return mk6(mul2(a.a0, b), mul2(a.a1, b), mul2(a.a2, b)); }
+
+// ============================================================================ the accumulator f = c0 + c1 w in its home
+// FA provides  F6 ld_f6(int half) const, void st_f6(int half, const F6&) const, F6 ld_x() const, void st_x(const F6&) const, void fence() const
+// (pairing.h: the same interface on the 8 x 32-bit types).  Stored values are F = FB<1, 1>.
+template <class FA> RB_HD void facc_set_one(FA a) { a.st_f6(0, one6()); a.st_f6(1, zero6()); }
+// r.c0 = t0 + v t1 ; r.c1 = t2 - t0 - t1, t0 parked
+template <class FA, class T1, class T2>
+RB_HD void facc_finish(FA a, const T1& t1, const T2& t2) {
+  const F6 t0 = a.ld_x();
+  a.st_f6(0, mk6(add_mul_xi2(t0.a0, t1.a2), normf2(add2(t0.a1, t1.a0)), normf2(add2(t0.a2, t1.a1))));
+  a.st_f6(1, mk6(normf2(sub2(sub2(t2.a0, t0.a0), t1.a0)), normf2(sub2(sub2(t2.a1, t0.a1), t1.a1)), normf2(sub2(sub2(t2.a2, t0.a2), t1.a2))));
+}
+// complex squaring: ab = c0 c1, t = (c0 + c1)(c0 + v c1);  c0' = t - ab - v ab, c1' = 2 ab
+template <class FA> RB_HD void facc_sqr(FA a) {
+  { const F6 ab = mul6(a.ld_f6(0), a.ld_f6(1)); a.st_x(ab); }
+  a.fence();
+  F6 t;
+  {
+    const F6 c0 = a.ld_f6(0), c1 = a.ld_f6(1);
+    t = mul6(norm6(add6(c0, c1)), mk6(add_mul_xi2(c0.a0, c1.a2), norm2(add2(c0.a1, c1.a0)), norm2(add2(c0.a2, c1.a1))));
+  }
+  a.fence();
+  const F6 ab = a.ld_x();
+  a.st_f6(0, mk6(add_mul_xi2(sub2(t.a0, ab.a0), neg2(ab.a2)), normf2(sub2(sub2(t.a1, ab.a1), ab.a0)), normf2(sub2(sub2(t.a2, ab.a2), ab.a1))));
+  a.st_f6(1, mk6(normf2(dbl2(ab.a0)), normf2(dbl2(ab.a1)), normf2(dbl2(ab.a2))));
+}
+// f (l0 + l1 w + l3 w^3): 13 Fq2 multiplications
+template <class FA> RB_HD void facc_mul_by_line(FA a, const F2& l0, const F2& l1, const F2& l3) {
+  { const F6 t0 = mul6_fp2(a.ld_f6(0), l0); a.st_x(t0); }
+  a.fence();
+  const auto t1 = mul6_by_01(a.ld_f6(1), l1, l3);
+  a.fence();
+  const auto t2 = mul6_by_01(norm6(add6(a.ld_f6(0), a.ld_f6(1))), norm2(add2(l0, l1)), l3);
+  a.fence();
+  facc_finish(a, t1, t2);
+}
+// f (a0 + a1 w + a3 w^3)(b0 + b1 w + b3 w^3): the two lines first (6 products), then 17
+template <class FA> RB_HD void facc_mul_by_two_lines(FA a, const F2& a0, const F2& a1, const F2& a3, const F2& b0, const F2& b1, const F2& b3) {
+  const F2 m00 = mul2(a0, b0);
+  const F2 m11 = mul2(a1, b1);
+  const F2 m33 = mul2(a3, b3);
+  const F2 x01 = normf2(sub2(sub2(mul2(add2(a0, a1), add2(b0, b1)), m00), m11));
+  const F2 x03 = normf2(sub2(sub2(mul2(add2(a0, a3), add2(b0, b3)), m00), m33));
+  const F2 x13 = normf2(sub2(sub2(mul2(add2(a1, a3), add2(b1, b3)), m11), m33));
+  const F6 p0 = mk6(add_mul_xi2(m00, m33), m11, x13);
+  { const F6 t0 = mul6(a.ld_f6(0), p0); a.st_x(t0); }
+  a.fence();
+  const auto t1 = mul6_by_01(a.ld_f6(1), x01, x03);
+  a.fence();
+  const F6 t2 = mul6(norm6(add6(a.ld_f6(0), a.ld_f6(1))), mk6(norm2(add2(p0.a0, x01)), norm2(add2(p0.a1, x03)), p0.a2));
+  a.fence();
+  facc_finish(a, t1, t2);
+}
+
+// ============================================================================ G2 steps (pairing.h: g2hom_double / g2hom_add)
+struct G2Hom29 { F2 x, y, z; };
+struct G2Aff29 { F2 x, y; };
+struct Line29 { F2B<3, 3> cy, cx; F2 c0; };          // cy, cx are scaled by y_P, x_P before they meet the accumulator
+struct MillerP29 { F px, py; };
+
+RB_MID Line29 g2hom_double(G2Hom29& r) {
+  const auto a = half2(mul2(r.x, r.y));                        // X Y / 2                     FB<2, 1>
+  const F2 b = sqr2(r.y);
+  const F2 c = sqr2(r.z);
+  const F2 e = mul2(twist_b(), tpl2(c));                       // 3 b' Z^2
+  const auto f = tpl2(e);                                      // 9 b' Z^2                    FB<3, 3>
+  const F2 g = normf2(half2(add2(b, f)));
+  const auto h = sub2(sqr2(add2(r.y, r.z)), add2(b, c));       // 2 Y Z                       FB<3, 3>
+  const F2 i = normf2(sub2(e, b));
+  const F2 j = sqr2(r.x);
+  const F2 e2 = sqr2(e);
+  r.x = mul2(a, normf2(sub2(b, f)));
+  r.y = normf2(sub2(sqr2(g), tpl2(e2)));
+  r.z = mul2(b, h);
+  Line29 l;
+  l.cy = neg2(h);
+  l.cx = tpl2(j);
+  l.c0 = i;
+  return l;
+}
+RB_MID Line29 g2hom_add(G2Hom29& r, const G2Aff29& q) {
+  const auto theta = sub2(r.y, mul2(q.y, r.z));                // FB<2, 2>
+  const auto lambda = sub2(r.x, mul2(q.x, r.z));
+  const F2 c = sqr2(theta);
+  const F2 d = sqr2(lambda);
+  const F2 e = mul2(lambda, d);
+  const F2 f = mul2(r.z, c);
+  const F2 g = mul2(r.x, d);
+  const F2 h = normf2(sub2(add2(e, f), dbl2(g)));
+  const F2 ry = r.y;
+  r.x = mul2(lambda, h);
+  r.y = normf2(sub2(mul2(theta, sub2(g, h)), mul2(e, ry)));
+  r.z = mul2(r.z, e);
+  Line29 l;
+  l.cy = lambda;
+  l.cx = neg2(theta);
+  l.c0 = normf2(sub2(mul2(theta, q.x), mul2(lambda, q.y)));
+  return l;
+}
+RB_HD G2Aff29 g2_frob1(const G2Aff29& q) { return G2Aff29{mul2(conj2(q.x), gamma1_2()), mul2(conj2(q.y), gamma1_3())}; }
+RB_HD G2Aff29 g2_frob2_neg(const G2Aff29& q) { return G2Aff29{mul2_fp(q.x, gamma2_2()), mul2_fp(neg2(q.y), gamma2_3())}; }
+
+template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& p) {
+  facc_mul_by_line(a, mul2_fp(l.cy, p.py), mul2_fp(l.cx, p.px), l.c0);
+}
+template <class FA> RB_HD void facc_ell2(FA a, const Line29& la, const MillerP29& pa, const Line29& lb, const MillerP29& pb) {
+  facc_mul_by_two_lines(a, mul2_fp(la.cy, pa.py), mul2_fp(la.cx, pa.px), la.c0, mul2_fp(lb.cy, pb.py), mul2_fp(lb.cx, pb.px), lb.c0);
+}
+
+// ============================================================================ the loop (pairing.h: miller_loop_multi, same event order)
+// ACC provides, beside the FA interface:  int count(), int kind(int j) (MP_WALK / MP_LINES / MP_SKIP), MillerP29 p(int j),
+// G2Aff29 q(int j), Line29 line(int j, int n), G2Hom29 ld_t(int j), void st_t(int j, const G2Hom29&), void begin()  (called once before
+// the loop: converts the lane's arguments)
+template <class ACC>
+RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, Line29& l) {
+  const int kind = acc.kind(j);
+  if (kind == MP_SKIP) return false;
+  if (kind == MP_LINES) { l = acc.line(j, ln); return true; }
+  G2Hom29 t = acc.ld_t(j);
+  if (mode == MS_DBL) {
+    l = g2hom_double(t);
+  } else {
+    G2Aff29 q = acc.q(j);
+    if (mode == MS_ADD_NEG) q.y = neg2(q.y);
+    else if (mode == MS_FROB1) q = g2_frob1(q);
+    else if (mode == MS_FROB2) q = g2_frob2_neg(q);
+    l = g2hom_add(t, q);
+  }
+  acc.st_t(j, t);
+  return true;
+}
+template <class ACC>
+RB_FN void miller_loop_multi(ACC acc) {
+  const int n = acc.count();
+  facc_set_one(acc);
+  acc.begin();
+  int i = RB_ATE_NAF_LEN - 2;
+  bool add_pending = false;
+  for (int ln = 0; ln < RB_MILLER_LINES; ln++) {
+    int mode;
+    if (i >= 0) {
+      const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+      const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+      if (!add_pending) {
+        facc_sqr(acc);
+        mode = MS_DBL;
+        if (pos | ngt) add_pending = true; else i--;
+      } else {
+        mode = pos ? MS_ADD_POS : MS_ADD_NEG;
+        add_pending = false;
+        i--;
+      }
+    } else {
+      mode = (i == -1) ? MS_FROB1 : MS_FROB2;
+      i--;
+    }
+    for (int j = 0; j < n; j += 2) {
+      Line29 la, lb;
+      const bool ha = miller_multi_line(acc, j, mode, ln, la);
+      const bool hb = (j + 1 < n) && miller_multi_line(acc, j + 1, mode, ln, lb);
+      if (ha && hb) facc_ell2(acc, la, acc.p(j), lb, acc.p(j + 1));
+      else if (ha) facc_ell(acc, la, acc.p(j));
+      else if (hb) facc_ell(acc, lb, acc.p(j + 1));
+    }
+  }
+}
+
+} } }   // namespace rabe::bn254::rr

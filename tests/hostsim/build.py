@@ -19,7 +19,7 @@ def _stale():
 
 def build(force=False):
     if force or _stale():
-        subprocess.run(["hipcc", "-O2", "-std=c++17", "-DRB_COUNT_MULS", "--cuda-host-only", "-shared", "-fPIC", "-pthread", "-o", LIB, SRC],
+        subprocess.run(["hipcc", "-O2", "-std=c++17", "-DRB_COUNT_MULS", "-DRB29_CHECK", "--cuda-host-only", "-shared", "-fPIC", "-pthread", "-o", LIB, SRC],
                        check=True, timeout=600)
     return LIB
 

@@ -6,6 +6,7 @@
 #include "../../rabe_amd/csrc/bn254/coop3.h"
 #include "../../rabe_amd/csrc/bn254/coop6.h"
 #include "../../rabe_amd/csrc/bn254/selftest.h"
+#include "../../rabe_amd/csrc/bn254/pairing29.h"
 #include <pthread.h>
 #include <string.h>
 
@@ -471,3 +472,96 @@ void hs_c6_pairing_multi(int n, const int* kinds, const uint32_t* p, const uint3
 // the context-creation self-test's per-lane digest (bn254/selftest.h) on the CPU, and the compiled-in expectation
 extern "C" unsigned hs_selftest_digest(int lane) { return selftest_digest(lane); }
 extern "C" unsigned hs_selftest_expected(int lane) { constexpr uint32_t e[64] = RB_SELFTEST_EXPECT; return e[lane]; }
+
+// ------------------------------------------------------------------------------------------------ reduced-radix core (bn254/fp29.h, pairing29.h)
+struct HostMultiAcc29 {
+  int n;
+  const int* kinds;
+  const G1Aff* P;
+  const G2Aff* Q;
+  const LineCoeffs* lines;     // [n][RB_MILLER_LINES], 8 x 32-bit form: converted where they are fetched
+  rr::G2Hom29* T;
+  rr::F6* F;                   // [3]
+  int count() const { return n; }
+  rr::F6 ld_f6(int h) const { return F[h]; }
+  void st_f6(int h, const rr::F6& v) const { F[h] = v; }
+  rr::F6 ld_x() const { return F[2]; }
+  void st_x(const rr::F6& v) const { F[2] = v; }
+  void fence() const {}
+  int kind(int j) const { return kinds[j]; }
+  rr::MillerP29 p(int j) const { return rr::MillerP29{rr::from_fp(P[j].x), rr::from_fp(P[j].y)}; }
+  rr::G2Aff29 q(int j) const { return rr::G2Aff29{rr::from_fp2(Q[j].x), rr::from_fp2(Q[j].y)}; }
+  rr::Line29 line(int j, int k) const {
+    const LineCoeffs& l = lines[j * RB_MILLER_LINES + k];
+    rr::Line29 r;
+    r.cy = rr::from_fp2(l.cy); r.cx = rr::from_fp2(l.cx); r.c0 = rr::from_fp2(l.c0);
+    return r;
+  }
+  rr::G2Hom29 ld_t(int j) const { return T[j]; }
+  void st_t(int j, const rr::G2Hom29& t) const { T[j] = t; }
+  void begin() const {
+    for (int j = 0; j < n; j++)
+      if (kinds[j] == MP_WALK) { const rr::G2Aff29 a = q(j); T[j] = rr::G2Hom29{a.x, a.y, rr::one2()}; }
+  }
+};
+extern "C" {
+void hs_rr_roundtrip(const uint32_t* a, uint32_t* out) { store_fp(out, rr::to_fp(rr::from_fp(load_fp(a)))); }
+void hs_rr_fp2_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp2(out, rr::to_fp2(rr::mul2(rr::from_fp2(load_fp2(a)), rr::from_fp2(load_fp2(b))))); }
+void hs_rr_fp2_sqr(const uint32_t* a, uint32_t* out) { store_fp2(out, rr::to_fp2(rr::sqr2(rr::from_fp2(load_fp2(a))))); }
+void hs_rr_fp2_mul_xi(const uint32_t* a, uint32_t* out) { store_fp2(out, rr::to_fp2(rr::mul_xi2(rr::from_fp2(load_fp2(a))))); }
+void hs_rr_fp_half(const uint32_t* a, uint32_t* out) { store_fp(out, rr::to_fp(rr::normf(rr::half(rr::from_fp(load_fp(a)))))); }
+// chains of lazily reduced operations: ((a + b)(a - b) - 3 a b) with sums of sums normalised on the way -- exercises norm / norm_lin9 / half
+void hs_rr_fp2_mix(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  const rr::F2 x = rr::from_fp2(load_fp2(a)), y = rr::from_fp2(load_fp2(b));
+  const rr::F2 m = rr::mul2(rr::add2(x, y), rr::sub2(x, y));
+  const rr::F2 n = rr::mul2(x, y);
+  const rr::F2 r = rr::normf2(rr::half2(rr::sub2(m, rr::tpl2(n))));
+  store_fp2(out, rr::to_fp2(rr::add_mul_xi2(r, rr::sub2(rr::dbl2(n), m))));
+}
+// the Miller value itself (no final exponentiation), converted back to the canonical 8 x 32-bit form; and the running points
+void hs_rr_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out, uint32_t* t_out /* n x 96 words or NULL */) {
+  G1Aff* P = new G1Aff[n];
+  G2Aff* Q = new G2Aff[n];
+  LineCoeffs* lines = new LineCoeffs[(size_t)n * RB_MILLER_LINES];
+  rr::G2Hom29* T = new rr::G2Hom29[n];
+  int* kk = new int[n];
+  for (int j = 0; j < n; j++) {
+    P[j] = load_g1(p + 16 * j);
+    Q[j] = load_g2(q + 32 * j);
+    kk[j] = kinds[j];
+    if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
+    if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
+  }
+  rr::F6 F[3];
+  rr::miller_loop_multi(HostMultiAcc29{n, kk, P, Q, lines, T, F});
+  Fp12 f;
+  f.c0 = Fp6{rr::to_fp2(F[0].a0), rr::to_fp2(F[0].a1), rr::to_fp2(F[0].a2)};
+  f.c1 = Fp6{rr::to_fp2(F[1].a0), rr::to_fp2(F[1].a1), rr::to_fp2(F[1].a2)};
+  store_gt(out, f);
+  if (t_out)
+    for (int j = 0; j < n; j++)
+      if (kk[j] == MP_WALK) { store_fp2(t_out + 96 * j, rr::to_fp2(T[j].x)); store_fp2(t_out + 96 * j + 32, rr::to_fp2(T[j].y)); store_fp2(t_out + 96 * j + 64, rr::to_fp2(T[j].z)); }
+  delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
+}
+// the same value from pairing.h's loop, for the comparison
+void hs_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out, uint32_t* t_out) {
+  G1Aff* P = new G1Aff[n];
+  G2Aff* Q = new G2Aff[n];
+  LineCoeffs* lines = new LineCoeffs[(size_t)n * RB_MILLER_LINES];
+  G2Hom* T = new G2Hom[n];
+  int* kk = new int[n];
+  for (int j = 0; j < n; j++) {
+    P[j] = load_g1(p + 16 * j);
+    Q[j] = load_g2(q + 32 * j);
+    kk[j] = kinds[j];
+    if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
+    if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
+  }
+  Fp6 F[3];
+  store_gt(out, miller_loop_multi(HostMultiAcc{n, kk, P, Q, lines, T, F}));
+  if (t_out)
+    for (int j = 0; j < n; j++)
+      if (kk[j] == MP_WALK) { store_fp2(t_out + 96 * j, T[j].x); store_fp2(t_out + 96 * j + 32, T[j].y); store_fp2(t_out + 96 * j + 64, T[j].z); }
+  delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
+}
+}

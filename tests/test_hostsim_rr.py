@@ -1,0 +1,96 @@
+"""The reduced-radix field core (rabe_amd/csrc/bn254/fp29.h, pairing29.h: 9 signed 29-bit limbs, lazily reduced sums with the
+bounds carried in the types) executed on the CPU and compared bit-for-bit with the 8 x 32-bit core of the same headers and with
+the Python big-int oracle.  The host build asserts every limb / value bound at run time as well (RB29_CHECK): a violated bound
+aborts the test process.  The same comparisons run on the device in tests/test_gpu_rr.py."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import bn254 as bn
+from tests.hostsim import build as hs_build
+
+try:
+    HS = hs_build.load()
+except Exception as e:  # pragma: no cover
+    HS = None
+
+pytestmark = pytest.mark.skipif(HS is None, reason="hostsim library could not be built")
+
+RND = random.Random(20260929)
+EDGE = [0, 1, 2, bn.P - 1, bn.P - 2, (bn.P - 1) // 2, (bn.P + 1) // 2, 1 << 253, (1 << 29) - 1, 1 << 29, (1 << 232) - 1, 1 << 232,
+        sum(((1 << 28)) << (29 * k) for k in range(8)) % bn.P, sum(((1 << 29) - 1) << (29 * k) for k in range(8)) % bn.P]
+
+
+def buf(n):
+    return (ctypes.c_uint32 * (n // 4))()
+
+
+def b2c(b):
+    return (ctypes.c_uint32 * (len(b) // 4)).from_buffer_copy(b)
+
+
+def le(x):
+    return int(x).to_bytes(32, "little")
+
+
+def fp2_le(a):
+    return le(a[0]) + le(a[1])
+
+
+def call(name, *ins, out=64):
+    o = buf(out)
+    getattr(HS, name)(*[b2c(x) for x in ins], o)
+    return bytes(o)
+
+
+def vals():
+    return EDGE + [RND.randrange(bn.P) for _ in range(60)]
+
+
+def test_round_trip_and_half():
+    inv2 = pow(2, bn.P - 2, bn.P)
+    for a in vals():
+        assert call("hs_rr_roundtrip", le(a), out=32) == le(a)
+        assert call("hs_rr_fp_half", le(a), out=32) == le(a * inv2 % bn.P)
+
+
+def test_fp2_operations_match_the_oracle_and_the_8x32_core():
+    vs = vals()
+    for i in range(len(vs)):
+        a = (vs[i], vs[(7 * i + 3) % len(vs)])
+        b = (vs[(5 * i + 1) % len(vs)], vs[(11 * i + 2) % len(vs)])
+        want = ((a[0] * b[0] - a[1] * b[1]) % bn.P, (a[0] * b[1] + a[1] * b[0]) % bn.P)
+        got = call("hs_rr_fp2_mul", fp2_le(a), fp2_le(b))
+        assert got == fp2_le(want) == call("hs_fp2_mul", fp2_le(a), fp2_le(b))
+        assert call("hs_rr_fp2_sqr", fp2_le(a)) == fp2_le(((a[0] * a[0] - a[1] * a[1]) % bn.P, 2 * a[0] * a[1] % bn.P))
+        assert call("hs_rr_fp2_mul_xi", fp2_le(a)) == fp2_le(((9 * a[0] - a[1]) % bn.P, (9 * a[1] + a[0]) % bn.P))
+        # ((a + b)(a - b) - 3 a b) / 2 + xi (2 a b - (a + b)(a - b)): unreduced sums of sums, half, norm, norm_lin9 in one chain
+        f2 = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % bn.P, (x[0] * y[1] + x[1] * y[0]) % bn.P)
+        m = f2(((a[0] + b[0]) % bn.P, (a[1] + b[1]) % bn.P), ((a[0] - b[0]) % bn.P, (a[1] - b[1]) % bn.P))
+        n = f2(a, b)
+        inv2 = pow(2, bn.P - 2, bn.P)
+        r = ((m[0] - 3 * n[0]) * inv2 % bn.P, (m[1] - 3 * n[1]) * inv2 % bn.P)
+        y = ((2 * n[0] - m[0]) % bn.P, (2 * n[1] - m[1]) % bn.P)
+        want = ((r[0] + 9 * y[0] - y[1]) % bn.P, (r[1] + 9 * y[1] + y[0]) % bn.P)
+        assert call("hs_rr_fp2_mix", fp2_le(a), fp2_le(b)) == fp2_le(want)
+
+
+@pytest.mark.parametrize("n,kinds", [(1, [0]), (1, [1]), (2, [0, 0]), (2, [1, 0]), (3, [0, 0, 1]), (5, [1, 0, 1, 0, 1]), (4, [0, 2, 1, 0]), (6, [1, 1, 1, 0, 0, 0])])
+def test_miller_loop_multi_same_value_and_same_running_points(n, kinds):
+    """pairing29.h: miller_loop_multi against pairing.h's -- the Miller value itself (before any final exponentiation) and the points the
+    walking pairs end on are the same field elements"""
+    ks = [(RND.randrange(1, bn.R), RND.randrange(1, bn.R)) for _ in range(n)]
+    p = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, a)) for a, _ in ks)
+    q = b"".join(bn.g2_to_le(bn.g2_mul(bn.G2_GEN, b)) for _, b in ks)
+    kk = (ctypes.c_int * n)(*kinds)
+    o1, o2, t1, t2 = buf(384), buf(384), buf(384 * n), buf(384 * n)
+    HS.hs_miller_multi(n, kk, b2c(p), b2c(q), o1, t1)
+    HS.hs_rr_miller_multi(n, kk, b2c(p), b2c(q), o2, t2)
+    assert bytes(o1) == bytes(o2)
+    assert bytes(t1) == bytes(t2)
+    if n >= 2:      # an argument at infinity contributes 1
+        p2 = bytes(64) + p[64:]
+        HS.hs_miller_multi(n, kk, b2c(p2), b2c(q), o1, None)
+        HS.hs_rr_miller_multi(n, kk, b2c(p2), b2c(q), o2, None)
+        assert bytes(o1) == bytes(o2)
