@@ -606,6 +606,8 @@ def main():
         impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_ac17_dec_miller2": IMPL_MILLER2_FPMUL + 2 * m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
                 "k_miller_multi": IMPL_MILLER_MULTI6_FPMUL if sk_lines is not None else IMPL_MILLER_MULTI6_WALK_FPMUL,
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
+        for d_ in (lanes, alg, impl):          # the reduced-radix kernel computes the same unit of work (engine_rr.hip)
+            d_["k_miller_multi_rr"] = d_["k_miller_multi"]
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         macs_impl = lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL

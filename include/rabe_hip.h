@@ -66,8 +66,9 @@ int32_t rhip_ctx_timing(rhip_ctx* ctx, int32_t enable);
 int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len);
 /* pairing kernels: 0 = auto (cooperating lanes for launches that would under-fill the chip, one lane per item and chunk
  * otherwise), 1 = always one lane, 3 = three lanes per pairing (pairwise paths), 6 = six lanes per Fq12 accumulator
- * (k_miller_c6 / k_final_exp_c6: one Fq2 coefficient per lane).  Results are identical.  RABE_PAIRING_MODE in the
- * environment of rhip_ctx_create presets the mode (A/B runs). */
+ * (k_miller_c6 / k_final_exp_c6: one Fq2 coefficient per lane), 29 = one lane per item and chunk on the reduced-radix field core
+ * (k_miller_multi_rr: 9 x 29-bit limbs; what mode 0 takes for launches that fill the chip).  Results are identical.
+ * RABE_PAIRING_MODE in the environment of rhip_ctx_create presets the mode (A/B runs). */
 int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode);
 /* number of compute units / device name of the context's GPU */
 int32_t rhip_device_info(rhip_ctx* ctx, int32_t* n_cu, char* name, size_t name_len);

@@ -209,12 +209,84 @@ RB_HD i32x9 mac2_raw(const i32x9& a, const i32x9& b, const i32x9& c, const i32x9
   cols_mac(t, c, d);
   return redc(t);
 }
+// ---- out-of-line forms for the device.  The Fq2-level routines are the call granularity of the pairing kernels, as in tower.h
+// (a kernel body has ~130 Fq2 multiplication sites; inlined they would be ~90 k instructions streaming through a 64 KB instruction
+// cache).  The calling convention passes 31 argument dwords and returns 16 in VGPRs; an Fq2 product has 36 in and 18 out.  The
+// remainder travels through a per-lane LDS slot (written before the call, read after it: the LDS serves a wave's accesses in
+// order) instead of the stack, which is HBM-backed scratch: measured 3.39 k cycles per multiplication against 3.17 k fully
+// inlined and 4.4 k with stack arguments (tools/ubench_rr29.hip).  Blocks of at most RB29_SIDE_LANES threads.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RB29_INLINE_ALL)
+#define RB29_CALLS 1
+#ifndef RB29_SIDE_LANES
+#define RB29_SIDE_LANES 256
+#endif
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
+static __shared__ uint32_t rr_side[5 * RB29_SIDE_LANES];
+struct Out16 { i32x8 lo0, lo1; };
+__device__ __forceinline__ i32x9 side_join(const i32x4& lo, const uint32_t* side) {
+  i32x9 b;
+  b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+  b[4] = (int32_t)side[0]; b[5] = (int32_t)side[RB29_SIDE_LANES]; b[6] = (int32_t)side[2 * RB29_SIDE_LANES]; b[7] = (int32_t)side[3 * RB29_SIDE_LANES];
+  b[8] = (int32_t)side[4 * RB29_SIDE_LANES];
+  return b;
+}
+__device__ __forceinline__ i32x4 side_split(const i32x9& b, uint32_t* side) {
+  side[0] = (uint32_t)b[4]; side[RB29_SIDE_LANES] = (uint32_t)b[5]; side[2 * RB29_SIDE_LANES] = (uint32_t)b[6]; side[3 * RB29_SIDE_LANES] = (uint32_t)b[7];
+  side[4 * RB29_SIDE_LANES] = (uint32_t)b[8];
+  i32x4 lo;
+  lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; lo[3] = b[3];
+  return lo;
+}
+__device__ __forceinline__ Out16 side_ret(const i32x9& c0, const i32x9& c1, uint32_t* side) {
+  side[0] = (uint32_t)c0[8]; side[RB29_SIDE_LANES] = (uint32_t)c1[8];
+  Out16 o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { o.lo0[i] = c0[i]; o.lo1[i] = c1[i]; }
+  return o;
+}
+#define RB29_TAKE(o, c0, c1, side)                                          \
+  i32x9 c0, c1;                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) { c0[i_] = o.lo0[i_]; c1[i_] = o.lo1[i_]; } \
+  c0[8] = (int32_t)side[0]; c1[8] = (int32_t)side[RB29_SIDE_LANES];
+// (a0 + a1 u)(b0 + b1 u)
+__device__ __attribute__((noinline)) Out16 mul2_core(i32x9 a0, i32x9 a1, i32x9 b0, i32x4 b1lo) {
+  uint32_t* side = rr_side + threadIdx.x;
+  const i32x9 b1 = side_join(b1lo, side);
+  return side_ret(mac2_raw(a0, b0, -a1, b1), mac2_raw(a0, b1, a1, b0), side);
+}
+// (s d) + (2 a0 a1) u with s = a0 + a1, d = a0 - a1 formed by the caller, or a0 a0 - a1 a1 when the bounds ask for it
+__device__ __attribute__((noinline)) Out16 sqr2_sd_core(i32x9 s, i32x9 d, i32x9 a0x2, i32x4 a1lo) {
+  uint32_t* side = rr_side + threadIdx.x;
+  const i32x9 a1 = side_join(a1lo, side);
+  return side_ret(mul_raw(s, d), mul_raw(a0x2, a1), side);
+}
+__device__ __attribute__((noinline)) Out16 sqr2_mac_core(i32x9 a0, i32x9 a1) {
+  uint32_t* side = rr_side + threadIdx.x;
+  return side_ret(mac2_raw(a0, a0, -a1, a1), mul_raw(a0 + a0, a1), side);
+}
+__device__ __attribute__((noinline)) Out16 mul2_fp_core(i32x9 a0, i32x9 a1, i32x9 k) {
+  uint32_t* side = rr_side + threadIdx.x;
+  return side_ret(mul_raw(a0, k), mul_raw(a1, k), side);
+}
+struct Out9 { i32x9 v; };
+__device__ __attribute__((noinline)) Out9 mul_core(i32x9 a, i32x9 b) { return Out9{mul_raw(a, b)}; }
+__device__ __attribute__((noinline)) Out9 mac2_core(i32x9 a, i32x9 b, i32x9 c, i32x4 dlo) {
+  uint32_t* side = rr_side + threadIdx.x;
+  return Out9{mac2_raw(a, b, c, side_join(dlo, side))};
+}
+#endif
+
 template <int L1, int V1, int L2, int V2>
 RB_HD F mul(const FB<L1, V1>& a, const FB<L2, V2>& b) {
   static_assert(L1 * L2 <= 10, "fp29: limb bounds of a product overflow the 64-bit column");
   static_assert(V1 * V2 <= 36, "fp29: value bounds of a product");
   RR_CHECK(a, "mul a"); RR_CHECK(b, "mul b");
+#ifdef RB29_CALLS
+  const F r = mk<1, 1>(mul_core(a.l, b.l).v);
+#else
   const F r = mk<1, 1>(mul_raw(a.l, b.l));
+#endif
   RR_CHECK(r, "mul out");
   return r;
 }
@@ -223,7 +295,11 @@ RB_HD F mac2(const FB<L1, V1>& a, const FB<L2, V2>& b, const FB<L3, V3>& c, cons
   static_assert(L1 * L2 + L3 * L4 <= 10, "fp29: limb bounds of a two-product sum overflow the 64-bit column");
   static_assert(V1 * V2 + V3 * V4 <= 36, "fp29: value bounds of a two-product sum");
   RR_CHECK(a, "mac2 a"); RR_CHECK(b, "mac2 b"); RR_CHECK(c, "mac2 c"); RR_CHECK(d, "mac2 d");
+#ifdef RB29_CALLS
+  const F r = mk<1, 1>(mac2_core(a.l, b.l, c.l, side_split(d.l, rr_side + threadIdx.x)).v);
+#else
   const F r = mk<1, 1>(mac2_raw(a.l, b.l, c.l, d.l));
+#endif
   RR_CHECK(r, "mac2 out");
   return r;
 }
@@ -294,16 +370,48 @@ template <int L, int V> RB_HD auto half2(const F2B<L, V>& a) { return mk2(half(a
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: four schoolbook products on two column sets, two reductions
 template <int L1, int V1, int L2, int V2>
 RB_HD F2 mul2(const F2B<L1, V1>& a, const F2B<L2, V2>& b) {
+#ifdef RB29_CALLS
+  static_assert(2 * L1 * L2 <= 10 && 2 * V1 * V2 <= 36, "fp29: bounds of an Fq2 product");
+  uint32_t* side = rr_side + threadIdx.x;
+  const Out16 o = mul2_core(a.c0.l, a.c1.l, b.c0.l, side_split(b.c1.l, side));
+  RB29_TAKE(o, c0, c1, side)
+  return mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+#else
   return mk2(mac2(a.c0, b.c0, neg(a.c1), b.c1), mac2(a.c0, b.c1, a.c1, b.c0));
+#endif
 }
 // (a0 + a1)(a0 - a1) + 2 a0 a1 u where the bounds allow the sum and the difference as operands, a0 a0 - a1 a1 otherwise
 template <int L, int V>
 RB_HD F2 sqr2(const F2B<L, V>& a) {
+#ifdef RB29_CALLS
+  static_assert(2 * L * L <= 10 && 2 * V * V <= 36, "fp29: bounds of an Fq2 square");
+  uint32_t* side = rr_side + threadIdx.x;
+  if constexpr (4 * L * L <= 10 && 4 * V * V <= 36) {
+    const Out16 o = sqr2_sd_core(a.c0.l + a.c1.l, a.c0.l - a.c1.l, a.c0.l + a.c0.l, side_split(a.c1.l, side));
+    RB29_TAKE(o, c0, c1, side)
+    return mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+  } else {
+    const Out16 o = sqr2_mac_core(a.c0.l, a.c1.l);
+    RB29_TAKE(o, c0, c1, side)
+    return mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+  }
+#else
   if constexpr (4 * L * L <= 10 && 4 * V * V <= 36) return mk2(mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1));
   else return mk2(mac2(a.c0, a.c0, neg(a.c1), a.c1), mul(dbl(a.c0), a.c1));
+#endif
 }
 template <int L1, int V1, int L2, int V2>
-RB_HD F2 mul2_fp(const F2B<L1, V1>& a, const FB<L2, V2>& k) { return mk2(mul(a.c0, k), mul(a.c1, k)); }
+RB_HD F2 mul2_fp(const F2B<L1, V1>& a, const FB<L2, V2>& k) {
+#ifdef RB29_CALLS
+  static_assert(L1 * L2 <= 10 && V1 * V2 <= 36, "fp29: bounds of an Fq2 x Fp product");
+  uint32_t* side = rr_side + threadIdx.x;
+  const Out16 o = mul2_fp_core(a.c0.l, a.c1.l, k.l);
+  RB29_TAKE(o, c0, c1, side)
+  return mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+#else
+  return mk2(mul(a.c0, k), mul(a.c1, k));
+#endif
+}
 // x + xi y,  xi = 9 + u:  (x0 + 9 y0 - y1) + (x1 + 9 y1 + y0) u, normalised
 template <int L1, int V1, int L2, int V2>
 RB_HD F2 add_mul_xi2(const F2B<L1, V1>& x, const F2B<L2, V2>& y) {

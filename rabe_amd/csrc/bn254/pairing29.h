@@ -185,7 +185,7 @@ RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, Line29& l) {
   return true;
 }
 template <class ACC>
-RB_FN void miller_loop_multi(ACC acc) {
+RB_MID void miller_loop_multi(ACC acc) {
   const int n = acc.count();
   facc_set_one(acc);
   acc.begin();

@@ -47,7 +47,7 @@ struct rhip_ctx {
   void* fe_ws = nullptr;
   size_t fe_ws_bytes = 0;
   // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
-  enum { N_WORK = 11 };
+  enum { N_WORK = 12 };
   void* work[N_WORK] = {};
   size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
@@ -663,6 +663,12 @@ int32_t rhip_launch_miller_c6(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_
                               size_t groups);
 int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
                                  uint32_t* started);
+// reduced-radix Miller kernel (engine_rr.hip, bn254/fp29.h): the drop-in for k_miller_multi on launches that fill the chip; ws / ws_bytes: the
+// workspace in k_miller_multi's layout (the walk verdicts read it), its own workspace is sized from it
+bool rhip_use_rr(const rhip_ctx* ctx);
+int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
+                              const uint32_t* qref, const void* lines, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan, const void* work,
+                              const uint32_t* chunk_off, size_t lanes);
 
 int32_t rhip_launch_gt_is_member_c6(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok);
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items);

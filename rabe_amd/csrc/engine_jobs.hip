@@ -533,7 +533,8 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     uint32_t* chunk_off = hist + hist_words;
     uint2* work = (uint2*)(chunk_off + off_words);
     void* ws = nullptr;
-    rc = rhip_ensure_work(ctx, 3, (total_pairs + n_items * (c_hi - 1) + 64 * c_hi + 64) * 12 * sizeof(uint4), &ws);
+    const size_t ws_bytes = (total_pairs + n_items * (c_hi - 1) + 64 * c_hi + 64) * 12 * sizeof(uint4);
+    rc = rhip_ensure_work(ctx, 3, ws_bytes, &ws);
     if (rc) return rc;
     rc = ensure_scratch(ctx, w_max * sizeof(GtM));
     if (rc) return rc;
@@ -546,6 +547,9 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     KLAUNCH(ctx, "k_plan_fill", k_plan_fill, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, n_items, pair_off, plan, work);
     if (rhip_use_c6(ctx, n_items, max_pairs)) {
       rc = rhip_launch_miller_c6(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, plan, work, chunk_off, w_max);
+      if (rc) return rc;
+    } else if (rhip_use_rr(ctx)) {
+      rc = rhip_launch_miller_rr(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, ws_bytes, mill, plan, work, chunk_off, w_max);
       if (rc) return rc;
     } else
     KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(w_max, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs,
@@ -565,13 +569,17 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   const size_t lanes = n_items * L;
   const size_t lanes_pad = (lanes + 63) / 64 * 64;
   void* ws = nullptr;
-  int32_t rc = rhip_ensure_work(ctx, 3, lanes_pad * C * 12 * sizeof(uint4), &ws);
+  const size_t ws_bytes = lanes_pad * C * 12 * sizeof(uint4);
+  int32_t rc = rhip_ensure_work(ctx, 3, ws_bytes, &ws);
   if (rc) return rc;
   rc = ensure_scratch(ctx, lanes * sizeof(GtM));
   if (rc) return rc;
   GtM* mill = (GtM*)ctx->scratch;
   if (c6) {       // six lanes per (item, chunk): engine_coop.hip; same (item, chunk) map and workspace layout, so the walk verdicts below apply unchanged
     rc = rhip_launch_miller_c6(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, nullptr, nullptr, nullptr, lanes);
+    if (rc) return rc;
+  } else if (rhip_use_rr(ctx)) {
+    rc = rhip_launch_miller_rr(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, ws_bytes, mill, nullptr, nullptr, nullptr, lanes);
     if (rc) return rc;
   } else
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,

@@ -9,47 +9,75 @@
 #include "bn254/tower.h"
 #include "bn254/fp29.h"
 using namespace rabe::bn254;
+using rr::i32x9;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-__device__ __forceinline__ F29x2 rr2_mul(const F29x2& a, const F29x2& b) { return rr2_mul_inl(a, b); }
-__device__ __attribute__((noinline)) F29x2 rr2_sqr(F29x2 a) { return rr2_sqr_inl(a); }
-
-// (a b + c d) / R: the ONE out-of-line routine of the call-based form -- four 9-dword operands (31 dwords in VGPRs, 5 on the stack), 9 back
-__device__ __attribute__((noinline)) F29 rr_mac2(F29 a, F29 b, F29 c, F29 d) {
-  int64_t t[18];
-  rr_cols_init(t);
-  rr_cols_mac(t, a, b);
-  rr_cols_mac(t, c, d);
-  return rr_redc(t);
+typedef int32_t i32x4v __attribute__((ext_vector_type(4)));
+typedef int32_t i32x8v __attribute__((ext_vector_type(8)));
+struct F29x2 { i32x9 c0, c1; };
+__device__ __forceinline__ F29x2 rr2_mul(const F29x2& a, const F29x2& b) {
+  return F29x2{rr::mac2_raw(a.c0, b.c0, -a.c1, b.c1), rr::mac2_raw(a.c0, b.c1, a.c1, b.c0)};
+}
+// call-based form: 31 argument dwords in VGPRs, the other 5 and the 2 result dwords beyond 16 through a per-lane LDS slot
+static __shared__ uint32_t rr_side[8 * 256];
+struct Out16 { i32x8v lo0, lo1; };
+__device__ __attribute__((noinline)) Out16 rr2_mul_core(i32x9 a0, i32x9 a1, i32x9 b0, i32x4v b1lo) {
+  uint32_t* side = rr_side + threadIdx.x;
+  i32x9 b1;
+  b1[0] = b1lo[0]; b1[1] = b1lo[1]; b1[2] = b1lo[2]; b1[3] = b1lo[3];
+  b1[4] = (int32_t)side[0]; b1[5] = (int32_t)side[256]; b1[6] = (int32_t)side[512]; b1[7] = (int32_t)side[768]; b1[8] = (int32_t)side[1024];
+  const i32x9 c0 = rr::mac2_raw(a0, b0, -a1, b1), c1 = rr::mac2_raw(a0, b1, a1, b0);
+  side[0] = (uint32_t)c0[8]; side[256] = (uint32_t)c1[8];
+  Out16 o;
+  for (int i = 0; i < 8; i++) { o.lo0[i] = c0[i]; o.lo1[i] = c1[i]; }
+  return o;
 }
 __device__ __forceinline__ F29x2 rr2_mul_calls(const F29x2& a, const F29x2& b) {
+  uint32_t* side = rr_side + threadIdx.x;
+  side[0] = (uint32_t)b.c1[4]; side[256] = (uint32_t)b.c1[5]; side[512] = (uint32_t)b.c1[6]; side[768] = (uint32_t)b.c1[7]; side[1024] = (uint32_t)b.c1[8];
+  i32x4v lo; lo[0] = b.c1[0]; lo[1] = b.c1[1]; lo[2] = b.c1[2]; lo[3] = b.c1[3];
+  const Out16 o = rr2_mul_core(a.c0, a.c1, b.c0, lo);
   F29x2 r;
-  r.c0 = rr_mac2(a.c0, b.c0, rr_neg(a.c1), b.c1);
-  r.c1 = rr_mac2(a.c0, b.c1, a.c1, b.c0);
+  for (int i = 0; i < 8; i++) { r.c0[i] = o.lo0[i]; r.c1[i] = o.lo1[i]; }
+  r.c0[8] = (int32_t)side[0]; r.c1[8] = (int32_t)side[256];
   return r;
 }
+#define LOAD29(x, y) \
+  F29x2 x, y; \
+  _Pragma("unroll") for (int i = 0; i < 9; i++) { \
+    x.c0[i] = (int32_t)((in[i] ^ (t & 0xff)) & 0x0fffffff); x.c1[i] = (int32_t)(in[9 + i] & 0x0fffffff); \
+    y.c0[i] = (int32_t)(in[18 + i] & 0x0fffffff); y.c1[i] = (int32_t)(in[27 + i] & 0x0fffffff); \
+  } \
+  x.c0[8] &= 0xffff; x.c1[8] &= 0xffff; y.c0[8] &= 0xffff; y.c1[8] &= 0xffff;
+#define SINK29(x, y) \
+  uint32_t acc = 0; \
+  _Pragma("unroll") for (int i = 0; i < 9; i++) acc ^= (uint32_t)(x.c0[i] ^ x.c1[i] ^ y.c0[i] ^ y.c1[i]); \
+  out[t] = acc; \
+  if (iters == 0xffffffffu) lds[threadIdx.x] = acc;
 extern "C" __global__ void __launch_bounds__(256) k_chain29c(uint32_t iters, const uint32_t* in, uint32_t* out) {
   extern __shared__ uint32_t lds[];
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  F29x2 x, y;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    x.c0.l[i] = (int32_t)((in[i] ^ (t & 0xff)) & 0x0fffffff); x.c1.l[i] = (int32_t)(in[9 + i] & 0x0fffffff);
-    y.c0.l[i] = (int32_t)(in[18 + i] & 0x0fffffff); y.c1.l[i] = (int32_t)(in[27 + i] & 0x0fffffff);
-  }
-  x.c0.l[8] &= 0xffff; x.c1.l[8] &= 0xffff; y.c0.l[8] &= 0xffff; y.c1.l[8] &= 0xffff;
+  LOAD29(x, y)
   for (uint32_t it = 0; it < iters; it++) {
     x = rr2_mul_calls(x, y);
     y = rr2_mul_calls(y, x);
     x = rr2_mul_calls(x, y);
     y = rr2_mul_calls(y, x);
   }
-  uint32_t acc = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) acc ^= (uint32_t)(x.c0.l[i] ^ x.c1.l[i] ^ y.c0.l[i] ^ y.c1.l[i]);
-  out[t] = acc;
-  if (iters == 0xffffffffu) lds[threadIdx.x] = acc;
+  SINK29(x, y)
+}
+extern "C" __global__ void __launch_bounds__(256) k_chain29(uint32_t iters, const uint32_t* in, uint32_t* out) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  LOAD29(x, y)
+  for (uint32_t it = 0; it < iters; it++) {
+    x = rr2_mul(x, y);
+    y = rr2_mul(y, x);
+    x = rr2_mul(x, y);
+    y = rr2_mul(y, x);
+  }
+  SINK29(x, y)
 }
 extern "C" __global__ void __launch_bounds__(256) k_chain32(uint32_t iters, const uint32_t* in, uint32_t* out) {
   extern __shared__ uint32_t lds[];
@@ -70,32 +98,9 @@ extern "C" __global__ void __launch_bounds__(256) k_chain32(uint32_t iters, cons
   out[t] = acc;
   if (iters == 0xffffffffu) lds[threadIdx.x] = acc;
 }
-extern "C" __global__ void __launch_bounds__(256) k_chain29(uint32_t iters, const uint32_t* in, uint32_t* out) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  F29x2 x, y;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    x.c0.l[i] = (int32_t)((in[i] ^ (t & 0xff)) & 0x0fffffff); x.c1.l[i] = (int32_t)(in[9 + i] & 0x0fffffff);
-    y.c0.l[i] = (int32_t)(in[18 + i] & 0x0fffffff); y.c1.l[i] = (int32_t)(in[27 + i] & 0x0fffffff);
-  }
-  x.c0.l[8] &= 0xffff; x.c1.l[8] &= 0xffff; y.c0.l[8] &= 0xffff; y.c1.l[8] &= 0xffff;
-  for (uint32_t it = 0; it < iters; it++) {
-    x = rr2_mul(x, y);
-    y = rr2_mul(y, x);
-    x = rr2_mul(x, y);
-    y = rr2_mul(y, x);
-  }
-  uint32_t acc = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) acc ^= (uint32_t)(x.c0.l[i] ^ x.c1.l[i] ^ y.c0.l[i] ^ y.c1.l[i]);
-  out[t] = acc;
-  if (iters == 0xffffffffu) lds[threadIdx.x] = acc;
-}
-
 template <class K>
 static void run(const char* name, K kern, int blocks, size_t lds_bytes, uint32_t iters, const uint32_t* d_in, uint32_t* d_out) {
-  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, 0, 64u, d_in, d_out);
@@ -123,10 +128,10 @@ int main() {
   CHECK(hipMalloc(&d_out, 4096 * 256 * 4));
   CHECK(hipMemcpy(d_in, h_in, sizeof(h_in), hipMemcpyHostToDevice));
   const uint32_t iters = 2000;
-  const size_t big = 144 * 1024;
+  const size_t big = 136 * 1024;
   run("8x32 lazy Fq2, 1 wave/SIMD", k_chain32, 256, big, iters, d_in, d_out);
   run("9x29 Fq2,      1 wave/SIMD", k_chain29, 256, big, iters, d_in, d_out);
-  run("9x29 Fq2 = 2 calls, 1 wave/SIMD", k_chain29c, 256, big, iters, d_in, d_out);
+  run("9x29 Fq2, one call + LDS side slot, 1 wave/SIMD", k_chain29c, 256, big, iters, d_in, d_out);
   run("8x32 lazy Fq2, 2 waves/SIMD", k_chain32, 512, 72 * 1024, iters, d_in, d_out);
   run("9x29 Fq2,      2 waves/SIMD", k_chain29, 512, 72 * 1024, iters, d_in, d_out);
   run("8x32 lazy Fq2, 4 waves/SIMD", k_chain32, 1024, 36 * 1024, iters, d_in, d_out);
