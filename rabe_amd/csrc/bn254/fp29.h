@@ -246,7 +246,7 @@ __device__ __forceinline__ Out16 side_ret(const i32x9& c0, const i32x9& c1, uint
   return o;
 }
 #define RB29_TAKE(o, c0, c1, side)                                          \
-  i32x9 c0, c1;                                                             \
+  ::rabe::bn254::rr::i32x9 c0, c1;                                                           \
   _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) { c0[i_] = o.lo0[i_]; c1[i_] = o.lo1[i_]; } \
   c0[8] = (int32_t)side[0]; c1[8] = (int32_t)side[RB29_SIDE_LANES];
 // (a0 + a1 u)(b0 + b1 u)
@@ -302,6 +302,29 @@ RB_HD F mac2(const FB<L1, V1>& a, const FB<L2, V2>& b, const FB<L3, V3>& c, cons
 #endif
   RR_CHECK(r, "mac2 out");
   return r;
+}
+
+// (x0 y0 + x1 y1 + x2 y2) over Fq2 on ONE pair of column sets: twelve schoolbook products, two reductions -- the form in which the
+// sparse line products of the Miller loop are taken (pairing29.h): no Karatsuba sums, nothing to normalise afterwards
+RB_HD void dot3_raw(i32x9& c0, i32x9& c1, const i32x9& x0a, const i32x9& x0b, const i32x9& y0a, const i32x9& y0b, const i32x9& x1a, const i32x9& x1b,
+                    const i32x9& y1a, const i32x9& y1b, const i32x9& x2a, const i32x9& x2b, const i32x9& y2a, const i32x9& y2b) {
+  RR_COUNT(12);
+  {
+    int64_t t[18];
+    cols_init(t);
+    cols_mac(t, x0a, y0a); cols_mac(t, -x0b, y0b);
+    cols_mac(t, x1a, y1a); cols_mac(t, -x1b, y1b);
+    cols_mac(t, x2a, y2a); cols_mac(t, -x2b, y2b);
+    c0 = redc(t);
+  }
+  {
+    int64_t t[18];
+    cols_init(t);
+    cols_mac(t, x0a, y0b); cols_mac(t, x0b, y0a);
+    cols_mac(t, x1a, y1b); cols_mac(t, x1b, y1a);
+    cols_mac(t, x2a, y2b); cols_mac(t, x2b, y2a);
+    c1 = redc(t);
+  }
 }
 
 // ---- conversions from / to fp.h's canonical Montgomery form (x 2^256 mod p in 8 x 32-bit limbs)
@@ -411,6 +434,18 @@ RB_HD F2 mul2_fp(const F2B<L1, V1>& a, const FB<L2, V2>& k) {
 #else
   return mk2(mul(a.c0, k), mul(a.c1, k));
 #endif
+}
+template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD, int LE, int VE, int LF, int VF>
+RB_HD F2 dot3(const F2B<LA, VA>& x0, const F2B<LB, VB>& y0, const F2B<LC, VC>& x1, const F2B<LD, VD>& y1, const F2B<LE, VE>& x2, const F2B<LF, VF>& y2) {
+  static_assert(2 * (LA * LB + LC * LD + LE * LF) <= 10, "fp29: limb bounds of an Fq2 dot product overflow the 64-bit column");
+  static_assert(2 * (VA * VB + VC * VD + VE * VF) <= 36, "fp29: value bounds of an Fq2 dot product");
+  RR_CHECK(x0.c0, "dot3"); RR_CHECK(x0.c1, "dot3"); RR_CHECK(y0.c0, "dot3"); RR_CHECK(y0.c1, "dot3"); RR_CHECK(x1.c0, "dot3"); RR_CHECK(x1.c1, "dot3");
+  RR_CHECK(y1.c0, "dot3"); RR_CHECK(y1.c1, "dot3"); RR_CHECK(x2.c0, "dot3"); RR_CHECK(x2.c1, "dot3"); RR_CHECK(y2.c0, "dot3"); RR_CHECK(y2.c1, "dot3");
+  i32x9 c0, c1;
+  dot3_raw(c0, c1, x0.c0.l, x0.c1.l, y0.c0.l, y0.c1.l, x1.c0.l, x1.c1.l, y1.c0.l, y1.c1.l, x2.c0.l, x2.c1.l, y2.c0.l, y2.c1.l);
+  const F2 r = mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+  RR_CHECK(r.c0, "dot3 out"); RR_CHECK(r.c1, "dot3 out");
+  return r;
 }
 // x + xi y,  xi = 9 + u:  (x0 + 9 y0 - y1) + (x1 + 9 y1 + y0) u, normalised
 template <int L1, int V1, int L2, int V2>

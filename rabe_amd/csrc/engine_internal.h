@@ -629,6 +629,7 @@ struct rhip_ac17_sk_lines {
   size_t n_sk;
   LineM* lines;      // [n_sk * 3][RB_MILLER_LINES]
   uint8_t* q_inf;    // [n_sk * 3]
+  void* lines29 = nullptr;      // the same triples in the reduced-radix form k_miller_multi_rr replays (engine_rr.hip: rhip_lines_to_rr)
 };
 // prepared lines of n arbitrary G2 points (rhip_g2_lines_prepare): lines[i * RB_MILLER_LINES + k]
 struct rhip_g2_lines {
@@ -636,6 +637,7 @@ struct rhip_g2_lines {
   size_t n;
   LineM* lines;
   uint8_t* q_inf;    // [n]
+  void* lines29 = nullptr;      // reduced-radix form (engine_rr.hip: rhip_lines_to_rr)
 };
 struct DevLineLoad {
   const LineM* base;
@@ -667,8 +669,10 @@ int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* 
 // workspace in k_miller_multi's layout (the walk verdicts read it), its own workspace is sized from it
 bool rhip_use_rr(const rhip_ctx* ctx);
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
-                              const uint32_t* qref, const void* lines, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan, const void* work,
-                              const uint32_t* chunk_off, size_t lanes);
+                              const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
+                              const void* work, const uint32_t* chunk_off, size_t lanes);
+// prepared line triples (LineM, 8 x 32-bit limbs) converted once into the records k_miller_multi_rr replays; *out is hipMalloc'ed
+int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void** out);
 
 int32_t rhip_launch_gt_is_member_c6(rhip_ctx* ctx, size_t n, const rhip_gt* a, uint32_t* ok);
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items);

@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(size_t n_items, const uint32_
 }
 // Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
 static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
-                              const LineM* lines, const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
+                              const LineM* lines, const void* lines29, const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
   if (pair_off && total_pairs && total_pairs < n_items * max_pairs && !getenv("RABE_NO_MILLER_PLAN")) {
     // ragged: plan on the device.  Bounds of what the plan may choose: no fewer pairs per chunk than four rounds' worth of lanes need
     // (more lanes only add shared squarings), no more than 64; the buffers are sized for the worst of the range.
@@ -549,7 +549,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
       rc = rhip_launch_miller_c6(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, plan, work, chunk_off, w_max);
       if (rc) return rc;
     } else if (rhip_use_rr(ctx)) {
-      rc = rhip_launch_miller_rr(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, ws_bytes, mill, plan, work, chunk_off, w_max);
+      rc = rhip_launch_miller_rr(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, plan, work, chunk_off, w_max);
       if (rc) return rc;
     } else
     KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(w_max, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs,
@@ -579,7 +579,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     rc = rhip_launch_miller_c6(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, nullptr, nullptr, nullptr, lanes);
     if (rc) return rc;
   } else if (rhip_use_rr(ctx)) {
-    rc = rhip_launch_miller_rr(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, ws_bytes, mill, nullptr, nullptr, nullptr, lanes);
+    rc = rhip_launch_miller_rr(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, nullptr, nullptr, nullptr, lanes);
     if (rc) return rc;
   } else
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,
@@ -907,7 +907,7 @@ static int32_t bsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
   if (compact)
     KLAUNCH(ctx, "k_bsw_entry_pairs", k_bsw_entry_pairs, dim3(blocks_for(n_items * (size_t)((ppi - 1) / 2), 256)), dim3(256), 0, ctx->stream, n_items, ppi, sel_start,
             sel_ct_leaf, ct_cy_g2, ct_leaf_off, (const G1M*)psel, (const uint8_t*)psel_inf, pl.P, pl.Q, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, ct_cp, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, sk_lines ? (const LineM*)sk_lines->l->lines : (const LineM*)nullptr, sk_lines ? sk_lines->l->lines29 : nullptr, ct_cp, out);
 }
 
 // ------------------------------------------------------------------------------------------------ shared-doubling sums
@@ -1275,7 +1275,7 @@ static int32_t lsw_decrypt_impl(rhip_ctx* ctx, size_t n_items, size_t max_pairs,
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
           (const G1JM*)w_part, pair_off, pl.P, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e1, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, ct_e2_lines ? (const LineM*)ct_e2_lines->lines : (const LineM*)nullptr, ct_e2_lines ? ct_e2_lines->lines29 : nullptr, ct_e1, out);
 }
 
 // ------------------------------------------------------------------------------------------------ GHW11 outsourced decryption
@@ -1348,7 +1348,7 @@ extern "C" int32_t rhip_ghw11_transform_batch(rhip_ctx* ctx, size_t n_items, siz
           (const uint32_t*)w_off, sel_start, (const G1M*)w_terms, (const uint32_t*)w_masks, 1, (G1JM*)w_part);
   KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
           (const G1JM*)w_part, pair_off, pl.P, pl.qref);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)tk_lines->lines, (const rhip_gt*)nullptr, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)tk_lines->lines, tk_lines->lines29, (const rhip_gt*)nullptr, out);
 }
 
 // ------------------------------------------------------------------------------------------------ AW11 multi-authority CP-ABE
@@ -1781,7 +1781,7 @@ extern "C" int32_t rhip_aw11_decrypt_batch(rhip_ctx* ctx, size_t n_items, size_t
   KLAUNCH(ctx, "k_gt_multiexp_partial", k_gt_multiexp_partial, dim3(blocks_for(n_items * L, 64)), dim3(64), 0, ctx->stream, n_items, L, C,
           (const uint32_t*)w_off, sel_start, (const GtM*)t_c1, (const uint32_t*)w_masks, 1, p_gt);
   KLAUNCH(ctx, "k_gt_lead", k_gt_lead, dim3(blocks_for(n_items, 64)), dim3(64), 0, ctx->stream, n_items, L, ct_c0, (const GtM*)p_gt, lead);
-  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)nullptr, (const rhip_gt*)lead, out);
+  return run_pair_lists(ctx, n_items, pair_off, max_pairs, total_pairs, pl, (const LineM*)nullptr, (const void*)nullptr, (const rhip_gt*)lead, out);
 }
 
 // ------------------------------------------------------------------------------------------------ membership of decoded elements
@@ -1995,7 +1995,7 @@ extern "C" int32_t rhip_pairing_jobs(rhip_ctx* ctx, size_t n_items, size_t max_p
     KLAUNCH(ctx, "k_msm_finish_g1", k_msm_finish_g1, dim3(blocks_for(n_items, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, L,
             (const G1JM*)w_part, (const uint32_t*)cpo, pl.P, pl.qref);
   }
-  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), total, pl, (const LineM*)nullptr, lead, out);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)cpo, max_pairs + (with_sum ? 1 : 0), total, pl, (const LineM*)nullptr, (const void*)nullptr, lead, out);
 }
 
 
@@ -2060,7 +2060,7 @@ static int32_t ac17_decrypt_shared(rhip_ctx* ctx, size_t n_items, const rhip_g2*
   KLAUNCH(ctx, "k_ac17_dec_pairs", k_ac17_dec_pairs, dim3(blocks_for((n_items * 3 + 63) / 64 * 128, RB_PAIRS_BLOCK)), dim3(RB_PAIRS_BLOCK), 0, ctx->stream, n_items, ct_c0, ct_c,
           ct_row_off, sk_k0, (const uint8_t*)(sk_lines ? sk_lines->q_inf : nullptr), sk_lines ? 1 : 0, sk_k, sk_row_off, sk_kp, sk_idx, ct_sel, ct_sel_off,
           sk_sel, sk_sel_off, pl.P, pl.Q, pl.qref);
-  return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, 0, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, ct_cp, out);
+  return run_pair_lists(ctx, n_items, (const uint32_t*)nullptr, 6, 0, pl, sk_lines ? (const LineM*)sk_lines->lines : (const LineM*)nullptr, sk_lines ? sk_lines->lines29 : nullptr, ct_cp, out);
 }
 // which AC17 decrypt path a launch takes: 0 = shared accumulators (this file), 1 = one lane per pairing / couple (engine.hip).
 // RABE_AC17_DEC_PATH overrides for A/B runs.  Small launches keep the pairwise kernels (their three-lane form is latency-optimised).

@@ -19,6 +19,10 @@ using rr::F6;
 // twelve Fp coefficients = quads 2 i, 2 i + 1 (limbs 0..7) + dword i (limb 8).  110.6 KB per four-wave block: a block owns a CU.
 static __shared__ uint4 rr_home_q[4 * 24 * 64];
 static __shared__ uint32_t rr_home_d[4 * 12 * 64];
+// the second and third right-hand operand of the line products' dot products (pairing29.h: facc_mul_by_line): two Fq2 per lane, same layout
+// (slot s, coefficient c: element 2 s + c).  36.9 KB per block; with the home and fp29.h's side slot 152.5 of the CU's 160 KB.
+static __shared__ uint4 rr_y_q[4 * 8 * 64];
+static __shared__ uint32_t rr_y_d[4 * 4 * 64];
 
 __device__ __forceinline__ Fp ld_fp_q(const uint4* p) {
   const uint4 a = p[0], b = p[1];
@@ -38,15 +42,44 @@ __device__ __forceinline__ uint4 rr_quad(const F& a, int h) {
   return make_uint4((uint32_t)a.l[4 * h], (uint32_t)a.l[4 * h + 1], (uint32_t)a.l[4 * h + 2], (uint32_t)a.l[4 * h + 3]);
 }
 
+__device__ __forceinline__ rr::i32x9 rr_lds_elem(const uint4* q, const uint32_t* d) {
+  const uint4 a = q[0], b = q[64];
+  rr::i32x9 r;
+  r[0] = (int32_t)a.x; r[1] = (int32_t)a.y; r[2] = (int32_t)a.z; r[3] = (int32_t)a.w;
+  r[4] = (int32_t)b.x; r[5] = (int32_t)b.y; r[6] = (int32_t)b.z; r[7] = (int32_t)b.w;
+  r[8] = (int32_t)d[0];
+  return r;
+}
+// f[ia] y0 + f[ib] y[1] + f[ic] y[2]: the accumulator's coefficients and y[1], y[2] come from the LDS, y0 in registers (18 of the 31 argument
+// registers), the result as the other Fq2 routines return theirs (16 dwords + the two top limbs through the side slot)
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass of this file only needs the kernels' signatures)
+__device__ __attribute__((noinline)) rr::Out16 rr_dot3_core(rr::i32x9 y0a, rr::i32x9 y0b, int ia, int ib, int ic) {
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const uint4* hq = rr_home_q + wv * (24 * 64) + ln;
+  const uint32_t* hd = rr_home_d + wv * (12 * 64) + ln;
+  const uint4* yq = rr_y_q + wv * (8 * 64) + ln;
+  const uint32_t* yd = rr_y_d + wv * (4 * 64) + ln;
+  const rr::i32x9 x0a = rr_lds_elem(hq + (4 * ia) * 64, hd + (2 * ia) * 64), x0b = rr_lds_elem(hq + (4 * ia + 2) * 64, hd + (2 * ia + 1) * 64);
+  const rr::i32x9 x1a = rr_lds_elem(hq + (4 * ib) * 64, hd + (2 * ib) * 64), x1b = rr_lds_elem(hq + (4 * ib + 2) * 64, hd + (2 * ib + 1) * 64);
+  const rr::i32x9 x2a = rr_lds_elem(hq + (4 * ic) * 64, hd + (2 * ic) * 64), x2b = rr_lds_elem(hq + (4 * ic + 2) * 64, hd + (2 * ic + 1) * 64);
+  const rr::i32x9 y1a = rr_lds_elem(yq, yd), y1b = rr_lds_elem(yq + 2 * 64, yd + 64);
+  const rr::i32x9 y2a = rr_lds_elem(yq + 4 * 64, yd + 2 * 64), y2b = rr_lds_elem(yq + 6 * 64, yd + 3 * 64);
+  rr::i32x9 c0, c1;
+  rr::dot3_raw(c0, c1, x0a, x0b, y0a, y0b, x1a, x1b, y1a, y1b, x2a, x2b, y2a, y2b);
+  return rr::side_ret(c0, c1, rr::rr_side + threadIdx.x);
+}
+#endif
+
 // a lane's slice of the global workspace: per pair slot RR_SLOT_QUADS quads at stride 64 (one coalesced 1 KB access per quad and wave)
 //   quads [0, 12): the running point T (six Fp: limbs 0..7), quads [12, 14): its six top limbs (+ 2 unused dwords)
 //   quads [14, 22) + 22: the converted G2 argument (four Fp + their top limbs), quads [23, 27) + 27: the converted G1 argument
 #define RR_SLOT_QUADS 28
+#define RR_LINE_QUADS 14
 struct DevMultiAcc29 {
   const G1M* P;
   const G2M* Q;
   const uint32_t* qref;
-  const LineM* lines;
+  const uint4* lines29;      // prepared triples in this core's form: 14 quads each (6 x 8 limbs, then the 6 top limbs + 2 unused dwords)
   int cnt;
   uint4* ws;                 // + lane
   F6* x;                     // the parked Fq6 (a local of the kernel)
@@ -69,6 +102,23 @@ struct DevMultiAcc29 {
   __device__ __forceinline__ void st_h2(int i, const F2& a) const { st_h(2 * i, a.c0); st_h(2 * i + 1, a.c1); }
   __device__ __forceinline__ F6 ld_f6(int h) const { return rr::mk6(ld_h2(3 * h), ld_h2(3 * h + 1), ld_h2(3 * h + 2)); }
   __device__ __forceinline__ void st_f6(int h, const F6& v) const { st_h2(3 * h, v.a0); st_h2(3 * h + 1, v.a1); st_h2(3 * h + 2, v.a2); }
+  __device__ __forceinline__ void st_f2(int i, const F2& a) const { st_h2(i, a); }
+  __device__ __forceinline__ void set_y(int slot, const F2& a) const {
+    uint4* q = rr_y_q + (threadIdx.x >> 6) * (8 * 64) + (threadIdx.x & 63) + (4 * (slot - 1)) * 64;
+    uint32_t* d = rr_y_d + (threadIdx.x >> 6) * (4 * 64) + (threadIdx.x & 63) + (2 * (slot - 1)) * 64;
+    q[0] = rr_quad(a.c0, 0); q[64] = rr_quad(a.c0, 1); q[128] = rr_quad(a.c1, 0); q[192] = rr_quad(a.c1, 1);
+    d[0] = (uint32_t)a.c0.l[8]; d[64] = (uint32_t)a.c1.l[8];
+  }
+  __device__ __forceinline__ F2 dot3(const F2& y0, int ia, int ib, int ic) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const rr::Out16 o = rr_dot3_core(y0.c0.l, y0.c1.l, ia, ib, ic);
+    uint32_t* side = rr::rr_side + threadIdx.x;
+    RB29_TAKE(o, c0, c1, side)
+    return rr::mk2(rr::mk<1, 1>(c0), rr::mk<1, 1>(c1));
+#else
+    return y0;
+#endif
+  }
   __device__ __forceinline__ F6 ld_x() const { return *x; }
   __device__ __forceinline__ void st_x(const F6& v) const { *x = v; }
   __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
@@ -116,11 +166,12 @@ struct DevMultiAcc29 {
     return rr::MillerP29{e[0], e[1]};
   }
   __device__ __forceinline__ rr::Line29 line(int j, int n) const {
-    const uint4* p = (const uint4*)(lines + (size_t)qref[j] * RB_MILLER_LINES + n);
+    const uint4* p = lines29 + ((size_t)qref[j] * RB_MILLER_LINES + n) * RR_LINE_QUADS;
+    const uint4 t0 = p[12], t1 = p[13];
     rr::Line29 r;
-    r.cy = rr::mk2(rr::from_fp(ld_fp_q(p)), rr::from_fp(ld_fp_q(p + 2)));
-    r.cx = rr::mk2(rr::from_fp(ld_fp_q(p + 4)), rr::from_fp(ld_fp_q(p + 6)));
-    r.c0 = rr::mk2(rr::from_fp(ld_fp_q(p + 8)), rr::from_fp(ld_fp_q(p + 10)));
+    r.cy = rr::mk2(rr_from_quads(p[0], p[1], t0.x), rr_from_quads(p[2], p[3], t0.y));
+    r.cx = rr::mk2(rr_from_quads(p[4], p[5], t0.z), rr_from_quads(p[6], p[7], t0.w));
+    r.c0 = rr::mk2(rr_from_quads(p[8], p[9], t1.x), rr_from_quads(p[10], p[11], t1.y));
     return r;
   }
   // once, before the loop: the lane's arguments in the field core's representation
@@ -146,7 +197,7 @@ struct DevMultiAcc29 {
 // Same arguments and lane map as k_miller_multi (engine_jobs.hip); ws29: the workspace in this kernel's layout; ws: the one k_walk_verdicts
 // reads ([wave][pair slot][12 quads][lane], 8 x 32-bit Montgomery limbs) -- written once, at the end, for the walking pairs.
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
-                                                                       const G2M* Q, const uint32_t* qref, const LineM* lines, uint4* ws, uint4* ws29, GtM* mill,
+                                                                       const G2M* Q, const uint32_t* qref, const uint4* lines29, uint4* ws, uint4* ws29, GtM* mill,
                                                                        const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t first;
@@ -180,7 +231,7 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n
     cnt = (int)(base + (cc < rem ? 1u : 0u));
   }
   F6 parked;
-  const DevMultiAcc29 acc{P + first, Q + first, qref + first, lines, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked};
+  const DevMultiAcc29 acc{P + first, Q + first, qref + first, lines29, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked};
   rr::miller_loop_multi(acc);
   // the value, back in the canonical Montgomery form of the 8 x 32-bit core
   {
@@ -210,13 +261,36 @@ bool rhip_use_rr(const rhip_ctx* ctx) {
   static const int on = getenv("RABE_RR") ? atoi(getenv("RABE_RR")) : 1;
   return ctx->pairing_mode == 29 || (on != 0 && ctx->pairing_mode == 0);
 }
+// one lane per prepared triple: six conversions, written as the 14-quad record line() reads
+__global__ void __launch_bounds__(256) k_lines_to_rr(size_t n, const LineM* in, uint4* out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint4* p = (const uint4*)(in + t);
+  uint4* o = out + t * RR_LINE_QUADS;
+  uint32_t top[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const F v = rr::from_fp(ld_fp_q(p + 2 * k));
+    o[2 * k] = rr_quad(v, 0);
+    o[2 * k + 1] = rr_quad(v, 1);
+    top[k] = (uint32_t)v.l[8];
+  }
+  o[12] = make_uint4(top[0], top[1], top[2], top[3]);
+  o[13] = make_uint4(top[4], top[5], top[6], top[7]);
+}
+int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void** out) {
+  HIP_TRY(ctx, hipMalloc(out, n_lines * RR_LINE_QUADS * sizeof(uint4)));
+  KLAUNCH(ctx, "k_lines_to_rr", k_lines_to_rr, dim3(blocks_for(n_lines, 256)), dim3(256), 0, ctx->stream, n_lines, (const LineM*)lines, (uint4*)*out);
+  return RHIP_OK;
+}
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
-                              const uint32_t* qref, const void* lines, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan, const void* work,
-                              const uint32_t* chunk_off, size_t lanes) {
+                              const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
+                              const void* work, const uint32_t* chunk_off, size_t lanes) {
+  if (lines && !lines29) return RHIP_ERR_ARG;          // every handle that carries prepared lines carries their converted form (rhip_lines_to_rr)
   void* ws29 = nullptr;
   const int32_t rc = rhip_ensure_work(ctx, 11, ws_bytes / 12 * RR_SLOT_QUADS, &ws29);
   if (rc) return rc;
   KLAUNCH(ctx, "k_miller_multi_rr", k_miller_multi_rr, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, uniform,
-          (const G1M*)P, (const G2M*)Q, qref, (const LineM*)lines, (uint4*)ws, (uint4*)ws29, (GtM*)mill, plan, (const uint2*)work, chunk_off);
+          (const G1M*)P, (const G2M*)Q, qref, (const uint4*)lines29, (uint4*)ws, (uint4*)ws29, (GtM*)mill, plan, (const uint2*)work, chunk_off);
   return RHIP_OK;
 }

@@ -488,6 +488,11 @@ struct HostMultiAcc29 {
   rr::F6 ld_x() const { return F[2]; }
   void st_x(const rr::F6& v) const { F[2] = v; }
   void fence() const {}
+  rr::F2* Y;                   // [3]: the right-hand operands of the dot products (slots 1, 2)
+  rr::F2& f2(int i) const { return (&F[i / 3].a0)[i % 3]; }
+  void st_f2(int i, const rr::F2& v) const { f2(i) = v; }
+  void set_y(int s, const rr::F2& v) const { Y[s] = v; }
+  rr::F2 dot3(const rr::F2& y0, int ia, int ib, int ic) const { return rr::dot3(f2(ia), y0, f2(ib), Y[1], f2(ic), Y[2]); }
   int kind(int j) const { return kinds[j]; }
   rr::MillerP29 p(int j) const { return rr::MillerP29{rr::from_fp(P[j].x), rr::from_fp(P[j].y)}; }
   rr::G2Aff29 q(int j) const { return rr::G2Aff29{rr::from_fp2(Q[j].x), rr::from_fp2(Q[j].y)}; }
@@ -533,7 +538,8 @@ void hs_rr_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32
     if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
   }
   rr::F6 F[3];
-  rr::miller_loop_multi(HostMultiAcc29{n, kk, P, Q, lines, T, F});
+  rr::F2 Y[3];
+  rr::miller_loop_multi(HostMultiAcc29{n, kk, P, Q, lines, T, F, Y});
   Fp12 f;
   f.c0 = Fp6{rr::to_fp2(F[0].a0), rr::to_fp2(F[0].a1), rr::to_fp2(F[0].a2)};
   f.c1 = Fp6{rr::to_fp2(F[1].a0), rr::to_fp2(F[1].a1), rr::to_fp2(F[1].a2)};
