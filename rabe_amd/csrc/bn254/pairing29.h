@@ -210,4 +210,151 @@ RB_MID void miller_loop_multi(ACC acc) {
   }
 }
 
+// ============================================================================ final exponentiation (pairing.h: final_exponentiation_ws)
+// The same chain value by value -- easy part, then the hard part's three exponentiations by u over the width-3 NAF with Granger-Scott
+// squarings -- on values that live in numbered workspace slots; only the representation of the field elements differs.
+struct F12 { F6 c0, c1; };
+RB_HD F6 neg6(const F6& a) { return mk6(neg2(a.a0), neg2(a.a1), neg2(a.a2)); }
+RB_HD F12 from_fp12(const Fp12& x) {
+  return F12{mk6(from_fp2(x.c0.a0), from_fp2(x.c0.a1), from_fp2(x.c0.a2)), mk6(from_fp2(x.c1.a0), from_fp2(x.c1.a1), from_fp2(x.c1.a2))};
+}
+RB_HD Fp12 to_fp12(const F12& x) {
+  return Fp12{Fp6{to_fp2(x.c0.a0), to_fp2(x.c0.a1), to_fp2(x.c0.a2)}, Fp6{to_fp2(x.c1.a0), to_fp2(x.c1.a1), to_fp2(x.c1.a2)}};
+}
+// f *= y for a general y; Y provides  F6 half(int h) const
+template <class FA, class Y> RB_HD void facc_mul(FA a, Y y) {
+  { const F6 t0 = mul6(a.ld_f6(0), y.half(0)); a.st_x(t0); }
+  a.fence();
+  const F6 t1 = mul6(a.ld_f6(1), y.half(1));
+  a.fence();
+  const F6 t2 = mul6(norm6(add6(a.ld_f6(0), a.ld_f6(1))), norm6(add6(y.half(0), y.half(1))));
+  a.fence();
+  rr::facc_finish(a, t1, t2);
+  a.fence();
+}
+// Granger-Scott squaring (tower.h: fp12_cyclotomic_sqr)
+RB_HD void fp4_sqr(F2& r0, F2& r1, const F2& a, const F2& b) {
+  const F2 t0 = sqr2(a);
+  const F2 t1 = sqr2(b);
+  r0 = add_mul_xi2(t0, t1);
+  r1 = normf2(sub2(sub2(sqr2(add2(a, b)), t0), t1));
+}
+RB_MID F12 cyclotomic_sqr(const F12& f) {
+  const F2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
+  F2 t0, t1, t2, t3, t4, t5;
+  fp4_sqr(t0, t1, z0, z1);
+  fp4_sqr(t2, t3, z2, z3);
+  fp4_sqr(t4, t5, z4, z5);
+  F12 r;
+  r.c0.a0 = normf2(add2(dbl2(sub2(t0, z0)), t0));
+  r.c1.a1 = normf2(add2(dbl2(add2(t1, z1)), t1));
+  const F2 x5 = mul_xi2(t5);
+  r.c1.a0 = normf2(add2(dbl2(add2(x5, z2)), x5));
+  r.c0.a2 = normf2(add2(dbl2(sub2(t4, z3)), t4));
+  r.c0.a1 = normf2(add2(dbl2(sub2(t2, z4)), t2));
+  r.c1.a2 = normf2(add2(dbl2(add2(t3, z5)), t3));
+  return r;
+}
+RB_MID F12 frob(const F12& a, int k) {
+  F12 r;
+  if (k == 2) {
+    r.c0 = mk6(a.c0.a0, mul2_fp(a.c0.a1, gamma2_2()), mul2_fp(a.c0.a2, gamma2_4()));
+    r.c1 = mk6(mul2_fp(a.c1.a0, gamma2_1()), mul2_fp(a.c1.a1, gamma2_3()), mul2_fp(a.c1.a2, gamma2_5()));
+  } else if (k == 1) {
+    r.c0 = mk6(conj2(a.c0.a0), mul2(conj2(a.c0.a1), gamma1_2()), mul2(conj2(a.c0.a2), gamma1_4()));
+    r.c1 = mk6(mul2(conj2(a.c1.a0), gamma1_1()), mul2(conj2(a.c1.a1), gamma1_3()), mul2(conj2(a.c1.a2), gamma1_5()));
+  } else {
+    r.c0 = mk6(conj2(a.c0.a0), mul2(conj2(a.c0.a1), gamma3_2()), mul2(conj2(a.c0.a2), gamma3_4()));
+    r.c1 = mk6(mul2(conj2(a.c1.a0), gamma3_1()), mul2(conj2(a.c1.a1), gamma3_3()), mul2(conj2(a.c1.a2), gamma3_5()));
+  }
+  return r;
+}
+// WS provides  F12 ld(int slot) const, void st(int slot, const F12&) const, F6 ld6(int slot, int half) const, void st6(int slot, int half, const F6&) const
+// and home() -- an FA for the value being worked on
+template <class WS> struct WsOperand29 {
+  WS ws; int slot; bool conj;
+  RB_HD F6 half(int h) const { const F6 v = ws.ld6(slot, h); return (conj && h == 1) ? neg6(v) : v; }
+};
+template <class WS> RB_HD void wsx_to_home(WS ws, int a, bool conj) {
+  auto h = ws.home();
+  const WsOperand29<WS> y{ws, a, conj};
+  h.st_f6(0, y.half(0)); h.st_f6(1, y.half(1)); h.fence();
+}
+template <class WS> RB_HD void wsx_from_home(WS ws, int dst) {
+  auto h = ws.home();
+  ws.st6(dst, 0, h.ld_f6(0));
+  ws.st6(dst, 1, h.ld_f6(1));
+  h.fence();
+}
+template <class WS> RB_FN void wsx_mul(WS ws, int dst, int a, bool conj_a, int b, bool conj_b) {
+  rr::wsx_to_home(ws, a, conj_a);
+  rr::facc_mul(ws.home(), WsOperand29<WS>{ws, b, conj_b});
+  rr::wsx_from_home(ws, dst);
+}
+template <class WS> RB_FN void wsx_csqr(WS ws, int dst, int a, bool conj_a) {
+  F12 x = ws.ld(a);
+  if (conj_a) x.c1 = neg6(x.c1);
+  ws.st(dst, cyclotomic_sqr(x));
+}
+template <class WS> RB_FN void wsx_frob_mul(WS ws, int dst, int a, int k, int b) {          // dst = a^(p^k) * b
+  {
+    const F12 x = frob(ws.ld(a), k);
+    auto h = ws.home();
+    h.st_f6(0, x.c0);
+    h.st_f6(1, x.c1);
+    h.fence();
+  }
+  rr::facc_mul(ws.home(), WsOperand29<WS>{ws, b, false});
+  rr::wsx_from_home(ws, dst);
+}
+// the one inversion of the chain (a twelfth of a percent of its multiplications are inside the Fp inversion's addition chain) goes through
+// the 8 x 32-bit core's fp12_inv: converted in, inverted, converted back
+template <class WS> RB_FN void wsx_inv(WS ws, int dst, int a) { ws.st(dst, from_fp12(fp12_inv(to_fp12(ws.ld(a))))); }
+template <class WS> RB_MID void wsx_sqrn_mul(WS ws, int dst, int a, int n, int b, bool conj_b) {
+  F12 x = ws.ld(a);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) x = cyclotomic_sqr(x);
+  if (b < 0) { ws.st(dst, x); return; }
+  auto h = ws.home();
+  h.st_f6(0, x.c0);
+  h.st_f6(1, x.c1);
+  h.fence();
+  rr::facc_mul(h, WsOperand29<WS>{ws, b, conj_b});
+  rr::wsx_from_home(ws, dst);
+}
+template <class WS> RB_FN void wsx_exp_u(WS ws, int dst, int src, int cube) {
+  constexpr signed char SQ[RB_U_WNAF_STEPS] = RB_U_WNAF_SQ;
+  constexpr signed char DG[RB_U_WNAF_STEPS] = RB_U_WNAF_DG;
+  rr::wsx_sqrn_mul(ws, cube, src, 1, src, false);               // f^3 = f^2 * f
+  int cur = (RB_U_WNAF_TOP == 3) ? cube : src;
+  for (int i = 0; i < RB_U_WNAF_STEPS; i++) {
+    const int d = DG[i];
+    rr::wsx_sqrn_mul(ws, dst, cur, SQ[i], (d == 1 || d == -1) ? src : cube, d < 0);
+    cur = dst;
+  }
+  if (RB_U_WNAF_TAIL) rr::wsx_sqrn_mul(ws, dst, cur, RB_U_WNAF_TAIL, -1, false);
+}
+// in: slot FE_T0 = the Miller value; out: slot FE_T1 (pairing.h: final_exponentiation_ws, step by step)
+template <class WS> RB_FN void final_exponentiation_ws(WS ws) {
+  rr::wsx_inv(ws, FE_T1, FE_T0);
+  rr::wsx_mul(ws, FE_T1, FE_T0, true, FE_T1, false);       // f^(p^6-1) = conj(f) * f^-1
+  rr::wsx_frob_mul(ws, FE_F, FE_T1, 2, FE_T1);             // ^(p^2+1)                                   F
+  rr::wsx_exp_u(ws, FE_T0, FE_F, FE_T1);                   // f^u        (a = conj of it)
+  rr::wsx_csqr(ws, FE_B, FE_T0, true);                     // b = a^2                                    B
+  rr::wsx_csqr(ws, FE_T0, FE_B, false);                    // c = b^2
+  rr::wsx_mul(ws, FE_D, FE_T0, false, FE_B, false);        // d = c*b                                    D
+  rr::wsx_exp_u(ws, FE_E, FE_D, FE_T1);                    // d^u        (e = conj of it)
+  rr::wsx_csqr(ws, FE_T0, FE_E, true);                     // f' = e^2
+  rr::wsx_exp_u(ws, FE_T1, FE_T0, FE_K);                   // f'^u = conj(g) = i
+  rr::wsx_mul(ws, FE_T0, FE_T1, false, FE_E, true);        // j = i*e
+  rr::wsx_mul(ws, FE_K, FE_T0, false, FE_D, true);         // k = j*h, h = d^-1                          K
+  rr::wsx_mul(ws, FE_L, FE_K, false, FE_B, false);         // l = k*b                                    L
+  rr::wsx_mul(ws, FE_T0, FE_K, false, FE_E, true);         // m = k*e
+  rr::wsx_mul(ws, FE_T0, FE_T0, false, FE_F, false);       // n = m*f
+  rr::wsx_frob_mul(ws, FE_T1, FE_L, 1, FE_T0);             // p = l^p * n
+  rr::wsx_frob_mul(ws, FE_T0, FE_K, 2, FE_T1);             // r = k^(p^2) * p
+  rr::wsx_mul(ws, FE_T1, FE_F, true, FE_L, false);         // t = f^-1 * l
+  rr::wsx_frob_mul(ws, FE_T1, FE_T1, 3, FE_T0);            // v = t^(p^3) * r
+}
+
 } } }   // namespace rabe::bn254::rr

@@ -1214,6 +1214,9 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
   live.unlock();
   // the six-lane kernel (engine_coop.hip) for launches that leave most of the chip idle: the same values, a chain six times shorter
   if (rhip_use_c6(ctx, n_items, 0)) return rhip_launch_final_exp_c6(ctx, n_items, off, stride, mill, mul_in, out, started);
+  // the reduced-radix kernel (engine_rr.hip) for the launches that fill the chip: the same chain on 9 x 29-bit limbs
+  static const int rr_fe = getenv("RABE_RR_FE") ? atoi(getenv("RABE_RR_FE")) : 1;
+  if (rr_fe && rhip_use_rr(ctx)) return rhip_launch_final_exp_rr(ctx, n_items, off, stride, mill, mul_in, out, started);
   KLAUNCH(ctx, "k_final_exp", k_final_exp, dim3(blocks), dim3(RB_FE_BLOCK), 0, ctx->stream, n_items, off, stride, mill, mul_in, out,
           (uint32_t*)ctx->fe_ws, lanes, started);
   return RHIP_OK;

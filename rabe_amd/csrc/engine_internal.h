@@ -671,6 +671,8 @@ bool rhip_use_rr(const rhip_ctx* ctx);
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
                               const void* work, const uint32_t* chunk_off, size_t lanes);
+int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                 uint32_t* started);
 // prepared line triples (LineM, 8 x 32-bit limbs) converted once into the records k_miller_multi_rr replays; *out is hipMalloc'ed
 int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void** out);
 

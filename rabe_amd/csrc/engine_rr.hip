@@ -255,6 +255,105 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n
   }
 }
 
+// ------------------------------------------------------------------------------------------------ final exponentiation
+// k_final_exp (engine.hip) on the reduced-radix core: out[item] = (mul_in ? mul_in[item] : 1) * FE(prod of the item's Miller values), the chain of
+// pairing29.h: final_exponentiation_ws value by value.  The Fq12 values of the chain live in the context's workspace, FE_SLOTS slots per lane of
+// RR_FE_QUADS quads ([slot][quad][lane]: 24 quads of limbs 0..7, 3 quads of top limbs); the value being multiplied into lives in the LDS home.
+#define RR_FE_QUADS 27
+struct DevHome29 {
+  F6* x;
+  __device__ __forceinline__ F ld_h(int i) const {
+    const uint4* q = rr_home_q + (threadIdx.x >> 6) * (24 * 64) + (threadIdx.x & 63) + (2 * i) * 64;
+    return rr_from_quads(q[0], q[64], rr_home_d[(threadIdx.x >> 6) * (12 * 64) + i * 64 + (threadIdx.x & 63)]);
+  }
+  __device__ __forceinline__ void st_h(int i, const F& a) const {
+    uint4* q = rr_home_q + (threadIdx.x >> 6) * (24 * 64) + (threadIdx.x & 63) + (2 * i) * 64;
+    q[0] = rr_quad(a, 0); q[64] = rr_quad(a, 1);
+    rr_home_d[(threadIdx.x >> 6) * (12 * 64) + i * 64 + (threadIdx.x & 63)] = (uint32_t)a.l[8];
+  }
+  __device__ __forceinline__ F2 ld_h2(int i) const { return rr::mk2(ld_h(2 * i), ld_h(2 * i + 1)); }
+  __device__ __forceinline__ void st_h2(int i, const F2& a) const { st_h(2 * i, a.c0); st_h(2 * i + 1, a.c1); }
+  __device__ __forceinline__ F6 ld_f6(int h) const { return rr::mk6(ld_h2(3 * h), ld_h2(3 * h + 1), ld_h2(3 * h + 2)); }
+  __device__ __forceinline__ void st_f6(int h, const F6& v) const { st_h2(3 * h, v.a0); st_h2(3 * h + 1, v.a1); st_h2(3 * h + 2, v.a2); }
+  __device__ __forceinline__ F6 ld_x() const { return *x; }
+  __device__ __forceinline__ void st_x(const F6& v) const { *x = v; }
+  __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
+};
+struct DevWs29 {
+  uint4* base;         // + lane
+  size_t stride;       // lanes (padded to 64)
+  F6* x;
+  __device__ __forceinline__ F6 ld6(int slot, int h) const {
+    const uint4* p = base + ((size_t)slot * RR_FE_QUADS + 12 * h) * stride;
+    const uint4* tp = base + ((size_t)slot * RR_FE_QUADS + 24) * stride;
+    uint32_t tops[6];
+    if (h == 0) { const uint4 a = tp[0], b = tp[stride]; tops[0] = a.x; tops[1] = a.y; tops[2] = a.z; tops[3] = a.w; tops[4] = b.x; tops[5] = b.y; }
+    else { const uint4 b = tp[stride], c = tp[2 * stride]; tops[0] = b.z; tops[1] = b.w; tops[2] = c.x; tops[3] = c.y; tops[4] = c.z; tops[5] = c.w; }
+    F e[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) e[i] = rr_from_quads(p[(size_t)(2 * i) * stride], p[(size_t)(2 * i + 1) * stride], tops[i]);
+    return rr::mk6(rr::mk2(e[0], e[1]), rr::mk2(e[2], e[3]), rr::mk2(e[4], e[5]));
+  }
+  // the top limbs of a half fill one and a half quads: the shared middle quad is written by whoever stores second, so a half is only ever
+  // stored together with the other one (st) or after it (st6 h = 0 then h = 1 -- wsx_from_home's order)
+  __device__ __forceinline__ void st(int slot, const rr::F12& a) const {
+    uint4* p = base + (size_t)slot * RR_FE_QUADS * stride;
+    const F e[12] = {a.c0.a0.c0, a.c0.a0.c1, a.c0.a1.c0, a.c0.a1.c1, a.c0.a2.c0, a.c0.a2.c1, a.c1.a0.c0, a.c1.a0.c1, a.c1.a1.c0, a.c1.a1.c1, a.c1.a2.c0, a.c1.a2.c1};
+#pragma unroll
+    for (int i = 0; i < 12; i++) { p[(size_t)(2 * i) * stride] = rr_quad(e[i], 0); p[(size_t)(2 * i + 1) * stride] = rr_quad(e[i], 1); }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      p[(size_t)(24 + k) * stride] = make_uint4((uint32_t)e[4 * k].l[8], (uint32_t)e[4 * k + 1].l[8], (uint32_t)e[4 * k + 2].l[8], (uint32_t)e[4 * k + 3].l[8]);
+  }
+  __device__ __forceinline__ rr::F12 ld(int slot) const { return rr::F12{ld6(slot, 0), ld6(slot, 1)}; }
+  __device__ __forceinline__ void st6(int slot, int h, const F6& v) const {
+    uint4* p = base + ((size_t)slot * RR_FE_QUADS + 12 * h) * stride;
+    uint4* tp = base + ((size_t)slot * RR_FE_QUADS + 24) * stride;
+    const F e[6] = {v.a0.c0, v.a0.c1, v.a1.c0, v.a1.c1, v.a2.c0, v.a2.c1};
+#pragma unroll
+    for (int i = 0; i < 6; i++) { p[(size_t)(2 * i) * stride] = rr_quad(e[i], 0); p[(size_t)(2 * i + 1) * stride] = rr_quad(e[i], 1); }
+    if (h == 0) {
+      tp[0] = make_uint4((uint32_t)e[0].l[8], (uint32_t)e[1].l[8], (uint32_t)e[2].l[8], (uint32_t)e[3].l[8]);
+      uint2* mid = (uint2*)(tp + stride);
+      mid[0] = make_uint2((uint32_t)e[4].l[8], (uint32_t)e[5].l[8]);
+    } else {
+      uint2* mid = (uint2*)(tp + stride);
+      mid[1] = make_uint2((uint32_t)e[0].l[8], (uint32_t)e[1].l[8]);
+      tp[2 * stride] = make_uint4((uint32_t)e[2].l[8], (uint32_t)e[3].l[8], (uint32_t)e[4].l[8], (uint32_t)e[5].l[8]);
+    }
+  }
+  __device__ __forceinline__ DevHome29 home() const { return DevHome29{x}; }
+};
+__global__ void __launch_bounds__(256, 1) k_final_exp_rr(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                                       uint4* ws_base, size_t ws_stride, uint32_t* started) {
+  if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const size_t lo = off ? off[i] : i * stride, hi = off ? off[i + 1] : (i + 1) * stride;
+  F6 parked;
+  const DevWs29 ws{ws_base + i, ws_stride, &parked};
+  if (lo == hi) ws.st(FE_T0, rr::from_fp12(fp12_one()));
+  for (size_t j = lo; j < hi; j++) {
+    ws.st(j == lo ? FE_T0 : FE_T1, rr::from_fp12(ld_gt_m(mill + j)));
+    if (j != lo) rr::wsx_mul(ws, FE_T0, FE_T0, false, FE_T1, false);
+  }
+  rr::final_exponentiation_ws(ws);
+  if (mul_in) {
+    ws.st(FE_T0, rr::from_fp12(load_gt(mul_in[i].l)));
+    rr::wsx_mul(ws, FE_T1, FE_T0, false, FE_T1, false);
+  }
+  store_gt(out[i].l, rr::to_fp12(ws.ld(FE_T1)));
+}
+int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                 uint32_t* started) {
+  const size_t lanes = (n_items + 63) / 64 * 64;
+  const int32_t rc = rhip_ensure_fe_ws(ctx, lanes * FE_SLOTS * RR_FE_QUADS * sizeof(uint4));
+  if (rc) return rc;
+  KLAUNCH(ctx, "k_final_exp_rr", k_final_exp_rr, dim3(blocks_for(n_items, 256)), dim3(256), 0, ctx->stream, n_items, off, stride, (const GtM*)mill, mul_in, out,
+          (uint4*)ctx->fe_ws, lanes, started);
+  return RHIP_OK;
+}
+
 // When it runs: pairing mode 29 (rhip_ctx_set_pairing_mode / RABE_PAIRING_MODE) -- every multi-pairing launch; mode 0 (auto) -- the launches
 // the six-lane kernels do not take (the caller asks rhip_use_c6 first), unless RABE_RR=0 (A/B runs, and the conservative switch).
 bool rhip_use_rr(const rhip_ctx* ctx) {

@@ -147,6 +147,7 @@ class Engine {
   int device() const { return device_; }
   void make_current() const { check(rhip_ctx_make_current(lanes_[0]->ctx), "rhip_ctx_make_current"); }
   void ensure_lanes(size_t count);                 // call before handing lanes to threads
+  size_t lane_count();                             // lanes that exist: a LaneScope beyond them falls back to lane 0 (cur_lane)
   size_t lanes() const { return lanes_.size(); }
   static int current_lane() { return tl_lane(); }
   struct LaneScope {

@@ -547,7 +547,11 @@ void run_queue_batch(rabe_host* h, const std::vector<T*>& batch) {
   const size_t SUB = rabe_host::Q_SUB;
   // (only the small batches of lightly loaded queues: under heavy load the lanes already run batches side by side, and more packed
   // calls at once only contend -- 64 x 64 calls in flight: 66 k ops/s with serial groups, 54 k with concurrent ones)
-  if (groups.size() < 2 || h->tape || lane < 0 || (size_t)lane >= (size_t)rabe_host::Q_LANES || batch.size() >= (size_t)h->q_min_extra) {
+  // The sub-lanes must EXIST (rabe_host_set_coalescing creates them): a lane index beyond the engine's lanes falls back to lane 0
+  // (Engine::cur_lane), and two groups on one lane would share its stream, arena, staging and the context's work buffers -- a batch call
+  // on a host without the queue (rabe_*_batch straight from the caller) runs its groups one after the other.
+  if (groups.size() < 2 || h->tape || lane < 0 || (size_t)lane >= (size_t)rabe_host::Q_LANES || batch.size() >= (size_t)h->q_min_extra ||
+      h->eng.lane_count() < (size_t)rabe_host::Q_LANES * SUB) {
     for (auto& g : groups) run_one(g);
     return;
   }

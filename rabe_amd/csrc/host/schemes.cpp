@@ -106,6 +106,10 @@ void Engine::ensure_lanes(size_t count) {
     lanes_.push_back(std::move(l));
   }
 }
+size_t Engine::lane_count() {
+  std::lock_guard<std::recursive_mutex> g(mu_);
+  return lanes_.size();
+}
 rhip_ac17_pk* Engine::ac17_pk(const G1& g, const std::vector<G2>& h_a, const std::vector<Gt>& e_gh_ka) {
   if (h_a.size() != 3 || e_gh_ka.size() != 2) throw RabeError("malformed Ac17PublicKey: h_a must have 3 and e_gh_ka 2 elements");
   auto fha = flatten(h_a), fe = flatten(e_gh_ka);

@@ -571,3 +571,40 @@ void hs_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32_t*
   delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
 }
 }
+
+struct HostHome29 {
+  rr::F6* F;
+  rr::F6 ld_f6(int h) const { return F[h]; }
+  void st_f6(int h, const rr::F6& v) const { F[h] = v; }
+  rr::F6 ld_x() const { return F[2]; }
+  void st_x(const rr::F6& v) const { F[2] = v; }
+  void fence() const {}
+};
+struct HostWs29 {
+  rr::F12* slots;
+  rr::F6* F;
+  rr::F12 ld(int i) const { return slots[i]; }
+  void st(int i, const rr::F12& v) const { slots[i] = v; }
+  rr::F6 ld6(int i, int h) const { return h ? slots[i].c1 : slots[i].c0; }
+  void st6(int i, int h, const rr::F6& v) const { (h ? slots[i].c1 : slots[i].c0) = v; }
+  HostHome29 home() const { return HostHome29{F}; }
+};
+extern "C" {
+void hs_rr_final_exp(const uint32_t* f, uint32_t* out) {
+  rr::F12 slots[FE_SLOTS];
+  slots[FE_T0] = rr::from_fp12(load_gt(f));
+  rr::F6 F[3];
+  rr::final_exponentiation_ws(HostWs29{slots, F});
+  store_gt(out, rr::to_fp12(slots[FE_T1]));
+}
+void hs_rr_fp12_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  rr::F12 slots[2];
+  slots[0] = rr::from_fp12(load_gt(a));
+  slots[1] = rr::from_fp12(load_gt(b));
+  rr::F6 F[3];
+  rr::wsx_mul(HostWs29{slots, F}, 0, 0, false, 1, true);
+  store_gt(out, rr::to_fp12(slots[0]));
+}
+void hs_rr_cyclotomic_sqr(const uint32_t* a, uint32_t* out) { store_gt(out, rr::to_fp12(rr::cyclotomic_sqr(rr::from_fp12(load_gt(a))))); }
+void hs_rr_fp12_frob(const uint32_t* a, int k, uint32_t* out) { store_gt(out, rr::to_fp12(rr::frob(rr::from_fp12(load_gt(a)), k))); }
+}

@@ -94,3 +94,34 @@ def test_miller_loop_multi_same_value_and_same_running_points(n, kinds):
         HS.hs_miller_multi(n, kk, b2c(p2), b2c(q), o1, None)
         HS.hs_rr_miller_multi(n, kk, b2c(p2), b2c(q), o2, None)
         assert bytes(o1) == bytes(o2)
+
+
+def _rand_fp12():
+    return bn.fp12_from_coeffs([RND.randrange(bn.P) for _ in range(12)])
+
+
+def test_fp12_operations_of_the_final_exponentiation():
+    o1, o2 = buf(384), buf(384)
+    for _ in range(4):
+        a, b = _rand_fp12(), _rand_fp12()
+        HS.hs_rr_fp12_mul(b2c(bn.gt_to_le(a)), b2c(bn.gt_to_le(b)), o1)          # a * conj(b)
+        assert bytes(o1) == bn.gt_to_le(bn.fp12_mul(a, bn.fp12_conj(b)))
+        for k in (1, 2, 3):
+            HS.hs_rr_fp12_frob(b2c(bn.gt_to_le(a)), k, o1)
+            HS.hs_fp12_frob(b2c(bn.gt_to_le(a)), k, o2)
+            assert bytes(o1) == bytes(o2)
+    e = bn.pairing(bn.G1_GEN, bn.G2_GEN)
+    for k in (1, 2, RND.randrange(bn.R)):
+        g = bn.gt_pow(e, k)
+        HS.hs_rr_cyclotomic_sqr(b2c(bn.gt_to_le(g)), o1)
+        assert bytes(o1) == bn.gt_to_le(bn.fp12_mul(g, g))
+
+
+def test_final_exponentiation_same_bytes():
+    """pairing29.h: final_exponentiation_ws against pairing.h's on Miller values and on arbitrary Fq12 elements"""
+    o1, o2 = buf(384), buf(384)
+    for _ in range(3):
+        f = _rand_fp12()
+        HS.hs_final_exp_ws(b2c(bn.gt_to_le(f)), o1)
+        HS.hs_rr_final_exp(b2c(bn.gt_to_le(f)), o2)
+        assert bytes(o1) == bytes(o2)
