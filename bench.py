@@ -57,6 +57,11 @@ IMPL_MILLER2_FPMUL = 11910          # tests/count_muls.py: miller_loop_pair_park
 IMPL_FINAL_EXP_FPMUL = 7553         # tests/count_muls.py: final_exponentiation_ws (width-3 NAF exponent chain)
 IMPL_MILLER_MULTI6_FPMUL = 29931    # tests/count_muls.py: miller_loop_multi, an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
 IMPL_MILLER_MULTI6_WALK_FPMUL = 37194   # the same with nothing prepared
+# the reduced-radix kernels (engine_rr.hip, 9 x 29-bit limbs): multiply-add INSTRUCTIONS per lane, tests/count_muls.py (81 per schoolbook
+# product, 81 per reduction; the line products are taken as dot products: more products, far fewer reductions and no carry instructions)
+IMPL_RR_MILLER_MULTI6_MADS = 5523147     # an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
+IMPL_RR_MILLER_MULTI6_WALK_MADS = 6728670
+IMPL_RR_FINAL_EXP_MADS = 1199772 + 600 * 136   # + the one inversion, which runs on the 8 x 32-bit core (~600 Fp multiplications)
 
 
 def parse_args():
@@ -606,8 +611,12 @@ def main():
         impl = {"k_ac17_dec_miller": IMPL_MILLER_FPMUL + m_avg * 11, "k_ac17_dec_miller2": IMPL_MILLER2_FPMUL + 2 * m_avg * 11, "k_final_exp": IMPL_FINAL_EXP_FPMUL + 6 * 54,
                 "k_miller_multi": IMPL_MILLER_MULTI6_FPMUL if sk_lines is not None else IMPL_MILLER_MULTI6_WALK_FPMUL,
                 "k_ac17_dec_miller_c3": IMPL_MILLER_FPMUL + m_avg * 11, "k_final_exp_c3": IMPL_FINAL_EXP_FPMUL + 6 * 54}
-        for d_ in (lanes, alg, impl):          # the reduced-radix kernel computes the same unit of work (engine_rr.hip)
-            d_["k_miller_multi_rr"] = d_["k_miller_multi"]
+        # the reduced-radix kernels compute the same units of work (engine_rr.hip); what they EXECUTE is counted in multiply-add instructions
+        lanes["k_miller_multi_rr"], lanes["k_final_exp_rr"] = lanes["k_miller_multi"], lanes["k_final_exp"]
+        alg["k_miller_multi_rr"], alg["k_final_exp_rr"] = alg["k_miller_multi"], alg["k_final_exp"]
+        impl["k_miller_multi_rr"] = (IMPL_RR_MILLER_MULTI6_MADS if sk_lines is not None else IMPL_RR_MILLER_MULTI6_WALK_MADS) / MAC_PER_FPMUL
+        impl["k_final_exp_rr"] = (IMPL_RR_FINAL_EXP_MADS + 6 * 54 * 162) / MAC_PER_FPMUL
+        equiv_8x32 = {"k_miller_multi_rr": impl["k_miller_multi"], "k_final_exp_rr": impl["k_final_exp"]}.get(dom)
         macs = lanes.get(dom, 0) * alg.get(dom, 0) * MAC_PER_FPMUL
         achieved = macs / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         macs_impl = lanes.get(dom, 0) * impl.get(dom, alg.get(dom, 0)) * MAC_PER_FPMUL
@@ -623,8 +632,12 @@ def main():
             "kernel_ms_per_step": round(dom_ms / G, 4),
             "achieved": round(achieved_impl, 4), "peak": round(peak_tmac, 3), "unit": "TMAC32/s",
             "frac": round(achieved_impl / peak_tmac, 4) if peak_tmac else None,
-            "work": "Fp multiplications this engine executes per lane (instrumented: tests/count_muls.py) x 136 MAC32 x lanes = %.3e MAC32 per launch"
+            "work": ("multiply-add instructions this kernel issues per lane (instrumented: tests/count_muls.py; 9 x 29-bit limbs: 81 per product, 81 per "
+                     "reduction) x lanes = %.3e per launch" if dom.endswith("_rr") else
+                     "Fp multiplications this engine executes per lane (instrumented: tests/count_muls.py) x 136 MAC32 x lanes = %.3e MAC32 per launch")
                     % macs_impl,
+            "frac_8x32_work": (round(lanes.get(dom, 0) * equiv_8x32 * MAC_PER_FPMUL / (dom_ms * 1e-3) / 1e12 / peak_tmac, 4) if (equiv_8x32 and peak_tmac and dom_ms > 0) else None),
+            "frac_8x32_work_note": "the 8 x 32-bit kernel's instrumented work (Fp multiplications x 136) over THIS kernel's time: comparable with earlier rounds' `frac`",
             "achieved_survey": round(achieved, 4),
             "frac_survey": round(achieved / peak_tmac, 4) if peak_tmac else None,
             "work_survey": "SURVEY.md 8d's algorithmic constants (8 k Fp-mul per Miller loop) x 136 MAC32 x lanes = %.3e MAC32 per launch; the engine "

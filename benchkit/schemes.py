@@ -123,10 +123,21 @@ class SchemeRunner:
             ms_c, ops_c = min((eng.calibrate(0, 20000) for _ in range(2)), key=lambda r_: r_[0])          # best of two: the first may see clocks ramping
             peak = ops_c / (ms_c * 1e-3) / 1e12
             alg = b.algorithmic_fpmul_per_item()          # {kernel: SURVEY 8d Fp-mul per item carried by that kernel}
+            impl_all = b.impl_fpmul_per_item()
+            # the reduced-radix kernels (engine_rr.hip) carry the same units of work; what they execute is counted in multiply-add instructions
+            # (tests/count_muls.py: 1.085 M per walking pair of a 14-pair chunk, 0.884 M per pair when half of them replay prepared lines),
+            # expressed here in units of 136 like the Fp multiplications of the 8 x 32-bit kernels
+            if "k_miller_multi" in alg:
+                alg["k_miller_multi_rr"] = alg["k_miller_multi"]
+                if "k_miller_multi" in impl_all:
+                    pairs = impl_all["k_miller_multi"] / (4766.0 if getattr(b, "sk_lines", None) else 5976.0)
+                    impl_all["k_miller_multi_rr"] = pairs * ((884237.0 if getattr(b, "sk_lines", None) else 1085157.0) / 136.0)
+            if "k_final_exp" in alg:
+                alg["k_final_exp_rr"] = alg["k_final_exp"]
             macs = alg.get(dom, 0) * MAC_PER_FPMUL * G * B
             achieved = macs / (per_kernel[dom] * 1e-3) / 1e12 if per_kernel[dom] > 0 else 0.0
             traffic, tsrc = pmc_traffic(dom, args.config)
-            impl = b.impl_fpmul_per_item().get(dom)
+            impl = impl_all.get(dom)
             achieved_impl = (impl or alg.get(dom, 0)) * MAC_PER_FPMUL * G * B / (per_kernel[dom] * 1e-3) / 1e12 if per_kernel[dom] > 0 else 0.0
             result["roofline"] = {
                 "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom, "kernel_ms": round(per_kernel[dom], 4),

@@ -30,6 +30,10 @@
 #include <stdlib.h>
 #endif
 
+#if defined(RB_COUNT_MULS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" unsigned long long rb_rr_mad_counter;
+#endif
+
 namespace rabe { namespace bn254 { namespace rr {
 
 #define RB29_MASK 0x1fffffff
@@ -189,20 +193,22 @@ RB_HD i32x9 redc(int64_t* t) {
   r[8] = (int32_t)t[17];
   return r;
 }
+// host-only instrumentation (tests/hostsim builds with -DRB_COUNT_MULS): multiply-add instructions this core issues -- 81 per schoolbook
+// product and 81 per reduction -- for the roofline's work count of the reduced-radix kernels (tests/count_muls.py)
 #if defined(RB_COUNT_MULS) && !defined(__HIP_DEVICE_COMPILE__)
-#define RR_COUNT(n) (::rb_mul_counter += (n))
+#define RR_COUNT(n) (::rb_rr_mad_counter += 81ull * (n))
 #else
 #define RR_COUNT(n) ((void)0)
 #endif
 RB_HD i32x9 mul_raw(const i32x9& a, const i32x9& b) {
-  RR_COUNT(1);
+  RR_COUNT(2);
   int64_t t[18];
   cols_init(t);
   cols_mac(t, a, b);
   return redc(t);
 }
 RB_HD i32x9 mac2_raw(const i32x9& a, const i32x9& b, const i32x9& c, const i32x9& d) {          // (a b + c d) / R
-  RR_COUNT(2);
+  RR_COUNT(3);
   int64_t t[18];
   cols_init(t);
   cols_mac(t, a, b);
@@ -308,7 +314,7 @@ RB_HD F mac2(const FB<L1, V1>& a, const FB<L2, V2>& b, const FB<L3, V3>& c, cons
 // sparse line products of the Miller loop are taken (pairing29.h): no Karatsuba sums, nothing to normalise afterwards
 RB_HD void dot3_raw(i32x9& c0, i32x9& c1, const i32x9& x0a, const i32x9& x0b, const i32x9& y0a, const i32x9& y0b, const i32x9& x1a, const i32x9& x1b,
                     const i32x9& y1a, const i32x9& y1b, const i32x9& x2a, const i32x9& x2b, const i32x9& y2a, const i32x9& y2b) {
-  RR_COUNT(12);
+  RR_COUNT(14);
   {
     int64_t t[18];
     cols_init(t);

@@ -102,3 +102,37 @@ HS.hs_mul_counter_reset()
 HS.hs_g1_msm(n, b2c(pts), b2c(ks), o)
 jobs["jac_msm_naf G1, 16 terms (254-bit) + to_affine incl. io"] = HS.hs_mul_counter_reset()
 print(json.dumps(jobs, indent=1))
+
+# ---- the reduced-radix kernels (engine_rr.hip): multiply-add INSTRUCTIONS per lane (81 per schoolbook product of two 9-limb elements,
+# 81 per reduction) -- what k_miller_multi_rr / k_final_exp_rr issue; the harness's conversion of prepared lines (done once per key
+# handle on the device: rhip_lines_to_rr) is subtracted
+HS.hs_rr_mad_counter_reset.restype = ctypes.c_ulonglong
+
+
+def rr_mads_multi(kinds):
+    n = len(kinds)
+    ps = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, rnd.randrange(1, bn.R))) for _ in range(n))
+    qs = b"".join(bn.g2_to_le(bn.g2_mul(bn.G2_GEN, rnd.randrange(1, bn.R))) for _ in range(n))
+    o = (ctypes.c_uint32 * 96)()
+    HS.hs_rr_mad_counter_reset()
+    HS.hs_rr_miller_multi(n, (ctypes.c_int * n)(*kinds), b2c(ps), b2c(qs), o, None)
+    total = HS.hs_rr_mad_counter_reset()
+    lines_conv = sum(1 for k in kinds if k == 1) * 88 * 6 * 162          # from_fp = one product + one reduction
+    # the host accessor converts P (and Q) at every fetch; the device converts them once (begin) -- count one conversion per argument
+    fetches_p = 88 * n * 2 * 162
+    fetches_q = sum(1 for k in kinds if k == 0) * (23 + 1) * 4 * 162        # 21 additions + 2 Frobenius steps + begin
+    once = n * 2 * 162 + sum(1 for k in kinds if k == 0) * 4 * 162
+    return total - lines_conv - fetches_p - fetches_q + once
+
+
+rrj = {}
+rrj["rr miller_loop_multi, 6 pairs: 3 prepared + 3 walking (an ac17 item with a prepared key): mad instructions"] = rr_mads_multi([1, 0] * 3)
+rrj["rr miller_loop_multi, 6 walking pairs: mad instructions"] = rr_mads_multi([0] * 6)
+rrj["rr miller_loop_multi, 14 walking pairs: mad instructions"] = rr_mads_multi([0] * 14)
+rrj["rr miller_loop_multi, 14 pairs: 7 prepared + 7 walking: mad instructions"] = rr_mads_multi([1, 0] * 7)
+rrj["rr miller_loop_multi, 1 walking pair: mad instructions"] = rr_mads_multi([0])
+HS.hs_rr_mad_counter_reset()
+_o = (ctypes.c_uint32 * 96)()
+HS.hs_rr_final_exp(b2c(bytes(m)), _o)
+rrj["rr final_exponentiation over workspace slots incl. 12 + 12 conversions: mad instructions (the one inversion runs on the 8 x 32-bit core: + its Fp multiplications x 136)"] = HS.hs_rr_mad_counter_reset()
+print(json.dumps(rrj, indent=1))

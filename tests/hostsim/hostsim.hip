@@ -12,10 +12,11 @@
 
 using namespace rabe::bn254;
 
-extern "C" { unsigned long long rb_mul_counter = 0; }
+extern "C" { unsigned long long rb_mul_counter = 0; unsigned long long rb_rr_mad_counter = 0; }
 
 extern "C" {
 
+unsigned long long hs_rr_mad_counter_reset() { unsigned long long v = ::rb_rr_mad_counter; ::rb_rr_mad_counter = 0; return v; }
 unsigned long long hs_mul_counter_reset() { unsigned long long v = ::rb_mul_counter; ::rb_mul_counter = 0; return v; }
 
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { store_fp(out, mul(load_fp(a), load_fp(b))); }
