@@ -317,7 +317,12 @@ static void choose_chunks(const rhip_ctx* ctx, size_t n_items, size_t max_pairs,
     const size_t rounds = (waves + simds - 1) / simds;
     // an odd chunk leaves one line unmerged (13 instead of 11.5 Fq2 products for it): small launches still prefer it -- a lone batch
     // of 4096 six-pair items runs as 384 waves of one pair each instead of 192 of two
-    const double cost = (double)rounds * (2340.0 + 5500.0 * (double)c_eff + ((c_eff & 1) ? 600.0 : 0.0));
+    static const double sq_env = getenv("RABE_CHUNK_SQ") ? atof(getenv("RABE_CHUNK_SQ")) : 0.0;          // tuning runs
+    // the reduced-radix kernel (engine_rr.hip) does not merge lines two by two (no penalty for an odd chunk) and its shared squaring weighs
+    // more against a pair (11 k against 15 k instructions per line event; 2.3 k against 5.5 k Fp multiplications in the 8 x 32-bit kernel)
+    const bool rr = rhip_use_rr(ctx);
+    const double sq = sq_env > 0 ? sq_env : (rr ? 4000.0 : 2340.0);
+    const double cost = (double)rounds * (sq + 5500.0 * (double)c_eff + ((!rr && (c_eff & 1)) ? 600.0 : 0.0));
     if (best == 0 || cost < best) { best = cost; best_c = c; }
     if (l == 1) break;
   }
