@@ -18,7 +18,8 @@
 // its result is below  p + (Va Vb + Vc Vd) 2.25 p^2 / 2^261 <= 1.5 p  for  Va Vb + Vc Vd <= 36.
 // Deeper sums are brought back by norm(): one parallel carry pass (limbs), plus -- when the value bound needs it -- the
 // subtraction of round(x / p) p, estimated from the top limb.
-// RB29_CHECK (host builds of the tests) asserts every bound at run time as well, on the values that actually occur.
+// RB29_CHECK (host builds of the tests) asserts every bound at run time as well, on the values that actually occur
+// (tests/test_hostsim_rr.py); tests/test_fp29_bounds.py restates the column, value and quotient-estimate bounds with exact integers.
 //
 // Replaces, for the kernels that use it, the same `rabe_bn::Fq` arithmetic as fp.h (src/schemes/ac17/mod.rs:42).
 #pragma once
