@@ -161,10 +161,8 @@ template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& 
 // G2Aff29 q(int j), Line29 line(int j, int n), G2Hom29 ld_t(int j), void st_t(int j, const G2Hom29&), void begin()  (called once before
 // the loop: converts the lane's arguments)
 template <class ACC>
-RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, Line29& l) {
-  const int kind = acc.kind(j);
-  if (kind == MP_SKIP) return false;
-  if (kind == MP_LINES) { l = acc.line(j, ln); return true; }
+RB_HD void miller_multi_line(ACC acc, int j, int kind, int mode, int ln, Line29& l) {          // kind: MP_WALK or MP_LINES
+  if (kind == MP_LINES) { l = acc.line(j, ln); return; }
   G2Hom29 t = acc.ld_t(j);
   if (mode == MS_DBL) {
     l = g2hom_double(t);
@@ -176,7 +174,6 @@ RB_HD bool miller_multi_line(ACC acc, int j, int mode, int ln, Line29& l) {
     l = g2hom_add(t, q);
   }
   acc.st_t(j, t);
-  return true;
 }
 template <class ACC>
 RB_MID void miller_loop_multi(ACC acc) {
@@ -204,8 +201,14 @@ RB_MID void miller_loop_multi(ACC acc) {
       i--;
     }
     for (int j = 0; j < n; j++) {          // lines are not merged two by two here: a dot-product line costs the same merged or not
+      const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
+      if (kind == MP_SKIP) continue;
+      // the G1 argument is fetched FIRST: the lone wave of a SIMD pays every memory round trip in full (~3 k cycles on the device), and this
+      // one then runs beside the running point's / the prepared line's
+      const MillerP29 p = acc.p(j);
       Line29 l;
-      if (miller_multi_line(acc, j, mode, ln, l)) facc_ell(acc, l, acc.p(j));
+      miller_multi_line(acc, j, kind, mode, ln, l);
+      facc_ell(acc, l, p);
     }
   }
 }

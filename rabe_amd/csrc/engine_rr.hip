@@ -84,9 +84,14 @@ struct DevMultiAcc29 {
   uint4* ws;                 // + lane
   F6* x;                     // the parked Fq6 (a local of the kernel)
   __device__ __forceinline__ int count() const { return cnt; }
+  // the kinds of the lane's pairs, read once (kernel prologue): a global-memory round trip per pair and line event otherwise
+  uint64_t walk_m, skip_m;
   __device__ __forceinline__ int kind(int j) const {
-    const uint32_t v = qref[j];
-    return v == RHIP_Q_WALK ? MP_WALK : v == RHIP_Q_SKIP ? MP_SKIP : MP_LINES;
+    if (cnt > 64) {
+      const uint32_t v = qref[j];
+      return v == RHIP_Q_WALK ? MP_WALK : v == RHIP_Q_SKIP ? MP_SKIP : MP_LINES;
+    }
+    return ((walk_m >> j) & 1ull) ? MP_WALK : ((skip_m >> j) & 1ull) ? MP_SKIP : MP_LINES;
   }
   // home
   __device__ __forceinline__ F ld_h(int i) const {
@@ -231,7 +236,13 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n
     cnt = (int)(base + (cc < rem ? 1u : 0u));
   }
   F6 parked;
-  const DevMultiAcc29 acc{P + first, Q + first, qref + first, lines29, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked};
+  uint64_t walk_m = 0, skip_m = 0;
+  for (int j = 0; j < cnt && j < 64; j++) {
+    const uint32_t v = qref[first + j];
+    if (v == RHIP_Q_WALK) walk_m |= 1ull << j;
+    else if (v == RHIP_Q_SKIP) skip_m |= 1ull << j;
+  }
+  const DevMultiAcc29 acc{P + first, Q + first, qref + first, lines29, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked, walk_m, skip_m};
   rr::miller_loop_multi(acc);
   // the value, back in the canonical Montgomery form of the 8 x 32-bit core
   {
