@@ -160,57 +160,62 @@ template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& 
 // ACC provides, beside the FA interface:  int count(), int kind(int j) (MP_WALK / MP_LINES / MP_SKIP), MillerP29 p(int j),
 // G2Aff29 q(int j), Line29 line(int j, int n), G2Hom29 ld_t(int j), void st_t(int j, const G2Hom29&), void begin()  (called once before
 // the loop: converts the lane's arguments)
+// One pair's share of a loop step: its line of the FIRST event (the doubling, or the first Frobenius addition) and, when the step has
+// one, of the SECOND (the addition of a non-zero digit, the second Frobenius addition) -- with the running point fetched and stored
+// ONCE for both and every argument requested in one batch: the lone wave of a SIMD pays each memory round trip in full (~3 k cycles on
+// the device, and a call boundary waits for all of them), so a step makes one instead of two or three per pair.  The lines multiply into
+// the accumulator pair by pair instead of event by event -- the same product.  (Written out per case rather than as a loop over the
+// step's events: the loop form keeps the running point live across a line product and spills it -- measured 268 against 259 ms on
+// config 3's launch set.)
 template <class ACC>
-RB_HD void miller_multi_line(ACC acc, int j, int kind, int mode, int ln, Line29& l) {          // kind: MP_WALK or MP_LINES
-  if (kind == MP_LINES) { l = acc.line(j, ln); return; }
+RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
+  const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
+  if (kind == MP_SKIP) return;
+  const MillerP29 p = acc.p(j);
+  if (kind == MP_LINES) {
+    const Line29 l1 = acc.line(j, ln);
+    if (second >= 0) {
+      const Line29 l2 = acc.line(j, ln + 1);
+      facc_ell(acc, l1, p);
+      facc_ell(acc, l2, p);
+    } else {
+      facc_ell(acc, l1, p);
+    }
+    return;
+  }
   G2Hom29 t = acc.ld_t(j);
-  if (mode == MS_DBL) {
-    l = g2hom_double(t);
-  } else {
-    G2Aff29 q = acc.q(j);
-    if (mode == MS_ADD_NEG) q.y = neg2(q.y);
-    else if (mode == MS_FROB1) q = g2_frob1(q);
-    else if (mode == MS_FROB2) q = g2_frob2_neg(q);
-    l = g2hom_add(t, q);
+  G2Aff29 q;
+  if (second >= 0 || first != MS_DBL) q = acc.q(j);
+  Line29 l1, l2;
+  if (first == MS_DBL) l1 = g2hom_double(t);
+  else l1 = g2hom_add(t, g2_frob1(q));
+  if (second >= 0) {
+    G2Aff29 q2 = q;
+    if (second == MS_ADD_NEG) q2.y = neg2(q.y);
+    else if (second == MS_FROB2) q2 = g2_frob2_neg(q);
+    l2 = g2hom_add(t, q2);
   }
   acc.st_t(j, t);
+  facc_ell(acc, l1, p);
+  if (second >= 0) facc_ell(acc, l2, p);
 }
+// The loop: 65 doubling steps (21 of them with an addition), then the two Frobenius additions -- the line events of pairing.h's
+// miller_loop_multi in the same order per pair, prepared lines numbered the same way.
 template <class ACC>
 RB_MID void miller_loop_multi(ACC acc) {
   const int n = acc.count();
   facc_set_one(acc);
   acc.begin();
-  int i = RB_ATE_NAF_LEN - 2;
-  bool add_pending = false;
-  for (int ln = 0; ln < RB_MILLER_LINES; ln++) {
-    int mode;
-    if (i >= 0) {
-      const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
-      const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
-      if (!add_pending) {
-        facc_sqr(acc);
-        mode = MS_DBL;
-        if (pos | ngt) add_pending = true; else i--;
-      } else {
-        mode = pos ? MS_ADD_POS : MS_ADD_NEG;
-        add_pending = false;
-        i--;
-      }
-    } else {
-      mode = (i == -1) ? MS_FROB1 : MS_FROB2;
-      i--;
-    }
-    for (int j = 0; j < n; j++) {          // lines are not merged two by two here: a dot-product line costs the same merged or not
-      const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
-      if (kind == MP_SKIP) continue;
-      // the G1 argument is fetched FIRST: the lone wave of a SIMD pays every memory round trip in full (~3 k cycles on the device), and this
-      // one then runs beside the running point's / the prepared line's
-      const MillerP29 p = acc.p(j);
-      Line29 l;
-      miller_multi_line(acc, j, kind, mode, ln, l);
-      facc_ell(acc, l, p);
-    }
+  int ln = 0;
+  for (int i = RB_ATE_NAF_LEN - 2; i >= 0; i--) {
+    const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
+    const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
+    const int second = pos ? MS_ADD_POS : ngt ? MS_ADD_NEG : -1;
+    facc_sqr(acc);
+    for (int j = 0; j < n; j++) miller_pair_step(acc, j, MS_DBL, second, ln);
+    ln += (second >= 0) ? 2 : 1;
   }
+  for (int j = 0; j < n; j++) miller_pair_step(acc, j, MS_FROB1, MS_FROB2, ln);
 }
 
 // ============================================================================ final exponentiation (pairing.h: final_exponentiation_ws)
