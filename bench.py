@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument("--no-tail-overlap", action="store_true",
                     help="run a remainder group (--steps not a multiple of --group) after the full groups on the same stream instead of first, "
                          "with the next group's encrypt kernels beside its final exponentiation")
+    ap.add_argument("--tail-mode", choices=["pairing", "final-exp"], default="pairing",
+                    help="what of a remainder group runs beside the next full group's encrypt kernels: 'pairing' = its Miller loops and its final "
+                         "exponentiation (rhip_ctx_release_when_miller_resident); 'final-exp' = only its final exponentiation "
+                         "(rhip_ctx_release_before_final_exp, round 3's form)")
     ap.add_argument("--no-single-batch", action="store_true", help="skip the informational single-batch legs (--group 1 submissions)")
     ap.add_argument("--no-configs-leg", action="store_true", help="skip the bounded runs of BASELINE configs 3-5 (N = 1 only)")
     ap.add_argument("--configs-min-time", type=float, default=0.3, help="timed seconds per config of the configs leg")
@@ -368,9 +372,12 @@ def main():
             e2, b2, _ = tail
             e2.wait_for(eng)                                   # the previous region's work on the main stream is done
             submit(sizes[-1], on=(e2, b2), part=1)
-            e2.release_before_final_exp(eng)                   # the main stream resumes when the tail's Miller loops are done
+            if args.tail_mode == "pairing":
+                e2.release_when_miller_resident(eng)           # the main stream resumes when the tail's Miller blocks own their CUs
+            else:
+                e2.release_before_final_exp(eng)               # the main stream resumes when the tail's Miller loops are done
             submit(sizes[-1], on=(e2, b2), part=2)
-            submit(sizes[0], lane=0, part=1)                   # beside the tail's final exponentiation
+            submit(sizes[0], lane=0, part=1)                   # beside the tail's pairings / final exponentiation
             eng.wait_for(e2)
             submit(sizes[0], lane=0, part=2)
             for g_ in sizes[1:-1]:
@@ -443,8 +450,10 @@ def main():
                    "batch_per_gpu": B, "attrs": args.attrs, "policies": args.policies, "rows": rows_per_batch // B,
                    "pruned_leaves_avg": round(sel_per_batch / B, 2), "msp_nnz_avg": round(sum(nnz) / len(nnz), 1),
                    "steps_per_launch_set": sizes, "launch_sets_in_flight": S, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"),
-                   "remainder_group": ("first, on its own stream; the next group's encrypt kernels run beside its final exponentiation"
-                                       if tail is not None else None),
+                   "remainder_group": (None if tail is None else
+                                       "first, on its own stream; the next group's encrypt kernels run beside its final exponentiation" if args.tail_mode != "pairing" else
+                                       "first, on its own stream; the next group's encrypt kernels run beside its Miller loops (on the CUs those leave) and "
+                                       "its final exponentiation"),
                    "pairing_mode": args.pairing_mode,
                    "value_definition": "n_gpus x batch_per_gpu x steps / (max over ranks of the barrier-to-barrier time of the K steps): every rank runs the same "
                                        "per-GPU batch whatever n_gpus is (weak scaling), so value / n_gpus is directly comparable across rank counts",

@@ -105,6 +105,11 @@ int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* waiter);
 /* The same hold, released as soon as ctx's Miller loops are DONE (no wait for the final exponentiation's blocks to be resident): for a
  * waiter with little work of its own -- the Gt membership checks of a packed decrypt run beside the final exponentiation this way. */
 int32_t rhip_ctx_release_after_miller(rhip_ctx* ctx, rhip_ctx* waiter);
+/* The hold for a SMALL launch set on ctx beside the waiter's large one: the waiter's stream goes on as soon as the blocks of ctx's next Miller
+ * launch are RESIDENT -- they own their CUs, the waiter's encrypt kernels take the CUs that are left -- instead of when that launch is done.
+ * Served by the reduced-radix Miller kernel on uniform pair lists (pairing mode 0 / 29); any other launch behaves as under
+ * rhip_ctx_release_before_final_exp.  One-shot; same bytes either way. */
+int32_t rhip_ctx_release_when_miller_resident(rhip_ctx* ctx, rhip_ctx* waiter);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------
  * rabe_bn surface replaced ("rabe_bn API surface actually used"):

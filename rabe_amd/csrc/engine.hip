@@ -289,6 +289,7 @@ extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* wa
   if (waiter && !g_live.count(waiter)) return RHIP_ERR_ARG;
   ctx->fe_waiter = waiter;          // NULL withdraws a pending request; rhip_ctx_destroy(waiter) withdraws it too
   ctx->fe_waiter_poll = true;
+  ctx->early_release = false;
   return RHIP_OK;
 }
 // The same hold without the wait for resident final-exponentiation blocks: the waiter goes on as soon as the Miller loops are done.  For a
@@ -298,6 +299,15 @@ extern "C" int32_t rhip_ctx_release_before_final_exp(rhip_ctx* ctx, rhip_ctx* wa
 extern "C" int32_t rhip_ctx_release_after_miller(rhip_ctx* ctx, rhip_ctx* waiter) {
   const int32_t rc = rhip_ctx_release_before_final_exp(ctx, waiter);
   if (rc == RHIP_OK) ctx->fe_waiter_poll = false;
+  return rc;
+}
+// The hold for a SMALL launch set on ctx beside the waiter's large one: the waiter's stream goes on as soon as the blocks of ctx's next Miller
+// launch are resident (they own their CUs; the waiter's occupancy-flexible kernels take the CUs that are left), instead of when that launch is
+// done.  Served by the reduced-radix Miller kernel (k_miller_multi_rr, uniform pair lists); any other launch behaves as under
+// rhip_ctx_release_before_final_exp.
+extern "C" int32_t rhip_ctx_release_when_miller_resident(rhip_ctx* ctx, rhip_ctx* waiter) {
+  const int32_t rc = rhip_ctx_release_before_final_exp(ctx, waiter);
+  if (rc == RHIP_OK) ctx->early_release = waiter != nullptr;
   return rc;
 }
 // a point of a context's stream a HOST thread can wait for (the host layer's helper threads wait for one part's copy, not for the stream)
@@ -1185,6 +1195,33 @@ __global__ void __launch_bounds__(64) k_wait_resident(const uint32_t* started, u
     __builtin_amdgcn_s_sleep(64);
   }
 }
+// A pending rhip_ctx_release_before_final_exp request is consumed here: the waiter's stream continues behind everything ctx's stream holds so far
+// and -- in the polling form -- once `blocks` blocks (at most one per CU) of the kernel launched next have announced themselves through *started.
+int32_t rhip_take_waiter(rhip_ctx* ctx, size_t blocks, uint32_t** started_out) {
+  *started_out = nullptr;
+  ctx->early_release = false;
+  std::unique_lock<std::mutex> live(g_live_mu);          // the waiter cannot be destroyed while its stream is being touched
+  rhip_ctx* w = ctx->fe_waiter;
+  ctx->fe_waiter = nullptr;
+  if (w && !g_live.count(w)) w = nullptr;
+  if (!w) return RHIP_OK;
+  if (!ctx->fe_started) HIP_TRY(ctx, hipMalloc((void**)&ctx->fe_started, 256));
+  uint32_t* started = (uint32_t*)ctx->fe_started;
+  HIP_TRY(ctx, hipMemsetAsync(started, 0, 4, ctx->stream));
+  hipEvent_t ev;
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ctx->stream);                  // everything before the launch is done
+  if (e == hipSuccess) e = hipStreamWaitEvent(w->stream, ev, 0);
+  (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(ctx, e, "rhip_ctx_release_before_final_exp");
+  // ... and the launch's waves are resident (at most as many as there are SIMDs); ~2 ms of polling at most
+  const uint32_t target = (uint32_t)(blocks < (size_t)ctx->n_cu ? blocks : (size_t)ctx->n_cu);
+  if (ctx->fe_waiter_poll) {
+    hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
+    *started_out = started;
+  }
+  return RHIP_OK;
+}
 int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in,
                                 rhip_gt* out) {
   const size_t lanes = (n_items + 63) / 64 * 64;
@@ -1192,26 +1229,8 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
   if (rc) return rc;
   uint32_t* started = nullptr;
   const size_t blocks = blocks_for(n_items, RB_FE_BLOCK);
-  std::unique_lock<std::mutex> live(g_live_mu);          // the waiter cannot be destroyed while its stream is being touched
-  rhip_ctx* w = ctx->fe_waiter;
-  ctx->fe_waiter = nullptr;
-  if (w && !g_live.count(w)) w = nullptr;
-  if (w) {                                  // rhip_ctx_release_before_final_exp: the other context's stream goes on from here
-    if (!ctx->fe_started) HIP_TRY(ctx, hipMalloc((void**)&ctx->fe_started, 256));
-    started = (uint32_t*)ctx->fe_started;
-    HIP_TRY(ctx, hipMemsetAsync(started, 0, 4, ctx->stream));
-    hipEvent_t ev;
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, ctx->stream);                  // everything before the final exponentiation is done
-    if (e == hipSuccess) e = hipStreamWaitEvent(w->stream, ev, 0);
-    (void)hipEventDestroy(ev);
-    if (e != hipSuccess) return fail(ctx, e, "rhip_ctx_release_before_final_exp");
-    // ... and the final exponentiation's waves are resident (at most as many as there are SIMDs); ~2 ms of polling at most
-    const uint32_t target = (uint32_t)(blocks < (size_t)ctx->n_cu ? blocks : (size_t)ctx->n_cu);
-    if (ctx->fe_waiter_poll) hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(64), 0, w->stream, (const uint32_t*)started, target, 20000u);
-    else started = nullptr;
-  }
-  live.unlock();
+  rc = rhip_take_waiter(ctx, blocks, &started);
+  if (rc) return rc;
   // the six-lane kernel (engine_coop.hip) for launches that leave most of the chip idle: the same values, a chain six times shorter
   if (rhip_use_c6(ctx, n_items, 0)) return rhip_launch_final_exp_c6(ctx, n_items, off, stride, mill, mul_in, out, started);
   // the reduced-radix kernel (engine_rr.hip) for the launches that fill the chip: the same chain on 9 x 29-bit limbs

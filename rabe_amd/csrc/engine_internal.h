@@ -57,6 +57,7 @@ struct rhip_ctx {
   uint32_t* walk_count = nullptr;
   bool fe_waiter_poll = true;      // false: the waiter is released when the Miller loops are done, without waiting for the final exponentiation's blocks
   rhip_ctx* fe_waiter = nullptr;   // one-shot (rhip_ctx_release_before_final_exp): released after this context's next Miller launch
+  bool early_release = false;      // one-shot (rhip_ctx_release_when_miller_resident): fe_waiter is released when the next reduced-radix Miller launch's blocks are resident
   // two side streams for launch sets whose kernels are independent and too small to fill the chip one by one (rhip_fork / rhip_join,
   // engine.hip): created on first use
   hipStream_t fork[2] = {nullptr, nullptr};
@@ -670,9 +671,11 @@ int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* 
 bool rhip_use_rr(const rhip_ctx* ctx);
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
-                              const void* work, const uint32_t* chunk_off, size_t lanes);
+                              const void* work, const uint32_t* chunk_off, size_t lanes, uint32_t* started = nullptr);
 int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
                                  uint32_t* started);
+// defined in engine.hip: consumes a pending rhip_ctx_release_before_final_exp request in front of the launch of `blocks` blocks
+int32_t rhip_take_waiter(rhip_ctx* ctx, size_t blocks, uint32_t** started_out);
 // prepared line triples (LineM, 8 x 32-bit limbs) converted once into the records k_miller_multi_rr replays; *out is hipMalloc'ed
 int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void** out);
 

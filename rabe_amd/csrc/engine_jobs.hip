@@ -584,7 +584,12 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
     rc = rhip_launch_miller_c6(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, nullptr, nullptr, nullptr, lanes);
     if (rc) return rc;
   } else if (rhip_use_rr(ctx)) {
-    rc = rhip_launch_miller_rr(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, nullptr, nullptr, nullptr, lanes);
+    uint32_t* started = nullptr;
+    if (ctx->early_release) {          // rhip_ctx_release_when_miller_resident: the waiter goes on beside the Miller loops already
+      rc = rhip_take_waiter(ctx, blocks_for(lanes, RB_MILLER_BLOCK), &started);
+      if (rc) return rc;
+    }
+    rc = rhip_launch_miller_rr(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, nullptr, nullptr, nullptr, lanes, started);
     if (rc) return rc;
   } else
   KLAUNCH(ctx, "k_miller_multi", k_miller_multi, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, (uint32_t)max_pairs, (const G1M*)pl.P,

@@ -201,9 +201,9 @@ struct DevMultiAcc29 {
 
 // Same arguments and lane map as k_miller_multi (engine_jobs.hip); ws29: the workspace in this kernel's layout; ws: the one k_walk_verdicts
 // reads ([wave][pair slot][12 quads][lane], 8 x 32-bit Montgomery limbs) -- written once, at the end, for the walking pairs.
-__global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
-                                                                       const G2M* Q, const uint32_t* qref, const uint4* lines29, uint4* ws, uint4* ws29, GtM* mill,
-                                                                       const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
+__device__ __forceinline__ void miller_multi_rr_lane(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
+                                                     const G2M* Q, const uint32_t* qref, const uint4* lines29, uint4* ws, uint4* ws29, GtM* mill,
+                                                     const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t first;
   int cnt;
@@ -264,6 +264,13 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n
       p[(size_t)(2 * k + 1) * 64] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
     }
   }
+}
+
+__global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_miller_multi_rr(size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const G1M* P,
+                                                                       const G2M* Q, const uint32_t* qref, const uint4* lines29, uint4* ws, uint4* ws29, GtM* mill,
+                                                                       const MillerPlan* plan, const uint2* work, const uint32_t* chunk_off, uint32_t* started) {
+  if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }          // rhip_ctx_release_when_miller_resident
+  miller_multi_rr_lane(n_items, L, C, pair_off, uniform, P, Q, qref, lines29, ws, ws29, mill, plan, work, chunk_off);
 }
 
 // ------------------------------------------------------------------------------------------------ final exponentiation
@@ -335,9 +342,8 @@ struct DevWs29 {
   }
   __device__ __forceinline__ DevHome29 home() const { return DevHome29{x}; }
 };
-__global__ void __launch_bounds__(256, 1) k_final_exp_rr(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in, rhip_gt* out,
-                                                       uint4* ws_base, size_t ws_stride, uint32_t* started) {
-  if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }
+__device__ __forceinline__ void final_exp_rr_lane(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                                  uint4* ws_base, size_t ws_stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const size_t lo = off ? off[i] : i * stride, hi = off ? off[i + 1] : (i + 1) * stride;
@@ -354,6 +360,11 @@ __global__ void __launch_bounds__(256, 1) k_final_exp_rr(size_t n_items, const u
     rr::wsx_mul(ws, FE_T1, FE_T0, false, FE_T1, false);
   }
   store_gt(out[i].l, rr::to_fp12(ws.ld(FE_T1)));
+}
+__global__ void __launch_bounds__(256, 1) k_final_exp_rr(size_t n_items, const uint32_t* off, uint32_t stride, const GtM* mill, const rhip_gt* mul_in, rhip_gt* out,
+                                                       uint4* ws_base, size_t ws_stride, uint32_t* started) {
+  if (started && threadIdx.x == 0) { atomicAdd(started, 1u); __threadfence(); }
+  final_exp_rr_lane(n_items, off, stride, mill, mul_in, out, ws_base, ws_stride);
 }
 int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* off, uint32_t stride, const void* mill, const rhip_gt* mul_in, rhip_gt* out,
                                  uint32_t* started) {
@@ -395,12 +406,12 @@ int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void*
 }
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
-                              const void* work, const uint32_t* chunk_off, size_t lanes) {
+                              const void* work, const uint32_t* chunk_off, size_t lanes, uint32_t* started) {
   if (lines && !lines29) return RHIP_ERR_ARG;          // every handle that carries prepared lines carries their converted form (rhip_lines_to_rr)
   void* ws29 = nullptr;
   const int32_t rc = rhip_ensure_work(ctx, 11, ws_bytes / 12 * RR_SLOT_QUADS, &ws29);
   if (rc) return rc;
   KLAUNCH(ctx, "k_miller_multi_rr", k_miller_multi_rr, dim3(blocks_for(lanes, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, uniform,
-          (const G1M*)P, (const G2M*)Q, qref, (const uint4*)lines29, (uint4*)ws, (uint4*)ws29, (GtM*)mill, plan, (const uint2*)work, chunk_off);
+          (const G1M*)P, (const G2M*)Q, qref, (const uint4*)lines29, (uint4*)ws, (uint4*)ws29, (GtM*)mill, plan, (const uint2*)work, chunk_off, started);
   return RHIP_OK;
 }

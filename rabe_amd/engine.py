@@ -225,6 +225,11 @@ class Engine:
         """one-shot: `waiter`'s stream is held until this context's next decrypt has issued its Miller loops (rhip_ctx_release_before_final_exp)"""
         self._check(self.lib.rhip_ctx_release_before_final_exp(self.ctx, waiter.ctx))
 
+    def release_when_miller_resident(self, waiter):
+        """one-shot: `waiter`'s stream goes on as soon as the blocks of this context's next Miller launch are resident
+        (rhip_ctx_release_when_miller_resident); waiter None withdraws"""
+        self._check(self.lib.rhip_ctx_release_when_miller_resident(self.ctx, waiter.ctx if waiter is not None else None))
+
     def wait_for(self, other):
         """order this context's future work after everything submitted to `other` so far (no host wait)"""
         self._check(self.lib.rhip_ctx_wait_for(self.ctx, other.ctx))

@@ -166,3 +166,53 @@ def test_release_before_final_exp_pipelines_two_contexts_with_identical_results(
     assert want[0] == bn.gt_to_le(acc)
     a.close()
     b.close()
+
+
+def test_release_when_miller_resident_gives_identical_results():
+    """rhip_ctx_release_when_miller_resident: context A's stream continues as soon as the blocks of context B's next Miller launch are
+    resident (k_miller_multi_rr counts them), i.e. A's kernels run beside B's Miller loops.  The bytes must be those of the serial order,
+    for uniform pair lists (the early release), for ragged ones and other pairing modes (the request falls back to the release before
+    the final exponentiation) and for items without pairs; an unused or withdrawn request holds nothing."""
+    import random
+    from rabe_amd import Engine
+    from oracle import bn254 as bn
+    rnd = random.Random(11)
+    a, b = Engine(0), Engine(0)
+    a.set_pairing_mode(1)
+    n_items = 333                                                 # two blocks, the second partly filled
+    ks = [rnd.randrange(1, bn.R) for _ in range(8)]
+    P = [bn.g1_to_le(bn.g1_mul(bn.G1_GEN, k)) for k in ks]
+    Q = [bn.g2_to_le(bn.g2_mul(bn.G2_GEN, k + 1)) for k in ks]
+    for per_item in (6, 1):
+        n = n_items * per_item
+        ps, qs = [P[(i * 5 + 1) % 8] for i in range(n)], [Q[(3 * i) % 8] for i in range(n)]
+        off = list(range(0, n + 1, per_item))
+        want = a.pairing_product(off, ps, qs)
+        for mode in (0, 29):
+            b.set_pairing_mode(mode)
+            b.release_when_miller_resident(a)
+            got_b = b.pairing_jobs(off, ps, qs)
+            got_a = a.pairing_product(off, ps, qs)                # behind the hold
+            assert got_b == want and got_a == want, (per_item, mode)
+        assert b.pairing_jobs(off, ps, qs) == want                # the request was one-shot
+    # ragged lists (an item without pairs among them) and explicit other modes: the fallback path, same values
+    n = 500
+    ps, qs = [P[i % 8] for i in range(n)], [Q[(3 * i + 1) % 8] for i in range(n)]
+    off = [0, 0]
+    while off[-1] < n:
+        off.append(min(n, off[-1] + rnd.randrange(0, 9)))
+    want = a.pairing_product(off, ps, qs)
+    for mode in (0, 6, 1):
+        b.set_pairing_mode(mode)
+        b.release_when_miller_resident(a)
+        assert b.pairing_jobs(off, ps, qs) == want, mode
+        assert a.pairing_product(off, ps, qs) == want
+    b.release_when_miller_resident(a)
+    b.release_when_miller_resident(None)                         # withdrawn
+    assert a.pairing_product(off, ps, qs) == want
+    acc = bn.GT_ONE
+    for i in range(off[2]):
+        acc = bn.gt_mul(acc, bn.pairing(bn.g1_from_le(ps[i]), bn.g2_from_le(qs[i])))
+    assert want[0] == bn.gt_to_le(bn.GT_ONE) and want[1] == bn.gt_to_le(acc)
+    a.close()
+    b.close()

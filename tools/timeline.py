@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel and copy timeline of the LAST packed call of a rocprofv3 --kernel-trace --memory-copy-trace run (rocpd .db): start / end in ms
 relative to the first event shown, so that overlap (or its absence) between the copy-out of one part and the kernels of the next is visible.
-usage: python tools/timeline.py x_results.db [last_ms=80]"""
+usage: python tools/timeline.py x_results.db [last_ms=80] [anchor [back_ms=8]]   (anchor: a kernel name -- the window then starts back_ms before the LAST
+launch of that kernel instead of last_ms before the end of the run)"""
 import sqlite3
 import sys
 
@@ -28,7 +29,11 @@ if not ev:
     print("no events; tables:", tabs)
     sys.exit(0)
 t_end = ev[-1][1]
-sel = [x for x in ev if x[0] >= t_end - span * 1e6 and (x[1] - x[0]) > 50e3]
+if len(sys.argv) > 3:
+    hits = [x for x in ev if x[2][2:].startswith(sys.argv[3])]
+    if hits:
+        t_end = hits[-1][0] - (float(sys.argv[4]) if len(sys.argv) > 4 else 8.0) * 1e6 + span * 1e6
+sel = [x for x in ev if t_end - span * 1e6 <= x[0] <= t_end and (x[1] - x[0]) > 50e3]
 t0 = sel[0][0]
 for s, e, n in sel:
     print("%9.3f %9.3f  %7.3f ms  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, n))
