@@ -59,8 +59,8 @@ IMPL_MILLER_MULTI6_FPMUL = 29931    # tests/count_muls.py: miller_loop_multi, an
 IMPL_MILLER_MULTI6_WALK_FPMUL = 37194   # the same with nothing prepared
 # the reduced-radix kernels (engine_rr.hip, 9 x 29-bit limbs): multiply-add INSTRUCTIONS per lane, tests/count_muls.py (81 per schoolbook
 # product, 81 per reduction; the line products are taken as dot products: more products, far fewer reductions and no carry instructions)
-IMPL_RR_MILLER_MULTI6_MADS = 5523147     # an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
-IMPL_RR_MILLER_MULTI6_WALK_MADS = 6728670
+IMPL_RR_MILLER_MULTI6_MADS = 5050755     # an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator; prepared lines with a unit y-coefficient
+IMPL_RR_MILLER_MULTI6_WALK_MADS = 6682014
 IMPL_RR_FINAL_EXP_MADS = 1199772 + 600 * 136   # + the one inversion, which runs on the 8 x 32-bit core (~600 Fp multiplications)
 
 
