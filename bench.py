@@ -402,8 +402,20 @@ def main():
             run_steps()
     sync_all()
     torch.cuda.synchronize()
+    prof_on = bool(os.environ.get("RABE_MILLER_PROF")) and hasattr(eng.lib, "rhip_debug_miller_prof")          # diagnostic build (tools/prof_miller.sh)
+    if prof_on:
+        import ctypes
+        pbuf = (ctypes.c_ulonglong * 8)()
+        eng.lib.rhip_debug_miller_prof(eng.ctx, pbuf)
     regions = timed_regions(run_steps, sync_all, args.min_time)
     elapsed = sum(regions) / len(regions)
+    if prof_on:
+        eng.lib.rhip_debug_miller_prof(eng.ctx, pbuf)
+        w = max(1, pbuf[6])
+        names = ["squaring", "prepared: loads + scaling", "prepared: line products", "walking: loads + G2 step + store", "walking: line products", "whole loop"]
+        print("k_miller_multi_rr regions, shader cycles per wave (mean over %d waves):" % w, file=sys.stderr)
+        for k in range(6):
+            print("   %-34s %12.0f  %5.1f %%" % (names[k], pbuf[k] / w, 100.0 * pbuf[k] / max(1, pbuf[5])), file=sys.stderr)
 
     # ---------------------------------------------------------------- size-independent correctness property on the FULL batch:
     # decrypt(encrypt(msg)) == msg, bit for bit, for every item of every group slot (oracle parity at small sizes is in tests/)

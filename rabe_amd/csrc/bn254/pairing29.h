@@ -192,22 +192,53 @@ template <class FA> RB_HD void facc_ell_u(FA a, const LineU29& l, const MillerP2
 // the accumulator pair by pair instead of event by event -- the same product.  (Written out per case rather than as a loop over the
 // step's events: the loop form keeps the running point live across a line product and spills it -- measured 268 against 259 ms on
 // config 3's launch set.)
+// RB_MILLER_PROF (a diagnostic build, tools/prof_miller.sh): shader cycles per region of the loop, summed per lane in registers and written
+// by the kernel -- 0 squaring, 1 prepared pair: loads + scaling, 2 prepared pair: line products, 3 walking pair: loads + G2 step + store,
+// 4 walking pair: line products
+#if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define RB_PROF_DECL unsigned long long rb_prof_t_ = clock64()
+#define RB_PROF_MARK(k) do { const unsigned long long n_ = clock64(); acc.prof[k] += n_ - rb_prof_t_; rb_prof_t_ = n_; } while (0)
+#else
+#define RB_PROF_DECL ((void)0)
+#define RB_PROF_MARK(k) ((void)0)
+#endif
+// (inlined into the loop: out of line -- RB_FN -- each kind of step gets a register allocation of its own, but the calling convention's
+// callee-saved registers turn into scratch spills: 177 scratch instructions in the walking step, 42.7 M against 39.5 M cycles per wave)
+#ifndef RB_STEP_FN
+#define RB_STEP_FN RB_HD
+#endif
 template <class ACC>
-RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
-  const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
-  if (kind == MP_SKIP) return;
+RB_STEP_FN void miller_prepared_step(ACC acc, int j, int second, int ln) {
   const MillerP29 p = acc.p(j);
-  if (kind == MP_LINES) {
-    const LineU29 l1 = acc.line_u(j, ln);
-    if (second >= 0) {
-      const LineU29 l2 = acc.line_u(j, ln + 1);
-      facc_ell_u(acc, l1, p);
-      facc_ell_u(acc, l2, p);
-    } else {
-      facc_ell_u(acc, l1, p);
-    }
-    return;
+  RB_PROF_DECL;
+  const LineU29 l1 = acc.line_u(j, ln);
+  if (second >= 0) {
+    const LineU29 l2 = acc.line_u(j, ln + 1);
+#if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const F2 s1 = mul2_fp(l1.cx, p.px), s2 = mul2_fp(l2.cx, p.px);
+    RB_PROF_MARK(1);
+    facc_mul_by_line_s(acc, p.py, s1, l1.c0);
+    facc_mul_by_line_s(acc, p.py, s2, l2.c0);
+    RB_PROF_MARK(2);
+#else
+    facc_ell_u(acc, l1, p);
+    facc_ell_u(acc, l2, p);
+#endif
+  } else {
+#if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const F2 s1 = mul2_fp(l1.cx, p.px);
+    RB_PROF_MARK(1);
+    facc_mul_by_line_s(acc, p.py, s1, l1.c0);
+    RB_PROF_MARK(2);
+#else
+    facc_ell_u(acc, l1, p);
+#endif
   }
+}
+template <class ACC>
+RB_STEP_FN void miller_walking_step(ACC acc, int j, int first, int second) {
+  const MillerP29 p = acc.p(j);
+  RB_PROF_DECL;
   G2Hom29 t = acc.ld_t(j);
   G2Aff29 q;
   if (second >= 0 || first != MS_DBL) q = acc.q(j);
@@ -221,8 +252,17 @@ RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
     l2 = g2hom_add(t, q2);
   }
   acc.st_t(j, t);
+  RB_PROF_MARK(3);
   facc_ell(acc, l1, p);
   if (second >= 0) facc_ell(acc, l2, p);
+  RB_PROF_MARK(4);
+}
+template <class ACC>
+RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
+  const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
+  if (kind == MP_SKIP) return;
+  if (kind == MP_LINES) miller_prepared_step(acc, j, second, ln);
+  else miller_walking_step(acc, j, first, second);
 }
 // The loop: 65 doubling steps (21 of them with an addition), then the two Frobenius additions -- the line events of pairing.h's
 // miller_loop_multi in the same order per pair, prepared lines numbered the same way.
@@ -236,7 +276,7 @@ RB_MID void miller_loop_multi(ACC acc) {
     const bool pos = (i < 64) && ((RB_ATE_NAF_POS >> i) & 1ull);
     const bool ngt = (i < 64) && ((RB_ATE_NAF_NEG >> i) & 1ull);
     const int second = pos ? MS_ADD_POS : ngt ? MS_ADD_NEG : -1;
-    facc_sqr(acc);
+    { RB_PROF_DECL; facc_sqr(acc); RB_PROF_MARK(0); }
     for (int j = 0; j < n; j++) miller_pair_step(acc, j, MS_DBL, second, ln);
     ln += (second >= 0) ? 2 : 1;
   }

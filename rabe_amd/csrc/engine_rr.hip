@@ -91,7 +91,13 @@ __device__ __attribute__((noinline)) rr::Out16 rr_dot3s_core(rr::i32x9 s, int ia
 //   quads [14, 22) + 22: the converted G2 argument (four Fp + their top limbs), quads [23, 27) + 27: the converted G1 argument
 #define RR_SLOT_QUADS 28
 #define RR_LINE_QUADS 9
+#ifdef RB_MILLER_PROF
+__device__ unsigned long long rb_miller_prof[8];          // summed over the lanes 0 of every wave: regions 0..4, [5] = whole loop, [6] = waves
+#endif
 struct DevMultiAcc29 {
+#ifdef RB_MILLER_PROF
+  unsigned long long* prof;
+#endif
   const G1M* P;
   const G2M* Q;
   const uint32_t* qref;
@@ -267,8 +273,21 @@ __device__ __forceinline__ void miller_multi_rr_lane(size_t n_items, uint32_t L,
     if (v == RHIP_Q_WALK) walk_m |= 1ull << j;
     else if (v == RHIP_Q_SKIP) skip_m |= 1ull << j;
   }
+#ifdef RB_MILLER_PROF
+  unsigned long long prof[5] = {0, 0, 0, 0, 0};
+  const unsigned long long prof_t0 = clock64();
+  const DevMultiAcc29 acc{prof, P + first, Q + first, qref + first, lines29, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked, walk_m, skip_m};
+#else
   const DevMultiAcc29 acc{P + first, Q + first, qref + first, lines29, cnt, ws29 + (t >> 6) * ((size_t)Cw * RR_SLOT_QUADS * 64) + (t & 63), &parked, walk_m, skip_m};
+#endif
   rr::miller_loop_multi(acc);
+#ifdef RB_MILLER_PROF
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 5; k++) atomicAdd(&rb_miller_prof[k], prof[k]);
+    atomicAdd(&rb_miller_prof[5], clock64() - prof_t0);
+    atomicAdd(&rb_miller_prof[6], 1ull);
+  }
+#endif
   // the value, back in the canonical Montgomery form of the 8 x 32-bit core
   {
     uint32_t* o = out->l;
@@ -431,6 +450,17 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_ubench_cores(uint32_t it
   if (ln == 0) out[(size_t)blockIdx.x * 4 + wv] = (t1 - t0) + (uint64_t)((a[0] ^ b[1]) & 1);
 #endif
 }
+#ifdef RB_MILLER_PROF
+// diagnostic build only: reads and clears the region sums of the k_miller_multi_rr launches since the last call
+extern "C" int32_t rhip_debug_miller_prof(rhip_ctx* ctx, unsigned long long out[8]) {
+  if (!ctx || !out) return RHIP_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_miller_prof), 8 * sizeof(unsigned long long)));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(rb_miller_prof), z, sizeof z));
+  return RHIP_OK;
+}
+#endif
 extern "C" int32_t rhip_debug_ubench_cores(rhip_ctx* ctx, uint32_t iters, int32_t which, uint32_t blocks, uint64_t* d_out) {
   if (!ctx || !d_out) return RHIP_ERR_ARG;
   KLAUNCH(ctx, "k_ubench_cores", k_ubench_cores, dim3(blocks), dim3(RB_MILLER_BLOCK), 0, ctx->stream, iters, (int)which, d_out);
