@@ -50,15 +50,33 @@ def _flags():
     return extra.split() if extra else []
 
 
+# Per-unit code-generation flags, MEASURED (tools/ab_variants.sh: fourteen scheduler / register-allocator settings of engine_rr.hip alternating
+# with the default build on one MI355X).  The reduced-radix pairing kernels are one wave per SIMD of straight-line multiply-add code around
+# ~13 k calls per lane, at the register limit: a top-down pre-RA schedule and the reversed order of local assignments give k_miller_multi_rr
+# 17.3 -> 17.0 ms and k_final_exp_rr 5.95 -> 5.8 ms per 65 536 items (config 4's launch set 170 -> 166 ms); the other units do not react.
+UNIT_FLAGS = {"engine_rr.hip": ["-mllvm", "-misched-prera-direction=topdown", "-mllvm", "-greedy-reverse-local-assignment"]}
+
+
+def _unit_flags(src):
+    return [] if os.environ.get("RABE_NO_UNIT_FLAGS") else UNIT_FLAGS.get(os.path.basename(src), [])
+
+
+def _flags_tag():
+    return " ".join(_flags()) + " | " + repr(sorted(UNIT_FLAGS.items())) + (" | no-unit-flags" if os.environ.get("RABE_NO_UNIT_FLAGS") else "")
+
+
 def stale():
     if not os.path.exists(LIB):
+        return True
+    tag_file = os.path.join(OBJ, ".flags")
+    if not os.path.exists(tag_file) or open(tag_file).read() != _flags_tag():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in _headers() + [s for s in SOURCES if os.path.exists(s)])
 
 
 def _compile(src, verbose, safe=False):
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src, safe)] + _flags() + (["-DRB_SAFE_CARRY"] if safe else [])
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src, safe)] + _unit_flags(src) + _flags() + (["-DRB_SAFE_CARRY"] if safe else [])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, timeout=3000)
@@ -71,14 +89,15 @@ def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(s)]
     hdr_t = {s: max(os.path.getmtime(h) for h in _headers(s)) for s in srcs}
     flags_tag = os.path.join(OBJ, ".flags")
-    same_flags = os.path.exists(flags_tag) and open(flags_tag).read() == " ".join(_flags())
+    tag = _flags_tag()
+    same_flags = os.path.exists(flags_tag) and open(flags_tag).read() == tag
     todo = [s for s in srcs if force or not same_flags or not os.path.exists(_obj(s))
             or os.path.getmtime(_obj(s)) < max(hdr_t[s], os.path.getmtime(s))]
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 2))) as ex:
             for f in [ex.submit(_compile, s, verbose) for s in todo]:
                 f.result()
-    open(flags_tag, "w").write(" ".join(_flags()))
+    open(flags_tag, "w").write(tag)
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in srcs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
