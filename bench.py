@@ -59,7 +59,7 @@ IMPL_MILLER_MULTI6_FPMUL = 29931    # tests/count_muls.py: miller_loop_multi, an
 IMPL_MILLER_MULTI6_WALK_FPMUL = 37194   # the same with nothing prepared
 # the reduced-radix kernels (engine_rr.hip, 9 x 29-bit limbs): multiply-add INSTRUCTIONS per lane, tests/count_muls.py (81 per schoolbook
 # product, 81 per reduction; the line products are taken as dot products: more products, far fewer reductions and no carry instructions)
-IMPL_RR_MILLER_MULTI6_MADS = 5478435     # an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator
+IMPL_RR_MILLER_MULTI6_MADS = 5050755     # an AC17 item's six pairs (3 prepared + 3 walking) on one accumulator; prepared lines carry a unit y-coefficient
 IMPL_RR_MILLER_MULTI6_WALK_MADS = 6682014
 IMPL_RR_FINAL_EXP_MADS = 1199772 + 600 * 136   # + the one inversion, which runs on the 8 x 32-bit core (~600 Fp multiplications)
 
@@ -411,7 +411,7 @@ def main():
     if prof_on:
         eng.lib.rhip_debug_miller_prof(eng.ctx, pbuf)
         w = max(1, pbuf[6])
-        names = ["squaring", "(unused)", "prepared: loads + scaling + line products", "walking: loads + G2 step + store", "walking: line products", "whole loop"]
+        names = ["squaring", "prepared: loads + scaling", "prepared: line products", "walking: loads + G2 step + store", "walking: line products", "whole loop"]
         print("k_miller_multi_rr regions, shader cycles per wave (mean over %d waves):" % w, file=sys.stderr)
         for k in range(6):
             print("   %-34s %12.0f  %5.1f %%" % (names[k], pbuf[k] / w, 100.0 * pbuf[k] / max(1, pbuf[5])), file=sys.stderr)

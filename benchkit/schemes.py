@@ -125,13 +125,13 @@ class SchemeRunner:
             alg = b.algorithmic_fpmul_per_item()          # {kernel: SURVEY 8d Fp-mul per item carried by that kernel}
             impl_all = b.impl_fpmul_per_item()
             # the reduced-radix kernels (engine_rr.hip) carry the same units of work; what they execute is counted in multiply-add instructions
-            # (tests/count_muls.py: 1.077 M per walking pair of a 14-pair chunk, 0.877 M per pair when half of them replay prepared lines),
+            # (tests/count_muls.py: 1.077 M per walking pair of a 14-pair chunk, 0.806 M per pair when half of them replay prepared lines),
             # expressed here in units of 136 like the Fp multiplications of the 8 x 32-bit kernels
             if "k_miller_multi" in alg:
                 alg["k_miller_multi_rr"] = alg["k_miller_multi"]
                 if "k_miller_multi" in impl_all:
                     pairs = impl_all["k_miller_multi"] / (4766.0 if getattr(b, "sk_lines", None) else 5976.0)
-                    impl_all["k_miller_multi_rr"] = pairs * ((876785.0 if getattr(b, "sk_lines", None) else 1077381.0) / 136.0)
+                    impl_all["k_miller_multi_rr"] = pairs * ((805505.0 if getattr(b, "sk_lines", None) else 1077381.0) / 136.0)
             if "k_final_exp" in alg:
                 alg["k_final_exp_rr"] = alg["k_final_exp"]
             macs = alg.get(dom, 0) * MAC_PER_FPMUL * G * B

@@ -54,6 +54,7 @@ def _flags():
 # with the default build on one MI355X).  The reduced-radix pairing kernels are one wave per SIMD of straight-line multiply-add code around
 # ~13 k calls per lane, at the register limit: a top-down pre-RA schedule and the reversed order of local assignments give k_miller_multi_rr
 # 17.3 -> 17.0 ms and k_final_exp_rr 5.95 -> 5.8 ms per 65 536 items (config 4's launch set 170 -> 166 ms); the other units do not react.
+# They are also what lets the unit-y prepared lines (bn254/pairing29.h) keep their gain: docs/rr29.md.
 UNIT_FLAGS = {"engine_rr.hip": ["-mllvm", "-misched-prera-direction=topdown", "-mllvm", "-greedy-reverse-local-assignment"]}
 
 

@@ -334,6 +334,29 @@ RB_HD void dot3_raw(i32x9& c0, i32x9& c1, const i32x9& x0a, const i32x9& x0b, co
   }
 }
 
+// the same with an Fp factor in the first term: (x0 s + x1 y1 + x2 y2), s in Fq -- ten products, two reductions.  The line of a PREPARED
+// pair is stored with a unit y-coefficient (engine_rr.hip: k_lines_to_rr), so that what meets the accumulator's k-th coefficient is y_P itself
+RB_HD void dot3s_raw(i32x9& c0, i32x9& c1, const i32x9& x0a, const i32x9& x0b, const i32x9& s, const i32x9& x1a, const i32x9& x1b,
+                     const i32x9& y1a, const i32x9& y1b, const i32x9& x2a, const i32x9& x2b, const i32x9& y2a, const i32x9& y2b) {
+  RR_COUNT(12);
+  {
+    int64_t t[18];
+    cols_init(t);
+    cols_mac(t, x0a, s);
+    cols_mac(t, x1a, y1a); cols_mac(t, -x1b, y1b);
+    cols_mac(t, x2a, y2a); cols_mac(t, -x2b, y2b);
+    c0 = redc(t);
+  }
+  {
+    int64_t t[18];
+    cols_init(t);
+    cols_mac(t, x0b, s);
+    cols_mac(t, x1a, y1b); cols_mac(t, x1b, y1a);
+    cols_mac(t, x2a, y2b); cols_mac(t, x2b, y2a);
+    c1 = redc(t);
+  }
+}
+
 // ---- conversions from / to fp.h's canonical Montgomery form (x 2^256 mod p in 8 x 32-bit limbs)
 RB_HD FB<2, 1> unpack(const Fp& x) {          // the 256-bit integer cut into 29-bit pieces (non-negative, < 2^29)
   i32x9 r;
@@ -452,6 +475,18 @@ RB_HD F2 dot3(const F2B<LA, VA>& x0, const F2B<LB, VB>& y0, const F2B<LC, VC>& x
   dot3_raw(c0, c1, x0.c0.l, x0.c1.l, y0.c0.l, y0.c1.l, x1.c0.l, x1.c1.l, y1.c0.l, y1.c1.l, x2.c0.l, x2.c1.l, y2.c0.l, y2.c1.l);
   const F2 r = mk2(mk<1, 1>(c0), mk<1, 1>(c1));
   RR_CHECK(r.c0, "dot3 out"); RR_CHECK(r.c1, "dot3 out");
+  return r;
+}
+template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD, int LE, int VE, int LF, int VF>
+RB_HD F2 dot3s(const F2B<LA, VA>& x0, const FB<LB, VB>& s, const F2B<LC, VC>& x1, const F2B<LD, VD>& y1, const F2B<LE, VE>& x2, const F2B<LF, VF>& y2) {
+  static_assert(LA * LB + 2 * (LC * LD + LE * LF) <= 10, "fp29: limb bounds of an Fq2 dot product overflow the 64-bit column");
+  static_assert(VA * VB + 2 * (VC * VD + VE * VF) <= 36, "fp29: value bounds of an Fq2 dot product");
+  RR_CHECK(x0.c0, "dot3s"); RR_CHECK(x0.c1, "dot3s"); RR_CHECK(s, "dot3s"); RR_CHECK(x1.c0, "dot3s"); RR_CHECK(x1.c1, "dot3s");
+  RR_CHECK(y1.c0, "dot3s"); RR_CHECK(y1.c1, "dot3s"); RR_CHECK(x2.c0, "dot3s"); RR_CHECK(x2.c1, "dot3s"); RR_CHECK(y2.c0, "dot3s"); RR_CHECK(y2.c1, "dot3s");
+  i32x9 c0, c1;
+  dot3s_raw(c0, c1, x0.c0.l, x0.c1.l, s.l, x1.c0.l, x1.c1.l, y1.c0.l, y1.c1.l, x2.c0.l, x2.c1.l, y2.c0.l, y2.c1.l);
+  const F2 r = mk2(mk<1, 1>(c0), mk<1, 1>(c1));
+  RR_CHECK(r.c0, "dot3s out"); RR_CHECK(r.c1, "dot3s out");
   return r;
 }
 // x + xi y,  xi = 9 + u:  (x0 + 9 y0 - y1) + (x1 + 9 y1 + y0) u, normalised

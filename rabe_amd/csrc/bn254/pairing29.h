@@ -104,10 +104,31 @@ template <class FA> RB_HD void facc_mul_by_line(FA a, const F2& l0, const F2& l1
   a.fence();
 }
 
+// The same product for a line with a UNIT y-coefficient, l = s + l1 w + l3 w^3 with s = y_P in Fq: the first term of every dot product is
+// an Fq2 x Fq product (ten schoolbook products per coefficient instead of twelve).  FA provides  F2 dot3s(const F& s, int ia, int ib, int ic).
+template <class FA> RB_HD void facc_mul_by_line_s(FA a, const F& s, const F2& l1, const F2& l3) {
+  a.set_y(1, mul_xi2(l1));
+  a.set_y(2, mul_xi2(l3));
+  const F2 o0 = a.dot3s(s, W0, W5, W3);
+  a.set_y(1, l1);
+  const F2 o1 = a.dot3s(s, W1, W0, W4);
+  const F2 o2 = a.dot3s(s, W2, W1, W5);
+  a.set_y(2, l3);
+  const F2 o3 = a.dot3s(s, W3, W2, W0);
+  const F2 o4 = a.dot3s(s, W4, W3, W1);
+  const F2 o5 = a.dot3s(s, W5, W4, W2);
+  a.fence();
+  a.st_f2(W0, o0); a.st_f2(W1, o1); a.st_f2(W2, o2); a.st_f2(W3, o3); a.st_f2(W4, o4); a.st_f2(W5, o5);
+  a.fence();
+}
+
 // ============================================================================ G2 steps (pairing.h: g2hom_double / g2hom_add)
 struct G2Hom29 { F2 x, y, z; };
 struct G2Aff29 { F2 x, y; };
 struct Line29 { F2B<3, 3> cy, cx; F2 c0; };          // cy, cx are scaled by y_P, x_P before they meet the accumulator
+// A PREPARED line, divided by its y-coefficient when the key's lines were converted (cx / cy, c0 / cy): the factor 1 / cy lies in Fq2, a
+// proper subfield of Fq12, so the final exponentiation removes it -- the pairing is the same element, the Miller value is not.
+struct LineU29 { F2 cx, c0; };
 struct MillerP29 { F px, py; };
 
 RB_MID Line29 g2hom_double(G2Hom29& r) {
@@ -156,9 +177,13 @@ template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& 
   facc_mul_by_line(a, mul2_fp(l.cy, p.py), mul2_fp(l.cx, p.px), l.c0);
 }
 
+template <class FA> RB_HD void facc_ell_u(FA a, const LineU29& l, const MillerP29& p) {
+  facc_mul_by_line_s(a, p.py, mul2_fp(l.cx, p.px), l.c0);
+}
+
 // ============================================================================ the loop (pairing.h: miller_loop_multi, same event order)
 // ACC provides, beside the FA interface:  int count(), int kind(int j) (MP_WALK / MP_LINES / MP_SKIP), MillerP29 p(int j),
-// G2Aff29 q(int j), Line29 line(int j, int n), G2Hom29 ld_t(int j), void st_t(int j, const G2Hom29&), void begin()  (called once before
+// G2Aff29 q(int j), LineU29 line_u(int j, int n) (line n of prepared pair j, unit y-coefficient), G2Hom29 ld_t(int j), void st_t(int j, const G2Hom29&), void begin()  (called once before
 // the loop: converts the lane's arguments)
 // One pair's share of a loop step: its line of the FIRST event (the doubling, or the first Frobenius addition) and, when the step has
 // one, of the SECOND (the addition of a non-zero digit, the second Frobenius addition) -- with the running point fetched and stored
@@ -167,8 +192,9 @@ template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& 
 // the accumulator pair by pair instead of event by event -- the same product.  (Written out per case rather than as a loop over the
 // step's events: the loop form keeps the running point live across a line product and spills it -- measured 268 against 259 ms on
 // config 3's launch set.)
-// RB_MILLER_PROF (a diagnostic build, tools/prof_miller.sh): shader cycles per region of the loop, summed per lane and written by the kernel --
-// 0 squaring, 2 prepared pair (loads, scaling, line products), 3 walking pair: loads + G2 step + store, 4 walking pair: line products
+// RB_MILLER_PROF (a diagnostic build, tools/prof_miller.sh): shader cycles per region of the loop, summed per lane in registers and written
+// by the kernel -- 0 squaring, 1 prepared pair: loads + scaling, 2 prepared pair: line products, 3 walking pair: loads + G2 step + store,
+// 4 walking pair: line products
 #if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define RB_PROF_DECL unsigned long long rb_prof_t_ = clock64()
 #define RB_PROF_MARK(k) do { const unsigned long long n_ = clock64(); acc.prof[k] += n_ - rb_prof_t_; rb_prof_t_ = n_; } while (0)
@@ -176,24 +202,42 @@ template <class FA> RB_HD void facc_ell(FA a, const Line29& l, const MillerP29& 
 #define RB_PROF_DECL ((void)0)
 #define RB_PROF_MARK(k) ((void)0)
 #endif
+// (inlined into the loop: out of line -- RB_FN -- each kind of step gets a register allocation of its own, but the calling convention's
+// callee-saved registers turn into scratch spills: 177 scratch instructions in the walking step, 42.7 M against 39.5 M cycles per wave)
+#ifndef RB_STEP_FN
+#define RB_STEP_FN RB_HD
+#endif
 template <class ACC>
-RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
-  const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
-  if (kind == MP_SKIP) return;
+RB_STEP_FN void miller_prepared_step(ACC acc, int j, int second, int ln) {
   const MillerP29 p = acc.p(j);
-  if (kind == MP_LINES) {
-    RB_PROF_DECL;
-    const Line29 l1 = acc.line(j, ln);
-    if (second >= 0) {
-      const Line29 l2 = acc.line(j, ln + 1);
-      facc_ell(acc, l1, p);
-      facc_ell(acc, l2, p);
-    } else {
-      facc_ell(acc, l1, p);
-    }
+  RB_PROF_DECL;
+  const LineU29 l1 = acc.line_u(j, ln);
+  if (second >= 0) {
+    const LineU29 l2 = acc.line_u(j, ln + 1);
+#if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const F2 s1 = mul2_fp(l1.cx, p.px), s2 = mul2_fp(l2.cx, p.px);
+    RB_PROF_MARK(1);
+    facc_mul_by_line_s(acc, p.py, s1, l1.c0);
+    facc_mul_by_line_s(acc, p.py, s2, l2.c0);
     RB_PROF_MARK(2);
-    return;
+#else
+    facc_ell_u(acc, l1, p);
+    facc_ell_u(acc, l2, p);
+#endif
+  } else {
+#if defined(RB_MILLER_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const F2 s1 = mul2_fp(l1.cx, p.px);
+    RB_PROF_MARK(1);
+    facc_mul_by_line_s(acc, p.py, s1, l1.c0);
+    RB_PROF_MARK(2);
+#else
+    facc_ell_u(acc, l1, p);
+#endif
   }
+}
+template <class ACC>
+RB_STEP_FN void miller_walking_step(ACC acc, int j, int first, int second) {
+  const MillerP29 p = acc.p(j);
   RB_PROF_DECL;
   G2Hom29 t = acc.ld_t(j);
   G2Aff29 q;
@@ -212,6 +256,13 @@ RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
   facc_ell(acc, l1, p);
   if (second >= 0) facc_ell(acc, l2, p);
   RB_PROF_MARK(4);
+}
+template <class ACC>
+RB_HD void miller_pair_step(ACC acc, int j, int first, int second, int ln) {
+  const int kind = acc.kind(j);          // (the device accessor keeps the kinds in registers: nothing to wait for)
+  if (kind == MP_SKIP) return;
+  if (kind == MP_LINES) miller_prepared_step(acc, j, second, ln);
+  else miller_walking_step(acc, j, first, second);
 }
 // The loop: 65 doubling steps (21 of them with an addition), then the two Frobenius additions -- the line events of pairing.h's
 // miller_loop_multi in the same order per pair, prepared lines numbered the same way.

@@ -68,13 +68,29 @@ __device__ __attribute__((noinline)) rr::Out16 rr_dot3_core(rr::i32x9 y0a, rr::i
   rr::dot3_raw(c0, c1, x0a, x0b, y0a, y0b, x1a, x1b, y1a, y1b, x2a, x2b, y2a, y2b);
   return rr::side_ret(c0, c1, rr::rr_side + threadIdx.x);
 }
+// f[ia] s + f[ib] y[1] + f[ic] y[2] with s in Fq (the unit-y lines of prepared pairs: pairing29.h facc_mul_by_line_s)
+__device__ __attribute__((noinline)) rr::Out16 rr_dot3s_core(rr::i32x9 s, int ia, int ib, int ic) {
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const uint4* hq = rr_home_q + wv * (24 * 64) + ln;
+  const uint32_t* hd = rr_home_d + wv * (12 * 64) + ln;
+  const uint4* yq = rr_y_q + wv * (8 * 64) + ln;
+  const uint32_t* yd = rr_y_d + wv * (4 * 64) + ln;
+  const rr::i32x9 x0a = rr_lds_elem(hq + (4 * ia) * 64, hd + (2 * ia) * 64), x0b = rr_lds_elem(hq + (4 * ia + 2) * 64, hd + (2 * ia + 1) * 64);
+  const rr::i32x9 x1a = rr_lds_elem(hq + (4 * ib) * 64, hd + (2 * ib) * 64), x1b = rr_lds_elem(hq + (4 * ib + 2) * 64, hd + (2 * ib + 1) * 64);
+  const rr::i32x9 x2a = rr_lds_elem(hq + (4 * ic) * 64, hd + (2 * ic) * 64), x2b = rr_lds_elem(hq + (4 * ic + 2) * 64, hd + (2 * ic + 1) * 64);
+  const rr::i32x9 y1a = rr_lds_elem(yq, yd), y1b = rr_lds_elem(yq + 2 * 64, yd + 64);
+  const rr::i32x9 y2a = rr_lds_elem(yq + 4 * 64, yd + 2 * 64), y2b = rr_lds_elem(yq + 6 * 64, yd + 3 * 64);
+  rr::i32x9 c0, c1;
+  rr::dot3s_raw(c0, c1, x0a, x0b, s, x1a, x1b, y1a, y1b, x2a, x2b, y2a, y2b);
+  return rr::side_ret(c0, c1, rr::rr_side + threadIdx.x);
+}
 #endif
 
 // a lane's slice of the global workspace: per pair slot RR_SLOT_QUADS quads at stride 64 (one coalesced 1 KB access per quad and wave)
 //   quads [0, 12): the running point T (six Fp: limbs 0..7), quads [12, 14): its six top limbs (+ 2 unused dwords)
 //   quads [14, 22) + 22: the converted G2 argument (four Fp + their top limbs), quads [23, 27) + 27: the converted G1 argument
 #define RR_SLOT_QUADS 28
-#define RR_LINE_QUADS 14
+#define RR_LINE_QUADS 9
 #ifdef RB_MILLER_PROF
 __device__ unsigned long long rb_miller_prof[8];          // summed over the lanes 0 of every wave: regions 0..4, [5] = whole loop, [6] = waves
 #endif
@@ -85,7 +101,7 @@ struct DevMultiAcc29 {
   const G1M* P;
   const G2M* Q;
   const uint32_t* qref;
-  const uint4* lines29;      // prepared triples in this core's form: 14 quads each (6 x 8 limbs, then the 6 top limbs + 2 unused dwords)
+  const uint4* lines29;      // prepared lines in this core's form, unit y-coefficient: 9 quads each (cx, c0: 4 x 8 limbs, then the 4 top limbs)
   int cnt;
   uint4* ws;                 // + lane
   F6* x;                     // the parked Fq6 (a local of the kernel)
@@ -128,6 +144,16 @@ struct DevMultiAcc29 {
     return rr::mk2(rr::mk<1, 1>(c0), rr::mk<1, 1>(c1));
 #else
     return y0;
+#endif
+  }
+  __device__ __forceinline__ F2 dot3s(const F& y, int ia, int ib, int ic) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const rr::Out16 o = rr_dot3s_core(y.l, ia, ib, ic);
+    uint32_t* side = rr::rr_side + threadIdx.x;
+    RB29_TAKE(o, c0, c1, side)
+    return rr::mk2(rr::mk<1, 1>(c0), rr::mk<1, 1>(c1));
+#else
+    return rr::mk2(y, y);
 #endif
   }
   __device__ __forceinline__ F6 ld_x() const { return *x; }
@@ -176,13 +202,12 @@ struct DevMultiAcc29 {
     ld_n<2>(j, 23, 27, e);
     return rr::MillerP29{e[0], e[1]};
   }
-  __device__ __forceinline__ rr::Line29 line(int j, int n) const {
+  __device__ __forceinline__ rr::LineU29 line_u(int j, int n) const {
     const uint4* p = lines29 + ((size_t)qref[j] * RB_MILLER_LINES + n) * RR_LINE_QUADS;
-    const uint4 t0 = p[12], t1 = p[13];
-    rr::Line29 r;
-    r.cy = rr::mk2(rr_from_quads(p[0], p[1], t0.x), rr_from_quads(p[2], p[3], t0.y));
-    r.cx = rr::mk2(rr_from_quads(p[4], p[5], t0.z), rr_from_quads(p[6], p[7], t0.w));
-    r.c0 = rr::mk2(rr_from_quads(p[8], p[9], t1.x), rr_from_quads(p[10], p[11], t1.y));
+    const uint4 t0 = p[8];
+    rr::LineU29 r;
+    r.cx = rr::mk2(rr_from_quads(p[0], p[1], t0.x), rr_from_quads(p[2], p[3], t0.y));
+    r.c0 = rr::mk2(rr_from_quads(p[4], p[5], t0.z), rr_from_quads(p[6], p[7], t0.w));
     return r;
   }
   // once, before the loop: the lane's arguments in the field core's representation
@@ -395,10 +420,9 @@ int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* 
   return RHIP_OK;
 }
 
-#ifdef RB_DIAG          // diagnostic build only (tools/build_diag.sh): even an unused extra kernel in this unit changes the code the compiler emits for the others
 // ---- micro-benchmark of the out-of-line routines at the kernels' own occupancy (one wave per SIMD, the 152 KB home: a block owns a CU): shader
-// cycles per call, measured inside the kernel (s_memtime), per wave.  which: 0 rr_dot3_core, 2 mul2_core, 3 the empty loop.
-// tools/ubench_cores.py prints the table; not part of the product path.
+// cycles per call, measured inside the kernel (s_memtime), per wave.  which: 0 rr_dot3_core, 1 rr_dot3s_core, 2 mul2_core, 3 sqr2_sd_core-free
+// baseline (empty loop).  tools/ubench_cores.py prints the table; not part of the product path.
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_ubench_cores(uint32_t iters, int which, uint64_t* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -416,6 +440,7 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_ubench_cores(uint32_t it
     const int ia = (int)(it % 6), ib = (int)((it + 1) % 6), ic = (int)((it + 3) % 6);
     rr::Out16 o;
     if (which == 0) o = rr_dot3_core(a, b, ia, ib, ic);
+    else if (which == 1) o = rr_dot3s_core(a, ia, ib, ic);
     else if (which == 2) { rr::i32x4 lo; lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; lo[3] = b[3]; o = rr::mul2_core(a, b, a, lo); }
     else { o.lo0 = (rr::i32x8)(0); o.lo1 = (rr::i32x8)(0); }
     a[0] = (a[0] ^ (o.lo0[0] & 1)) & 0x0fffffff;          // a dependence from call to call, as in the loop
@@ -441,7 +466,6 @@ extern "C" int32_t rhip_debug_ubench_cores(rhip_ctx* ctx, uint32_t iters, int32_
   KLAUNCH(ctx, "k_ubench_cores", k_ubench_cores, dim3(blocks), dim3(RB_MILLER_BLOCK), 0, ctx->stream, iters, (int)which, d_out);
   return RHIP_OK;
 }
-#endif
 
 // When it runs: pairing mode 29 (rhip_ctx_set_pairing_mode / RABE_PAIRING_MODE) -- every multi-pairing launch; mode 0 (auto) -- the launches
 // the six-lane kernels do not take (the caller asks rhip_use_c6 first), unless RABE_RR=0 (A/B runs, and the conservative switch).
@@ -449,22 +473,26 @@ bool rhip_use_rr(const rhip_ctx* ctx) {
   static const int on = getenv("RABE_RR") ? atoi(getenv("RABE_RR")) : 1;
   return ctx->pairing_mode == 29 || (on != 0 && ctx->pairing_mode == 0);
 }
-// one lane per prepared triple: six conversions, written as the 14-quad record line() reads
+// one lane per prepared triple (cy, cx, c0): divided by its y-coefficient -- cx / cy, c0 / cy, the unit-y form pairing29.h's facc_ell_u takes (the
+// factor lies in Fq2 and dies in the final exponentiation) -- and converted: the 9-quad record line_u() reads (4 x 8 limbs, then the 4 top limbs)
 __global__ void __launch_bounds__(256) k_lines_to_rr(size_t n, const LineM* in, uint4* out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint4* p = (const uint4*)(in + t);
+  const Fp2 cy{ld_fp_q(p), ld_fp_q(p + 2)}, cx{ld_fp_q(p + 4), ld_fp_q(p + 6)}, c0{ld_fp_q(p + 8), ld_fp_q(p + 10)};
+  const Fp2 iy = fp2_inv(cy);          // cy = 0 only for arguments outside G2 (the chord / tangent of a point of order <= 2): the line stays 0
+  const Fp2 ux = fp2_mul(cx, iy), u0 = fp2_mul(c0, iy);
+  const Fp e[4] = {ux.c0, ux.c1, u0.c0, u0.c1};
   uint4* o = out + t * RR_LINE_QUADS;
-  uint32_t top[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t top[4];
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const F v = rr::from_fp(ld_fp_q(p + 2 * k));
+  for (int k = 0; k < 4; k++) {
+    const F v = rr::from_fp(e[k]);
     o[2 * k] = rr_quad(v, 0);
     o[2 * k + 1] = rr_quad(v, 1);
     top[k] = (uint32_t)v.l[8];
   }
-  o[12] = make_uint4(top[0], top[1], top[2], top[3]);
-  o[13] = make_uint4(top[4], top[5], top[6], top[7]);
+  o[8] = make_uint4(top[0], top[1], top[2], top[3]);
 }
 int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void** out) {
   HIP_TRY(ctx, hipMalloc(out, n_lines * RR_LINE_QUADS * sizeof(uint4)));

@@ -497,10 +497,12 @@ struct HostMultiAcc29 {
   int kind(int j) const { return kinds[j]; }
   rr::MillerP29 p(int j) const { return rr::MillerP29{rr::from_fp(P[j].x), rr::from_fp(P[j].y)}; }
   rr::G2Aff29 q(int j) const { return rr::G2Aff29{rr::from_fp2(Q[j].x), rr::from_fp2(Q[j].y)}; }
-  rr::Line29 line(int j, int k) const {
+  rr::F2 dot3s(const rr::F& s, int ia, int ib, int ic) const { return rr::dot3s(f2(ia), s, f2(ib), Y[1], f2(ic), Y[2]); }
+  rr::LineU29 line_u(int j, int k) const {          // what engine_rr.hip's k_lines_to_rr stores: the line divided by its y-coefficient
     const LineCoeffs& l = lines[j * RB_MILLER_LINES + k];
-    rr::Line29 r;
-    r.cy = rr::from_fp2(l.cy); r.cx = rr::from_fp2(l.cx); r.c0 = rr::from_fp2(l.c0);
+    const Fp2 iy = fp2_inv(l.cy);
+    rr::LineU29 r;
+    r.cx = rr::from_fp2(fp2_mul(l.cx, iy)); r.c0 = rr::from_fp2(fp2_mul(l.c0, iy));
     return r;
   }
   rr::G2Hom29 ld_t(int j) const { return T[j]; }

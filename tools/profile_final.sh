@@ -13,6 +13,6 @@ bash tools/trace_tail.sh "pairing final-exp"
 cp gpurun_out/timeline_tail_pairing.txt gpurun_out/${TAG}_timeline_tail_miller_resident.txt
 cp gpurun_out/timeline_tail_final-exp.txt gpurun_out/${TAG}_timeline_tail_final_exp.txt
 bash tools/ab_tail.sh > gpurun_out/${TAG}_ab_tail.txt 2>&1
-RABE_HIP_LIB=build/variants/libdiag.so python tools/ubench_cores.py 2000 > gpurun_out/${TAG}_ubench_cores.txt 2>&1
+python tools/ubench_cores.py 2000 > gpurun_out/${TAG}_ubench_cores.txt 2>&1
 [ -f build/variants/libdiag.so ] && bash tools/prof_miller.sh > gpurun_out/${TAG}_prof_miller.txt 2>&1
 ls gpurun_out | grep ${TAG}

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Shader cycles per call of the reduced-radix kernels' out-of-line routines at their own occupancy (one wave per SIMD, every CU busy):
-rhip_debug_ubench_cores (engine_rr.hip: k_ubench_cores, compiled into the diagnostic library only -- tools/build_diag.sh).
-usage: RABE_HIP_LIB=build/variants/libdiag.so python tools/ubench_cores.py [iters=2000]"""
+rhip_debug_ubench_cores (engine_rr.hip: k_ubench_cores).  usage: python tools/ubench_cores.py [iters=2000]"""
 import ctypes
 import struct
 import sys
@@ -13,14 +12,14 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 eng = Engine(0)
 blocks = 256
 out = eng.alloc(blocks * 4 * 8)
-names = {0: "rr_dot3_core", 2: "mul2_core", 3: "empty loop"}
+names = {0: "rr_dot3_core", 1: "rr_dot3s_core", 2: "mul2_core", 3: "empty loop"}
 res = {}
 for rep in range(2):
-    for which in (3, 0, 2):
+    for which in (3, 0, 1, 2):
         eng._check(eng.lib.rhip_debug_ubench_cores(eng.ctx, ctypes.c_uint32(iters), ctypes.c_int32(which), ctypes.c_uint32(blocks), out.ptr))
         raw = eng.download(out, blocks * 4 * 8)
         v = struct.unpack("<%dQ" % (blocks * 4), raw)
         res[which] = (sum(v) / len(v) / iters, min(v) / iters, max(v) / iters)
-for which in (3, 0, 2):
+for which in (3, 0, 1, 2):
     m, lo, hi = res[which]
     print("%-14s %8.1f cycles per call (min %.1f, max %.1f over %d waves)" % (names[which], m, lo, hi, blocks * 4))
