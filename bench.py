@@ -453,7 +453,7 @@ def main():
     result = {
         "metric": "ABE ops/sec (AC17 CP-ABE encrypt+decrypt)", "value": round(value, 2), "unit": "ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "exact BN254 integers in 32-bit limbs (Montgomery: 8 x 32 bits; 9 signed x 29 bits in the pairing kernels of full launches)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "exact BN254 integers in 32-bit limbs (Montgomery: 8 x 32 bits; 9 signed x 29 bits in the pairing kernels of full launches)",
         "data": "synthetic", "roundtrip_bit_exact": ok,
         "timed_regions": regions_summary(regions, args.steps),
         "config": {"workload": "AC17 CP-ABE, %d-attribute random binary AND/OR MSP policies (%d distinct), batch %d encrypt+decrypt per GPU"
@@ -760,6 +760,7 @@ def configs_leg(args):
     env = dict(os.environ)
     for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k_, None)
+    env["RABE_BENCH_FULL_LINE"] = "1"          # the sub-runs hand their whole object over the pipe (benchkit.lib.emit_line)
     # (key, config, steps, extra flags, items of the CPU sample): "3_mixed" is SURVEY 8d's 50 %-OR variant of config 3, the "_ragged" legs draw
     # every policy's leaf count from 10 .. the config's (a batch of mixed shapes)
     legs = (("2_ragged", 2, 16, ["--ragged", "--no-single-batch", "--no-configs-leg", "--no-host-io-leg", "--wide-window", "0"], 0),

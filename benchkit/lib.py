@@ -89,13 +89,157 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
+# ---------------------------------------------------------------------------------------------------------------- the printed line
+# The driver keeps a bounded tail of stdout and parses its LAST line: round 5's 20 KB object did not survive that (BENCH_r05.parsed =
+# null).  So stdout carries ONE compact JSON line (<= COMPACT_LIMIT bytes, the contract's keys + `roofline` + `cpu_baseline` + the
+# headline's neighbours + configs 3-5); everything else -- prose notes, the object-level legs, ragged legs, per-kernel maps -- goes to
+# bench_detail.json beside the script (and under gpurun_out/ when that exists) and, as one line, to STDERR.
+COMPACT_LIMIT = 4096
+_CONFIG_KEYS = ("workload", "batch_per_gpu", "attrs", "policies", "steps_per_launch_set", "parallelism", "device", "pairing_mode",
+                "launch_sets_in_flight", "tree", "ragged")
+_ROOFLINE_KEYS = ("bound", "kernel", "kernel_ms", "items_per_launch", "achieved", "peak", "unit", "frac", "frac_survey", "achieved_survey",
+                  "traffic", "traffic_source", "kernels_ms_sum_per_step")
+_CPU_KEYS = ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
+_GATHER_KEYS = ("backend", "ms", "bytes", "ok", "records_match_unsharded", "collective")
+
+
+def _num(v):
+    """strict JSON has no NaN / Infinity: they become null"""
+    if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+        return None
+    return v
+
+
+def _clean(o):
+    if isinstance(o, dict):
+        return {str(k): _clean(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v) for v in o]
+    return _num(o)
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1].rstrip() + "~"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(result):
+    """The driver-parseable form of a bench result: contract keys, `roofline`, `cpu_baseline`, neighbours, configs 3-5.  Prose is cut to a
+    few dozen characters; whatever does not fit COMPACT_LIMIT is dropped from the least important end (never the contract keys)."""
+    r = _clean(result)
+    out = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        out[k] = r.get(k)
+    out["dtype"] = _short(r.get("dtype", ""), 24)
+    out["data"] = r.get("data")
+    if "roundtrip_bit_exact" in r:
+        out["roundtrip_bit_exact"] = r["roundtrip_bit_exact"]
+    cfg = r.get("config") if isinstance(r.get("config"), dict) else {}
+    c = _pick(cfg, _CONFIG_KEYS)
+    if "workload" in c:
+        c["workload"] = _short(c["workload"], 150)
+    if "parallelism" in c:
+        c["parallelism"] = _short(c["parallelism"], 60)
+    out["config"] = c
+    rf = r.get("roofline")
+    if isinstance(rf, dict):
+        o = _pick(rf, _ROOFLINE_KEYS)
+        if "bound" in o:
+            o["bound"] = _short(o["bound"], 64)
+        if "traffic" not in o:
+            o["traffic"] = None
+        out["roofline"] = o
+    cb = r.get("cpu_baseline")
+    if isinstance(cb, dict):
+        o = _pick(cb, _CPU_KEYS)
+        if "sample" in o:
+            o["sample"] = _short(o["sample"], 96)
+        out["cpu_baseline"] = o
+    mc = r.get("cpu_baseline_multicore")
+    if isinstance(mc, dict) and "value" in mc:
+        out["cpu_baseline_multicore"] = _pick(mc, ("value", "cores"))
+    for k in ("value_lone_batch", "value_end_to_end", "value_end_to_end_inflight2"):
+        if r.get(k) is not None:
+            out[k] = r[k]
+    if isinstance(r.get("gather"), dict):
+        out["gather"] = _pick(r["gather"], _GATHER_KEYS) or {k: v for k, v in r["gather"].items() if not isinstance(v, (str, dict, list))}
+    cfs = r.get("configs")
+    if isinstance(cfs, dict):
+        oc = {}
+        for k in sorted(cfs):
+            v = cfs[k]
+            if not isinstance(v, dict):
+                continue
+            if "error" in v and "value" not in v:
+                oc[k] = {"error": _short(v["error"], 60)}
+                continue
+            rr = v.get("roofline") if isinstance(v.get("roofline"), dict) else {}
+            e = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "steps": v.get("steps"), "batch_per_gpu": v.get("batch_per_gpu"),
+                 "kernel_ms": rr.get("kernel_ms"), "frac": rr.get("frac"), "frac_survey": rr.get("frac_survey"),
+                 "roundtrip_bit_exact": v.get("roundtrip_bit_exact")}
+            if isinstance(v.get("cpu_baseline"), dict):
+                e["cpu_baseline"] = _pick(v["cpu_baseline"], ("value", "cores", "kind"))
+            oc[k] = {kk: vv for kk, vv in e.items() if vv is not None}
+        out["configs"] = oc
+    out["detail"] = "bench_detail.json"
+
+    def size():
+        return len(json.dumps(out, allow_nan=False, separators=(",", ":")))
+    # shrink from the least important end; the contract keys, roofline and cpu_baseline are never touched
+    if size() > COMPACT_LIMIT and "configs" in out:
+        for k in [k for k in list(out["configs"]) if not k.isdigit()]:          # ragged / mixed neighbours of the BASELINE configs first
+            del out["configs"][k]
+            if size() <= COMPACT_LIMIT:
+                break
+    for k in ("cpu_baseline_multicore", "gather", "configs"):
+        if size() > COMPACT_LIMIT and k in out:
+            del out[k]
+    if size() > COMPACT_LIMIT and "sample" in out.get("cpu_baseline", {}):
+        del out["cpu_baseline"]["sample"]
+    assert size() <= COMPACT_LIMIT, size()
+    return out
+
+
+def write_detail(result, root=None):
+    """bench_detail.json: the full result object (every leg, every note) -- beside bench.py and, on a gpurun box, under gpurun_out/"""
+    import os
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = json.dumps(_clean(result), allow_nan=False)
+    written = []
+    for d in (root, os.path.join(root, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text + "\n")
+                written.append(d)
+            except OSError:
+                pass
+    return text, written
+
+
 def emit_line(result):
-    """rank 0's ONE JSON line, as the LAST line of stdout: RCCL writes a version banner through C stdio, which would otherwise be flushed
-    at exit -- after the line (found on the GPU box, RABE_FORCE_DIST run) -- so everything buffered is flushed first."""
+    """rank 0's ONE JSON line, as the LAST line of stdout (and the only JSON on stdout): RCCL writes a version banner through C stdio,
+    which would otherwise be flushed at exit -- after the line (found on the GPU box, RABE_FORCE_DIST run) -- so everything buffered is
+    flushed first.  The full object goes to bench_detail.json and to stderr."""
     import ctypes
+    import os
+    if os.environ.get("RABE_BENCH_FULL_LINE"):          # a sub-run of bench.py's configs leg: the parent reads the whole object from the pipe
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(_clean(result), allow_nan=False), flush=True)
+        return
+    text, _ = write_detail(result)
     sys.stdout.flush()
+    print("bench_detail: " + text, file=sys.stderr, flush=True)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(result), flush=True)
+    print(json.dumps(compact_line(result), allow_nan=False, separators=(",", ":")), flush=True)

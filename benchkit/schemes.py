@@ -102,7 +102,7 @@ class SchemeRunner:
         result = {
             "metric": b.metric, "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "exact BN254 integers in 32-bit limbs (Montgomery: 8 x 32 bits; 9 signed x 29 bits in the pairing kernels of full launches)", "data": "synthetic", "roundtrip_bit_exact": ok,
+            "dtype": "u32", "dtype_note": "exact BN254 integers in 32-bit limbs (Montgomery: 8 x 32 bits; 9 signed x 29 bits in the pairing kernels of full launches)", "data": "synthetic", "roundtrip_bit_exact": ok,
             "timed_regions": regions_summary(regions, args.steps),
             "config": dict(b.describe(), batch_per_gpu=B, steps_per_launch_set=sizes, launch_sets_in_flight=S,
                            hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default"),
