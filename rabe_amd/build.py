@@ -76,6 +76,39 @@ def stale():
     return any(os.path.getmtime(d) > t for d in _headers() + [s for s in SOURCES if os.path.exists(s)])
 
 
+def declared_symbols():
+    """the C API: every function include/rabe_hip.h (rhip_*) and include/rabe_host.h (rabe_*) declare"""
+    import re
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    out = set()
+    for header, prefix in (("rabe_hip.h", "rhip_"), ("rabe_host.h", "rabe_")):
+        text = open(os.path.join(inc, header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # macros (rabe_host_open) are not symbols
+        out |= set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text))
+    return sorted(out)
+
+
+def _version_script():
+    """build/obj/exports.map: the dynamic symbol table of the library is EXACTLY the two headers' function lists -- no std:: / rabe:: C++
+    symbols for a Rust or C++ host to interpose (the C convention of the reference's own FFI, src/ffi/bsw.rs:22-163)."""
+    path = os.path.join(OBJ, "exports.map")
+    text = "RABE_AMD {\n  global:\n" + "".join("    %s;\n" % s for s in declared_symbols()) + "  local:\n    *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
+LINK_FLAGS = ["-static-libstdc++", "-static-libgcc"] if os.environ.get("RABE_STATIC_CXX") else []
+
+
+def _link(out, objs, verbose):
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + _version_script(), "-o", out] + LINK_FLAGS + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, timeout=600)
+
+
 def _compile(src, verbose, safe=False):
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", _obj(src, safe)] + _unit_flags(src) + _flags() + (["-DRB_SAFE_CARRY"] if safe else [])
     if verbose:
@@ -99,10 +132,7 @@ def build(force=False, verbose=False):
             for f in [ex.submit(_compile, s, verbose) for s in todo]:
                 f.result()
     open(flags_tag, "w").write(tag)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in srcs]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, timeout=600)
+    _link(LIB, [_obj(s) for s in srcs], verbose)
     return LIB
 
 
@@ -120,10 +150,7 @@ def build_safe(force=False, verbose=False):
             for f in [ex.submit(_compile, s, verbose, True) for s in todo]:
                 f.result()
     srcs = [s for s in SOURCES if os.path.exists(s)]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_SAFE] + [_obj(s, s in DEVICE_SOURCES) for s in srcs]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, timeout=600)
+    _link(LIB_SAFE, [_obj(s, s in DEVICE_SOURCES) for s in srcs], verbose)
     return LIB_SAFE
 
 

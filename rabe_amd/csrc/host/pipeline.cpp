@@ -106,27 +106,43 @@ Cut cut(size_t n_engines, size_t n, size_t min_chunk) {
 }
 // run(k, engine) for every chunk; the first exception is rethrown after all workers ended.  One engine: `lanes` chunks at a time on its
 // lanes, chunks handed out in order.  A group: chunk k on engine k, lane 0, one thread each, the engine's device current in that thread.
-void fan_out(const std::vector<Engine*>& engines, const Cut& c, const std::function<void(size_t, Engine&)>& run) {
+//
+// In a group chunk w belongs to worker w alone, so a worker that fails BEFORE run(w) (its device cannot be made current, its lane cannot be
+// set up) leaves a chunk nobody will run: `never_runs(w)` tells the caller, which must let the chunks behind it go on (produce: the draw
+// gate would otherwise keep every later chunk waiting for w's turn and the join below would never return).  With one engine the other
+// workers take the chunk.  RABE_FAULT_GROUP_WORKER=w injects exactly that failure (tests/test_gpu_device_group.py).
+void fan_out(const std::vector<Engine*>& engines, const Cut& c, const std::function<void(size_t, Engine&)>& run,
+             const std::function<void(size_t)>& never_runs = nullptr) {
   std::atomic<size_t> next{0};
   std::mutex mu;
   std::exception_ptr first;
   const bool group = engines.size() > 1;
   if (!group) engines[0]->ensure_lanes(c.lanes);
+  const char* fault_env = group ? getenv("RABE_FAULT_GROUP_WORKER") : nullptr;
+  const long fault_w = (fault_env && *fault_env) ? atol(fault_env) : -1;
   auto work = [&](size_t w) {
     Engine& eng = *engines[group ? w : 0];
+    bool entered = false;
     try {
+      if ((long)w == fault_w) throw RabeError("device group: worker " + std::to_string(w) + " failed before its block started (injected fault)");
       eng.make_current();
       Engine::Busy working(eng);
       Engine::LaneScope scope(group ? 0 : (int)w);
       for (;;) {
         const size_t k = group ? w : next.fetch_add(1);
         if (k >= c.chunks) return;
+        entered = true;
         run(k, eng);
         if (group) return;
       }
     } catch (...) {
-      std::lock_guard<std::mutex> g(mu);
-      if (!first) first = std::current_exception();
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (!first) first = std::current_exception();
+      }
+      if (group && !entered && w < c.chunks && never_runs) {
+        try { never_runs(w); } catch (...) {}
+      }
     }
   };
   std::vector<std::thread> th;
@@ -154,7 +170,7 @@ bool produce(const std::vector<Engine*>& engines, Rng& rng, size_t n, size_t min
     std::vector<uint64_t> off(hi - lo + 1);
     if (!call(eng, lo, hi, r, out_buf + out_off[lo], (size_t)(out_off[hi] - out_off[lo]), off.data())) ok = false;
     else if (off[hi - lo] != out_off[hi] - out_off[lo]) throw RabeError("pipelined batch: a chunk's records do not have the announced size");
-  });
+  }, [&](size_t k) { gate.enter(k); gate.leave(k); });          // a block that never started takes its turn at the draw gate and passes it on
   return ok;
 }
 

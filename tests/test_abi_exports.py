@@ -49,6 +49,19 @@ def test_every_declared_symbol_is_exported(lib):
     assert missing == []
 
 
+def test_dynamic_symbol_table_is_exactly_the_two_headers():
+    """rabe_amd/build.py links with a version script: nothing but the C API is exported -- no std:: / rabe:: C++ symbols, no kernel stubs
+    (a Rust or C++ host that links the library must not inherit libstdc++ interposition; the C convention of src/ffi/bsw.rs:22-163)."""
+    import subprocess
+    from rabe_amd import build
+    for path in (build.build(), build.LIB_SAFE):
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, stdout=subprocess.PIPE).stdout.decode()
+        exported = sorted(line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip() and line.split()[-1] != "RABE_AMD")
+        assert exported == declared_symbols() == build.declared_symbols(), (sorted(set(exported) ^ set(declared_symbols())), path)
+
+
 def test_no_cpu_fallback_without_device(lib):
     import torch
     if torch.cuda.is_available():

@@ -129,3 +129,41 @@ def test_aw11_group_equals_single_engine(hosts):
             assert not got[4].any() and got[2].tobytes() == b"".join(pts)
         else:
             assert same(ref, got), "group of %d engines differs from the single engine" % g
+
+
+@pytest.mark.parametrize("bad", [0, 1])
+def test_a_worker_that_fails_before_its_block_is_an_error_not_a_hang(hosts, bad, monkeypatch):
+    """pipeline.cpp: fan_out -- in a group, chunk w belongs to worker w alone; if that worker fails before run(w) (injected here), the chunk
+    never takes its turn at the draw gate.  The call has to come back with the error, and the group has to work afterwards."""
+    import threading
+    from rabe_amd.schemes import ac17
+    h = hosts[2]
+    pk, _msk = ac17.setup(hosts[1])
+    n = 6
+    pts = [b"fault-%d" % i for i in range(n)]
+    tape = [7919 * (i + 3) for i in range(4 * n)]
+    box = {}
+
+    def call():
+        try:
+            h.set_tape(tape)
+            box["out"] = ac17.cp_encrypt_packed(h, pk, AC_POLS, [i % 3 for i in range(n)], b"".join(pts), offsets(pts), hl.HUMAN_POLICY)
+        except Exception as ex:          # the C ABI's error, as hostlib raises it
+            box["err"] = ex
+        finally:
+            h.clear_tape()
+
+    monkeypatch.setenv("RABE_FAULT_GROUP_WORKER", str(bad))
+    t = threading.Thread(target=call, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "the packed call hangs when worker %d fails before its block" % bad
+    assert "err" in box and "injected fault" in str(box["err"]), box
+    monkeypatch.delenv("RABE_FAULT_GROUP_WORKER")
+    h.set_tape(tape)
+    blob, off = ac17.cp_encrypt_packed(h, pk, AC_POLS, [i % 3 for i in range(n)], b"".join(pts), offsets(pts), hl.HUMAN_POLICY)
+    h.clear_tape()
+    hosts[1].set_tape(tape)
+    blob1, off1 = ac17.cp_encrypt_packed(hosts[1], pk, AC_POLS, [i % 3 for i in range(n)], b"".join(pts), offsets(pts), hl.HUMAN_POLICY)
+    hosts[1].clear_tape()
+    assert np.array_equal(blob, blob1) and np.array_equal(off, off1)
