@@ -85,8 +85,9 @@ def parse_args():
     ap.add_argument("--min-time", type=float, default=1.0,
                     help="the K-step timed region is repeated until this many seconds have been timed; every region times exactly --steps steps")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for experiments (0 = leave the HIP default)")
-    ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3, 6],
-                    help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (identical results)")
+    ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3, 6, 29, 99],
+                    help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per accumulator, 29 reduced radix "
+                         "(identical results); 99 cross-check of all families on every launch (not a measurement)")
     ap.add_argument("--g-window", type=int, default=20,
                     help="window width (bits) of the fixed-base table of g: 16 (67 MB, unsigned digits), or 17..27 signed digits "
                          "(20: 0.4 GB -- the default, a third of what the key's other tables take; 24: 5.4 GB; 26: 19 GB, reported as value_wide_tables)")

@@ -100,7 +100,6 @@ _CONFIG_KEYS = ("workload", "batch_per_gpu", "attrs", "policies", "steps_per_lau
 _ROOFLINE_KEYS = ("bound", "kernel", "kernel_ms", "items_per_launch", "achieved", "peak", "unit", "frac", "frac_survey", "achieved_survey",
                   "traffic", "traffic_source", "kernels_ms_sum_per_step")
 _CPU_KEYS = ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
-_GATHER_KEYS = ("backend", "ms", "bytes", "ok", "records_match_unsharded", "collective")
 
 
 def _num(v):
@@ -165,8 +164,9 @@ def compact_line(result):
     for k in ("value_lone_batch", "value_end_to_end", "value_end_to_end_inflight2"):
         if r.get(k) is not None:
             out[k] = r[k]
-    if isinstance(r.get("gather"), dict):
-        out["gather"] = _pick(r["gather"], _GATHER_KEYS) or {k: v for k, v in r["gather"].items() if not isinstance(v, (str, dict, list))}
+    if isinstance(r.get("gather"), dict):          # every field but prose: backend, collective, bytes, ms, matches_unsharded_order
+        out["gather"] = {k: (v if not isinstance(v, str) else _short(v, 40)) for k, v in r["gather"].items()
+                         if not isinstance(v, (dict, list)) and k not in ("note",)}
     cfs = r.get("configs")
     if isinstance(cfs, dict):
         oc = {}

@@ -68,6 +68,10 @@ int32_t rhip_ctx_timing_read(rhip_ctx* ctx, char* buf, size_t len);
  * otherwise), 1 = always one lane, 3 = three lanes per pairing (pairwise paths), 6 = six lanes per Fq12 accumulator
  * (k_miller_c6 / k_final_exp_c6: one Fq2 coefficient per lane), 29 = one lane per item and chunk on the reduced-radix field core
  * (k_miller_multi_rr: 9 x 29-bit limbs; what mode 0 takes for launches that fill the chip).  Results are identical.
+ * 99 = cross-check: every multi-pairing launch runs as mode 0 would run it (the caller gets that result) and again with modes 1, 6 and 29
+ * forced -- Miller loops and final exponentiation of each family on the same pair lists -- and the results are compared on the device; a
+ * difference fails the call (RHIP_ERR_HIP, the families named in rhip_last_error).  Synchronous and about four times the pairing work: a
+ * self-check for tests and suspect devices, not a production mode.
  * RABE_PAIRING_MODE in the environment of rhip_ctx_create presets the mode (A/B runs). */
 int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode);
 /* number of compute units / device name of the context's GPU */

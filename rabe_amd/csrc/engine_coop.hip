@@ -362,8 +362,8 @@ void rhip_choose_chunks_c6(const rhip_ctx* ctx, size_t n_items, size_t max_pairs
 }
 // max_pairs == 0: the question is about the final exponentiation of n_items items
 bool rhip_use_c6(const rhip_ctx* ctx, size_t n_items, size_t max_pairs) {
-  if (ctx->pairing_mode == 6) return true;
-  if (ctx->pairing_mode != 0) return false;
+  if (rhip_mode(ctx) == 6) return true;
+  if (rhip_mode(ctx) != 0) return false;
   static const int auto_on = getenv("RABE_C6_AUTO") ? atoi(getenv("RABE_C6_AUTO")) : 1;
   if (!auto_on) return false;
   const size_t simds = (size_t)ctx->n_cu * 4;
@@ -454,8 +454,8 @@ int32_t rhip_launch_gt_is_member_c6(rhip_ctx* ctx, size_t n, const rhip_gt* a, u
 }
 // the fixed-base Gt kernels: 32 (16-bit windows) or 64 dependent products per item in one lane against ~5 k instructions each here
 bool rhip_use_c6_gt_pow(const rhip_ctx* ctx, size_t n_items) {
-  if (ctx->pairing_mode == 6) return true;
-  if (ctx->pairing_mode != 0) return false;
+  if (rhip_mode(ctx) == 6) return true;
+  if (rhip_mode(ctx) != 0) return false;
   static const int auto_on = getenv("RABE_C6_AUTO") ? atoi(getenv("RABE_C6_AUTO")) : 1;
   return auto_on && n_items <= (size_t)ctx->n_cu * 4 * 32;
 }

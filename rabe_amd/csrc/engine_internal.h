@@ -47,11 +47,12 @@ struct rhip_ctx {
   void* fe_ws = nullptr;
   size_t fe_ws_bytes = 0;
   // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
-  enum { N_WORK = 12 };
+  enum { N_WORK = 14 };          // 12, 13: the cross-check mode's second result buffer and its snapshot of an in-place factor (engine_jobs.hip)
   void* work[N_WORK] = {};
   size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg
-  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per Fq12 accumulator (engine_coop.hip)
+  int pairing_mode = 0;   // 0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per Fq12 accumulator (engine_coop.hip),
+                          // 29 reduced radix (engine_rr.hip), 99 cross-check: auto, and every other family of kernels on the same inputs, compared on the device
   void* fe_started = nullptr;      // device counter of resident final-exponentiation waves (rhip_ctx_release_before_final_exp)
   uint32_t* walk_fail = nullptr;    // one-shot (rhip_ctx_collect_walk_verdicts): per-item verdict / count arrays of the next pair-list launch
   uint32_t* walk_count = nullptr;
@@ -70,6 +71,9 @@ struct rhip_ctx {
 void rhip_ktime_begin(rhip_ctx* ctx, const char* name);
 void rhip_ktime_end(rhip_ctx* ctx);
 int32_t rhip_fail(rhip_ctx* ctx, hipError_t e, const char* what);
+// the mode the kernel-selection predicates see: the cross-check mode (99) selects as "auto" does (engine_jobs.hip: run_pair_lists forces the
+// other families one after the other)
+static inline int rhip_mode(const rhip_ctx* ctx) { return ctx->pairing_mode == 99 ? 0 : ctx->pairing_mode; }
 // fork: the side streams wait for everything queued on ctx->stream so far; join: ctx->stream waits for what was queued on them since.
 // Between the two, `RhipOnFork f(ctx, i)` makes ctx->stream side stream i for the launches in its scope.
 int32_t rhip_fork(rhip_ctx* ctx);

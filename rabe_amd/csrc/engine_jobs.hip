@@ -516,7 +516,64 @@ __global__ void __launch_bounds__(256) k_plan_fill(size_t n_items, const uint32_
   }
 }
 // Miller values of all items' pairs + final exponentiation: out[i] = mul_in[i] * FE(prod_j ML(P_j, Q_j))
+static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
+                                   const LineM* lines, const void* lines29, const rhip_gt* mul_in, rhip_gt* out);
+// ---- pairing mode 99, the cross-check: the launch runs as "auto" would run it (that result is the one the caller gets, walk verdicts and early
+// releases included), then AGAIN with each family of pairing kernels forced -- one lane per accumulator on 8 x 32-bit limbs (1), six lanes (6),
+// reduced radix (29): Miller loops AND final exponentiation of that family -- on the same pair lists, and every result is compared with the
+// first on the device, byte for byte.  A difference fails the call.  The three families compute the same field elements by construction
+// (docs/coop6.md, docs/rr29.md); this mode is how the GPU test suite holds them to it on every pairing launch of every scheme
+// (tests/conftest.py) and what an operator can switch on to have a suspect device check itself.
+// RABE_XCHECK_FAULT=<family> flips one bit of that family's result before the comparison (tests/test_gpu_xcheck.py: the check must notice).
+__global__ void __launch_bounds__(256) k_xcheck_compare(size_t n_quads, const uint4* a, uint4* b, uint32_t bit, uint32_t flip, uint32_t* flag) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_quads) return;
+  uint4 y = b[t];
+  if (flip && t == n_quads / 2) y.y ^= 0x10000u;
+  const uint4 x = a[t];
+  if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) atomicOr(flag, bit);
+}
 static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
+                              const LineM* lines, const void* lines29, const rhip_gt* mul_in, rhip_gt* out) {
+  if (ctx->pairing_mode != 99) return run_pair_lists_mode(ctx, n_items, pair_off, max_pairs, total_pairs, pl, lines, lines29, mul_in, out);
+  struct Restore { rhip_ctx* c; ~Restore() { c->pairing_mode = 99; } } restore{ctx};
+  const size_t bytes = n_items * sizeof(rhip_gt);
+  void* tmp = nullptr;
+  int32_t rc = rhip_ensure_work(ctx, 12, bytes + 256, &tmp);
+  if (rc) return rc;
+  uint32_t* flag = (uint32_t*)((uint8_t*)tmp + bytes);
+  HIP_TRY(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+  const rhip_gt* factor = mul_in;
+  if (mul_in && (const void*)mul_in == (const void*)out) {          // in place: the other families need the factor as it was
+    void* keep = nullptr;
+    rc = rhip_ensure_work(ctx, 13, bytes, &keep);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(keep, mul_in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    factor = (const rhip_gt*)keep;
+  }
+  ctx->pairing_mode = 0;
+  rc = run_pair_lists_mode(ctx, n_items, pair_off, max_pairs, total_pairs, pl, lines, lines29, factor, out);
+  if (rc) return rc;
+  const int fault = getenv("RABE_XCHECK_FAULT") ? atoi(getenv("RABE_XCHECK_FAULT")) : 0;
+  static const int families[3] = {1, 6, 29};
+  for (int f = 0; f < 3; f++) {
+    ctx->pairing_mode = families[f];
+    rc = run_pair_lists_mode(ctx, n_items, pair_off, max_pairs, total_pairs, pl, lines, lines29, factor, (rhip_gt*)tmp);
+    if (rc) return rc;
+    KLAUNCH(ctx, "k_xcheck_compare", k_xcheck_compare, dim3(blocks_for(bytes / 16, 256)), dim3(256), 0, ctx->stream, bytes / 16, (const uint4*)out, (uint4*)tmp,
+            1u << f, (uint32_t)(fault == families[f]), flag);
+  }
+  uint32_t h = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (h) {
+    ctx->err = std::string("pairing cross-check: the kernel families disagree on this launch (differing from the automatic choice:") + ((h & 1) ? " one-lane 8x32" : "") +
+               ((h & 2) ? " six-lane" : "") + ((h & 4) ? " reduced-radix" : "") + ")";
+    return RHIP_ERR_HIP;
+  }
+  return RHIP_OK;
+}
+static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t* pair_off, size_t max_pairs, size_t total_pairs, const PairLists& pl,
                               const LineM* lines, const void* lines29, const rhip_gt* mul_in, rhip_gt* out) {          // pair_off == NULL: every item owns max_pairs pairs
   if (pair_off && total_pairs && total_pairs < n_items * max_pairs && !getenv("RABE_NO_MILLER_PLAN")) {
     // ragged: plan on the device.  Bounds of what the plan may choose: no fewer pairs per chunk than four rounds' worth of lanes need

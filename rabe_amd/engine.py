@@ -131,7 +131,8 @@ class Engine:
         self._check(self.lib.rhip_ctx_set_stream(self.ctx, ctypes.c_void_p(hip_stream_ptr)))
 
     def set_pairing_mode(self, mode):
-        """0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing (same results)."""
+        """0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per accumulator, 29 reduced radix (same
+        results); 99 cross-check: auto, then every family forced on the same inputs, compared on the device (a difference fails the call)."""
         self._check(self.lib.rhip_ctx_set_pairing_mode(self.ctx, ctypes.c_int32(mode)))
 
     def timing(self, enable):

@@ -87,9 +87,11 @@ def test_multi_gpu_line_keeps_the_gather_block():
     r["n_gpus"] = 8
     r.pop("cpu_baseline")
     r.pop("configs")
-    r["gather"] = {"backend": "nccl", "ms": 1.2, "bytes": 8 * 4096 * 384, "records_match_unsharded": True, "note": "x" * 900}
+    r["gather"] = {"backend": "nccl", "collective": "all_gather_into_tensor", "ms": 1.2, "bytes": 8 * 4096 * 384, "matches_unsharded_order": True,
+                   "note": "x" * 900}
     c = lib.compact_line(r)
-    assert c["gather"]["backend"] == "nccl" and c["gather"]["records_match_unsharded"] is True and "note" not in c["gather"]
+    assert c["gather"]["backend"] == "nccl" and c["gather"]["matches_unsharded_order"] is True and "note" not in c["gather"]
+    assert c["gather"]["collective"] == "all_gather_into_tensor"
     assert len(json.dumps(c, separators=(",", ":"))) < lib.COMPACT_LIMIT
 
 
