@@ -729,6 +729,9 @@ def main():
         thr = oa.get("threads") if isinstance(oa.get("threads"), dict) else {}
         result["value_lone_batch"] = sb.get("ops_per_s_alone")
         result["value_end_to_end"] = pk_leg.get("ops_per_s")
+        if2 = oa.get("packed_inflight2") if isinstance(oa.get("packed_inflight2"), dict) else {}
+        if if2.get("ops_per_s") and if2.get("plaintexts_match"):
+            result["value_end_to_end_inflight2"] = if2["ops_per_s"]
         result["config"]["neighbours"] = {
             "value_lone_batch": sb.get("ops_per_s_alone"), "lone_batch_latency_ms": sb.get("latency_ms"),
             "value_end_to_end": pk_leg.get("ops_per_s"), "end_to_end_batch": pk_leg.get("batch"),
@@ -860,6 +863,13 @@ def object_api_leg(args, trees):
                 ghost.close()
         except Exception as ex:          # the leg is informational
             packed_group = {"error": repr(ex)[:300]}
+        # ... and TWO packed calls in flight: two host handles (own engine, stream, staging buffers and table replicas each), one caller thread
+        # per handle, every thread encrypts and decrypts (checked) its own 8 steps' worth of items over and over -- one call's parsing, copies
+        # and AES beside the other's group arithmetic.  65 536 items are in the air at any time, as in `packed_full_group`.
+        try:
+            packed_inflight2 = packed_inflight_leg(hl, ac17, pk, sk, pols, 8 * args.batch, 2, 4)
+        except Exception as ex:          # informational
+            packed_inflight2 = {"error": repr(ex)[:300]}
         n = args.batch
         pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
         # ---- one object handle per ciphertext (round 1's path), one step's worth
@@ -873,12 +883,83 @@ def object_api_leg(args, trees):
         objects = {"ops_per_s": round(n / (t2 - t0), 1), "encrypt_s": round(t1 - t0, 4), "decrypt_s": round(t2 - t1, 4), "plaintexts_match": out == pts}
         del cts
         threads = threads_leg(host, pk, sk, pols)
-        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "packed_full_group": packed_full, "packed_group": packed_group, "threads": threads,
+        return {"ops_per_s": packed["ops_per_s"], "packed": packed, "packed_full_group": packed_full, "packed_group": packed_group,
+                "packed_inflight2": packed_inflight2, "threads": threads,
                 "objects": objects,
                 "note": "policy text + plaintext bytes -> canonical ciphertext records -> plaintext bytes through the C ABI of the host layer; "
                         "parse/MSP/pruning/KDF/AES-GCM, record assembly and the PCIe copies are inside the timed region (best of 3 for `packed`)"}
     finally:
         host.close()
+
+
+def packed_inflight_leg(hl, ac17, pk, sk, pols, n, handles, rounds):
+    """`handles` host handles on GPU 0, one Python thread each (ctypes releases the GIL inside the C ABI), every thread runs `rounds` timed
+    rounds of rabe_ac17_cp_encrypt_packed + rabe_ac17_cp_decrypt_packed (membership pass on) over its own n items after one untimed round;
+    rate = all items of all timed rounds / (last end - first start)."""
+    import threading
+    import numpy as np
+    hosts = [hl.Host(0) for _ in range(handles)]
+    try:
+        pts = [b"dance like no one's watching, encrypt like everyone is!" + i.to_bytes(4, "little") for i in range(n)]
+        pt_blob = b"".join(pts)
+        pt_off = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.uint64)
+        pt_np = np.frombuffer(pt_blob, dtype=np.uint8)
+        item_pol = np.arange(n, dtype=np.uint32) % len(pols)
+        gate = threading.Barrier(handles)
+        res = [None] * handles
+
+        def worker(w):
+            try:
+                h = hosts[w]
+                ct_buf, _ = ac17.cp_encrypt_packed(h, pk, pols, item_pol, pt_np, pt_off)
+                ct_buf = np.empty(ct_buf.size, dtype=np.uint8)
+                pt_buf = np.zeros(ct_buf.size, dtype=np.uint8)
+                ct_blob, ct_off = ac17.cp_encrypt_packed(h, pk, pols, item_pol, pt_np, pt_off, out=ct_buf)          # untimed: tables, staging buffers
+                ac17.cp_decrypt_packed(h, sk, ct_blob, ct_off, out=pt_buf)
+                gate.wait()
+                if w:
+                    time.sleep(0.5 * res_hint[0])          # start half a call apart: one handle's copies beside the other's kernels
+                t0 = time.perf_counter()
+                ok = True
+                for _ in range(rounds):
+                    ct_blob, ct_off = ac17.cp_encrypt_packed(h, pk, pols, item_pol, pt_np, pt_off, out=ct_buf)
+                    out_blob, out_off, status = ac17.cp_decrypt_packed(h, sk, ct_blob, ct_off, out=pt_buf)
+                    ok = ok and not status.any() and int(out_off[n]) == len(pt_blob)
+                t1 = time.perf_counter()
+                ok = ok and out_blob.tobytes() == pt_blob
+                res[w] = (t0, t1, ok)
+            except Exception as ex:
+                res[w] = ex
+                try:
+                    gate.abort()
+                except Exception:
+                    pass
+        # how long one call takes alone (for the half-call offset)
+        h0 = hosts[0]
+        ct0, off0 = ac17.cp_encrypt_packed(h0, pk, pols, item_pol, pt_np, pt_off)
+        ac17.cp_decrypt_packed(h0, sk, ct0, off0)
+        ta = time.perf_counter()
+        ct0, off0 = ac17.cp_encrypt_packed(h0, pk, pols, item_pol, pt_np, pt_off)
+        ac17.cp_decrypt_packed(h0, sk, ct0, off0)
+        res_hint = [time.perf_counter() - ta]
+        del ct0
+        th = [threading.Thread(target=worker, args=(w,)) for w in range(handles)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for r in res:
+            if isinstance(r, Exception):
+                raise r
+        wall = max(r[1] for r in res) - min(r[0] for r in res)
+        return {"ops_per_s": round(handles * rounds * n / wall, 1), "handles": handles, "items_per_call": n, "rounds_per_handle": rounds,
+                "wall_s": round(wall, 4), "one_call_alone_s": round(res_hint[0], 4), "ops_per_s_one_call_alone": round(n / res_hint[0], 1),
+                "plaintexts_match": all(r[2] for r in res),
+                "note": "two callers, one host handle each, every call = encrypt + checked decrypt of its items; copies and host stages of one call run "
+                        "beside the other call's kernels"}
+    finally:
+        for h in hosts:
+            h.close()
 
 
 def threads_leg(host, pk, sk, pols):

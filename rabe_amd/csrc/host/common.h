@@ -4,6 +4,7 @@
 // This layer mirrors the reference's scheme API (rabe::schemes::{ac17,bsw,lsw,aw11}) in C++ because the
 // container has no Rust toolchain; a Rust host would call the same rhip_* entry points.
 #pragma once
+#include <set>
 #include <array>
 #include <map>
 #include <memory>
@@ -161,6 +162,7 @@ class Engine {
   // launch with it, or have kernels running on it -- and the parked handles are destroyed when the last Busy ends.
   struct Busy {
     Engine& e;
+    uint64_t start;                                  // the engine's busy clock when this scope began
     explicit Busy(Engine& eng);
     ~Busy();
   };
@@ -251,7 +253,13 @@ class Engine {
   std::map<std::string, std::map<std::string, Aux>> aux_;
   uint64_t use_clock_ = 0;                         // least-recently-used eviction of the two caches above: ONE entry at a time
   int busy_ = 0;                                   // live Busy scopes
-  std::vector<std::pair<void*, void (*)(void*)>> parked_;   // evicted while busy_ > 0
+  // Evicted while busy_ > 0: parked with the busy clock of the eviction.  Only scopes that began BEFORE the eviction can still hold the handle
+  // (it left the cache then), so a parked handle is destroyed as soon as every live scope is younger than it -- under sustained load from
+  // overlapping queue lanes busy_ may never reach 0, and rotating public keys would otherwise park ~1.7 GB of tables per eviction without bound.
+  struct Parked { uint64_t at; void* h; void (*destroy)(void*); };
+  std::vector<Parked> parked_;
+  uint64_t busy_clock_ = 0;
+  std::multiset<uint64_t> busy_starts_;
   void retire(void* h, void (*destroy)(void*));    // destroy now (nobody else is working) or park
   rhip_gt_table* e_gen_tbl_ = nullptr;
   void destroy_table(rhip_g1_table* t);

@@ -37,6 +37,7 @@ struct rabe_ticket {
   Bytes pt;                                // plaintext (a copy: an asynchronous caller may reuse its buffer)
   const void* ct = nullptr;                // decrypt: the ciphertext object (the caller keeps it alive until the wait)
   bool done = false;
+  bool has_verdict = false;                // set wherever rc is decided: a ticket without one is what the leader's catch fails (an empty plaintext is a verdict too)
   int32_t rc = 0;
   std::string err;
   void* obj = nullptr;                     // encrypt: the ciphertext object
@@ -362,7 +363,7 @@ namespace {
 typedef rabe_ticket T;
 thread_local Rng* tl_queue_rng = nullptr;          // the running batch's randomness source (a lane's own, or the host's tape)
 Rng& qrng(rabe_host* h) { return tl_queue_rng ? *tl_queue_rng : h->rng(); }
-void fail(T* t, const std::string& why, int32_t rc = -1) { t->rc = rc; t->err = why; }
+void fail(T* t, const std::string& why, int32_t rc = -1) { t->rc = rc; t->err = why; t->has_verdict = true; }
 // one call on its own, exactly as the unqueued entry points run it: the fallback when a batch as a whole throws (e.g. one request's
 // policy does not parse: it fails alone)
 void run_single(rabe_host* h, T* t) {
@@ -382,7 +383,7 @@ void run_single(rabe_host* h, T* t) {
       }
       case T::AW11_DEC: t->out = aw11::decrypt(h->eng, *(const aw11::Aw11GlobalKey*)t->a, *(const aw11::Aw11SecretKey*)t->b, *(const aw11::Aw11Ciphertext*)t->ct); break;
     }
-    t->rc = 0;
+    t->rc = 0; t->has_verdict = true;
   } catch (const RabeError& e) { fail(t, e.what());
   } catch (const PolicyError& e) { fail(t, e.what());
   } catch (const std::exception& e) { fail(t, std::string("panic: ") + e.what(), -2); }
@@ -410,7 +411,7 @@ void run_encrypt_group(rabe_host* h, const std::vector<T*>& g, int32_t kind,
   rabe::parallel_for(n, [&](size_t i) {
     R r(buf.data() + out_off[i], (size_t)(out_off[i + 1] - out_off[i]));
     g[i]->obj = deser(r, kind);
-    g[i]->rc = 0;
+    g[i]->rc = 0; g[i]->has_verdict = true;
   });
 }
 // decrypt requests of one group (one key) -> records -> one packed call (objects of this process: no membership pass, like the
@@ -429,7 +430,7 @@ void run_decrypt_group(rabe_host* h, const std::vector<T*>& g, int32_t ct_kind,
   if (!packed(n, blob.data(), (size_t)off[n], off.data(), status.data(), out.data(), out.size(), pt_off.data(), &errors))
     throw RabeError("submission queue: packed decrypt refused its buffer");
   for (size_t i = 0; i < n; i++) {
-    if (status[i] == 0) { g[i]->out.assign(out.begin() + pt_off[i], out.begin() + pt_off[i + 1]); g[i]->rc = 0; }
+    if (status[i] == 0) { g[i]->out.assign(out.begin() + pt_off[i], out.begin() + pt_off[i + 1]); g[i]->rc = 0; g[i]->has_verdict = true; }
     else fail(g[i], i < errors.size() && !errors[i].empty() ? errors[i] : "decryption failed");
   }
 }
@@ -488,7 +489,7 @@ void run_group(rabe_host* h, const std::vector<T*>& g) {
       rabe::parallel_for(n, [&](size_t i) {
         R r(buf.data() + out_off[i], (size_t)(out_off[i + 1] - out_off[i]));
         g[i]->obj = deser(r, RABE_LSW_CT);
-        g[i]->rc = 0;
+        g[i]->rc = 0; g[i]->has_verdict = true;
       });
       break;
     }
@@ -498,7 +499,7 @@ void run_group(rabe_host* h, const std::vector<T*>& g) {
       for (T* t : g) { sks.push_back((const lsw::KpAbeSecretKey*)t->a); cts.push_back((const lsw::KpAbeCiphertext*)t->ct); }
       auto r = lsw::decrypt_batch(eng, sks, cts);
       for (size_t i = 0; i < g.size(); i++) {
-        if (r[i].ok) { g[i]->out = r[i].plaintext; g[i]->rc = 0; }
+        if (r[i].ok) { g[i]->out = r[i].plaintext; g[i]->rc = 0; g[i]->has_verdict = true; }
         else fail(g[i], r[i].error);
       }
       break;
@@ -536,6 +537,7 @@ void run_queue_batch(rabe_host* h, const std::vector<T*>& batch) {
       for (T* t : g) {
         if (t->obj) { rabe_obj_free(t->op == T::AC17_ENC ? RABE_AC17_CP_CT : t->op == T::BSW_ENC ? RABE_BSW_CT : t->op == T::LSW_ENC ? RABE_LSW_CT : RABE_AW11_CT, t->obj); t->obj = nullptr; }
         t->out.clear();
+        t->has_verdict = false;
         run_single(h, t);
       }
     }
@@ -619,10 +621,10 @@ void queue_wait(rabe_host* h, T* t) {
       tl_queue_rng = nullptr;
     } catch (const std::exception& e) {      // e.g. bad_alloc while grouping: every ticket of the batch that has no verdict yet fails,
       tl_queue_rng = nullptr;                // the lane is released and the waiters are woken -- nothing crosses the C boundary
-      for (T* x : batch) if (x->rc == 0 && !x->obj && x->out.empty()) { x->rc = -2; x->err = std::string("panic: ") + e.what(); }
+      for (T* x : batch) if (!x->has_verdict) { x->has_verdict = true; x->rc = -2; x->err = std::string("panic: ") + e.what(); }
     } catch (...) {
       tl_queue_rng = nullptr;
-      for (T* x : batch) if (x->rc == 0 && !x->obj && x->out.empty()) { x->rc = -2; x->err = "panic: unknown exception in the submission queue"; }
+      for (T* x : batch) if (!x->has_verdict) { x->has_verdict = true; x->rc = -2; x->err = "panic: unknown exception in the submission queue"; }
     }
     const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - b0).count();
     lk.lock();

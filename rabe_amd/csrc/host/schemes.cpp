@@ -149,7 +149,8 @@ uint8_t* Engine::pinned(int slot, size_t bytes) {
   return (uint8_t*)l.pin[slot];
 }
 void Engine::scrub_when_done() { lanes_[cur_lane()]->scrub = 31; }
-void Engine::scrub_session_when_done() { lanes_[cur_lane()]->scrub |= 3; }
+// device arena, pinned slot 0 and the ParamPack block (pinned slot 3: emit_sealed_records stages plaintexts of up to 8 MB through it)
+void Engine::scrub_session_when_done() { lanes_[cur_lane()]->scrub |= 3 | 16; }
 void Engine::pinned_reserve(size_t bytes) {
   Lane& l = *lanes_[cur_lane()];
   if (l.pin3_used + bytes <= l.pin_bytes[3]) return;
@@ -380,23 +381,34 @@ void* Engine::aux(const std::string& kind, const std::string& key, void* (*make)
   return h;
 }
 void Engine::retire(void* h, void (*destroy)(void*)) {        // mu_ held
-  if (busy_ > 0) parked_.emplace_back(h, destroy);
+  if (busy_ > 0) parked_.push_back(Parked{++busy_clock_, h, destroy});
   else destroy(h);
 }
-Engine::Busy::Busy(Engine& eng) : e(eng) {
+Engine::Busy::Busy(Engine& eng) : e(eng), start(0) {
   std::lock_guard<std::recursive_mutex> lk(e.mu_);
   e.busy_++;
+  start = ++e.busy_clock_;
+  e.busy_starts_.insert(start);
 }
 Engine::Busy::~Busy() {
-  std::vector<std::pair<void*, void (*)(void*)>> dead;
+  std::vector<Parked> dead;
   {
     std::lock_guard<std::recursive_mutex> lk(e.mu_);
-    if (--e.busy_ == 0) dead.swap(e.parked_);
+    --e.busy_;
+    auto it = e.busy_starts_.find(start);
+    if (it != e.busy_starts_.end()) e.busy_starts_.erase(it);
+    const uint64_t oldest = e.busy_starts_.empty() ? ~(uint64_t)0 : *e.busy_starts_.begin();
+    size_t keep = 0;
+    for (auto& p : e.parked_) {
+      if (p.at < oldest) dead.push_back(p);       // every scope that began before the eviction has ended
+      else e.parked_[keep++] = p;
+    }
+    e.parked_.resize(keep);
   }
-  for (auto& d : dead) d.second(d.first);        // every operation that could have seen these handles has waited for its stream
+  for (auto& d : dead) d.destroy(d.h);            // every operation that could have seen these handles has waited for its stream
 }
 Engine::~Engine() {
-  for (auto& d : parked_) d.second(d.first);
+  for (auto& d : parked_) d.destroy(d.h);
   for (auto& k : aux_) for (auto& c : k.second) c.second.destroy(c.second.h);
   if (e_gen_tbl_) rhip_gt_table_destroy(e_gen_tbl_);
   for (auto& c : pk17_) rhip_ac17_pk_destroy(c.second.h);
