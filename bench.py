@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--min-time", type=float, default=1.0,
                     help="the K-step timed region is repeated until this many seconds have been timed; every region times exactly --steps steps")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for experiments (0 = leave the HIP default)")
-    ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3, 6, 29, 99],
+    ap.add_argument("--pairing-mode", type=int, default=0, choices=[0, 1, 3, 6, 29, 58, 99],
                     help="0 auto, 1 one lane per pairing, 3 three cooperating lanes per pairing, 6 six lanes per accumulator, 29 reduced radix "
                          "(identical results); 99 cross-check of all families on every launch (not a measurement)")
     ap.add_argument("--g-window", type=int, default=20,
@@ -864,10 +864,10 @@ def object_api_leg(args, trees):
         except Exception as ex:          # the leg is informational
             packed_group = {"error": repr(ex)[:300]}
         # ... and TWO packed calls in flight: two host handles (own engine, stream, staging buffers and table replicas each), one caller thread
-        # per handle, every thread encrypts and decrypts (checked) its own 8 steps' worth of items over and over -- one call's parsing, copies
-        # and AES beside the other's group arithmetic.  65 536 items are in the air at any time, as in `packed_full_group`.
+        # per handle, every thread encrypts and decrypts (checked) its own 16 steps' worth of items over and over -- one call's parsing, copies
+        # and AES beside the other's group arithmetic (tools/bench_packed_inflight.py: 2 x 32 768 items 672 k, 2 x 65 536 856 k ops/s).
         try:
-            packed_inflight2 = packed_inflight_leg(hl, ac17, pk, sk, pols, 8 * args.batch, 2, 4)
+            packed_inflight2 = packed_inflight_leg(hl, ac17, pk, sk, pols, 16 * args.batch, 2, 3)
         except Exception as ex:          # informational
             packed_inflight2 = {"error": repr(ex)[:300]}
         n = args.batch

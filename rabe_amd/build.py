@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librabe_hip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
-SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_coop.hip"), os.path.join(CSRC, "engine_coop_w1.hip"), os.path.join(CSRC, "engine_rr.hip"), os.path.join(CSRC, "engine_sym.hip"),
+SOURCES = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "engine_jobs.hip"), os.path.join(CSRC, "engine_coop.hip"), os.path.join(CSRC, "engine_coop_w1.hip"), os.path.join(CSRC, "engine_rr.hip"), os.path.join(CSRC, "engine_rr2.hip"), os.path.join(CSRC, "engine_sym.hip"),
            os.path.join(CSRC, "host", "schemes.cpp"),
            os.path.join(CSRC, "host", "host_abi.cpp"), os.path.join(CSRC, "host", "packed.cpp"),
            os.path.join(CSRC, "host", "pipeline.cpp"), os.path.join(CSRC, "host", "records.cpp")]
@@ -38,7 +38,7 @@ def _headers(src=None):
 
 
 LIB_SAFE = os.path.join(HERE, "librabe_hip_safe.so")          # the RB_SAFE_CARRY build of the same sources (fp.h): an A/B reference
-DEVICE_SOURCES = SOURCES[:5]
+DEVICE_SOURCES = SOURCES[:5]          # (the reduced-radix units have no carry chains: nothing for RB_SAFE_CARRY to change)
 
 
 def _obj(src, safe=False):

@@ -125,7 +125,7 @@ extern "C" int32_t rhip_ctx_create(int32_t device, rhip_ctx** out) {
   c->stream = c->own_stream;
   if (const char* pm = getenv("RABE_PAIRING_MODE")) {           // A/B runs of whole test suites: 1 / 3 / 6 / 29 as rhip_ctx_set_pairing_mode
     const int m = atoi(pm);
-    if (m == 1 || m == 3 || m == 6 || m == 29 || m == 99) c->pairing_mode = m;
+    if (m == 1 || m == 3 || m == 6 || m == 29 || m == 58 || m == 99) c->pairing_mode = m;
   }
   // known answers of the field arithmetic on every SIMD of THIS device before anything is computed with it (bn254/selftest.h)
   if (rhip_device_selftest(c, nullptr, nullptr) != RHIP_OK) {
@@ -1242,12 +1242,12 @@ int32_t rhip_launch_final_exp(rhip_ctx* ctx, size_t n_items, const uint32_t* off
 }
 bool rhip_use_c3(const rhip_ctx* ctx, size_t n_pairs) {
   const int mode = rhip_mode(ctx);
-  if (mode == 1 || mode == 6 || mode == 29) return false;
+  if (mode == 1 || mode == 6 || mode == 29 || mode == 58) return false;
   if (mode == 3) return true;
   return n_pairs * 3 <= (size_t)ctx->n_cu * 4 * 63 / 4;      // at most a quarter of the SIMDs busy with one lane each
 }
 extern "C" int32_t rhip_ctx_set_pairing_mode(rhip_ctx* ctx, int32_t mode) {
-  if (!ctx || (mode != 0 && mode != 1 && mode != 3 && mode != 6 && mode != 29 && mode != 99)) return RHIP_ERR_ARG;
+  if (!ctx || (mode != 0 && mode != 1 && mode != 3 && mode != 6 && mode != 29 && mode != 58 && mode != 99)) return RHIP_ERR_ARG;
   ctx->pairing_mode = mode;
   return RHIP_OK;
 }

@@ -520,7 +520,7 @@ static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t
                                    const LineM* lines, const void* lines29, const rhip_gt* mul_in, rhip_gt* out);
 // ---- pairing mode 99, the cross-check: the launch runs as "auto" would run it (that result is the one the caller gets, walk verdicts and early
 // releases included), then AGAIN with each family of pairing kernels forced -- one lane per accumulator on 8 x 32-bit limbs (1), six lanes (6),
-// reduced radix (29): Miller loops AND final exponentiation of that family -- on the same pair lists, and every result is compared with the
+// reduced radix (29), reduced radix with a unit on two lanes (58): Miller loops AND final exponentiation of that family -- on the same pair lists, and every result is compared with the
 // first on the device, byte for byte.  A difference fails the call.  The three families compute the same field elements by construction
 // (docs/coop6.md, docs/rr29.md); this mode is how the GPU test suite holds them to it on every pairing launch of every scheme
 // (tests/conftest.py) and what an operator can switch on to have a suspect device check itself.
@@ -555,8 +555,8 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   rc = run_pair_lists_mode(ctx, n_items, pair_off, max_pairs, total_pairs, pl, lines, lines29, factor, out);
   if (rc) return rc;
   const int fault = getenv("RABE_XCHECK_FAULT") ? atoi(getenv("RABE_XCHECK_FAULT")) : 0;
-  static const int families[3] = {1, 6, 29};
-  for (int f = 0; f < 3; f++) {
+  static const int families[4] = {1, 6, 29, 58};
+  for (int f = 0; f < 4; f++) {
     ctx->pairing_mode = families[f];
     rc = run_pair_lists_mode(ctx, n_items, pair_off, max_pairs, total_pairs, pl, lines, lines29, factor, (rhip_gt*)tmp);
     if (rc) return rc;
@@ -568,7 +568,7 @@ static int32_t run_pair_lists(rhip_ctx* ctx, size_t n_items, const uint32_t* pai
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (h) {
     ctx->err = std::string("pairing cross-check: the kernel families disagree on this launch (differing from the automatic choice:") + ((h & 1) ? " one-lane 8x32" : "") +
-               ((h & 2) ? " six-lane" : "") + ((h & 4) ? " reduced-radix" : "") + ")";
+               ((h & 2) ? " six-lane" : "") + ((h & 4) ? " reduced-radix" : "") + ((h & 8) ? " two-lane" : "") + ")";
     return RHIP_ERR_HIP;
   }
   return RHIP_OK;
@@ -610,6 +610,10 @@ static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t
     if (rhip_use_c6(ctx, n_items, max_pairs)) {
       rc = rhip_launch_miller_c6(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, plan, work, chunk_off, w_max);
       if (rc) return rc;
+    } else if (rhip_use_rr2(ctx, (uint32_t)c_hi)) {          // one unit on two lanes, two waves per SIMD (engine_rr2.hip)
+      rc = rhip_launch_miller_rr2(ctx, n_items, 0u, 0u, (uint32_t)c_hi, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, mill, plan, work, chunk_off, w_max,
+                                  nullptr);
+      if (rc) return rc;
     } else if (rhip_use_rr(ctx)) {
       rc = rhip_launch_miller_rr(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, plan, work, chunk_off, w_max);
       if (rc) return rc;
@@ -639,6 +643,14 @@ static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t
   GtM* mill = (GtM*)ctx->scratch;
   if (c6) {       // six lanes per (item, chunk): engine_coop.hip; same (item, chunk) map and workspace layout, so the walk verdicts below apply unchanged
     rc = rhip_launch_miller_c6(ctx, n_items, L, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, ws, mill, nullptr, nullptr, nullptr, lanes);
+    if (rc) return rc;
+  } else if (rhip_use_rr2(ctx, C)) {          // one unit on two lanes, two waves per SIMD (engine_rr2.hip)
+    uint32_t* started = nullptr;
+    if (ctx->early_release) {          // rhip_ctx_release_when_miller_resident: the waiter goes on beside the Miller loops already
+      rc = rhip_take_waiter(ctx, blocks_for(2 * lanes, RB_MILLER_BLOCK), &started);
+      if (rc) return rc;
+    }
+    rc = rhip_launch_miller_rr2(ctx, n_items, L, C, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, mill, nullptr, nullptr, nullptr, lanes, started);
     if (rc) return rc;
   } else if (rhip_use_rr(ctx)) {
     uint32_t* started = nullptr;

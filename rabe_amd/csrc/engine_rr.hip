@@ -471,7 +471,7 @@ extern "C" int32_t rhip_debug_ubench_cores(rhip_ctx* ctx, uint32_t iters, int32_
 // the six-lane kernels do not take (the caller asks rhip_use_c6 first), unless RABE_RR=0 (A/B runs, and the conservative switch).
 bool rhip_use_rr(const rhip_ctx* ctx) {
   static const int on = getenv("RABE_RR") ? atoi(getenv("RABE_RR")) : 1;
-  return rhip_mode(ctx) == 29 || (on != 0 && rhip_mode(ctx) == 0);
+  return rhip_mode(ctx) == 29 || rhip_mode(ctx) == 58 || (on != 0 && rhip_mode(ctx) == 0);
 }
 // one lane per prepared triple (cy, cx, c0): divided by its y-coefficient -- cx / cy, c0 / cy, the unit-y form pairing29.h's facc_ell_u takes (the
 // factor lies in Fq2 and dies in the final exponentiation) -- and converted: the 9-quad record line_u() reads (4 x 8 limbs, then the 4 top limbs)

@@ -118,6 +118,13 @@ extern "C" __global__ void __launch_bounds__(256, 1) k_one_wave(uint32_t iters, 
 extern "C" __global__ void __launch_bounds__(256, 2) k_two_waves(uint32_t iters, int which, uint64_t* out) { body<1>(iters, which, out); }
 // the one-lane layout at two waves per SIMD does not fit the LDS (2 x 152.5 KB): only its register-only routine can be run there
 extern "C" __global__ void __launch_bounds__(256, 2) k_two_waves_fullregs(uint32_t iters, int which, uint64_t* out) { body<1>(iters, 1, out); }
+// the same with a scratch frame of PAD dwords per lane (touched once): does a kernel's private segment cost it its second wave?
+template <int PAD> __global__ void __launch_bounds__(256, 2) k_two_waves_scratch(uint32_t iters, int which, uint64_t* out) {
+  volatile uint32_t pad[PAD];
+  for (int i = 0; i < PAD; i += 16) pad[i] = iters + i;
+  body<1>(iters, which, out);
+  if (pad[(iters * 16) % PAD] == 0xdeadbeefu) out[0] = 1;
+}
 
 template <class K>
 static double run(const char* name, K kern, int blocks, size_t lds_bytes, int which, uint32_t iters, uint64_t* d_out, int waves_per_simd) {
@@ -153,12 +160,18 @@ int main() {
   const uint32_t iters = 2000;
   const size_t lds1 = 4 * (size_t)Lay<0>::WAVE_BYTES, lds2 = 4 * (size_t)Lay<1>::WAVE_BYTES;
   printf("LDS per four-wave block: one-lane layout %zu B, two-lane layout %zu B\n", lds1, lds2);
+  // how much LDS may a four-wave block take before a CU no longer holds two of them?  (the Miller kernel's block: 78 848 B)
+  for (size_t l : {(size_t)75776, (size_t)78848, (size_t)79872, (size_t)80896, (size_t)81920}) run("dot3, two-lane layout, 512 blocks, LDS sweep", k_two_waves, 512, l, 0, iters, d_out, 2);
   for (int rep = 0; rep < 2; rep++) {
     const double a1 = run("dot3 (LDS operands), one-lane layout, 1 wave/SIMD", k_one_wave, 256, lds1, 0, iters, d_out, 1);
     const double a2 = run("dot3 (LDS operands), two-lane layout, 2 waves/SIMD", k_two_waves, 512, lds2, 0, iters, d_out, 2);
     const double a3 = run("dot3 (LDS operands), two-lane layout, 1 wave/SIMD", k_two_waves, 256, lds2, 0, iters, d_out, 1);
     const double b1 = run("Fq2 mul (registers), 1 wave/SIMD", k_one_wave, 256, lds1, 1, iters, d_out, 1);
     const double b2 = run("Fq2 mul (registers), 2 waves/SIMD", k_two_waves, 512, lds2, 1, iters, d_out, 2);
+    run("dot3, two-lane layout, 2 waves/SIMD, 448 B scratch", k_two_waves_scratch<112>, 512, lds2, 0, iters, d_out, 2);
+    run("dot3, two-lane layout, 2 waves/SIMD, 768 B scratch", k_two_waves_scratch<192>, 512, lds2, 0, iters, d_out, 2);
+    run("dot3, two-lane layout, 2 waves/SIMD, 1280 B scratch", k_two_waves_scratch<320>, 512, lds2, 0, iters, d_out, 2);
+    run("dot3, two-lane layout, 2 waves/SIMD, 2048 B scratch", k_two_waves_scratch<512>, 512, lds2, 0, iters, d_out, 2);
     printf("  -> dot3: %.3f x at two waves per SIMD (two-lane layout alone: %.3f x); Fq2 mul: %.3f x\n", a1 / a2, a1 / a3, b1 / b2);
   }
   return 0;
