@@ -114,10 +114,6 @@ int32_t rhip_ctx_release_after_miller(rhip_ctx* ctx, rhip_ctx* waiter);
  * Served by the reduced-radix Miller kernel on uniform pair lists (pairing mode 0 / 29); any other launch behaves as under
  * rhip_ctx_release_before_final_exp.  One-shot; same bytes either way. */
 int32_t rhip_ctx_release_when_miller_resident(rhip_ctx* ctx, rhip_ctx* waiter);
-/* Diagnostic (tools/ubench_cores.py): shader cycles that `iters` calls of one out-of-line field routine of the reduced-radix pairing kernels
- * take at those kernels' occupancy; d_out: blocks x 4 uint64 (device memory), one per wave.  which: 0 / 1 the line products' dot
- * products (general / unit-y form), 2 the Fq2 multiplication, 3 the empty loop.  No reference counterpart; not on any product path. */
-int32_t rhip_debug_ubench_cores(rhip_ctx* ctx, uint32_t iters, int32_t which, uint32_t blocks, uint64_t* d_out);
 
 /* ---- Level E: element batches (n independent operations) --------------------------------------
  * rabe_bn surface replaced ("rabe_bn API surface actually used"):

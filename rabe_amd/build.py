@@ -93,7 +93,10 @@ def _version_script():
     """build/obj/exports.map: the dynamic symbol table of the library is EXACTLY the two headers' function lists -- no std:: / rabe:: C++
     symbols for a Rust or C++ host to interpose (the C convention of the reference's own FFI, src/ffi/bsw.rs:22-163)."""
     path = os.path.join(OBJ, "exports.map")
-    text = "RABE_AMD {\n  global:\n" + "".join("    %s;\n" % s for s in declared_symbols()) + "  local:\n    *;\n};\n"
+    # diagnostic builds (RABE_HIPCC_FLAGS=-DRB_MILLER_PROF / -DRB_UBENCH_CORES: tools/prof_miller.sh, tools/ubench_cores.py) also export their
+    # rhip_debug_* entry points; the product build has none
+    debug = "    rhip_debug_*;\n" if _flags() else ""
+    text = "RABE_AMD {\n  global:\n" + "".join("    %s;\n" % s for s in declared_symbols()) + debug + "  local:\n    *;\n};\n"
     if not os.path.exists(path) or open(path).read() != text:
         open(path, "w").write(text)
     return path

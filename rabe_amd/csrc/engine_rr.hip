@@ -423,6 +423,7 @@ int32_t rhip_launch_final_exp_rr(rhip_ctx* ctx, size_t n_items, const uint32_t* 
 // ---- micro-benchmark of the out-of-line routines at the kernels' own occupancy (one wave per SIMD, the 152 KB home: a block owns a CU): shader
 // cycles per call, measured inside the kernel (s_memtime), per wave.  which: 0 rr_dot3_core, 1 rr_dot3s_core, 2 mul2_core, 3 sqr2_sd_core-free
 // baseline (empty loop).  tools/ubench_cores.py prints the table; not part of the product path.
+#ifdef RB_UBENCH_CORES          // diagnostic builds only (tools/ubench_cores.py: RABE_HIPCC_FLAGS=-DRB_UBENCH_CORES); not in the product library
 __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_ubench_cores(uint32_t iters, int which, uint64_t* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -450,6 +451,7 @@ __global__ void __launch_bounds__(RB_MILLER_BLOCK, 1) k_ubench_cores(uint32_t it
   if (ln == 0) out[(size_t)blockIdx.x * 4 + wv] = (t1 - t0) + (uint64_t)((a[0] ^ b[1]) & 1);
 #endif
 }
+#endif
 #ifdef RB_MILLER_PROF
 // diagnostic build only: reads and clears the region sums of the k_miller_multi_rr launches since the last call
 extern "C" int32_t rhip_debug_miller_prof(rhip_ctx* ctx, unsigned long long out[8]) {
@@ -461,11 +463,13 @@ extern "C" int32_t rhip_debug_miller_prof(rhip_ctx* ctx, unsigned long long out[
   return RHIP_OK;
 }
 #endif
+#ifdef RB_UBENCH_CORES
 extern "C" int32_t rhip_debug_ubench_cores(rhip_ctx* ctx, uint32_t iters, int32_t which, uint32_t blocks, uint64_t* d_out) {
   if (!ctx || !d_out) return RHIP_ERR_ARG;
   KLAUNCH(ctx, "k_ubench_cores", k_ubench_cores, dim3(blocks), dim3(RB_MILLER_BLOCK), 0, ctx->stream, iters, (int)which, d_out);
   return RHIP_OK;
 }
+#endif
 
 // When it runs: pairing mode 29 (rhip_ctx_set_pairing_mode / RABE_PAIRING_MODE) -- every multi-pairing launch; mode 0 (auto) -- the launches
 // the six-lane kernels do not take (the caller asks rhip_use_c6 first), unless RABE_RR=0 (A/B runs, and the conservative switch).

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Shader cycles per call of the reduced-radix kernels' out-of-line routines at their own occupancy (one wave per SIMD, every CU busy):
-rhip_debug_ubench_cores (engine_rr.hip: k_ubench_cores).  usage: python tools/ubench_cores.py [iters=2000]"""
+rhip_debug_ubench_cores (engine_rr.hip: k_ubench_cores) of a DIAGNOSTIC build -- the product library does not contain the kernel:
+    RABE_HIPCC_FLAGS=-DRB_UBENCH_CORES python -m rabe_amd.build --force && python tools/ubench_cores.py [iters=2000]
+(int32_t rhip_debug_ubench_cores(rhip_ctx*, uint32_t iters, int32_t which, uint32_t blocks, uint64_t* d_out): d_out = blocks x 4 uint64 of device
+memory, one per wave; which: 0 / 1 the line products' dot products (general / unit-y form), 2 the Fq2 multiplication, 3 the empty loop)"""
 import ctypes
 import struct
 import sys
