@@ -647,6 +647,14 @@ def main():
         # HBM side (reported, not binding): algorithmic bytes of the whole step
         alg_bytes = B * (2 * 32 + 384) + rows_per_batch * 192 * 2 + B * (384 + 384) * 2 + sel_per_batch * 4 * 2 + B * 384
         traffic, traffic_src = pmc_traffic(dom)
+        # ALL VALU instructions the kernel issues per second (SQ_INSTS_VALU of the committed counter run x 64 lanes / this run's kernel time)
+        # against the same ceiling: the chip issues ~0.54 G wave-instructions per second and SIMD whatever the mix (round 6: at a higher
+        # VALU density the clock drops -- docs/tried.md "two waves per SIMD"), so this is how close the kernel is to the machine; `frac`
+        # is the share of that which is multiply-adds
+        vi = pmc_valu_issue(dom)
+        frac_issue = None
+        if vi and dom_ms > 0 and peak_tmac:
+            frac_issue = round(vi["valu_insts_per_launch"] * 64.0 / (dom_ms * 1e-3) / (peak_tmac * 1e12), 4)
         result["roofline"] = {
             "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
             "kernel_ms": round(dom_ms, 4), "items_per_launch": NB, "steps_per_launch": G,
@@ -667,7 +675,7 @@ def main():
             "whole_step_frac": round(step_macs / (elapsed / args.steps) / 1e12 / peak_tmac, 4) if peak_tmac else None,
             "traffic": traffic, "traffic_unit": "bytes of HBM fetch + write per launch of the dominant kernel (PMC FETCH_SIZE + WRITE_SIZE, separate passes)",
             "traffic_source": traffic_src,
-            "valu_issue": pmc_valu_issue(dom),
+            "valu_issue": vi, "frac_valu_issue": frac_issue,
             "hbm": {"algorithmic_bytes_per_step": alg_bytes, "GBps_at_measured_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 3),
                     "peak_GBps": 8000},
             "kernels_ms": {kk: round(v, 4) for kk, v in sorted(per_kernel.items(), key=lambda x: -x[1])},

@@ -97,7 +97,7 @@ def cpu_model():
 COMPACT_LIMIT = 4096
 _CONFIG_KEYS = ("workload", "batch_per_gpu", "attrs", "policies", "steps_per_launch_set", "parallelism", "device", "pairing_mode",
                 "launch_sets_in_flight", "tree", "ragged")
-_ROOFLINE_KEYS = ("bound", "kernel", "kernel_ms", "items_per_launch", "achieved", "peak", "unit", "frac", "frac_survey", "achieved_survey",
+_ROOFLINE_KEYS = ("bound", "kernel", "kernel_ms", "items_per_launch", "achieved", "peak", "unit", "frac", "frac_survey", "frac_valu_issue", "achieved_survey",
                   "traffic", "traffic_source", "kernels_ms_sum_per_step")
 _CPU_KEYS = ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
 
