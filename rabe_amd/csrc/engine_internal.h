@@ -47,7 +47,7 @@ struct rhip_ctx {
   void* fe_ws = nullptr;
   size_t fe_ws_bytes = 0;
   // grow-only work arenas of the job kernels (engine_jobs.hip: pair lists, running G2 points, scalars)
-  enum { N_WORK = 14 };          // 12, 13: the cross-check mode's second result buffer and its snapshot of an in-place factor (engine_jobs.hip)
+  enum { N_WORK = 15 };          // 12, 13: the cross-check mode's second result buffer and its snapshot of an in-place factor (engine_jobs.hip); 14: the two-lane Miller kernel's workspace (its own slot: in the cross-check mode it alternates with the one-lane kernel's, and a grow-only slot shared by two sizes would be re-allocated -- a device-wide hipFree -- on every launch)
   void* work[N_WORK] = {};
   size_t work_bytes[N_WORK] = {};
   // optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg

@@ -376,7 +376,7 @@ int32_t rhip_launch_miller_rr2(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32
   if (c_max > 64 || !units) return RHIP_ERR_ARG;
   void* ws2 = nullptr;
   const size_t waves = (2 * units + 63) / 64;
-  const int32_t rc = rhip_ensure_work(ctx, 11, waves * 64 * rr2_col_quads(c_max) * sizeof(uint4), &ws2);
+  const int32_t rc = rhip_ensure_work(ctx, 14, waves * 64 * rr2_col_quads(c_max) * sizeof(uint4), &ws2);
   if (rc) return rc;
   KLAUNCH(ctx, "k_miller_pair_rr", k_miller_pair_rr, dim3(blocks_for(2 * units, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, uniform,
           (const G1M*)P, (const G2M*)Q, qref, (const uint4*)lines29, (uint4*)ws, (uint4*)ws2, (GtM*)mill, plan, (const uint2*)work, chunk_off, started);

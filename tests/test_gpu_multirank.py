@@ -16,6 +16,7 @@ def run_bench(*extra):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env["RABE_PAIRING_MODE"] = "0"          # these tests are about sharding and the gather: the ranks run the automatic kernel selection, not the suite's cross-check
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--warmup", "1", "--min-time", "0", "--no-cpu-baseline",
                           "--no-object-api", "--no-host-io-leg"] + list(extra), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
@@ -53,6 +54,7 @@ def run_bench_n(n, *extra, env_extra=None, timeout=1800):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
+    env["RABE_PAIRING_MODE"] = "0"          # (as above: several ranks share this box's one GPU; the cross-check would run every launch five times in each)
     env.update(env_extra or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--warmup", "1", "--min-time", "0", "--no-cpu-baseline",
                           "--no-object-api", "--no-host-io-leg", "--no-single-batch", "--no-configs-leg", "--wide-window", "0"] + list(extra), env=env,

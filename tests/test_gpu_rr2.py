@@ -78,10 +78,10 @@ def test_many_items_with_arguments_at_infinity(eng):
         assert two[i] == bn.gt_to_le(bn.gt_pow(e, exp))
 
 
-@pytest.mark.parametrize("module", ["tests/test_gpu_walk_verdicts.py", "tests/test_gpu_ac17.py"])
+@pytest.mark.parametrize("module", ["tests/test_gpu_walk_verdicts.py"])
 def test_scheme_suites_pass_with_the_two_lane_kernel_forced(module):
-    """walk verdicts are read off the points THIS kernel's lanes end on (the cross-check mode compares pairing values only), and the AC17 suite
-    runs prepared + walking pairs side by side in one chunk: both modules with RABE_PAIRING_MODE=58"""
+    """walk verdicts are read off the points THIS kernel's lanes end on (the cross-check mode compares pairing values only): that module with
+    RABE_PAIRING_MODE=58.  (Prepared + walking pairs side by side in one chunk -- AC17 -- run through this kernel in the cross-check mode.)"""
     env = dict(os.environ, RABE_PAIRING_MODE="58")
     r = subprocess.run([sys.executable, "-m", "pytest", module, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=3000)
