@@ -7,6 +7,8 @@
 #include "../../rabe_amd/csrc/bn254/coop6.h"
 #include "../../rabe_amd/csrc/bn254/selftest.h"
 #include "../../rabe_amd/csrc/bn254/pairing29.h"
+#include "../../rabe_amd/csrc/bn254/pairing29p.h"
+#include <thread>
 #include <pthread.h>
 #include <string.h>
 
@@ -552,6 +554,97 @@ void hs_rr_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32
       if (kk[j] == MP_WALK) { store_fp2(t_out + 96 * j, rr::to_fp2(T[j].x)); store_fp2(t_out + 96 * j + 32, rr::to_fp2(T[j].y)); store_fp2(t_out + 96 * j + 64, rr::to_fp2(T[j].z)); }
   delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
 }
+}  // extern "C"
+// ---- bn254/pairing29p.h: ONE unit on TWO lanes.  The two lanes of a pair are two host THREADS that run miller_loop_pair side by side;
+// every accessor that touches what the lanes share (the LDS home, the operand slots, the DPP moves) is bracketed by barriers, which is what
+// a wave's lock-step execution and its in-order LDS traffic give the device code: all reads of a step see the state before any write of it.
+struct PairShared {
+  rr::F2 home[6];
+  rr::F2 slot[2];
+  rr::F slot0_fp;
+  rr::F2 xch[2];
+  pthread_barrier_t bar;
+};
+struct HostPairAcc29 {
+  PairShared* s;
+  int me;                      // 0: owns c0, 1: owns c1
+  int n;
+  const int* kinds;
+  const G1Aff* P;
+  const G2Aff* Q;
+  const LineCoeffs* lines;
+  rr::G2Hom29* T;
+  void sync() const { pthread_barrier_wait(&s->bar); }
+  bool hi() const { return me != 0; }
+  int count() const { return n; }
+  int kind(int j) const { return kinds[j]; }
+  void fence() const {}
+  rr::F2 ld_co(int i) const { sync(); const rr::F2 v = s->home[i]; sync(); return v; }
+  void st_own(int i, const rr::F2& v) const { sync(); s->home[3 * me + i] = v; sync(); }
+  void set_slot(int k, const rr::F2& v, bool w) const { sync(); if (w) s->slot[k] = v; sync(); }
+  void set_slot0_fp(const rr::F& v, bool w) const { sync(); if (w) s->slot0_fp = v; sync(); }
+  rr::F2 dotp(const rr::F2& yr, int is0, int ir, int is1) const {
+    sync();
+    const rr::F2 r = rr::dot3(s->home[is0], s->slot[0], s->home[ir], yr, s->home[is1], s->slot[1]);
+    sync();
+    return r;
+  }
+  rr::F2 dotps(const rr::F2& yr, int is0, int ir, int is1) const {
+    sync();
+    const rr::F2 r = rr::dot3s(s->home[is0], s->slot0_fp, s->home[ir], yr, s->home[is1], s->slot[1]);
+    sync();
+    return r;
+  }
+  rr::F2 other2(const rr::F2& v) const { sync(); s->xch[me] = v; sync(); const rr::F2 r = s->xch[1 - me]; sync(); return r; }
+  template <int O> rr::F2 from2(const rr::F2& v) const { sync(); if (me == O) s->xch[0] = v; sync(); const rr::F2 r = s->xch[0]; sync(); return r; }
+  rr::MillerP29 p(int j) const { return rr::MillerP29{rr::from_fp(P[j].x), rr::from_fp(P[j].y)}; }
+  rr::G2Aff29 q(int j) const { return rr::G2Aff29{rr::from_fp2(Q[j].x), rr::from_fp2(Q[j].y)}; }
+  rr::LineU29 line_u(int j, int k) const {
+    const LineCoeffs& l = lines[j * RB_MILLER_LINES + k];
+    const Fp2 iy = fp2_inv(l.cy);
+    rr::LineU29 r;
+    r.cx = rr::from_fp2(fp2_mul(l.cx, iy)); r.c0 = rr::from_fp2(fp2_mul(l.c0, iy));
+    return r;
+  }
+  rr::G2Hom29 ld_t(int j) const { return T[j]; }          // a walking pair is walked by ONE lane: nothing to synchronise
+  void st_t(int j, const rr::G2Hom29& t) const { T[j] = t; }
+  void begin() const {
+    sync();
+    if (me == 0)
+      for (int j = 0; j < n; j++)
+        if (kinds[j] == MP_WALK) { const rr::G2Aff29 a = q(j); T[j] = rr::G2Hom29{a.x, a.y, rr::one2()}; }
+    sync();
+  }
+};
+extern "C" void hs_rr_miller_pair(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out, uint32_t* t_out) {
+  G1Aff* P = new G1Aff[n];
+  G2Aff* Q = new G2Aff[n];
+  LineCoeffs* lines = new LineCoeffs[(size_t)n * RB_MILLER_LINES];
+  rr::G2Hom29* T = new rr::G2Hom29[n];
+  int* kk = new int[n];
+  for (int j = 0; j < n; j++) {
+    P[j] = load_g1(p + 16 * j);
+    Q[j] = load_g2(q + 32 * j);
+    kk[j] = kinds[j];
+    if (aff_is_inf(P[j]) || aff_is_inf(Q[j])) kk[j] = MP_SKIP;
+    if (kk[j] == MP_LINES) g2_prepare_lines(Q[j], lines + (size_t)j * RB_MILLER_LINES);
+  }
+  PairShared sh;
+  pthread_barrier_init(&sh.bar, nullptr, 2);
+  std::thread lane1([&] { rr::miller_loop_pair(HostPairAcc29{&sh, 1, n, kk, P, Q, lines, T}); });
+  rr::miller_loop_pair(HostPairAcc29{&sh, 0, n, kk, P, Q, lines, T});
+  lane1.join();
+  pthread_barrier_destroy(&sh.bar);
+  Fp12 f;
+  f.c0 = Fp6{rr::to_fp2(sh.home[0]), rr::to_fp2(sh.home[1]), rr::to_fp2(sh.home[2])};
+  f.c1 = Fp6{rr::to_fp2(sh.home[3]), rr::to_fp2(sh.home[4]), rr::to_fp2(sh.home[5])};
+  store_gt(out, f);
+  if (t_out)
+    for (int j = 0; j < n; j++)
+      if (kk[j] == MP_WALK) { store_fp2(t_out + 96 * j, rr::to_fp2(T[j].x)); store_fp2(t_out + 96 * j + 32, rr::to_fp2(T[j].y)); store_fp2(t_out + 96 * j + 64, rr::to_fp2(T[j].z)); }
+  delete[] P; delete[] Q; delete[] lines; delete[] T; delete[] kk;
+}
+extern "C" {
 // the same value from pairing.h's loop, for the comparison
 void hs_miller_multi(int n, const int* kinds, const uint32_t* p, const uint32_t* q, uint32_t* out, uint32_t* t_out) {
   G1Aff* P = new G1Aff[n];

@@ -148,3 +148,26 @@ def test_final_exponentiation_same_bytes():
         HS.hs_final_exp_ws(b2c(bn.gt_to_le(f)), o1)
         HS.hs_rr_final_exp(b2c(bn.gt_to_le(f)), o2)
         assert bytes(o1) == bytes(o2)
+
+
+@pytest.mark.parametrize("n,kinds", [(1, [0]), (1, [1]), (2, [0, 0]), (3, [0, 0, 0]), (2, [1, 0]), (3, [0, 1, 0]), (5, [1, 0, 1, 0, 1]), (4, [0, 2, 1, 0]),
+                                     (6, [1, 1, 1, 0, 0, 0])])
+def test_miller_loop_on_two_lanes_same_value_and_same_running_points(n, kinds):
+    """pairing29p.h: miller_loop_pair -- one unit on TWO lanes (the device kernel k_miller_pair_rr; here two host threads in lock step, every
+    shared access bracketed by barriers) -- against pairing29.h's one-lane loop: the Miller value is the SAME field element (prepared lines are
+    unit-y lines in both), and so are the points the walking pairs end on, for even and odd numbers of walking pairs (lane 1 idle in the
+    last round), prepared and walking pairs mixed, and a skipped pair.  The host build checks every limb / value bound at run time."""
+    ks = [(RND.randrange(1, bn.R), RND.randrange(1, bn.R)) for _ in range(n)]
+    p = b"".join(bn.g1_to_le(bn.g1_mul(bn.G1_GEN, a)) for a, _ in ks)
+    q = b"".join(bn.g2_to_le(bn.g2_mul(bn.G2_GEN, b)) for _, b in ks)
+    kk = (ctypes.c_int * n)(*kinds)
+    o1, o2, t1, t2 = buf(384), buf(384), buf(384 * n), buf(384 * n)
+    HS.hs_rr_miller_multi(n, kk, b2c(p), b2c(q), o1, t1)
+    HS.hs_rr_miller_pair(n, kk, b2c(p), b2c(q), o2, t2)
+    assert bytes(o1) == bytes(o2)
+    assert bytes(t1) == bytes(t2)
+    if n >= 2:      # an argument at infinity: the pair is skipped, the lanes' shares of the walking pairs shift
+        p2 = bytes(64) + p[64:]
+        HS.hs_rr_miller_multi(n, kk, b2c(p2), b2c(q), o1, None)
+        HS.hs_rr_miller_pair(n, kk, b2c(p2), b2c(q), o2, None)
+        assert bytes(o1) == bytes(o2)
