@@ -677,7 +677,7 @@ bool rhip_use_rr(const rhip_ctx* ctx);
 bool rhip_use_rr2(const rhip_ctx* ctx, uint32_t c_max);
 int32_t rhip_launch_miller_rr2(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, uint32_t c_max, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                                const uint32_t* qref, const void* lines, const void* lines29, void* ws, void* mill, const MillerPlan* plan,
-                               const void* work, const uint32_t* chunk_off, size_t units, uint32_t* started);
+                               const void* work, const uint32_t* chunk_off, size_t units, uint32_t* started, size_t plan_pairs, uint32_t plan_c_lo);
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
                               const void* work, const uint32_t* chunk_off, size_t lanes, uint32_t* started = nullptr);

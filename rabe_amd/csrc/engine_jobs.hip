@@ -612,7 +612,7 @@ static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t
       if (rc) return rc;
     } else if (rhip_use_rr2(ctx, (uint32_t)c_hi)) {          // one unit on two lanes, two waves per SIMD (engine_rr2.hip)
       rc = rhip_launch_miller_rr2(ctx, n_items, 0u, 0u, (uint32_t)c_hi, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, mill, plan, work, chunk_off, w_max,
-                                  nullptr);
+                                  nullptr, total_pairs, (uint32_t)c_lo);
       if (rc) return rc;
     } else if (rhip_use_rr(ctx)) {
       rc = rhip_launch_miller_rr(ctx, n_items, 0u, 0u, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, ws_bytes, mill, plan, work, chunk_off, w_max);
@@ -650,7 +650,7 @@ static int32_t run_pair_lists_mode(rhip_ctx* ctx, size_t n_items, const uint32_t
       rc = rhip_take_waiter(ctx, blocks_for(2 * lanes, RB_MILLER_BLOCK), &started);
       if (rc) return rc;
     }
-    rc = rhip_launch_miller_rr2(ctx, n_items, L, C, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, mill, nullptr, nullptr, nullptr, lanes, started);
+    rc = rhip_launch_miller_rr2(ctx, n_items, L, C, C, pair_off, (uint32_t)max_pairs, pl.P, pl.Q, pl.qref, lines, lines29, ws, mill, nullptr, nullptr, nullptr, lanes, started, 0, 0u);
     if (rc) return rc;
   } else if (rhip_use_rr(ctx)) {
     uint32_t* started = nullptr;

@@ -369,14 +369,27 @@ bool rhip_use_rr2(const rhip_ctx* ctx, uint32_t c_max) {
 }
 // `units` = (item, chunk) units of the launch (the `lanes` of rhip_launch_miller_rr); c_max: the largest chunk the launch can hold (the
 // chunk size C, or the upper bound of a device-side plan)
+// plan_pairs / plan_c_lo: for a device-side plan (plan != NULL) the total number of pairs and the smallest chunk size the plan may choose -- the
+// workspace is sized for the worst chunk size of the range (a plan with chunks of C pairs has at most plan_pairs / C + n_items units of
+// rr2_col_quads(C) quads per lane), not for the most units times the largest column
 int32_t rhip_launch_miller_rr2(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, uint32_t c_max, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                                const uint32_t* qref, const void* lines, const void* lines29, void* ws, void* mill, const MillerPlan* plan,
-                               const void* work, const uint32_t* chunk_off, size_t units, uint32_t* started) {
+                               const void* work, const uint32_t* chunk_off, size_t units, uint32_t* started, size_t plan_pairs, uint32_t plan_c_lo) {
   if (lines && !lines29) return RHIP_ERR_ARG;          // every handle that carries prepared lines carries their converted form (rhip_lines_to_rr)
   if (c_max > 64 || !units) return RHIP_ERR_ARG;
   void* ws2 = nullptr;
-  const size_t waves = (2 * units + 63) / 64;
-  const int32_t rc = rhip_ensure_work(ctx, 14, waves * 64 * rr2_col_quads(c_max) * sizeof(uint4), &ws2);
+  size_t quads = 0;
+  if (plan) {
+    for (uint32_t c = plan_c_lo ? plan_c_lo : 1; c <= c_max; c++) {
+      size_t u = plan_pairs / c + n_items + 64;
+      if (u > units) u = units;
+      const size_t q = (2 * u + 63) / 64 * 64 * rr2_col_quads(c);
+      if (q > quads) quads = q;
+    }
+  } else {
+    quads = (2 * units + 63) / 64 * 64 * rr2_col_quads(c_max);
+  }
+  const int32_t rc = rhip_ensure_work(ctx, 14, quads * sizeof(uint4), &ws2);
   if (rc) return rc;
   KLAUNCH(ctx, "k_miller_pair_rr", k_miller_pair_rr, dim3(blocks_for(2 * units, RB_MILLER_BLOCK)), dim3(RB_MILLER_BLOCK), 0, ctx->stream, n_items, L, C, pair_off, uniform,
           (const G1M*)P, (const G2M*)Q, qref, (const uint4*)lines29, (uint4*)ws, (uint4*)ws2, (GtM*)mill, plan, (const uint2*)work, chunk_off, started);
