@@ -654,7 +654,8 @@ def main():
         vi = pmc_valu_issue(dom)
         frac_issue = None
         if vi and dom_ms > 0 and peak_tmac:
-            frac_issue = round(vi["valu_insts_per_launch"] * 64.0 / (dom_ms * 1e-3) / (peak_tmac * 1e12), 4)
+            # (the committed counters are per launch of tools/pmc_sq.sh's full group: 16 steps x 4096 items; this run's launch has G x B)
+            frac_issue = round(vi["valu_insts_per_launch"] * (G * B / 65536.0) * 64.0 / (dom_ms * 1e-3) / (peak_tmac * 1e12), 4)
         result["roofline"] = {
             "bound": "valu_int (v_mad_u64_u32 issue rate; not hbm, not mfma)", "kernel": dom,
             "kernel_ms": round(dom_ms, 4), "items_per_launch": NB, "steps_per_launch": G,
