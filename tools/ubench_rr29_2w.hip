@@ -150,14 +150,18 @@ static double run(const char* name, K kern, int blocks, size_t lds_bytes, int wh
   free(h);
   const double per_call_wave = sum / (blocks * 4.0) / iters;          // shader cycles a WAVE spends per call (s_memtime)
   const double simd = per_call_wave / waves_per_simd;                  // ... and a SIMD per call of one of its waves
-  printf("%-58s blocks/CU %d regs %3d lds %6zu  %8.3f ms  wave %7.1f  SIMD %7.1f cycles per call\n", name, occ, fa.numRegs, lds_bytes, ms, per_call_wave, simd);
+  // the shader clock this launch ran at: s_memtime cycles of a wave over the launch's event time (launch overhead makes it a lower bound)
+  const double ghz = per_call_wave * iters / (ms * 1e-3) * 1e-9;
+  const double calls_per_s = (double)blocks * 4.0 * iters / (ms * 1e-3);
+  printf("%-58s blocks/CU %d regs %3d lds %6zu  %8.3f ms  wave %7.1f  SIMD %7.1f cycles per call  clock >= %.2f GHz  %.0f M calls/s\n", name, occ, fa.numRegs, lds_bytes, ms,
+         per_call_wave, simd, ghz, calls_per_s * 1e-6);
   return simd;
 }
 
 int main() {
   uint64_t* d_out;
   CHECK(hipMalloc(&d_out, 4096 * 4 * 8));
-  const uint32_t iters = 2000;
+  const uint32_t iters = 8000;          // ~25-45 ms per launch: long enough for the clock to settle
   const size_t lds1 = 4 * (size_t)Lay<0>::WAVE_BYTES, lds2 = 4 * (size_t)Lay<1>::WAVE_BYTES;
   printf("LDS per four-wave block: one-lane layout %zu B, two-lane layout %zu B\n", lds1, lds2);
   // how much LDS may a four-wave block take before a CU no longer holds two of them?  (the Miller kernel's block: 78 848 B)
