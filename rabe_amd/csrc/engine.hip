@@ -1680,7 +1680,7 @@ extern "C" int32_t rhip_ac17_sk_prepare(rhip_ctx* ctx, size_t n_sk, const rhip_g
     return fail(ctx, e, "rhip_ac17_sk_prepare: hipMalloc");
   }
   KLAUNCH(ctx, "k_g2_prepare_lines", k_g2_prepare_lines, dim3(blocks_for(n_sk * 3, 64)), dim3(64), 0, ctx->stream, n_sk * 3, sk_k0, p->lines, p->q_inf);
-  { const int32_t rc29 = rhip_lines_to_rr(ctx, n_sk * 3 * RB_MILLER_LINES, p->lines, &p->lines29); if (rc29) { rhip_ac17_sk_lines_destroy(p); return rc29; } }
+  if (rhip_want_lines29(ctx)) { const int32_t rc29 = rhip_lines_to_rr(ctx, n_sk * 3 * RB_MILLER_LINES, p->lines, &p->lines29); if (rc29) { rhip_ac17_sk_lines_destroy(p); return rc29; } }
   // the handle is read by decrypt calls of ANY context (other streams): it must be complete when it is handed out
   hipError_t es = hipStreamSynchronize(ctx->stream);
   if (es != hipSuccess) { rhip_ac17_sk_lines_destroy(p); return fail(ctx, es, "rhip_ac17_sk_prepare: sync"); }
@@ -1707,7 +1707,7 @@ extern "C" int32_t rhip_g2_lines_prepare(rhip_ctx* ctx, size_t n, const rhip_g2*
     return fail(ctx, e, "rhip_g2_lines_prepare: hipMalloc");
   }
   KLAUNCH(ctx, "k_g2_prepare_lines", k_g2_prepare_lines, dim3(blocks_for(n, 64)), dim3(64), 0, ctx->stream, n, dev_q, p->lines, p->q_inf);
-  { const int32_t rc29 = rhip_lines_to_rr(ctx, n * RB_MILLER_LINES, p->lines, &p->lines29); if (rc29) { rhip_g2_lines_destroy(p); return rc29; } }
+  if (rhip_want_lines29(ctx)) { const int32_t rc29 = rhip_lines_to_rr(ctx, n * RB_MILLER_LINES, p->lines, &p->lines29); if (rc29) { rhip_g2_lines_destroy(p); return rc29; } }
   hipError_t es = hipStreamSynchronize(ctx->stream);      // the handle is read from any context afterwards
   if (es != hipSuccess) { rhip_g2_lines_destroy(p); return fail(ctx, es, "rhip_g2_lines_prepare: sync"); }
   *out = p;

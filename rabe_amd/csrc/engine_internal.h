@@ -673,6 +673,7 @@ int32_t rhip_launch_final_exp_c6(rhip_ctx* ctx, size_t n_items, const uint32_t* 
 // reduced-radix Miller kernel (engine_rr.hip, bn254/fp29.h): the drop-in for k_miller_multi on launches that fill the chip; ws / ws_bytes: the
 // workspace in k_miller_multi's layout (the walk verdicts read it), its own workspace is sized from it
 bool rhip_use_rr(const rhip_ctx* ctx);
+bool rhip_want_lines29(const rhip_ctx* ctx);
 // engine_rr2.hip: the reduced-radix Miller kernel with one (item, chunk) unit on two lanes (two waves per SIMD)
 bool rhip_use_rr2(const rhip_ctx* ctx, uint32_t c_max);
 int32_t rhip_launch_miller_rr2(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, uint32_t c_max, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,

@@ -477,6 +477,13 @@ bool rhip_use_rr(const rhip_ctx* ctx) {
   static const int on = getenv("RABE_RR") ? atoi(getenv("RABE_RR")) : 1;
   return rhip_mode(ctx) == 29 || rhip_mode(ctx) == 58 || (on != 0 && rhip_mode(ctx) == 0);
 }
+// Does a handle that carries prepared lines need their converted form?  Always, unless the reduced-radix kernels are switched off for the
+// process (RABE_RR=0, the conservative switch) AND the context is not in a mode that forces them: then the conversion (+ 75 % of the lines'
+// memory) is skipped, and a later launch that wants the converted lines of such a handle fails with a message instead of reading nothing.
+bool rhip_want_lines29(const rhip_ctx* ctx) {
+  static const int on = getenv("RABE_RR") ? atoi(getenv("RABE_RR")) : 1;
+  return on != 0 || ctx->pairing_mode == 29 || ctx->pairing_mode == 58 || ctx->pairing_mode == 99;
+}
 // one lane per prepared triple (cy, cx, c0): divided by its y-coefficient -- cx / cy, c0 / cy, the unit-y form pairing29.h's facc_ell_u takes (the
 // factor lies in Fq2 and dies in the final exponentiation) -- and converted: the 9-quad record line_u() reads (4 x 8 limbs, then the 4 top limbs)
 __global__ void __launch_bounds__(256) k_lines_to_rr(size_t n, const LineM* in, uint4* out) {
@@ -506,7 +513,10 @@ int32_t rhip_lines_to_rr(rhip_ctx* ctx, size_t n_lines, const void* lines, void*
 int32_t rhip_launch_miller_rr(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                               const uint32_t* qref, const void* lines, const void* lines29, void* ws, size_t ws_bytes, void* mill, const MillerPlan* plan,
                               const void* work, const uint32_t* chunk_off, size_t lanes, uint32_t* started) {
-  if (lines && !lines29) return RHIP_ERR_ARG;          // every handle that carries prepared lines carries their converted form (rhip_lines_to_rr)
+  if (lines && !lines29) {          // a handle prepared while the reduced-radix kernels were switched off (rhip_want_lines29) has no converted lines
+    ctx->err = "reduced-radix pairing kernels: this prepared-lines handle was made with RABE_RR=0 and carries no converted lines; prepare it again";
+    return RHIP_ERR_ARG;
+  }
   void* ws29 = nullptr;
   const int32_t rc = rhip_ensure_work(ctx, 11, ws_bytes / 12 * RR_SLOT_QUADS, &ws29);
   if (rc) return rc;

@@ -375,7 +375,10 @@ bool rhip_use_rr2(const rhip_ctx* ctx, uint32_t c_max) {
 int32_t rhip_launch_miller_rr2(rhip_ctx* ctx, size_t n_items, uint32_t L, uint32_t C, uint32_t c_max, const uint32_t* pair_off, uint32_t uniform, const void* P, const void* Q,
                                const uint32_t* qref, const void* lines, const void* lines29, void* ws, void* mill, const MillerPlan* plan,
                                const void* work, const uint32_t* chunk_off, size_t units, uint32_t* started, size_t plan_pairs, uint32_t plan_c_lo) {
-  if (lines && !lines29) return RHIP_ERR_ARG;          // every handle that carries prepared lines carries their converted form (rhip_lines_to_rr)
+  if (lines && !lines29) {
+    ctx->err = "reduced-radix pairing kernels: this prepared-lines handle was made with RABE_RR=0 and carries no converted lines; prepare it again";
+    return RHIP_ERR_ARG;
+  }
   if (c_max > 64 || !units) return RHIP_ERR_ARG;
   void* ws2 = nullptr;
   size_t quads = 0;
